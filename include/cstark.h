@@ -1,0 +1,148 @@
+/* cstark.h -- C ABI of the MI355X-native prover backend for the Topos state-transition AIR.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference (a Rust crate) has no
+ * FFI of its own; these entry points are what a Rust shim bound at
+ *     impl Prover for TransactionProver            /root/reference/src/prover.rs:101-134
+ *     TransactionProver::build_trace               /root/reference/src/prover.rs:37-98
+ *     TransactionExample::prove                    /root/reference/src/lib.rs:116-141
+ * would call (the binding a maintainer adds is shown in INTEGRATION.md).
+ *
+ * Conventions
+ *  - Field elements cross the ABI as uint64_t holding the in-memory representation of the
+ *    reference's `f63::BaseElement`: Montgomery form, R = 2^64, p = 2^62+2^56+2^55+1, reduced to
+ *    [0,p).  A Rust `&[BaseElement]` can therefore be passed without conversion.
+ *  - Matrices of field elements are column-major ("one Vec per register", as TraceTable stores
+ *    them): element (column c, row r) of a W x N table lives at  base[c * N + r].
+ *  - `d_*` pointers are device (HBM) addresses, everything else is host memory.
+ *  - All functions return CSTARK_OK (0) or a negative cstark_status; they never abort.  The
+ *    reference reports failure through Result / panics (src/lib.rs:140, :212-218).
+ *  - The library is re-entrant per context: one cstark_ctx owns one HIP stream and its workspace.
+ */
+#ifndef CSTARK_H
+#define CSTARK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cstark_status {
+    CSTARK_OK = 0,
+    CSTARK_ERR_INVALID_ARG = -1,   /* malformed sizes / null pointers (reference: assert! panics) */
+    CSTARK_ERR_NO_DEVICE = -2,     /* no HIP device / kernel image missing: fail loudly, no CPU fallback */
+    CSTARK_ERR_HIP = -3,           /* a HIP runtime call failed; see cstark_last_error() */
+    CSTARK_ERR_OOM = -4,
+    CSTARK_ERR_UNSUPPORTED = -5
+} cstark_status;
+
+/* which AIR program (BASELINE.json configs; reference benches/{rescue,range,merkle,schnorr,state_transition}.rs) */
+typedef enum cstark_air_id {
+    CSTARK_AIR_STATE_TRANSITION = 0, /* TransactionAir, src/air.rs:64-189; 94 registers, 1024 rows / tx */
+    CSTARK_AIR_MERKLE_UPDATE = 1,    /* MerkleAir, src/merkle/update/air.rs:36-177; 65 registers, 512 rows / tx */
+    CSTARK_AIR_SCHNORR = 2,          /* SchnorrAir, src/schnorr/air.rs:41-300; 56 registers, 512 rows / sig */
+    CSTARK_AIR_RANGE = 3,            /* RangeProofAir, src/range/air.rs:23-105; 2 registers, 64 rows */
+    CSTARK_AIR_RESCUE_CHAIN = 4      /* benches/rescue.rs:128-360; 14 registers, 8 rows / link */
+} cstark_air_id;
+
+#define CSTARK_TX_TRACE_WIDTH 94      /* src/constants.rs:35 */
+#define CSTARK_TX_CYCLE_LENGTH 1024   /* src/constants.rs:83 */
+#define CSTARK_TX_NUM_CONSTRAINTS 115 /* src/air.rs:76-100 */
+#define CSTARK_TX_NUM_PERIODIC 48     /* src/air.rs:195, src/constants.rs:116 */
+#define CSTARK_DIGEST_BYTES 32        /* Blake3_256, src/lib.rs:82 */
+
+/* Witness for a batch of transfers: field-for-field the reference's TransactionMetadata
+ * (src/lib.rs:183-194).  Field elements in BaseElement memory form (see Conventions). */
+typedef struct cstark_tx_witness {
+    uint32_t n_tx;                /* number of transactions; a power of two for proving */
+    uint32_t merkle_depth;        /* MERKLE_TREE_DEPTH: 15 (src/merkle/constants.rs:25), 3 under cfg(test) (:22) */
+    const uint64_t *initial_roots; /* [n_tx][7]   root before each transaction */
+    const uint64_t *final_root;    /* [7] */
+    const uint64_t *s_old_values;  /* [n_tx][14]  sender leaf: pk.x(6) pk.y(6) balance nonce */
+    const uint64_t *r_old_values;  /* [n_tx][14]  receiver leaf */
+    const uint64_t *s_indices;     /* [n_tx] */
+    const uint64_t *r_indices;     /* [n_tx] */
+    const uint64_t *s_paths;       /* [n_tx][merkle_depth+1][7]  [leaf, sibling_0 .. sibling_{d-1}] */
+    const uint64_t *r_paths;       /* [n_tx][merkle_depth+1][7]  (after the sender update) */
+    const uint64_t *deltas;        /* [n_tx] */
+    const uint64_t *sig_rx;        /* [n_tx][6]   signature.0 = R.x */
+    const uint8_t *sig_s;          /* [n_tx][32]  signature.1.to_bytes(), little-endian (src/schnorr/trace.rs:133) */
+} cstark_tx_witness;
+
+/* Mirror of the 7 ProofOptions fields (src/lib.rs:78-86). */
+typedef struct cstark_options {
+    uint32_t num_queries;      /* 42 */
+    uint32_t blowup_factor;    /* 8 */
+    uint32_t grinding_factor;  /* 0 */
+    uint32_t hash_fn;          /* 0 = Blake3_256 (only one implemented), 1 = Sha3_256 */
+    uint32_t field_extension;  /* 0 = None (only one implemented), 1 = Quadratic, 2 = Cubic */
+    uint32_t fri_folding_factor; /* 4 */
+    uint32_t fri_max_remainder;  /* 256 */
+} cstark_options;
+
+/* Composition coefficients for the constraint-evaluation driver (what the engine draws from the
+ * public coin after the trace commitment; inputs here so the stage can be tested in isolation). */
+typedef struct cstark_tx_coeffs {
+    uint64_t t_alpha[CSTARK_TX_NUM_CONSTRAINTS]; /* per transition constraint: (alpha, beta) */
+    uint64_t t_beta[CSTARK_TX_NUM_CONSTRAINTS];
+    uint64_t b_alpha[4];                         /* boundary assertions in get_assertions order, src/air.rs:175-184 */
+    uint64_t b_beta[4];
+} cstark_tx_coeffs;
+
+typedef struct cstark_ctx cstark_ctx;
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* device < 0: current HIP device.  stream: a hipStream_t to launch on, or NULL to create one. */
+int cstark_ctx_create(int device, void *stream, cstark_ctx **out);
+void cstark_ctx_destroy(cstark_ctx *ctx);
+const char *cstark_last_error(void);
+const char *cstark_version(void);
+int cstark_ctx_synchronize(cstark_ctx *ctx);
+
+/* ---- K1: execution trace (replaces TransactionProver::build_trace, src/prover.rs:37-98) ---- */
+/* Copies the witness to device memory owned by the context (host -> HBM, ~2.3 KB / tx). */
+int cstark_tx_witness_upload(cstark_ctx *ctx, const cstark_tx_witness *w);
+/* Fills the 94 x (1024*n_tx) column-major trace at d_trace from the uploaded witness. */
+int cstark_tx_build_trace(cstark_ctx *ctx, uint64_t *d_trace);
+
+/* ---- K2/K3: low-degree extension (engine: trace.extend) ------------------------------------- */
+/* d_cols: width x n evaluations over the trace domain (natural order), overwritten with the
+ * polynomial coefficients (natural order). */
+int cstark_interpolate_columns(cstark_ctx *ctx, uint64_t *d_cols, uint32_t width, uint32_t log_n);
+/* d_coeffs: width x n coefficients.  d_lde: blowup cosets, coset-major:
+ *   d_lde[(k * width + c) * n + j] = f_c(g * w_{bn}^k * w_n^j),  g = field generator,
+ * i.e. natural LDE-domain index i = b*j + k.  cosets [k0, k0+nk) are produced (multi-GPU sharding). */
+int cstark_lde_columns(cstark_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width,
+                       uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+
+/* ---- K4/K5: Blake3 row hashing + Merkle tree (engine: build_commitment) ---------------------- */
+/* Hash row j of coset k (width elements, 8 bytes LE each, memory form) into leaf i = b*j + k:
+ *   d_leaves[32 * i .. 32 * i + 32]. */
+int cstark_hash_rows(cstark_ctx *ctx, const uint64_t *d_lde, uint8_t *d_leaves, uint32_t width,
+                     uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* d_nodes: 2 * n_leaves digests; nodes[n_leaves + i] = leaf i on input; on return nodes[1] is the
+ * root and nodes[i] = Blake3(nodes[2i] || nodes[2i+1]). nodes[0] is zero. */
+int cstark_merkle_build(cstark_ctx *ctx, uint8_t *d_nodes, uint32_t log_leaves);
+
+/* ---- K6/K7: constraint evaluation (Air::evaluate_transition, src/air.rs:114-173, + driver) --- */
+/* All 115 transition-constraint values at every point of cosets [k0,k0+nk):
+ *   d_out[(k - k0) * 115 * n + i * n + j].  Parity / debugging entry point. */
+int cstark_tx_evaluate_transitions(cstark_ctx *ctx, const uint64_t *d_lde, uint64_t *d_out, uint32_t log_n,
+                                   uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* Fused production path: combined constraint evaluations
+ *   d_out[(k - k0) * n + j] = sum_i (alpha_i + beta_i x^adj_i) C_i(x) / Z(x) + boundary terms,
+ * x = g * w_{bn}^k * w_n^j.  pub_inputs = initial_root[0..2], final_root[0..2] (src/air.rs:175-184). */
+int cstark_tx_evaluate_constraints(cstark_ctx *ctx, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs,
+                                   const uint64_t pub_inputs[4], uint64_t *d_out, uint32_t log_n,
+                                   uint32_t log_blowup, uint32_t k0, uint32_t nk);
+
+/* ---- device memory helpers for callers without a HIP runtime of their own (the Rust shim) ---- */
+int cstark_malloc(cstark_ctx *ctx, size_t bytes, void **d_ptr);
+int cstark_free(cstark_ctx *ctx, void *d_ptr);
+int cstark_memcpy_h2d(cstark_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int cstark_memcpy_d2h(cstark_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSTARK_H */

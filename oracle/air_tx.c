@@ -1,0 +1,389 @@
+/* ORACLE (test infrastructure, not product code).
+ *
+ * CPU restatement of the reference's composite state-transition AIR:
+ *   trace:        src/prover.rs:37-98, src/trace.rs:28-142, src/merkle/update/trace.rs:19-136,
+ *                 src/schnorr/trace.rs:18-142, src/schnorr/mod.rs:247-288, src/range/prover.rs:65-84,
+ *                 src/lib.rs:467-481
+ *   masks:        src/air.rs:194-380 (+ src/merkle/update/air.rs:182-212, src/schnorr/air.rs:335-391)
+ *   constraints:  src/air.rs:114-173, :383-610, src/merkle/init/air.rs:159-202,
+ *                 src/merkle/update/air.rs:215-369, src/schnorr/air.rs:309-330, :394-531
+ *   degrees:      src/air.rs:76-108, src/merkle/update/air.rs:371-401, src/schnorr/air.rs:533-585
+ * MERKLE_TREE_DEPTH (src/merkle/constants.rs:21-25) is a run-time parameter here.
+ *
+ * Pinning: no golden vectors exist in the reference; this restatement is
+ * pinned by the algebraic known answers of SURVEY.md 8(c): every one of the 115 constraints
+ * vanishes on every row pair of a trace built from a valid witness and some constraint is nonzero
+ * after any witness perturbation; Merkle roots / signature / range end-values match the witness.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "oracle.h"
+#include "gadgets.h"
+
+/* register map: src/merkle/constants.rs:33-45, src/schnorr/constants.rs, src/constants.rs:35-81 */
+enum {
+    TX_W = 94, TX_CYCLE = 1024, MERKLE_CYCLE = 512, SIG_CYCLE = 512,
+    S_INIT = 0, S_BIT = 14, S_UPD = 15, R_INIT = 29, R_BIT = 43, R_UPD = 44, PREV_ROOT = 58, MERKLE_W = 65,
+    S_KEY = 65, R_KEY = 77, DELTA_COPY = 89, SIGMA_COPY = 90, NONCE_COPY = 91,
+    SCHNORR_W = 56, DELTA_BIT = 56, DELTA_ACC = 57, SIGMA_BIT = 92, SIGMA_ACC = 93,
+    /* result indices */
+    VALUE_RES = 65, BALANCE_RES = 90, NONCE_UPD_RES = 91, INT_ROOT_RES = 92, PREV_MATCH_RES = 99,
+    S_KEY_RES = 101, R_KEY_RES = 103, DELTA_COPY_RES = 105, SIGMA_COPY_RES = 106, NONCE_COPY_RES = 107,
+    DELTA_RANGE_RES = 108, SIGMA_RANGE_RES = 109, TX_NC = 115,
+    /* periodic column indices: src/constants.rs:85-116 */
+    P_SETUP = 0, P_MERKLE = 1, P_HASH_INPUT = 2, P_FINISH = 3, P_HASH = 4, P_SCHNORR = 5, P_SCALAR_MULT = 6,
+    P_DOUBLING = 7, P_DIGEST = 8, P_SCHNORR_HASH = 12, P_HASH_INTERNAL = 13, P_RANGE_STEP = 17,
+    P_RANGE_FINISH = 18, P_VALUE_COPY = 19, P_ARK = 20, TX_NP = 48,
+    SCALAR_MUL_LEN = 510, NUM_HASH_ITER = 5, TOTAL_HASH_LEN = 40, RANGE_LOG = 64
+};
+
+static inline int bit_of(const uint8_t *bytes, int i) { return (bytes[i >> 3] >> (i & 7)) & 1; } /* Lsb0 */
+
+/* ---- trace ------------------------------------------------------------------------------------ */
+
+/* src/lib.rs:467-481 */
+static void build_tx_message(const fp *s_val, const fp *r_val, fp delta, fp nonce, fp *msg /*28*/) {
+    memset(msg, 0, 28 * sizeof(fp));
+    memcpy(msg, s_val, 12 * sizeof(fp));
+    memcpy(msg + 12, r_val, 12 * sizeof(fp));
+    msg[24] = delta;
+    msg[25] = nonce;
+}
+
+/* src/schnorr/mod.rs:247-288 */
+void cso_schnorr_hash_message(const uint64_t *rx /*6*/, const uint64_t *msg /*28*/, uint64_t *out /*7*/) {
+    fp h[7];
+    rescue_digest(rx, 6, h);
+    for (int k = 0; k < 4; k++) rescue_merge(h, msg + 7 * k, h);
+    memcpy(out, h, sizeof h);
+}
+
+/* src/merkle/update/trace.rs:96-136; state = 29 registers [hash(14) | bit | hash(14)] */
+static void merkle_auth_step(size_t pos, uint64_t index, const fp *branch, fp *st) {
+    size_t cycle_num = pos / HASH_CYCLE, cycle_pos = pos % HASH_CYCLE;
+    if (cycle_pos < RESCUE_ROUNDS) {
+        rescue_apply_round(st, pos);
+        rescue_apply_round(st + 15, pos);
+    } else {
+        const fp *node = branch + 7 * (cycle_num + 1);
+        int bit = (index >> cycle_num) & 1;
+        if (!bit) {
+            for (int i = 0; i < 7; i++) { st[7 + i] = node[i]; st[15 + 7 + i] = node[i]; }
+        } else {
+            for (int i = 0; i < 7; i++) {
+                st[7 + i] = st[i]; st[15 + 7 + i] = st[15 + i];
+                st[i] = node[i]; st[15 + i] = node[i];
+            }
+        }
+        st[14] = bit ? FP_ONE : 0;
+    }
+}
+
+/* src/schnorr/trace.rs:35-122; st = 56 registers */
+static void schnorr_step(size_t step, const fp *msg, const fp *pkey, const uint8_t *s_bytes, const uint8_t *h_bytes, fp *st) {
+    const int bit_length = SCALAR_MUL_LEN / 2;
+    int rescue_flag = step < TOTAL_HASH_LEN;
+    size_t rescue_step = step % HASH_CYCLE;
+    if (rescue_flag && rescue_step < RESCUE_ROUNDS) {
+        rescue_apply_round(st + 42, step);
+    } else if (rescue_flag && step < (NUM_HASH_ITER - 1) * HASH_CYCLE) {
+        size_t index = step / HASH_CYCLE;
+        for (int i = 0; i < 7; i++) st[42 + 7 + i] = msg[7 * index + i];
+    } else if (rescue_flag) {
+        for (int i = 0; i < 7; i++) st[42 + 7 + i] = 0;
+    }
+    if (step < SCALAR_MUL_LEN) {
+        size_t real_step = step / 2;
+        int chunk = real_step < 63 ? 0 : (int)((real_step - 63) / 64 + 1);
+        st[18] = bit_of(s_bytes, bit_length - 1 - (int)real_step) ? FP_ONE : 0;
+        st[37] = bit_of(h_bytes, bit_length - 1 - (int)real_step) ? FP_ONE : 0;
+        if (step % 2 == 0) {
+            ecc_double(st);
+            ecc_double(st + 19);
+            field_apply_double_and_add(st + 37, 4 - chunk, 0);
+        } else {
+            ecc_apply_addition_mixed(st, CS_GENERATOR_MONT);
+            ecc_apply_addition_mixed(st + 19, pkey);
+        }
+    } else if (step == SCALAR_MUL_LEN) {
+        fp hp[PROJ];
+        memcpy(hp, st + 19, sizeof hp);
+        st[18] = FP_ONE;
+        ecc_apply_addition(st, hp);
+        fp6 x = fp6_mul(fp6_load(st), fp6_inv(fp6_load(st + 12)));
+        fp6_store(st, x);
+    }
+}
+
+int cso_tx_build_trace(const cstark_tx_witness *w, uint64_t *trace) {
+    const size_t n = (size_t)w->n_tx * TX_CYCLE;
+    const unsigned depth = w->merkle_depth;
+    const size_t hash_len = HASH_CYCLE * depth + RESCUE_ROUNDS; /* TRANSACTION_HASH_LENGTH */
+    if (hash_len > MERKLE_CYCLE - 1 || depth == 0) return -1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t t = 0; t < w->n_tx; t++) {
+        const fp *sv = w->s_old_values + 14 * t, *rv = w->r_old_values + 14 * t;
+        const fp *root = w->initial_roots + 7 * t;
+        const fp *sb = w->s_paths + 7 * (depth + 1) * t, *rb = w->r_paths + 7 * (depth + 1) * t;
+        fp delta = w->deltas[t];
+        /* per-transaction preamble, src/prover.rs:53-67 */
+        uint64_t dv = fp_to_u64(delta), sg = fp_to_u64(fp_sub(sv[12], delta));
+        uint8_t delta_bytes[8], sigma_bytes[8], h_bytes[32];
+        for (int i = 0; i < 8; i++) { delta_bytes[i] = dv >> (8 * i); sigma_bytes[i] = sg >> (8 * i); }
+        fp msg[28], h[7];
+        build_tx_message(sv, rv, delta, sv[13], msg);
+        const fp *pkey = msg; /* build_sig_info, src/schnorr/trace.rs:127-142 */
+        const uint8_t *s_bytes = w->sig_s + 32 * t;
+        cso_schnorr_hash_message(w->sig_rx + 6 * t, msg, h);
+        for (int i = 0; i < 4; i++) { uint64_t v = fp_to_u64(h[i]); for (int b = 0; b < 8; b++) h_bytes[8 * i + b] = v >> (8 * b); }
+
+        fp st[TX_W];
+        memset(st, 0, sizeof st);
+        /* init_transaction_state src/trace.rs:28-53 + init_merkle_update_state src/merkle/update/trace.rs:19-48 */
+        memcpy(st + S_INIT, sv, 14 * sizeof(fp));
+        st[S_BIT] = 0;
+        memcpy(st + S_UPD, sv, 14 * sizeof(fp));
+        st[S_UPD + 12] = fp_sub(st[S_UPD + 12], delta);
+        st[S_UPD + 13] = fp_add(st[S_UPD + 13], FP_ONE);
+        memcpy(st + R_INIT, rv, 14 * sizeof(fp));
+        st[R_BIT] = 0;
+        memcpy(st + R_UPD, rv, 14 * sizeof(fp));
+        st[R_UPD + 12] = fp_add(st[R_UPD + 12], delta);
+        memcpy(st + PREV_ROOT, root, 7 * sizeof(fp));
+        memcpy(st + S_KEY, sv, 12 * sizeof(fp));
+        memcpy(st + R_KEY, rv, 12 * sizeof(fp));
+        st[DELTA_COPY] = delta;
+        st[SIGMA_COPY] = fp_sub(sv[12], delta);
+        st[NONCE_COPY] = sv[13];
+
+        const size_t base = t * TX_CYCLE;
+        for (int c = 0; c < TX_W; c++) trace[(size_t)c * n + base] = st[c];
+        /* fill(): update(step) turns row `step` into row `step+1`; src/trace.rs:59-142 */
+        for (size_t step = 0; step < TX_CYCLE - 1; step++) {
+            if (step < MERKLE_CYCLE - 1) {
+                /* update_merkle_update_state src/merkle/update/trace.rs:53-94 */
+                if (step < hash_len) {
+                    merkle_auth_step(step, w->s_indices[t], sb, st + S_INIT);
+                    merkle_auth_step(step, w->r_indices[t], rb, st + R_INIT);
+                }
+                if (step == hash_len - 1)
+                    for (int i = 0; i < 7; i++) st[PREV_ROOT + i] = st[R_UPD + i];
+            } else if (step == MERKLE_CYCLE - 1) {
+                /* init_sig_verification_state src/schnorr/trace.rs:18-30 */
+                memset(st, 0, SCHNORR_W * sizeof(fp));
+                st[COORD] = FP_ONE;
+                st[PROJ + COORD + 1] = FP_ONE;
+                memcpy(st + 42, w->sig_rx + 6 * t, 6 * sizeof(fp));
+                st[DELTA_BIT] = st[DELTA_ACC] = 0; /* range init src/range/prover.rs:65-69 */
+                st[SIGMA_BIT] = st[SIGMA_ACC] = 0;
+            } else {
+                size_t ss = step - MERKLE_CYCLE;
+                schnorr_step(ss, msg, pkey, s_bytes, h_bytes, st);
+                if (ss < RANGE_LOG) { /* src/range/prover.rs:74-84 */
+                    st[DELTA_BIT] = bit_of(delta_bytes, RANGE_LOG - 1 - (int)ss) ? FP_ONE : 0;
+                    field_apply_double_and_add(st + DELTA_BIT, 1, 0);
+                    st[SIGMA_BIT] = bit_of(sigma_bytes, RANGE_LOG - 1 - (int)ss) ? FP_ONE : 0;
+                    field_apply_double_and_add(st + SIGMA_BIT, 1, 0);
+                }
+            }
+            for (int c = 0; c < TX_W; c++) trace[(size_t)c * n + base + step + 1] = st[c];
+        }
+    }
+    return 0;
+}
+
+/* ---- periodic columns: src/air.rs:194-380 ---------------------------------------------------- */
+/* out[48][1024]; the two kinds of length-8 columns (HASH_INPUT, ARK) are tiled to 1024, which
+ * defines the same periodic polynomial in x^(n/1024). */
+int cso_tx_periodic_columns(unsigned depth, uint64_t *out) {
+    const size_t hash_len = HASH_CYCLE * depth + RESCUE_ROUNDS;
+    if (hash_len > MERKLE_CYCLE - 1 || depth == 0) return -1;
+    memset(out, 0, (size_t)TX_NP * TX_CYCLE * sizeof(fp));
+#define COL(c) (out + (size_t)(c) * TX_CYCLE)
+    COL(P_SETUP)[0] = FP_ONE;
+    for (size_t i = 0; i < hash_len; i++) {
+        COL(P_MERKLE)[i] = FP_ONE;
+        COL(P_HASH)[i] = (i % HASH_CYCLE) != HASH_CYCLE - 1 ? FP_ONE : 0; /* HASH_CYCLE_MASK, rescue.rs:40-49 */
+    }
+    COL(P_FINISH)[hash_len - 1] = FP_ONE;
+    for (size_t i = 0; i < TX_CYCLE; i++) COL(P_HASH_INPUT)[i] = (i % HASH_CYCLE) == HASH_CYCLE - 1 ? FP_ONE : 0;
+    /* Schnorr block appended at row 512: src/schnorr/air.rs:335-391 */
+    fp *g = COL(P_SCHNORR) + MERKLE_CYCLE, *sm = COL(P_SCALAR_MULT) + MERKLE_CYCLE, *db = COL(P_DOUBLING) + MERKLE_CYCLE;
+    for (int i = 0; i < SCALAR_MUL_LEN + 1; i++) g[i] = FP_ONE;
+    for (int i = 0; i < SCALAR_MUL_LEN; i++) { sm[i] = FP_ONE; db[i] = (i % 2 == 0) ? FP_ONE : 0; }
+    const int lo[4] = {0, 126, 254, 382}, hi[4] = {126, 254, 382, 510};
+    for (int k = 0; k < 4; k++)
+        for (int i = lo[k]; i < hi[k]; i++) COL(P_DIGEST + k)[MERKLE_CYCLE + i] = FP_ONE;
+    for (int i = 0; i < TOTAL_HASH_LEN; i++)
+        COL(P_SCHNORR_HASH)[MERKLE_CYCLE + i] = (i % HASH_CYCLE) != HASH_CYCLE - 1 ? FP_ONE : 0;
+    for (int k = 0; k < NUM_HASH_ITER - 1; k++) COL(P_HASH_INTERNAL + k)[MERKLE_CYCLE + (k + 1) * HASH_CYCLE - 1] = FP_ONE;
+    for (int i = 0; i < RANGE_LOG; i++) COL(P_RANGE_STEP)[MERKLE_CYCLE + i] = FP_ONE;
+    COL(P_RANGE_FINISH)[MERKLE_CYCLE + RANGE_LOG - 1] = FP_ONE;
+    for (int i = 1; i < MERKLE_CYCLE + RANGE_LOG; i++) COL(P_VALUE_COPY)[i] = FP_ONE;
+    for (int j = 0; j < 2 * RESCUE_STATE; j++) /* get_round_constants, rescue.rs:306-320 */
+        for (size_t i = 0; i < TX_CYCLE; i++) COL(P_ARK + j)[i] = CS_ARK_MONT[(i % HASH_CYCLE) * 2 * RESCUE_STATE + j];
+#undef COL
+    return 0;
+}
+
+/* ---- constraints ------------------------------------------------------------------------------- */
+
+/* src/merkle/update/air.rs:291-369 */
+static void merkle_auth_constraints(fp *res, const fp *cur, const fp *next, const fp *ark, fp tx_hash_flag, fp hash_input_flag, fp hash_flag) {
+    fp hash_copy_flag = fp_mul(tx_hash_flag, c_not(fp_add(hash_flag, hash_input_flag)));
+    fp hash_init_flag = fp_mul(tx_hash_flag, hash_input_flag);
+    fp bit = next[14];
+    agg(res, 14, tx_hash_flag, c_is_binary(bit));
+    fp not_bit = c_not(bit);
+    for (int k = 0; k < 2; k++) {
+        int b = 15 * k;
+        rescue_enforce_round(res + b, cur + b, next + b, ark, hash_flag);
+        for (int i = 0; i < 7; i++) {
+            agg(res, b + i, hash_copy_flag, c_are_equal(cur[b + i], next[b + i]));
+            agg(res, b + i, hash_init_flag, fp_mul(not_bit, c_are_equal(cur[b + i], next[b + i])));
+            agg(res, b + 7 + i, hash_init_flag, fp_mul(bit, c_are_equal(cur[b + i], next[b + 7 + i])));
+        }
+    }
+    for (int i = 0; i < 7; i++) agg(res, i, hash_init_flag, fp_mul(bit, c_are_equal(next[15 + i], next[i])));
+    for (int i = 7; i < 14; i++) agg(res, i, hash_init_flag, fp_mul(not_bit, c_are_equal(next[15 + i], next[i])));
+}
+
+/* src/schnorr/air.rs:394-531 on registers/results [0,56) */
+static void schnorr_constraints(fp *res, const fp *cur, const fp *next, const fp *ark, fp doubling_flag, fp addition_flag,
+                                const fp *digest_flags, const fp *pkey, fp final_add_flag, fp hash_flag, fp copy_hash_flag,
+                                const fp *internal_inputs) {
+    ecc_enforce_doubling(res, cur, next, doubling_flag);
+    ecc_enforce_addition_mixed(res, cur, next, CS_GENERATOR_MONT, addition_flag);
+    ecc_enforce_doubling(res + 19, cur + 19, next + 19, doubling_flag);
+    ecc_enforce_addition_mixed(res + 19, cur + 19, next + 19, pkey, addition_flag);
+    for (int i = 0; i < 4; i++)
+        field_enforce_double_and_add_constrained(res + 37, cur + 37, next + 37, 4 - i, 0, fp_mul(digest_flags[i], doubling_flag));
+    for (int i = 0; i < 4; i++) agg(res, 38 + i, addition_flag, c_are_equal(cur[38 + i], next[38 + i]));
+    for (int i = 0; i < 4; i++)
+        agg(res, 41 - i, fp_mul(c_not(digest_flags[i]), doubling_flag), c_are_equal(cur[41 - i], next[41 - i]));
+    rescue_enforce_round(res + 42, cur + 42, next + 42, ark, hash_flag);
+    /* enforce_hash_copy :309-330 */
+    for (int i = 0; i < 7; i++) agg(res + 42, i, copy_hash_flag, c_are_equal(cur[42 + i], next[42 + i]));
+    for (int i = 0; i < 7; i++) agg(res + 42, 7 + i, copy_hash_flag, fp_sub(next[42 + 7 + i], internal_inputs[i]));
+    ecc_enforce_addition_reduce_x(res, cur, next, cur + 19, final_add_flag);
+    for (int i = 0; i < 4; i++) agg(res, 38 + i, final_add_flag, c_are_equal(cur[38 + i], cur[42 + i]));
+}
+
+/* Air::evaluate_transition, src/air.rs:114-173 + evaluate_constraints :383-610 */
+void cso_tx_evaluate_transition(const uint64_t *cur, const uint64_t *next, const uint64_t *pv, uint64_t *res) {
+    memset(res, 0, TX_NC * sizeof(fp));
+    fp setup = pv[P_SETUP], tx_hash = pv[P_MERKLE], hash_input = pv[P_HASH_INPUT], finish = pv[P_FINISH], hash_flag = pv[P_HASH];
+    fp schnorr_mask = pv[P_SCHNORR], scalar_mult = pv[P_SCALAR_MULT], doubling = pv[P_DOUBLING];
+    const fp *digest_flags = pv + P_DIGEST;
+    fp schnorr_hash = pv[P_SCHNORR_HASH];
+    const fp *internal_flags = pv + P_HASH_INTERNAL;
+    fp range_flag = pv[P_RANGE_STEP], range_finish = pv[P_RANGE_FINISH], copy_values = pv[P_VALUE_COPY];
+    const fp *ark = pv + P_ARK;
+    fp copy_hash = fp_mul(c_not(schnorr_hash), schnorr_mask);
+    fp final_add = fp_mul(c_not(scalar_mult), schnorr_mask);
+    fp addition = fp_mul(c_not(doubling), scalar_mult);
+
+    /* merkle::init::evaluate_constraints, src/merkle/init/air.rs:159-202 (result indices shifted) */
+    rescue_enforce_round(res + S_INIT, cur + S_INIT, next + S_INIT, ark, setup);
+    rescue_enforce_round(res + S_UPD - 1, cur + S_UPD, next + S_UPD, ark, setup);
+    rescue_enforce_round(res + R_INIT - 1, cur + R_INIT, next + R_INIT, ark, setup);
+    rescue_enforce_round(res + R_UPD - 2, cur + R_UPD, next + R_UPD, ark, setup);
+
+    for (int i = 0; i < 12; i++) { /* src/air.rs:406-423 */
+        agg(res, VALUE_RES + i, setup, c_are_equal(cur[S_INIT + i], cur[S_UPD + i]));
+        agg(res, VALUE_RES + 12 + i, setup, c_are_equal(cur[R_INIT + i], cur[R_UPD + i]));
+    }
+    agg(res, VALUE_RES + 24, setup, c_are_equal(cur[R_INIT + 13], cur[R_UPD + 13]));
+    agg(res, BALANCE_RES, setup, c_are_equal(fp_sub(cur[S_INIT + 12], cur[S_UPD + 12]), fp_sub(cur[R_UPD + 12], cur[R_INIT + 12])));
+    agg(res, NONCE_UPD_RES, setup, c_are_equal(cur[S_UPD + 13], fp_add(cur[S_INIT + 13], FP_ONE)));
+    for (int o = 0; o < 12; o++) { /* :456-476 (indices alias, reproduced as written) */
+        agg(res, S_KEY_RES + o, setup, c_are_equal(next[S_KEY + o], cur[S_INIT + o]));
+        agg(res, R_KEY_RES + o, setup, c_are_equal(next[R_KEY + o], cur[R_INIT + o]));
+    }
+    agg(res, DELTA_COPY_RES, setup, c_are_equal(next[DELTA_COPY], fp_sub(cur[S_INIT + 12], cur[S_UPD + 12])));
+    agg(res, SIGMA_COPY_RES, setup, c_are_equal(next[SIGMA_COPY], cur[S_UPD + 12]));
+    agg(res, NONCE_COPY_RES, setup, c_are_equal(next[NONCE_COPY], cur[S_INIT + 13]));
+    for (int o = 0; o < 12; o++) { /* :506-519 */
+        agg(res, S_KEY_RES + o, copy_values, c_are_equal(next[S_KEY + o], cur[S_KEY + o]));
+        agg(res, R_KEY_RES + o, copy_values, c_are_equal(next[R_KEY + o], cur[R_KEY + o]));
+    }
+    agg(res, DELTA_COPY_RES, copy_values, c_are_equal(next[DELTA_COPY], cur[DELTA_COPY]));
+    agg(res, SIGMA_COPY_RES, copy_values, c_are_equal(next[SIGMA_COPY], cur[SIGMA_COPY]));
+    agg(res, NONCE_COPY_RES, copy_values, c_are_equal(next[NONCE_COPY], cur[NONCE_COPY]));
+
+    /* merkle::update::evaluate_constraints, src/merkle/update/air.rs:215-289 */
+    fp not_finish = c_not(finish);
+    merkle_auth_constraints(res + S_INIT, cur + S_INIT, next + S_INIT, ark, tx_hash, hash_input, hash_flag);
+    merkle_auth_constraints(res + R_INIT, cur + R_INIT, next + R_INIT, ark, tx_hash, hash_input, hash_flag);
+    for (int i = 0; i < 7; i++) {
+        agg(res, PREV_ROOT + i, not_finish, c_are_equal(next[PREV_ROOT + i], cur[PREV_ROOT + i]));
+        agg(res, PREV_ROOT + i, finish, c_are_equal(next[PREV_ROOT + i], next[R_UPD + i]));
+    }
+    for (int i = 0; i < 7; i++) agg(res, INT_ROOT_RES + i, finish, c_are_equal(cur[S_UPD + i], cur[R_INIT + i]));
+    for (int i = 0; i < 7; i++) agg(res, PREV_MATCH_RES + i, finish, c_are_equal(next[S_INIT + i], cur[PREV_ROOT + i]));
+
+    /* hash_internal_inputs, src/air.rs:543-565 */
+    fp internal_inputs[7] = {0};
+    for (int k = 0; k < NUM_HASH_ITER - 1; k++)
+        for (int i = 0; i < 7; i++) {
+            int m = k * 7 + i;
+            fp cell = m < 12 ? next[S_KEY + m] : m < 24 ? next[R_KEY + m - 12] : m == 24 ? next[DELTA_COPY] : m == 25 ? next[NONCE_COPY] : 0;
+            internal_inputs[i] = fp_add(internal_inputs[i], fp_mul(internal_flags[k], cell));
+        }
+    schnorr_constraints(res, cur, next, ark, doubling, addition, digest_flags, next + S_KEY, final_add, schnorr_hash, copy_hash, internal_inputs);
+
+    /* range proofs, src/air.rs:583-609 (SIGMA_RANGE_RES re-checks the delta registers, as written) */
+    field_enforce_double_and_add(res, cur, next, DELTA_ACC, DELTA_BIT, range_flag);
+    field_enforce_double_and_add(res, cur, next, SIGMA_ACC, SIGMA_BIT, range_flag);
+    agg(res, DELTA_RANGE_RES, range_finish, c_are_equal(next[DELTA_ACC], next[DELTA_COPY]));
+    agg(res, SIGMA_RANGE_RES, range_finish, c_are_equal(next[DELTA_ACC], next[DELTA_COPY]));
+}
+
+/* Evaluate all 115 constraints on every consecutive row pair (r, r+1), r < n-1, of a base trace.
+ * Returns -1 if all vanish, else (row * 115 + constraint) of the first violation. */
+long cso_tx_check_trace(const uint64_t *trace, uint32_t n_tx, unsigned depth) {
+    const size_t n = (size_t)n_tx * TX_CYCLE;
+    fp *periodic = malloc((size_t)TX_NP * TX_CYCLE * sizeof(fp));
+    if (cso_tx_periodic_columns(depth, periodic)) { free(periodic); return -2; }
+    long bad = -1;
+#pragma omp parallel for schedule(static)
+    for (size_t r = 0; r < n - 1; r++) {
+        fp cur[TX_W], next[TX_W], pv[TX_NP], res[TX_NC];
+        for (int c = 0; c < TX_W; c++) { cur[c] = trace[(size_t)c * n + r]; next[c] = trace[(size_t)c * n + r + 1]; }
+        for (int c = 0; c < TX_NP; c++) pv[c] = periodic[(size_t)c * TX_CYCLE + r % TX_CYCLE];
+        cso_tx_evaluate_transition(cur, next, pv, res);
+        for (int i = 0; i < TX_NC; i++)
+            if (res[i] != 0) {
+                long code = (long)(r * TX_NC + i);
+#pragma omp critical
+                if (bad < 0 || code < bad) bad = code;
+                break;
+            }
+    }
+    free(periodic);
+    return bad;
+}
+
+/* TransactionAir::new degree vector, src/air.rs:76-108: base[i], number of 1024-cycles[i] */
+void cso_tx_constraint_degrees(uint32_t *base, uint32_t *cycles) {
+    for (int i = 0; i < 106; i++) { base[i] = 1; cycles[i] = 1; }       /* merkle::update degrees, :371-401 */
+    for (int b = 0; b < 58; b += 29) {
+        for (int i = 0; i < 29; i++) base[b + i] = 3;
+        base[b + 14] = 2;
+    }
+    base[R_BIT] = 3;        /* src/air.rs:80-81 */
+    base[INT_ROOT_RES] = 2; /* :82-83 */
+    uint32_t sb[56], sc[56]; /* schnorr::transition_constraint_degrees(2, 1024), src/schnorr/air.rs:533-585 */
+    for (int i = 0; i < 6; i++) { sb[i] = 5; sc[i] = 2; }
+    for (int i = 6; i < 18; i++) { sb[i] = 4; sc[i] = 2; }
+    sb[18] = 2; sc[18] = 1;
+    for (int i = 19; i < 37; i++) { sb[i] = 5; sc[i] = 2; }
+    sb[37] = 2; sc[37] = 1;
+    for (int i = 38; i < 42; i++) { sb[i] = 1; sc[i] = 2; }
+    for (int i = 42; i < 56; i++) { sb[i] = 3; sc[i] = 1; }
+    for (int i = 0; i < PROJ; i++) { /* src/air.rs:87-91 */
+        base[i] = sb[i]; cycles[i] = sc[i];
+        base[i + PROJ + 1] = sb[i + PROJ + 1]; cycles[i + PROJ + 1] = sc[i + PROJ + 1];
+    }
+    for (int i = 106; i < TX_NC; i++) { base[i] = 1; cycles[i] = 1; } /* :94-100 */
+}

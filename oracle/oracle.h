@@ -1,0 +1,63 @@
+/* ORACLE (test infrastructure, not product code).
+ *
+ * Public interface of the CPU restatement of the reference's hot path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (certificate-stark_amd/) never does.  Field elements are uint64_t in f63::BaseElement memory form
+ * (Montgomery, R = 2^64), matrices are column-major -- the same conventions as include/cstark.h.
+ *
+ * PARITY STATUS: the AIR-level code (trace, masks, constraints) is pinned by the algebraic known
+ * answers listed in SURVEY.md 8(c).  The engine-level code (LDE, Blake3 commitment, evaluator
+ * driver) restates the un-vendored winterfell fork (Cargo.toml:20) from its public design; BLAKE3
+ * is pinned by the official test vectors, everything else at that level is "parity unpinned".
+ */
+#ifndef CS_ORACLE_H
+#define CS_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#include "../include/cstark.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* field helpers (vectorised, for the Python tests) */
+void cso_fp_from_u64(const uint64_t *in, uint64_t *out, size_t n);
+void cso_fp_to_u64(const uint64_t *in, uint64_t *out, size_t n);
+void cso_fp_mul(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+void cso_fp_add(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+void cso_fp_sub(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+void cso_fp_inv(const uint64_t *a, uint64_t *out, size_t n);
+void cso_fp_pow(const uint64_t *a, uint64_t e, uint64_t *out, size_t n);
+uint64_t cso_fp_root_of_unity(unsigned log_n);
+
+/* gadgets */
+void cso_rescue_permutation(uint64_t *state14);
+void cso_rescue_round(uint64_t *state14, uint32_t step);
+void cso_rescue_enforce_round(uint64_t *result14, const uint64_t *cur14, const uint64_t *next14, const uint64_t *ark28, uint64_t flag);
+void cso_rescue_merge(const uint64_t *a7, const uint64_t *b7, uint64_t *out7);
+void cso_rescue_digest(const uint64_t *data, size_t n, uint64_t *out7);
+void cso_fp6_mul(const uint64_t *a, const uint64_t *b, uint64_t *out);
+void cso_fp6_sqr(const uint64_t *a, uint64_t *out);
+void cso_fp6_inv(const uint64_t *a, uint64_t *out);
+void cso_ecc_double(uint64_t *p18);
+void cso_ecc_add(uint64_t *p18, const uint64_t *q18);
+void cso_ecc_add_mixed(uint64_t *p18, const uint64_t *q12);
+int cso_ecc_on_curve_affine(const uint64_t *q12);
+void cso_ecc_scalar_mul_affine(const uint64_t *k_limbs, unsigned n_limbs, const uint64_t *base12, uint64_t *out12);
+void cso_schnorr_hash_message(const uint64_t *rx6, const uint64_t *msg28, uint64_t *out7);
+
+/* state-transition AIR */
+int cso_tx_build_trace(const cstark_tx_witness *w, uint64_t *trace);
+int cso_tx_periodic_columns(unsigned depth, uint64_t *out /*[48][1024]*/);
+void cso_tx_evaluate_transition(const uint64_t *cur94, const uint64_t *next94, const uint64_t *periodic48, uint64_t *result115);
+long cso_tx_check_trace(const uint64_t *trace, uint32_t n_tx, unsigned depth);
+void cso_tx_constraint_degrees(uint32_t *base115, uint32_t *cycles115);
+
+/* deterministic witness synthesis (counterpart of TransactionMetadata::build_random, src/lib.rs:235-465).
+ * The caller allocates every array of *w (non-const use). */
+int cso_tx_witness_generate(cstark_tx_witness *w, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,189 @@
+"""ORACLE (test infrastructure, not product code): ctypes bindings of oracle/_build/libcs_oracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+Field elements are numpy uint64 arrays in f63::BaseElement memory form (Montgomery, R = 2^64).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libcs_oracle.so")
+
+P = 2**62 + 2**56 + 2**55 + 1
+R = 2**64
+TX_W, TX_CYCLE, TX_NC, TX_NP = 94, 1024, 115, 48
+
+u64p = C.POINTER(C.c_uint64)
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+
+
+class TxWitnessStruct(C.Structure):
+    """struct cstark_tx_witness (include/cstark.h)."""
+    _fields_ = [("n_tx", C.c_uint32), ("merkle_depth", C.c_uint32),
+                ("initial_roots", u64p), ("final_root", u64p), ("s_old_values", u64p), ("r_old_values", u64p),
+                ("s_indices", u64p), ("r_indices", u64p), ("s_paths", u64p), ("r_paths", u64p),
+                ("deltas", u64p), ("sig_rx", u64p), ("sig_s", u8p)]
+
+
+class TxCoeffsStruct(C.Structure):
+    """struct cstark_tx_coeffs (include/cstark.h)."""
+    _fields_ = [("t_alpha", C.c_uint64 * TX_NC), ("t_beta", C.c_uint64 * TX_NC),
+                ("b_alpha", C.c_uint64 * 4), ("b_beta", C.c_uint64 * 4)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
+            for f in os.listdir(_HERE) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.cso_fp_root_of_unity.restype = C.c_uint64
+        _lib.cso_tx_check_trace.restype = C.c_long
+    return _lib
+
+
+def _p(a, t=u64p):
+    return a.ctypes.data_as(t)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+# ---- field helpers --------------------------------------------------------------------------------
+def to_mont(x):
+    x = _u64(x); out = np.empty_like(x); lib().cso_fp_from_u64(_p(x), _p(out), C.c_size_t(x.size)); return out
+
+
+def from_mont(x):
+    x = _u64(x); out = np.empty_like(x); lib().cso_fp_to_u64(_p(x), _p(out), C.c_size_t(x.size)); return out
+
+
+def _bin(name, a, b):
+    a, b = _u64(a), _u64(b); out = np.empty_like(a)
+    getattr(lib(), name)(_p(a), _p(b), _p(out), C.c_size_t(a.size)); return out
+
+
+def fp_mul(a, b): return _bin("cso_fp_mul", a, b)
+def fp_add(a, b): return _bin("cso_fp_add", a, b)
+def fp_sub(a, b): return _bin("cso_fp_sub", a, b)
+
+
+def fp_inv(a):
+    a = _u64(a); out = np.empty_like(a); lib().cso_fp_inv(_p(a), _p(out), C.c_size_t(a.size)); return out
+
+
+def fp_pow(a, e):
+    a = _u64(a); out = np.empty_like(a); lib().cso_fp_pow(_p(a), C.c_uint64(e), _p(out), C.c_size_t(a.size)); return out
+
+
+def root_of_unity(log_n):
+    return int(lib().cso_fp_root_of_unity(C.c_uint(log_n)))
+
+
+# ---- witness --------------------------------------------------------------------------------------
+class TxWitness:
+    """Owns the arrays of a cstark_tx_witness (TransactionMetadata, src/lib.rs:183-194)."""
+    FIELDS = ("initial_roots", "final_root", "s_old_values", "r_old_values", "s_indices", "r_indices",
+              "s_paths", "r_paths", "deltas", "sig_rx", "sig_s")
+
+    def __init__(self, n_tx, depth=15):
+        self.n_tx, self.depth = n_tx, depth
+        self.initial_roots = np.zeros((n_tx, 7), np.uint64)
+        self.final_root = np.zeros(7, np.uint64)
+        self.s_old_values = np.zeros((n_tx, 14), np.uint64)
+        self.r_old_values = np.zeros((n_tx, 14), np.uint64)
+        self.s_indices = np.zeros(n_tx, np.uint64)
+        self.r_indices = np.zeros(n_tx, np.uint64)
+        self.s_paths = np.zeros((n_tx, depth + 1, 7), np.uint64)
+        self.r_paths = np.zeros((n_tx, depth + 1, 7), np.uint64)
+        self.deltas = np.zeros(n_tx, np.uint64)
+        self.sig_rx = np.zeros((n_tx, 6), np.uint64)
+        self.sig_s = np.zeros((n_tx, 32), np.uint8)
+
+    def struct(self):
+        s = TxWitnessStruct()
+        s.n_tx, s.merkle_depth = self.n_tx, self.depth
+        for f in self.FIELDS:
+            a = getattr(self, f)
+            assert a.flags["C_CONTIGUOUS"]
+            setattr(s, f, _p(a, u8p if f == "sig_s" else u64p))
+        return s
+
+    @classmethod
+    def generate(cls, n_tx, depth=15, seed=0x5EED):
+        w = cls(n_tx, depth)
+        s = w.struct()
+        rc = lib().cso_tx_witness_generate(C.byref(s), C.c_uint64(seed))
+        if rc:
+            raise RuntimeError("cso_tx_witness_generate failed: %d" % rc)
+        return w
+
+    def copy(self):
+        w = TxWitness(self.n_tx, self.depth)
+        for f in self.FIELDS:
+            getattr(w, f)[...] = getattr(self, f)
+        return w
+
+    def save(self, path):
+        np.savez_compressed(path, n_tx=self.n_tx, depth=self.depth, **{f: getattr(self, f) for f in self.FIELDS})
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path)
+        w = cls(int(z["n_tx"]), int(z["depth"]))
+        for f in cls.FIELDS:
+            getattr(w, f)[...] = z[f]
+        return w
+
+
+# ---- state-transition AIR -------------------------------------------------------------------------
+def tx_build_trace(w):
+    n = w.n_tx * TX_CYCLE
+    trace = np.zeros((TX_W, n), np.uint64)
+    s = w.struct()
+    rc = lib().cso_tx_build_trace(C.byref(s), _p(trace))
+    if rc:
+        raise RuntimeError("cso_tx_build_trace failed: %d" % rc)
+    return trace
+
+
+def tx_periodic_columns(depth=15):
+    out = np.zeros((TX_NP, TX_CYCLE), np.uint64)
+    rc = lib().cso_tx_periodic_columns(C.c_uint(depth), _p(out))
+    if rc:
+        raise RuntimeError("cso_tx_periodic_columns failed: %d" % rc)
+    return out
+
+
+def tx_evaluate_transition(cur, nxt, periodic):
+    cur, nxt, periodic = _u64(cur), _u64(nxt), _u64(periodic)
+    out = np.zeros(TX_NC, np.uint64)
+    lib().cso_tx_evaluate_transition(_p(cur), _p(nxt), _p(periodic), _p(out))
+    return out
+
+
+def tx_check_trace(trace, n_tx, depth=15):
+    trace = _u64(trace)
+    return int(lib().cso_tx_check_trace(_p(trace), C.c_uint32(n_tx), C.c_uint(depth)))
+
+
+def tx_constraint_degrees():
+    base = np.zeros(TX_NC, np.uint32); cyc = np.zeros(TX_NC, np.uint32)
+    lib().cso_tx_constraint_degrees(_p(base, u32p), _p(cyc, u32p))
+    return base, cyc
