@@ -1,0 +1,84 @@
+"""Device plumbing for the C ABI: torch owns HBM allocations and the HIP stream, the library does the work.
+
+Field-element buffers are torch.int64 tensors holding the uint64 bit patterns (BaseElement memory form).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, u64p, u8p
+
+
+def _np_u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def to_numpy_u64(t):
+    return t.detach().cpu().contiguous().numpy().view(np.uint64)
+
+
+class Backend:
+    """One cstark_ctx bound to a torch device and the current torch stream."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.CstarkError(-2, "no HIP device visible (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        ctx = C.c_void_p()
+        check(self.lib.cstark_ctx_create(C.c_int(self.device.index), C.c_void_p(self.stream.cuda_stream), C.byref(ctx)))
+        self.ctx = ctx
+        self.n_tx = 0
+        self.depth = 0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.cstark_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.cstark_ctx_synchronize(self.ctx))
+
+    def empty_u64(self, *shape):
+        return torch.empty(shape, dtype=torch.int64, device=self.device)
+
+    def from_numpy_u64(self, a):
+        return torch.from_numpy(_np_u64(a).view(np.int64)).to(self.device)
+
+    @staticmethod
+    def _ptr(t, typ=u64p):
+        assert t.is_contiguous()
+        return C.cast(C.c_void_p(t.data_ptr()), typ)
+
+    # ---- K1 ----
+    def upload_witness(self, w):
+        """w: any object with the TransactionMetadata arrays as numpy attributes (see prover.TransactionMetadata)."""
+        s = _lib.TxWitnessStruct()
+        s.n_tx, s.merkle_depth = int(w.n_tx), int(w.depth)
+        keep = []
+        for f, typ in (("initial_roots", u64p), ("final_root", u64p), ("s_old_values", u64p), ("r_old_values", u64p),
+                       ("s_indices", u64p), ("r_indices", u64p), ("s_paths", u64p), ("r_paths", u64p),
+                       ("deltas", u64p), ("sig_rx", u64p), ("sig_s", u8p)):
+            a = np.ascontiguousarray(getattr(w, f), dtype=np.uint8 if typ is u8p else np.uint64)
+            keep.append(a)
+            setattr(s, f, a.ctypes.data_as(typ))
+        check(self.lib.cstark_tx_witness_upload(self.ctx, C.byref(s)))
+        self.n_tx, self.depth = int(w.n_tx), int(w.depth)
+
+    def build_trace(self, out=None):
+        n = self.n_tx * _lib.TX_CYCLE_LENGTH
+        if out is None:
+            out = self.empty_u64(_lib.TX_TRACE_WIDTH, n)
+        assert out.shape == (_lib.TX_TRACE_WIDTH, n) and out.dtype == torch.int64
+        check(self.lib.cstark_tx_build_trace(self.ctx, self._ptr(out)))
+        return out

@@ -1,0 +1,94 @@
+// Device-side arithmetic in the 63-bit prime field p = 2^62 + 2^56 + 2^55 + 1 used by the reference
+// (winterfell-fork f63::BaseElement; modulus at /root/reference/src/range/tests.rs:59).
+//
+// Elements are uint64_t in Montgomery form (R = 2^64), reduced to [0,p) -- the in-memory form of
+// BaseElement -- so HBM buffers can be shared byte-for-byte with a Rust caller.
+//
+// CDNA4 notes: there is no 64x64 multiplier; a product is four v_mad_u64_u32.  Because
+// p = P1 * 2^32 + 1, -p^-1 mod 2^32 = 0xFFFFFFFF: each 32-bit REDC step is one negate plus one
+// v_mad_u64_u32 (the low word cancels by construction and only contributes a carry bit), for a
+// total of six v_mad_u64_u32 per modular multiplication.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cs {
+
+typedef uint64_t fp;
+
+constexpr uint64_t FP_P = 0x4180000000000001ULL;
+constexpr uint32_t FP_P1 = 0x41800000u;            // high word of p (low word is 1)
+constexpr uint64_t FP_ONE = 0x3b7ffffffffffffdULL; // 2^64 mod p
+constexpr uint64_t FP_R2 = 0x32734c36b7b1d512ULL;  // 2^128 mod p
+constexpr uint64_t FP_INV_ALPHA = 3146514939656186539ULL; // Rescue inverse S-box exponent (rescue.rs:383)
+
+__device__ __forceinline__ uint64_t mad_u64_u32(uint32_t a, uint32_t b, uint64_t c) {
+    return (uint64_t)a * b + c; // one v_mad_u64_u32
+}
+
+__device__ __forceinline__ fp fp_reduce_once(uint64_t r) { return r >= FP_P ? r - FP_P : r; }
+
+__device__ __forceinline__ fp fp_add(fp a, fp b) { return fp_reduce_once(a + b); } // a + b < 2^64
+__device__ __forceinline__ fp fp_sub(fp a, fp b) { return a >= b ? a - b : a + (FP_P - b); }
+__device__ __forceinline__ fp fp_neg(fp a) { return a ? FP_P - a : 0; }
+__device__ __forceinline__ fp fp_dbl(fp a) { return fp_reduce_once(a << 1); }
+
+// Montgomery product without the final conditional subtraction: result in [0, 2p) for a, b < p
+// (and in [0, 2p) as well when a < 2p and b < p).
+__device__ __forceinline__ uint64_t fp_mul_lazy(uint64_t a, uint64_t b) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+    const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    uint64_t t = (uint64_t)a0 * b0;
+    uint64_t u = mad_u64_u32(a1, b0, t >> 32);
+    uint32_t t0 = (uint32_t)t;
+    uint32_t m = 0u - t0;
+    uint64_t v = mad_u64_u32(m, FP_P1, u + (t0 != 0u));
+    uint64_t w = mad_u64_u32(a0, b1, (uint32_t)v);
+    uint64_t x = mad_u64_u32(a1, b1, (w >> 32) + (v >> 32));
+    uint32_t w0 = (uint32_t)w;
+    uint32_t m2 = 0u - w0;
+    return mad_u64_u32(m2, FP_P1, x + (w0 != 0u));
+}
+__device__ __forceinline__ fp fp_mul(fp a, fp b) { return fp_reduce_once(fp_mul_lazy(a, b)); }
+__device__ __forceinline__ fp fp_sqr(fp a) { return fp_mul(a, a); }
+
+__device__ __forceinline__ fp fp_from_u64(uint64_t x) { return fp_mul(x % FP_P, FP_R2); }
+__device__ __forceinline__ uint64_t fp_to_u64(fp a) { return fp_mul(a, 1); }
+
+__device__ inline fp fp_pow(fp base, uint64_t e) {
+    fp r = FP_ONE;
+    while (e) {
+        if (e & 1) r = fp_mul(r, base);
+        base = fp_sqr(base);
+        e >>= 1;
+    }
+    return r;
+}
+__device__ inline fp fp_inv(fp a) { return fp_pow(a, FP_P - 2); }
+
+// x^INV_ALPHA, MSB-first square-and-multiply on the fixed 62-bit exponent (61 squarings + 32 products).
+__device__ inline fp fp_inv_sbox(fp x) {
+    fp r = x;
+#pragma unroll 1
+    for (int i = 60; i >= 0; i--) {
+        r = fp_sqr(r);
+        if ((FP_INV_ALPHA >> i) & 1) r = fp_mul(r, x);
+    }
+    return r;
+}
+
+// small-integer multiples by repeated addition (|c| <= 4), for the linear steps of the curve formulas
+__device__ __forceinline__ fp fp_mul_small(fp a, int c) {
+    fp r;
+    int k = c < 0 ? -c : c;
+    switch (k) {
+        case 0: r = 0; break;
+        case 1: r = a; break;
+        case 2: r = fp_dbl(a); break;
+        case 3: r = fp_add(fp_dbl(a), a); break;
+        default: r = fp_dbl(fp_dbl(a)); break;
+    }
+    return c < 0 ? fp_neg(r) : r;
+}
+
+} // namespace cs

@@ -1,0 +1,18 @@
+// Host-visible declarations for the trace-generation kernels (trace_gen.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cs {
+
+// Device-resident copy of a cstark_tx_witness (include/cstark.h); all pointers are HBM addresses.
+struct TxWitnessDev {
+    uint32_t n_tx, depth;
+    const uint64_t *initial_roots, *s_old, *r_old, *s_idx, *r_idx, *s_paths, *r_paths, *deltas, *sig_rx;
+    const uint8_t *sig_s;
+    uint64_t *h_limbs; // [n_tx][4] canonical limbs of hash_message(), produced by k_trace_schnorr_hash
+};
+
+hipError_t launch_trace_gen(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream);
+
+} // namespace cs

@@ -1,0 +1,382 @@
+// K1 -- execution-trace generation for the state-transition AIR on gfx950.
+//
+// Replaces TransactionProver::build_trace (/root/reference/src/prover.rs:37-98): the reference fills
+// one 1024-row fragment per transaction with a sequential init/update loop (src/trace.rs:28-142).
+// Here the 94 registers are split by the chain that produces them, because each chain is an
+// independent, latency-bound recurrence:
+//   k_trace_merkle        regs 0..64, rows 0..511 (+ root copy rows 512..1023): four Rescue states,
+//                         one lane per state element      (src/merkle/update/trace.rs:19-136)
+//   k_trace_schnorr_hash  regs 42..55, rows 512..1023: the 5-permutation message hash, also yields h
+//                         (src/schnorr/trace.rs:47-67, src/schnorr/mod.rs:247-288)
+//   k_trace_schnorr_ec    regs 0..17 and 19..36, rows 512..1023: the two double-and-add ladders,
+//                         one lane per F_p6 product       (src/schnorr/trace.rs:69-121, src/utils/ecc.rs)
+//   k_trace_aux           every register that is a closed form of the witness (bit registers, limb and
+//                         range accumulators, key/delta/sigma/nonce copies; src/trace.rs:43-53,
+//                         src/range/prover.rs:65-84, src/utils/field.rs:16-22)
+// Rows are staged in LDS 64 at a time and written column-wise, so every global store is a
+// contiguous 512-byte line of one column (the trace is column-major, 94 x N).
+#include "trace_gen.h"
+#include "rescue.cuh"
+#include "tower.cuh"
+
+namespace cs {
+
+namespace {
+
+constexpr int TXC = 1024;       // TRANSACTION_CYCLE_LENGTH, src/constants.rs:83
+constexpr int MERKLE_LEN = 512; // src/merkle/constants.rs:29
+constexpr int SCALAR_MUL_LEN = 510; // src/schnorr/constants.rs:30
+
+// One Rescue round on a 14-element state held one element per lane (rescue.rs:246-263).
+// `xch` is the state's 14-word LDS exchange row.  Must be called by every lane of the block
+// (it synchronises); lanes with active == false only take part in the barriers.
+__device__ __forceinline__ fp rescue_round_lane(fp v, fp *xch, const fp (&mrow)[14], int e, int cyc, bool active) {
+    fp x = 0;
+    if (active) { x = fp_cube(v); xch[e] = x; }
+    __syncthreads();
+    if (active) {
+        fp acc = 0;
+#pragma unroll
+        for (int j = 0; j < 14; j++) acc = fp_add(acc, fp_mul(mrow[j], xch[j]));
+        x = fp_inv_sbox(fp_add(acc, c_ark[cyc * 28 + e]));
+    }
+    __syncthreads();
+    if (active) xch[e] = x;
+    __syncthreads();
+    if (active) {
+        fp acc = 0;
+#pragma unroll
+        for (int j = 0; j < 14; j++) acc = fp_add(acc, fp_mul(mrow[j], xch[j]));
+        v = fp_add(acc, c_ark[cyc * 28 + 14 + e]);
+    }
+    __syncthreads();
+    return v;
+}
+
+template <int NCOLS, int LD>
+__device__ __forceinline__ void flush_tile(const fp (*tile)[LD], fp *__restrict__ trace, size_t n, size_t row0, int c0, int lane,
+                                           int skip_at = -1) {
+    // tile column c -> trace column c0 + c (+1 past skip_at); lane = row within the 64-row tile
+    for (int c = 0; c < NCOLS; c++) {
+        int tc = c0 + c + ((skip_at >= 0 && c >= skip_at) ? 1 : 0);
+        trace[(size_t)tc * n + row0 + lane] = tile[lane][c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    __shared__ fp tile[64][65];
+    __shared__ fp st[4][14];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int hash_len = 8 * (int)w.depth + 7; // TRANSACTION_HASH_LENGTH
+    const bool is_state = lane < 56;
+    const int s = is_state ? lane / 14 : 0, e = is_state ? lane % 14 : 0;
+    // lanes 0..55: state elements; lane 56: both index-bit registers; lanes 57..63: previous-root registers 58..64
+    const int col = is_state ? (s == 0 ? 0 : s == 1 ? 15 : s == 2 ? 29 : 44) + e : (lane == 56 ? 14 : lane + 1);
+    fp mrow[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) mrow[j] = c_mds[e * 14 + j];
+
+    const fp *sv = w.s_old + 14 * (size_t)t, *rv = w.r_old + 14 * (size_t)t;
+    const fp delta = w.deltas[t];
+    const uint64_t s_index = w.s_idx[t], r_index = w.r_idx[t];
+    const fp *s_branch = w.s_paths + (size_t)7 * (w.depth + 1) * t, *r_branch = w.r_paths + (size_t)7 * (w.depth + 1) * t;
+
+    // row 0: init_merkle_update_state, src/merkle/update/trace.rs:19-48
+    fp v = 0, v2 = 0;
+    if (is_state) {
+        v = (s < 2 ? sv : rv)[e];
+        if (s == 1 && e == 12) v = fp_sub(v, delta);
+        if (s == 1 && e == 13) v = fp_add(v, FP_ONE);
+        if (s == 3 && e == 12) v = fp_add(v, delta);
+    } else if (lane >= 57) {
+        v = w.initial_roots[7 * (size_t)t + lane - 57];
+    }
+    tile[0][col] = v;
+    if (lane == 56) tile[0][43] = 0;
+
+    const size_t gbase = (size_t)t * TXC;
+    for (int step = 0; step < MERKLE_LEN - 1; step++) {
+        if (step < hash_len) {
+            const int cyc = step & 7, lvl = step >> 3;
+            if (cyc < 7) {
+                v = rescue_round_lane(v, st[s], mrow, e, cyc, is_state);
+            } else {
+                // sibling insertion, src/merkle/update/trace.rs:112-135
+                if (is_state) st[s][e] = v;
+                __syncthreads();
+                if (is_state) {
+                    const fp *node = (s < 2 ? s_branch : r_branch) + 7 * (lvl + 1);
+                    const int bit = (int)(((s < 2 ? s_index : r_index) >> lvl) & 1);
+                    if (!bit) { if (e >= 7) v = node[e - 7]; }
+                    else v = e >= 7 ? st[s][e - 7] : node[e];
+                } else if (lane == 56) {
+                    v = ((s_index >> lvl) & 1) ? FP_ONE : 0;
+                    v2 = ((r_index >> lvl) & 1) ? FP_ONE : 0;
+                }
+                __syncthreads();
+            }
+            if (step == hash_len - 1) { // root copy, src/merkle/update/trace.rs:87-93
+                if (is_state) st[s][e] = v;
+                __syncthreads();
+                if (lane >= 57) v = st[3][lane - 57];
+                __syncthreads();
+            }
+        }
+        const int r = (step + 1) & 63;
+        tile[r][col] = v;
+        if (lane == 56) tile[r][43] = v2;
+        if (r == 63) {
+            __syncthreads();
+            flush_tile<65, 65>(tile, trace, n, gbase + (step + 1 - 63), 0, lane);
+            __syncthreads();
+        }
+    }
+    // registers 58..64 keep the new root through the Schnorr half (rows 512..1023)
+    if (lane >= 57)
+        for (int r = 0; r < 64; r++) tile[r][col] = v;
+    __syncthreads();
+    for (int k = 0; k < 8; k++)
+        for (int c = 58; c < 65; c++) trace[(size_t)c * n + gbase + MERKLE_LEN + 64 * k + lane] = tile[lane][c];
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trace_schnorr_hash(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    __shared__ fp tile[64][15];
+    __shared__ fp st[14];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const bool active = lane < 14;
+    const int e = active ? lane : 0;
+    fp mrow[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) mrow[j] = c_mds[e * 14 + j];
+    const fp *sv = w.s_old + 14 * (size_t)t, *rv = w.r_old + 14 * (size_t)t;
+
+    // row 512: init_sig_verification_state, src/schnorr/trace.rs:18-30
+    fp v = (active && e < 6) ? w.sig_rx[6 * (size_t)t + e] : 0;
+    if (active) tile[0][e] = v;
+    const size_t gbase = (size_t)t * TXC + MERKLE_LEN;
+    for (int step = 0; step < MERKLE_LEN - 1; step++) {
+        if (step < 40) { // TOTAL_HASH_LENGTH
+            const int cyc = step & 7;
+            if (cyc < 7) {
+                v = rescue_round_lane(v, st, mrow, e, cyc, active);
+            } else if (step < 32) { // message chunk, src/lib.rs:467-481 layout
+                if (active && e >= 7) {
+                    int m = 7 * (step >> 3) + e - 7;
+                    v = m < 12 ? sv[m] : m < 24 ? rv[m - 12] : m == 24 ? w.deltas[t] : m == 25 ? sv[13] : 0;
+                }
+            } else {
+                if (active && e >= 7) v = 0;
+            }
+            if (step == 38 && active && e < 4) w.h_limbs[4 * (size_t)t + e] = fp_to_u64(v); // build_sig_info h_bytes
+        }
+        const int r = (step + 1) & 63;
+        if (active) tile[r][e] = v;
+        if (r == 63) {
+            __syncthreads();
+            flush_tile<14, 15>(tile, trace, n, gbase + (step + 1 - 63), 42, lane);
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Curve ladders.  A point operation is a short program of F_p6 products whose operands are small
+// integer combinations of LDS-resident F_p6 "slots"; each product is done by one lane.
+struct Term { int8_t slot, coef; };
+struct Instr { int8_t out; Term a[3]; Term b[3]; }; // out < 0: no-op; b[0].coef == 0: linear (no product)
+
+enum { SX = 0, SY = 1, SZ = 2, SB3 = 3, SPX = 4, SPY = 5, QX = 23, QY = 24, QZ = 25, NSLOT = 26 };
+enum { OP_DOUBLE = 0, OP_ADD_MIXED = 1, OP_ADD_FULL = 2, NPHASE = 5, NROLE = 6 };
+#define NOP {-1, {{0, 0}, {0, 0}, {0, 0}}, {{0, 0}, {0, 0}, {0, 0}}}
+#define T1(s, c) {{s, c}, {0, 0}, {0, 0}}
+#define T2(s, c, s2, c2) {{s, c}, {s2, c2}, {0, 0}}
+#define T3(s, c, s2, c2, s3, c3) {{s, c}, {s2, c2}, {s3, c3}}
+#define NONE {{0, 0}, {0, 0}, {0, 0}}
+__constant__ Instr c_prog[3][NPHASE][NROLE] = {
+    // OP_DOUBLE: X3 = 2XY(Y^2-2XZ-3bZ^2) - 2YZ(X^2+6bXZ-Z^2), ... (complete doubling, ecc.rs:177-242)
+    {{{6, T1(0, 1), T1(0, 1)}, {7, T1(1, 1), T1(1, 1)}, {8, T1(2, 1), T1(2, 1)}, {9, T1(0, 1), T1(1, 1)}, {10, T1(0, 1), T1(2, 1)}, {11, T1(1, 1), T1(2, 1)}},
+     {{12, T1(3, 1), T1(8, 1)}, {13, T1(3, 1), T1(10, 2)}, NOP, NOP, NOP, NOP},
+     {{14, T3(7, 1, 10, -2, 12, -1), T3(7, 1, 10, 2, 12, 1)}, {15, T1(9, 2), T3(7, 1, 10, -2, 12, -1)}, {16, T2(6, 3, 8, 1), T3(6, 1, 8, -1, 13, 1)},
+      {17, T1(11, 2), T3(6, 1, 8, -1, 13, 1)}, {18, T1(11, 2), T1(7, 1)}, NOP},
+     {{0, T2(15, 1, 17, -1), NONE}, {1, T2(14, 1, 16, 1), NONE}, {2, T1(18, 4), NONE}, NOP, NOP, NOP},
+     {NOP, NOP, NOP, NOP, NOP, NOP}},
+    // OP_ADD_MIXED with the affine point in slots 4,5 (complete mixed addition, ecc.rs:330-404)
+    {{{6, T1(0, 1), T1(4, 1)}, {7, T1(1, 1), T1(5, 1)}, {8, T2(4, 1, 5, 1), T2(0, 1, 1, 1)}, {9, T1(4, 1), T1(2, 1)}, {10, T1(5, 1), T1(2, 1)}, {11, T1(2, 1), T1(3, 1)}},
+     {{19, T2(9, 1, 0, 1), NONE}, NOP, NOP, NOP, NOP, NOP},
+     {{12, T1(19, 1), T1(3, 1)}, NOP, NOP, NOP, NOP, NOP},
+     {{13, T3(7, 1, 11, -1, 19, -1), T3(7, 1, 11, 1, 19, 1)}, {14, T2(6, 3, 2, 1), T3(12, 1, 6, 1, 2, -1)}, {15, T2(10, 1, 1, 1), T3(12, 1, 6, 1, 2, -1)},
+      {16, T3(8, 1, 6, -1, 7, -1), T3(7, 1, 11, -1, 19, -1)}, {17, T3(8, 1, 6, -1, 7, -1), T2(6, 3, 2, 1)}, {18, T2(10, 1, 1, 1), T3(7, 1, 11, 1, 19, 1)}},
+     {{0, T2(16, 1, 15, -1), NONE}, {1, T2(13, 1, 14, 1), NONE}, {2, T2(18, 1, 17, 1), NONE}, NOP, NOP, NOP}},
+    // OP_ADD_FULL with the projective point in slots 23..25 (complete addition, ecc.rs:244-328)
+    {{{6, T1(0, 1), T1(23, 1)}, {7, T1(1, 1), T1(24, 1)}, {8, T1(2, 1), T1(25, 1)}, {9, T2(0, 1, 1, 1), T2(23, 1, 24, 1)}, {10, T2(0, 1, 2, 1), T2(23, 1, 25, 1)},
+      {11, T2(1, 1, 2, 1), T2(24, 1, 25, 1)}},
+     {{19, T3(10, 1, 6, -1, 8, -1), NONE}, NOP, NOP, NOP, NOP, NOP},
+     {{12, T1(3, 1), T1(8, 1)}, {13, T1(3, 1), T1(19, 1)}, NOP, NOP, NOP, NOP},
+     {{14, T3(7, 1, 12, -1, 19, -1), T3(7, 1, 12, 1, 19, 1)}, {15, T2(6, 3, 8, 1), T3(13, 1, 6, 1, 8, -1)}, {16, T3(11, 1, 7, -1, 8, -1), T3(13, 1, 6, 1, 8, -1)},
+      {17, T3(9, 1, 6, -1, 7, -1), T3(7, 1, 12, -1, 19, -1)}, {18, T3(9, 1, 6, -1, 7, -1), T2(6, 3, 8, 1)}, {20, T3(11, 1, 7, -1, 8, -1), T3(7, 1, 12, 1, 19, 1)}},
+     {{0, T2(17, 1, 16, -1), NONE}, {1, T2(14, 1, 15, 1), NONE}, {2, T2(20, 1, 18, 1), NONE}, NOP, NOP, NOP}},
+};
+#undef NOP
+#undef T1
+#undef T2
+#undef T3
+#undef NONE
+
+__device__ __forceinline__ Fp6 lincomb(const fp (*slot)[6], const Term (&t)[3]) {
+    Fp6 r = fp6_mul_small(fp6_load(slot[t[0].slot]), t[0].coef);
+#pragma unroll
+    for (int k = 1; k < 3; k++)
+        if (t[k].coef != 0) r = fp6_add(r, fp6_mul_small(fp6_load(slot[t[k].slot]), t[k].coef));
+    return r;
+}
+
+// Runs program `op` on the slots of one point.  Called by all lanes of the block (barriers inside).
+__device__ __forceinline__ void run_point_op(int op, fp (*slot)[6], int role, bool enabled) {
+#pragma unroll 1
+    for (int ph = 0; ph < NPHASE; ph++) {
+        Fp6 r;
+        int out = -1;
+        if (enabled && role < NROLE) {
+            const Instr ins = c_prog[op][ph][role];
+            out = ins.out;
+            if (out >= 0) {
+                r = lincomb(slot, ins.a);
+                if (ins.b[0].coef != 0) r = fp6_mul(r, lincomb(slot, ins.b));
+            }
+        }
+        __syncthreads();
+        if (out >= 0) fp6_store(slot[out], r);
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int bit_le(const uint8_t *bytes, int i) { return (bytes[i >> 3] >> (i & 7)) & 1; }
+
+__global__ __launch_bounds__(64) void k_trace_schnorr_ec(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    __shared__ fp tile[64][37];
+    __shared__ fp slots[2][NSLOT][6];
+    __shared__ uint8_t sbytes[2][32];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int g = lane >> 5, role = lane & 31; // g = 0: s*G (regs 0..17), g = 1: h*P (regs 19..36)
+    fp(*slot)[6] = slots[g];
+
+    // scalars: s from the signature, h from the message hash (little-endian bytes, Lsb0 bit order)
+    if (lane < 32) sbytes[0][lane] = w.sig_s[32 * (size_t)t + lane];
+    else { int b = lane - 32; sbytes[1][b] = (uint8_t)(w.h_limbs[4 * (size_t)t + (b >> 3)] >> (8 * (b & 7))); }
+    // constant slots and the initial point (0 : 1 : 0), src/schnorr/trace.rs:22-27
+    if (role < 6) {
+        slot[SX][role] = 0;
+        slot[SY][role] = role == 0 ? FP_ONE : 0;
+        slot[SZ][role] = 0;
+        slot[SB3][role] = c_b3[role];
+        slot[SPX][role] = g == 0 ? c_generator[role] : w.s_old[14 * (size_t)t + role];
+        slot[SPY][role] = g == 0 ? c_generator[6 + role] : w.s_old[14 * (size_t)t + 6 + role];
+    }
+    __syncthreads();
+    if (role < 18) tile[0][g * 18 + role] = slot[role / 6][role % 6];
+    const size_t gbase = (size_t)t * TXC + MERKLE_LEN;
+
+    for (int step = 0; step < MERKLE_LEN - 1; step++) {
+        if (step < SCALAR_MUL_LEN) {
+            if ((step & 1) == 0) {
+                run_point_op(OP_DOUBLE, slot, role, true);
+            } else {
+                const int bit = bit_le(sbytes[g], 254 - (step >> 1)); // MSB first, src/schnorr/trace.rs:79-82
+                run_point_op(OP_ADD_MIXED, slot, role, bit != 0);
+            }
+        } else if (step == SCALAR_MUL_LEN) {
+            // S += h*P, then X <- X / Z  (src/schnorr/trace.rs:105-119)
+            if (g == 0 && role < 18) slot[QX + role / 6][role % 6] = slots[1][role / 6][role % 6];
+            __syncthreads();
+            run_point_op(OP_ADD_FULL, slot, role, g == 0);
+            if (lane == 0) {
+                Fp6 x = fp6_mul(fp6_load(slot[SX]), fp6_inv(fp6_load(slot[SZ])));
+                fp6_store(slot[SX], x);
+            }
+            __syncthreads();
+        }
+        const int r = (step + 1) & 63;
+        if (role < 18) tile[r][g * 18 + role] = slot[role / 6][role % 6];
+        if (r == 63) {
+            __syncthreads();
+            flush_tile<36, 37>(tile, trace, n, gbase + (step + 1 - 63), 0, lane, 18);
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Closed-form registers.  grid = (n_tx, 4), block = 256: one lane per row.
+__device__ __forceinline__ fp small_to_fp(uint64_t x) { return fp_mul(x, FP_R2); } // x < p
+
+__global__ __launch_bounds__(256) void k_trace_aux(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    const int t = blockIdx.x;
+    const int r = blockIdx.y * 256 + threadIdx.x; // row inside the transaction
+    const size_t g = (size_t)t * TXC + r;
+    const fp *sv = w.s_old + 14 * (size_t)t, *rv = w.r_old + 14 * (size_t)t;
+    const fp delta = w.deltas[t];
+    const fp sigma = fp_sub(sv[12], delta);
+    // copies: src/trace.rs:43-53 (constant over the whole transaction)
+    for (int i = 0; i < 12; i++) {
+        trace[(size_t)(65 + i) * n + g] = sv[i];
+        trace[(size_t)(77 + i) * n + g] = rv[i];
+    }
+    trace[(size_t)89 * n + g] = delta;
+    trace[(size_t)90 * n + g] = sigma;
+    trace[(size_t)91 * n + g] = sv[13];
+    if (r < MERKLE_LEN) {
+        trace[(size_t)92 * n + g] = 0;
+        trace[(size_t)93 * n + g] = 0;
+        return;
+    }
+    const int q = r - MERKLE_LEN; // q = 0 is the Schnorr init row; row q is produced by step q-1
+    const uint64_t dv = fp_to_u64(delta), sg = fp_to_u64(sigma);
+    // range accumulators, src/range/prover.rs:65-84: after k = min(q,64) steps acc = value >> (64-k)
+    {
+        const int k = q < 64 ? q : 64;
+        uint64_t dacc = k == 0 ? 0 : dv >> (64 - k), sacc = k == 0 ? 0 : sg >> (64 - k);
+        trace[(size_t)56 * n + g] = (dacc & 1) ? FP_ONE : 0;
+        trace[(size_t)57 * n + g] = small_to_fp(dacc);
+        trace[(size_t)92 * n + g] = (sacc & 1) ? FP_ONE : 0;
+        trace[(size_t)93 * n + g] = small_to_fp(sacc);
+    }
+    // scalar bit registers 18 / 37, src/schnorr/trace.rs:79-82 and :110
+    const uint8_t *sb = w.sig_s + 32 * (size_t)t;
+    const uint64_t *h = w.h_limbs + 4 * (size_t)t;
+    fp bs = 0, bh = 0;
+    if (q >= 1) {
+        const int step = q - 1 < SCALAR_MUL_LEN - 1 ? q - 1 : SCALAR_MUL_LEN - 1;
+        const int bi = 254 - (step >> 1);
+        bs = bit_le(sb, bi) ? FP_ONE : 0;
+        bh = ((h[bi >> 6] >> (bi & 63)) & 1) ? FP_ONE : 0;
+        if (q == SCALAR_MUL_LEN + 1) bs = FP_ONE;
+    }
+    trace[(size_t)18 * n + g] = bs;
+    trace[(size_t)37 * n + g] = bh;
+    // h-limb accumulators 38..41: k bits consumed MSB-first; chunk 0 = 63 bits into reg 41, then 64-bit chunks
+    const int k = (q + 1) / 2 < 255 ? (q + 1) / 2 : 255;
+    for (int c = 0; c < 4; c++) {
+        const int width = c == 0 ? 63 : 64;
+        const int start = c == 0 ? 0 : 63 + 64 * (c - 1);
+        int kc = k - start;
+        kc = kc < 0 ? 0 : kc > width ? width : kc;
+        const uint64_t limb = h[3 - c];
+        const uint64_t acc = kc == 0 ? 0 : (c == 0 ? (limb >> (63 - kc)) : (kc == 64 ? limb : limb >> (64 - kc)));
+        trace[(size_t)(41 - c) * n + g] = small_to_fp(acc);
+    }
+}
+
+} // namespace
+
+hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stream) {
+    const size_t n = (size_t)w.n_tx * TXC;
+    hipLaunchKernelGGL(k_trace_schnorr_hash, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_merkle, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_ec, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_aux, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
+    return hipGetLastError();
+}
+
+} // namespace cs
