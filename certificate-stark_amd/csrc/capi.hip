@@ -27,7 +27,6 @@ int fail(int code, const char *fmt, const char *detail = "") {
 struct cstark_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool own_stream = false;
     // uploaded witness
     void *wit_buf = nullptr;
     size_t wit_bytes = 0;
@@ -50,13 +49,7 @@ int cstark_ctx_create(int device, void *stream, cstark_ctx **out) {
     cstark_ctx *c = new (std::nothrow) cstark_ctx();
     if (!c) return fail(CSTARK_ERR_OOM, "host allocation failed");
     c->device = device;
-    if (stream) {
-        c->stream = (hipStream_t)stream;
-    } else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete c; return fail(CSTARK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
-        c->own_stream = true;
-    }
+    c->stream = (hipStream_t)stream; // NULL is HIP's default stream
     *out = c;
     return CSTARK_OK;
 }
@@ -66,7 +59,6 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->wit_buf) (void)hipFree(c->wit_buf);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 

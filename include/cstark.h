@@ -92,7 +92,8 @@ typedef struct cstark_tx_coeffs {
 typedef struct cstark_ctx cstark_ctx;
 
 /* ---- context ------------------------------------------------------------------------------- */
-/* device < 0: current HIP device.  stream: a hipStream_t to launch on, or NULL to create one. */
+/* device < 0: current HIP device.  stream: the hipStream_t every launch of this context goes to
+ * (NULL = HIP's default stream).  Work is asynchronous; cstark_ctx_synchronize() waits for it. */
 int cstark_ctx_create(int device, void *stream, cstark_ctx **out);
 void cstark_ctx_destroy(cstark_ctx *ctx);
 const char *cstark_last_error(void);
