@@ -53,6 +53,27 @@ void cso_tx_evaluate_transition(const uint64_t *cur94, const uint64_t *next94, c
 long cso_tx_check_trace(const uint64_t *trace, uint32_t n_tx, unsigned depth);
 void cso_tx_constraint_degrees(uint32_t *base115, uint32_t *cycles115);
 
+/* engine stages (engine.c) */
+void cso_ntt(uint64_t *a, unsigned log_n);
+void cso_intt(uint64_t *a, unsigned log_n);
+void cso_dft_naive(const uint64_t *a, uint64_t *out, unsigned log_n);
+uint64_t cso_fp_generator(void);
+void cso_interpolate_columns(uint64_t *cols, uint32_t width, unsigned log_n);
+void cso_lde_columns(const uint64_t *coeffs, uint64_t *lde, uint32_t width, unsigned log_n, unsigned log_b, uint64_t offset,
+                     uint32_t k0, uint32_t nk);
+void cso_blake3(const uint8_t *in, size_t len, uint8_t out[32]);
+void cso_hash_rows(const uint64_t *lde, uint8_t *leaves, uint32_t width, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk);
+void cso_merkle_build(uint8_t *nodes, unsigned log_leaves);
+void cso_tx_periodic_table(unsigned depth, unsigned log_n, unsigned log_b, uint64_t *out /*[b][48][1024]*/);
+void cso_tx_degree_adjustments(unsigned log_n, unsigned log_b, uint64_t *adj115);
+void cso_tx_evaluate_transitions(const uint64_t *lde, uint64_t *out, unsigned depth, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk);
+void cso_tx_evaluate_constraints(const uint64_t *lde, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4], uint64_t *out,
+                                 unsigned depth, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk);
+
+uint64_t cso_poly_eval(const uint64_t *co, size_t n, uint64_t x);
+uint64_t cso_tx_combined_at(const uint64_t *trace_coeffs, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
+                            unsigned depth, unsigned log_n, unsigned log_b, uint64_t z);
+
 /* deterministic witness synthesis (counterpart of TransactionMetadata::build_random, src/lib.rs:235-465).
  * The caller allocates every array of *w (non-const use). */
 int cso_tx_witness_generate(cstark_tx_witness *w, uint64_t seed);

@@ -53,6 +53,9 @@ def lib():
             build()
         _lib = C.CDLL(_SO)
         _lib.cso_fp_root_of_unity.restype = C.c_uint64
+        _lib.cso_fp_generator.restype = C.c_uint64
+        _lib.cso_poly_eval.restype = C.c_uint64
+        _lib.cso_tx_combined_at.restype = C.c_uint64
         _lib.cso_tx_check_trace.restype = C.c_long
     return _lib
 
@@ -187,3 +190,120 @@ def tx_constraint_degrees():
     base = np.zeros(TX_NC, np.uint32); cyc = np.zeros(TX_NC, np.uint32)
     lib().cso_tx_constraint_degrees(_p(base, u32p), _p(cyc, u32p))
     return base, cyc
+
+
+# ---- engine stages ----------------------------------------------------------------------------------
+def generator():
+    return int(lib().cso_fp_generator())
+
+
+def ntt(a, inverse=False):
+    a = _u64(a).copy()
+    log_n = a.size.bit_length() - 1
+    assert a.size == 1 << log_n
+    (lib().cso_intt if inverse else lib().cso_ntt)(_p(a), C.c_uint(log_n))
+    return a
+
+
+def dft_naive(a):
+    a = _u64(a); out = np.empty_like(a)
+    lib().cso_dft_naive(_p(a), _p(out), C.c_uint(a.size.bit_length() - 1)); return out
+
+
+def interpolate_columns(cols):
+    cols = _u64(cols).copy()
+    width, n = cols.shape
+    lib().cso_interpolate_columns(_p(cols), C.c_uint32(width), C.c_uint(n.bit_length() - 1))
+    return cols
+
+
+def lde_columns(coeffs, log_b, offset=None, k0=0, nk=None):
+    coeffs = _u64(coeffs)
+    width, n = coeffs.shape
+    nk = (1 << log_b) - k0 if nk is None else nk
+    out = np.zeros((nk, width, n), np.uint64)
+    lib().cso_lde_columns(_p(coeffs), _p(out), C.c_uint32(width), C.c_uint(n.bit_length() - 1), C.c_uint(log_b),
+                          C.c_uint64(generator() if offset is None else offset), C.c_uint32(k0), C.c_uint32(nk))
+    return out
+
+
+def blake3(data):
+    data = bytes(data)
+    buf = np.frombuffer(data, np.uint8) if data else np.zeros(1, np.uint8)
+    out = np.zeros(32, np.uint8)
+    lib().cso_blake3(_p(np.ascontiguousarray(buf), u8p), C.c_size_t(len(data)), _p(out, u8p))
+    return out.tobytes()
+
+
+def hash_rows(lde, log_b, k0=0):
+    lde = _u64(lde)
+    nk, width, n = lde.shape
+    leaves = np.zeros((n << log_b, 32), np.uint8)
+    lib().cso_hash_rows(_p(lde), _p(leaves, u8p), C.c_uint32(width), C.c_uint(n.bit_length() - 1), C.c_uint(log_b),
+                        C.c_uint32(k0), C.c_uint32(nk))
+    return leaves
+
+
+def merkle_build(leaves):
+    leaves = np.ascontiguousarray(leaves, np.uint8)
+    L = leaves.shape[0]
+    nodes = np.zeros((2 * L, 32), np.uint8)
+    nodes[L:] = leaves
+    lib().cso_merkle_build(_p(nodes, u8p), C.c_uint(L.bit_length() - 1))
+    return nodes
+
+
+def tx_periodic_table(depth, log_n, log_b):
+    out = np.zeros((1 << log_b, TX_NP, 1024), np.uint64)
+    lib().cso_tx_periodic_table(C.c_uint(depth), C.c_uint(log_n), C.c_uint(log_b), _p(out))
+    return out
+
+
+def tx_degree_adjustments(log_n, log_b):
+    out = np.zeros(TX_NC, np.uint64)
+    lib().cso_tx_degree_adjustments(C.c_uint(log_n), C.c_uint(log_b), _p(out)); return out
+
+
+def make_coeffs(seed=1):
+    """Pseudo-random composition coefficients (stand-in for the public-coin draw)."""
+    rng = np.random.default_rng(seed)
+    draw = lambda k: to_mont(rng.integers(0, P, size=k, dtype=np.uint64))
+    cf = TxCoeffsStruct()
+    for name, k in (("t_alpha", TX_NC), ("t_beta", TX_NC), ("b_alpha", 4), ("b_beta", 4)):
+        v = draw(k)
+        for i in range(k):
+            getattr(cf, name)[i] = int(v[i])
+    return cf
+
+
+def tx_evaluate_transitions(lde, depth, log_b, k0=0):
+    lde = _u64(lde)
+    nk, width, n = lde.shape
+    assert width == TX_W
+    out = np.zeros((nk, TX_NC, n), np.uint64)
+    lib().cso_tx_evaluate_transitions(_p(lde), _p(out), C.c_uint(depth), C.c_uint(n.bit_length() - 1), C.c_uint(log_b),
+                                      C.c_uint32(k0), C.c_uint32(nk))
+    return out
+
+
+def tx_evaluate_constraints(lde, coeffs, pub_inputs, depth, log_b, k0=0):
+    lde = _u64(lde)
+    nk, width, n = lde.shape
+    pub = _u64(pub_inputs)
+    out = np.zeros((nk, n), np.uint64)
+    lib().cso_tx_evaluate_constraints(_p(lde), C.byref(coeffs), _p(pub), _p(out), C.c_uint(depth),
+                                      C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_uint32(k0), C.c_uint32(nk))
+    return out
+
+
+def poly_eval(coeffs, x):
+    coeffs = _u64(coeffs)
+    return int(lib().cso_poly_eval(_p(coeffs), C.c_size_t(coeffs.size), C.c_uint64(x)))
+
+
+def tx_combined_at(trace_coeffs, coeffs, pub_inputs, depth, log_b, z):
+    trace_coeffs = _u64(trace_coeffs)
+    width, n = trace_coeffs.shape
+    pub = _u64(pub_inputs)
+    return int(lib().cso_tx_combined_at(_p(trace_coeffs), C.byref(coeffs), _p(pub), C.c_uint(depth),
+                                        C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_uint64(z)))

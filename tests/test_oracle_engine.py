@@ -1,0 +1,138 @@
+"""Pins the oracle's engine stages: BLAKE3 against the official test vectors, the NTT against a naive DFT,
+the LDE against Horner evaluation, the Merkle tree against direct hashing, and the constraint-evaluation
+driver through the algebraic fact that the combined evaluations are a polynomial of degree < 8n
+(SURVEY.md 8(c) (11),(12)).  CPU only."""
+import hashlib
+import random
+
+import numpy as np
+
+P = 2**62 + 2**56 + 2**55 + 1
+R = 2**64
+
+
+def unmont(x): return int(x) * pow(R, -1, P) % P
+
+
+# official BLAKE3 test vectors (test_vectors.json of the BLAKE3 repository): input byte i = i % 251
+B3_VECTORS = {
+    0: "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262",
+    1: "2d3adedff11b61f14c886e35afa036736dcd87a74d27b5c1510225d0f592e213",
+    1023: "10108970eeda3eb932baac1428c7a2163b0e924c9a9e25b35bba72b28f70bd11",
+    1024: "42214739f095a406f3fc83deb889744ac00df831c10daa55189b5d121c855af7",
+    1025: "d00278ae47eb27b34faecf67b4fe263f82d5412916c1ffd97c8cb7fb814b8444",
+    2048: "e776b6028c7cd22a4d0ba182a8bf62205d2ef576467e838ed6f2529b85fba24a",
+}
+
+
+def test_blake3_official_vectors(oracle):
+    for n, hexd in B3_VECTORS.items():
+        data = bytes(i % 251 for i in range(n))
+        assert oracle.blake3(data).hex() == hexd, n
+
+
+def test_ntt_vs_naive_and_roundtrip(oracle):
+    rng = random.Random(5)
+    for log_n in (1, 2, 5, 8):
+        a = oracle.to_mont([rng.randrange(P) for _ in range(1 << log_n)])
+        f = oracle.ntt(a)
+        assert (f == oracle.dft_naive(a)).all()
+        assert (oracle.ntt(f, inverse=True) == a).all()
+    a = oracle.to_mont([rng.randrange(P) for _ in range(1 << 14)])
+    assert (oracle.ntt(oracle.ntt(a), inverse=True) == a).all()
+
+
+def test_lde_matches_horner(oracle):
+    rng = random.Random(6)
+    log_n, log_b, width = 6, 3, 3
+    n = 1 << log_n
+    ev = oracle.to_mont(np.array([[rng.randrange(P) for _ in range(n)] for _ in range(width)], np.uint64).ravel()).reshape(width, n)
+    co = oracle.interpolate_columns(ev)
+    lde = oracle.lde_columns(co, log_b)
+    assert lde.shape == (8, width, n)
+    g = 3
+    w8n = unmont(oracle.root_of_unity(log_n + log_b))
+    wn = unmont(oracle.root_of_unity(log_n))
+    coc = [[unmont(v) for v in co[c]] for c in range(width)]
+    for (k, c, j) in [(0, 0, 0), (1, 1, 5), (7, 2, 63), (3, 0, 17)]:
+        x = g * pow(w8n, k, P) * pow(wn, j, P) % P
+        assert x == g * pow(w8n, 8 * j + k, P) % P           # natural LDE index i = 8 j + k
+        y = sum(coc[c][m] * pow(x, m, P) for m in range(n)) % P
+        assert unmont(lde[k, c, j]) == y
+    # the trace domain itself is recovered from the polynomial (offset 1, coset 0)
+    back = oracle.lde_columns(co, 0, offset=int(oracle.to_mont([1])[0]))
+    assert (back[0] == ev).all()
+    # coset subset request equals the slice of the full result
+    part = oracle.lde_columns(co, log_b, k0=2, nk=3)
+    assert (part == lde[2:5]).all()
+
+
+def test_row_hash_and_merkle(oracle):
+    rng = random.Random(7)
+    log_n, log_b, width = 3, 2, 5
+    n = 1 << log_n
+    lde = oracle.to_mont(np.array([rng.randrange(P) for _ in range(4 * width * n)], np.uint64)).reshape(4, width, n)
+    leaves = oracle.hash_rows(lde, log_b)
+    for (k, j) in [(0, 0), (3, 7), (2, 4)]:
+        row = b"".join(int(lde[k, c, j]).to_bytes(8, "little") for c in range(width))
+        assert leaves[4 * j + k].tobytes() == oracle.blake3(row)
+    nodes = oracle.merkle_build(leaves)
+    L = leaves.shape[0]
+    assert (nodes[L:] == leaves).all() and not nodes[0].any()
+    for i in (1, 2, 5, L - 1):
+        assert nodes[i].tobytes() == oracle.blake3(nodes[2 * i].tobytes() + nodes[2 * i + 1].tobytes())
+
+
+def test_periodic_table_matches_direct_evaluation(oracle):
+    depth, log_n, log_b = 3, 11, 3
+    n = 1 << log_n
+    tab = oracle.tx_periodic_table(depth, log_n, log_b)
+    cols = oracle.tx_periodic_columns(depth)
+    co = oracle.interpolate_columns(cols)
+    g, w8n, wn = 3, unmont(oracle.root_of_unity(log_n + log_b)), unmont(oracle.root_of_unity(log_n))
+    for (k, c, j) in [(0, 0, 0), (5, 19, 700), (7, 33, 1500), (2, 2, 1023)]:
+        x = g * pow(w8n, k, P) * pow(wn, j, P) % P
+        y = pow(x, n // 1024, P)
+        val = sum(unmont(co[c, m]) * pow(y, m, P) for m in range(1024)) % P
+        assert unmont(tab[k, c, j % 1024]) == val
+
+
+def test_combined_evaluations_interpolate_to_the_composition_polynomial(oracle, witness_d3):
+    """Out-of-domain consistency (the check the verifier performs): for a valid trace the combined evaluations
+    over the 8n-point domain g<w_8n> are those of a polynomial H of degree < 8n, so H(z) -- interpolated from
+    the evaluations -- must equal the constraint expression evaluated directly at a random z from the trace
+    polynomials.  For an invalid trace or wrong public inputs (the reference's negative test,
+    src/lib.rs:153-161) the quotient is not a polynomial and the two values differ."""
+    w = witness_d3
+    log_n, log_b = 11, 3
+    n = 1 << log_n
+    cf = oracle.make_coeffs(3)
+    pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
+    z = int(oracle.to_mont([0x1234567890ABCDEF % P])[0])
+    ginv = int(oracle.fp_inv(np.array([oracle.generator()], np.uint64))[0])
+    zg = int(oracle.fp_mul(np.array([z], np.uint64), np.array([ginv], np.uint64))[0])
+
+    def both(wit, pub_inputs):
+        trace = oracle.tx_build_trace(wit)
+        co = oracle.interpolate_columns(trace)
+        lde = oracle.lde_columns(co, log_b)
+        comb = oracle.tx_evaluate_constraints(lde, cf, pub_inputs, wit.depth, log_b)   # [8][n], coset-major
+        nat = np.ascontiguousarray(comb.T).ravel()                                     # natural order i = 8 j + k
+        h = oracle.ntt(nat, inverse=True)                                              # H(g y) as a polynomial in y
+        return oracle.poly_eval(h, zg), oracle.tx_combined_at(co, cf, pub_inputs, wit.depth, log_b, z)
+    a, b = both(w, pub)
+    assert a == b
+    bad_pub = pub.copy(); bad_pub[3] = pub[2]
+    a, b = both(w, bad_pub)
+    assert a != b
+    bad = w.copy(); bad.deltas[1] = oracle.fp_add(bad.deltas[1:2], oracle.to_mont([1]))[0]
+    a, b = both(bad, pub)
+    assert a != b
+
+
+def test_degree_adjustments(oracle):
+    log_n, log_b = 11, 3
+    n = 1 << log_n
+    adj = oracle.tx_degree_adjustments(log_n, log_b)
+    assert int(adj[0]) == (8 * n - 1 + n - 1) - (5 * (n - 1) + 2 * (n // 1024) * 1023)
+    assert int(adj[60]) == (8 * n - 1 + n - 1) - (1 * (n - 1) + (n // 1024) * 1023)
