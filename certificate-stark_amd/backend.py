@@ -82,3 +82,28 @@ class Backend:
         assert out.shape == (_lib.TX_TRACE_WIDTH, n) and out.dtype == torch.int64
         check(self.lib.cstark_tx_build_trace(self.ctx, self._ptr(out)))
         return out
+
+    # ---- K2 / K3 ----
+    def field_generator(self):
+        self.lib.cstark_field_generator.restype = C.c_uint64
+        return int(self.lib.cstark_field_generator())
+
+    def interpolate_columns(self, evals, out=None):
+        """evals: int64 [width, n] tensor (destroyed). Returns the coefficient tensor."""
+        width, n = evals.shape
+        if out is None:
+            out = self.empty_u64(width, n)
+        check(self.lib.cstark_interpolate_columns(self.ctx, self._ptr(evals), self._ptr(out), C.c_uint32(width),
+                                                  C.c_uint32(n.bit_length() - 1)))
+        return out
+
+    def lde_columns(self, coeffs, log_blowup, offset=None, k0=0, nk=None, out=None):
+        width, n = coeffs.shape
+        nk = (1 << log_blowup) - k0 if nk is None else nk
+        if out is None:
+            out = self.empty_u64(nk, width, n)
+        off = self.field_generator() if offset is None else int(offset)
+        check(self.lib.cstark_lde_columns(self.ctx, self._ptr(coeffs), self._ptr(out), C.c_uint32(width),
+                                          C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint64(off),
+                                          C.c_uint32(k0), C.c_uint32(nk)))
+        return out

@@ -6,7 +6,10 @@
 #include <string.h>
 #include <new>
 #include "../../include/cstark.h"
+#include <deque>
 #include "trace_gen.h"
+#include "ntt.h"
+#include "hostfield.h"
 
 namespace {
 
@@ -24,6 +27,17 @@ int fail(int code, const char *fmt, const char *detail = "") {
 
 } // namespace
 
+struct NttPlan {
+    unsigned log_n;
+    uint64_t *w, *winv; // [n] each: powers of w_n and of its inverse
+    uint64_t n_inv;
+};
+struct CosetTable {
+    unsigned log_n, log_b;
+    uint64_t offset;
+    uint64_t *s; // [b][n]: (offset * w_{bn}^k)^m
+};
+
 struct cstark_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -31,7 +45,57 @@ struct cstark_ctx {
     void *wit_buf = nullptr;
     size_t wit_bytes = 0;
     cs::TxWitnessDev wit{};
+    // cached tables and workspace
+    std::deque<NttPlan> plans;   // deque: references stay valid as entries are added
+    std::deque<CosetTable> cosets;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
 };
+
+namespace {
+
+int get_plan(cstark_ctx *c, unsigned log_n, const NttPlan **out) {
+    for (const NttPlan &p : c->plans)
+        if (p.log_n == log_n) { *out = &p; return CSTARK_OK; }
+    const size_t n = (size_t)1 << log_n;
+    NttPlan p{log_n, nullptr, nullptr, 0};
+    HIP_TRY(hipMalloc((void **)&p.w, n * 8));
+    HIP_TRY(hipMalloc((void **)&p.winv, n * 8));
+    const uint64_t w = cs::host::root_of_unity(log_n);
+    HIP_TRY(cs::ntt_power_table(p.w, n, w, c->stream));
+    HIP_TRY(cs::ntt_power_table(p.winv, n, cs::host::inv(w), c->stream));
+    p.n_inv = cs::host::inv(cs::host::from_u64(n));
+    c->plans.push_back(p);
+    *out = &c->plans.back();
+    return CSTARK_OK;
+}
+
+int get_coset_table(cstark_ctx *c, unsigned log_n, unsigned log_b, uint64_t offset, const CosetTable **out) {
+    for (const CosetTable &t : c->cosets)
+        if (t.log_n == log_n && t.log_b == log_b && t.offset == offset) { *out = &t; return CSTARK_OK; }
+    const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b;
+    CosetTable t{log_n, log_b, offset, nullptr};
+    HIP_TRY(hipMalloc((void **)&t.s, b * n * 8));
+    const uint64_t wbn = cs::host::root_of_unity(log_n + log_b);
+    uint64_t shift = offset;
+    for (size_t k = 0; k < b; k++) {
+        HIP_TRY(cs::ntt_power_table(t.s + k * n, n, shift, c->stream));
+        shift = cs::host::mul(shift, wbn);
+    }
+    c->cosets.push_back(t);
+    *out = &c->cosets.back();
+    return CSTARK_OK;
+}
+
+int ensure_ws(cstark_ctx *c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return CSTARK_OK;
+    if (c->ws) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->ws, bytes));
+    c->ws_bytes = bytes;
+    return CSTARK_OK;
+}
+
+} // namespace
 
 extern "C" {
 
@@ -59,6 +123,9 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->wit_buf) (void)hipFree(c->wit_buf);
+    if (c->ws) (void)hipFree(c->ws);
+    for (NttPlan &p : c->plans) { (void)hipFree(p.w); (void)hipFree(p.winv); }
+    for (CosetTable &t : c->cosets) (void)hipFree(t.s);
     delete c;
 }
 
@@ -141,6 +208,50 @@ int cstark_tx_build_trace(cstark_ctx *c, uint64_t *d_trace) {
     if (!c->wit_buf || c->wit.n_tx == 0) return fail(CSTARK_ERR_INVALID_ARG, "no witness uploaded");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(cs::launch_trace_gen(c->wit, d_trace, c->stream));
+    return CSTARK_OK;
+}
+
+// ---- K2 / K3 ---------------------------------------------------------------------------------------
+uint64_t cstark_field_generator(void) { return cs::host::generator(); }
+uint64_t cstark_field_root_of_unity(uint32_t log_n) { return log_n <= 55 ? cs::host::root_of_unity(log_n) : 0; }
+
+int cstark_interpolate_columns(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint32_t width, uint32_t log_n) {
+    if (!c || !d_evals || !d_coeffs || width == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_interpolate_columns: bad argument");
+    if (d_evals == d_coeffs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_interpolate_columns: output must not alias input");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "domain size must be 2^6 .. 2^24");
+    HIP_TRY(hipSetDevice(c->device));
+    const NttPlan *p;
+    int rc = get_plan(c, log_n, &p);
+    if (rc) return rc;
+    cs::NttArgs a{};
+    a.in = d_evals; a.scratch = d_evals; a.out = d_coeffs;
+    a.width = width; a.batch = 1; a.log_n = log_n;
+    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true;
+    HIP_TRY(cs::ntt_columns(a, c->stream));
+    return CSTARK_OK;
+}
+
+int cstark_lde_columns(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t log_n, uint32_t log_blowup,
+                       uint64_t domain_offset, uint32_t k0, uint32_t nk) {
+    if (!c || !d_coeffs || !d_lde || width == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_lde_columns: bad argument");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6) return fail(CSTARK_ERR_UNSUPPORTED, "unsupported domain size");
+    if (domain_offset == 0 || domain_offset >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "domain offset must be a nonzero field element");
+    if ((uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "coset range exceeds the blowup factor");
+    HIP_TRY(hipSetDevice(c->device));
+    const NttPlan *p;
+    const CosetTable *t;
+    int rc = get_plan(c, log_n, &p);
+    if (rc) return rc;
+    if ((rc = get_coset_table(c, log_n, log_blowup, domain_offset, &t))) return rc;
+    const size_t n = (size_t)1 << log_n;
+    if ((rc = ensure_ws(c, (size_t)width * n * 8))) return rc;
+    for (uint32_t k = k0; k < k0 + nk; k++) {
+        cs::NttArgs a{};
+        a.in = d_coeffs; a.scratch = (uint64_t *)c->ws; a.out = d_lde + (size_t)(k - k0) * width * n;
+        a.width = width; a.batch = 1; a.log_n = log_n;
+        a.w = p->w; a.prescale = t->s + (size_t)k * n; a.do_scale = false;
+        HIP_TRY(cs::ntt_columns(a, c->stream));
+    }
     return CSTARK_OK;
 }
 

@@ -1,0 +1,40 @@
+// Host-side f63 arithmetic for the small amount of scalar work the C ABI does on the CPU (roots of unity,
+// coset offsets, table parameters).  Same representation as the device code: Montgomery form, R = 2^64.
+#pragma once
+#include <stdint.h>
+
+namespace cs {
+namespace host {
+
+typedef unsigned __int128 u128;
+constexpr uint64_t P = 0x4180000000000001ULL;
+constexpr uint64_t NPINV = 0x417fffffffffffffULL;
+constexpr uint64_t ONE = 0x3b7ffffffffffffdULL;
+constexpr uint64_t R2 = 0x32734c36b7b1d512ULL;
+
+inline uint64_t mul(uint64_t a, uint64_t b) {
+    u128 t = (u128)a * b;
+    uint64_t m = (uint64_t)t * NPINV;
+    uint64_t r = (uint64_t)((t + (u128)m * P) >> 64);
+    return r >= P ? r - P : r;
+}
+inline uint64_t add(uint64_t a, uint64_t b) { uint64_t s = a + b; return s >= P ? s - P : s; }
+inline uint64_t sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (P - b); }
+inline uint64_t from_u64(uint64_t x) { return mul(x % P, R2); }
+inline uint64_t to_u64(uint64_t a) { return mul(a, 1); }
+inline uint64_t pow(uint64_t b, uint64_t e) {
+    uint64_t r = ONE;
+    while (e) { if (e & 1) r = mul(r, b); b = mul(b, b); e >>= 1; }
+    return r;
+}
+inline uint64_t inv(uint64_t a) { return pow(a, P - 2); }
+// multiplicative generator 3 and the 2^55-th root of unity 3^131 (engine conventions [UPSTREAM-RECALL])
+inline uint64_t generator() { return from_u64(3); }
+inline uint64_t root_of_unity(unsigned log_n) {
+    uint64_t g = pow(from_u64(3), 131);
+    for (unsigned i = log_n; i < 55; i++) g = mul(g, g);
+    return g;
+}
+
+} // namespace host
+} // namespace cs

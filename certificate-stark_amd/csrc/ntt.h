@@ -1,0 +1,29 @@
+// Host-visible declarations for the NTT kernels (ntt.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cs {
+
+constexpr unsigned NTT_MIN_LOG_N = 6, NTT_MAX_LOG_N = 24;
+
+// One batched transform: `batch` x `width` independent length-2^log_n sequences, column stride n.
+struct NttArgs {
+    const uint64_t *in;    // natural order
+    uint64_t *scratch;     // same shape as one batch of `in` times batch; may alias `in` (destroys it)
+    uint64_t *out;         // natural order; must not alias scratch
+    unsigned width, batch, log_n;
+    const uint64_t *w;         // [n] powers of the root of unity to use (forward or inverse table)
+    const uint64_t *prescale;  // optional [n] per batch: input element m is multiplied by prescale[m] (coset shift^m)
+    size_t prescale_batch_stride;
+    uint64_t post_scale;       // applied to every output when do_scale (n^-1 for the inverse transform)
+    bool do_scale;
+    size_t in_batch_stride, scratch_batch_stride, out_batch_stride; // in elements
+};
+
+hipError_t ntt_columns(const NttArgs &a, hipStream_t stream);
+// table[e] = base^e, e < n
+hipError_t ntt_power_table(uint64_t *d_table, size_t n, uint64_t base, hipStream_t stream);
+
+} // namespace cs

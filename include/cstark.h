@@ -107,14 +107,19 @@ int cstark_tx_witness_upload(cstark_ctx *ctx, const cstark_tx_witness *w);
 int cstark_tx_build_trace(cstark_ctx *ctx, uint64_t *d_trace);
 
 /* ---- K2/K3: low-degree extension (engine: trace.extend) ------------------------------------- */
-/* d_cols: width x n evaluations over the trace domain (natural order), overwritten with the
- * polynomial coefficients (natural order). */
-int cstark_interpolate_columns(cstark_ctx *ctx, uint64_t *d_cols, uint32_t width, uint32_t log_n);
-/* d_coeffs: width x n coefficients.  d_lde: blowup cosets, coset-major:
- *   d_lde[(k * width + c) * n + j] = f_c(g * w_{bn}^k * w_n^j),  g = field generator,
- * i.e. natural LDE-domain index i = b*j + k.  cosets [k0, k0+nk) are produced (multi-GPU sharding). */
-int cstark_lde_columns(cstark_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width,
-                       uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* Field conventions of the engine [UPSTREAM-RECALL]: multiplicative generator (domain offset) and
+ * the primitive 2^log_n-th root of unity, in memory form. */
+uint64_t cstark_field_generator(void);
+uint64_t cstark_field_root_of_unity(uint32_t log_n);
+/* d_evals: width x n evaluations over the trace domain <w_n> (natural order); it is used as scratch
+ * and destroyed.  d_coeffs (distinct buffer): width x n polynomial coefficients, natural order. */
+int cstark_interpolate_columns(cstark_ctx *ctx, uint64_t *d_evals, uint64_t *d_coeffs, uint32_t width, uint32_t log_n);
+/* d_coeffs: width x n coefficients.  d_lde: cosets [k0, k0+nk) of the blowup-times larger domain,
+ * coset-major:  d_lde[((k - k0) * width + c) * n + j] = f_c(offset * w_{bn}^k * w_n^j),
+ * i.e. natural LDE-domain index i = b*j + k.  offset = cstark_field_generator() for the STARK domain.
+ * Sharding by coset is what distributes one proof over several GPUs. */
+int cstark_lde_columns(cstark_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t log_n,
+                       uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);
 
 /* ---- K4/K5: Blake3 row hashing + Merkle tree (engine: build_commitment) ---------------------- */
 /* Hash row j of coset k (width elements, 8 bytes LE each, memory form) into leaf i = b*j + k:
