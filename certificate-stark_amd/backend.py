@@ -107,3 +107,22 @@ class Backend:
                                           C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint64(off),
                                           C.c_uint32(k0), C.c_uint32(nk)))
         return out
+
+    # ---- K4 / K5 ----
+    def empty_u8(self, *shape):
+        return torch.empty(shape, dtype=torch.uint8, device=self.device)
+
+    def hash_rows(self, lde, log_blowup, k0=0, leaves=None):
+        """lde: [nk, width, n]. leaves: uint8 [(n << log_blowup), 32]; rows of cosets [k0, k0+nk) are written."""
+        nk, width, n = lde.shape
+        if leaves is None:
+            leaves = torch.zeros((n << log_blowup, 32), dtype=torch.uint8, device=self.device)
+        check(self.lib.cstark_hash_rows(self.ctx, self._ptr(lde), self._ptr(leaves, u8p), C.c_uint32(width),
+                                        C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
+        return leaves
+
+    def merkle_build(self, nodes):
+        """nodes: uint8 [2 L, 32] with the leaves in the upper half; filled in place, nodes[1] is the root."""
+        L2 = nodes.shape[0]
+        check(self.lib.cstark_merkle_build(self.ctx, self._ptr(nodes, u8p), C.c_uint32((L2 // 2).bit_length() - 1)))
+        return nodes

@@ -1,0 +1,13 @@
+// Host-visible declarations for the Blake3 commitment kernels (blake3.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cs {
+// leaf i = b*j + k of row j of coset k: d_leaves[32 i ..]; d_lde holds cosets [k0, k0+nk) coset-major
+hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, unsigned log_n, unsigned log_b, unsigned k0, unsigned nk,
+                     hipStream_t stream);
+// d_nodes: 2 * 2^log_leaves digests, leaves in the upper half; fills nodes[1 .. 2^log_leaves)
+hipError_t merkle_build(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream);
+} // namespace cs

@@ -1,0 +1,126 @@
+// K4/K5 -- Blake3-256 row hashing and Merkle tree for the trace commitment.
+//
+// Engine stage behind `prover.prove(trace)` (/root/reference/src/lib.rs:140); the hash function is the one
+// the reference selects (HashFunction::Blake3_256, src/lib.rs:82).  BLAKE3 is implemented from its public
+// specification.  A row of W <= 128 field elements is a single chunk (W*8 <= 1024 bytes): ceil(W/8)
+// chained compressions.  One lane hashes one row; with the coset-major column layout the 64 lanes of a wave
+// read 64 consecutive rows of the same column, i.e. one contiguous 512-byte line per load.
+#include "blake3.h"
+#include <hip/hip_runtime.h>
+
+namespace cs {
+namespace {
+
+constexpr uint32_t IV0 = 0x6A09E667u, IV1 = 0xBB67AE85u, IV2 = 0x3C6EF372u, IV3 = 0xA54FF53Au, IV4 = 0x510E527Fu, IV5 = 0x9B05688Cu,
+                   IV6 = 0x1F83D9ABu, IV7 = 0x5BE0CD19u;
+enum : uint32_t { CHUNK_START = 1, CHUNK_END = 2, PARENT = 4, ROOT = 8 };
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int r) { return __funnelshift_r(x, x, r); } // v_alignbit_b32
+
+#define B3_G(a, b, c, d, mx, my)            \
+    a = a + b + (mx); d = rotr(d ^ a, 16);  \
+    c = c + d;        b = rotr(b ^ c, 12);  \
+    a = a + b + (my); d = rotr(d ^ a, 8);   \
+    c = c + d;        b = rotr(b ^ c, 7);
+
+// message word indices for each of the 7 rounds (the BLAKE3 permutation applied repeatedly)
+#define B3_ROUND(m, i0, i1, i2, i3, i4, i5, i6, i7, i8, i9, i10, i11, i12, i13, i14, i15) \
+    B3_G(s0, s4, s8, s12, m[i0], m[i1]) B3_G(s1, s5, s9, s13, m[i2], m[i3])               \
+    B3_G(s2, s6, s10, s14, m[i4], m[i5]) B3_G(s3, s7, s11, s15, m[i6], m[i7])             \
+    B3_G(s0, s5, s10, s15, m[i8], m[i9]) B3_G(s1, s6, s11, s12, m[i10], m[i11])           \
+    B3_G(s2, s7, s8, s13, m[i12], m[i13]) B3_G(s3, s4, s9, s14, m[i14], m[i15])
+
+// cv <- first 8 words of compress(cv, m, counter = 0, block_len, flags)
+__device__ __forceinline__ void compress(uint32_t (&cv)[8], const uint32_t (&m)[16], uint32_t block_len, uint32_t flags) {
+    uint32_t s0 = cv[0], s1 = cv[1], s2 = cv[2], s3 = cv[3], s4 = cv[4], s5 = cv[5], s6 = cv[6], s7 = cv[7];
+    uint32_t s8 = IV0, s9 = IV1, s10 = IV2, s11 = IV3, s12 = 0, s13 = 0, s14 = block_len, s15 = flags;
+    B3_ROUND(m, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    B3_ROUND(m, 2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8)
+    B3_ROUND(m, 3, 4, 10, 12, 13, 2, 7, 14, 6, 5, 9, 0, 11, 15, 8, 1)
+    B3_ROUND(m, 10, 7, 12, 9, 14, 3, 13, 15, 4, 0, 11, 2, 5, 8, 1, 6)
+    B3_ROUND(m, 12, 13, 9, 11, 15, 10, 14, 8, 7, 2, 5, 3, 0, 1, 6, 4)
+    B3_ROUND(m, 9, 14, 11, 5, 8, 12, 15, 1, 13, 3, 0, 10, 2, 6, 4, 7)
+    B3_ROUND(m, 11, 15, 5, 0, 1, 9, 8, 6, 14, 10, 2, 12, 3, 4, 7, 13)
+    cv[0] = s0 ^ s8; cv[1] = s1 ^ s9; cv[2] = s2 ^ s10; cv[3] = s3 ^ s11;
+    cv[4] = s4 ^ s12; cv[5] = s5 ^ s13; cv[6] = s6 ^ s14; cv[7] = s7 ^ s15;
+}
+
+// grid = (ceil(n / 256), nk); one lane per row j of coset k0 + blockIdx.y
+__global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ lde, uint8_t *__restrict__ leaves, unsigned width, unsigned log_n,
+                                                   unsigned log_b, unsigned k0) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (j >= n) return;
+    const unsigned kk = blockIdx.y;
+    const uint64_t *col = lde + (size_t)kk * width * n + j;
+    uint32_t cv[8] = {IV0, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+    const unsigned nblocks = (width + 7) / 8;
+    for (unsigned b = 0; b < nblocks; b++) {
+        uint32_t m[16];
+        const unsigned c0 = b * 8;
+        const unsigned cnt = width - c0 < 8 ? width - c0 : 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t v = (unsigned)i < cnt ? col[(size_t)(c0 + i) * n] : 0;
+            m[2 * i] = (uint32_t)v;
+            m[2 * i + 1] = (uint32_t)(v >> 32);
+        }
+        const uint32_t flags = (b == 0 ? CHUNK_START : 0u) | (b + 1 == nblocks ? (CHUNK_END | ROOT) : 0u);
+        compress(cv, m, cnt * 8, flags);
+    }
+    const size_t leaf = (j << log_b) + k0 + kk;
+    uint4 *dst = reinterpret_cast<uint4 *>(leaves + 32 * leaf);
+    dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+__device__ __forceinline__ void merge_node(const uint8_t *__restrict__ children, uint8_t *__restrict__ parent) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(children);
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+    const uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    uint32_t cv[8] = {IV0, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+    compress(cv, m, 64, CHUNK_START | CHUNK_END | ROOT); // Blake3 hash of a 64-byte message
+    uint4 *dst = reinterpret_cast<uint4 *>(parent);
+    dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+// one tree level: parents [cnt, 2 cnt) from children [2 cnt, 4 cnt)
+__global__ __launch_bounds__(256) void k_merkle_level(uint8_t *__restrict__ nodes, size_t cnt) {
+    const size_t t = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (t >= cnt) return;
+    const size_t i = cnt + t;
+    merge_node(nodes + 64 * i, nodes + 32 * i);
+}
+// the last levels (<= 1024 parents) in one workgroup
+__global__ __launch_bounds__(1024) void k_merkle_top(uint8_t *__restrict__ nodes, size_t cnt) {
+    for (; cnt >= 1; cnt >>= 1) {
+        if (threadIdx.x < cnt) {
+            const size_t i = cnt + threadIdx.x;
+            merge_node(nodes + 64 * i, nodes + 32 * i);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) reinterpret_cast<uint4 *>(nodes)[threadIdx.x] = make_uint4(0, 0, 0, 0); // nodes[0] unused
+}
+
+} // namespace
+
+hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, unsigned log_n, unsigned log_b, unsigned k0, unsigned nk,
+                     hipStream_t stream) {
+    if (width == 0 || width > 128) return hipErrorInvalidValue; // single-chunk rows only
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + 255) / 256), nk), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b, k0);
+    return hipGetLastError();
+}
+
+hipError_t merkle_build(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream) {
+    size_t cnt = ((size_t)1 << log_leaves) >> 1;
+    for (; cnt > 1024; cnt >>= 1)
+        hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d_nodes, cnt);
+    if (cnt >= 1) hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(1024), 0, stream, d_nodes, cnt);
+    return hipGetLastError();
+}
+
+} // namespace cs

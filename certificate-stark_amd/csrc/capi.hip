@@ -9,6 +9,7 @@
 #include <deque>
 #include "trace_gen.h"
 #include "ntt.h"
+#include "blake3.h"
 #include "hostfield.h"
 
 namespace {
@@ -252,6 +253,27 @@ int cstark_lde_columns(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde,
         a.w = p->w; a.prescale = t->s + (size_t)k * n; a.do_scale = false;
         HIP_TRY(cs::ntt_columns(a, c->stream));
     }
+    return CSTARK_OK;
+}
+
+// ---- K4 / K5 ---------------------------------------------------------------------------------------
+int cstark_hash_rows(cstark_ctx *c, const uint64_t *d_lde, uint8_t *d_leaves, uint32_t width, uint32_t log_n, uint32_t log_blowup,
+                     uint32_t k0, uint32_t nk) {
+    if (!c || !d_lde || !d_leaves) return fail(CSTARK_ERR_INVALID_ARG, "cstark_hash_rows: null argument");
+    if (width == 0 || width > 128) return fail(CSTARK_ERR_UNSUPPORTED, "row width must be 1..128 elements (single Blake3 chunk)");
+    if (log_n > 30 || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
+    if (((uintptr_t)d_leaves & 15) != 0) return fail(CSTARK_ERR_INVALID_ARG, "d_leaves must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::hash_rows(d_lde, d_leaves, width, log_n, log_blowup, k0, nk, c->stream));
+    return CSTARK_OK;
+}
+
+int cstark_merkle_build(cstark_ctx *c, uint8_t *d_nodes, uint32_t log_leaves) {
+    if (!c || !d_nodes) return fail(CSTARK_ERR_INVALID_ARG, "cstark_merkle_build: null argument");
+    if (log_leaves == 0 || log_leaves > 30) return fail(CSTARK_ERR_INVALID_ARG, "tree must have 2 .. 2^30 leaves");
+    if (((uintptr_t)d_nodes & 15) != 0) return fail(CSTARK_ERR_INVALID_ARG, "d_nodes must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::merkle_build(d_nodes, log_leaves, c->stream));
     return CSTARK_OK;
 }
 
