@@ -126,3 +126,21 @@ class Backend:
         L2 = nodes.shape[0]
         check(self.lib.cstark_merkle_build(self.ctx, self._ptr(nodes, u8p), C.c_uint32((L2 // 2).bit_length() - 1)))
         return nodes
+
+    # ---- K6 / K7 ----
+    def evaluate_transitions(self, lde, depth, log_blowup=3, k0=0):
+        nk, width, n = lde.shape
+        out = self.empty_u64(nk, _lib.TX_NUM_CONSTRAINTS, n)
+        check(self.lib.cstark_tx_evaluate_transitions(self.ctx, self._ptr(lde), self._ptr(out), C.c_uint32(depth),
+                                                      C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
+        return out
+
+    def evaluate_constraints(self, lde, coeffs, pub_inputs, depth, log_blowup=3, k0=0, out=None):
+        """coeffs: _lib.TxCoeffsStruct (or any ctypes struct of the same layout); pub_inputs: 4 uint64."""
+        nk, width, n = lde.shape
+        if out is None:
+            out = self.empty_u64(nk, n)
+        pub = (C.c_uint64 * 4)(*[int(v) for v in pub_inputs])
+        check(self.lib.cstark_tx_evaluate_constraints(self.ctx, self._ptr(lde), C.byref(coeffs), pub, self._ptr(out), C.c_uint32(depth),
+                                                      C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
+        return out

@@ -1,0 +1,61 @@
+// Host-side description of the composite TransactionAir that the engine would obtain through the Air trait:
+// periodic (mask) columns, constraint degrees and degree adjustments.  Restates
+//   periodic_columns()          /root/reference/src/air.rs:194-380
+//     merkle masks              src/merkle/update/air.rs:182-212
+//     schnorr masks             src/schnorr/air.rs:335-391
+//     round constants           src/utils/rescue.rs:306-320
+//   TransactionAir::new degrees src/air.rs:76-108
+// It runs once per (depth, trace length); the resulting table is kernel input (K7).
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "constants_gen.h"
+#include "constraints.h"
+#include "hostfield.h"
+
+namespace cs {
+namespace host {
+
+constexpr int TX_NUM_PERIODIC = 48, TX_CYCLE = 1024;
+
+// 48 columns x 1024 rows, column-major.  The length-8 columns of the reference (HASH_INPUT mask and the 28
+// round-constant columns) are written out over the full 1024-row cycle: same periodic polynomial.
+inline bool tx_periodic_columns(unsigned depth, std::vector<uint64_t> &out) {
+    const unsigned hash_len = 8 * depth + 7; // TRANSACTION_HASH_LENGTH, src/merkle/constants.rs:27
+    if (depth == 0 || hash_len > 511) return false;
+    out.assign((size_t)TX_NUM_PERIODIC * TX_CYCLE, 0);
+    auto col = [&](int c) { return out.data() + (size_t)c * TX_CYCLE; };
+    const unsigned S = 512; // Schnorr half starts here (MERKLE_UPDATE_LENGTH)
+    col(0)[0] = ONE;                                                     // SETUP
+    for (unsigned i = 0; i < hash_len; i++) {
+        col(1)[i] = ONE;                                                 // MERKLE (hashing in progress)
+        col(4)[i] = (i % 8) != 7 ? ONE : 0;                              // HASH (round steps)
+    }
+    col(3)[hash_len - 1] = ONE;                                          // FINISH
+    for (unsigned i = 0; i < TX_CYCLE; i++) col(2)[i] = (i % 8) == 7 ? ONE : 0; // HASH_INPUT (period 8)
+    for (unsigned i = 0; i < 511; i++) col(5)[S + i] = ONE;              // SCHNORR global mask (SCALAR_MUL_LENGTH + 1)
+    for (unsigned i = 0; i < 510; i++) {
+        col(6)[S + i] = ONE;                                             // SCALAR_MULT
+        col(7)[S + i] = (i % 2 == 0) ? ONE : 0;                          // DOUBLING
+    }
+    const unsigned lo[4] = {0, 126, 254, 382}, hi[4] = {126, 254, 382, 510};
+    for (int k = 0; k < 4; k++)
+        for (unsigned i = lo[k]; i < hi[k]; i++) col(8 + k)[S + i] = ONE; // h-limb selectors
+    for (unsigned i = 0; i < 40; i++) col(12)[S + i] = (i % 8) != 7 ? ONE : 0; // SCHNORR_HASH
+    for (int k = 0; k < 4; k++) col(13 + k)[S + 8 * (k + 1) - 1] = ONE;  // message-chunk insertion steps
+    for (unsigned i = 0; i < 64; i++) col(17)[S + i] = ONE;              // RANGE_STEP
+    col(18)[S + 63] = ONE;                                               // RANGE_FINISH
+    for (unsigned i = 1; i < S + 64; i++) col(19)[i] = ONE;              // VALUE_COPY
+    for (int j = 0; j < 28; j++)
+        for (unsigned i = 0; i < TX_CYCLE; i++) col(20 + j)[i] = CS_ARK_MONT[(i % 8) * 28 + j];
+    return true;
+}
+
+// evaluation degree of degree group g for trace length n (TransitionConstraintDegree [UPSTREAM-RECALL])
+inline uint64_t tx_group_eval_degree(int g, uint64_t n) { return TX_GROUP_BASE[g] * (n - 1) + TX_GROUP_CYCLES[g] * (n / TX_CYCLE) * (TX_CYCLE - 1); }
+// adjustment so that every merged constraint reaches degree (ce_size - 1) + (n - 1) before division
+inline uint64_t tx_group_adjustment(int g, uint64_t n, uint64_t ce_size) { return (ce_size - 1 + n - 1) - tx_group_eval_degree(g, n); }
+inline uint64_t tx_boundary_adjustment(uint64_t n, uint64_t ce_size) { return ce_size - n + 1; }
+
+} // namespace host
+} // namespace cs

@@ -1,16 +1,19 @@
-// C ABI of the backend (include/cstark.h): context management, witness upload and the stage entry
-// points.  No torch types, no CPU fallback: without a HIP device every compute entry point returns
-// CSTARK_ERR_NO_DEVICE.
+// C ABI of the backend (include/cstark.h): context management, cached tables, witness upload and the stage
+// entry points.  No torch types, no CPU fallback: without a HIP device every compute entry point returns
+// CSTARK_ERR_NO_DEVICE (context creation fails).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
-#include <new>
-#include "../../include/cstark.h"
 #include <deque>
-#include "trace_gen.h"
-#include "ntt.h"
+#include <new>
+#include <vector>
+#include "../../include/cstark.h"
+#include "air_tx_host.h"
 #include "blake3.h"
+#include "constraints.h"
 #include "hostfield.h"
+#include "ntt.h"
+#include "trace_gen.h"
 
 namespace {
 
@@ -20,13 +23,16 @@ int fail(int code, const char *fmt, const char *detail = "") {
     snprintf(g_err, sizeof g_err, fmt, detail);
     return code;
 }
-#define HIP_TRY(expr)                                                                   \
-    do {                                                                                \
-        hipError_t e_ = (expr);                                                         \
+#define HIP_TRY(expr)                                                                                                              \
+    do {                                                                                                                           \
+        hipError_t e_ = (expr);                                                                                                    \
         if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? CSTARK_ERR_OOM : CSTARK_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
-
-} // namespace
+#define RC_TRY(expr)            \
+    do {                        \
+        int rc_ = (expr);       \
+        if (rc_) return rc_;    \
+    } while (0)
 
 struct NttPlan {
     unsigned log_n;
@@ -38,6 +44,13 @@ struct CosetTable {
     uint64_t offset;
     uint64_t *s; // [b][n]: (offset * w_{bn}^k)^m
 };
+struct PeriodicTable {
+    unsigned depth, log_n, log_b;
+    uint64_t *tab;   // [b][48][1024]
+    uint64_t *coset; // [b][CE_COSET_CONSTS]
+};
+
+} // namespace
 
 struct cstark_ctx {
     int device = 0;
@@ -46,9 +59,11 @@ struct cstark_ctx {
     void *wit_buf = nullptr;
     size_t wit_bytes = 0;
     cs::TxWitnessDev wit{};
-    // cached tables and workspace
-    std::deque<NttPlan> plans;   // deque: references stay valid as entries are added
+    // cached tables (deque: references stay valid as entries are added) and workspace
+    std::deque<NttPlan> plans;
     std::deque<CosetTable> cosets;
+    std::deque<PeriodicTable> periodic;
+    uint64_t *coef_buf = nullptr; // device copy of the composition coefficients
     void *ws = nullptr;
     size_t ws_bytes = 0;
 };
@@ -96,6 +111,106 @@ int ensure_ws(cstark_ctx *c, size_t bytes) {
     return CSTARK_OK;
 }
 
+int interpolate_impl(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint32_t width, uint32_t log_n) {
+    if (!c || !d_evals || !d_coeffs || width == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_interpolate_columns: bad argument");
+    if (d_evals == d_coeffs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_interpolate_columns: output must not alias input");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "domain size must be 2^6 .. 2^24");
+    HIP_TRY(hipSetDevice(c->device));
+    const NttPlan *p;
+    RC_TRY(get_plan(c, log_n, &p));
+    cs::NttArgs a{};
+    a.in = d_evals; a.scratch = d_evals; a.out = d_coeffs;
+    a.width = width; a.batch = 1; a.log_n = log_n;
+    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true;
+    HIP_TRY(cs::ntt_columns(a, c->stream));
+    return CSTARK_OK;
+}
+
+int lde_impl(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t log_n, uint32_t log_blowup,
+             uint64_t domain_offset, uint32_t k0, uint32_t nk) {
+    if (!c || !d_coeffs || !d_lde || width == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_lde_columns: bad argument");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6) return fail(CSTARK_ERR_UNSUPPORTED, "unsupported domain size");
+    if (domain_offset == 0 || domain_offset >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "domain offset must be a nonzero field element");
+    if ((uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "coset range exceeds the blowup factor");
+    HIP_TRY(hipSetDevice(c->device));
+    const NttPlan *p;
+    const CosetTable *t;
+    RC_TRY(get_plan(c, log_n, &p));
+    RC_TRY(get_coset_table(c, log_n, log_blowup, domain_offset, &t));
+    const size_t n = (size_t)1 << log_n;
+    RC_TRY(ensure_ws(c, (size_t)width * n * 8));
+    for (uint32_t k = k0; k < k0 + nk; k++) {
+        cs::NttArgs a{};
+        a.in = d_coeffs; a.scratch = (uint64_t *)c->ws; a.out = d_lde + (size_t)(k - k0) * width * n;
+        a.width = width; a.batch = 1; a.log_n = log_n;
+        a.w = p->w; a.prescale = t->s + (size_t)k * n; a.do_scale = false;
+        HIP_TRY(cs::ntt_columns(a, c->stream));
+    }
+    return CSTARK_OK;
+}
+
+// K7: periodic values of the 48 mask / round-constant columns over the constraint-evaluation domain, plus the
+// per-coset scalars of the driver.  Built once per (depth, trace length, blowup) and cached.
+int get_periodic(cstark_ctx *c, unsigned depth, unsigned log_n, unsigned log_b, const PeriodicTable **out) {
+    for (const PeriodicTable &t : c->periodic)
+        if (t.depth == depth && t.log_n == log_n && t.log_b == log_b) { *out = &t; return CSTARK_OK; }
+    if (log_n < 10) return fail(CSTARK_ERR_INVALID_ARG, "the trace must hold at least one 1024-row transaction");
+    std::vector<uint64_t> cols;
+    if (!cs::host::tx_periodic_columns(depth, cols)) return fail(CSTARK_ERR_INVALID_ARG, "unsupported Merkle depth");
+    const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b, C = cs::host::TX_CYCLE, NP = cs::host::TX_NUM_PERIODIC;
+    PeriodicTable t{depth, log_n, log_b, nullptr, nullptr};
+    uint64_t *d_cols = nullptr, *d_poly = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_cols, NP * C * 8));
+    HIP_TRY(hipMalloc((void **)&d_poly, NP * C * 8));
+    HIP_TRY(hipMalloc((void **)&t.tab, b * NP * C * 8));
+    HIP_TRY(hipMalloc((void **)&t.coset, b * cs::CE_COSET_CONSTS * 8));
+    HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), NP * C * 8, hipMemcpyHostToDevice, c->stream));
+    RC_TRY(interpolate_impl(c, d_cols, d_poly, (uint32_t)NP, 10));
+    // a column of period 1024 is a polynomial in x^(n/1024): evaluate it over offset' * <w_{b*1024}>, offset' = g^(n/1024)
+    const uint64_t g = cs::host::generator();
+    RC_TRY(lde_impl(c, d_poly, t.tab, (uint32_t)NP, 10, log_b, cs::host::pow(g, n / C), 0, (uint32_t)b));
+    // per-coset scalars: shift_k = g w_{bn}^k, 1/(shift^n - 1), shift^adj_g, shift^badj
+    std::vector<uint64_t> cc(b * cs::CE_COSET_CONSTS);
+    const uint64_t wbn = cs::host::root_of_unity(log_n + log_b);
+    uint64_t shift = g;
+    for (size_t k = 0; k < b; k++) {
+        uint64_t *o = cc.data() + k * cs::CE_COSET_CONSTS;
+        o[0] = shift;
+        o[1] = cs::host::inv(cs::host::sub(cs::host::pow(shift, n), cs::host::ONE));
+        for (int gi = 0; gi < 5; gi++) o[2 + gi] = cs::host::pow(shift, cs::host::tx_group_adjustment(gi, n, n * b));
+        o[7] = cs::host::pow(shift, cs::host::tx_boundary_adjustment(n, n * b));
+        shift = cs::host::mul(shift, wbn);
+    }
+    HIP_TRY(hipMemcpyAsync(t.coset, cc.data(), cc.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream)); // cc / cols go out of scope
+    HIP_TRY(hipFree(d_cols));
+    HIP_TRY(hipFree(d_poly));
+    c->periodic.push_back(t);
+    *out = &c->periodic.back();
+    return CSTARK_OK;
+}
+
+int ce_params(cstark_ctx *c, const uint64_t *d_lde, uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0,
+              uint32_t nk, cs::CeParams *p) {
+    if (!c || !d_lde || !d_out) return fail(CSTARK_ERR_INVALID_ARG, "constraint evaluation: null argument");
+    if (log_n < 10 || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_INVALID_ARG, "trace length must be 2^10 .. 2^24");
+    if (log_blowup != 3) return fail(CSTARK_ERR_UNSUPPORTED, "TransactionAir needs a constraint-evaluation blowup of 8 (max degree 7, src/air.rs:76-108)");
+    if ((uint64_t)k0 + nk > (1ull << log_blowup) || nk == 0) return fail(CSTARK_ERR_INVALID_ARG, "coset range exceeds the blowup factor");
+    HIP_TRY(hipSetDevice(c->device));
+    const PeriodicTable *pt;
+    const NttPlan *plan;
+    RC_TRY(get_periodic(c, merkle_depth, log_n, log_blowup, &pt));
+    RC_TRY(get_plan(c, log_n, &plan));
+    const uint64_t n = 1ull << log_n, ce = n << log_blowup;
+    *p = cs::CeParams{};
+    p->lde = d_lde; p->ptab = pt->tab; p->w = plan->w; p->coset = pt->coset; p->out = d_out;
+    p->w_last = cs::host::inv(cs::host::root_of_unity(log_n));
+    for (int g = 0; g < 5; g++) p->adj_mod_n[g] = (uint32_t)(cs::host::tx_group_adjustment(g, n, ce) & (n - 1));
+    p->badj_mod_n = (uint32_t)(cs::host::tx_boundary_adjustment(n, ce) & (n - 1));
+    p->log_n = log_n; p->log_b = log_blowup; p->k0 = k0;
+    return CSTARK_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -125,8 +240,10 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->wit_buf) (void)hipFree(c->wit_buf);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->coef_buf) (void)hipFree(c->coef_buf);
     for (NttPlan &p : c->plans) { (void)hipFree(p.w); (void)hipFree(p.winv); }
     for (CosetTable &t : c->cosets) (void)hipFree(t.s);
+    for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); }
     delete c;
 }
 
@@ -217,43 +334,11 @@ uint64_t cstark_field_generator(void) { return cs::host::generator(); }
 uint64_t cstark_field_root_of_unity(uint32_t log_n) { return log_n <= 55 ? cs::host::root_of_unity(log_n) : 0; }
 
 int cstark_interpolate_columns(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint32_t width, uint32_t log_n) {
-    if (!c || !d_evals || !d_coeffs || width == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_interpolate_columns: bad argument");
-    if (d_evals == d_coeffs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_interpolate_columns: output must not alias input");
-    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "domain size must be 2^6 .. 2^24");
-    HIP_TRY(hipSetDevice(c->device));
-    const NttPlan *p;
-    int rc = get_plan(c, log_n, &p);
-    if (rc) return rc;
-    cs::NttArgs a{};
-    a.in = d_evals; a.scratch = d_evals; a.out = d_coeffs;
-    a.width = width; a.batch = 1; a.log_n = log_n;
-    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true;
-    HIP_TRY(cs::ntt_columns(a, c->stream));
-    return CSTARK_OK;
+    return interpolate_impl(c, d_evals, d_coeffs, width, log_n);
 }
-
 int cstark_lde_columns(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t log_n, uint32_t log_blowup,
                        uint64_t domain_offset, uint32_t k0, uint32_t nk) {
-    if (!c || !d_coeffs || !d_lde || width == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_lde_columns: bad argument");
-    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6) return fail(CSTARK_ERR_UNSUPPORTED, "unsupported domain size");
-    if (domain_offset == 0 || domain_offset >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "domain offset must be a nonzero field element");
-    if ((uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "coset range exceeds the blowup factor");
-    HIP_TRY(hipSetDevice(c->device));
-    const NttPlan *p;
-    const CosetTable *t;
-    int rc = get_plan(c, log_n, &p);
-    if (rc) return rc;
-    if ((rc = get_coset_table(c, log_n, log_blowup, domain_offset, &t))) return rc;
-    const size_t n = (size_t)1 << log_n;
-    if ((rc = ensure_ws(c, (size_t)width * n * 8))) return rc;
-    for (uint32_t k = k0; k < k0 + nk; k++) {
-        cs::NttArgs a{};
-        a.in = d_coeffs; a.scratch = (uint64_t *)c->ws; a.out = d_lde + (size_t)(k - k0) * width * n;
-        a.width = width; a.batch = 1; a.log_n = log_n;
-        a.w = p->w; a.prescale = t->s + (size_t)k * n; a.do_scale = false;
-        HIP_TRY(cs::ntt_columns(a, c->stream));
-    }
-    return CSTARK_OK;
+    return lde_impl(c, d_coeffs, d_lde, width, log_n, log_blowup, domain_offset, k0, nk);
 }
 
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
@@ -274,6 +359,45 @@ int cstark_merkle_build(cstark_ctx *c, uint8_t *d_nodes, uint32_t log_leaves) {
     if (((uintptr_t)d_nodes & 15) != 0) return fail(CSTARK_ERR_INVALID_ARG, "d_nodes must be 16-byte aligned");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(cs::merkle_build(d_nodes, log_leaves, c->stream));
+    return CSTARK_OK;
+}
+
+// ---- K6 / K7 ---------------------------------------------------------------------------------------
+int cstark_tx_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n,
+                                   uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    cs::CeParams p;
+    RC_TRY(ce_params(c, d_lde, d_out, merkle_depth, log_n, log_blowup, k0, nk, &p));
+    HIP_TRY(cs::launch_eval_transitions(p, nk, c->stream));
+    return CSTARK_OK;
+}
+
+int cstark_tx_evaluate_constraints(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, const uint64_t pub_inputs[4],
+                                   uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!coeffs || !pub_inputs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null argument");
+    cs::CeParams p;
+    RC_TRY(ce_params(c, d_lde, d_out, merkle_depth, log_n, log_blowup, k0, nk, &p));
+    if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, sizeof(cstark_tx_coeffs)));
+    static_assert(sizeof(cstark_tx_coeffs) == (115 * 2 + 8) * 8, "coefficient block layout");
+    HIP_TRY(hipMemcpyAsync(c->coef_buf, coeffs, sizeof(cstark_tx_coeffs), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream)); // the caller's struct may be transient
+    p.coef = c->coef_buf;
+    for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
+    HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream));
+    return CSTARK_OK;
+}
+
+// host-side view of the AIR description, for the CPU tests
+int cstark_tx_constraint_degree(uint32_t i, uint32_t *base, uint32_t *cycles) {
+    if (i >= CSTARK_TX_NUM_CONSTRAINTS || !base || !cycles) return fail(CSTARK_ERR_INVALID_ARG, "constraint index out of range");
+    const int g = cs::tx_degree_group((int)i);
+    *base = cs::TX_GROUP_BASE[g];
+    *cycles = cs::TX_GROUP_CYCLES[g];
+    return CSTARK_OK;
+}
+int cstark_tx_periodic_columns(uint32_t merkle_depth, uint64_t *out /* [48][1024] host */) {
+    std::vector<uint64_t> cols;
+    if (!out || !cs::host::tx_periodic_columns(merkle_depth, cols)) return fail(CSTARK_ERR_INVALID_ARG, "unsupported Merkle depth");
+    memcpy(out, cols.data(), cols.size() * 8);
     return CSTARK_OK;
 }
 

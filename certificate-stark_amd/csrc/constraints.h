@@ -1,0 +1,37 @@
+// Host-visible declarations for the constraint-evaluation kernels (constraints.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cs {
+
+// Degree group of transition constraint i of TransactionAir (src/air.rs:76-108): constraints are merged per
+// evaluation degree; the AIR has exactly five (base degree; number of 1024-cycles) classes.
+//   0: (5;2)  1: (4;2)  2: (3;1)  3: (2;1)  4: (1;1)
+__host__ __device__ constexpr int tx_degree_group(int i) {
+    return (i < 6 || (i >= 19 && i < 37)) ? 0 : (i >= 6 && i < 18) ? 1 : (i == 18 || (i >= 37 && i < 58)) ? 2 : (i == 92) ? 3 : 4;
+}
+constexpr unsigned TX_GROUP_BASE[5] = {5, 4, 3, 2, 1};
+constexpr unsigned TX_GROUP_CYCLES[5] = {2, 2, 1, 1, 1};
+
+constexpr int CE_COSET_CONSTS = 8; // per coset: shift, 1/(shift^n - 1), shift^adj[0..5), shift^badj
+
+struct CeParams {
+    const uint64_t *lde;   // cosets [k0, k0+nk), coset-major [kk][94][n]
+    const uint64_t *ptab;  // periodic table [b][48][1024]
+    const uint64_t *w;     // [n] powers of w_n
+    const uint64_t *coset; // [b][CE_COSET_CONSTS]
+    const uint64_t *coef;  // alpha[115] | beta[115] | b_alpha[4] | b_beta[4]   (device)
+    uint64_t *out;
+    uint64_t pub[4];       // initial_root[0..2], final_root[0..2]
+    uint64_t w_last;       // w_n^(n-1)
+    uint32_t adj_mod_n[5]; // degree adjustments reduced mod n (x^adj = shift^adj * w^(j*adj mod n))
+    uint32_t badj_mod_n;
+    uint32_t log_n, log_b, k0;
+};
+
+hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream);
+
+} // namespace cs

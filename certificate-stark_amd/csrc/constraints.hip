@@ -1,0 +1,401 @@
+// K6 -- constraint evaluation for the state-transition AIR over the LDE / constraint-evaluation domain.
+//
+// Per point x = g * w_{bn}^k * w_n^j this computes what the engine's ConstraintEvaluator obtains by calling
+// back into the reference:
+//   Air::evaluate_transition            /root/reference/src/air.rs:114-173
+//   evaluate_constraints                src/air.rs:383-610  (merkle::init  src/merkle/init/air.rs:159-202,
+//                                       merkle::update src/merkle/update/air.rs:215-369,
+//                                       schnorr src/schnorr/air.rs:394-531, range src/utils/field.rs:31-50)
+//   gadgets                             src/utils/rescue.rs:269-300, src/utils/ecc.rs:73-172
+// and then the driver's merge [UPSTREAM-RECALL winterfell v0.3]: sum_i (alpha_i + beta_i x^adj_i) C_i(x)
+// divided by the transition divisor, plus the four boundary terms of get_assertions (src/air.rs:175-184).
+//
+// Mapping: ONE LANE PER EVALUATION POINT.  With the coset-major column layout, lane j reads element j of a
+// column, so every load of the 94 current-row and 94 next-row registers is a contiguous 512-byte line per
+// wave and there is no cross-lane traffic at all.  The kernel is integer-VALU bound (~4.4 k modular products
+// per point), not HBM bound; see DESIGN.md.
+//
+// Exact field arithmetic lets the evaluation be reorganised without changing any value:
+//  * the Rescue round gadget is evaluated once per register window (5 windows) although the reference calls
+//    it 9 times -- merkle::init and merkle::update constrain the same registers with different flags;
+//  * result slots are never materialised in the fused kernel: each flag*value is folded straight into the
+//    random linear combination (the index aliasing of src/constants.rs:56-68 is reproduced because every
+//    contribution still uses the coefficient of the slot the reference adds it to).
+#include "constraints.h"
+#include "rescue.cuh"
+#include "tower.cuh"
+
+namespace cs {
+namespace {
+
+constexpr int NT = 128; // threads per workgroup
+
+// register / result / periodic-column indices (src/merkle/constants.rs:33-63, src/constants.rs:35-116)
+enum {
+    S_INIT = 0, S_UPD = 15, R_INIT = 29, R_UPD = 44, PREV_ROOT = 58, S_KEY = 65, R_KEY = 77, DELTA_COPY = 89, SIGMA_COPY = 90,
+    NONCE_COPY = 91, DELTA_BIT = 56, DELTA_ACC = 57, SIGMA_BIT = 92, SIGMA_ACC = 93,
+    VALUE_RES = 65, BALANCE_RES = 90, NONCE_UPD_RES = 91, INT_ROOT_RES = 92, PREV_MATCH_RES = 99, S_KEY_RES = 101, R_KEY_RES = 103,
+    DELTA_COPY_RES = 105, SIGMA_COPY_RES = 106, NONCE_COPY_RES = 107, DELTA_RANGE_RES = 108, SIGMA_RANGE_RES = 109,
+    P_SETUP = 0, P_MERKLE = 1, P_HASH_INPUT = 2, P_FINISH = 3, P_HASH = 4, P_SCHNORR = 5, P_SCALAR_MULT = 6, P_DOUBLING = 7,
+    P_DIGEST = 8, P_SCHNORR_HASH = 12, P_HASH_INTERNAL = 13, P_RANGE_STEP = 17, P_RANGE_FINISH = 18, P_VALUE_COPY = 19, P_ARK = 20
+};
+
+// one evaluation frame: strided views of the current / next LDE rows and of the periodic values
+struct Frame {
+    const fp *cur_p, *next_p, *per_p; // element c at cur_p[c * n], per_p[c * 1024]
+    size_t n;
+    __device__ __forceinline__ fp cur(int c) const { return cur_p[(size_t)c * n]; }
+    __device__ __forceinline__ fp next(int c) const { return next_p[(size_t)c * n]; }
+    __device__ __forceinline__ fp pv(int c) const { return per_p[(size_t)c * 1024]; }
+};
+
+// ---- accumulators ---------------------------------------------------------------------------------
+// Parity/debug: every result slot is kept, in global memory: out[i * n + j] += flag * value.
+struct AccAll {
+    fp *out; // points at element j of slot 0
+    size_t n;
+    __device__ __forceinline__ void add(int i, fp flag, fp val) { out[(size_t)i * n] = fp_add(out[(size_t)i * n], fp_mul(flag, val)); }
+};
+// Production: fold into sum_i alpha_i r_i and, per degree group, sum_i beta_i r_i (kept in LDS, one column per lane).
+struct AccFused {
+    fp *lds; // [6][NT]
+    const fp *alpha, *beta;
+    __device__ __forceinline__ void add(int i, fp flag, fp val) {
+        const fp t = fp_mul(flag, val);
+        const int g = 1 + tx_degree_group(i);
+        lds[threadIdx.x] = fp_add(lds[threadIdx.x], fp_mul(alpha[i], t));
+        lds[g * NT + threadIdx.x] = fp_add(lds[g * NT + threadIdx.x], fp_mul(beta[i], t));
+    }
+};
+
+__device__ __forceinline__ fp c_not(fp a) { return fp_sub(FP_ONE, a); }
+__device__ __forceinline__ fp c_is_binary(fp a) { return fp_sub(fp_sqr(a), a); }
+
+// ---- Rescue round gadget (rescue.rs:269-300) on the 14-register window starting at `reg`; the same 14
+// differences feed up to two (result base, flag) pairs.
+template <class Acc>
+__device__ __forceinline__ void enforce_round(Acc &acc, const Frame &f, int reg, int res_a, fp flag_a, int res_b, fp flag_b, bool two) {
+    fp cube[14], d[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        cube[j] = fp_cube(f.cur(reg + j));
+        d[j] = fp_sub(f.next(reg + j), f.pv(P_ARK + 14 + j));
+    }
+#pragma unroll 1
+    for (int i = 0; i < 14; i++) {
+        fp s1 = f.pv(P_ARK + i), s2 = 0;
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            s1 = fp_add(s1, fp_mul(c_mds[i * 14 + j], cube[j]));
+            s2 = fp_add(s2, fp_mul(c_inv_mds[i * 14 + j], d[j]));
+        }
+        const fp diff = fp_sub(fp_cube(s2), s1);
+        acc.add(res_a + i, flag_a, diff);
+        if (two) acc.add(res_b + i, flag_b, diff);
+    }
+}
+
+// ---- curve gadgets (ecc.rs:73-172).  F_p6 products are real calls to keep the kernel inside the
+// instruction cache: the five gadgets contain 69 of them.
+__device__ __noinline__ Fp6 mul6(const Fp6 a, const Fp6 b) { return fp6_mul(a, b); }
+
+struct Point { Fp6 x, y, z; };
+
+__device__ __forceinline__ Fp6 load6(const Frame &f, int reg, bool next) {
+    Fp6 r;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r.c[i] = next ? f.next(reg + i) : f.cur(reg + i);
+    return r;
+}
+__device__ __forceinline__ Fp6 const6(const fp *p) { return fp6_load(p); }
+
+__device__ __forceinline__ Point ec_double(const Point &p) { // complete doubling, ecc.rs:177-242
+    const Fp6 b3 = const6(c_b3);
+    Fp6 t0 = mul6(p.x, p.x), t1 = mul6(p.y, p.y), t2 = mul6(p.z, p.z);
+    Fp6 t3 = fp6_dbl(mul6(p.x, p.y));
+    Fp6 z3 = fp6_dbl(mul6(p.x, p.z));
+    Fp6 y3 = fp6_add(z3, mul6(b3, t2));
+    Fp6 x3 = fp6_sub(t1, y3);
+    y3 = fp6_add(t1, y3);
+    y3 = mul6(x3, y3);
+    x3 = mul6(t3, x3);
+    z3 = mul6(b3, z3);
+    t3 = fp6_add(fp6_sub(t0, t2), z3);
+    t0 = fp6_add(fp6_add(fp6_dbl(t0), t0), t2);
+    y3 = fp6_add(y3, mul6(t0, t3));
+    t2 = fp6_dbl(mul6(p.y, p.z));
+    x3 = fp6_sub(x3, mul6(t2, t3));
+    z3 = fp6_dbl(fp6_dbl(mul6(t2, t1)));
+    return {x3, y3, z3};
+}
+__device__ __forceinline__ Point ec_add_mixed(const Point &p, const Fp6 &qx, const Fp6 &qy) { // ecc.rs:330-404
+    const Fp6 b3 = const6(c_b3);
+    Fp6 t0 = mul6(p.x, qx), t1 = mul6(p.y, qy);
+    Fp6 t3 = fp6_sub(mul6(fp6_add(qx, qy), fp6_add(p.x, p.y)), fp6_add(t0, t1));
+    Fp6 t4 = fp6_add(mul6(qx, p.z), p.x);
+    Fp6 t5 = fp6_add(mul6(qy, p.z), p.y);
+    Fp6 z3 = fp6_add(mul6(p.z, b3), t4);
+    Fp6 x3 = fp6_sub(t1, z3);
+    z3 = fp6_add(t1, z3);
+    Fp6 y3 = mul6(x3, z3);
+    t1 = fp6_add(fp6_add(fp6_dbl(t0), t0), p.z);
+    t4 = fp6_add(mul6(t4, b3), fp6_sub(t0, p.z));
+    y3 = fp6_add(y3, mul6(t1, t4));
+    x3 = fp6_sub(mul6(t3, x3), mul6(t5, t4));
+    z3 = fp6_add(mul6(t5, z3), mul6(t3, t1));
+    return {x3, y3, z3};
+}
+__device__ __forceinline__ Point ec_add(const Point &p, const Point &q) { // ecc.rs:244-328
+    const Fp6 b3 = const6(c_b3);
+    Fp6 t0 = mul6(p.x, q.x), t1 = mul6(p.y, q.y), t2 = mul6(p.z, q.z);
+    Fp6 t3 = fp6_sub(mul6(fp6_add(p.x, p.y), fp6_add(q.x, q.y)), fp6_add(t0, t1));
+    Fp6 t4 = fp6_sub(mul6(fp6_add(p.x, p.z), fp6_add(q.x, q.z)), fp6_add(t0, t2));
+    Fp6 t5 = fp6_sub(mul6(fp6_add(p.y, p.z), fp6_add(q.y, q.z)), fp6_add(t1, t2));
+    Fp6 z3 = fp6_add(mul6(b3, t2), t4);
+    Fp6 x3 = fp6_sub(t1, z3);
+    z3 = fp6_add(t1, z3);
+    Fp6 y3 = mul6(x3, z3);
+    t1 = fp6_add(fp6_add(fp6_dbl(t0), t0), t2);
+    t4 = fp6_add(mul6(b3, t4), fp6_sub(t0, t2));
+    y3 = fp6_add(y3, mul6(t1, t4));
+    x3 = fp6_sub(mul6(t3, x3), mul6(t5, t4));
+    z3 = fp6_add(mul6(t5, z3), mul6(t3, t1));
+    return {x3, y3, z3};
+}
+
+// doubling + conditional mixed addition constraints for the point at registers [reg, reg+19)
+template <class Acc>
+__device__ __forceinline__ void enforce_scalar_mult_step(Acc &acc, const Frame &f, int reg, const Fp6 &qx, const Fp6 &qy, fp doubling, fp addition) {
+    const Point p = {load6(f, reg, false), load6(f, reg + 6, false), load6(f, reg + 12, false)};
+    const fp bit = f.cur(reg + 18);
+    {   // enforce_point_doubling ecc.rs:73-98
+        const Point d = ec_double(p);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc.add(reg + i, doubling, fp_sub(f.next(reg + i), d.x.c[i]));
+            acc.add(reg + 6 + i, doubling, fp_sub(f.next(reg + 6 + i), d.y.c[i]));
+            acc.add(reg + 12 + i, doubling, fp_sub(f.next(reg + 12 + i), d.z.c[i]));
+        }
+        acc.add(reg + 18, doubling, c_is_binary(bit));
+    }
+    {   // enforce_point_addition_mixed ecc.rs:102-138: next = bit * (p + q) + (1 - bit) * p
+        const Point a = ec_add_mixed(p, qx, qy);
+        const fp nb = c_not(bit);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc.add(reg + i, addition, fp_sub(f.next(reg + i), fp_add(fp_mul(bit, a.x.c[i]), fp_mul(nb, p.x.c[i]))));
+            acc.add(reg + 6 + i, addition, fp_sub(f.next(reg + 6 + i), fp_add(fp_mul(bit, a.y.c[i]), fp_mul(nb, p.y.c[i]))));
+            acc.add(reg + 12 + i, addition, fp_sub(f.next(reg + 12 + i), fp_add(fp_mul(bit, a.z.c[i]), fp_mul(nb, p.z.c[i]))));
+        }
+        acc.add(reg + 18, addition, fp_sub(bit, f.next(reg + 18)));
+    }
+}
+
+// src/merkle/update/air.rs:291-369 without its two enforce_round calls (done by the caller per window)
+template <class Acc>
+__device__ __forceinline__ void merkle_auth_rest(Acc &acc, const Frame &f, int base, fp tx_hash, fp hash_input, fp hash_flag) {
+    const fp hash_copy = fp_mul(tx_hash, c_not(fp_add(hash_flag, hash_input)));
+    const fp hash_init = fp_mul(tx_hash, hash_input);
+    const fp bit = f.next(base + 14), not_bit = c_not(bit);
+    acc.add(base + 14, tx_hash, c_is_binary(bit));
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        const int b = base + 15 * k;
+#pragma unroll 1
+        for (int i = 0; i < 7; i++) {
+            const fp ci = f.cur(b + i), d = fp_sub(ci, f.next(b + i));
+            acc.add(b + i, hash_copy, d);
+            acc.add(b + i, hash_init, fp_mul(not_bit, d));
+            acc.add(b + 7 + i, hash_init, fp_mul(bit, fp_sub(ci, f.next(b + 7 + i))));
+        }
+    }
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) acc.add(base + i, hash_init, fp_mul(bit, fp_sub(f.next(base + 15 + i), f.next(base + i))));
+#pragma unroll 1
+    for (int i = 7; i < 14; i++) acc.add(base + i, hash_init, fp_mul(not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i))));
+}
+
+// All 115 transition constraints at one point (src/air.rs:114-173, :383-610).
+template <class Acc>
+__device__ __forceinline__ void evaluate_transition(Acc &acc, const Frame &f) {
+    const fp setup = f.pv(P_SETUP), tx_hash = f.pv(P_MERKLE), hash_input = f.pv(P_HASH_INPUT), finish = f.pv(P_FINISH), hash_flag = f.pv(P_HASH);
+    const fp schnorr_mask = f.pv(P_SCHNORR), scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING), schnorr_hash = f.pv(P_SCHNORR_HASH);
+    const fp range_flag = f.pv(P_RANGE_STEP), range_finish = f.pv(P_RANGE_FINISH), copy_values = f.pv(P_VALUE_COPY);
+    const fp copy_hash = fp_mul(c_not(schnorr_hash), schnorr_mask);
+    const fp final_add = fp_mul(c_not(scalar_mult), schnorr_mask);
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
+
+    // Rescue windows: merkle::init (setup flag, shifted result bases, src/merkle/init/air.rs:166-201) and
+    // merkle::update (hash flag, src/merkle/update/air.rs:316-322) share their register windows.
+    enforce_round(acc, f, S_INIT, S_INIT, setup, S_INIT, hash_flag, true);
+    enforce_round(acc, f, S_UPD, S_UPD - 1, setup, S_UPD, hash_flag, true);
+    enforce_round(acc, f, R_INIT, R_INIT - 1, setup, R_INIT, hash_flag, true);
+    enforce_round(acc, f, R_UPD, R_UPD - 2, setup, R_UPD, hash_flag, true);
+    enforce_round(acc, f, 42, 42, schnorr_hash, 0, 0, false); // src/schnorr/air.rs:488-494
+
+    // transaction setup (src/air.rs:406-453)
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        acc.add(VALUE_RES + i, setup, fp_sub(f.cur(S_INIT + i), f.cur(S_UPD + i)));
+        acc.add(VALUE_RES + 12 + i, setup, fp_sub(f.cur(R_INIT + i), f.cur(R_UPD + i)));
+    }
+    acc.add(VALUE_RES + 24, setup, fp_sub(f.cur(R_INIT + 13), f.cur(R_UPD + 13)));
+    const fp s_spent = fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12));
+    acc.add(BALANCE_RES, setup, fp_sub(s_spent, fp_sub(f.cur(R_UPD + 12), f.cur(R_INIT + 12))));
+    acc.add(NONCE_UPD_RES, setup, fp_sub(f.cur(S_UPD + 13), fp_add(f.cur(S_INIT + 13), FP_ONE)));
+    // key / delta / sigma / nonce copies (src/air.rs:456-529; result indices alias as in the reference)
+#pragma unroll 1
+    for (int o = 0; o < 12; o++) {
+        const fp sk = f.next(S_KEY + o), rk = f.next(R_KEY + o);
+        acc.add(S_KEY_RES + o, setup, fp_sub(sk, f.cur(S_INIT + o)));
+        acc.add(R_KEY_RES + o, setup, fp_sub(rk, f.cur(R_INIT + o)));
+        acc.add(S_KEY_RES + o, copy_values, fp_sub(sk, f.cur(S_KEY + o)));
+        acc.add(R_KEY_RES + o, copy_values, fp_sub(rk, f.cur(R_KEY + o)));
+    }
+    acc.add(DELTA_COPY_RES, setup, fp_sub(f.next(DELTA_COPY), s_spent));
+    acc.add(SIGMA_COPY_RES, setup, fp_sub(f.next(SIGMA_COPY), f.cur(S_UPD + 12)));
+    acc.add(NONCE_COPY_RES, setup, fp_sub(f.next(NONCE_COPY), f.cur(S_INIT + 13)));
+    acc.add(DELTA_COPY_RES, copy_values, fp_sub(f.next(DELTA_COPY), f.cur(DELTA_COPY)));
+    acc.add(SIGMA_COPY_RES, copy_values, fp_sub(f.next(SIGMA_COPY), f.cur(SIGMA_COPY)));
+    acc.add(NONCE_COPY_RES, copy_values, fp_sub(f.next(NONCE_COPY), f.cur(NONCE_COPY)));
+
+    // merkle::update (src/merkle/update/air.rs:215-289)
+    merkle_auth_rest(acc, f, S_INIT, tx_hash, hash_input, hash_flag);
+    merkle_auth_rest(acc, f, R_INIT, tx_hash, hash_input, hash_flag);
+    const fp not_finish = c_not(finish);
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) {
+        const fp nr = f.next(PREV_ROOT + i), cr = f.cur(PREV_ROOT + i);
+        acc.add(PREV_ROOT + i, not_finish, fp_sub(nr, cr));
+        acc.add(PREV_ROOT + i, finish, fp_sub(nr, f.next(R_UPD + i)));
+        acc.add(INT_ROOT_RES + i, finish, fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)));
+        acc.add(PREV_MATCH_RES + i, finish, fp_sub(f.next(S_INIT + i), cr));
+    }
+
+    // schnorr (src/schnorr/air.rs:394-531) on registers / results [0, 56)
+    {
+        const Fp6 gx = const6(c_generator), gy = const6(c_generator + 6);
+        enforce_scalar_mult_step(acc, f, 0, gx, gy, doubling, addition);
+        const Fp6 px = load6(f, S_KEY, true), py = load6(f, S_KEY + 6, true); // pkey = next[S_KEY..], src/air.rs:575
+        enforce_scalar_mult_step(acc, f, 19, px, py, doubling, addition);
+    }
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) { // h-limb double-and-add, accumulator copies (:451-484)
+        const fp dflag = f.pv(P_DIGEST + i);
+        const fp c = f.cur(41 - i), nx = f.next(41 - i);
+        acc.add(41 - i, fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37))));
+        acc.add(41 - i, fp_mul(c_not(dflag), doubling), fp_sub(c, nx));
+        acc.add(38 + i, addition, fp_sub(f.cur(38 + i), f.next(38 + i)));
+        acc.add(38 + i, final_add, fp_sub(f.cur(38 + i), f.cur(42 + i))); // h == hash output (:521-530)
+    }
+    // enforce_hash_copy (:309-330) with the internal inputs of src/air.rs:543-565
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) {
+        acc.add(42 + i, copy_hash, fp_sub(f.cur(42 + i), f.next(42 + i)));
+        fp inp = 0;
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const int m = k * 7 + i;
+            const fp cell = m < 12 ? f.next(S_KEY + m) : m < 24 ? f.next(R_KEY + m - 12) : m == 24 ? f.next(DELTA_COPY) : m == 25 ? f.next(NONCE_COPY) : 0;
+            inp = fp_add(inp, fp_mul(f.pv(P_HASH_INTERNAL + k), cell));
+        }
+        acc.add(49 + i, copy_hash, fp_sub(f.next(49 + i), inp));
+    }
+    {   // final addition S + h*P with X reduced to affine (ecc.rs:146-172)
+        const Point s = {load6(f, 0, false), load6(f, 6, false), load6(f, 12, false)};
+        const Point hp = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
+        const Point r = ec_add(s, hp);
+        const Fp6 xz = mul6(load6(f, 0, true), r.z);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc.add(i, final_add, fp_sub(xz.c[i], r.x.c[i]));
+            acc.add(6 + i, final_add, fp_sub(f.next(6 + i), r.y.c[i]));
+            acc.add(12 + i, final_add, fp_sub(f.next(12 + i), r.z.c[i]));
+        }
+    }
+    // range proofs (src/air.rs:583-609); SIGMA_RANGE_RES re-checks the delta registers, as in the reference
+    {
+        const fp db = f.next(DELTA_BIT), sb = f.next(SIGMA_BIT);
+        acc.add(DELTA_ACC, range_flag, fp_sub(f.next(DELTA_ACC), fp_add(fp_dbl(f.cur(DELTA_ACC)), db)));
+        acc.add(DELTA_BIT, range_flag, c_is_binary(db));
+        acc.add(SIGMA_ACC, range_flag, fp_sub(f.next(SIGMA_ACC), fp_add(fp_dbl(f.cur(SIGMA_ACC)), sb)));
+        acc.add(SIGMA_BIT, range_flag, c_is_binary(sb));
+        const fp dr = fp_sub(f.next(DELTA_ACC), f.next(DELTA_COPY));
+        acc.add(DELTA_RANGE_RES, range_finish, dr);
+        acc.add(SIGMA_RANGE_RES, range_finish, dr);
+    }
+}
+
+__device__ __forceinline__ Frame make_frame(const CeParams &p, unsigned kk, size_t j) {
+    const size_t n = (size_t)1 << p.log_n;
+    const fp *base = p.lde + (size_t)kk * 94 * n;
+    Frame f;
+    f.n = n;
+    f.cur_p = base + j;
+    f.next_p = base + ((j + 1) & (n - 1)); // LDE row i + blowup = (k, j + 1)
+    f.per_p = p.ptab + (size_t)(p.k0 + kk) * 48 * 1024 + (j & 1023);
+    return f;
+}
+
+// grid = (n / NT, nk)
+__global__ __launch_bounds__(NT) void k_eval_transitions(CeParams p) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)NT + threadIdx.x;
+    const unsigned kk = blockIdx.y;
+    const Frame f = make_frame(p, kk, j);
+    AccAll acc{p.out + (size_t)kk * 115 * n + j, n}; // caller zero-fills
+    evaluate_transition(acc, f);
+}
+
+__global__ __launch_bounds__(NT) void k_eval_constraints(CeParams p) {
+    __shared__ fp lds[6 * NT];
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)NT + threadIdx.x;
+    const unsigned kk = blockIdx.y;
+    const Frame f = make_frame(p, kk, j);
+#pragma unroll
+    for (int g = 0; g < 6; g++) lds[g * NT + threadIdx.x] = 0;
+    AccFused acc{lds, p.coef, p.coef + 115};
+    evaluate_transition(acc, f);
+
+    // x = shift_k * w_n^j and its powers (per-coset constants precomputed on the host)
+    const fp *cc = p.coset + (size_t)(p.k0 + kk) * CE_COSET_CONSTS;
+    const fp wj = p.w[j];
+    const fp x = fp_mul(cc[0], wj);
+    fp t = lds[threadIdx.x];
+#pragma unroll
+    for (int g = 0; g < 5; g++) {
+        const fp xp = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
+        t = fp_add(t, fp_mul(xp, lds[(1 + g) * NT + threadIdx.x]));
+    }
+    // transition divisor (x^n - 1) / (x - w^(n-1)); x^n is constant on a coset
+    t = fp_mul(t, fp_mul(fp_sub(x, p.w_last), cc[1]));
+    // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184)
+    const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
+    const fp *ba = p.coef + 230, *bb = p.coef + 234;
+    const fp r58 = f.cur(58), r59 = f.cur(59);
+    fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
+    fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
+    const fp d0 = fp_sub(x, FP_ONE), d1 = fp_sub(x, p.w_last);
+    const fp inv01 = fp_inv(fp_mul(d0, d1)); // one inversion for both divisors
+    t = fp_add(t, fp_mul(first, fp_mul(inv01, d1)));
+    t = fp_add(t, fp_mul(last, fp_mul(inv01, d0)));
+    p.out[(size_t)kk * n + j] = t;
+}
+
+} // namespace
+
+hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    hipError_t e = hipMemsetAsync(p.out, 0, (size_t)nk * 115 * n * sizeof(fp), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_eval_transitions, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    hipLaunchKernelGGL(k_eval_constraints, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace cs

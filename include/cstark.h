@@ -131,16 +131,23 @@ int cstark_hash_rows(cstark_ctx *ctx, const uint64_t *d_lde, uint8_t *d_leaves, 
 int cstark_merkle_build(cstark_ctx *ctx, uint8_t *d_nodes, uint32_t log_leaves);
 
 /* ---- K6/K7: constraint evaluation (Air::evaluate_transition, src/air.rs:114-173, + driver) --- */
-/* All 115 transition-constraint values at every point of cosets [k0,k0+nk):
- *   d_out[(k - k0) * 115 * n + i * n + j].  Parity / debugging entry point. */
-int cstark_tx_evaluate_transitions(cstark_ctx *ctx, const uint64_t *d_lde, uint64_t *d_out, uint32_t log_n,
-                                   uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* d_lde: cosets [k0,k0+nk) of the extended 94-column trace, coset-major as cstark_lde_columns writes them.
+ * merkle_depth selects the mask columns (src/merkle/constants.rs:21-27).  log_blowup must be 3.
+ *
+ * All 115 transition-constraint values at every point:  d_out[((k - k0) * 115 + i) * n + j].
+ * Parity / debugging entry point (the production path never materialises them). */
+int cstark_tx_evaluate_transitions(cstark_ctx *ctx, const uint64_t *d_lde, uint64_t *d_out, uint32_t merkle_depth,
+                                   uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 /* Fused production path: combined constraint evaluations
  *   d_out[(k - k0) * n + j] = sum_i (alpha_i + beta_i x^adj_i) C_i(x) / Z(x) + boundary terms,
  * x = g * w_{bn}^k * w_n^j.  pub_inputs = initial_root[0..2], final_root[0..2] (src/air.rs:175-184). */
 int cstark_tx_evaluate_constraints(cstark_ctx *ctx, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs,
-                                   const uint64_t pub_inputs[4], uint64_t *d_out, uint32_t log_n,
-                                   uint32_t log_blowup, uint32_t k0, uint32_t nk);
+                                   const uint64_t pub_inputs[4], uint64_t *d_out, uint32_t merkle_depth,
+                                   uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* Host-side AIR description (no GPU needed): degree (base; number of 1024-row cycles) of transition constraint i
+ * (TransactionAir::new, src/air.rs:76-108) and the 48 periodic columns (src/air.rs:194-380), [48][1024]. */
+int cstark_tx_constraint_degree(uint32_t i, uint32_t *base, uint32_t *cycles);
+int cstark_tx_periodic_columns(uint32_t merkle_depth, uint64_t *out);
 
 /* ---- device memory helpers for callers without a HIP runtime of their own (the Rust shim) ---- */
 int cstark_malloc(cstark_ctx *ctx, size_t bytes, void **d_ptr);

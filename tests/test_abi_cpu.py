@@ -1,0 +1,73 @@
+"""CPU-only checks of the product library: it loads, exports every symbol include/cstark.h declares, refuses to
+compute without a GPU (no fallback), and its host-side AIR description equals the oracle's restatement."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib():
+    from certificate_stark_amd import _lib
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cstark.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(cstark_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 20
+    lib = _lib()
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    lib = _lib()
+    ctx = C.c_void_p()
+    rc = lib.cstark_ctx_create(C.c_int(-1), None, C.byref(ctx))
+    assert rc == -2  # CSTARK_ERR_NO_DEVICE
+    assert b"no HIP device" in lib.cstark_last_error()
+    from certificate_stark_amd.backend import Backend
+    from certificate_stark_amd import CstarkError
+    try:
+        Backend()
+        assert False, "Backend() must fail without a GPU"
+    except CstarkError as e:
+        assert e.code == -2
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may import, link or call it."""
+    pkg = os.path.join(ROOT, "certificate-stark_amd")
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|oracle/|libcs_oracle|\bcso_)")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(txt), (dirpath, f)
+
+
+def test_host_air_description_matches_oracle(oracle):
+    lib = _lib()
+    base, cyc = oracle.tx_constraint_degrees()
+    for i in range(115):
+        b, c = C.c_uint32(), C.c_uint32()
+        assert lib.cstark_tx_constraint_degree(C.c_uint32(i), C.byref(b), C.byref(c)) == 0
+        assert (b.value, c.value) == (int(base[i]), int(cyc[i])), i
+    assert lib.cstark_tx_constraint_degree(C.c_uint32(115), C.byref(b), C.byref(c)) == -1
+    for depth in (3, 7, 15, 31):
+        out = np.zeros((48, 1024), np.uint64)
+        assert lib.cstark_tx_periodic_columns(C.c_uint32(depth), out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+        assert (out == oracle.tx_periodic_columns(depth)).all()
+    assert lib.cstark_tx_periodic_columns(C.c_uint32(64), out.ctypes.data_as(C.POINTER(C.c_uint64))) == -1
+    lib.cstark_field_generator.restype = C.c_uint64
+    lib.cstark_field_root_of_unity.restype = C.c_uint64
+    assert lib.cstark_field_generator() == oracle.generator()
+    for k in (1, 10, 20, 23):
+        assert lib.cstark_field_root_of_unity(C.c_uint32(k)) == oracle.root_of_unity(k)
