@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X hot path for the Topos state-transition AIR (BASELINE.json north_star).
+
+One "step" = one pass of the hot path over one synthetic batch: the witness of 1024 transfers (2^20 trace rows,
+94 registers, Merkle depth 15) is already resident in HBM; the timed region is
+    K1 trace generation -> K2 interpolation -> K3 coset LDE (blowup 8) -> K4 Blake3 row hashing -> K5 Merkle tree
+    -> K6 constraint evaluation (115 constraints, fused random linear combination + boundary terms)
+i.e. the region the reference times (TransactionExample::prove = build_trace + Prover::prove, src/lib.rs:116-141) up to
+and including the constraint-evaluation stage; composition/DEEP/FRI are not part of this round's hot path.
+
+Launch:  python bench.py --gpus N --steps K --warmup W      (N > 1: one rank per GPU via torch.distributed.run)
+Multi-GPU = independent proofs per GPU (replicas, no data-path collective): weak scaling.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P = 2**62 + 2**56 + 2**55 + 1
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a streaming copy reaches
+LOG_N, WIDTH, LOG_B, DEPTH = 20, 94, 3, 15
+FIXTURE = os.path.join(ROOT, "tests", "golden", "witness_1024_d15.npz")
+
+
+def algorithmic_bytes(n, w, b):
+    """every stage reads its input once and writes its output once."""
+    return {
+        "trace_gen": n * w * 8,
+        "interpolate": 2 * n * w * 8,
+        "lde": n * w * 8 + b * n * w * 8,
+        "hash_rows": b * n * w * 8 + b * n * 32,
+        "merkle": 2 * b * n * 32,
+        "constraints": b * n * w * 8 + b * n * 8,
+    }
+
+
+def cpu_baseline(meta, sample_tx):
+    """The oracle (CPU port, OpenMP) on a bounded sample of the same workload, all host cores."""
+    from oracle import oracle as O
+    w = O.TxWitness(sample_tx, meta.depth)
+    for f in w.FIELDS:
+        src = getattr(meta, f)
+        getattr(w, f)[...] = src if f == "final_root" else src[:sample_tx]
+    w.final_root[...] = meta.initial_roots[sample_tx] if sample_tx < meta.n_tx else meta.final_root
+    cf = O.make_coeffs(17)
+    pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
+    t0 = time.perf_counter()
+    trace = O.tx_build_trace(w)
+    t1 = time.perf_counter()
+    co = O.interpolate_columns(trace)
+    lde = O.lde_columns(co, LOG_B)
+    t2 = time.perf_counter()
+    leaves = O.hash_rows(lde, LOG_B)
+    O.merkle_build(leaves)
+    t3 = time.perf_counter()
+    O.tx_evaluate_constraints(lde, cf, pub, w.depth, LOG_B)
+    t4 = time.perf_counter()
+    total = t4 - t0
+    frac = sample_tx / meta.n_tx
+    return {
+        "value": round(frac / total, 5), "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port",
+        "sample": "%d of %d transactions (2^%d of 2^20 rows) through the same stages, linearly extrapolated; "
+                  "OpenMP oracle: trace %.2fs, lde %.2fs, commit %.2fs, constraints %.2fs" % (
+                      sample_tx, meta.n_tx, (sample_tx * 1024).bit_length() - 1, t1 - t0, t2 - t1, t3 - t2, t4 - t3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-tx", type=int, default=1024, help="transactions per proof (1024 = BASELINE's 2^20 rows)")
+    ap.add_argument("--cpu-sample-tx", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from certificate_stark_amd import _lib
+    from certificate_stark_amd.backend import Backend
+    from certificate_stark_amd.prover import ProofOptions, TransactionMetadata, TransactionProver
+
+    meta_full = TransactionMetadata.load(FIXTURE)
+    n_tx = args.n_tx
+    meta = meta_full if n_tx == meta_full.n_tx else TransactionMetadata(
+        *[getattr(meta_full, f) if f == "final_root" else getattr(meta_full, f)[:n_tx] for f in TransactionMetadata.FIELDS])
+    if n_tx != meta_full.n_tx:
+        meta.final_root = meta_full.initial_roots[n_tx].copy()
+    n = n_tx * 1024
+    log_n = n.bit_length() - 1
+
+    prover = TransactionProver(ProofOptions(num_queries=96), Backend(local))
+    prover.load_witness(meta)  # witness resident in HBM before the timed region
+    rng = np.random.default_rng(1234 + rank)
+    cf = _lib.TxCoeffsStruct()
+    for name, k in (("t_alpha", 115), ("t_beta", 115), ("b_alpha", 4), ("b_beta", 4)):
+        v = rng.integers(1, P, size=k, dtype=np.uint64)
+        for i in range(k):
+            getattr(cf, name)[i] = int(v[i])
+    pub = [int(meta.initial_roots[0][0]), int(meta.initial_roots[0][1]), int(meta.final_root[0]), int(meta.final_root[1])]
+
+    stages = ["trace_gen", "interpolate", "lde", "hash_rows", "merkle", "constraints"]
+    acc_ms = {s: 0.0 for s in stages}
+
+    def step(timed):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if timed else None
+        b = prover.backend
+        if timed: ev[0].record()
+        trace = prover.build_trace()
+        if timed: ev[1].record()
+        coeffs = b.interpolate_columns(trace, out=prover._buf("coeffs", (WIDTH, n)))
+        if timed: ev[2].record()
+        lde = b.lde_columns(coeffs, LOG_B, out=prover._buf("lde", (1 << LOG_B, WIDTH, n)))
+        if timed: ev[3].record()
+        L = n << LOG_B
+        nodes = prover._buf("nodes", (2 * L, 32), torch.uint8)
+        b.hash_rows(lde, LOG_B, leaves=nodes[L:])
+        if timed: ev[4].record()
+        b.merkle_build(nodes)
+        if timed: ev[5].record()
+        prover.evaluate_constraints(lde, cf, pub)
+        if timed: ev[6].record()
+        return ev
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    events = [step(True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for ev in events:
+        for i, s in enumerate(stages):
+            acc_ms[s] += ev[i].elapsed_time(ev[i + 1])
+    stage_ms = {s: acc_ms[s] / args.steps for s in stages}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        ab = algorithmic_bytes(n, WIDTH, 1 << LOG_B)
+        dom = max(stage_ms, key=stage_ms.get)
+        achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "proofs/sec, state_transition AIR @ 2^%d steps (hot path: trace gen + LDE + Blake3 commitment + constraint evaluation)" % log_n,
+            "value": round(world / (ms_per_step * 1e-3), 4),
+            "unit": "proofs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 (63-bit prime field, Montgomery) + u32 (Blake3)", "data": "synthetic",
+            "config": {"workload": "benches/state_transition.rs full TransactionAir, %d transactions = 2^%d steps, blowup 8, "
+                                   "Merkle depth %d, Blake3_256, no field extension" % (n_tx, log_n, meta.depth),
+                       "parallelism": "replica x%d (independent proofs per GPU, no collective)" % world,
+                       "trace": "%d x 2^%d" % (WIDTH, log_n)},
+            "stage_ms": {s: round(v, 3) for s, v in stage_ms.items()},
+            "stage_gbs": {s: round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1) for s in stages},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes": ab[dom], "kernel_ms": round(stage_ms[dom], 3),
+                         "note": "integer-VALU bound stage priced against the HBM roofline as BASELINE.json asks"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(meta_full, min(args.cpu_sample_tx, n_tx))
+            except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+                out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

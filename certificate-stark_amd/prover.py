@@ -1,0 +1,137 @@
+"""Host-side mirror of the reference's prover interface for the state-transition AIR.
+
+Names and argument meaning follow the reference so tests read like its own:
+  ProofOptions(num_queries, blowup_factor, grinding_factor, hash_fn, field_extension, fri_folding_factor,
+               fri_max_remainder)                          -- winterfell::ProofOptions as used at src/lib.rs:78-86
+  TransactionMetadata                                      -- src/lib.rs:183-232 (field for field)
+  TransactionProver(options).build_trace(tx_metadata)     -- src/prover.rs:20-98
+  TransactionProver.get_pub_inputs(trace)                  -- src/prover.rs:106-129
+  TransactionProver.commit_and_evaluate(...)               -- the hot half of Prover::prove (src/lib.rs:140):
+        interpolate -> LDE -> Blake3 row hashes -> Merkle tree -> constraint evaluations
+All device work goes through the C ABI (include/cstark.h); there is no CPU path here.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .backend import Backend, to_numpy_u64
+
+TRACE_WIDTH = _lib.TX_TRACE_WIDTH
+TRANSACTION_CYCLE_LENGTH = _lib.TX_CYCLE_LENGTH
+PREV_TREE_ROOT_POS = 58  # src/merkle/constants.rs:45
+
+
+class ProofOptions:
+    """The 7 fields of winterfell::ProofOptions; defaults are the reference's (src/lib.rs:78-86)."""
+    BLAKE3_256, SHA3_256 = 0, 1
+    EXT_NONE, EXT_QUADRATIC, EXT_CUBIC = 0, 1, 2
+
+    def __init__(self, num_queries=42, blowup_factor=8, grinding_factor=0, hash_fn=0, field_extension=0,
+                 fri_folding_factor=4, fri_max_remainder=256):
+        if blowup_factor & (blowup_factor - 1) or blowup_factor < 2:
+            raise ValueError("blowup factor must be a power of two >= 2")
+        self.num_queries, self.blowup_factor, self.grinding_factor = num_queries, blowup_factor, grinding_factor
+        self.hash_fn, self.field_extension = hash_fn, field_extension
+        self.fri_folding_factor, self.fri_max_remainder = fri_folding_factor, fri_max_remainder
+
+    @property
+    def log_blowup(self):
+        return self.blowup_factor.bit_length() - 1
+
+
+class TransactionMetadata:
+    """Series of transfers in the account tree (src/lib.rs:183-194); arrays are uint64 in BaseElement memory form."""
+    FIELDS = ("initial_roots", "final_root", "s_old_values", "r_old_values", "s_indices", "r_indices",
+              "s_paths", "r_paths", "deltas", "sig_rx", "sig_s")
+
+    def __init__(self, initial_roots, final_root, s_old_values, r_old_values, s_indices, r_indices, s_paths, r_paths,
+                 deltas, sig_rx, sig_s):
+        n = len(initial_roots)
+        # "Enforce that all vectors are of equal length" (src/lib.rs:211-218)
+        for name, a in (("s_old_values", s_old_values), ("r_old_values", r_old_values), ("s_indices", s_indices),
+                        ("r_indices", r_indices), ("s_paths", s_paths), ("r_paths", r_paths), ("deltas", deltas),
+                        ("sig_rx", sig_rx), ("sig_s", sig_s)):
+            if len(a) != n:
+                raise ValueError("%s has %d entries, expected %d" % (name, len(a), n))
+        self.initial_roots = np.ascontiguousarray(initial_roots, np.uint64).reshape(n, 7)
+        self.final_root = np.ascontiguousarray(final_root, np.uint64).reshape(7)
+        self.s_old_values = np.ascontiguousarray(s_old_values, np.uint64).reshape(n, 14)
+        self.r_old_values = np.ascontiguousarray(r_old_values, np.uint64).reshape(n, 14)
+        self.s_indices = np.ascontiguousarray(s_indices, np.uint64).reshape(n)
+        self.r_indices = np.ascontiguousarray(r_indices, np.uint64).reshape(n)
+        self.s_paths = np.ascontiguousarray(s_paths, np.uint64)
+        self.r_paths = np.ascontiguousarray(r_paths, np.uint64)
+        self.deltas = np.ascontiguousarray(deltas, np.uint64).reshape(n)
+        self.sig_rx = np.ascontiguousarray(sig_rx, np.uint64).reshape(n, 6)
+        self.sig_s = np.ascontiguousarray(sig_s, np.uint8).reshape(n, 32)
+        self.n_tx = n
+        self.depth = self.s_paths.shape[1] - 1
+        if self.s_paths.shape != (n, self.depth + 1, 7) or self.r_paths.shape != self.s_paths.shape:
+            raise ValueError("authentication paths must be [n][depth+1][7]")
+        if (self.depth + 1) & self.depth:
+            raise ValueError("tree depth must be one less than a power of 2")  # src/lib.rs:102-105
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path)
+        return cls(*[z[f] for f in cls.FIELDS])
+
+    def save(self, path):
+        np.savez_compressed(path, **{f: getattr(self, f) for f in self.FIELDS})
+
+
+class TransactionProver:
+    """MI355X counterpart of src/prover.rs::TransactionProver plus the hot half of Prover::prove."""
+
+    def __init__(self, options=None, backend=None):
+        self.options = options or ProofOptions()
+        self.backend = backend or Backend()
+        self._bufs = {}
+
+    def _buf(self, name, shape, dtype=torch.int64):
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.backend.device)
+            self._bufs[name] = t
+        return t
+
+    # -- src/prover.rs:37-98
+    def load_witness(self, tx_metadata):
+        self.backend.upload_witness(tx_metadata)
+        self.n_tx, self.depth = tx_metadata.n_tx, tx_metadata.depth
+        self.trace_length = self.n_tx * TRANSACTION_CYCLE_LENGTH
+        if self.trace_length & (self.trace_length - 1):
+            raise ValueError("the number of transactions must be a power of two")
+
+    def build_trace(self, tx_metadata=None):
+        if tx_metadata is not None:
+            self.load_witness(tx_metadata)
+        return self.backend.build_trace(self._buf("trace", (TRACE_WIDTH, self.trace_length)))
+
+    # -- src/prover.rs:106-129
+    @staticmethod
+    def get_pub_inputs(trace):
+        first = to_numpy_u64(trace[PREV_TREE_ROOT_POS:PREV_TREE_ROOT_POS + 7, 0])
+        last = to_numpy_u64(trace[PREV_TREE_ROOT_POS:PREV_TREE_ROOT_POS + 7, -1])
+        return first, last  # initial_root, final_root
+
+    # -- hot half of Prover::prove
+    def extend_and_commit(self, trace, k0=0, nk=None):
+        """interpolate -> LDE (cosets [k0,k0+nk)) -> leaf hashes; returns (coeffs, lde, nodes)."""
+        b, lb = self.backend, self.options.log_blowup
+        n = trace.shape[1]
+        nk = (1 << lb) - k0 if nk is None else nk
+        coeffs = b.interpolate_columns(trace, out=self._buf("coeffs", (TRACE_WIDTH, n)))
+        lde = b.lde_columns(coeffs, lb, k0=k0, nk=nk, out=self._buf("lde", (nk, TRACE_WIDTH, n)))
+        L = n << lb
+        nodes = self._buf("nodes", (2 * L, 32), torch.uint8)
+        b.hash_rows(lde, lb, k0=k0, leaves=nodes[L:])
+        return coeffs, lde, nodes
+
+    def build_tree(self, nodes):
+        return self.backend.merkle_build(nodes)
+
+    def evaluate_constraints(self, lde, coeffs_struct, pub_inputs4, k0=0):
+        n = lde.shape[2]
+        return self.backend.evaluate_constraints(lde, coeffs_struct, pub_inputs4, self.depth, self.options.log_blowup, k0=k0,
+                                                 out=self._buf("combined", (lde.shape[0], n)))
