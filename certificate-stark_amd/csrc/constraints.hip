@@ -56,18 +56,6 @@ struct AccAll {
     size_t n;
     __device__ __forceinline__ void add(int i, fp flag, fp val) { out[(size_t)i * n] = fp_add(out[(size_t)i * n], fp_mul(flag, val)); }
 };
-// Production: fold into sum_i alpha_i r_i and, per degree group, sum_i beta_i r_i (kept in LDS, one column per lane).
-struct AccFused {
-    fp *lds; // [6][NT]
-    const fp *alpha, *beta;
-    __device__ __forceinline__ void add(int i, fp flag, fp val) {
-        const fp t = fp_mul(flag, val);
-        const int g = 1 + tx_degree_group(i);
-        lds[threadIdx.x] = fp_add(lds[threadIdx.x], fp_mul(alpha[i], t));
-        lds[g * NT + threadIdx.x] = fp_add(lds[g * NT + threadIdx.x], fp_mul(beta[i], t));
-    }
-};
-
 __device__ __forceinline__ fp c_not(fp a) { return fp_sub(FP_ONE, a); }
 __device__ __forceinline__ fp c_is_binary(fp a) { return fp_sub(fp_sqr(a), a); }
 
@@ -347,40 +335,305 @@ __global__ __launch_bounds__(NT) void k_eval_transitions(CeParams p) {
     evaluate_transition(acc, f);
 }
 
-__global__ __launch_bounds__(NT) void k_eval_constraints(CeParams p) {
-    __shared__ fp lds[6 * NT];
+// =====================================================================================================
+// Production path: fused evaluation.  The work is split into four launches ("parts") so that each has a
+// small instruction footprint and register budget:  ROUNDS (the five Rescue windows), EC0 / EC1 (double +
+// mixed-add gadgets of s*G and h*P), REST (final addition, every linear constraint, boundary terms).
+// Each part folds its constraints straight into the random linear combination
+//     sum_i (alpha_i + beta_i x^adj_g(i)) * flag * value_i
+// using one 128-bit lazy accumulator per (gadget, flag) section, multiplies by 1/Z(x) and adds its share to
+// the output.  Exact arithmetic: the sum of the parts equals the reference's merged evaluation.
+constexpr int FNT = 256;
+enum { PART_ROUNDS = 0, PART_EC0 = 1, PART_EC1 = 2, PART_REST = 3 };
+
+struct Fused {
+    const fp *alpha, *beta; // uniform
+    const fp *xp;           // LDS [5][FNT]: x^adj_g of this lane's point
+    Acc128 s;
+    int cnt;
+    fp total;
+    __device__ __forceinline__ fp coef(int i) const { return fp_add(alpha[i], fp_mul(beta[i], xp[tx_degree_group(i) * FNT + threadIdx.x])); }
+    __device__ __forceinline__ void begin() { s = acc_zero(); cnt = 0; }
+    __device__ __forceinline__ void term(int i, fp v) {
+        acc_mad(s, coef(i), v);
+        if (++cnt == 7) { acc_fold(s); cnt = 0; }
+    }
+    __device__ __forceinline__ void end(fp flag) {
+        acc_fold(s);
+        total = fp_add(total, fp_mul(flag, acc_reduce(s)));
+    }
+};
+
+// sum_j m[j] * x[j] for a row of 14 uniform constants, one reduction
+__device__ __forceinline__ fp dot14(const fp *__restrict__ m, const fp (&x)[14]) {
+    Acc128 a = acc_zero();
+#pragma unroll
+    for (int j = 0; j < 7; j++) acc_mad(a, m[j], x[j]);
+    acc_fold(a);
+#pragma unroll
+    for (int j = 7; j < 14; j++) acc_mad(a, m[j], x[j]);
+    acc_fold(a);
+    return acc_reduce(a);
+}
+
+// the five Rescue windows: {first register, result base A, flag A, result base B, flag B (-1: none)}
+struct RoundWindow { int8_t reg, res_a, flag_a, res_b, flag_b; };
+__constant__ RoundWindow c_windows[5] = {
+    {S_INIT, S_INIT, 0, S_INIT, 1}, {S_UPD, S_UPD - 1, 0, S_UPD, 1}, {R_INIT, R_INIT - 1, 0, R_INIT, 1}, {R_UPD, R_UPD - 2, 0, R_UPD, 1},
+    {42, 42, 2, 0, -1}};
+
+__device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f) {
+    const fp flags[3] = {f.pv(P_SETUP), f.pv(P_HASH), f.pv(P_SCHNORR_HASH)};
+    fp ark2[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) ark2[j] = f.pv(P_ARK + 14 + j);
+#pragma unroll 1
+    for (int wdx = 0; wdx < 5; wdx++) {
+        const RoundWindow w = c_windows[wdx];
+        fp cube[14], d[14];
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            cube[j] = fp_cube(f.cur(w.reg + j));
+            d[j] = fp_sub(f.next(w.reg + j), ark2[j]);
+        }
+        Acc128 sa = acc_zero(), sb = acc_zero();
+#pragma unroll 1
+        for (int i = 0; i < 14; i++) {
+            const fp s1 = fp_add(dot14(c_mds + i * 14, cube), f.pv(P_ARK + i));
+            const fp s2 = fp_cube(dot14(c_inv_mds + i * 14, d));
+            const fp diff = fp_sub(s2, s1);
+            acc_mad(sa, acc.coef(w.res_a + i), diff);
+            if (w.flag_b >= 0) acc_mad(sb, acc.coef(w.res_b + i), diff);
+            if (i == 6) { acc_fold(sa); acc_fold(sb); }
+        }
+        acc_fold(sa);
+        acc_fold(sb);
+        const fp fa = w.flag_a == 0 ? flags[0] : w.flag_a == 1 ? flags[1] : flags[2];
+        acc.total = fp_add(acc.total, fp_mul(fa, acc_reduce(sa)));
+        if (w.flag_b >= 0) acc.total = fp_add(acc.total, fp_mul(flags[1], acc_reduce(sb)));
+    }
+}
+
+// doubling + conditional mixed addition for the point at registers [reg, reg + 19)
+__device__ __forceinline__ void fused_scalar_mult_step(Fused &acc, const Frame &f, int reg, const Fp6 &qx, const Fp6 &qy, fp doubling, fp addition) {
+    const Point p = {load6(f, reg, false), load6(f, reg + 6, false), load6(f, reg + 12, false)};
+    const fp bit = f.cur(reg + 18);
+    {
+        const Point d = ec_double(p);
+        acc.begin();
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc.term(reg + i, fp_sub(f.next(reg + i), d.x.c[i]));
+            acc.term(reg + 6 + i, fp_sub(f.next(reg + 6 + i), d.y.c[i]));
+            acc.term(reg + 12 + i, fp_sub(f.next(reg + 12 + i), d.z.c[i]));
+        }
+        acc.term(reg + 18, c_is_binary(bit));
+        acc.end(doubling);
+    }
+    {
+        // next - (bit * (p+q) + (1-bit) * p)  =  (next - p) - bit * ((p+q) - p)
+        const Point a = ec_add_mixed(p, qx, qy);
+        acc.begin();
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc.term(reg + i, fp_sub(fp_sub(f.next(reg + i), p.x.c[i]), fp_mul(bit, fp_sub(a.x.c[i], p.x.c[i]))));
+            acc.term(reg + 6 + i, fp_sub(fp_sub(f.next(reg + 6 + i), p.y.c[i]), fp_mul(bit, fp_sub(a.y.c[i], p.y.c[i]))));
+            acc.term(reg + 12 + i, fp_sub(fp_sub(f.next(reg + 12 + i), p.z.c[i]), fp_mul(bit, fp_sub(a.z.c[i], p.z.c[i]))));
+        }
+        acc.term(reg + 18, fp_sub(bit, f.next(reg + 18)));
+        acc.end(addition);
+    }
+}
+
+__device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &f, int base, fp tx_hash, fp hash_copy, fp hash_init) {
+    const fp bit = f.next(base + 14), not_bit = c_not(bit);
+    acc.begin();
+    acc.term(base + 14, c_is_binary(bit));
+    acc.end(tx_hash);
+    Acc128 s_copy = acc_zero(), s_init = acc_zero(); // two sections accumulated side by side (7 + 28 terms)
+    int cnt = 0;
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        const int b = base + 15 * k;
+#pragma unroll 1
+        for (int i = 0; i < 7; i++) {
+            const fp ci = f.cur(b + i), dd = fp_sub(ci, f.next(b + i));
+            const fp c0 = acc.coef(b + i);
+            acc_mad(s_copy, c0, dd);
+            acc_mad(s_init, c0, fp_mul(not_bit, dd));
+            acc_mad(s_init, acc.coef(b + 7 + i), fp_mul(bit, fp_sub(ci, f.next(b + 7 + i))));
+            cnt += 2;
+            if (cnt >= 6) { acc_fold(s_init); cnt = 0; }
+        }
+        acc_fold(s_copy);
+    }
+#pragma unroll 1
+    for (int i = 0; i < 14; i++) {
+        acc_mad(s_init, acc.coef(base + i), fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i))));
+        if ((i & 3) == 3) acc_fold(s_init);
+    }
+    acc_fold(s_init);
+    acc.total = fp_add(acc.total, fp_add(fp_mul(hash_copy, acc_reduce(s_copy)), fp_mul(hash_init, acc_reduce(s_init))));
+}
+
+__device__ __forceinline__ void fused_rest(Fused &acc, const Frame &f) {
+    const fp setup = f.pv(P_SETUP), tx_hash = f.pv(P_MERKLE), hash_input = f.pv(P_HASH_INPUT), finish = f.pv(P_FINISH), hash_flag = f.pv(P_HASH);
+    const fp schnorr_mask = f.pv(P_SCHNORR), scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING), schnorr_hash = f.pv(P_SCHNORR_HASH);
+    const fp range_flag = f.pv(P_RANGE_STEP), range_finish = f.pv(P_RANGE_FINISH), copy_values = f.pv(P_VALUE_COPY);
+    const fp copy_hash = fp_mul(c_not(schnorr_hash), schnorr_mask);
+    const fp final_add = fp_mul(c_not(scalar_mult), schnorr_mask);
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
+
+    // ---- flag: setup (src/air.rs:406-503)
+    const fp s_spent = fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12));
+    acc.begin();
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        acc.term(VALUE_RES + i, fp_sub(f.cur(S_INIT + i), f.cur(S_UPD + i)));
+        acc.term(VALUE_RES + 12 + i, fp_sub(f.cur(R_INIT + i), f.cur(R_UPD + i)));
+        acc.term(S_KEY_RES + i, fp_sub(f.next(S_KEY + i), f.cur(S_INIT + i)));
+        acc.term(R_KEY_RES + i, fp_sub(f.next(R_KEY + i), f.cur(R_INIT + i)));
+    }
+    acc.term(VALUE_RES + 24, fp_sub(f.cur(R_INIT + 13), f.cur(R_UPD + 13)));
+    acc.term(BALANCE_RES, fp_sub(s_spent, fp_sub(f.cur(R_UPD + 12), f.cur(R_INIT + 12))));
+    acc.term(NONCE_UPD_RES, fp_sub(f.cur(S_UPD + 13), fp_add(f.cur(S_INIT + 13), FP_ONE)));
+    acc.term(DELTA_COPY_RES, fp_sub(f.next(DELTA_COPY), s_spent));
+    acc.term(SIGMA_COPY_RES, fp_sub(f.next(SIGMA_COPY), f.cur(S_UPD + 12)));
+    acc.term(NONCE_COPY_RES, fp_sub(f.next(NONCE_COPY), f.cur(S_INIT + 13)));
+    acc.end(setup);
+    // ---- flag: copy_values (src/air.rs:506-529)
+    acc.begin();
+#pragma unroll 1
+    for (int o = 0; o < 12; o++) {
+        acc.term(S_KEY_RES + o, fp_sub(f.next(S_KEY + o), f.cur(S_KEY + o)));
+        acc.term(R_KEY_RES + o, fp_sub(f.next(R_KEY + o), f.cur(R_KEY + o)));
+    }
+    acc.term(DELTA_COPY_RES, fp_sub(f.next(DELTA_COPY), f.cur(DELTA_COPY)));
+    acc.term(SIGMA_COPY_RES, fp_sub(f.next(SIGMA_COPY), f.cur(SIGMA_COPY)));
+    acc.term(NONCE_COPY_RES, fp_sub(f.next(NONCE_COPY), f.cur(NONCE_COPY)));
+    acc.end(copy_values);
+    // ---- merkle::update without its rounds (src/merkle/update/air.rs:215-369)
+    {
+        const fp hash_copy = fp_mul(tx_hash, c_not(fp_add(hash_flag, hash_input)));
+        const fp hash_init = fp_mul(tx_hash, hash_input);
+        fused_merkle_auth_rest(acc, f, S_INIT, tx_hash, hash_copy, hash_init);
+        fused_merkle_auth_rest(acc, f, R_INIT, tx_hash, hash_copy, hash_init);
+    }
+    {
+        Acc128 s_nf = acc_zero(), s_f = acc_zero();
+#pragma unroll 1
+        for (int i = 0; i < 7; i++) {
+            const fp nr = f.next(PREV_ROOT + i), cr = f.cur(PREV_ROOT + i);
+            const fp c0 = acc.coef(PREV_ROOT + i);
+            acc_mad(s_nf, c0, fp_sub(nr, cr));
+            acc_mad(s_f, c0, fp_sub(nr, f.next(R_UPD + i)));
+            acc_mad(s_f, acc.coef(INT_ROOT_RES + i), fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)));
+            acc_mad(s_f, acc.coef(PREV_MATCH_RES + i), fp_sub(f.next(S_INIT + i), cr));
+            if (i & 1) acc_fold(s_f);
+        }
+        acc_fold(s_nf);
+        acc_fold(s_f);
+        acc.total = fp_add(acc.total, fp_add(fp_mul(c_not(finish), acc_reduce(s_nf)), fp_mul(finish, acc_reduce(s_f))));
+    }
+    // ---- schnorr linear parts (src/schnorr/air.rs:451-530)
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+        const fp dflag = f.pv(P_DIGEST + i);
+        const fp c = f.cur(41 - i), nx = f.next(41 - i);
+        const fp k41 = acc.coef(41 - i), k38 = acc.coef(38 + i);
+        fp t = fp_mul(fp_mul(dflag, doubling), fp_mul(k41, fp_sub(nx, fp_add(fp_dbl(c), f.next(37)))));
+        t = fp_add(t, fp_mul(fp_mul(c_not(dflag), doubling), fp_mul(k41, fp_sub(c, nx))));
+        t = fp_add(t, fp_mul(addition, fp_mul(k38, fp_sub(f.cur(38 + i), f.next(38 + i)))));
+        t = fp_add(t, fp_mul(final_add, fp_mul(k38, fp_sub(f.cur(38 + i), f.cur(42 + i)))));
+        acc.total = fp_add(acc.total, t);
+    }
+    acc.begin(); // enforce_hash_copy (:309-330) with the internal inputs of src/air.rs:543-565
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) {
+        acc.term(42 + i, fp_sub(f.cur(42 + i), f.next(42 + i)));
+        fp inp = 0;
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const int m = k * 7 + i;
+            const fp cell = m < 12 ? f.next(S_KEY + m) : m < 24 ? f.next(R_KEY + m - 12) : m == 24 ? f.next(DELTA_COPY) : m == 25 ? f.next(NONCE_COPY) : 0;
+            inp = fp_add(inp, fp_mul(f.pv(P_HASH_INTERNAL + k), cell));
+        }
+        acc.term(49 + i, fp_sub(f.next(49 + i), inp));
+    }
+    acc.end(copy_hash);
+    {   // final addition S + h*P with X reduced to affine (ecc.rs:146-172)
+        const Point sp = {load6(f, 0, false), load6(f, 6, false), load6(f, 12, false)};
+        const Point hp = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
+        const Point r = ec_add(sp, hp);
+        const Fp6 xz = mul6(load6(f, 0, true), r.z);
+        acc.begin();
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc.term(i, fp_sub(xz.c[i], r.x.c[i]));
+            acc.term(6 + i, fp_sub(f.next(6 + i), r.y.c[i]));
+            acc.term(12 + i, fp_sub(f.next(12 + i), r.z.c[i]));
+        }
+        acc.end(final_add);
+    }
+    {   // range proofs (src/air.rs:583-609)
+        const fp db = f.next(DELTA_BIT), sb = f.next(SIGMA_BIT);
+        acc.begin();
+        acc.term(DELTA_ACC, fp_sub(f.next(DELTA_ACC), fp_add(fp_dbl(f.cur(DELTA_ACC)), db)));
+        acc.term(DELTA_BIT, c_is_binary(db));
+        acc.term(SIGMA_ACC, fp_sub(f.next(SIGMA_ACC), fp_add(fp_dbl(f.cur(SIGMA_ACC)), sb)));
+        acc.term(SIGMA_BIT, c_is_binary(sb));
+        acc.end(range_flag);
+        const fp dr = fp_sub(f.next(DELTA_ACC), f.next(DELTA_COPY));
+        acc.begin();
+        acc.term(DELTA_RANGE_RES, dr);
+        acc.term(SIGMA_RANGE_RES, dr);
+        acc.end(range_finish);
+    }
+}
+
+// grid = (n / FNT, nk)
+template <int PART>
+__global__ __launch_bounds__(FNT) void k_eval_fused(CeParams p) {
+    __shared__ fp xp_lds[5 * FNT];
     const size_t n = (size_t)1 << p.log_n;
-    const size_t j = blockIdx.x * (size_t)NT + threadIdx.x;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kk = blockIdx.y;
     const Frame f = make_frame(p, kk, j);
-#pragma unroll
-    for (int g = 0; g < 6; g++) lds[g * NT + threadIdx.x] = 0;
-    AccFused acc{lds, p.coef, p.coef + 115};
-    evaluate_transition(acc, f);
-
     // x = shift_k * w_n^j and its powers (per-coset constants precomputed on the host)
     const fp *cc = p.coset + (size_t)(p.k0 + kk) * CE_COSET_CONSTS;
-    const fp wj = p.w[j];
-    const fp x = fp_mul(cc[0], wj);
-    fp t = lds[threadIdx.x];
+    const fp x = fp_mul(cc[0], p.w[j]);
 #pragma unroll
-    for (int g = 0; g < 5; g++) {
-        const fp xp = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
-        t = fp_add(t, fp_mul(xp, lds[(1 + g) * NT + threadIdx.x]));
+    for (int g = 0; g < 5; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
+    Fused acc{p.coef, p.coef + 115, xp_lds, acc_zero(), 0, 0};
+
+    if (PART == PART_ROUNDS) fused_rounds(acc, f);
+    if (PART == PART_EC0 || PART == PART_EC1) {
+        const fp scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING);
+        const fp addition = fp_mul(c_not(doubling), scalar_mult);
+        if (PART == PART_EC0) {
+            fused_scalar_mult_step(acc, f, 0, const6(c_generator), const6(c_generator + 6), doubling, addition);
+        } else {
+            fused_scalar_mult_step(acc, f, 19, load6(f, S_KEY, true), load6(f, S_KEY + 6, true), doubling, addition); // pkey, src/air.rs:575
+        }
     }
+    if (PART == PART_REST) fused_rest(acc, f);
+
     // transition divisor (x^n - 1) / (x - w^(n-1)); x^n is constant on a coset
-    t = fp_mul(t, fp_mul(fp_sub(x, p.w_last), cc[1]));
-    // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184)
-    const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
-    const fp *ba = p.coef + 230, *bb = p.coef + 234;
-    const fp r58 = f.cur(58), r59 = f.cur(59);
-    fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
-    fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
-    const fp d0 = fp_sub(x, FP_ONE), d1 = fp_sub(x, p.w_last);
-    const fp inv01 = fp_inv(fp_mul(d0, d1)); // one inversion for both divisors
-    t = fp_add(t, fp_mul(first, fp_mul(inv01, d1)));
-    t = fp_add(t, fp_mul(last, fp_mul(inv01, d0)));
-    p.out[(size_t)kk * n + j] = t;
+    fp t = fp_mul(acc.total, fp_mul(fp_sub(x, p.w_last), cc[1]));
+    fp *o = p.out + (size_t)kk * n + j;
+    if (PART == PART_REST) {
+        // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184)
+        const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
+        const fp *ba = p.coef + 230, *bb = p.coef + 234;
+        const fp r58 = f.cur(58), r59 = f.cur(59);
+        const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
+        const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
+        const fp d0 = fp_sub(x, FP_ONE), d1 = fp_sub(x, p.w_last);
+        const fp inv01 = fp_inv(fp_mul(d0, d1)); // one inversion for both divisors
+        t = fp_add(t, fp_mul(first, fp_mul(inv01, d1)));
+        t = fp_add(t, fp_mul(last, fp_mul(inv01, d0)));
+    }
+    *o = PART == PART_ROUNDS ? t : fp_add(*o, t); // ROUNDS is launched first, the others accumulate in stream order
 }
 
 } // namespace
@@ -394,7 +647,11 @@ hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t s
 }
 hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    hipLaunchKernelGGL(k_eval_constraints, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, p);
+    const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
+    hipLaunchKernelGGL(k_eval_fused<PART_ROUNDS>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_EC0>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_EC1>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_REST>, grid, block, 0, stream, p);
     return hipGetLastError();
 }
 

@@ -92,3 +92,48 @@ __device__ __forceinline__ fp fp_mul_small(fp a, int c) {
 }
 
 } // namespace cs
+
+// ---- lazy (unreduced) 128-bit accumulation ------------------------------------------------------------
+// Sums of products of reduced elements are accumulated in 128 bits and Montgomery-reduced once.  A product
+// of two reduced elements is < p^2 < 2^124.07, so seven of them fit below 2^126.9; `fold()` brings the
+// accumulator back under 2p * 2^64 (< 2^127.04) so that another seven terms can be added without overflow.
+namespace cs {
+
+struct Acc128 {
+    uint64_t lo, hi;
+};
+
+__device__ __forceinline__ Acc128 acc_zero() { return {0, 0}; }
+
+// acc += a * b  (full 128-bit product, no reduction)
+__device__ __forceinline__ void acc_mad(Acc128 &acc, uint64_t a, uint64_t b) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t t0 = (uint64_t)a0 * b0;
+    const uint64_t t1 = mad_u64_u32(a1, b0, t0 >> 32);
+    const uint64_t t2 = mad_u64_u32(a0, b1, (uint32_t)t1);
+    const uint64_t t3 = mad_u64_u32(a1, b1, (t1 >> 32) + (t2 >> 32));
+    const uint64_t plo = (t2 << 32) | (uint32_t)t0;
+    const uint64_t lo = acc.lo + plo;
+    acc.hi += t3 + (lo < plo);
+    acc.lo = lo;
+}
+// keep the value (mod p * 2^64 multiples are free: they vanish after reduction) below 2p * 2^64
+__device__ __forceinline__ void acc_fold(Acc128 &acc) {
+    if (acc.hi >= 2 * FP_P) acc.hi -= 2 * FP_P;
+}
+// Montgomery reduction of an accumulator < 2^127.04 to a fully reduced element
+__device__ __forceinline__ fp acc_reduce(const Acc128 &acc) {
+    const uint32_t t0 = (uint32_t)acc.lo, t1 = (uint32_t)(acc.lo >> 32);
+    const uint32_t m = 0u - t0;
+    // (acc + m * p) / 2^32 : the low word cancels, leaving a carry
+    const uint64_t v = mad_u64_u32(m, FP_P1, (uint64_t)t1 + (t0 != 0u)); // words 1.. of the low half
+    const uint32_t v0 = (uint32_t)v;
+    const uint32_t m2 = 0u - v0;
+    // next word: v0 + m2 = 2^32 * (v0 != 0)
+    uint64_t r = acc.hi + (v >> 32) + (v0 != 0u);
+    r = mad_u64_u32(m2, FP_P1, r); // < 2^63.6 + 2^62.04 < 2^64
+    if (r >= 2 * FP_P) r -= 2 * FP_P;
+    return fp_reduce_once(r);
+}
+
+} // namespace cs
