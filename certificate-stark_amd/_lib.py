@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcstark_hip.so")
+LIB_PATH = os.environ.get("CSTARK_LIB") or os.path.join(HERE, "libcstark_hip.so")  # CSTARK_LIB: tuning variants
 
 TX_TRACE_WIDTH, TX_CYCLE_LENGTH, TX_NUM_CONSTRAINTS, TX_NUM_PERIODIC = 94, 1024, 115, 48
 

@@ -31,6 +31,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines):
+    """Tuning helper: compile the whole library with extra -D flags into libcstark_hip_<name>.so (not used by the product)."""
+    out = os.path.join(HERE, "libcstark_hip_%s.so" % name)
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
+    cmd = [hipcc()] + FLAGS + ["-D" + d for d in defines] + ["-shared", "-o", out] + srcs
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cuh"))]

@@ -48,6 +48,7 @@ struct PeriodicTable {
     unsigned depth, log_n, log_b;
     uint64_t *tab;   // [b][48][1024]
     uint64_t *coset; // [b][CE_COSET_CONSTS]
+    uint64_t *binv;  // [b][2][n] inverses of the boundary divisors
 };
 
 } // namespace
@@ -158,7 +159,7 @@ int get_periodic(cstark_ctx *c, unsigned depth, unsigned log_n, unsigned log_b, 
     std::vector<uint64_t> cols;
     if (!cs::host::tx_periodic_columns(depth, cols)) return fail(CSTARK_ERR_INVALID_ARG, "unsupported Merkle depth");
     const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b, C = cs::host::TX_CYCLE, NP = cs::host::TX_NUM_PERIODIC;
-    PeriodicTable t{depth, log_n, log_b, nullptr, nullptr};
+    PeriodicTable t{depth, log_n, log_b, nullptr, nullptr, nullptr};
     uint64_t *d_cols = nullptr, *d_poly = nullptr;
     HIP_TRY(hipMalloc((void **)&d_cols, NP * C * 8));
     HIP_TRY(hipMalloc((void **)&d_poly, NP * C * 8));
@@ -182,6 +183,10 @@ int get_periodic(cstark_ctx *c, unsigned depth, unsigned log_n, unsigned log_b, 
         shift = cs::host::mul(shift, wbn);
     }
     HIP_TRY(hipMemcpyAsync(t.coset, cc.data(), cc.size() * 8, hipMemcpyHostToDevice, c->stream));
+    const NttPlan *plan;
+    RC_TRY(get_plan(c, log_n, &plan));
+    HIP_TRY(hipMalloc((void **)&t.binv, b * 2 * n * 8));
+    HIP_TRY(cs::build_boundary_inverses(t.binv, plan->w, t.coset, cs::host::inv(cs::host::root_of_unity(log_n)), log_n, log_b, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream)); // cc / cols go out of scope
     HIP_TRY(hipFree(d_cols));
     HIP_TRY(hipFree(d_poly));
@@ -203,7 +208,7 @@ int ce_params(cstark_ctx *c, const uint64_t *d_lde, uint64_t *d_out, uint32_t me
     RC_TRY(get_plan(c, log_n, &plan));
     const uint64_t n = 1ull << log_n, ce = n << log_blowup;
     *p = cs::CeParams{};
-    p->lde = d_lde; p->ptab = pt->tab; p->w = plan->w; p->coset = pt->coset; p->out = d_out;
+    p->lde = d_lde; p->ptab = pt->tab; p->w = plan->w; p->coset = pt->coset; p->binv = pt->binv; p->out = d_out;
     p->w_last = cs::host::inv(cs::host::root_of_unity(log_n));
     for (int g = 0; g < 5; g++) p->adj_mod_n[g] = (uint32_t)(cs::host::tx_group_adjustment(g, n, ce) & (n - 1));
     p->badj_mod_n = (uint32_t)(cs::host::tx_boundary_adjustment(n, ce) & (n - 1));
@@ -243,7 +248,7 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     if (c->coef_buf) (void)hipFree(c->coef_buf);
     for (NttPlan &p : c->plans) { (void)hipFree(p.w); (void)hipFree(p.winv); }
     for (CosetTable &t : c->cosets) (void)hipFree(t.s);
-    for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); }
+    for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); (void)hipFree(t.binv); }
     delete c;
 }
 

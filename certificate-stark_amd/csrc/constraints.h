@@ -23,6 +23,7 @@ struct CeParams {
     const uint64_t *w;     // [n] powers of w_n
     const uint64_t *coset; // [b][CE_COSET_CONSTS]
     const uint64_t *coef;  // alpha[115] | beta[115] | b_alpha[4] | b_beta[4]   (device)
+    const uint64_t *binv;  // [b][2][n]: 1/(x-1), 1/(x-w^(n-1)) over the evaluation domain
     uint64_t *out;
     uint64_t pub[4];       // initial_root[0..2], final_root[0..2]
     uint64_t w_last;       // w_n^(n-1)
@@ -33,5 +34,7 @@ struct CeParams {
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);
 hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream);
+hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,
+                                   hipStream_t stream);
 
 } // namespace cs

@@ -85,7 +85,19 @@ __device__ __forceinline__ void enforce_round(Acc &acc, const Frame &f, int reg,
 
 // ---- curve gadgets (ecc.rs:73-172).  F_p6 products are real calls to keep the kernel inside the
 // instruction cache: the five gadgets contain 69 of them.
+#ifdef CS_EC_NOINLINE
 __device__ __noinline__ Fp6 mul6(const Fp6 a, const Fp6 b) { return fp6_mul(a, b); }
+#else
+__device__ __forceinline__ Fp6 mul6(const Fp6 &a, const Fp6 &b) { return fp6_mul(a, b); }
+#endif
+// the parity/debug kernel keeps everything in one launch and must stay compact: always a call there
+__device__ __noinline__ Fp6 mul6_call(const Fp6 a, const Fp6 b) { return fp6_mul(a, b); }
+
+template <bool CALL>
+__device__ __forceinline__ Fp6 MUL6_SEL(const Fp6 &a, const Fp6 &b) {
+    if constexpr (CALL) return mul6_call(a, b);
+    else return mul6(a, b);
+}
 
 struct Point { Fp6 x, y, z; };
 
@@ -97,7 +109,9 @@ __device__ __forceinline__ Fp6 load6(const Frame &f, int reg, bool next) {
 }
 __device__ __forceinline__ Fp6 const6(const fp *p) { return fp6_load(p); }
 
-__device__ __forceinline__ Point ec_double(const Point &p) { // complete doubling, ecc.rs:177-242
+template <bool CALL>
+__device__ __forceinline__ Point ec_double(const Point &p) {
+#define mul6 MUL6_SEL<CALL> // complete doubling, ecc.rs:177-242
     const Fp6 b3 = const6(c_b3);
     Fp6 t0 = mul6(p.x, p.x), t1 = mul6(p.y, p.y), t2 = mul6(p.z, p.z);
     Fp6 t3 = fp6_dbl(mul6(p.x, p.y));
@@ -115,8 +129,11 @@ __device__ __forceinline__ Point ec_double(const Point &p) { // complete doublin
     x3 = fp6_sub(x3, mul6(t2, t3));
     z3 = fp6_dbl(fp6_dbl(mul6(t2, t1)));
     return {x3, y3, z3};
+#undef mul6
 }
-__device__ __forceinline__ Point ec_add_mixed(const Point &p, const Fp6 &qx, const Fp6 &qy) { // ecc.rs:330-404
+template <bool CALL>
+__device__ __forceinline__ Point ec_add_mixed(const Point &p, const Fp6 &qx, const Fp6 &qy) {
+#define mul6 MUL6_SEL<CALL> // ecc.rs:330-404
     const Fp6 b3 = const6(c_b3);
     Fp6 t0 = mul6(p.x, qx), t1 = mul6(p.y, qy);
     Fp6 t3 = fp6_sub(mul6(fp6_add(qx, qy), fp6_add(p.x, p.y)), fp6_add(t0, t1));
@@ -132,8 +149,11 @@ __device__ __forceinline__ Point ec_add_mixed(const Point &p, const Fp6 &qx, con
     x3 = fp6_sub(mul6(t3, x3), mul6(t5, t4));
     z3 = fp6_add(mul6(t5, z3), mul6(t3, t1));
     return {x3, y3, z3};
+#undef mul6
 }
-__device__ __forceinline__ Point ec_add(const Point &p, const Point &q) { // ecc.rs:244-328
+template <bool CALL>
+__device__ __forceinline__ Point ec_add(const Point &p, const Point &q) {
+#define mul6 MUL6_SEL<CALL> // ecc.rs:244-328
     const Fp6 b3 = const6(c_b3);
     Fp6 t0 = mul6(p.x, q.x), t1 = mul6(p.y, q.y), t2 = mul6(p.z, q.z);
     Fp6 t3 = fp6_sub(mul6(fp6_add(p.x, p.y), fp6_add(q.x, q.y)), fp6_add(t0, t1));
@@ -149,6 +169,7 @@ __device__ __forceinline__ Point ec_add(const Point &p, const Point &q) { // ecc
     x3 = fp6_sub(mul6(t3, x3), mul6(t5, t4));
     z3 = fp6_add(mul6(t5, z3), mul6(t3, t1));
     return {x3, y3, z3};
+#undef mul6
 }
 
 // doubling + conditional mixed addition constraints for the point at registers [reg, reg+19)
@@ -157,7 +178,7 @@ __device__ __forceinline__ void enforce_scalar_mult_step(Acc &acc, const Frame &
     const Point p = {load6(f, reg, false), load6(f, reg + 6, false), load6(f, reg + 12, false)};
     const fp bit = f.cur(reg + 18);
     {   // enforce_point_doubling ecc.rs:73-98
-        const Point d = ec_double(p);
+        const Point d = ec_double<true>(p);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             acc.add(reg + i, doubling, fp_sub(f.next(reg + i), d.x.c[i]));
@@ -167,7 +188,7 @@ __device__ __forceinline__ void enforce_scalar_mult_step(Acc &acc, const Frame &
         acc.add(reg + 18, doubling, c_is_binary(bit));
     }
     {   // enforce_point_addition_mixed ecc.rs:102-138: next = bit * (p + q) + (1 - bit) * p
-        const Point a = ec_add_mixed(p, qx, qy);
+        const Point a = ec_add_mixed<true>(p, qx, qy);
         const fp nb = c_not(bit);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -292,8 +313,8 @@ __device__ __forceinline__ void evaluate_transition(Acc &acc, const Frame &f) {
     {   // final addition S + h*P with X reduced to affine (ecc.rs:146-172)
         const Point s = {load6(f, 0, false), load6(f, 6, false), load6(f, 12, false)};
         const Point hp = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
-        const Point r = ec_add(s, hp);
-        const Fp6 xz = mul6(load6(f, 0, true), r.z);
+        const Point r = ec_add<true>(s, hp);
+        const Fp6 xz = mul6_call(load6(f, 0, true), r.z);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             acc.add(i, final_add, fp_sub(xz.c[i], r.x.c[i]));
@@ -344,7 +365,11 @@ __global__ __launch_bounds__(NT) void k_eval_transitions(CeParams p) {
 // using one 128-bit lazy accumulator per (gadget, flag) section, multiplies by 1/Z(x) and adds its share to
 // the output.  Exact arithmetic: the sum of the parts equals the reference's merged evaluation.
 constexpr int FNT = 256;
-enum { PART_ROUNDS = 0, PART_EC0 = 1, PART_EC1 = 2, PART_REST = 3 };
+#ifndef CS_ROUNDS_UNROLL
+#define CS_ROUNDS_UNROLL 1
+#endif
+constexpr int ROUNDS_UNROLL = CS_ROUNDS_UNROLL;
+enum { PART_ROUNDS = 0, PART_DBL0, PART_ADD0, PART_DBL1, PART_ADD1, PART_FINAL, PART_LIN_A, PART_LIN_B, PART_LIN_C, NUM_PARTS };
 
 struct Fused {
     const fp *alpha, *beta; // uniform
@@ -414,35 +439,50 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f) {
     }
 }
 
-// doubling + conditional mixed addition for the point at registers [reg, reg + 19)
-__device__ __forceinline__ void fused_scalar_mult_step(Fused &acc, const Frame &f, int reg, const Fp6 &qx, const Fp6 &qy, fp doubling, fp addition) {
+// doubling gadget for the point at registers [reg, reg + 19)  (ecc.rs:73-98)
+__device__ __forceinline__ void fused_doubling(Fused &acc, const Frame &f, int reg, fp doubling) {
+    const Point p = {load6(f, reg, false), load6(f, reg + 6, false), load6(f, reg + 12, false)};
+    const Point d = ec_double<false>(p);
+    acc.begin();
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        acc.term(reg + i, fp_sub(f.next(reg + i), d.x.c[i]));
+        acc.term(reg + 6 + i, fp_sub(f.next(reg + 6 + i), d.y.c[i]));
+        acc.term(reg + 12 + i, fp_sub(f.next(reg + 12 + i), d.z.c[i]));
+    }
+    acc.term(reg + 18, c_is_binary(f.cur(reg + 18)));
+    acc.end(doubling);
+}
+// conditional mixed addition gadget (ecc.rs:102-138):
+//   next - (bit * (p+q) + (1-bit) * p)  =  (next - p) - bit * ((p+q) - p)
+__device__ __forceinline__ void fused_addition(Fused &acc, const Frame &f, int reg, const Fp6 &qx, const Fp6 &qy, fp addition) {
     const Point p = {load6(f, reg, false), load6(f, reg + 6, false), load6(f, reg + 12, false)};
     const fp bit = f.cur(reg + 18);
-    {
-        const Point d = ec_double(p);
-        acc.begin();
+    const Point a = ec_add_mixed<false>(p, qx, qy);
+    acc.begin();
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            acc.term(reg + i, fp_sub(f.next(reg + i), d.x.c[i]));
-            acc.term(reg + 6 + i, fp_sub(f.next(reg + 6 + i), d.y.c[i]));
-            acc.term(reg + 12 + i, fp_sub(f.next(reg + 12 + i), d.z.c[i]));
-        }
-        acc.term(reg + 18, c_is_binary(bit));
-        acc.end(doubling);
+    for (int i = 0; i < 6; i++) {
+        acc.term(reg + i, fp_sub(fp_sub(f.next(reg + i), f.cur(reg + i)), fp_mul(bit, fp_sub(a.x.c[i], f.cur(reg + i)))));
+        acc.term(reg + 6 + i, fp_sub(fp_sub(f.next(reg + 6 + i), f.cur(reg + 6 + i)), fp_mul(bit, fp_sub(a.y.c[i], f.cur(reg + 6 + i)))));
+        acc.term(reg + 12 + i, fp_sub(fp_sub(f.next(reg + 12 + i), f.cur(reg + 12 + i)), fp_mul(bit, fp_sub(a.z.c[i], f.cur(reg + 12 + i)))));
     }
-    {
-        // next - (bit * (p+q) + (1-bit) * p)  =  (next - p) - bit * ((p+q) - p)
-        const Point a = ec_add_mixed(p, qx, qy);
-        acc.begin();
+    acc.term(reg + 18, fp_sub(bit, f.next(reg + 18)));
+    acc.end(addition);
+}
+// final addition S + h*P with X reduced to affine (ecc.rs:146-172)
+__device__ __forceinline__ void fused_final_addition(Fused &acc, const Frame &f, fp final_add) {
+    const Point sp = {load6(f, 0, false), load6(f, 6, false), load6(f, 12, false)};
+    const Point hp = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
+    const Point r = ec_add<false>(sp, hp);
+    const Fp6 xz = mul6(load6(f, 0, true), r.z);
+    acc.begin();
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            acc.term(reg + i, fp_sub(fp_sub(f.next(reg + i), p.x.c[i]), fp_mul(bit, fp_sub(a.x.c[i], p.x.c[i]))));
-            acc.term(reg + 6 + i, fp_sub(fp_sub(f.next(reg + 6 + i), p.y.c[i]), fp_mul(bit, fp_sub(a.y.c[i], p.y.c[i]))));
-            acc.term(reg + 12 + i, fp_sub(fp_sub(f.next(reg + 12 + i), p.z.c[i]), fp_mul(bit, fp_sub(a.z.c[i], p.z.c[i]))));
-        }
-        acc.term(reg + 18, fp_sub(bit, f.next(reg + 18)));
-        acc.end(addition);
+    for (int i = 0; i < 6; i++) {
+        acc.term(i, fp_sub(xz.c[i], r.x.c[i]));
+        acc.term(6 + i, fp_sub(f.next(6 + i), r.y.c[i]));
+        acc.term(12 + i, fp_sub(f.next(12 + i), r.z.c[i]));
     }
+    acc.end(final_add);
 }
 
 __device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &f, int base, fp tx_hash, fp hash_copy, fp hash_init) {
@@ -452,10 +492,10 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &
     acc.end(tx_hash);
     Acc128 s_copy = acc_zero(), s_init = acc_zero(); // two sections accumulated side by side (7 + 28 terms)
     int cnt = 0;
-#pragma unroll 1
+#pragma unroll
     for (int k = 0; k < 2; k++) {
         const int b = base + 15 * k;
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < 7; i++) {
             const fp ci = f.cur(b + i), dd = fp_sub(ci, f.next(b + i));
             const fp c0 = acc.coef(b + i);
@@ -467,7 +507,7 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &
         }
         acc_fold(s_copy);
     }
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 14; i++) {
         acc_mad(s_init, acc.coef(base + i), fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i))));
         if ((i & 3) == 3) acc_fold(s_init);
@@ -476,18 +516,13 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &
     acc.total = fp_add(acc.total, fp_add(fp_mul(hash_copy, acc_reduce(s_copy)), fp_mul(hash_init, acc_reduce(s_init))));
 }
 
-__device__ __forceinline__ void fused_rest(Fused &acc, const Frame &f) {
-    const fp setup = f.pv(P_SETUP), tx_hash = f.pv(P_MERKLE), hash_input = f.pv(P_HASH_INPUT), finish = f.pv(P_FINISH), hash_flag = f.pv(P_HASH);
-    const fp schnorr_mask = f.pv(P_SCHNORR), scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING), schnorr_hash = f.pv(P_SCHNORR_HASH);
-    const fp range_flag = f.pv(P_RANGE_STEP), range_finish = f.pv(P_RANGE_FINISH), copy_values = f.pv(P_VALUE_COPY);
-    const fp copy_hash = fp_mul(c_not(schnorr_hash), schnorr_mask);
-    const fp final_add = fp_mul(c_not(scalar_mult), schnorr_mask);
-    const fp addition = fp_mul(c_not(doubling), scalar_mult);
-
+// setup + value-copy constraints (src/air.rs:406-529)
+__device__ __forceinline__ void fused_linear_a(Fused &acc, const Frame &f) {
+    const fp setup = f.pv(P_SETUP), copy_values = f.pv(P_VALUE_COPY);
     // ---- flag: setup (src/air.rs:406-503)
     const fp s_spent = fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12));
     acc.begin();
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 12; i++) {
         acc.term(VALUE_RES + i, fp_sub(f.cur(S_INIT + i), f.cur(S_UPD + i)));
         acc.term(VALUE_RES + 12 + i, fp_sub(f.cur(R_INIT + i), f.cur(R_UPD + i)));
@@ -503,7 +538,7 @@ __device__ __forceinline__ void fused_rest(Fused &acc, const Frame &f) {
     acc.end(setup);
     // ---- flag: copy_values (src/air.rs:506-529)
     acc.begin();
-#pragma unroll 1
+#pragma unroll
     for (int o = 0; o < 12; o++) {
         acc.term(S_KEY_RES + o, fp_sub(f.next(S_KEY + o), f.cur(S_KEY + o)));
         acc.term(R_KEY_RES + o, fp_sub(f.next(R_KEY + o), f.cur(R_KEY + o)));
@@ -512,16 +547,20 @@ __device__ __forceinline__ void fused_rest(Fused &acc, const Frame &f) {
     acc.term(SIGMA_COPY_RES, fp_sub(f.next(SIGMA_COPY), f.cur(SIGMA_COPY)));
     acc.term(NONCE_COPY_RES, fp_sub(f.next(NONCE_COPY), f.cur(NONCE_COPY)));
     acc.end(copy_values);
+}
+// merkle::update without its rounds (src/merkle/update/air.rs:215-369)
+__device__ __forceinline__ void fused_linear_b(Fused &acc, const Frame &f) {
+    const fp tx_hash = f.pv(P_MERKLE), hash_input = f.pv(P_HASH_INPUT), finish = f.pv(P_FINISH), hash_flag = f.pv(P_HASH);
     // ---- merkle::update without its rounds (src/merkle/update/air.rs:215-369)
     {
         const fp hash_copy = fp_mul(tx_hash, c_not(fp_add(hash_flag, hash_input)));
         const fp hash_init = fp_mul(tx_hash, hash_input);
-        fused_merkle_auth_rest(acc, f, S_INIT, tx_hash, hash_copy, hash_init);
-        fused_merkle_auth_rest(acc, f, R_INIT, tx_hash, hash_copy, hash_init);
+#pragma unroll 1
+        for (int blk = 0; blk < 2; blk++) fused_merkle_auth_rest(acc, f, blk == 0 ? S_INIT : R_INIT, tx_hash, hash_copy, hash_init);
     }
     {
         Acc128 s_nf = acc_zero(), s_f = acc_zero();
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < 7; i++) {
             const fp nr = f.next(PREV_ROOT + i), cr = f.cur(PREV_ROOT + i);
             const fp c0 = acc.coef(PREV_ROOT + i);
@@ -535,8 +574,16 @@ __device__ __forceinline__ void fused_rest(Fused &acc, const Frame &f) {
         acc_fold(s_f);
         acc.total = fp_add(acc.total, fp_add(fp_mul(c_not(finish), acc_reduce(s_nf)), fp_mul(finish, acc_reduce(s_f))));
     }
+}
+// schnorr linear parts, hash copy, range proofs (src/schnorr/air.rs:451-530, src/air.rs:543-609)
+__device__ __forceinline__ void fused_linear_c(Fused &acc, const Frame &f) {
+    const fp schnorr_mask = f.pv(P_SCHNORR), scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING), schnorr_hash = f.pv(P_SCHNORR_HASH);
+    const fp range_flag = f.pv(P_RANGE_STEP), range_finish = f.pv(P_RANGE_FINISH);
+    const fp copy_hash = fp_mul(c_not(schnorr_hash), schnorr_mask);
+    const fp final_add = fp_mul(c_not(scalar_mult), schnorr_mask);
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
     // ---- schnorr linear parts (src/schnorr/air.rs:451-530)
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 4; i++) {
         const fp dflag = f.pv(P_DIGEST + i);
         const fp c = f.cur(41 - i), nx = f.next(41 - i);
@@ -548,11 +595,11 @@ __device__ __forceinline__ void fused_rest(Fused &acc, const Frame &f) {
         acc.total = fp_add(acc.total, t);
     }
     acc.begin(); // enforce_hash_copy (:309-330) with the internal inputs of src/air.rs:543-565
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 7; i++) {
         acc.term(42 + i, fp_sub(f.cur(42 + i), f.next(42 + i)));
         fp inp = 0;
-#pragma unroll 1
+#pragma unroll
         for (int k = 0; k < 4; k++) {
             const int m = k * 7 + i;
             const fp cell = m < 12 ? f.next(S_KEY + m) : m < 24 ? f.next(R_KEY + m - 12) : m == 24 ? f.next(DELTA_COPY) : m == 25 ? f.next(NONCE_COPY) : 0;
@@ -561,20 +608,6 @@ __device__ __forceinline__ void fused_rest(Fused &acc, const Frame &f) {
         acc.term(49 + i, fp_sub(f.next(49 + i), inp));
     }
     acc.end(copy_hash);
-    {   // final addition S + h*P with X reduced to affine (ecc.rs:146-172)
-        const Point sp = {load6(f, 0, false), load6(f, 6, false), load6(f, 12, false)};
-        const Point hp = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
-        const Point r = ec_add(sp, hp);
-        const Fp6 xz = mul6(load6(f, 0, true), r.z);
-        acc.begin();
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            acc.term(i, fp_sub(xz.c[i], r.x.c[i]));
-            acc.term(6 + i, fp_sub(f.next(6 + i), r.y.c[i]));
-            acc.term(12 + i, fp_sub(f.next(12 + i), r.z.c[i]));
-        }
-        acc.end(final_add);
-    }
     {   // range proofs (src/air.rs:583-609)
         const fp db = f.next(DELTA_BIT), sb = f.next(SIGMA_BIT);
         acc.begin();
@@ -592,8 +625,14 @@ __device__ __forceinline__ void fused_rest(Fused &acc, const Frame &f) {
 }
 
 // grid = (n / FNT, nk)
+#ifndef CS_ROUNDS_WAVES
+#define CS_ROUNDS_WAVES 2
+#endif
+#ifndef CS_ROUNDS_UNROLL
+#define CS_ROUNDS_UNROLL 1
+#endif
 template <int PART>
-__global__ __launch_bounds__(FNT) void k_eval_fused(CeParams p) {
+__global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : 2) void k_eval_fused(CeParams p) {
     __shared__ fp xp_lds[5 * FNT];
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
@@ -607,31 +646,33 @@ __global__ __launch_bounds__(FNT) void k_eval_fused(CeParams p) {
     Fused acc{p.coef, p.coef + 115, xp_lds, acc_zero(), 0, 0};
 
     if (PART == PART_ROUNDS) fused_rounds(acc, f);
-    if (PART == PART_EC0 || PART == PART_EC1) {
+    if (PART >= PART_DBL0 && PART <= PART_FINAL) {
         const fp scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING);
-        const fp addition = fp_mul(c_not(doubling), scalar_mult);
-        if (PART == PART_EC0) {
-            fused_scalar_mult_step(acc, f, 0, const6(c_generator), const6(c_generator + 6), doubling, addition);
-        } else {
-            fused_scalar_mult_step(acc, f, 19, load6(f, S_KEY, true), load6(f, S_KEY + 6, true), doubling, addition); // pkey, src/air.rs:575
-        }
+        if (PART == PART_DBL0) fused_doubling(acc, f, 0, doubling);
+        if (PART == PART_DBL1) fused_doubling(acc, f, 19, doubling);
+        if (PART == PART_ADD0) fused_addition(acc, f, 0, const6(c_generator), const6(c_generator + 6), fp_mul(c_not(doubling), scalar_mult));
+        if (PART == PART_ADD1) // pkey = next[S_KEY..], src/air.rs:575
+            fused_addition(acc, f, 19, load6(f, S_KEY, true), load6(f, S_KEY + 6, true), fp_mul(c_not(doubling), scalar_mult));
+        if (PART == PART_FINAL) fused_final_addition(acc, f, fp_mul(c_not(scalar_mult), f.pv(P_SCHNORR)));
     }
-    if (PART == PART_REST) fused_rest(acc, f);
+    if (PART == PART_LIN_A) fused_linear_a(acc, f);
+    if (PART == PART_LIN_B) fused_linear_b(acc, f);
+    if (PART == PART_LIN_C) fused_linear_c(acc, f);
 
     // transition divisor (x^n - 1) / (x - w^(n-1)); x^n is constant on a coset
     fp t = fp_mul(acc.total, fp_mul(fp_sub(x, p.w_last), cc[1]));
     fp *o = p.out + (size_t)kk * n + j;
-    if (PART == PART_REST) {
+    if (PART == PART_LIN_C) {
         // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184)
         const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
         const fp *ba = p.coef + 230, *bb = p.coef + 234;
         const fp r58 = f.cur(58), r59 = f.cur(59);
         const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
         const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
-        const fp d0 = fp_sub(x, FP_ONE), d1 = fp_sub(x, p.w_last);
-        const fp inv01 = fp_inv(fp_mul(d0, d1)); // one inversion for both divisors
-        t = fp_add(t, fp_mul(first, fp_mul(inv01, d1)));
-        t = fp_add(t, fp_mul(last, fp_mul(inv01, d0)));
+        // 1/(x - 1) and 1/(x - w^(n-1)) depend on the domain only: cached tables
+        const fp *bi = p.binv + (size_t)(p.k0 + kk) * 2 * n + j;
+        t = fp_add(t, fp_mul(first, bi[0]));
+        t = fp_add(t, fp_mul(last, bi[n]));
     }
     *o = PART == PART_ROUNDS ? t : fp_add(*o, t); // ROUNDS is launched first, the others accumulate in stream order
 }
@@ -649,9 +690,32 @@ hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t s
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
     hipLaunchKernelGGL(k_eval_fused<PART_ROUNDS>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_EC0>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_EC1>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_REST>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_DBL0>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_ADD0>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_DBL1>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_ADD1>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_FINAL>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_LIN_A>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_LIN_B>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART_LIN_C>, grid, block, 0, stream, p);
+    return hipGetLastError();
+}
+
+// table[k][0][j] = 1 / (x - 1), table[k][1][j] = 1 / (x - w^(n-1)), x = shift_k * w^j   (grid = (n / 256, b))
+__global__ void k_boundary_inverses(fp *table, const fp *w, const fp *coset, fp w_last, unsigned log_n) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const unsigned k = blockIdx.y;
+    const fp x = fp_mul(coset[(size_t)k * CE_COSET_CONSTS], w[j]);
+    const fp d0 = fp_sub(x, FP_ONE), d1 = fp_sub(x, w_last);
+    const fp inv01 = fp_inv(fp_mul(d0, d1)); // one inversion for both
+    table[((size_t)k * 2 + 0) * n + j] = fp_mul(inv01, d1);
+    table[((size_t)k * 2 + 1) * n + j] = fp_mul(inv01, d0);
+}
+hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,
+                                   hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_boundary_inverses, dim3((unsigned)(n / 256), 1u << log_b), dim3(256), 0, stream, d_table, d_w, d_coset, w_last, log_n);
     return hipGetLastError();
 }
 
