@@ -122,7 +122,7 @@ int interpolate_impl(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint3
     cs::NttArgs a{};
     a.in = d_evals; a.scratch = d_evals; a.out = d_coeffs;
     a.width = width; a.batch = 1; a.log_n = log_n;
-    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true;
+    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true; a.inverse = true;
     HIP_TRY(cs::ntt_columns(a, c->stream));
     return CSTARK_OK;
 }

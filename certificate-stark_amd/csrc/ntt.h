@@ -19,6 +19,7 @@ struct NttArgs {
     size_t prescale_batch_stride;
     uint64_t post_scale;       // applied to every output when do_scale (n^-1 for the inverse transform)
     bool do_scale;
+    bool inverse;              // w is the inverse table (selects the compile-time twiddles of the register kernels)
     size_t in_batch_stride, scratch_batch_stride, out_batch_stride; // in elements
 };
 

@@ -105,6 +105,199 @@ __global__ __launch_bounds__(NT) void k_ntt_rows(const fp *__restrict__ in, fp *
     }
 }
 
+// =====================================================================================================
+// v2 kernels for sub-transform sizes M = 2^(LA+LB) with LA, LB <= 5: every thread runs 2^LA- and 2^LB-point
+// transforms entirely in registers (compile-time twiddles, fully unrolled), with ONE exchange through LDS in
+// between.  L = 16 adjacent columns / rows per workgroup make every global access a 128-byte segment.
+// -----------------------------------------------------------------------------------------------------
+// compile-time field arithmetic for the small twiddle tables
+__host__ __device__ constexpr uint64_t cx_mul(uint64_t a, uint64_t b) {
+    unsigned __int128 t = (unsigned __int128)a * b;
+    uint64_t m = (uint64_t)t * 0x417fffffffffffffULL;
+    uint64_t r = (uint64_t)((t + (unsigned __int128)m * FP_P) >> 64);
+    return r >= FP_P ? r - FP_P : r;
+}
+__host__ __device__ constexpr uint64_t cx_pow(uint64_t b, uint64_t e) {
+    uint64_t r = FP_ONE;
+    while (e) { if (e & 1) r = cx_mul(r, b); b = cx_mul(b, b); e >>= 1; }
+    return r;
+}
+// w_{2^log}^k (INV: its inverse); 2^55-th root of unity = 3^131 [UPSTREAM-RECALL, same as hostfield.h]
+__host__ __device__ constexpr uint64_t cx_root(int log, bool inv) {
+    uint64_t g = cx_pow(cx_mul(3, FP_R2), 131);
+    for (int i = log; i < 55; i++) g = cx_mul(g, g);
+    return inv ? cx_pow(g, FP_P - 2) : g;
+}
+template <int LOG, bool INV>
+struct SmallTw {
+    uint64_t v[LOG == 0 ? 1 : (1 << LOG) / 2 + 1];
+    constexpr SmallTw() : v{} {
+        const uint64_t w = cx_root(LOG, INV);
+        uint64_t x = FP_ONE;
+        for (int i = 0; i < (1 << LOG) / 2 + (LOG == 0); i++) { v[i] = x; x = cx_mul(x, w); }
+    }
+};
+
+// 2^LOG-point DIF transform in registers: natural order in, x[p] = X[bitrev(p)] out
+template <int LOG, bool INV>
+__device__ __forceinline__ void reg_ntt_dif(fp (&x)[1 << LOG]) {
+    constexpr SmallTw<LOG, INV> tw{};
+    constexpr int N = 1 << LOG;
+#pragma unroll
+    for (int s = 0; s < LOG; s++) {
+        const int half = N >> (s + 1);
+#pragma unroll
+        for (int blk = 0; blk < (1 << s); blk++) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const int i0 = blk * 2 * half + j, i1 = i0 + half;
+                const fp u = x[i0], v = x[i1];
+                x[i0] = fp_add(u, v);
+                const fp t = fp_sub(u, v);
+                x[i1] = (j == 0) ? t : fp_mul(t, tw.v[j << s]);
+            }
+        }
+    }
+}
+__host__ __device__ constexpr unsigned cx_brev(unsigned x, int bits) {
+    unsigned r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+#ifndef CS_NTT_L
+#define CS_NTT_L 16
+#endif
+constexpr int L2 = CS_NTT_L; // columns / rows per workgroup in the v2 kernels
+
+// grid = (batch, C / L2, width): batch (coset) is the fastest grid dimension so that the workgroups re-reading the
+// same coefficient tile for different cosets run close in time (the re-reads are served by L2 / Infinity Cache).
+template <int LA, int LB, bool INV>
+__global__ __launch_bounds__(L2 << (LA > LB ? LA : LB)) void k_ntt_cols_v2(const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n,
+                                                                          const fp *__restrict__ w, const fp *__restrict__ prescale,
+                                                                          size_t in_batch_stride, size_t out_batch_stride,
+                                                                          size_t prescale_batch_stride) {
+    constexpr int A = 1 << LA, B = 1 << LB, M = A * B, LOGM = LA + LB;
+    extern __shared__ __attribute__((aligned(16))) fp smem[];
+    fp *tile = smem;                           // [A][B + 1][L2]
+    fp *tw = smem + (size_t)A * (B + 1) * L2;  // [M] powers of w_M
+    const unsigned log_c = log_n - LOGM;
+    const size_t n = (size_t)1 << log_n;
+    const unsigned c0 = blockIdx.y * L2;
+    const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
+    fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
+    const fp *ps = prescale ? prescale + blockIdx.x * prescale_batch_stride : nullptr;
+    const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2;
+
+    for (unsigned e = threadIdx.x; e < M; e += blockDim.x) tw[e] = w[(size_t)e << log_c];
+    if (t < B) { // step 1: A-point transforms over r1 for fixed r2 = t (rows r = r1 * B + r2)
+        fp a[A];
+#pragma unroll
+        for (int r1 = 0; r1 < A; r1++) {
+            const size_t m = ((size_t)(r1 * B + t) << log_c) + c0 + l;
+            a[r1] = src[m];
+        }
+        if (ps) {
+#pragma unroll
+            for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], ps[((size_t)(r1 * B + t) << log_c) + c0 + l]);
+        }
+        reg_ntt_dif<LA, INV>(a);
+        __syncthreads(); // tw[] ready
+#pragma unroll
+        for (int p = 0; p < A; p++) {
+            const unsigned k1 = cx_brev(p, LA);
+            const fp v = (k1 == 0) ? a[p] : fp_mul(a[p], tw[k1 * t]);
+            tile[((size_t)k1 * (B + 1) + t) * L2 + l] = v;
+        }
+    } else {
+        __syncthreads();
+    }
+    __syncthreads();
+    if (t < A) { // step 2: B-point transforms over r2 for fixed k1 = t; output row k = k1 + A * k2
+        fp b[B];
+#pragma unroll
+        for (int r2 = 0; r2 < B; r2++) b[r2] = tile[((size_t)t * (B + 1) + r2) * L2 + l];
+        reg_ntt_dif<LB, INV>(b);
+        const unsigned c = c0 + l;
+#pragma unroll
+        for (int p = 0; p < B; p++) {
+            const unsigned k = t + A * cx_brev(p, LB);
+            dst[((size_t)k << log_c) + c] = fp_mul(b[p], w[(size_t)k * c]);
+        }
+    }
+}
+
+// grid = (batch, R / L2, width).  in: rows [k1][c] (each row M contiguous); out: natural order k = k1 + R * k2.
+template <int LA, int LB, bool INV>
+__global__ __launch_bounds__(L2 << (LA > LB ? LA : LB)) void k_ntt_rows_v2(const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n,
+                                                                          const fp *__restrict__ w, fp post_scale, int do_scale,
+                                                                          size_t in_batch_stride, size_t out_batch_stride) {
+    constexpr int A = 1 << LA, B = 1 << LB, M = A * B, LOGM = LA + LB;
+    extern __shared__ __attribute__((aligned(16))) fp smem[];
+    fp *tile = smem;                     // [L2][A][B] with the B index XOR-swizzled
+    fp *tw = smem + (size_t)L2 * A * B;  // [M]
+    const unsigned log_r = log_n - LOGM;
+    const size_t n = (size_t)1 << log_n;
+    const unsigned k10 = blockIdx.y * L2;
+    const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
+    fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
+
+    for (unsigned e = threadIdx.x; e < M; e += blockDim.x) tw[e] = w[(size_t)e << log_r];
+    {   // step 1: task (l, c2) with c2 fastest across lanes (coalesced row reads): A-point transforms over c1
+        const unsigned c2 = threadIdx.x % B, l = threadIdx.x / B;
+        if (l < L2) {
+            fp a[A];
+#pragma unroll
+            for (int c1 = 0; c1 < A; c1++) a[c1] = src[((size_t)(k10 + l) << LOGM) + c1 * B + c2];
+            reg_ntt_dif<LA, INV>(a);
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < A; p++) {
+                const unsigned j1 = cx_brev(p, LA);
+                const fp v = (j1 == 0) ? a[p] : fp_mul(a[p], tw[j1 * c2]);
+                const unsigned sw = (l | ((j1 % (32 / L2)) * L2)) & (B - 1);
+                tile[((size_t)l * A + j1) * B + (c2 ^ sw)] = v;
+            }
+        } else {
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    {   // step 2: task (j1, l) with l fastest across lanes (128-byte transposed stores): B-point transforms over c2
+        const unsigned l = threadIdx.x % L2, j1 = threadIdx.x / L2;
+        if (j1 < A) {
+            fp b[B];
+            const unsigned sw = (l | ((j1 % (32 / L2)) * L2)) & (B - 1);
+#pragma unroll
+            for (int c2 = 0; c2 < B; c2++) b[c2] = tile[((size_t)l * A + j1) * B + (c2 ^ sw)];
+            reg_ntt_dif<LB, INV>(b);
+#pragma unroll
+            for (int p = 0; p < B; p++) {
+                const unsigned k2 = j1 + A * cx_brev(p, LB);
+                fp v = b[p];
+                if (do_scale) v = fp_mul(v, post_scale);
+                dst[((size_t)k2 << log_r) + k10 + l] = v;
+            }
+        }
+    }
+}
+
+template <int LRA, int LRB, int LCA, int LCB, bool INV>
+hipError_t launch_v2(const NttArgs &a, hipStream_t stream) {
+    constexpr int LOG_R = LRA + LRB, LOG_C = LCA + LCB;
+    constexpr int TA = L2 << (LRA > LRB ? LRA : LRB), TB = L2 << (LCA > LCB ? LCA : LCB);
+    const size_t lds_a = ((size_t)(1 << LRA) * ((1 << LRB) + 1) * L2 + (1 << LOG_R)) * sizeof(fp);
+    const size_t lds_b = ((size_t)L2 * (1 << LOG_C) + (1 << LOG_C)) * sizeof(fp);
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void *)k_ntt_cols_v2<LRA, LRB, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_ntt_rows_v2<LCA, LCB, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
+    hipLaunchKernelGGL((k_ntt_cols_v2<LRA, LRB, INV>), dim3(a.batch, (1u << LOG_C) / L2, a.width), dim3(TA), lds_a, stream, a.in, a.scratch, a.log_n,
+                       a.w, a.prescale, a.in_batch_stride, a.scratch_batch_stride, a.prescale_batch_stride);
+    hipLaunchKernelGGL((k_ntt_rows_v2<LCA, LCB, INV>), dim3(a.batch, (1u << LOG_R) / L2, a.width), dim3(TB), lds_b, stream,
+                       (const fp *)a.scratch, a.out, a.log_n, a.w, a.post_scale, a.do_scale ? 1 : 0, a.scratch_batch_stride, a.out_batch_stride);
+    return hipGetLastError();
+}
+
 // table[e] = base^e for e < n; each thread produces CHUNK consecutive powers
 constexpr int CHUNK = 16;
 __global__ void k_power_table(fp *table, size_t n, fp base) {
@@ -142,6 +335,10 @@ hipError_t ntt_power_table(fp *d_table, size_t n, fp base, hipStream_t stream) {
 
 hipError_t ntt_columns(const NttArgs &a, hipStream_t stream) {
     if (a.log_n < NTT_MIN_LOG_N || a.log_n > NTT_MAX_LOG_N) return hipErrorInvalidValue;
+    // register-tiled kernels for the production sizes; `inverse` selects the compile-time small twiddles
+    if (a.log_n == 20) return a.inverse ? launch_v2<5, 5, 5, 5, true>(a, stream) : launch_v2<5, 5, 5, 5, false>(a, stream);
+    if (a.log_n == 18) return a.inverse ? launch_v2<5, 4, 5, 4, true>(a, stream) : launch_v2<5, 4, 5, 4, false>(a, stream);
+    if (a.log_n == 16) return a.inverse ? launch_v2<4, 4, 4, 4, true>(a, stream) : launch_v2<4, 4, 4, 4, false>(a, stream);
     // L = 8 keeps global segments at 64 bytes; sub-transforms above 2^11 points need the narrower tile to fit LDS
     const unsigned log_r = (a.log_n + 1) / 2;
     if (log_r <= 11)

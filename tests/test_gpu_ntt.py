@@ -20,7 +20,7 @@ def _rand(oracle, shape, seed):
     return oracle.to_mont(rng.integers(0, P, size=int(np.prod(shape)), dtype=np.uint64)).reshape(shape)
 
 
-@pytest.mark.parametrize("log_n,width", [(6, 1), (7, 3), (10, 5), (11, 2), (13, 3), (14, 2)])
+@pytest.mark.parametrize("log_n,width", [(6, 1), (7, 3), (10, 5), (11, 2), (13, 3), (14, 2), (16, 2), (18, 1)])
 def test_interpolate_and_lde_match_oracle(oracle, backend, log_n, width):
     from certificate_stark_amd.backend import to_numpy_u64
     ev = _rand(oracle, (width, 1 << log_n), log_n)
@@ -61,5 +61,7 @@ def test_full_size_roundtrip_2_20(oracle, backend):
     back = backend.lde_columns(co, 0, offset=one)
     assert torch.equal(back[0], d_ev)
     lde0 = to_numpy_u64(backend.lde_columns(co, 3, k0=3, nk=1))
-    ref = oracle.lde_columns(oracle.interpolate_columns(ev[:1]), 3, k0=3, nk=1)
+    co_ref = oracle.interpolate_columns(ev[:1])
+    assert (to_numpy_u64(co[0]) == co_ref[0]).all()
+    ref = oracle.lde_columns(co_ref, 3, k0=3, nk=1)
     assert (lde0[0, 0] == ref[0, 0]).all()
