@@ -56,6 +56,8 @@ struct PeriodicTable {
 struct cstark_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr; // internal second stream (forked from / joined into `stream`)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // uploaded witness
     void *wit_buf = nullptr;
     size_t wit_bytes = 0;
@@ -235,6 +237,11 @@ int cstark_ctx_create(int device, void *stream, cstark_ctx **out) {
     if (!c) return fail(CSTARK_ERR_OOM, "host allocation failed");
     c->device = device;
     c->stream = (hipStream_t)stream; // NULL is HIP's default stream
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return fail(CSTARK_ERR_HIP, "could not create the internal stream / events");
+    }
     *out = c;
     return CSTARK_OK;
 }
@@ -243,6 +250,9 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->wit_buf) (void)hipFree(c->wit_buf);
     if (c->ws) (void)hipFree(c->ws);
     if (c->coef_buf) (void)hipFree(c->coef_buf);
@@ -330,7 +340,7 @@ int cstark_tx_build_trace(cstark_ctx *c, uint64_t *d_trace) {
     if (!c || !d_trace) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_build_trace: null argument");
     if (!c->wit_buf || c->wit.n_tx == 0) return fail(CSTARK_ERR_INVALID_ARG, "no witness uploaded");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(cs::launch_trace_gen(c->wit, d_trace, c->stream));
+    HIP_TRY(cs::launch_trace_gen(c->wit, d_trace, c->stream, c->side, c->ev_fork, c->ev_join));
     return CSTARK_OK;
 }
 

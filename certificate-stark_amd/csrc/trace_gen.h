@@ -13,6 +13,8 @@ struct TxWitnessDev {
     uint64_t *h_limbs; // [n_tx][4] canonical limbs of hash_message(), produced by k_trace_schnorr_hash
 };
 
-hipError_t launch_trace_gen(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream);
+// `side` is a second stream used for the part of the trace that is independent of the rest; `fork`/`join` are events
+// owned by the caller (fork: stream -> side, join: side -> stream)
+hipError_t launch_trace_gen(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t join);
 
 } // namespace cs

@@ -187,121 +187,187 @@ __global__ __launch_bounds__(64) void k_trace_schnorr_hash(TxWitnessDev w, fp *_
 struct Term { int8_t slot, coef; };
 struct Instr { int8_t out; Term a[3]; Term b[3]; }; // out < 0: no-op; b[0].coef == 0: linear (no product)
 
-enum { SX = 0, SY = 1, SZ = 2, SB3 = 3, SPX = 4, SPY = 5, QX = 23, QY = 24, QZ = 25, NSLOT = 26 };
-enum { OP_DOUBLE = 0, OP_ADD_MIXED = 1, OP_ADD_FULL = 2, NPHASE = 5, NROLE = 6 };
+enum { SX = 0, SY = 1, SZ = 2, SB3 = 3, SPX = 4, SPY = 5, QX = 27, QY = 28, QZ = 29, NSLOT = 30 };
+enum { OP_DOUBLE = 0, OP_ADD_MIXED = 1, OP_ADD_FULL = 2, NPHASE = 6, NROLE = 6 };
 #define NOP {-1, {{0, 0}, {0, 0}, {0, 0}}, {{0, 0}, {0, 0}, {0, 0}}}
 #define T1(s, c) {{s, c}, {0, 0}, {0, 0}}
 #define T2(s, c, s2, c2) {{s, c}, {s2, c2}, {0, 0}}
 #define T3(s, c, s2, c2, s3, c3) {{s, c}, {s2, c2}, {s3, c3}}
 #define NONE {{0, 0}, {0, 0}, {0, 0}}
+#define NOPS6 {NOP, NOP, NOP, NOP, NOP, NOP}
+// Product phases take single-slot operands (optionally scaled by a small integer); every other operand is
+// materialised by a preceding linear phase, so that no lane recomputes a combination another lane also needs.
 __constant__ Instr c_prog[3][NPHASE][NROLE] = {
     // OP_DOUBLE: X3 = 2XY(Y^2-2XZ-3bZ^2) - 2YZ(X^2+6bXZ-Z^2), ... (complete doubling, ecc.rs:177-242)
     {{{6, T1(0, 1), T1(0, 1)}, {7, T1(1, 1), T1(1, 1)}, {8, T1(2, 1), T1(2, 1)}, {9, T1(0, 1), T1(1, 1)}, {10, T1(0, 1), T1(2, 1)}, {11, T1(1, 1), T1(2, 1)}},
      {{12, T1(3, 1), T1(8, 1)}, {13, T1(3, 1), T1(10, 2)}, NOP, NOP, NOP, NOP},
-     {{14, T3(7, 1, 10, -2, 12, -1), T3(7, 1, 10, 2, 12, 1)}, {15, T1(9, 2), T3(7, 1, 10, -2, 12, -1)}, {16, T2(6, 3, 8, 1), T3(6, 1, 8, -1, 13, 1)},
-      {17, T1(11, 2), T3(6, 1, 8, -1, 13, 1)}, {18, T1(11, 2), T1(7, 1)}, NOP},
+     {{19, T3(7, 1, 10, -2, 12, -1), NONE}, {20, T3(7, 1, 10, 2, 12, 1), NONE}, {21, T3(6, 1, 8, -1, 13, 1), NONE}, {22, T2(6, 3, 8, 1), NONE}, NOP, NOP},
+     {{14, T1(19, 1), T1(20, 1)}, {15, T1(9, 2), T1(19, 1)}, {16, T1(22, 1), T1(21, 1)}, {17, T1(11, 2), T1(21, 1)}, {18, T1(11, 2), T1(7, 1)}, NOP},
      {{0, T2(15, 1, 17, -1), NONE}, {1, T2(14, 1, 16, 1), NONE}, {2, T1(18, 4), NONE}, NOP, NOP, NOP},
-     {NOP, NOP, NOP, NOP, NOP, NOP}},
+     NOPS6},
     // OP_ADD_MIXED with the affine point in slots 4,5 (complete mixed addition, ecc.rs:330-404)
-    {{{6, T1(0, 1), T1(4, 1)}, {7, T1(1, 1), T1(5, 1)}, {8, T2(4, 1, 5, 1), T2(0, 1, 1, 1)}, {9, T1(4, 1), T1(2, 1)}, {10, T1(5, 1), T1(2, 1)}, {11, T1(2, 1), T1(3, 1)}},
+    {{{6, T1(0, 1), T1(4, 1)}, {7, T1(1, 1), T1(5, 1)}, {8, T1(26, 1), T1(25, 1)}, {9, T1(4, 1), T1(2, 1)}, {10, T1(5, 1), T1(2, 1)}, {11, T1(2, 1), T1(3, 1)}},
      {{19, T2(9, 1, 0, 1), NONE}, NOP, NOP, NOP, NOP, NOP},
      {{12, T1(19, 1), T1(3, 1)}, NOP, NOP, NOP, NOP, NOP},
-     {{13, T3(7, 1, 11, -1, 19, -1), T3(7, 1, 11, 1, 19, 1)}, {14, T2(6, 3, 2, 1), T3(12, 1, 6, 1, 2, -1)}, {15, T2(10, 1, 1, 1), T3(12, 1, 6, 1, 2, -1)},
-      {16, T3(8, 1, 6, -1, 7, -1), T3(7, 1, 11, -1, 19, -1)}, {17, T3(8, 1, 6, -1, 7, -1), T2(6, 3, 2, 1)}, {18, T2(10, 1, 1, 1), T3(7, 1, 11, 1, 19, 1)}},
+     {{20, T3(7, 1, 11, -1, 19, -1), NONE}, {21, T3(7, 1, 11, 1, 19, 1), NONE}, {22, T2(6, 3, 2, 1), NONE}, {23, T3(12, 1, 6, 1, 2, -1), NONE},
+      {24, T2(10, 1, 1, 1), NONE}, {25, T3(8, 1, 6, -1, 7, -1), NONE}},
+     {{13, T1(20, 1), T1(21, 1)}, {14, T1(22, 1), T1(23, 1)}, {15, T1(24, 1), T1(23, 1)}, {16, T1(25, 1), T1(20, 1)}, {17, T1(25, 1), T1(22, 1)}, {18, T1(24, 1), T1(21, 1)}},
      {{0, T2(16, 1, 15, -1), NONE}, {1, T2(13, 1, 14, 1), NONE}, {2, T2(18, 1, 17, 1), NONE}, NOP, NOP, NOP}},
-    // OP_ADD_FULL with the projective point in slots 23..25 (complete addition, ecc.rs:244-328)
-    {{{6, T1(0, 1), T1(23, 1)}, {7, T1(1, 1), T1(24, 1)}, {8, T1(2, 1), T1(25, 1)}, {9, T2(0, 1, 1, 1), T2(23, 1, 24, 1)}, {10, T2(0, 1, 2, 1), T2(23, 1, 25, 1)},
-      {11, T2(1, 1, 2, 1), T2(24, 1, 25, 1)}},
+    // OP_ADD_FULL with the projective point in slots 27..29 (complete addition, ecc.rs:244-328)
+    {{{6, T1(0, 1), T1(27, 1)}, {7, T1(1, 1), T1(28, 1)}, {8, T1(2, 1), T1(29, 1)}, {9, T1(20, 1), T1(21, 1)}, {10, T1(22, 1), T1(23, 1)}, {11, T1(24, 1), T1(25, 1)}},
      {{19, T3(10, 1, 6, -1, 8, -1), NONE}, NOP, NOP, NOP, NOP, NOP},
      {{12, T1(3, 1), T1(8, 1)}, {13, T1(3, 1), T1(19, 1)}, NOP, NOP, NOP, NOP},
-     {{14, T3(7, 1, 12, -1, 19, -1), T3(7, 1, 12, 1, 19, 1)}, {15, T2(6, 3, 8, 1), T3(13, 1, 6, 1, 8, -1)}, {16, T3(11, 1, 7, -1, 8, -1), T3(13, 1, 6, 1, 8, -1)},
-      {17, T3(9, 1, 6, -1, 7, -1), T3(7, 1, 12, -1, 19, -1)}, {18, T3(9, 1, 6, -1, 7, -1), T2(6, 3, 8, 1)}, {20, T3(11, 1, 7, -1, 8, -1), T3(7, 1, 12, 1, 19, 1)}},
-     {{0, T2(17, 1, 16, -1), NONE}, {1, T2(14, 1, 15, 1), NONE}, {2, T2(20, 1, 18, 1), NONE}, NOP, NOP, NOP}},
+     {{20, T3(7, 1, 12, -1, 19, -1), NONE}, {21, T3(7, 1, 12, 1, 19, 1), NONE}, {22, T2(6, 3, 8, 1), NONE}, {23, T3(13, 1, 6, 1, 8, -1), NONE},
+      {24, T3(9, 1, 6, -1, 7, -1), NONE}, {25, T3(11, 1, 7, -1, 8, -1), NONE}},
+     {{14, T1(20, 1), T1(21, 1)}, {15, T1(22, 1), T1(23, 1)}, {16, T1(25, 1), T1(23, 1)}, {17, T1(24, 1), T1(20, 1)}, {18, T1(24, 1), T1(22, 1)}, {26, T1(25, 1), T1(21, 1)}},
+     {{0, T2(17, 1, 16, -1), NONE}, {1, T2(14, 1, 15, 1), NONE}, {2, T2(26, 1, 18, 1), NONE}, NOP, NOP, NOP}},
+};
+// operand sums that feed the first product phase of the additions (a "phase -1" run before the program):
+//   mixed: 26 = x2 + y2 (constant per ladder, set once), 25 = X + Y;  full: 20..25 = X1+Y1, X2+Y2, X1+Z1, X2+Z2, Y1+Z1, Y2+Z2
+__constant__ Instr c_pre[3][NROLE] = {
+    NOPS6,
+    {{25, T2(0, 1, 1, 1), NONE}, NOP, NOP, NOP, NOP, NOP},
+    {{20, T2(0, 1, 1, 1), NONE}, {21, T2(27, 1, 28, 1), NONE}, {22, T2(0, 1, 2, 1), NONE}, {23, T2(27, 1, 29, 1), NONE}, {24, T2(1, 1, 2, 1), NONE}, {25, T2(28, 1, 29, 1), NONE}},
 };
 #undef NOP
 #undef T1
 #undef T2
 #undef T3
 #undef NONE
+#undef NOPS6
 
-__device__ __forceinline__ Fp6 lincomb(const fp (*slot)[6], const Term (&t)[3]) {
-    Fp6 r = fp6_mul_small(fp6_load(slot[t[0].slot]), t[0].coef);
+// F_p2 component `comp` (0..2) of an integer combination of slots; comp2 >= 0 adds a second component
+// (the Karatsuba operand sums c_i + c_j)
+__device__ __forceinline__ Fp2 lincomb2(const fp (*slot)[6], const Term (&t)[3], int comp, int comp2) {
+    Fp2 r = {0, 0};
 #pragma unroll
-    for (int k = 1; k < 3; k++)
-        if (t[k].coef != 0) r = fp6_add(r, fp6_mul_small(fp6_load(slot[t[k].slot]), t[k].coef));
+    for (int k = 0; k < 3; k++) {
+        if (t[k].coef == 0) continue;
+        const fp *s = slot[t[k].slot];
+        Fp2 v = {s[2 * comp], s[2 * comp + 1]};
+        if (comp2 >= 0) v = fp2_add(v, {s[2 * comp2], s[2 * comp2 + 1]});
+        r = fp2_add(r, {fp_mul_small(v.a, t[k].coef), fp_mul_small(v.b, t[k].coef)});
+    }
     return r;
 }
 
-// Runs program `op` on the slots of one point.  Called by all lanes of the block (barriers inside).
-__device__ __forceinline__ void run_point_op(int op, fp (*slot)[6], int role, bool enabled) {
+// single-slot product operand: component `comp` (+ comp2) of slot t.slot scaled by t.coef (1 or 2)
+__device__ __forceinline__ Fp2 operand2(const fp (*slot)[6], const Term t, int comp, int comp2) {
+    const fp *s = slot[t.slot];
+    Fp2 v = {s[2 * comp], s[2 * comp + 1]};
+    if (comp2 >= 0) v = fp2_add(v, {s[2 * comp2], s[2 * comp2 + 1]});
+    if (t.coef == 2) v = fp2_dbl(v);
+    return v;
+}
+
+// Runs program `op` on the slots of one point with the 64 lanes of one wave:
+//   product phase  lane (m, q), q < 6: the q-th Karatsuba F_p2 product of instruction m  (3 base products per lane)
+//   recombination  lane (m, r), r < 3: F_p2 coefficient r of the F_p6 result of instruction m
+//   linear phase   lane (m, r): coefficient r of an integer combination of slots
+// Called by all lanes of the workgroup (barriers inside).  prod = this point's [6][6] F_p2 scratch.
+__device__ __forceinline__ void run_linear_phase(const Instr (&prog)[NROLE], fp (*slot)[6], int lane, bool enabled) {
+    const int m = lane / 3, r = lane % 3;
+    Fp2 c = {0, 0};
+    int out = -1;
+    if (enabled && m < NROLE) {
+        const Instr ins = prog[m];
+        out = ins.out;
+        if (out >= 0) c = lincomb2(slot, ins.a, r, -1);
+    }
+    __syncthreads();
+    if (out >= 0) { slot[out][2 * r] = c.a; slot[out][2 * r + 1] = c.b; }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void run_point_op(int op, fp (*slot)[6], Fp2 (*prod)[6], int lane, bool enabled) {
+    if (op != OP_DOUBLE) run_linear_phase(c_pre[op], slot, lane, enabled);
 #pragma unroll 1
     for (int ph = 0; ph < NPHASE; ph++) {
-        Fp6 r;
-        int out = -1;
-        if (enabled && role < NROLE) {
-            const Instr ins = c_prog[op][ph][role];
-            out = ins.out;
-            if (out >= 0) {
-                r = lincomb(slot, ins.a);
-                if (ins.b[0].coef != 0) r = fp6_mul(r, lincomb(slot, ins.b));
+        const bool is_nop = c_prog[op][ph][0].out < 0;
+        if (is_nop) break;
+        const bool is_mul = c_prog[op][ph][0].b[0].coef != 0; // phases are homogeneous
+        if (is_mul) {
+            const int m = lane / 6, q = lane % 6;
+            if (enabled && m < NROLE) {
+                const Instr ins = c_prog[op][ph][m];
+                if (ins.out >= 0) {
+                    const int c1 = q < 3 ? q : (q == 5 ? 1 : 0), c2 = q < 3 ? -1 : (q == 3 ? 1 : 2);
+                    prod[m][q] = fp2_mul(operand2(slot, ins.a[0], c1, c2), operand2(slot, ins.b[0], c1, c2));
+                }
             }
+            __syncthreads();
+            const int m2 = lane / 3, r = lane % 3;
+            if (enabled && m2 < NROLE) {
+                const int out = c_prog[op][ph][m2].out;
+                if (out >= 0) {
+                    const Fp2 d0 = prod[m2][0], d1 = prod[m2][1], d2 = prod[m2][2];
+                    Fp2 c;
+                    if (r == 0) c = fp2_sub(fp2_add(fp2_add(d0, d1), d2), prod[m2][5]);       // d0 + d1 + d2 - e12
+                    else if (r == 1) c = fp2_sub(fp2_sub(prod[m2][3], prod[m2][5]), d0);       // e01 - e12 - d0
+                    else c = fp2_add(fp2_sub(fp2_sub(prod[m2][4], fp2_add(d0, d2)), d2), d1);  // e02 - d0 - 2 d2 + d1
+                    slot[out][2 * r] = c.a;
+                    slot[out][2 * r + 1] = c.b;
+                }
+            }
+            __syncthreads();
+        } else {
+            run_linear_phase(c_prog[op][ph], slot, lane, enabled);
         }
-        __syncthreads();
-        if (out >= 0) fp6_store(slot[out], r);
-        __syncthreads();
     }
 }
 
 __device__ __forceinline__ int bit_le(const uint8_t *bytes, int i) { return (bytes[i >> 3] >> (i & 7)) & 1; }
 
-__global__ __launch_bounds__(64) void k_trace_schnorr_ec(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+__global__ __launch_bounds__(128) void k_trace_schnorr_ec(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
     __shared__ fp tile[64][37];
     __shared__ fp slots[2][NSLOT][6];
+    __shared__ Fp2 prods[2][6][6];
     __shared__ uint8_t sbytes[2][32];
-    const int t = blockIdx.x, lane = threadIdx.x;
-    const int g = lane >> 5, role = lane & 31; // g = 0: s*G (regs 0..17), g = 1: h*P (regs 19..36)
+    const int t = blockIdx.x;
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63; // wave 0: s*G (regs 0..17), wave 1: h*P (regs 19..36)
     fp(*slot)[6] = slots[g];
 
     // scalars: s from the signature, h from the message hash (little-endian bytes, Lsb0 bit order)
-    if (lane < 32) sbytes[0][lane] = w.sig_s[32 * (size_t)t + lane];
-    else { int b = lane - 32; sbytes[1][b] = (uint8_t)(w.h_limbs[4 * (size_t)t + (b >> 3)] >> (8 * (b & 7))); }
+    if (threadIdx.x < 32) sbytes[0][threadIdx.x] = w.sig_s[32 * (size_t)t + threadIdx.x];
+    else if (threadIdx.x < 64) { int b = threadIdx.x - 32; sbytes[1][b] = (uint8_t)(w.h_limbs[4 * (size_t)t + (b >> 3)] >> (8 * (b & 7))); }
     // constant slots and the initial point (0 : 1 : 0), src/schnorr/trace.rs:22-27
-    if (role < 6) {
-        slot[SX][role] = 0;
-        slot[SY][role] = role == 0 ? FP_ONE : 0;
-        slot[SZ][role] = 0;
-        slot[SB3][role] = c_b3[role];
-        slot[SPX][role] = g == 0 ? c_generator[role] : w.s_old[14 * (size_t)t + role];
-        slot[SPY][role] = g == 0 ? c_generator[6 + role] : w.s_old[14 * (size_t)t + 6 + role];
+    if (lane < 6) {
+        slot[SX][lane] = 0;
+        slot[SY][lane] = lane == 0 ? FP_ONE : 0;
+        slot[SZ][lane] = 0;
+        slot[SB3][lane] = c_b3[lane];
+        slot[SPX][lane] = g == 0 ? c_generator[lane] : w.s_old[14 * (size_t)t + lane];
+        slot[SPY][lane] = g == 0 ? c_generator[6 + lane] : w.s_old[14 * (size_t)t + 6 + lane];
+        slot[26][lane] = fp_add(slot[SPX][lane], slot[SPY][lane]); // x2 + y2, operand of the mixed addition
     }
     __syncthreads();
-    if (role < 18) tile[0][g * 18 + role] = slot[role / 6][role % 6];
+    if (lane < 18) tile[0][g * 18 + lane] = slot[lane / 6][lane % 6];
     const size_t gbase = (size_t)t * TXC + MERKLE_LEN;
 
     for (int step = 0; step < MERKLE_LEN - 1; step++) {
         if (step < SCALAR_MUL_LEN) {
             if ((step & 1) == 0) {
-                run_point_op(OP_DOUBLE, slot, role, true);
+                run_point_op(OP_DOUBLE, slot, prods[g], lane, true);
             } else {
                 const int bit = bit_le(sbytes[g], 254 - (step >> 1)); // MSB first, src/schnorr/trace.rs:79-82
-                run_point_op(OP_ADD_MIXED, slot, role, bit != 0);
+                run_point_op(OP_ADD_MIXED, slot, prods[g], lane, bit != 0);
             }
         } else if (step == SCALAR_MUL_LEN) {
             // S += h*P, then X <- X / Z  (src/schnorr/trace.rs:105-119)
-            if (g == 0 && role < 18) slot[QX + role / 6][role % 6] = slots[1][role / 6][role % 6];
+            if (g == 0 && lane < 18) slot[QX + lane / 6][lane % 6] = slots[1][lane / 6][lane % 6];
             __syncthreads();
-            run_point_op(OP_ADD_FULL, slot, role, g == 0);
-            if (lane == 0) {
+            run_point_op(OP_ADD_FULL, slot, prods[g], lane, g == 0);
+            if (threadIdx.x == 0) {
                 Fp6 x = fp6_mul(fp6_load(slot[SX]), fp6_inv(fp6_load(slot[SZ])));
                 fp6_store(slot[SX], x);
             }
             __syncthreads();
         }
         const int r = (step + 1) & 63;
-        if (role < 18) tile[r][g * 18 + role] = slot[role / 6][role % 6];
+        if (lane < 18) tile[r][g * 18 + lane] = slot[lane / 6][lane % 6];
         if (r == 63) {
             __syncthreads();
-            flush_tile<36, 37>(tile, trace, n, gbase + (step + 1 - 63), 0, lane, 18);
+            if (g == 0) flush_tile<36, 37>(tile, trace, n, gbase + (step + 1 - 63), 0, lane, 18);
             __syncthreads();
         }
     }
@@ -370,12 +436,19 @@ __global__ __launch_bounds__(256) void k_trace_aux(TxWitnessDev w, fp *__restric
 
 } // namespace
 
-hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stream) {
+hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
     const size_t n = (size_t)w.n_tx * TXC;
+    // the Merkle-phase recurrence is independent of the Schnorr half: run it beside the curve ladders (both are
+    // latency-bound, one wave per transaction) on a side stream forked from / joined back into `stream`
+    hipError_t e;
+    if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_trace_merkle, dim3(w.n_tx), dim3(64), 0, side, w, d_trace, n);
+    if ((e = hipEventRecord(join, side)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_trace_schnorr_hash, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
-    hipLaunchKernelGGL(k_trace_merkle, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
-    hipLaunchKernelGGL(k_trace_schnorr_ec, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_ec, dim3(w.n_tx), dim3(128), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_aux, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
+    if ((e = hipStreamWaitEvent(stream, join, 0)) != hipSuccess) return e;
     return hipGetLastError();
 }
 
