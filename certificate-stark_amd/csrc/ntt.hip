@@ -198,8 +198,11 @@ __global__ __launch_bounds__(L2 << (LA > LB ? LA : LB)) void k_ntt_cols_v2(const
             a[r1] = src[m];
         }
         if (ps) {
+            // coset scaling shift^m, m = r * C + c: the row part shift^(r*C) here (M-entry slice of the power table,
+            // cache resident); the column part shift^c commutes with the transform over r and is folded into the
+            // output factor below
 #pragma unroll
-            for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], ps[((size_t)(r1 * B + t) << log_c) + c0 + l]);
+            for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], ps[(size_t)(r1 * B + t) << log_c]);
         }
         reg_ntt_dif<LA, INV>(a);
         __syncthreads(); // tw[] ready
@@ -219,10 +222,15 @@ __global__ __launch_bounds__(L2 << (LA > LB ? LA : LB)) void k_ntt_cols_v2(const
         for (int r2 = 0; r2 < B; r2++) b[r2] = tile[((size_t)t * (B + 1) + r2) * L2 + l];
         reg_ntt_dif<LB, INV>(b);
         const unsigned c = c0 + l;
+        // output factor shift^c * w_n^(k*c), k = t + A*k2: a geometric sequence in k2 with ratio w_n^(A*c), generated
+        // in registers instead of gathering 8-byte entries of the 8 MB twiddle table
+        fp g = w[(size_t)t * c];
+        if (ps) g = fp_mul(g, ps[c]);
+        const fp ratio = w[(size_t)A * c];
 #pragma unroll
-        for (int p = 0; p < B; p++) {
-            const unsigned k = t + A * cx_brev(p, LB);
-            dst[((size_t)k << log_c) + c] = fp_mul(b[p], w[(size_t)k * c]);
+        for (int k2 = 0; k2 < B; k2++) { // b[] holds the outputs in bit-reversed positions
+            dst[((size_t)(t + A * k2) << log_c) + c] = fp_mul(b[cx_brev(k2, LB)], g);
+            if (k2 + 1 < B) g = fp_mul(g, ratio);
         }
     }
 }

@@ -2,6 +2,7 @@
  * field and gadget restatements (fp.h, gadgets.h) so the Python tests can call them. */
 #include "oracle.h"
 #include "gadgets.h"
+#include <omp.h>
 
 void cso_fp_from_u64(const uint64_t *in, uint64_t *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = fp_from_u64(in[i]); }
 void cso_fp_to_u64(const uint64_t *in, uint64_t *out, size_t n) { for (size_t i = 0; i < n; i++) out[i] = fp_to_u64(in[i]); }
@@ -25,3 +26,5 @@ void cso_fp6_inv(const uint64_t *a, uint64_t *out) { fp6_store(out, fp6_inv(fp6_
 void cso_ecc_double(uint64_t *p) { ecc_double(p); }
 void cso_ecc_add(uint64_t *p, const uint64_t *q) { ecc_add(p, q); }
 void cso_ecc_add_mixed(uint64_t *p, const uint64_t *q) { ecc_add_mixed(p, q); }
+
+int cso_num_threads(void) { return omp_get_max_threads(); }

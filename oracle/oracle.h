@@ -30,6 +30,8 @@ void cso_fp_inv(const uint64_t *a, uint64_t *out, size_t n);
 void cso_fp_pow(const uint64_t *a, uint64_t e, uint64_t *out, size_t n);
 uint64_t cso_fp_root_of_unity(unsigned log_n);
 
+int cso_num_threads(void);
+
 /* gadgets */
 void cso_rescue_permutation(uint64_t *state14);
 void cso_rescue_round(uint64_t *state14, uint32_t step);

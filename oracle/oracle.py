@@ -307,3 +307,8 @@ def tx_combined_at(trace_coeffs, coeffs, pub_inputs, depth, log_b, z):
     pub = _u64(pub_inputs)
     return int(lib().cso_tx_combined_at(_p(trace_coeffs), C.byref(coeffs), _p(pub), C.c_uint(depth),
                                         C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_uint64(z)))
+
+
+def num_threads():
+    """OpenMP threads the oracle actually uses (cpu_baseline.cores)."""
+    return int(lib().cso_num_threads())
