@@ -76,6 +76,31 @@ uint64_t cso_poly_eval(const uint64_t *co, size_t n, uint64_t x);
 uint64_t cso_tx_combined_at(const uint64_t *trace_coeffs, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
                             unsigned depth, unsigned log_n, unsigned log_b, uint64_t z);
 
+/* standalone sub-AIRs and the generic driver (air_small.c) */
+typedef struct cso_air_desc {
+    uint32_t width, n_constraints, cycle_len, log_ce_blowup;
+    const uint32_t *base, *cycles;          /* [n_constraints] */
+    uint32_t n_assertions;
+    const uint32_t *a_reg, *a_last;         /* [n_assertions]: register, 0 = first step / 1 = last step */
+    const uint64_t *a_value;
+} cso_air_desc;
+int cso_merkle_build_trace(const cstark_tx_witness *w, uint64_t *trace);
+int cso_merkle_periodic_columns(unsigned depth, uint64_t *out);
+void cso_merkle_evaluate_transition(const uint64_t *cur, const uint64_t *next, const uint64_t *pv, uint64_t *res);
+void cso_merkle_constraint_degrees(uint32_t *base, uint32_t *cycles);
+int cso_range_build_trace(uint64_t number_canonical, uint64_t *trace);
+void cso_range_evaluate_transition(const uint64_t *cur, const uint64_t *next, const uint64_t *pv, uint64_t *res);
+int cso_rescue_chain_build_trace(const uint64_t *seed7, uint32_t iterations, uint64_t *trace);
+void cso_rescue_compute_hash_chain(const uint64_t *seed7, uint32_t length, uint64_t *out7);
+void cso_rescue_chain_evaluate_transition(const uint64_t *cur, const uint64_t *next, const uint64_t *pv, uint64_t *res);
+void cso_rescue_chain_periodic_columns(uint64_t *out);
+void cso_air_combine(const cso_air_desc *d, const uint64_t *lde, const uint64_t *evals, const uint64_t *t_alpha, const uint64_t *t_beta,
+                     const uint64_t *b_alpha, const uint64_t *b_beta, uint64_t *out, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk,
+                     int all_cosets);
+void cso_air_evaluate_transitions(int air, const uint64_t *lde, const uint64_t *ptab, uint64_t *out, uint32_t width, uint32_t nc, uint32_t np,
+                                  uint32_t cycle_len, unsigned log_n, uint32_t k0, uint32_t nk);
+void cso_periodic_table(const uint64_t *cols, uint32_t np, unsigned log_cycle, unsigned log_n, unsigned log_b, uint64_t *out);
+
 /* deterministic witness synthesis (counterpart of TransactionMetadata::build_random, src/lib.rs:235-465).
  * The caller allocates every array of *w (non-const use). */
 int cso_tx_witness_generate(cstark_tx_witness *w, uint64_t seed);

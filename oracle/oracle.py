@@ -312,3 +312,125 @@ def tx_combined_at(trace_coeffs, coeffs, pub_inputs, depth, log_b, z):
 def num_threads():
     """OpenMP threads the oracle actually uses (cpu_baseline.cores)."""
     return int(lib().cso_num_threads())
+
+
+# ---- standalone sub-AIRs (air_small.c) ---------------------------------------------------------------
+AIR_STATE_TRANSITION, AIR_MERKLE, AIR_SCHNORR, AIR_RANGE, AIR_RESCUE_CHAIN = 0, 1, 2, 3, 4
+
+
+class AirDescStruct(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("n_constraints", C.c_uint32), ("cycle_len", C.c_uint32), ("log_ce_blowup", C.c_uint32),
+                ("base", u32p), ("cycles", u32p), ("n_assertions", C.c_uint32), ("a_reg", u32p), ("a_last", u32p), ("a_value", u64p)]
+
+
+class AirDesc:
+    """Python-side holder of a cso_air_desc."""
+
+    def __init__(self, width, base, cycles, cycle_len, a_reg, a_last, a_value):
+        self.width, self.cycle_len = width, cycle_len
+        self.base = np.ascontiguousarray(base, np.uint32)
+        self.cycles = np.ascontiguousarray(cycles, np.uint32)
+        self.a_reg = np.ascontiguousarray(a_reg, np.uint32)
+        self.a_last = np.ascontiguousarray(a_last, np.uint32)
+        self.a_value = np.ascontiguousarray(a_value, np.uint64)
+        self.nc, self.na = len(self.base), len(self.a_reg)
+        m = max(int(b) + (int(c) if cycle_len else 0) for b, c in zip(self.base, self.cycles))
+        self.log_ce = max(1, (m - 1).bit_length())  # next power of two >= max degree, at least 2
+
+    def struct(self):
+        s = AirDescStruct()
+        s.width, s.n_constraints, s.cycle_len, s.log_ce_blowup = self.width, self.nc, self.cycle_len, self.log_ce
+        s.base, s.cycles = _p(self.base, u32p), _p(self.cycles, u32p)
+        s.n_assertions, s.a_reg, s.a_last, s.a_value = self.na, _p(self.a_reg, u32p), _p(self.a_last, u32p), _p(self.a_value)
+        return s
+
+
+def merkle_build_trace(w):
+    trace = np.zeros((65, w.n_tx * 512), np.uint64)
+    s = w.struct()
+    if lib().cso_merkle_build_trace(C.byref(s), _p(trace)):
+        raise RuntimeError("cso_merkle_build_trace failed")
+    return trace
+
+
+def merkle_periodic_columns(depth):
+    out = np.zeros((33, 512), np.uint64)
+    if lib().cso_merkle_periodic_columns(C.c_uint(depth), _p(out)):
+        raise RuntimeError("bad depth")
+    return out
+
+
+def merkle_desc(trace):
+    base = np.zeros(106, np.uint32); cyc = np.zeros(106, np.uint32)
+    lib().cso_merkle_constraint_degrees(_p(base, u32p), _p(cyc, u32p))
+    regs = list(range(58, 65)) * 2
+    return AirDesc(65, base, cyc, 512, regs, [0] * 7 + [1] * 7, np.concatenate([trace[58:65, 0], trace[58:65, -1]]))
+
+
+def range_build_trace(number):
+    trace = np.zeros((2, 64), np.uint64)
+    lib().cso_range_build_trace(C.c_uint64(number), _p(trace))
+    return trace
+
+
+def range_desc(number):
+    return AirDesc(2, [2, 1], [0, 0], 0, [1, 1], [0, 1], [0, int(to_mont([number])[0])])
+
+
+def rescue_chain_build_trace(seed, iterations):
+    seed = _u64(seed)
+    trace = np.zeros((14, 8 * iterations), np.uint64)
+    lib().cso_rescue_chain_build_trace(_p(seed), C.c_uint32(iterations), _p(trace))
+    return trace
+
+
+def rescue_chain_periodic_columns():
+    out = np.zeros((29, 8), np.uint64)
+    lib().cso_rescue_chain_periodic_columns(_p(out))
+    return out
+
+
+def rescue_chain_desc(trace):
+    return AirDesc(14, [3] * 14, [1] * 14, 8, list(range(7)) * 2, [0] * 7 + [1] * 7, np.concatenate([trace[:7, 0], trace[:7, -1]]))
+
+
+def rescue_compute_hash_chain(seed, length):
+    seed = _u64(seed); out = np.zeros(7, np.uint64)
+    lib().cso_rescue_compute_hash_chain(_p(seed), C.c_uint32(length), _p(out))
+    return out
+
+
+def periodic_table(cols, log_n, log_b):
+    cols = _u64(cols)
+    np_, C_ = cols.shape
+    out = np.zeros((1 << log_b, np_, C_), np.uint64)
+    lib().cso_periodic_table(_p(cols), C.c_uint32(np_), C.c_uint(C_.bit_length() - 1), C.c_uint(log_n), C.c_uint(log_b), _p(out))
+    return out
+
+
+def air_evaluate_transitions(air, lde, ptab, nc, k0=0):
+    lde = _u64(lde)
+    nk, width, n = lde.shape
+    if ptab is None:
+        np_, cl, pp = 0, 1, None
+    else:
+        ptab = _u64(ptab); np_, cl, pp = ptab.shape[1], ptab.shape[2], _p(ptab)
+    out = np.zeros((nk, nc, n), np.uint64)
+    lib().cso_air_evaluate_transitions(C.c_int(air), _p(lde), pp, _p(out), C.c_uint32(width), C.c_uint32(nc), C.c_uint32(np_),
+                                       C.c_uint32(cl), C.c_uint(n.bit_length() - 1), C.c_uint32(k0), C.c_uint32(nk))
+    return out
+
+
+def air_combine(desc, lde, evals, t_alpha, t_beta, b_alpha, b_beta, log_b, k0=0, all_cosets=False):
+    lde, evals = _u64(lde), _u64(evals)
+    nk, width, n = lde.shape
+    out = np.zeros((nk, n), np.uint64)
+    s = desc.struct()
+    lib().cso_air_combine(C.byref(s), _p(lde), _p(evals), _p(_u64(t_alpha)), _p(_u64(t_beta)), _p(_u64(b_alpha)), _p(_u64(b_beta)),
+                          _p(out), C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_uint32(k0), C.c_uint32(nk), C.c_int(1 if all_cosets else 0))
+    return out
+
+
+def random_elements(k, seed):
+    rng = np.random.default_rng(seed)
+    return to_mont(rng.integers(0, P, size=k, dtype=np.uint64))
