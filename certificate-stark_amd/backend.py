@@ -144,3 +144,37 @@ class Backend:
         check(self.lib.cstark_tx_evaluate_constraints(self.ctx, self._ptr(lde), C.byref(coeffs), pub, self._ptr(out), C.c_uint32(depth),
                                                       C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out
+
+    # ---- standalone sub-AIRs (MerkleAir, RangeProofAir) ----
+    AIR_MERKLE, AIR_RANGE = 1, 3
+
+    def merkle_build_trace(self):
+        out = self.empty_u64(65, self.n_tx * 512)
+        check(self.lib.cstark_merkle_build_trace(self.ctx, self._ptr(out)))
+        return out
+
+    def range_build_trace(self, number_mont):
+        out = self.empty_u64(2, 64)
+        check(self.lib.cstark_range_build_trace(self.ctx, C.c_uint64(int(number_mont)), self._ptr(out)))
+        return out
+
+    def air_shape(self, air):
+        w, nc, na, lce = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(self.lib.cstark_air_shape(C.c_int(air), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)))
+        return w.value, nc.value, na.value, lce.value
+
+    def air_evaluate_transitions(self, air, lde, depth, log_blowup, k0=0):
+        nk, width, n = lde.shape
+        nc = self.air_shape(air)[1]
+        out = self.empty_u64(nk, nc, n)
+        check(self.lib.cstark_air_evaluate_transitions(self.ctx, C.c_int(air), self._ptr(lde), self._ptr(out), C.c_uint32(depth),
+                                                       C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
+        return out
+
+    def air_combine(self, air, lde, evals, t_alpha, t_beta, b_alpha, b_beta, assertion_values, log_blowup, k0=0):
+        nk, width, n = lde.shape
+        out = self.empty_u64(nk, n)
+        arrs = [_np_u64(a) for a in (t_alpha, t_beta, b_alpha, b_beta, assertion_values)]
+        check(self.lib.cstark_air_combine(self.ctx, C.c_int(air), self._ptr(lde), self._ptr(evals), *[a.ctypes.data_as(u64p) for a in arrs],
+                                          self._ptr(out), C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
+        return out

@@ -57,5 +57,55 @@ inline uint64_t tx_group_eval_degree(int g, uint64_t n) { return TX_GROUP_BASE[g
 inline uint64_t tx_group_adjustment(int g, uint64_t n, uint64_t ce_size) { return (ce_size - 1 + n - 1) - tx_group_eval_degree(g, n); }
 inline uint64_t tx_boundary_adjustment(uint64_t n, uint64_t ce_size) { return ce_size - n + 1; }
 
+// ---- standalone sub-AIRs ------------------------------------------------------------
+// MerkleAir periodic columns (src/merkle/update/air.rs:182-212): setup, hash, hash_input (period 8), finish,
+// hash_mask, 28 round constants; 33 columns x 512 rows
+inline bool merkle_periodic_columns(unsigned depth, std::vector<uint64_t> &out) {
+    const unsigned hash_len = 8 * depth + 7;
+    if (depth == 0 || hash_len > 511) return false;
+    out.assign((size_t)33 * 512, 0);
+    auto col = [&](int c) { return out.data() + (size_t)c * 512; };
+    col(0)[0] = ONE;
+    for (unsigned i = 0; i < hash_len; i++) { col(1)[i] = ONE; col(4)[i] = (i % 8) != 7 ? ONE : 0; }
+    for (unsigned i = 0; i < 512; i++) col(2)[i] = (i % 8) == 7 ? ONE : 0;
+    col(3)[hash_len - 1] = ONE;
+    for (int j = 0; j < 28; j++)
+        for (unsigned i = 0; i < 512; i++) col(5 + j)[i] = CS_ARK_MONT[(i % 8) * 28 + j];
+    return true;
+}
+
+// Static description of an AIR as the engine sees it: width, constraint degrees (base; cycles of length cycle_len),
+// single-step assertions.  air ids as in cstark_air_id.
+struct AirShape {
+    uint32_t width = 0, n_constraints = 0, cycle_len = 0, n_periodic = 0;
+    std::vector<uint32_t> base, cycles;
+    std::vector<uint32_t> a_reg, a_last; // assertion register, 0 = first step / 1 = last step
+    uint32_t log_ce_blowup() const {     // next power of two >= max(base + cycles), at least 2 [UPSTREAM-RECALL]
+        uint32_t m = 2;
+        for (size_t i = 0; i < base.size(); i++) m = base[i] + (cycle_len ? cycles[i] : 0) > m ? base[i] + (cycle_len ? cycles[i] : 0) : m;
+        uint32_t l = 0;
+        while ((1u << l) < m) l++;
+        return l;
+    }
+    uint64_t eval_degree(size_t i, uint64_t n) const { return base[i] * (n - 1) + (cycle_len ? cycles[i] * (n / cycle_len) * (cycle_len - 1) : 0); }
+};
+inline bool air_shape(int air, AirShape &s) {
+    s = AirShape{};
+    if (air == 1) { // MerkleAir: transition_constraint_degrees(512), src/merkle/update/air.rs:371-401; 14 root assertions :142-170
+        s.width = 65; s.n_constraints = 106; s.cycle_len = 512; s.n_periodic = 33;
+        s.base.assign(106, 1); s.cycles.assign(106, 1);
+        for (int b = 0; b < 58; b += 29) { for (int i = 0; i < 29; i++) s.base[b + i] = 3; s.base[b + 14] = 2; }
+        for (int a = 0; a < 14; a++) { s.a_reg.push_back(58 + a % 7); s.a_last.push_back(a / 7); }
+        return true;
+    }
+    if (air == 3) { // RangeProofAir: degrees (2), (1), src/range/air.rs:100-105; assertions :79-86
+        s.width = 2; s.n_constraints = 2; s.cycle_len = 0; s.n_periodic = 0;
+        s.base = {2, 1}; s.cycles = {0, 0};
+        s.a_reg = {1, 1}; s.a_last = {0, 1};
+        return true;
+    }
+    return false;
+}
+
 } // namespace host
 } // namespace cs

@@ -49,6 +49,7 @@ struct PeriodicTable {
     uint64_t *tab;   // [b][48][1024]
     uint64_t *coset; // [b][CE_COSET_CONSTS]
     uint64_t *binv;  // [b][2][n] inverses of the boundary divisors
+    int air = 0;     // cstark_air_id the table belongs to
 };
 
 } // namespace
@@ -67,6 +68,9 @@ struct cstark_ctx {
     std::deque<CosetTable> cosets;
     std::deque<PeriodicTable> periodic;
     uint64_t *coef_buf = nullptr; // device copy of the composition coefficients
+    std::deque<PeriodicTable> small_periodic; // standalone sub-AIRs: keyed by (air, depth, log_n, log_b); coset/binv unused
+    void *desc_buf = nullptr;     // device copy of a generic AIR description (cstark_air_combine)
+    size_t desc_bytes = 0;
     void *ws = nullptr;
     size_t ws_bytes = 0;
 };
@@ -259,6 +263,8 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     for (NttPlan &p : c->plans) { (void)hipFree(p.w); (void)hipFree(p.winv); }
     for (CosetTable &t : c->cosets) (void)hipFree(t.s);
     for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); (void)hipFree(t.binv); }
+    for (PeriodicTable &t : c->small_periodic) (void)hipFree(t.tab);
+    if (c->desc_buf) (void)hipFree(c->desc_buf);
     delete c;
 }
 
@@ -398,6 +404,132 @@ int cstark_tx_evaluate_constraints(cstark_ctx *c, const uint64_t *d_lde, const c
     p.coef = c->coef_buf;
     for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
     HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream));
+    return CSTARK_OK;
+}
+
+// ---- standalone sub-AIRs -------------------------------------------------------------
+int cstark_merkle_build_trace(cstark_ctx *c, uint64_t *d_trace) {
+    if (!c || !d_trace) return fail(CSTARK_ERR_INVALID_ARG, "cstark_merkle_build_trace: null argument");
+    if (!c->wit_buf || c->wit.n_tx == 0) return fail(CSTARK_ERR_INVALID_ARG, "no witness uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::launch_merkle_trace(c->wit, d_trace, c->stream));
+    return CSTARK_OK;
+}
+int cstark_range_build_trace(cstark_ctx *c, uint64_t number, uint64_t *d_trace) {
+    if (!c || !d_trace) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_build_trace: null argument");
+    if (number >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "number is not a field element");
+    const uint64_t canonical = cs::host::to_u64(number);
+    if (canonical >> 63) return fail(CSTARK_ERR_INVALID_ARG, "range proofs cover 63-bit values (src/range/tests.rs:54-62 panics above)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::launch_range_trace(canonical, d_trace, c->stream));
+    return CSTARK_OK;
+}
+
+int cstark_air_shape(int air, uint32_t *width, uint32_t *n_constraints, uint32_t *n_assertions, uint32_t *log_ce_blowup) {
+    cs::host::AirShape s;
+    if (!cs::host::air_shape(air, s) || !width || !n_constraints || !n_assertions || !log_ce_blowup) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
+    *width = s.width; *n_constraints = s.n_constraints; *n_assertions = (uint32_t)s.a_reg.size(); *log_ce_blowup = s.log_ce_blowup();
+    return CSTARK_OK;
+}
+int cstark_air_constraint_degree(int air, uint32_t i, uint32_t *base, uint32_t *cycles) {
+    cs::host::AirShape s;
+    if (!cs::host::air_shape(air, s) || i >= s.n_constraints || !base || !cycles) return fail(CSTARK_ERR_INVALID_ARG, "bad AIR / constraint index");
+    *base = s.base[i]; *cycles = s.cycles[i];
+    return CSTARK_OK;
+}
+int cstark_merkle_periodic_columns(uint32_t merkle_depth, uint64_t *out /* [33][512] host */) {
+    std::vector<uint64_t> cols;
+    if (!out || !cs::host::merkle_periodic_columns(merkle_depth, cols)) return fail(CSTARK_ERR_INVALID_ARG, "unsupported Merkle depth");
+    memcpy(out, cols.data(), cols.size() * 8);
+    return CSTARK_OK;
+}
+
+int cstark_air_evaluate_transitions(cstark_ctx *c, int air, const uint64_t *d_lde, uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n,
+                                    uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!c || !d_lde || !d_out || nk == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_evaluate_transitions: bad argument");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup))
+        return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
+    HIP_TRY(hipSetDevice(c->device));
+    if (air == CSTARK_AIR_RANGE) {
+        HIP_TRY(cs::launch_eval_transitions_range(d_lde, d_out, log_n, nk, c->stream));
+        return CSTARK_OK;
+    }
+    if (air != CSTARK_AIR_MERKLE_UPDATE) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
+    if (log_n < 9) return fail(CSTARK_ERR_INVALID_ARG, "the trace must hold at least one 512-row transaction");
+    const PeriodicTable *pt = nullptr;
+    for (const PeriodicTable &t : c->small_periodic)
+        if (t.air == air && t.depth == merkle_depth && t.log_n == log_n && t.log_b == log_blowup) pt = &t;
+    if (!pt) {
+        std::vector<uint64_t> cols;
+        if (!cs::host::merkle_periodic_columns(merkle_depth, cols)) return fail(CSTARK_ERR_INVALID_ARG, "unsupported Merkle depth");
+        const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_blowup;
+        PeriodicTable t{merkle_depth, log_n, log_blowup, nullptr, nullptr, nullptr, air};
+        uint64_t *d_cols = nullptr, *d_poly = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_cols, cols.size() * 8));
+        HIP_TRY(hipMalloc((void **)&d_poly, cols.size() * 8));
+        HIP_TRY(hipMalloc((void **)&t.tab, b * cols.size() * 8));
+        HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), cols.size() * 8, hipMemcpyHostToDevice, c->stream));
+        RC_TRY(interpolate_impl(c, d_cols, d_poly, 33, 9));
+        RC_TRY(lde_impl(c, d_poly, t.tab, 33, 9, log_blowup, cs::host::pow(cs::host::generator(), n / 512), 0, (uint32_t)b));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(d_cols));
+        HIP_TRY(hipFree(d_poly));
+        c->small_periodic.push_back(t);
+        pt = &c->small_periodic.back();
+    }
+    HIP_TRY(cs::launch_eval_transitions_merkle(d_lde, pt->tab, d_out, log_n, k0, nk, c->stream));
+    return CSTARK_OK;
+}
+
+int cstark_air_combine(cstark_ctx *c, int air, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha, const uint64_t *t_beta,
+                       const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values, uint64_t *d_out, uint32_t log_n,
+                       uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!c || !d_lde || !d_evals || !t_alpha || !t_beta || !b_alpha || !b_beta || !assertion_values || !d_out || nk == 0)
+        return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: null argument");
+    cs::host::AirShape s;
+    if (!cs::host::air_shape(air, s)) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
+    const uint32_t log_ce = s.log_ce_blowup();
+    if (log_blowup < log_ce || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "blowup factor below the constraint degree");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_INVALID_ARG, "bad trace length");
+    HIP_TRY(hipSetDevice(c->device));
+    const NttPlan *plan;
+    RC_TRY(get_plan(c, log_n, &plan));
+    const uint64_t n = 1ull << log_n, ce = n << log_ce, b = 1ull << log_blowup;
+    const size_t nc = s.n_constraints, na = s.a_reg.size();
+    // one device block: t_alpha | t_beta | adj | b_alpha | b_beta | a_value | shifts | a_reg(u32) | a_last(u32)
+    std::vector<uint64_t> blk(3 * nc + 3 * na + b + na);
+    uint64_t *q = blk.data();
+    memcpy(q, t_alpha, nc * 8); q += nc;
+    memcpy(q, t_beta, nc * 8); q += nc;
+    for (size_t i = 0; i < nc; i++) *q++ = (ce - 1 + n - 1) - s.eval_degree(i, n);
+    memcpy(q, b_alpha, na * 8); q += na;
+    memcpy(q, b_beta, na * 8); q += na;
+    memcpy(q, assertion_values, na * 8); q += na;
+    const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
+    uint64_t shift = cs::host::generator();
+    for (uint64_t k = 0; k < b; k++) { *q++ = shift; shift = cs::host::mul(shift, wbn); }
+    uint32_t *q32 = (uint32_t *)q;
+    for (size_t a = 0; a < na; a++) q32[a] = s.a_reg[a];
+    for (size_t a = 0; a < na; a++) q32[na + a] = s.a_last[a];
+    const size_t bytes = blk.size() * 8;
+    if (bytes > c->desc_bytes) {
+        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); }
+        HIP_TRY(hipMalloc(&c->desc_buf, bytes));
+        c->desc_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(c->desc_buf, blk.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t *d = (const uint64_t *)c->desc_buf;
+    cs::AirCombineParams p{};
+    p.lde = d_lde; p.evals = d_evals; p.w = plan->w; p.out = d_out;
+    p.t_alpha = d; p.t_beta = d + nc; p.adj = d + 2 * nc;
+    p.b_alpha = d + 3 * nc; p.b_beta = d + 3 * nc + na; p.a_value = d + 3 * nc + 2 * na; p.shifts = d + 3 * nc + 3 * na;
+    p.a_reg = (const uint32_t *)(d + 3 * nc + 3 * na + b); p.a_last = p.a_reg + na;
+    p.w_last = cs::host::inv(cs::host::root_of_unity(log_n));
+    p.badj = ce - n + 1;
+    p.width = s.width; p.n_constraints = (uint32_t)nc; p.n_assertions = (uint32_t)na;
+    p.stride = 1u << (log_blowup - log_ce); p.log_n = log_n; p.k0 = k0;
+    HIP_TRY(cs::launch_air_combine(p, nk, c->stream));
     return CSTARK_OK;
 }
 

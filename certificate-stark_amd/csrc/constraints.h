@@ -32,6 +32,21 @@ struct CeParams {
     uint32_t log_n, log_b, k0;
 };
 
+// generic merge of materialised constraint evaluations (standalone sub-AIRs); all pointers are device memory
+struct AirCombineParams {
+    const uint64_t *lde, *evals, *w, *shifts; // shifts[k] = g * w_{bn}^k for every LDE coset
+    const uint64_t *t_alpha, *t_beta, *adj;   // [n_constraints]; adj = degree adjustment exponent
+    const uint64_t *b_alpha, *b_beta, *a_value;
+    const uint32_t *a_reg, *a_last;           // [n_assertions]
+    uint64_t *out;
+    uint64_t w_last, badj;
+    uint32_t width, n_constraints, n_assertions, stride, log_n, k0;
+};
+hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_t stream);
+hipError_t launch_eval_transitions_merkle(const uint64_t *lde, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0, unsigned nk,
+                                          hipStream_t stream);
+hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream);
+
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);
 hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream);
 hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,

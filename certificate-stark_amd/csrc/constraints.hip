@@ -42,11 +42,12 @@ enum {
 
 // one evaluation frame: strided views of the current / next LDE rows and of the periodic values
 struct Frame {
-    const fp *cur_p, *next_p, *per_p; // element c at cur_p[c * n], per_p[c * 1024]
+    const fp *cur_p, *next_p, *per_p; // element c at cur_p[c * n], per_p[c * pcycle]
     size_t n;
+    unsigned pcycle;                  // rows per periodic cycle (1024 for the composite AIR)
     __device__ __forceinline__ fp cur(int c) const { return cur_p[(size_t)c * n]; }
     __device__ __forceinline__ fp next(int c) const { return next_p[(size_t)c * n]; }
-    __device__ __forceinline__ fp pv(int c) const { return per_p[(size_t)c * 1024]; }
+    __device__ __forceinline__ fp pv(int c) const { return per_p[(size_t)c * pcycle]; }
 };
 
 // ---- accumulators ---------------------------------------------------------------------------------
@@ -343,6 +344,7 @@ __device__ __forceinline__ Frame make_frame(const CeParams &p, unsigned kk, size
     f.cur_p = base + j;
     f.next_p = base + ((j + 1) & (n - 1)); // LDE row i + blowup = (k, j + 1)
     f.per_p = p.ptab + (size_t)(p.k0 + kk) * 48 * 1024 + (j & 1023);
+    f.pcycle = 1024;
     return f;
 }
 
@@ -677,6 +679,95 @@ __global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : 2) voi
     *o = PART == PART_ROUNDS ? t : fp_add(*o, t); // ROUNDS is launched first, the others accumulate in stream order
 }
 
+// =====================================================================================================
+// Standalone sub-AIRs: parity-oriented kernels, every constraint materialised.
+// MerkleAir::evaluate_transition  /root/reference/src/merkle/update/air.rs:64-141, :215-289
+__global__ __launch_bounds__(NT) void k_eval_transitions_merkle(const fp *lde, const fp *ptab, fp *out, unsigned log_n, unsigned k0) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)NT + threadIdx.x;
+    const unsigned kk = blockIdx.y;
+    const fp *base = lde + (size_t)kk * 65 * n;
+    Frame f;
+    f.n = n;
+    f.cur_p = base + j;
+    f.next_p = base + ((j + 1) & (n - 1));
+    f.per_p = ptab + (size_t)(k0 + kk) * 33 * 512 + (j & 511);
+    f.pcycle = 512;
+    AccAll acc{out + (size_t)kk * 106 * n + j, n};
+    // periodic layout: setup, hash(tx), hash_input, finish, hash_mask, ark[28]; the gadget templates read the round
+    // constants at P_ARK + i relative to per_p, so give them a view shifted by (5 - P_ARK) columns
+    Frame fr = f;
+    fr.per_p = f.per_p - (size_t)(P_ARK - 5) * 512;
+    const fp setup = f.pv(0), tx_hash = f.pv(1), hash_input = f.pv(2), finish = f.pv(3), hash_flag = f.pv(4);
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        acc.add(VALUE_RES + i, setup, fp_sub(f.cur(S_INIT + i), f.cur(S_UPD + i)));
+        acc.add(VALUE_RES + 12 + i, setup, fp_sub(f.cur(R_INIT + i), f.cur(R_UPD + i)));
+    }
+    acc.add(VALUE_RES + 24, setup, fp_sub(f.cur(R_INIT + 13), f.cur(R_UPD + 13)));
+    acc.add(BALANCE_RES, setup, fp_sub(fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12)), fp_sub(f.cur(R_UPD + 12), f.cur(R_INIT + 12))));
+    acc.add(NONCE_UPD_RES, setup, fp_sub(f.cur(S_UPD + 13), fp_add(f.cur(S_INIT + 13), FP_ONE)));
+    enforce_round(acc, fr, S_INIT, S_INIT, hash_flag, 0, 0, false);
+    enforce_round(acc, fr, S_UPD, S_UPD, hash_flag, 0, 0, false);
+    enforce_round(acc, fr, R_INIT, R_INIT, hash_flag, 0, 0, false);
+    enforce_round(acc, fr, R_UPD, R_UPD, hash_flag, 0, 0, false);
+    merkle_auth_rest(acc, f, S_INIT, tx_hash, hash_input, hash_flag);
+    merkle_auth_rest(acc, f, R_INIT, tx_hash, hash_input, hash_flag);
+    const fp not_finish = c_not(finish);
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) {
+        const fp nr = f.next(PREV_ROOT + i), cr = f.cur(PREV_ROOT + i);
+        acc.add(PREV_ROOT + i, not_finish, fp_sub(nr, cr));
+        acc.add(PREV_ROOT + i, finish, fp_sub(nr, f.next(R_UPD + i)));
+        acc.add(INT_ROOT_RES + i, finish, fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)));
+        acc.add(PREV_MATCH_RES + i, finish, fp_sub(f.next(S_INIT + i), cr));
+    }
+}
+// RangeProofAir::evaluate_transition  src/range/air.rs:60-98 (enforce_double_and_add_step with flag ONE)
+__global__ void k_eval_transitions_range(const fp *lde, fp *out, unsigned log_n) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const unsigned kk = blockIdx.y;
+    const fp *base = lde + (size_t)kk * 2 * n;
+    const size_t jn = (j + 1) & (n - 1);
+    const fp nb = base[jn];
+    out[((size_t)kk * 2 + 1) * n + j] = fp_sub(base[n + jn], fp_add(fp_dbl(base[n + j]), nb)); // result[1]: accumulator
+    out[((size_t)kk * 2 + 0) * n + j] = c_is_binary(nb);                                         // result[0]: bit
+}
+
+// Generic merge of materialised transition evaluations with single-step boundary constraints:
+//   out = sum_i (alpha_i + beta_i x^adj_i) C_i(x) / Z(x) + sum_a (T_reg(x) - v_a)(alpha_a + beta_a x^badj) / (x - w^step_a)
+// Cosets outside the constraint-evaluation domain (k % stride != 0) are written as 0.
+__global__ void k_air_combine(AirCombineParams p) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const unsigned kk = blockIdx.y, k = p.k0 + kk;
+    fp *o = p.out + (size_t)kk * n + j;
+    if (k % p.stride) { *o = 0; return; }
+    const fp shift = p.shifts[k];
+    const fp x = fp_mul(shift, p.w[j]);
+    fp acc = 0;
+    for (unsigned i = 0; i < p.n_constraints; i++) {
+        const fp xp = fp_pow(x, p.adj[i]);
+        acc = fp_add(acc, fp_mul(p.evals[((size_t)kk * p.n_constraints + i) * n + j], fp_add(p.t_alpha[i], fp_mul(p.t_beta[i], xp))));
+    }
+    const fp d0 = fp_sub(x, FP_ONE), d1 = fp_sub(x, p.w_last);
+    const fp zinv = fp_mul(d1, fp_inv(fp_sub(fp_pow(x, n), FP_ONE)));
+    acc = fp_mul(acc, zinv);
+    const fp xb = fp_pow(x, p.badj);
+    fp first = 0, last = 0;
+    for (unsigned a = 0; a < p.n_assertions; a++) {
+        const fp tv = p.lde[((size_t)kk * p.width + p.a_reg[a]) * n + j];
+        const fp term = fp_mul(fp_sub(tv, p.a_value[a]), fp_add(p.b_alpha[a], fp_mul(p.b_beta[a], xb)));
+        if (p.a_last[a]) last = fp_add(last, term); else first = fp_add(first, term);
+    }
+    acc = fp_add(acc, fp_mul(first, fp_inv(d0)));
+    acc = fp_add(acc, fp_mul(last, fp_inv(d1)));
+    *o = acc;
+}
+
 } // namespace
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream) {
@@ -686,6 +777,25 @@ hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t s
     hipLaunchKernelGGL(k_eval_transitions, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, p);
     return hipGetLastError();
 }
+hipError_t launch_eval_transitions_merkle(const uint64_t *lde, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0, unsigned nk,
+                                          hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)nk * 106 * n * sizeof(fp), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_eval_transitions_merkle, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, ptab, out, log_n, k0);
+    return hipGetLastError();
+}
+hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_eval_transitions_range, dim3((unsigned)((n + 63) / 64), nk), dim3(64), 0, stream, lde, out, log_n);
+    return hipGetLastError();
+}
+hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    hipLaunchKernelGGL(k_air_combine, dim3((unsigned)((n + 63) / 64), nk), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), nk), block(FNT);

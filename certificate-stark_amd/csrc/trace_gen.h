@@ -17,4 +17,8 @@ struct TxWitnessDev {
 // owned by the caller (fork: stream -> side, join: side -> stream)
 hipError_t launch_trace_gen(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t join);
 
+// standalone sub-AIR traces
+hipError_t launch_merkle_trace(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream); // 65 x 512*n_tx
+hipError_t launch_range_trace(uint64_t number_canonical, uint64_t *d_trace, hipStream_t stream); // 2 x 64
+
 } // namespace cs

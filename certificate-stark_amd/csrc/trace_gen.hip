@@ -64,6 +64,8 @@ __device__ __forceinline__ void flush_tile(const fp (*tile)[LD], fp *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// STANDALONE: the 65-register, 512-rows-per-transaction trace of MerkleProver (src/merkle/update/prover.rs:28-80)
+template <bool STANDALONE>
 __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
     __shared__ fp tile[64][65];
     __shared__ fp st[4][14];
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restr
     tile[0][col] = v;
     if (lane == 56) tile[0][43] = 0;
 
-    const size_t gbase = (size_t)t * TXC;
+    const size_t gbase = (size_t)t * (STANDALONE ? MERKLE_LEN : TXC);
     for (int step = 0; step < MERKLE_LEN - 1; step++) {
         if (step < hash_len) {
             const int cyc = step & 7, lvl = step >> 3;
@@ -131,6 +133,11 @@ __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restr
             flush_tile<65, 65>(tile, trace, n, gbase + (step + 1 - 63), 0, lane);
             __syncthreads();
         }
+    }
+    if (STANDALONE) {
+        // index-bit poke at global row 1 (src/merkle/update/prover.rs:72-77); after this workgroup's own flushes
+        if (t == 0 && lane == 0) { trace[(size_t)14 * n + 1] = FP_ONE; trace[(size_t)43 * n + 1] = FP_ONE; }
+        return;
     }
     // registers 58..64 keep the new root through the Schnorr half (rows 512..1023)
     if (lane >= 57)
@@ -443,12 +450,31 @@ hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stre
     hipError_t e;
     if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace_merkle, dim3(w.n_tx), dim3(64), 0, side, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_merkle<false>, dim3(w.n_tx), dim3(64), 0, side, w, d_trace, n);
     if ((e = hipEventRecord(join, side)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_trace_schnorr_hash, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_ec, dim3(w.n_tx), dim3(128), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_aux, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
     if ((e = hipStreamWaitEvent(stream, join, 0)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_merkle_trace(const TxWitnessDev &w, fp *d_trace, hipStream_t stream) {
+    const size_t n = (size_t)w.n_tx * MERKLE_LEN;
+    hipLaunchKernelGGL(k_trace_merkle<true>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    return hipGetLastError();
+}
+
+// RangeProver::build_trace (src/range/prover.rs:24-43): row q holds bit (62 - (q-1)) and the top q bits of the 63-bit value
+__global__ void k_trace_range(uint64_t number, fp *trace) {
+    const int q = threadIdx.x; // 64 rows
+    const uint64_t v63 = number & 0x7FFFFFFFFFFFFFFFULL; // bits 62..0 are consumed, MSB first
+    const uint64_t acc = q == 0 ? 0 : v63 >> (63 - q);
+    trace[q] = (q >= 1 && (acc & 1)) ? FP_ONE : 0;
+    trace[64 + q] = fp_from_u64(acc);
+}
+hipError_t launch_range_trace(uint64_t number_canonical, fp *d_trace, hipStream_t stream) {
+    hipLaunchKernelGGL(k_trace_range, dim3(1), dim3(64), 0, stream, number_canonical, d_trace);
     return hipGetLastError();
 }
 

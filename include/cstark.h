@@ -146,8 +146,31 @@ int cstark_tx_evaluate_constraints(cstark_ctx *ctx, const uint64_t *d_lde, const
                                    uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 /* Host-side AIR description (no GPU needed): degree (base; number of 1024-row cycles) of transition constraint i
  * (TransactionAir::new, src/air.rs:76-108) and the 48 periodic columns (src/air.rs:194-380), [48][1024]. */
-int cstark_tx_constraint_degree(uint32_t i, uint32_t *base, uint32_t *cycles);
+int cstark_tx_constraint_degree(uint32_t i, uint32_t *base, uint32_t *cycles);  /* CSTARK_AIR_STATE_TRANSITION */
 int cstark_tx_periodic_columns(uint32_t merkle_depth, uint64_t *out);
+
+/* ---- standalone sub-AIRs (reference src/merkle/update, src/range; BASELINE configs 1-2) ---------- */
+/* MerkleProver::build_trace (src/merkle/update/prover.rs:28-80): 65 x (512*n_tx) from the uploaded witness. */
+int cstark_merkle_build_trace(cstark_ctx *ctx, uint64_t *d_trace);
+/* RangeProver::build_trace (src/range/prover.rs:24-43): 2 x 64; `number` is a field element in memory form
+ * whose canonical value must be below 2^63. */
+int cstark_range_build_trace(cstark_ctx *ctx, uint64_t number, uint64_t *d_trace);
+/* Shape of an AIR as the engine sees it (host side): trace width, number of transition constraints and of
+ * assertions, log2 of the constraint-evaluation blowup; degree (base; cycles) of constraint i. */
+int cstark_air_shape(int air, uint32_t *width, uint32_t *n_constraints, uint32_t *n_assertions, uint32_t *log_ce_blowup);
+int cstark_air_constraint_degree(int air, uint32_t i, uint32_t *base, uint32_t *cycles);
+int cstark_merkle_periodic_columns(uint32_t merkle_depth, uint64_t *out /* [33][512] host */);
+/* All transition constraints of AIR `air` (CSTARK_AIR_MERKLE_UPDATE, CSTARK_AIR_RANGE) on LDE cosets [k0,k0+nk):
+ *   d_out[((k - k0) * n_constraints + i) * n + j]. */
+int cstark_air_evaluate_transitions(cstark_ctx *ctx, int air, const uint64_t *d_lde, uint64_t *d_out, uint32_t merkle_depth,
+                                    uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* Generic merge of those evaluations with the AIR's single-step assertions into the combined constraint
+ * evaluations d_out[(k - k0) * n + j].  Coefficient arrays and assertion values (in get_assertions order) are host
+ * memory.  The constraint-evaluation domain may be smaller than the LDE domain (MerkleAir: blowup 4); cosets
+ * outside it are written as 0. */
+int cstark_air_combine(cstark_ctx *ctx, int air, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha,
+                       const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values,
+                       uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 
 /* ---- device memory helpers for callers without a HIP runtime of their own (the Rust shim) ---- */
 int cstark_malloc(cstark_ctx *ctx, size_t bytes, void **d_ptr);

@@ -71,3 +71,21 @@ def test_host_air_description_matches_oracle(oracle):
     assert lib.cstark_field_generator() == oracle.generator()
     for k in (1, 10, 20, 23):
         assert lib.cstark_field_root_of_unity(C.c_uint32(k)) == oracle.root_of_unity(k)
+
+
+def test_small_air_host_descriptions_match_oracle(oracle):
+    lib = _lib()
+    base = np.zeros(106, np.uint32); cyc = np.zeros(106, np.uint32)
+    oracle.lib().cso_merkle_constraint_degrees(base.ctypes.data_as(C.POINTER(C.c_uint32)), cyc.ctypes.data_as(C.POINTER(C.c_uint32)))
+    for i in range(106):
+        b, c = C.c_uint32(), C.c_uint32()
+        assert lib.cstark_air_constraint_degree(C.c_int(1), C.c_uint32(i), C.byref(b), C.byref(c)) == 0
+        assert (b.value, c.value) == (int(base[i]), int(cyc[i]))
+    for depth in (3, 15, 31):
+        out = np.zeros((33, 512), np.uint64)
+        assert lib.cstark_merkle_periodic_columns(C.c_uint32(depth), out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+        assert (out == oracle.merkle_periodic_columns(depth)).all()
+    w, nc, na, lce = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    assert lib.cstark_air_shape(C.c_int(3), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == 0
+    assert (w.value, nc.value, na.value, lce.value) == (2, 2, 2, 1)
+    assert lib.cstark_air_shape(C.c_int(2), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == -5   # SchnorrAir: not built yet

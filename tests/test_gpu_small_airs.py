@@ -1,0 +1,73 @@
+"""GPU parity for the standalone sub-AIRs: MerkleAir and RangeProofAir traces, all transition
+constraints and the generic merged constraint evaluations (constraint-evaluation blowup below the LDE blowup),
+bit-exact against the oracle through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def backend():
+    from certificate_stark_amd.backend import Backend
+    b = Backend()
+    yield b
+    b.close()
+
+
+@pytest.mark.parametrize("n_tx,depth", [(1, 3), (2, 15), (8, 7)])
+def test_merkle_air(oracle, backend, n_tx, depth):
+    from certificate_stark_amd.backend import to_numpy_u64
+    w = oracle.TxWitness.generate(n_tx, depth, seed=900 + n_tx)
+    ref_trace = oracle.merkle_build_trace(w)
+    backend.upload_witness(w)
+    d_trace = backend.merkle_build_trace()
+    assert (to_numpy_u64(d_trace) == ref_trace).all()
+    log_b, log_n = 3, ref_trace.shape[1].bit_length() - 1
+    co = oracle.interpolate_columns(ref_trace)
+    lde = oracle.lde_columns(co, log_b)
+    d_lde = backend.lde_columns(backend.interpolate_columns(d_trace), log_b)
+    assert (to_numpy_u64(d_lde) == lde).all()
+    ptab = oracle.periodic_table(oracle.merkle_periodic_columns(depth), log_n, log_b)
+    ref_ev = oracle.air_evaluate_transitions(oracle.AIR_MERKLE, lde, ptab, 106)
+    d_ev = backend.air_evaluate_transitions(backend.AIR_MERKLE, d_lde, depth, log_b)
+    got = to_numpy_u64(d_ev)
+    if not (got == ref_ev).all():
+        raise AssertionError("constraints differ: %s" % sorted(set(np.argwhere(got != ref_ev)[:, 1].tolist())))
+    desc = oracle.merkle_desc(ref_trace)
+    assert backend.air_shape(backend.AIR_MERKLE) == (65, 106, 14, 2) and desc.log_ce == 2
+    ta, tb = oracle.random_elements(106, 1), oracle.random_elements(106, 2)
+    ba, bb = oracle.random_elements(14, 3), oracle.random_elements(14, 4)
+    ref = oracle.air_combine(desc, lde, ref_ev, ta, tb, ba, bb, log_b)
+    out = to_numpy_u64(backend.air_combine(backend.AIR_MERKLE, d_lde, d_ev, ta, tb, ba, bb, desc.a_value, log_b))
+    assert (out == ref).all()
+    assert not out[1::2].any() and out[0::2].any()      # odd cosets are outside the 4n-point evaluation domain
+
+
+@pytest.mark.parametrize("number", [0, 1, 2**63 - 1, 0x0123456789ABCDEF])
+def test_range_air(oracle, backend, number):
+    from certificate_stark_amd.backend import to_numpy_u64
+    number %= 2**62 + 2**56 + 2**55 + 1   # BaseElement::from reduces (the reference's "max input" 2^63 - 1 wraps mod p)
+    nm = int(oracle.to_mont([number])[0])
+    ref_trace = oracle.range_build_trace(number)
+    d_trace = backend.range_build_trace(nm)
+    assert (to_numpy_u64(d_trace) == ref_trace).all()
+    log_b = 3
+    lde = oracle.lde_columns(oracle.interpolate_columns(ref_trace), log_b)
+    d_lde = backend.lde_columns(backend.interpolate_columns(d_trace), log_b)
+    assert (to_numpy_u64(d_lde) == lde).all()
+    ref_ev = oracle.air_evaluate_transitions(oracle.AIR_RANGE, lde, None, 2)
+    d_ev = backend.air_evaluate_transitions(backend.AIR_RANGE, d_lde, 0, log_b)
+    assert (to_numpy_u64(d_ev) == ref_ev).all()
+    desc = oracle.range_desc(number)
+    ta, tb = oracle.random_elements(2, 5), oracle.random_elements(2, 6)
+    ba, bb = oracle.random_elements(2, 7), oracle.random_elements(2, 8)
+    ref = oracle.air_combine(desc, lde, ref_ev, ta, tb, ba, bb, log_b)
+    out = to_numpy_u64(backend.air_combine(backend.AIR_RANGE, d_lde, d_ev, ta, tb, ba, bb, desc.a_value, log_b))
+    assert (out == ref).all()
+
+
+def test_range_rejects_non_field_elements(oracle, backend):
+    from certificate_stark_amd import CstarkError
+    with pytest.raises(CstarkError):
+        backend.range_build_trace(2**62 + 2**56 + 2**55 + 1)   # raw value M is not a field element (src/range/tests.rs:54-62: should_panic)

@@ -42,7 +42,7 @@ def test_merkle_air_constraints_vanish(oracle, witness_d3, witness_d15):
 
 
 def test_range_air(oracle):
-    for number in (0, 1, 2**63 - 1, 0x123456789ABCDEF):             # src/range/tests.rs:44-52: max input 2^63 - 1
+    for number in (0, 1, (2**63 - 1) % P, 0x123456789ABCDEF, P - 1):   # src/range/tests.rs:44-52 (2^63 - 1 wraps mod p)
         trace = oracle.range_build_trace(number)
         assert not _check_trace(oracle, oracle.AIR_RANGE, trace, None, 2).any()
         assert int(oracle.from_mont(trace[1, -1:])[0]) == number % P and trace[1, 0] == 0
