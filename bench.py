@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-tx", type=int, default=1024, help="transactions per proof (1024 = BASELINE's 2^20 rows)")
-    ap.add_argument("--cpu-sample-tx", type=int, default=64)
+    ap.add_argument("--cpu-sample-tx", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["replica", "coset"], default="replica",
                     help="replica: independent proofs per GPU (weak scaling, no collective); "

@@ -628,7 +628,7 @@ __device__ __forceinline__ void fused_linear_c(Fused &acc, const Frame &f) {
 
 // grid = (n / FNT, nk)
 #ifndef CS_ROUNDS_WAVES
-#define CS_ROUNDS_WAVES 2
+#define CS_ROUNDS_WAVES 3
 #endif
 #ifndef CS_ROUNDS_UNROLL
 #define CS_ROUNDS_UNROLL 1
