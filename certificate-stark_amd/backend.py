@@ -178,3 +178,29 @@ class Backend:
         check(self.lib.cstark_air_combine(self.ctx, C.c_int(air), self._ptr(lde), self._ptr(evals), *[a.ctypes.data_as(u64p) for a in arrs],
                                           self._ptr(out), C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out
+
+    # ---- standalone SchnorrAir ----
+    def upload_schnorr_witness(self, messages, sig_rx, sig_s):
+        m, rx = _np_u64(messages), _np_u64(sig_rx)
+        s = np.ascontiguousarray(sig_s, np.uint8)
+        n_sig = m.shape[0]
+        check(self.lib.cstark_schnorr_witness_upload(self.ctx, C.c_uint32(n_sig), m.ctypes.data_as(u64p), rx.ctypes.data_as(u64p),
+                                                     s.ctypes.data_as(u8p)))
+        self.n_tx = n_sig
+
+    def schnorr_build_trace(self):
+        out = self.empty_u64(56, self.n_tx * 512)
+        check(self.lib.cstark_schnorr_build_trace(self.ctx, self._ptr(out)))
+        return out
+
+    def schnorr_aux_columns(self):
+        out = self.empty_u64(19, self.n_tx * 512)
+        check(self.lib.cstark_schnorr_aux_columns(self.ctx, self._ptr(out)))
+        return out
+
+    def schnorr_evaluate_transitions(self, lde, aux_lde, log_blowup, k0=0):
+        nk, width, n = lde.shape
+        out = self.empty_u64(nk, 56, n)
+        check(self.lib.cstark_schnorr_evaluate_transitions(self.ctx, self._ptr(lde), self._ptr(aux_lde), self._ptr(out),
+                                                           C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
+        return out

@@ -74,6 +74,21 @@ inline bool merkle_periodic_columns(unsigned depth, std::vector<uint64_t> &out) 
     return true;
 }
 
+// SchnorrAir input-independent periodic columns (src/schnorr/air.rs:335-391): global mask, scalar-mult, doubling, four
+// h-limb selectors, hash flag, then the 28 round constants; 36 columns x 512 rows
+inline void schnorr_mask_columns(std::vector<uint64_t> &out) {
+    out.assign((size_t)36 * 512, 0);
+    auto col = [&](int c) { return out.data() + (size_t)c * 512; };
+    for (unsigned i = 0; i < 511; i++) col(0)[i] = ONE;
+    for (unsigned i = 0; i < 510; i++) { col(1)[i] = ONE; col(2)[i] = (i % 2 == 0) ? ONE : 0; }
+    const unsigned lo[4] = {0, 126, 254, 382}, hi[4] = {126, 254, 382, 510};
+    for (int k = 0; k < 4; k++)
+        for (unsigned i = lo[k]; i < hi[k]; i++) col(3 + k)[i] = ONE;
+    for (unsigned i = 0; i < 40; i++) col(7)[i] = (i % 8) != 7 ? ONE : 0;
+    for (int j = 0; j < 28; j++)
+        for (unsigned i = 0; i < 512; i++) col(8 + j)[i] = CS_ARK_MONT[(i % 8) * 28 + j];
+}
+
 // Static description of an AIR as the engine sees it: width, constraint degrees (base; cycles of length cycle_len),
 // single-step assertions.  air ids as in cstark_air_id.
 struct AirShape {

@@ -70,6 +70,8 @@ struct cstark_ctx {
     uint64_t *coef_buf = nullptr; // device copy of the composition coefficients
     std::deque<PeriodicTable> small_periodic; // standalone sub-AIRs: keyed by (air, depth, log_n, log_b); coset/binv unused
     void *desc_buf = nullptr;     // device copy of a generic AIR description (cstark_air_combine)
+    uint64_t *tail_buf = nullptr; // standalone SchnorrAir: message[26..28] per signature
+    size_t tail_bytes = 0;
     size_t desc_bytes = 0;
     void *ws = nullptr;
     size_t ws_bytes = 0;
@@ -265,6 +267,7 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); (void)hipFree(t.binv); }
     for (PeriodicTable &t : c->small_periodic) (void)hipFree(t.tab);
     if (c->desc_buf) (void)hipFree(c->desc_buf);
+    if (c->tail_buf) (void)hipFree(c->tail_buf);
     delete c;
 }
 
@@ -339,6 +342,7 @@ int cstark_tx_witness_upload(cstark_ctx *c, const cstark_tx_witness *w) {
     dv.sig_rx = (const uint64_t *)(base + off[8]);
     dv.h_limbs = (uint64_t *)(base + off[9]);
     dv.sig_s = (const uint8_t *)(base + off[10]);
+    dv.msg_tail = nullptr;
     return CSTARK_OK;
 }
 
@@ -422,6 +426,88 @@ int cstark_range_build_trace(cstark_ctx *c, uint64_t number, uint64_t *d_trace) 
     if (canonical >> 63) return fail(CSTARK_ERR_INVALID_ARG, "range proofs cover 63-bit values (src/range/tests.rs:54-62 panics above)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(cs::launch_range_trace(canonical, d_trace, c->stream));
+    return CSTARK_OK;
+}
+
+// SchnorrAir (src/schnorr): messages [n][28], signatures (R.x [n][6], s bytes [n][32]); host arrays are copied
+int cstark_schnorr_witness_upload(cstark_ctx *c, uint32_t n_sig, const uint64_t *messages, const uint64_t *sig_rx, const uint8_t *sig_s) {
+    if (!c || !messages || !sig_rx || !sig_s || n_sig == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_witness_upload: bad argument");
+    // reuse the transaction-witness device view: message[0..12] -> s_old[0..12], [12..24] -> r_old[0..12], [24] -> deltas,
+    // [25] -> s_old[13]; the two trailing elements go to msg_tail
+    std::vector<uint64_t> s_old((size_t)n_sig * 14, 0), r_old((size_t)n_sig * 14, 0), deltas(n_sig), zeros((size_t)n_sig * 28, 0), tail((size_t)n_sig * 2);
+    for (uint32_t t = 0; t < n_sig; t++) {
+        const uint64_t *m = messages + 28 * (size_t)t;
+        memcpy(&s_old[14 * (size_t)t], m, 12 * 8);
+        s_old[14 * (size_t)t + 13] = m[25];
+        memcpy(&r_old[14 * (size_t)t], m + 12, 12 * 8);
+        deltas[t] = m[24];
+        tail[2 * (size_t)t] = m[26];
+        tail[2 * (size_t)t + 1] = m[27];
+    }
+    cstark_tx_witness w{};
+    w.n_tx = n_sig; w.merkle_depth = 3;
+    w.initial_roots = zeros.data(); w.final_root = zeros.data(); w.s_old_values = s_old.data(); w.r_old_values = r_old.data();
+    w.s_indices = zeros.data(); w.r_indices = zeros.data(); w.s_paths = zeros.data(); w.r_paths = zeros.data();
+    w.deltas = deltas.data(); w.sig_rx = sig_rx; w.sig_s = sig_s;
+    RC_TRY(cstark_tx_witness_upload(c, &w));
+    if (c->tail_bytes < tail.size() * 8) {
+        if (c->tail_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->tail_buf)); }
+        HIP_TRY(hipMalloc((void **)&c->tail_buf, tail.size() * 8));
+        c->tail_bytes = tail.size() * 8;
+    }
+    HIP_TRY(hipMemcpyAsync(c->tail_buf, tail.data(), tail.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->wit.msg_tail = c->tail_buf;
+    return CSTARK_OK;
+}
+int cstark_schnorr_build_trace(cstark_ctx *c, uint64_t *d_trace) {
+    if (!c || !d_trace) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_build_trace: null argument");
+    if (!c->wit_buf || c->wit.n_tx == 0 || !c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no Schnorr witness uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::launch_schnorr_trace(c->wit, d_trace, c->stream));
+    return CSTARK_OK;
+}
+int cstark_schnorr_aux_columns(cstark_ctx *c, uint64_t *d_out) {
+    if (!c || !d_out) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_aux_columns: null argument");
+    if (!c->wit_buf || c->wit.n_tx == 0 || !c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no Schnorr witness uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::launch_schnorr_aux_columns(c->wit, d_out, c->stream));
+    return CSTARK_OK;
+}
+int cstark_schnorr_mask_columns(uint64_t *out /* [36][512] host */) {
+    if (!out) return fail(CSTARK_ERR_INVALID_ARG, "null argument");
+    std::vector<uint64_t> cols;
+    cs::host::schnorr_mask_columns(cols);
+    memcpy(out, cols.data(), cols.size() * 8);
+    return CSTARK_OK;
+}
+int cstark_schnorr_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, const uint64_t *d_aux_lde, uint64_t *d_out, uint32_t log_n,
+                                        uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!c || !d_lde || !d_aux_lde || !d_out || nk == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_evaluate_transitions: bad argument");
+    if (log_n < 9 || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
+    HIP_TRY(hipSetDevice(c->device));
+    const PeriodicTable *pt = nullptr;
+    for (const PeriodicTable &t : c->small_periodic)
+        if (t.air == CSTARK_AIR_SCHNORR && t.log_n == log_n && t.log_b == log_blowup) pt = &t;
+    if (!pt) {
+        std::vector<uint64_t> cols;
+        cs::host::schnorr_mask_columns(cols);
+        const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_blowup;
+        PeriodicTable t{0, log_n, log_blowup, nullptr, nullptr, nullptr, CSTARK_AIR_SCHNORR};
+        uint64_t *d_cols = nullptr, *d_poly = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_cols, cols.size() * 8));
+        HIP_TRY(hipMalloc((void **)&d_poly, cols.size() * 8));
+        HIP_TRY(hipMalloc((void **)&t.tab, b * cols.size() * 8));
+        HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), cols.size() * 8, hipMemcpyHostToDevice, c->stream));
+        RC_TRY(interpolate_impl(c, d_cols, d_poly, 36, 9));
+        RC_TRY(lde_impl(c, d_poly, t.tab, 36, 9, log_blowup, cs::host::pow(cs::host::generator(), n / 512), 0, (uint32_t)b));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(d_cols));
+        HIP_TRY(hipFree(d_poly));
+        c->small_periodic.push_back(t);
+        pt = &c->small_periodic.back();
+    }
+    HIP_TRY(cs::launch_eval_transitions_schnorr(d_lde, d_aux_lde, pt->tab, d_out, log_n, k0, nk, c->stream));
     return CSTARK_OK;
 }
 

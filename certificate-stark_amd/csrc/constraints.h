@@ -45,6 +45,8 @@ struct AirCombineParams {
 hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_t stream);
 hipError_t launch_eval_transitions_merkle(const uint64_t *lde, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0, unsigned nk,
                                           hipStream_t stream);
+hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *aux, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0,
+                                           unsigned nk, hipStream_t stream);
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream);
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);

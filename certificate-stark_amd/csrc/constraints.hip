@@ -723,6 +723,61 @@ __global__ __launch_bounds__(NT) void k_eval_transitions_merkle(const fp *lde, c
         acc.add(PREV_MATCH_RES + i, finish, fp_sub(f.next(S_INIT + i), cr));
     }
 }
+// SchnorrAir::evaluate_transition  src/schnorr/air.rs:68-109 -> evaluate_constraints :394-531.
+// lde: [nk][56][n]; aux: [nk][19][n] (LDE of pkey x12 and message-chunk x7 columns); ptab: [b][36][512] (8 masks, 28 ark)
+__global__ __launch_bounds__(NT) void k_eval_transitions_schnorr(const fp *lde, const fp *aux, const fp *ptab, fp *out, unsigned log_n, unsigned k0) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)NT + threadIdx.x;
+    const unsigned kk = blockIdx.y;
+    const fp *base = lde + (size_t)kk * 56 * n;
+    Frame f;
+    f.n = n;
+    f.cur_p = base + j;
+    f.next_p = base + ((j + 1) & (n - 1));
+    f.per_p = ptab + (size_t)(k0 + kk) * 36 * 512 + (j & 511);
+    f.pcycle = 512;
+    Frame fr = f; // view whose column P_ARK is the first round-constant column (index 8 here)
+    fr.per_p = f.per_p - (size_t)(P_ARK - 8) * 512;
+    const fp *ax = aux + (size_t)kk * 19 * n + j;
+    AccAll acc{out + (size_t)kk * 56 * n + j, n};
+    const fp global_mask = f.pv(0), scalar_mult = f.pv(1), doubling = f.pv(2), hash_flag = f.pv(7);
+    const fp copy_hash = fp_mul(c_not(hash_flag), global_mask);
+    const fp final_add = fp_mul(c_not(scalar_mult), global_mask);
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
+    {
+        const Fp6 gx = const6(c_generator), gy = const6(c_generator + 6);
+        enforce_scalar_mult_step(acc, f, 0, gx, gy, doubling, addition);
+        const Fp6 px = fp6_load_strided(ax, n), py = fp6_load_strided(ax + 6 * n, n); // periodic pkey columns
+        enforce_scalar_mult_step(acc, f, 19, px, py, doubling, addition);
+    }
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+        const fp dflag = f.pv(3 + i);
+        const fp c = f.cur(41 - i), nx = f.next(41 - i);
+        acc.add(41 - i, fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37))));
+        acc.add(41 - i, fp_mul(c_not(dflag), doubling), fp_sub(c, nx));
+        acc.add(38 + i, addition, fp_sub(f.cur(38 + i), f.next(38 + i)));
+        acc.add(38 + i, final_add, fp_sub(f.cur(38 + i), f.cur(42 + i)));
+    }
+    enforce_round(acc, fr, 42, 42, hash_flag, 0, 0, false);
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) {
+        acc.add(42 + i, copy_hash, fp_sub(f.cur(42 + i), f.next(42 + i)));
+        acc.add(49 + i, copy_hash, fp_sub(f.next(49 + i), ax[(size_t)(12 + i) * n]));
+    }
+    {
+        const Point s = {load6(f, 0, false), load6(f, 6, false), load6(f, 12, false)};
+        const Point hp = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
+        const Point r = ec_add<true>(s, hp);
+        const Fp6 xz = mul6_call(load6(f, 0, true), r.z);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc.add(i, final_add, fp_sub(xz.c[i], r.x.c[i]));
+            acc.add(6 + i, final_add, fp_sub(f.next(6 + i), r.y.c[i]));
+            acc.add(12 + i, final_add, fp_sub(f.next(12 + i), r.z.c[i]));
+        }
+    }
+}
 // RangeProofAir::evaluate_transition  src/range/air.rs:60-98 (enforce_double_and_add_step with flag ONE)
 __global__ void k_eval_transitions_range(const fp *lde, fp *out, unsigned log_n) {
     const size_t n = (size_t)1 << log_n;
@@ -783,6 +838,14 @@ hipError_t launch_eval_transitions_merkle(const uint64_t *lde, const uint64_t *p
     hipError_t e = hipMemsetAsync(out, 0, (size_t)nk * 106 * n * sizeof(fp), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_eval_transitions_merkle, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, ptab, out, log_n, k0);
+    return hipGetLastError();
+}
+hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *aux, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0,
+                                           unsigned nk, hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)nk * 56 * n * sizeof(fp), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_eval_transitions_schnorr, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, aux, ptab, out, log_n, k0);
     return hipGetLastError();
 }
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream) {

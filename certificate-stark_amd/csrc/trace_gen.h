@@ -11,6 +11,7 @@ struct TxWitnessDev {
     const uint64_t *initial_roots, *s_old, *r_old, *s_idx, *r_idx, *s_paths, *r_paths, *deltas, *sig_rx;
     const uint8_t *sig_s;
     uint64_t *h_limbs; // [n_tx][4] canonical limbs of hash_message(), produced by k_trace_schnorr_hash
+    const uint64_t *msg_tail; // standalone SchnorrAir only: message[26], message[27] per signature (zero in the composite AIR)
 };
 
 // `side` is a second stream used for the part of the trace that is independent of the rest; `fork`/`join` are events
@@ -20,5 +21,10 @@ hipError_t launch_trace_gen(const TxWitnessDev &w, uint64_t *d_trace, hipStream_
 // standalone sub-AIR traces
 hipError_t launch_merkle_trace(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream); // 65 x 512*n_tx
 hipError_t launch_range_trace(uint64_t number_canonical, uint64_t *d_trace, hipStream_t stream); // 2 x 64
+// SchnorrProver::build_trace (src/schnorr/prover.rs:40-67): 56 x 512*n; the witness view holds message[0..12] in s_old,
+// [12..24] in r_old, [24] in deltas, [25] in s_old[13], [26..28] in msg_tail
+hipError_t launch_schnorr_trace(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream);
+// the 19 public-input columns of SchnorrAir (pkey x12, message chunks x7; src/schnorr/air.rs:228-290): 19 x 512*n
+hipError_t launch_schnorr_aux_columns(const TxWitnessDev &w, uint64_t *d_out, hipStream_t stream);
 
 } // namespace cs

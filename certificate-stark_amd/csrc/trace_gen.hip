@@ -148,6 +148,7 @@ __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------
+template <bool STANDALONE>
 __global__ __launch_bounds__(64) void k_trace_schnorr_hash(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
     __shared__ fp tile[64][15];
     __shared__ fp st[14];
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(64) void k_trace_schnorr_hash(TxWitnessDev w, fp *_
     // row 512: init_sig_verification_state, src/schnorr/trace.rs:18-30
     fp v = (active && e < 6) ? w.sig_rx[6 * (size_t)t + e] : 0;
     if (active) tile[0][e] = v;
-    const size_t gbase = (size_t)t * TXC + MERKLE_LEN;
+    const size_t gbase = STANDALONE ? (size_t)t * MERKLE_LEN : (size_t)t * TXC + MERKLE_LEN;
     for (int step = 0; step < MERKLE_LEN - 1; step++) {
         if (step < 40) { // TOTAL_HASH_LENGTH
             const int cyc = step & 7;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64) void k_trace_schnorr_hash(TxWitnessDev w, fp *_
             } else if (step < 32) { // message chunk, src/lib.rs:467-481 layout
                 if (active && e >= 7) {
                     int m = 7 * (step >> 3) + e - 7;
-                    v = m < 12 ? sv[m] : m < 24 ? rv[m - 12] : m == 24 ? w.deltas[t] : m == 25 ? sv[13] : 0;
+                    v = m < 12 ? sv[m] : m < 24 ? rv[m - 12] : m == 24 ? w.deltas[t] : m == 25 ? sv[13] : (STANDALONE ? w.msg_tail[2 * (size_t)t + m - 26] : 0);
                 }
             } else {
                 if (active && e >= 7) v = 0;
@@ -325,6 +326,7 @@ __device__ __forceinline__ void run_point_op(int op, fp (*slot)[6], Fp2 (*prod)[
 
 __device__ __forceinline__ int bit_le(const uint8_t *bytes, int i) { return (bytes[i >> 3] >> (i & 7)) & 1; }
 
+template <bool STANDALONE>
 __global__ __launch_bounds__(128) void k_trace_schnorr_ec(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
     __shared__ fp tile[64][37];
     __shared__ fp slots[2][NSLOT][6];
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(128) void k_trace_schnorr_ec(TxWitnessDev w, fp *__
     }
     __syncthreads();
     if (lane < 18) tile[0][g * 18 + lane] = slot[lane / 6][lane % 6];
-    const size_t gbase = (size_t)t * TXC + MERKLE_LEN;
+    const size_t gbase = STANDALONE ? (size_t)t * MERKLE_LEN : (size_t)t * TXC + MERKLE_LEN;
 
     for (int step = 0; step < MERKLE_LEN - 1; step++) {
         if (step < SCALAR_MUL_LEN) {
@@ -452,10 +454,66 @@ hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stre
     if ((e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_trace_merkle<false>, dim3(w.n_tx), dim3(64), 0, side, w, d_trace, n);
     if ((e = hipEventRecord(join, side)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace_schnorr_hash, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
-    hipLaunchKernelGGL(k_trace_schnorr_ec, dim3(w.n_tx), dim3(128), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_hash<false>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_ec<false>, dim3(w.n_tx), dim3(128), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_aux, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
     if ((e = hipStreamWaitEvent(stream, join, 0)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// standalone SchnorrAir: bit registers 18 / 37 and h-limb accumulators 38..41 (closed forms, as in k_trace_aux); grid (n, 2) x 256
+__global__ __launch_bounds__(256) void k_trace_schnorr_bits(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    const int t = blockIdx.x;
+    const int q = blockIdx.y * 256 + threadIdx.x; // row inside the signature block; row q is produced by step q-1
+    const size_t g = (size_t)t * MERKLE_LEN + q;
+    const uint8_t *sb = w.sig_s + 32 * (size_t)t;
+    const uint64_t *h = w.h_limbs + 4 * (size_t)t;
+    fp bs = 0, bh = 0;
+    if (q >= 1) {
+        const int step = q - 1 < SCALAR_MUL_LEN - 1 ? q - 1 : SCALAR_MUL_LEN - 1;
+        const int bi = 254 - (step >> 1);
+        bs = bit_le(sb, bi) ? FP_ONE : 0;
+        bh = ((h[bi >> 6] >> (bi & 63)) & 1) ? FP_ONE : 0;
+        if (q == SCALAR_MUL_LEN + 1) bs = FP_ONE;
+    }
+    trace[(size_t)18 * n + g] = bs;
+    trace[(size_t)37 * n + g] = bh;
+    const int k = (q + 1) / 2 < 255 ? (q + 1) / 2 : 255;
+    for (int c = 0; c < 4; c++) {
+        const int width = c == 0 ? 63 : 64, start = c == 0 ? 0 : 63 + 64 * (c - 1);
+        int kc = k - start;
+        kc = kc < 0 ? 0 : kc > width ? width : kc;
+        const uint64_t limb = h[3 - c];
+        const uint64_t acc = kc == 0 ? 0 : (c == 0 ? (limb >> (63 - kc)) : (kc == 64 ? limb : limb >> (64 - kc)));
+        trace[(size_t)(41 - c) * n + g] = small_to_fp(acc);
+    }
+}
+__global__ __launch_bounds__(256) void k_schnorr_aux_columns(TxWitnessDev w, fp *__restrict__ out, size_t n) {
+    const int t = blockIdx.x;
+    const int q = blockIdx.y * 256 + threadIdx.x;
+    const size_t g = (size_t)t * MERKLE_LEN + q;
+    const fp *sv = w.s_old + 14 * (size_t)t, *rv = w.r_old + 14 * (size_t)t;
+    for (int j = 0; j < 12; j++) out[(size_t)j * n + g] = sv[j];
+    const bool chunk_row = q < 32 && (q & 7) == 7;
+    for (int j = 0; j < 7; j++) {
+        fp v = 0;
+        if (chunk_row) {
+            const int m = j + 7 * (q >> 3);
+            v = m < 12 ? sv[m] : m < 24 ? rv[m - 12] : m == 24 ? w.deltas[t] : m == 25 ? sv[13] : w.msg_tail[2 * (size_t)t + m - 26];
+        }
+        out[(size_t)(12 + j) * n + g] = v;
+    }
+}
+hipError_t launch_schnorr_trace(const TxWitnessDev &w, fp *d_trace, hipStream_t stream) {
+    const size_t n = (size_t)w.n_tx * MERKLE_LEN;
+    hipLaunchKernelGGL(k_trace_schnorr_hash<true>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_ec<true>, dim3(w.n_tx), dim3(128), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_bits, dim3(w.n_tx, 2), dim3(256), 0, stream, w, d_trace, n);
+    return hipGetLastError();
+}
+hipError_t launch_schnorr_aux_columns(const TxWitnessDev &w, fp *d_out, hipStream_t stream) {
+    const size_t n = (size_t)w.n_tx * MERKLE_LEN;
+    hipLaunchKernelGGL(k_schnorr_aux_columns, dim3(w.n_tx, 2), dim3(256), 0, stream, w, d_out, n);
     return hipGetLastError();
 }
 

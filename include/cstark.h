@@ -155,6 +155,17 @@ int cstark_merkle_build_trace(cstark_ctx *ctx, uint64_t *d_trace);
 /* RangeProver::build_trace (src/range/prover.rs:24-43): 2 x 64; `number` is a field element in memory form
  * whose canonical value must be below 2^63. */
 int cstark_range_build_trace(cstark_ctx *ctx, uint64_t number, uint64_t *d_trace);
+/* SchnorrAir (src/schnorr/air.rs:41-300, src/schnorr/prover.rs:21-67): n signatures over 28-element messages
+ * (message[0..12] = public key).  Trace 56 x (512*n); the 19 public-input columns (pkey x12, message chunks x7;
+ * src/schnorr/air.rs:228-290) as a 19 x (512*n) table that the caller extends like trace columns; the 8 mask + 28
+ * round-constant periodic columns [36][512] (host).  Transition constraints only: the periodic / sequence
+ * assertions of src/schnorr/air.rs:111-226 are not merged by this library yet. */
+int cstark_schnorr_witness_upload(cstark_ctx *ctx, uint32_t n_sig, const uint64_t *messages, const uint64_t *sig_rx, const uint8_t *sig_s);
+int cstark_schnorr_build_trace(cstark_ctx *ctx, uint64_t *d_trace);
+int cstark_schnorr_aux_columns(cstark_ctx *ctx, uint64_t *d_out);
+int cstark_schnorr_mask_columns(uint64_t *out /* [36][512] host */);
+int cstark_schnorr_evaluate_transitions(cstark_ctx *ctx, const uint64_t *d_lde, const uint64_t *d_aux_lde, uint64_t *d_out,
+                                        uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 /* Shape of an AIR as the engine sees it (host side): trace width, number of transition constraints and of
  * assertions, log2 of the constraint-evaluation blowup; degree (base; cycles) of constraint i. */
 int cstark_air_shape(int air, uint32_t *width, uint32_t *n_constraints, uint32_t *n_assertions, uint32_t *log_ce_blowup);

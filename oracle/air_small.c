@@ -183,6 +183,104 @@ void cso_rescue_chain_periodic_columns(uint64_t *out /*[29][8]*/) {
     for (int j = 0; j < 28; j++) for (int i = 0; i < 8; i++) out[(1 + j) * 8 + i] = CS_ARK_MONT[i * 28 + j];
 }
 
+/* ---- SchnorrAir (src/schnorr/air.rs:41-300, src/schnorr/prover.rs:21-67) ------------------------------ */
+void cso_schnorr_step(size_t step, const uint64_t *msg, const uint64_t *pkey, const uint8_t *s_bytes, const uint8_t *h_bytes, uint64_t *st);
+void cso_schnorr_constraints(uint64_t *res, const uint64_t *cur, const uint64_t *next, const uint64_t *ark, uint64_t doubling_flag, uint64_t addition_flag,
+                             const uint64_t *digest_flags, const uint64_t *pkey, uint64_t final_add_flag, uint64_t hash_flag, uint64_t copy_hash_flag,
+                             const uint64_t *internal_inputs);
+void cso_sign_message(uint64_t *rng_state, const uint64_t *msg28, uint64_t sk, uint64_t *rx6, uint8_t *s32);
+
+/* messages: [n][28] = pkey(12) | 16 elements; trace: [56][512 n] */
+int cso_schnorr_build_trace(uint32_t n_sig, const uint64_t *messages, const uint64_t *sig_rx, const uint8_t *sig_s, uint64_t *trace) {
+    const size_t n = (size_t)n_sig * 512;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t t = 0; t < n_sig; t++) {
+        const fp *msg = messages + 28 * t;
+        fp h[7], st[56];
+        uint8_t h_bytes[32];
+        cso_schnorr_hash_message(sig_rx + 6 * t, msg, h); /* build_sig_info, src/schnorr/trace.rs:127-142 */
+        for (int i = 0; i < 4; i++) { uint64_t v = fp_to_u64(h[i]); for (int b = 0; b < 8; b++) h_bytes[8 * i + b] = v >> (8 * b); }
+        memset(st, 0, sizeof st); /* init_sig_verification_state :18-30 */
+        st[6] = FP_ONE; st[25] = FP_ONE;
+        memcpy(st + 42, sig_rx + 6 * t, 6 * sizeof(fp));
+        for (int c = 0; c < 56; c++) trace[(size_t)c * n + 512 * t] = st[c];
+        for (size_t step = 0; step < 511; step++) {
+            cso_schnorr_step(step, msg, msg, sig_s + 32 * t, h_bytes, st);
+            for (int c = 0; c < 56; c++) trace[(size_t)c * n + 512 * t + step + 1] = st[c];
+        }
+    }
+    return 0;
+}
+/* the public-input-dependent "periodic" columns of SchnorrAir (:228-290): pkey (12) constant over each 512-row
+ * block, message chunks (7) at rows 8i+7 (i < 4) of each block; [19][512 n] */
+void cso_schnorr_aux_columns(uint32_t n_sig, const uint64_t *messages, uint64_t *out) {
+    const size_t n = (size_t)n_sig * 512;
+    memset(out, 0, 19 * n * sizeof(fp));
+    for (size_t t = 0; t < n_sig; t++) {
+        const fp *msg = messages + 28 * t;
+        for (int j = 0; j < 12; j++) for (int i = 0; i < 512; i++) out[(size_t)j * n + 512 * t + i] = msg[j];
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 7; j++) out[(size_t)(12 + j) * n + 512 * t + 8 * i + 7] = msg[j + 7 * i];
+    }
+}
+/* the input-independent periodic columns: 8 masks of src/schnorr/air.rs:335-391 then the 28 round constants; [36][512] */
+void cso_schnorr_mask_columns(uint64_t *out) {
+    memset(out, 0, 36 * 512 * sizeof(fp));
+#define COL(c) (out + (size_t)(c) * 512)
+    for (int i = 0; i < 511; i++) COL(0)[i] = FP_ONE;
+    for (int i = 0; i < 510; i++) { COL(1)[i] = FP_ONE; COL(2)[i] = (i % 2 == 0) ? FP_ONE : 0; }
+    const int lo[4] = {0, 126, 254, 382}, hi[4] = {126, 254, 382, 510};
+    for (int k = 0; k < 4; k++) for (int i = lo[k]; i < hi[k]; i++) COL(3 + k)[i] = FP_ONE;
+    for (int i = 0; i < 40; i++) COL(7)[i] = (i % 8) != 7 ? FP_ONE : 0;
+    for (int j = 0; j < 28; j++) for (int i = 0; i < 512; i++) COL(8 + j)[i] = CS_ARK_MONT[(i % 8) * 28 + j];
+#undef COL
+}
+/* SchnorrAir::evaluate_transition (:68-109) over LDE cosets: lde [nk][56][n], aux [nk][19][n] (LDE of the aux columns),
+ * ptab [b][36][512]; out [nk][56][n] */
+void cso_schnorr_evaluate_transitions(const uint64_t *lde, const uint64_t *aux, const uint64_t *ptab, uint64_t *out, unsigned log_n, uint32_t k0, uint32_t nk) {
+    const size_t n = (size_t)1 << log_n;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (uint32_t k = k0; k < k0 + nk; k++)
+        for (size_t j = 0; j < n; j++) {
+            fp cur[56], next[56], m[36], pk[12], inp[7], res[56];
+            for (int c = 0; c < 56; c++) { cur[c] = lde[((size_t)(k - k0) * 56 + c) * n + j]; next[c] = lde[((size_t)(k - k0) * 56 + c) * n + (j + 1) % n]; }
+            for (int c = 0; c < 36; c++) m[c] = ptab[((size_t)k * 36 + c) * 512 + j % 512];
+            for (int c = 0; c < 12; c++) pk[c] = aux[((size_t)(k - k0) * 19 + c) * n + j];
+            for (int c = 0; c < 7; c++) inp[c] = aux[((size_t)(k - k0) * 19 + 12 + c) * n + j];
+            memset(res, 0, sizeof res);
+            fp copy_hash = fp_mul(c_not(m[7]), m[0]), final_add = fp_mul(c_not(m[1]), m[0]), addition = fp_mul(c_not(m[2]), m[1]);
+            cso_schnorr_constraints(res, cur, next, m + 8, m[2], addition, m + 3, pk, final_add, m[7], copy_hash, inp);
+            for (int i = 0; i < 56; i++) out[((size_t)(k - k0) * 56 + i) * n + j] = res[i];
+        }
+}
+/* schnorr::transition_constraint_degrees(num_sig, 512), src/schnorr/air.rs:533-585 */
+void cso_schnorr_constraint_degrees(uint32_t n_sig, uint32_t *base, uint32_t *cycles) {
+    const uint32_t bit_degree = n_sig == 1 ? 3 : 5;
+    for (int i = 0; i < 6; i++) { base[i] = 5; cycles[i] = 2; }
+    for (int i = 6; i < 18; i++) { base[i] = 4; cycles[i] = 2; }
+    base[18] = 2; cycles[18] = 1;
+    for (int i = 19; i < 37; i++) { base[i] = bit_degree; cycles[i] = 2; }
+    base[37] = 2; cycles[37] = 1;
+    for (int i = 38; i < 42; i++) { base[i] = 1; cycles[i] = 2; }
+    for (int i = 42; i < 56; i++) { base[i] = 3; cycles[i] = 1; }
+}
+/* deterministic messages and signatures (counterpart of SchnorrExample::new, src/schnorr/mod.rs:86-141) */
+int cso_schnorr_witness_generate(uint32_t n_sig, uint64_t seed, uint64_t *messages, uint64_t *sig_rx, uint8_t *sig_s) {
+    uint64_t rng = seed;
+    for (uint32_t t = 0; t < n_sig; t++) {
+        fp *msg = messages + 28 * t;
+        uint64_t z = (rng += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
+        uint64_t sk = 1 + z % 8;
+        cso_ecc_scalar_mul_affine(&sk, 1, CS_GENERATOR_MONT, msg);
+        for (int i = 12; i < 28; i++) {
+            z = (rng += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
+            msg[i] = fp_from_u64(z);
+        }
+        uint64_t r2 = rng ^ 0xA5A5A5A5DEADBEEFULL;
+        cso_sign_message(&r2, msg, sk, sig_rx + 6 * t, sig_s + 32 * t);
+    }
+    return 0;
+}
+
 /* ---- generic driver --------------------------------------------------------------------------------
  * evals: [nk][nc][n] transition evaluations on the LDE cosets k0.. (coset-major), lde: [nk][width][n].
  * Degree (base_i; cyc_i cycles of length cycle_len).  Single-step assertions only: (reg, last?, value).

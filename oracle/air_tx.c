@@ -80,7 +80,7 @@ static void merkle_auth_step(size_t pos, uint64_t index, const fp *branch, fp *s
 }
 
 /* src/schnorr/trace.rs:35-122; st = 56 registers */
-static void schnorr_step(size_t step, const fp *msg, const fp *pkey, const uint8_t *s_bytes, const uint8_t *h_bytes, fp *st) {
+void cso_schnorr_step(size_t step, const uint64_t *msg, const uint64_t *pkey, const uint8_t *s_bytes, const uint8_t *h_bytes, uint64_t *st) {
     const int bit_length = SCALAR_MUL_LEN / 2;
     int rescue_flag = step < TOTAL_HASH_LEN;
     size_t rescue_step = step % HASH_CYCLE;
@@ -178,7 +178,7 @@ int cso_tx_build_trace(const cstark_tx_witness *w, uint64_t *trace) {
                 st[SIGMA_BIT] = st[SIGMA_ACC] = 0;
             } else {
                 size_t ss = step - MERKLE_CYCLE;
-                schnorr_step(ss, msg, pkey, s_bytes, h_bytes, st);
+                cso_schnorr_step(ss, msg, pkey, s_bytes, h_bytes, st);
                 if (ss < RANGE_LOG) { /* src/range/prover.rs:74-84 */
                     st[DELTA_BIT] = bit_of(delta_bytes, RANGE_LOG - 1 - (int)ss) ? FP_ONE : 0;
                     field_apply_double_and_add(st + DELTA_BIT, 1, 0);
@@ -249,9 +249,9 @@ static void merkle_auth_constraints(fp *res, const fp *cur, const fp *next, cons
 }
 
 /* src/schnorr/air.rs:394-531 on registers/results [0,56) */
-static void schnorr_constraints(fp *res, const fp *cur, const fp *next, const fp *ark, fp doubling_flag, fp addition_flag,
-                                const fp *digest_flags, const fp *pkey, fp final_add_flag, fp hash_flag, fp copy_hash_flag,
-                                const fp *internal_inputs) {
+void cso_schnorr_constraints(uint64_t *res, const uint64_t *cur, const uint64_t *next, const uint64_t *ark, uint64_t doubling_flag, uint64_t addition_flag,
+                             const uint64_t *digest_flags, const uint64_t *pkey, uint64_t final_add_flag, uint64_t hash_flag, uint64_t copy_hash_flag,
+                             const uint64_t *internal_inputs) {
     ecc_enforce_doubling(res, cur, next, doubling_flag);
     ecc_enforce_addition_mixed(res, cur, next, CS_GENERATOR_MONT, addition_flag);
     ecc_enforce_doubling(res + 19, cur + 19, next + 19, doubling_flag);
@@ -330,7 +330,7 @@ void cso_tx_evaluate_transition(const uint64_t *cur, const uint64_t *next, const
             fp cell = m < 12 ? next[S_KEY + m] : m < 24 ? next[R_KEY + m - 12] : m == 24 ? next[DELTA_COPY] : m == 25 ? next[NONCE_COPY] : 0;
             internal_inputs[i] = fp_add(internal_inputs[i], fp_mul(internal_flags[k], cell));
         }
-    schnorr_constraints(res, cur, next, ark, doubling, addition, digest_flags, next + S_KEY, final_add, schnorr_hash, copy_hash, internal_inputs);
+    cso_schnorr_constraints(res, cur, next, ark, doubling, addition, digest_flags, next + S_KEY, final_add, schnorr_hash, copy_hash, internal_inputs);
 
     /* range proofs, src/air.rs:583-609 (SIGMA_RANGE_RES re-checks the delta registers, as written) */
     field_enforce_double_and_add(res, cur, next, DELTA_ACC, DELTA_BIT, range_flag);

@@ -94,6 +94,12 @@ int cso_rescue_chain_build_trace(const uint64_t *seed7, uint32_t iterations, uin
 void cso_rescue_compute_hash_chain(const uint64_t *seed7, uint32_t length, uint64_t *out7);
 void cso_rescue_chain_evaluate_transition(const uint64_t *cur, const uint64_t *next, const uint64_t *pv, uint64_t *res);
 void cso_rescue_chain_periodic_columns(uint64_t *out);
+int cso_schnorr_build_trace(uint32_t n_sig, const uint64_t *messages, const uint64_t *sig_rx, const uint8_t *sig_s, uint64_t *trace);
+void cso_schnorr_aux_columns(uint32_t n_sig, const uint64_t *messages, uint64_t *out);
+void cso_schnorr_mask_columns(uint64_t *out);
+void cso_schnorr_evaluate_transitions(const uint64_t *lde, const uint64_t *aux, const uint64_t *ptab, uint64_t *out, unsigned log_n, uint32_t k0, uint32_t nk);
+void cso_schnorr_constraint_degrees(uint32_t n_sig, uint32_t *base, uint32_t *cycles);
+int cso_schnorr_witness_generate(uint32_t n_sig, uint64_t seed, uint64_t *messages, uint64_t *sig_rx, uint8_t *sig_s);
 void cso_air_combine(const cso_air_desc *d, const uint64_t *lde, const uint64_t *evals, const uint64_t *t_alpha, const uint64_t *t_beta,
                      const uint64_t *b_alpha, const uint64_t *b_beta, uint64_t *out, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk,
                      int all_cosets);

@@ -434,3 +434,50 @@ def air_combine(desc, lde, evals, t_alpha, t_beta, b_alpha, b_beta, log_b, k0=0,
 def random_elements(k, seed):
     rng = np.random.default_rng(seed)
     return to_mont(rng.integers(0, P, size=k, dtype=np.uint64))
+
+
+# ---- SchnorrAir (standalone) ---------------------------------------------------------------------------
+class SchnorrWitness:
+    def __init__(self, n_sig):
+        self.n_sig = n_sig
+        self.messages = np.zeros((n_sig, 28), np.uint64)
+        self.sig_rx = np.zeros((n_sig, 6), np.uint64)
+        self.sig_s = np.zeros((n_sig, 32), np.uint8)
+
+    @classmethod
+    def generate(cls, n_sig, seed=0x5EED):
+        w = cls(n_sig)
+        lib().cso_schnorr_witness_generate(C.c_uint32(n_sig), C.c_uint64(seed), _p(w.messages), _p(w.sig_rx), _p(w.sig_s, u8p))
+        return w
+
+
+def schnorr_build_trace(w):
+    trace = np.zeros((56, 512 * w.n_sig), np.uint64)
+    lib().cso_schnorr_build_trace(C.c_uint32(w.n_sig), _p(w.messages), _p(w.sig_rx), _p(w.sig_s, u8p), _p(trace))
+    return trace
+
+
+def schnorr_aux_columns(w):
+    out = np.zeros((19, 512 * w.n_sig), np.uint64)
+    lib().cso_schnorr_aux_columns(C.c_uint32(w.n_sig), _p(w.messages), _p(out))
+    return out
+
+
+def schnorr_mask_columns():
+    out = np.zeros((36, 512), np.uint64)
+    lib().cso_schnorr_mask_columns(_p(out))
+    return out
+
+
+def schnorr_evaluate_transitions(lde, aux_lde, ptab, k0=0):
+    lde, aux_lde, ptab = _u64(lde), _u64(aux_lde), _u64(ptab)
+    nk, width, n = lde.shape
+    out = np.zeros((nk, 56, n), np.uint64)
+    lib().cso_schnorr_evaluate_transitions(_p(lde), _p(aux_lde), _p(ptab), _p(out), C.c_uint(n.bit_length() - 1), C.c_uint32(k0), C.c_uint32(nk))
+    return out
+
+
+def schnorr_constraint_degrees(n_sig):
+    base = np.zeros(56, np.uint32); cyc = np.zeros(56, np.uint32)
+    lib().cso_schnorr_constraint_degrees(C.c_uint32(n_sig), _p(base, u32p), _p(cyc, u32p))
+    return base, cyc

@@ -132,6 +132,8 @@ static void sign_tx(uint64_t *rng, const fp *msg, uint64_t sk, const fp *pkey, f
     }
 }
 
+void cso_sign_message(uint64_t *rng_state, const uint64_t *msg28, uint64_t sk, uint64_t *rx6, uint8_t *s32) { sign_tx(rng_state, msg28, sk, msg28, rx6, s32); }
+
 int cso_tx_witness_generate(cstark_tx_witness *w, uint64_t seed) {
     const uint32_t n = w->n_tx, depth = w->merkle_depth;
     if (n == 0 || depth == 0 || depth > 24) return -1;

@@ -88,4 +88,7 @@ def test_small_air_host_descriptions_match_oracle(oracle):
     w, nc, na, lce = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
     assert lib.cstark_air_shape(C.c_int(3), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == 0
     assert (w.value, nc.value, na.value, lce.value) == (2, 2, 2, 1)
-    assert lib.cstark_air_shape(C.c_int(2), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == -5   # SchnorrAir: not built yet
+    assert lib.cstark_air_shape(C.c_int(2), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == -5   # SchnorrAir: no generic merge yet
+    out = np.zeros((36, 512), np.uint64)
+    assert lib.cstark_schnorr_mask_columns(out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+    assert (out == oracle.schnorr_mask_columns()).all()

@@ -71,3 +71,34 @@ def test_range_rejects_non_field_elements(oracle, backend):
     from certificate_stark_amd import CstarkError
     with pytest.raises(CstarkError):
         backend.range_build_trace(2**62 + 2**56 + 2**55 + 1)   # raw value M is not a field element (src/range/tests.rs:54-62: should_panic)
+
+
+@pytest.mark.parametrize("n_sig", [1, 2, 8])
+def test_schnorr_air_trace_and_transitions(oracle, backend, n_sig):
+    """SchnorrAir (src/schnorr): trace, public-input columns and all 56 transition constraints over the LDE."""
+    from certificate_stark_amd.backend import to_numpy_u64
+    w = oracle.SchnorrWitness.generate(n_sig, seed=4000 + n_sig)
+    ref_trace = oracle.schnorr_build_trace(w)
+    backend.upload_schnorr_witness(w.messages, w.sig_rx, w.sig_s)
+    d_trace = backend.schnorr_build_trace()
+    got = to_numpy_u64(d_trace)
+    if not (got == ref_trace).all():
+        raise AssertionError("trace columns differ: %s" % sorted(set(np.argwhere(got != ref_trace)[:, 0].tolist())))
+    for t in range(n_sig):   # the assertion of src/schnorr/air.rs:217-224: x(s*G + h*P) == R.x at step 511 of each block
+        assert (got[0:6, 512 * t + 511] == w.sig_rx[t]).all()
+    ref_aux = oracle.schnorr_aux_columns(w)
+    d_aux = backend.schnorr_aux_columns()
+    assert (to_numpy_u64(d_aux) == ref_aux).all()
+    log_b, log_n = 3, ref_trace.shape[1].bit_length() - 1
+    lde = oracle.lde_columns(oracle.interpolate_columns(ref_trace), log_b)
+    aux_lde = oracle.lde_columns(oracle.interpolate_columns(ref_aux), log_b)
+    d_lde = backend.lde_columns(backend.interpolate_columns(d_trace), log_b)
+    d_aux_lde = backend.lde_columns(backend.interpolate_columns(d_aux), log_b)
+    assert (to_numpy_u64(d_lde) == lde).all() and (to_numpy_u64(d_aux_lde) == aux_lde).all()
+    ptab = oracle.periodic_table(oracle.schnorr_mask_columns(), log_n, log_b)
+    ref_ev = oracle.schnorr_evaluate_transitions(lde, aux_lde, ptab)
+    got_ev = to_numpy_u64(backend.schnorr_evaluate_transitions(d_lde, d_aux_lde, log_b))
+    if not (got_ev == ref_ev).all():
+        raise AssertionError("constraints differ: %s" % sorted(set(np.argwhere(got_ev != ref_ev)[:, 1].tolist())))
+    part = to_numpy_u64(backend.schnorr_evaluate_transitions(d_lde[3:5].contiguous(), d_aux_lde[3:5].contiguous(), log_b, k0=3))
+    assert (part == ref_ev[3:5]).all()

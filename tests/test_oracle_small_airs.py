@@ -102,3 +102,26 @@ def test_combined_evaluations_are_polynomial(oracle, witness_d3, which):
     assert off_domain_error(trace) == 0
     bad = trace.copy(); bad[0, 3] = oracle.fp_add(bad[0, 3:4], oracle.to_mont([1]))[0]
     assert off_domain_error(bad) > 0
+
+
+def test_schnorr_air(oracle):
+    """SchnorrAir (src/schnorr/air.rs): all 56 transition constraints vanish on the trace of valid signatures, the final x
+    equals R.x (the assertion of :217-224), the h limbs equal the hash output; a wrong message breaks the constraints."""
+    w = oracle.SchnorrWitness.generate(2, seed=9)
+    trace = oracle.schnorr_build_trace(w)
+    aux = oracle.schnorr_aux_columns(w)
+    ptab = oracle.schnorr_mask_columns().reshape(1, 36, 512)
+    n = trace.shape[1]
+    ev = oracle.schnorr_evaluate_transitions(trace.reshape(1, 56, n), aux.reshape(1, 19, n), ptab)[0]
+    assert not ev[:, :n - 1].any()
+    for t in range(2):
+        assert (trace[0:6, 512 * t + 511] == w.sig_rx[t]).all()
+        assert (trace[38:42, 512 * t + 510] == trace[42:46, 512 * t + 510]).all()
+    bad_aux = aux.copy(); bad_aux[13, 7] = oracle.fp_add(bad_aux[13, 7:8], oracle.to_mont([1]))[0]
+    ev = oracle.schnorr_evaluate_transitions(trace.reshape(1, 56, n), bad_aux.reshape(1, 19, n), ptab)[0]
+    assert ev[:, :n - 1].any()
+    from collections import Counter
+    b1, c1 = oracle.schnorr_constraint_degrees(1)
+    b2, c2 = oracle.schnorr_constraint_degrees(2)
+    assert Counter(zip(b2.tolist(), c2.tolist())) == {(5, 2): 24, (4, 2): 12, (2, 1): 2, (1, 2): 4, (3, 1): 14}
+    assert b1[19] == 3 and b2[19] == 5
