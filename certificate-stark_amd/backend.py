@@ -204,3 +204,14 @@ class Backend:
         check(self.lib.cstark_schnorr_evaluate_transitions(self.ctx, self._ptr(lde), self._ptr(aux_lde), self._ptr(out),
                                                            C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out
+
+    # ---- measurement ----
+    CE_PARTS = ("rounds", "dbl_sG", "add_sG", "dbl_hP", "add_hP", "final_add", "lin_a", "lin_b", "lin_c")
+
+    def set_part_timing(self, enable=True):
+        check(self.lib.cstark_ctx_set_part_timing(self.ctx, C.c_int(1 if enable else 0)))
+
+    def constraint_part_ms(self):
+        ms = (C.c_float * 9)()
+        check(self.lib.cstark_tx_constraint_part_ms(self.ctx, ms))
+        return dict(zip(self.CE_PARTS, [float(v) for v in ms]))

@@ -70,6 +70,8 @@ struct cstark_ctx {
     uint64_t *coef_buf = nullptr; // device copy of the composition coefficients
     std::deque<PeriodicTable> small_periodic; // standalone sub-AIRs: keyed by (air, depth, log_n, log_b); coset/binv unused
     void *desc_buf = nullptr;     // device copy of a generic AIR description (cstark_air_combine)
+    hipEvent_t part_ev[cs::CE_NUM_PARTS + 1] = {}; // optional per-launch timing of the fused constraint evaluation
+    bool part_timing = false, part_valid = false;
     uint64_t *tail_buf = nullptr; // standalone SchnorrAir: message[26..28] per signature
     size_t tail_bytes = 0;
     size_t desc_bytes = 0;
@@ -268,6 +270,7 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     for (PeriodicTable &t : c->small_periodic) (void)hipFree(t.tab);
     if (c->desc_buf) (void)hipFree(c->desc_buf);
     if (c->tail_buf) (void)hipFree(c->tail_buf);
+    for (hipEvent_t e : c->part_ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -407,7 +410,8 @@ int cstark_tx_evaluate_constraints(cstark_ctx *c, const uint64_t *d_lde, const c
     HIP_TRY(hipStreamSynchronize(c->stream)); // the caller's struct may be transient
     p.coef = c->coef_buf;
     for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
-    HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream));
+    HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, c->part_timing ? c->part_ev : nullptr));
+    c->part_valid = c->part_timing;
     return CSTARK_OK;
 }
 
@@ -616,6 +620,24 @@ int cstark_air_combine(cstark_ctx *c, int air, const uint64_t *d_lde, const uint
     p.width = s.width; p.n_constraints = (uint32_t)nc; p.n_assertions = (uint32_t)na;
     p.stride = 1u << (log_blowup - log_ce); p.log_n = log_n; p.k0 = k0;
     HIP_TRY(cs::launch_air_combine(p, nk, c->stream));
+    return CSTARK_OK;
+}
+
+// per-launch timing of the fused constraint evaluation (HIP events on the context's stream)
+int cstark_ctx_set_part_timing(cstark_ctx *c, int enable) {
+    if (!c) return fail(CSTARK_ERR_INVALID_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (enable && !c->part_ev[0])
+        for (hipEvent_t &e : c->part_ev) HIP_TRY(hipEventCreate(&e));
+    c->part_timing = enable != 0;
+    c->part_valid = false;
+    return CSTARK_OK;
+}
+int cstark_tx_constraint_part_ms(cstark_ctx *c, float *ms /* [9] */) {
+    if (!c || !ms) return fail(CSTARK_ERR_INVALID_ARG, "null argument");
+    if (!c->part_valid) return fail(CSTARK_ERR_INVALID_ARG, "no timed constraint evaluation has run (cstark_ctx_set_part_timing)");
+    HIP_TRY(hipEventSynchronize(c->part_ev[cs::CE_NUM_PARTS]));
+    for (int i = 0; i < cs::CE_NUM_PARTS; i++) HIP_TRY(hipEventElapsedTime(&ms[i], c->part_ev[i], c->part_ev[i + 1]));
     return CSTARK_OK;
 }
 

@@ -50,7 +50,8 @@ hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream);
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);
-hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream);
+constexpr int CE_NUM_PARTS = 9; // launches of the fused evaluation: rounds, dbl0, add0, dbl1, add1, final, lin_a, lin_b, lin_c
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events = nullptr);
 hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,
                                    hipStream_t stream);
 

@@ -859,18 +859,18 @@ hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream) {
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events) {
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
-    hipLaunchKernelGGL(k_eval_fused<PART_ROUNDS>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_DBL0>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_ADD0>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_DBL1>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_ADD1>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_FINAL>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_LIN_A>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_LIN_B>, grid, block, 0, stream, p);
-    hipLaunchKernelGGL(k_eval_fused<PART_LIN_C>, grid, block, 0, stream, p);
+    // part_events (optional, CE_NUM_PARTS + 1 events): recorded around every part so that callers can time each launch
+#define CS_PART(PART)                                                                    \
+    if (part_events) (void)hipEventRecord(part_events[PART], stream);                    \
+    hipLaunchKernelGGL(k_eval_fused<PART>, grid, block, 0, stream, p);
+    CS_PART(PART_ROUNDS) CS_PART(PART_DBL0) CS_PART(PART_ADD0) CS_PART(PART_DBL1) CS_PART(PART_ADD1) CS_PART(PART_FINAL)
+    CS_PART(PART_LIN_A) CS_PART(PART_LIN_B) CS_PART(PART_LIN_C)
+#undef CS_PART
+    if (part_events) (void)hipEventRecord(part_events[NUM_PARTS], stream);
+    static_assert(NUM_PARTS == CE_NUM_PARTS, "part count");
     return hipGetLastError();
 }
 

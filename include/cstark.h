@@ -144,6 +144,11 @@ int cstark_tx_evaluate_transitions(cstark_ctx *ctx, const uint64_t *d_lde, uint6
 int cstark_tx_evaluate_constraints(cstark_ctx *ctx, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs,
                                    const uint64_t pub_inputs[4], uint64_t *d_out, uint32_t merkle_depth,
                                    uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* Measurement aid: when enabled, cstark_tx_evaluate_constraints records HIP events around each of its 9 launches
+ * (Rescue windows; doubling / mixed addition of s*G; of h*P; final addition; three linear groups) on the context's
+ * stream; cstark_tx_constraint_part_ms waits for the last one and returns the 9 durations in milliseconds. */
+int cstark_ctx_set_part_timing(cstark_ctx *ctx, int enable);
+int cstark_tx_constraint_part_ms(cstark_ctx *ctx, float *ms /* [9] */);
 /* Host-side AIR description (no GPU needed): degree (base; number of 1024-row cycles) of transition constraint i
  * (TransactionAir::new, src/air.rs:76-108) and the 48 periodic columns (src/air.rs:194-380), [48][1024]. */
 int cstark_tx_constraint_degree(uint32_t i, uint32_t *base, uint32_t *cycles);  /* CSTARK_AIR_STATE_TRANSITION */
