@@ -146,7 +146,7 @@ class Backend:
         return out
 
     # ---- standalone sub-AIRs (MerkleAir, RangeProofAir) ----
-    AIR_MERKLE, AIR_RANGE = 1, 3
+    AIR_MERKLE, AIR_SCHNORR, AIR_RANGE = 1, 2, 3
 
     def merkle_build_trace(self):
         out = self.empty_u64(65, self.n_tx * 512)
@@ -158,9 +158,9 @@ class Backend:
         check(self.lib.cstark_range_build_trace(self.ctx, C.c_uint64(int(number_mont)), self._ptr(out)))
         return out
 
-    def air_shape(self, air):
+    def air_shape(self, air, n_items=2):
         w, nc, na, lce = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-        check(self.lib.cstark_air_shape(C.c_int(air), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)))
+        check(self.lib.cstark_air_shape(C.c_int(air), C.c_uint32(n_items), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)))
         return w.value, nc.value, na.value, lce.value
 
     def air_evaluate_transitions(self, air, lde, depth, log_blowup, k0=0):
@@ -171,11 +171,14 @@ class Backend:
                                                        C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out
 
-    def air_combine(self, air, lde, evals, t_alpha, t_beta, b_alpha, b_beta, assertion_values, log_blowup, k0=0):
+    def air_combine(self, air, lde, evals, t_alpha, t_beta, b_alpha, b_beta, assertion_values, log_blowup, k0=0, n_items=2, avals_lde=None):
         nk, width, n = lde.shape
         out = self.empty_u64(nk, n)
-        arrs = [_np_u64(a) for a in (t_alpha, t_beta, b_alpha, b_beta, assertion_values)]
-        check(self.lib.cstark_air_combine(self.ctx, C.c_int(air), self._ptr(lde), self._ptr(evals), *[a.ctypes.data_as(u64p) for a in arrs],
+        arrs = [_np_u64(a) for a in (t_alpha, t_beta, b_alpha, b_beta)]
+        av = None if assertion_values is None else _np_u64(assertion_values)
+        check(self.lib.cstark_air_combine(self.ctx, C.c_int(air), C.c_uint32(n_items), self._ptr(lde), self._ptr(evals),
+                                          *[a.ctypes.data_as(u64p) for a in arrs], None if av is None else av.ctypes.data_as(u64p),
+                                          None if avals_lde is None else self._ptr(avals_lde), C.c_uint32(0 if avals_lde is None else avals_lde.shape[1]),
                                           self._ptr(out), C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out
 
@@ -215,3 +218,8 @@ class Backend:
         ms = (C.c_float * 9)()
         check(self.lib.cstark_tx_constraint_part_ms(self.ctx, ms))
         return dict(zip(self.CE_PARTS, [float(v) for v in ms]))
+
+    def schnorr_assertion_polys(self, log_n):
+        out = self.empty_u64(12, 1 << log_n)
+        check(self.lib.cstark_schnorr_assertion_polys(self.ctx, self._ptr(out), C.c_uint32(log_n)))
+        return out

@@ -94,7 +94,13 @@ inline void schnorr_mask_columns(std::vector<uint64_t> &out) {
 struct AirShape {
     uint32_t width = 0, n_constraints = 0, cycle_len = 0, n_periodic = 0;
     std::vector<uint32_t> base, cycles;
-    std::vector<uint32_t> a_reg, a_last; // assertion register, 0 = first step / 1 = last step
+    std::vector<uint32_t> a_reg, a_last; // assertion register, 0 = first step / 1 = last step (single assertions)
+    // generalisation (Assertion::periodic / ::sequence): when a_stride is non-empty assertion a holds at steps
+    // a_first[a] + k * a_stride[a]; its value is the caller's assertion_values[a] or, if a_seq[a] >= 0, column a_seq[a] of
+    // the extended sequence-value polynomials
+    std::vector<uint32_t> a_first, a_stride;
+    std::vector<int32_t> a_seq;
+    std::vector<uint64_t> a_const; // built-in constant values (SchnorrAir), empty when the caller supplies them
     uint32_t log_ce_blowup() const {     // next power of two >= max(base + cycles), at least 2 [UPSTREAM-RECALL]
         uint32_t m = 2;
         for (size_t i = 0; i < base.size(); i++) m = base[i] + (cycle_len ? cycles[i] : 0) > m ? base[i] + (cycle_len ? cycles[i] : 0) : m;
@@ -104,13 +110,37 @@ struct AirShape {
     }
     uint64_t eval_degree(size_t i, uint64_t n) const { return base[i] * (n - 1) + (cycle_len ? cycles[i] * (n / cycle_len) * (cycle_len - 1) : 0); }
 };
-inline bool air_shape(int air, AirShape &s) {
+inline bool air_shape(int air, AirShape &s, uint32_t n_items = 2) {
     s = AirShape{};
     if (air == 1) { // MerkleAir: transition_constraint_degrees(512), src/merkle/update/air.rs:371-401; 14 root assertions :142-170
         s.width = 65; s.n_constraints = 106; s.cycle_len = 512; s.n_periodic = 33;
         s.base.assign(106, 1); s.cycles.assign(106, 1);
         for (int b = 0; b < 58; b += 29) { for (int i = 0; i < 29; i++) s.base[b + i] = 3; s.base[b + 14] = 2; }
         for (int a = 0; a < 14; a++) { s.a_reg.push_back(58 + a % 7); s.a_last.push_back(a / 7); }
+        return true;
+    }
+    if (air == 2) { // SchnorrAir: degrees src/schnorr/air.rs:533-585 (bit degree depends on the number of signatures),
+                    // the 61 periodic / sequence assertions of get_assertions (:111-226) in order
+        s.width = 56; s.n_constraints = 56; s.cycle_len = 512; s.n_periodic = 36;
+        s.base.assign(56, 0); s.cycles.assign(56, 0);
+        const uint32_t bit_degree = n_items == 1 ? 3 : 5;
+        for (int i = 0; i < 6; i++) { s.base[i] = 5; s.cycles[i] = 2; }
+        for (int i = 6; i < 18; i++) { s.base[i] = 4; s.cycles[i] = 2; }
+        s.base[18] = 2; s.cycles[18] = 1;
+        for (int i = 19; i < 37; i++) { s.base[i] = bit_degree; s.cycles[i] = 2; }
+        s.base[37] = 2; s.cycles[37] = 1;
+        for (int i = 38; i < 42; i++) { s.base[i] = 1; s.cycles[i] = 2; }
+        for (int i = 42; i < 56; i++) { s.base[i] = 3; s.cycles[i] = 1; }
+        auto add = [&](uint32_t r, uint32_t first, uint64_t v, int32_t q) {
+            s.a_reg.push_back(r); s.a_last.push_back(0); s.a_first.push_back(first); s.a_stride.push_back(512); s.a_const.push_back(v); s.a_seq.push_back(q);
+        };
+        for (int i = 0; i < 18; i++) add(i, 0, i == 6 ? ONE : 0, -1);
+        add(18, 0, 0, -1);
+        for (int i = 0; i < 18; i++) add(19 + i, 0, i == 6 ? ONE : 0, -1);
+        for (int i = 0; i < 5; i++) add(37 + i, 0, 0, -1);
+        for (int k = 0; k < 6; k++) add(42 + k, 0, 0, k);
+        for (int i = 0; i < 7; i++) add(48 + i, 0, 0, -1);
+        for (int k = 0; k < 6; k++) add(k, 511, 0, 6 + k);
         return true;
     }
     if (air == 3) { // RangeProofAir: degrees (2), (1), src/range/air.rs:100-105; assertions :79-86

@@ -73,6 +73,7 @@ struct cstark_ctx {
     hipEvent_t part_ev[cs::CE_NUM_PARTS + 1] = {}; // optional per-launch timing of the fused constraint evaluation
     bool part_timing = false, part_valid = false;
     uint64_t *tail_buf = nullptr; // standalone SchnorrAir: message[26..28] per signature
+    std::vector<uint64_t> schnorr_rx; // host copy of the signatures' R.x ([n][6]) for the sequence assertions
     size_t tail_bytes = 0;
     size_t desc_bytes = 0;
     void *ws = nullptr;
@@ -462,6 +463,7 @@ int cstark_schnorr_witness_upload(cstark_ctx *c, uint32_t n_sig, const uint64_t 
     HIP_TRY(hipMemcpyAsync(c->tail_buf, tail.data(), tail.size() * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->wit.msg_tail = c->tail_buf;
+    c->schnorr_rx.assign(sig_rx, sig_rx + (size_t)n_sig * 6);
     return CSTARK_OK;
 }
 int cstark_schnorr_build_trace(cstark_ctx *c, uint64_t *d_trace) {
@@ -515,15 +517,15 @@ int cstark_schnorr_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, co
     return CSTARK_OK;
 }
 
-int cstark_air_shape(int air, uint32_t *width, uint32_t *n_constraints, uint32_t *n_assertions, uint32_t *log_ce_blowup) {
+int cstark_air_shape(int air, uint32_t n_items, uint32_t *width, uint32_t *n_constraints, uint32_t *n_assertions, uint32_t *log_ce_blowup) {
     cs::host::AirShape s;
-    if (!cs::host::air_shape(air, s) || !width || !n_constraints || !n_assertions || !log_ce_blowup) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
+    if (!cs::host::air_shape(air, s, n_items) || !width || !n_constraints || !n_assertions || !log_ce_blowup) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
     *width = s.width; *n_constraints = s.n_constraints; *n_assertions = (uint32_t)s.a_reg.size(); *log_ce_blowup = s.log_ce_blowup();
     return CSTARK_OK;
 }
-int cstark_air_constraint_degree(int air, uint32_t i, uint32_t *base, uint32_t *cycles) {
+int cstark_air_constraint_degree(int air, uint32_t n_items, uint32_t i, uint32_t *base, uint32_t *cycles) {
     cs::host::AirShape s;
-    if (!cs::host::air_shape(air, s) || i >= s.n_constraints || !base || !cycles) return fail(CSTARK_ERR_INVALID_ARG, "bad AIR / constraint index");
+    if (!cs::host::air_shape(air, s, n_items) || i >= s.n_constraints || !base || !cycles) return fail(CSTARK_ERR_INVALID_ARG, "bad AIR / constraint index");
     *base = s.base[i]; *cycles = s.cycles[i];
     return CSTARK_OK;
 }
@@ -571,36 +573,74 @@ int cstark_air_evaluate_transitions(cstark_ctx *c, int air, const uint64_t *d_ld
     return CSTARK_OK;
 }
 
-int cstark_air_combine(cstark_ctx *c, int air, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha, const uint64_t *t_beta,
-                       const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values, uint64_t *d_out, uint32_t log_n,
-                       uint32_t log_blowup, uint32_t k0, uint32_t nk) {
-    if (!c || !d_lde || !d_evals || !t_alpha || !t_beta || !b_alpha || !b_beta || !assertion_values || !d_out || nk == 0)
+// coefficient columns [12][n] of the value polynomials of SchnorrAir's sequence assertions (R.x at step 0 and at step 511 of
+// every 512-row block, src/schnorr/air.rs:172-224); the caller extends them with cstark_lde_columns
+int cstark_schnorr_assertion_polys(cstark_ctx *c, uint64_t *d_out, uint32_t log_n) {
+    if (!c || !d_out) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_assertion_polys: null argument");
+    const size_t n = (size_t)1 << log_n, m = c->schnorr_rx.size() / 6;
+    if (m == 0 || m * 512 != n) return fail(CSTARK_ERR_INVALID_ARG, "no Schnorr witness uploaded for this trace length");
+    unsigned log_m = 0;
+    while (((size_t)1 << log_m) < m) log_m++;
+    std::vector<uint64_t> cols(12 * n, 0);
+    const uint64_t winv = cs::host::inv(cs::host::root_of_unity(log_n));
+    for (int half = 0; half < 2; half++) {
+        const uint64_t off = cs::host::pow(winv, half ? 511 : 0); // c(x) = P(x * w^-first_step)
+        for (int k = 0; k < 6; k++) {
+            uint64_t *o = cols.data() + (size_t)(6 * half + k) * n;
+            for (size_t t = 0; t < m; t++) o[t] = c->schnorr_rx[6 * t + k];
+            if (m > 1) cs::host::intt_small(o, log_m);
+            uint64_t sc = cs::host::ONE;
+            for (size_t t = 0; t < m; t++) { o[t] = cs::host::mul(o[t], sc); sc = cs::host::mul(sc, off); }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(d_out, cols.data(), cols.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CSTARK_OK;
+}
+
+int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha,
+                       const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values,
+                       const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!c || !d_lde || !d_evals || !t_alpha || !t_beta || !b_alpha || !b_beta || !d_out || nk == 0)
         return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: null argument");
     cs::host::AirShape s;
-    if (!cs::host::air_shape(air, s)) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
+    if (!cs::host::air_shape(air, s, n_items)) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
+    if (s.a_const.empty() && !assertion_values) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: assertion values required");
     const uint32_t log_ce = s.log_ce_blowup();
     if (log_blowup < log_ce || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "blowup factor below the constraint degree");
     if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_INVALID_ARG, "bad trace length");
+    const uint64_t n = 1ull << log_n, ce = n << log_ce, b = 1ull << log_blowup;
+    const size_t nc = s.n_constraints, na = s.a_reg.size();
+    bool needs_avals = false;
+    for (int32_t q : s.a_seq) needs_avals |= q >= 0;
+    if (needs_avals && (!d_avals_lde || n_avals == 0)) return fail(CSTARK_ERR_INVALID_ARG, "this AIR has sequence assertions: pass the extended value polynomials");
     HIP_TRY(hipSetDevice(c->device));
     const NttPlan *plan;
     RC_TRY(get_plan(c, log_n, &plan));
-    const uint64_t n = 1ull << log_n, ce = n << log_ce, b = 1ull << log_blowup;
-    const size_t nc = s.n_constraints, na = s.a_reg.size();
-    // one device block: t_alpha | t_beta | adj | b_alpha | b_beta | a_value | shifts | a_reg(u32) | a_last(u32)
-    std::vector<uint64_t> blk(3 * nc + 3 * na + b + na);
+    const uint64_t wn = cs::host::root_of_unity(log_n);
+    // one device block of u64: t_alpha | t_beta | adj | b_alpha | b_beta | a_value | a_badj | a_m | a_zc | shifts, then u32: a_reg | a_seq
+    std::vector<uint64_t> blk(3 * nc + 6 * na + b + na);
     uint64_t *q = blk.data();
     memcpy(q, t_alpha, nc * 8); q += nc;
     memcpy(q, t_beta, nc * 8); q += nc;
     for (size_t i = 0; i < nc; i++) *q++ = (ce - 1 + n - 1) - s.eval_degree(i, n);
     memcpy(q, b_alpha, na * 8); q += na;
     memcpy(q, b_beta, na * 8); q += na;
-    memcpy(q, assertion_values, na * 8); q += na;
+    for (size_t a = 0; a < na; a++) *q++ = s.a_const.empty() ? assertion_values[a] : s.a_const[a];
+    std::vector<uint64_t> am(na), afirst(na);
+    for (size_t a = 0; a < na; a++) {
+        afirst[a] = s.a_stride.empty() ? (s.a_last[a] ? n - 1 : 0) : s.a_first[a];
+        am[a] = (!s.a_stride.empty() && s.a_stride[a]) ? n / s.a_stride[a] : 1;
+    }
+    for (size_t a = 0; a < na; a++) *q++ = ce - 1 + am[a] - (n - 1);                       // a_badj
+    for (size_t a = 0; a < na; a++) *q++ = am[a];                                          // a_m
+    for (size_t a = 0; a < na; a++) *q++ = cs::host::pow(wn, (afirst[a] * am[a]) % n);     // a_zc
     const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
     uint64_t shift = cs::host::generator();
     for (uint64_t k = 0; k < b; k++) { *q++ = shift; shift = cs::host::mul(shift, wbn); }
     uint32_t *q32 = (uint32_t *)q;
     for (size_t a = 0; a < na; a++) q32[a] = s.a_reg[a];
-    for (size_t a = 0; a < na; a++) q32[na + a] = s.a_last[a];
+    for (size_t a = 0; a < na; a++) ((int32_t *)q32)[na + a] = s.a_seq.empty() ? -1 : s.a_seq[a];
     const size_t bytes = blk.size() * 8;
     if (bytes > c->desc_bytes) {
         if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); }
@@ -611,12 +651,12 @@ int cstark_air_combine(cstark_ctx *c, int air, const uint64_t *d_lde, const uint
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t *d = (const uint64_t *)c->desc_buf;
     cs::AirCombineParams p{};
-    p.lde = d_lde; p.evals = d_evals; p.w = plan->w; p.out = d_out;
+    p.lde = d_lde; p.evals = d_evals; p.w = plan->w; p.out = d_out; p.avals = d_avals_lde; p.n_avals = n_avals;
     p.t_alpha = d; p.t_beta = d + nc; p.adj = d + 2 * nc;
-    p.b_alpha = d + 3 * nc; p.b_beta = d + 3 * nc + na; p.a_value = d + 3 * nc + 2 * na; p.shifts = d + 3 * nc + 3 * na;
-    p.a_reg = (const uint32_t *)(d + 3 * nc + 3 * na + b); p.a_last = p.a_reg + na;
-    p.w_last = cs::host::inv(cs::host::root_of_unity(log_n));
-    p.badj = ce - n + 1;
+    const uint64_t *e = d + 3 * nc;
+    p.b_alpha = e; p.b_beta = e + na; p.a_value = e + 2 * na; p.a_badj = e + 3 * na; p.a_m = e + 4 * na; p.a_zc = e + 5 * na; p.shifts = e + 6 * na;
+    p.a_reg = (const uint32_t *)(e + 6 * na + b); p.a_seq = (const int32_t *)(p.a_reg + na);
+    p.w_last = cs::host::inv(wn);
     p.width = s.width; p.n_constraints = (uint32_t)nc; p.n_assertions = (uint32_t)na;
     p.stride = 1u << (log_blowup - log_ce); p.log_n = log_n; p.k0 = k0;
     HIP_TRY(cs::launch_air_combine(p, nk, c->stream));

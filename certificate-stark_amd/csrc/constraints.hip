@@ -808,18 +808,16 @@ __global__ void k_air_combine(AirCombineParams p) {
         const fp xp = fp_pow(x, p.adj[i]);
         acc = fp_add(acc, fp_mul(p.evals[((size_t)kk * p.n_constraints + i) * n + j], fp_add(p.t_alpha[i], fp_mul(p.t_beta[i], xp))));
     }
-    const fp d0 = fp_sub(x, FP_ONE), d1 = fp_sub(x, p.w_last);
-    const fp zinv = fp_mul(d1, fp_inv(fp_sub(fp_pow(x, n), FP_ONE)));
+    const fp zinv = fp_mul(fp_sub(x, p.w_last), fp_inv(fp_sub(fp_pow(x, n), FP_ONE)));
     acc = fp_mul(acc, zinv);
-    const fp xb = fp_pow(x, p.badj);
-    fp first = 0, last = 0;
+    // boundary constraints (single, periodic and sequence assertions): divisor x^m - w^(first*m)
     for (unsigned a = 0; a < p.n_assertions; a++) {
         const fp tv = p.lde[((size_t)kk * p.width + p.a_reg[a]) * n + j];
-        const fp term = fp_mul(fp_sub(tv, p.a_value[a]), fp_add(p.b_alpha[a], fp_mul(p.b_beta[a], xb)));
-        if (p.a_last[a]) last = fp_add(last, term); else first = fp_add(first, term);
+        const fp cv = p.a_seq[a] >= 0 ? p.avals[((size_t)kk * p.n_avals + p.a_seq[a]) * n + j] : p.a_value[a];
+        const fp z = fp_sub(fp_pow(x, p.a_m[a]), p.a_zc[a]);
+        const fp term = fp_mul(fp_sub(tv, cv), fp_add(p.b_alpha[a], fp_mul(p.b_beta[a], fp_pow(x, p.a_badj[a]))));
+        acc = fp_add(acc, fp_mul(term, fp_inv(z)));
     }
-    acc = fp_add(acc, fp_mul(first, fp_inv(d0)));
-    acc = fp_add(acc, fp_mul(last, fp_inv(d1)));
     *o = acc;
 }
 

@@ -36,5 +36,33 @@ inline uint64_t root_of_unity(unsigned log_n) {
     return g;
 }
 
+// in-place inverse transform of a short sequence (m = 2^log_m values over the m-th roots of unity) -> coefficients
+inline void intt_small(uint64_t *a, unsigned log_m) {
+    const size_t m = (size_t)1 << log_m;
+    for (size_t i = 1, j = 0; i < m; i++) {
+        size_t bit = m >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { uint64_t t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    const uint64_t winv = inv(root_of_unity(log_m));
+    for (unsigned s = 1; s <= log_m; s++) {
+        const size_t len = (size_t)1 << s, half = len >> 1;
+        uint64_t wl = winv;
+        for (unsigned i = s; i < log_m; i++) wl = mul(wl, wl);
+        for (size_t k = 0; k < m; k += len) {
+            uint64_t tw = ONE;
+            for (size_t j = 0; j < half; j++) {
+                const uint64_t u = a[k + j], v = mul(a[k + j + half], tw);
+                a[k + j] = add(u, v);
+                a[k + j + half] = sub(u, v);
+                tw = mul(tw, wl);
+            }
+        }
+    }
+    const uint64_t minv = inv(from_u64(m));
+    for (size_t i = 0; i < m; i++) a[i] = mul(a[i], minv);
+}
+
 } // namespace host
 } // namespace cs

@@ -163,30 +163,38 @@ int cstark_range_build_trace(cstark_ctx *ctx, uint64_t number, uint64_t *d_trace
 /* SchnorrAir (src/schnorr/air.rs:41-300, src/schnorr/prover.rs:21-67): n signatures over 28-element messages
  * (message[0..12] = public key).  Trace 56 x (512*n); the 19 public-input columns (pkey x12, message chunks x7;
  * src/schnorr/air.rs:228-290) as a 19 x (512*n) table that the caller extends like trace columns; the 8 mask + 28
- * round-constant periodic columns [36][512] (host).  Transition constraints only: the periodic / sequence
- * assertions of src/schnorr/air.rs:111-226 are not merged by this library yet. */
+ * round-constant periodic columns [36][512] (host).  The 61 periodic / sequence assertions (:111-226) are merged by
+ * cstark_air_combine. */
 int cstark_schnorr_witness_upload(cstark_ctx *ctx, uint32_t n_sig, const uint64_t *messages, const uint64_t *sig_rx, const uint8_t *sig_s);
 int cstark_schnorr_build_trace(cstark_ctx *ctx, uint64_t *d_trace);
 int cstark_schnorr_aux_columns(cstark_ctx *ctx, uint64_t *d_out);
 int cstark_schnorr_mask_columns(uint64_t *out /* [36][512] host */);
 int cstark_schnorr_evaluate_transitions(cstark_ctx *ctx, const uint64_t *d_lde, const uint64_t *d_aux_lde, uint64_t *d_out,
                                         uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* Coefficient columns [12][n] of the value polynomials of SchnorrAir's sequence assertions (R.x asserted at step 0 and at
+ * step 511 of every block, src/schnorr/air.rs:172-224); extend them with cstark_lde_columns and pass them to
+ * cstark_air_combine. */
+int cstark_schnorr_assertion_polys(cstark_ctx *ctx, uint64_t *d_out, uint32_t log_n);
 /* Shape of an AIR as the engine sees it (host side): trace width, number of transition constraints and of
- * assertions, log2 of the constraint-evaluation blowup; degree (base; cycles) of constraint i. */
-int cstark_air_shape(int air, uint32_t *width, uint32_t *n_constraints, uint32_t *n_assertions, uint32_t *log_ce_blowup);
-int cstark_air_constraint_degree(int air, uint32_t i, uint32_t *base, uint32_t *cycles);
+ * assertions, log2 of the constraint-evaluation blowup; degree (base; cycles) of constraint i.  n_items = number of
+ * signatures for CSTARK_AIR_SCHNORR (its degrees depend on it, src/schnorr/air.rs:537), ignored otherwise. */
+int cstark_air_shape(int air, uint32_t n_items, uint32_t *width, uint32_t *n_constraints, uint32_t *n_assertions, uint32_t *log_ce_blowup);
+int cstark_air_constraint_degree(int air, uint32_t n_items, uint32_t i, uint32_t *base, uint32_t *cycles);
 int cstark_merkle_periodic_columns(uint32_t merkle_depth, uint64_t *out /* [33][512] host */);
 /* All transition constraints of AIR `air` (CSTARK_AIR_MERKLE_UPDATE, CSTARK_AIR_RANGE) on LDE cosets [k0,k0+nk):
- *   d_out[((k - k0) * n_constraints + i) * n + j]. */
+ *   d_out[((k - k0) * n_constraints + i) * n + j].  (SchnorrAir: cstark_schnorr_evaluate_transitions.) */
 int cstark_air_evaluate_transitions(cstark_ctx *ctx, int air, const uint64_t *d_lde, uint64_t *d_out, uint32_t merkle_depth,
                                     uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
-/* Generic merge of those evaluations with the AIR's single-step assertions into the combined constraint
- * evaluations d_out[(k - k0) * n + j].  Coefficient arrays and assertion values (in get_assertions order) are host
- * memory.  The constraint-evaluation domain may be smaller than the LDE domain (MerkleAir: blowup 4); cosets
- * outside it are written as 0. */
-int cstark_air_combine(cstark_ctx *ctx, int air, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha,
-                       const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values,
-                       uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* Generic merge of materialised transition evaluations with the AIR's assertions (single, periodic and sequence) into
+ * the combined constraint evaluations d_out[(k - k0) * n + j].  Coefficient arrays (per transition constraint / per
+ * assertion in get_assertions order) are host memory.  assertion_values: host, one per assertion, for Merkle (7+7 roots)
+ * and Range (0, number); NULL for Schnorr whose constants are built in and whose sequence values arrive as
+ * d_avals_lde = [nk][n_avals][n] (extension of cstark_schnorr_assertion_polys).  The constraint-evaluation domain may be
+ * smaller than the LDE domain (MerkleAir: blowup 4); cosets outside it are written as 0. */
+int cstark_air_combine(cstark_ctx *ctx, int air, uint32_t n_items, const uint64_t *d_lde, const uint64_t *d_evals,
+                       const uint64_t *t_alpha, const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta,
+                       const uint64_t *assertion_values, const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out,
+                       uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 
 /* ---- device memory helpers for callers without a HIP runtime of their own (the Rust shim) ---- */
 int cstark_malloc(cstark_ctx *ctx, size_t bytes, void **d_ptr);

@@ -287,11 +287,11 @@ int cso_schnorr_witness_generate(uint32_t n_sig, uint64_t seed, uint64_t *messag
  * Only cosets with k % (lde_b / ce_b) == 0 belong to the constraint-evaluation domain; others get 0. */
 void cso_air_combine(const cso_air_desc *d, const uint64_t *lde, const uint64_t *evals, const uint64_t *t_alpha, const uint64_t *t_beta,
                      const uint64_t *b_alpha, const uint64_t *b_beta, uint64_t *out, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk,
-                     int all_cosets) {
+                     int all_cosets, const uint64_t *avals /* [nk][n_avals][n] LDE of the sequence-value polynomials, or NULL */, uint32_t n_avals) {
     const size_t n = (size_t)1 << log_n;
     const unsigned log_ce = d->log_ce_blowup, stride = 1u << (log_b - log_ce);
     const uint64_t ce = (uint64_t)n << log_ce;
-    fp g = fp_from_u64(FP_GENERATOR_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n), w_last = fp_inv(wn);
+    fp g = fp_from_u64(FP_GENERATOR_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
 #pragma omp parallel for schedule(static) collapse(2)
     for (uint32_t k = k0; k < k0 + nk; k++)
         for (size_t j = 0; j < n; j++) {
@@ -304,17 +304,37 @@ void cso_air_combine(const cso_air_desc *d, const uint64_t *lde, const uint64_t 
                 fp c = evals[((size_t)(k - k0) * d->n_constraints + i) * n + j];
                 acc = fp_add(acc, fp_mul(c, fp_add(t_alpha[i], fp_mul(t_beta[i], fp_pow(x, adj)))));
             }
-            acc = fp_mul(acc, fp_inv(fp_mul(fp_sub(fp_pow(x, n), FP_ONE), fp_inv(fp_sub(x, w_last)))));
-            fp xb = fp_pow(x, ce - n + 1), first = 0, last = 0;
+            acc = fp_mul(acc, fp_inv(fp_mul(fp_sub(fp_pow(x, n), FP_ONE), fp_inv(fp_sub(x, fp_inv(wn))))));
+            /* boundary constraints: (T_reg(x) - c_a(x)) (alpha_a + beta_a x^(ce - 1 + m - (n - 1))) / (x^m - w^(first * m)),
+             * m = number of asserted steps; assertions with the same divisor could be summed first (same value) */
             for (uint32_t a = 0; a < d->n_assertions; a++) {
+                uint64_t first = d->a_stride ? d->a_first[a] : (d->a_last[a] ? n - 1 : 0);
+                uint64_t m = (d->a_stride && d->a_stride[a]) ? n / d->a_stride[a] : 1;
                 fp tv = lde[((size_t)(k - k0) * d->width + d->a_reg[a]) * n + j];
-                fp term = fp_mul(fp_sub(tv, d->a_value[a]), fp_add(b_alpha[a], fp_mul(b_beta[a], xb)));
-                if (d->a_last[a]) last = fp_add(last, term); else first = fp_add(first, term);
+                fp cv = (d->a_seq && d->a_seq[a] >= 0) ? avals[((size_t)(k - k0) * n_avals + d->a_seq[a]) * n + j] : d->a_value[a];
+                fp xb = fp_pow(x, ce - 1 + m - (n - 1));
+                fp z = fp_sub(fp_pow(x, m), fp_pow(wn, (first * m) % n));
+                acc = fp_add(acc, fp_mul(fp_mul(fp_sub(tv, cv), fp_add(b_alpha[a], fp_mul(b_beta[a], xb))), fp_inv(z)));
             }
-            acc = fp_add(acc, fp_mul(first, fp_inv(fp_sub(x, FP_ONE))));
-            acc = fp_add(acc, fp_mul(last, fp_inv(fp_sub(x, w_last))));
             *o = acc;
         }
+}
+/* Coefficients (in x, zero-padded to n) of the value polynomials of sequence assertions: values [n_seq][m] are asserted at
+ * steps first_step + k * (n / m); c(x) = P(x * w^-first_step) with P = interpolation of the values over the m-th roots. */
+void cso_sequence_value_polys(const uint64_t *values, uint32_t n_seq, uint32_t m, uint32_t first_step, unsigned log_n, uint64_t *out) {
+    const size_t n = (size_t)1 << log_n;
+    unsigned log_m = 0;
+    while ((1u << log_m) < m) log_m++;
+    fp winv = fp_inv(fp_root_of_unity(log_n));
+    fp off = fp_pow(winv, first_step);
+    memset(out, 0, (size_t)n_seq * n * sizeof(fp));
+    for (uint32_t s = 0; s < n_seq; s++) {
+        fp *o = out + (size_t)s * n;
+        memcpy(o, values + (size_t)s * m, m * sizeof(fp));
+        if (m > 1) cso_intt(o, log_m);
+        fp sc = FP_ONE;
+        for (uint32_t t = 0; t < m; t++) { o[t] = fp_mul(o[t], sc); sc = fp_mul(sc, off); }
+    }
 }
 
 typedef void (*transition_fn)(const uint64_t *, const uint64_t *, const uint64_t *, uint64_t *);

@@ -81,8 +81,13 @@ typedef struct cso_air_desc {
     uint32_t width, n_constraints, cycle_len, log_ce_blowup;
     const uint32_t *base, *cycles;          /* [n_constraints] */
     uint32_t n_assertions;
-    const uint32_t *a_reg, *a_last;         /* [n_assertions]: register, 0 = first step / 1 = last step */
+    const uint32_t *a_reg, *a_last;         /* [n_assertions]: register, 0 = first step / 1 = last step (single assertions) */
     const uint64_t *a_value;
+    /* optional generalisation to periodic / sequence assertions (Assertion::periodic / ::sequence): when a_stride is
+     * non-NULL, assertion a holds at steps a_first[a] + k * a_stride[a] (a_stride 0: the single step a_first[a]); its value
+     * is a_value[a], or column a_seq[a] of the `avals` table passed to cso_air_combine when a_seq[a] >= 0 */
+    const uint32_t *a_first, *a_stride;
+    const int32_t *a_seq;
 } cso_air_desc;
 int cso_merkle_build_trace(const cstark_tx_witness *w, uint64_t *trace);
 int cso_merkle_periodic_columns(unsigned depth, uint64_t *out);
@@ -102,7 +107,8 @@ void cso_schnorr_constraint_degrees(uint32_t n_sig, uint32_t *base, uint32_t *cy
 int cso_schnorr_witness_generate(uint32_t n_sig, uint64_t seed, uint64_t *messages, uint64_t *sig_rx, uint8_t *sig_s);
 void cso_air_combine(const cso_air_desc *d, const uint64_t *lde, const uint64_t *evals, const uint64_t *t_alpha, const uint64_t *t_beta,
                      const uint64_t *b_alpha, const uint64_t *b_beta, uint64_t *out, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk,
-                     int all_cosets);
+                     int all_cosets, const uint64_t *avals, uint32_t n_avals);
+void cso_sequence_value_polys(const uint64_t *values, uint32_t n_seq, uint32_t m, uint32_t first_step, unsigned log_n, uint64_t *out);
 void cso_air_evaluate_transitions(int air, const uint64_t *lde, const uint64_t *ptab, uint64_t *out, uint32_t width, uint32_t nc, uint32_t np,
                                   uint32_t cycle_len, unsigned log_n, uint32_t k0, uint32_t nk);
 void cso_periodic_table(const uint64_t *cols, uint32_t np, unsigned log_cycle, unsigned log_n, unsigned log_b, uint64_t *out);

@@ -320,14 +320,18 @@ AIR_STATE_TRANSITION, AIR_MERKLE, AIR_SCHNORR, AIR_RANGE, AIR_RESCUE_CHAIN = 0, 
 
 class AirDescStruct(C.Structure):
     _fields_ = [("width", C.c_uint32), ("n_constraints", C.c_uint32), ("cycle_len", C.c_uint32), ("log_ce_blowup", C.c_uint32),
-                ("base", u32p), ("cycles", u32p), ("n_assertions", C.c_uint32), ("a_reg", u32p), ("a_last", u32p), ("a_value", u64p)]
+                ("base", u32p), ("cycles", u32p), ("n_assertions", C.c_uint32), ("a_reg", u32p), ("a_last", u32p), ("a_value", u64p),
+                ("a_first", u32p), ("a_stride", u32p), ("a_seq", C.POINTER(C.c_int32))]
 
 
 class AirDesc:
     """Python-side holder of a cso_air_desc."""
 
-    def __init__(self, width, base, cycles, cycle_len, a_reg, a_last, a_value):
+    def __init__(self, width, base, cycles, cycle_len, a_reg, a_last, a_value, a_first=None, a_stride=None, a_seq=None):
         self.width, self.cycle_len = width, cycle_len
+        self.a_first = None if a_first is None else np.ascontiguousarray(a_first, np.uint32)
+        self.a_stride = None if a_stride is None else np.ascontiguousarray(a_stride, np.uint32)
+        self.a_seq = None if a_seq is None else np.ascontiguousarray(a_seq, np.int32)
         self.base = np.ascontiguousarray(base, np.uint32)
         self.cycles = np.ascontiguousarray(cycles, np.uint32)
         self.a_reg = np.ascontiguousarray(a_reg, np.uint32)
@@ -342,6 +346,8 @@ class AirDesc:
         s.width, s.n_constraints, s.cycle_len, s.log_ce_blowup = self.width, self.nc, self.cycle_len, self.log_ce
         s.base, s.cycles = _p(self.base, u32p), _p(self.cycles, u32p)
         s.n_assertions, s.a_reg, s.a_last, s.a_value = self.na, _p(self.a_reg, u32p), _p(self.a_last, u32p), _p(self.a_value)
+        if self.a_stride is not None:
+            s.a_first, s.a_stride, s.a_seq = _p(self.a_first, u32p), _p(self.a_stride, u32p), _p(self.a_seq, C.POINTER(C.c_int32))
         return s
 
 
@@ -421,14 +427,49 @@ def air_evaluate_transitions(air, lde, ptab, nc, k0=0):
     return out
 
 
-def air_combine(desc, lde, evals, t_alpha, t_beta, b_alpha, b_beta, log_b, k0=0, all_cosets=False):
+def air_combine(desc, lde, evals, t_alpha, t_beta, b_alpha, b_beta, log_b, k0=0, all_cosets=False, avals=None):
     lde, evals = _u64(lde), _u64(evals)
     nk, width, n = lde.shape
     out = np.zeros((nk, n), np.uint64)
     s = desc.struct()
+    if avals is not None:
+        avals = _u64(avals)
     lib().cso_air_combine(C.byref(s), _p(lde), _p(evals), _p(_u64(t_alpha)), _p(_u64(t_beta)), _p(_u64(b_alpha)), _p(_u64(b_beta)),
-                          _p(out), C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_uint32(k0), C.c_uint32(nk), C.c_int(1 if all_cosets else 0))
+                          _p(out), C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_uint32(k0), C.c_uint32(nk), C.c_int(1 if all_cosets else 0),
+                          None if avals is None else _p(avals), C.c_uint32(0 if avals is None else avals.shape[1]))
     return out
+
+
+def sequence_value_polys(values, first_step, log_n):
+    """values [n_seq][m] -> coefficient columns [n_seq][n] of c(x) = P(x w^-first_step)"""
+    values = _u64(values)
+    n_seq, m = values.shape
+    out = np.zeros((n_seq, 1 << log_n), np.uint64)
+    lib().cso_sequence_value_polys(_p(values), C.c_uint32(n_seq), C.c_uint32(m), C.c_uint32(first_step), C.c_uint(log_n), _p(out))
+    return out
+
+
+def schnorr_desc(w):
+    """SchnorrAir: degrees (src/schnorr/air.rs:533-585) and the 61 assertions of get_assertions (:111-226), in order."""
+    base, cyc = schnorr_constraint_degrees(w.n_sig)
+    one = int(to_mont([1])[0])
+    reg, first, stride, seq, val = [], [], [], [], []
+    def add(r, f, v=0, q=-1):
+        reg.append(r); first.append(f); stride.append(512); val.append(v); seq.append(q)
+    for i in range(18): add(i, 0, one if i == 6 else 0)
+    add(18, 0)
+    for i in range(18): add(19 + i, 0, one if i == 6 else 0)
+    for i in range(5): add(37 + i, 0)
+    for k in range(6): add(42 + k, 0, 0, k)            # sequence: R.x at the first step of every block
+    for i in range(7): add(48 + i, 0)
+    for k in range(6): add(k, 511, 0, 6 + k)           # sequence: x(s*G + h*P) == R.x at step 511 of every block
+    return AirDesc(56, base, cyc, 512, reg, [0] * len(reg), val, first, stride, seq)
+
+
+def schnorr_assertion_polys(w, log_n):
+    """[12][n] coefficient columns: 6 for the step-0 sequences, 6 for the step-511 sequences (same values)."""
+    vals = np.ascontiguousarray(w.sig_rx.T)            # [6][n_sig]
+    return np.concatenate([sequence_value_polys(vals, 0, log_n), sequence_value_polys(vals, 511, log_n)])
 
 
 def random_elements(k, seed):

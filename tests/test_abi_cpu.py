@@ -79,16 +79,24 @@ def test_small_air_host_descriptions_match_oracle(oracle):
     oracle.lib().cso_merkle_constraint_degrees(base.ctypes.data_as(C.POINTER(C.c_uint32)), cyc.ctypes.data_as(C.POINTER(C.c_uint32)))
     for i in range(106):
         b, c = C.c_uint32(), C.c_uint32()
-        assert lib.cstark_air_constraint_degree(C.c_int(1), C.c_uint32(i), C.byref(b), C.byref(c)) == 0
+        assert lib.cstark_air_constraint_degree(C.c_int(1), C.c_uint32(2), C.c_uint32(i), C.byref(b), C.byref(c)) == 0
         assert (b.value, c.value) == (int(base[i]), int(cyc[i]))
     for depth in (3, 15, 31):
         out = np.zeros((33, 512), np.uint64)
         assert lib.cstark_merkle_periodic_columns(C.c_uint32(depth), out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
         assert (out == oracle.merkle_periodic_columns(depth)).all()
     w, nc, na, lce = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-    assert lib.cstark_air_shape(C.c_int(3), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == 0
+    assert lib.cstark_air_shape(C.c_int(3), C.c_uint32(1), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == 0
     assert (w.value, nc.value, na.value, lce.value) == (2, 2, 2, 1)
-    assert lib.cstark_air_shape(C.c_int(2), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == -5   # SchnorrAir: no generic merge yet
+    assert lib.cstark_air_shape(C.c_int(2), C.c_uint32(4), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == 0
+    assert (w.value, nc.value, na.value, lce.value) == (56, 56, 61, 3)
+    for n_sig in (1, 2):
+        sb, sc = oracle.schnorr_constraint_degrees(n_sig)
+        for i in range(56):
+            b, c = C.c_uint32(), C.c_uint32()
+            assert lib.cstark_air_constraint_degree(C.c_int(2), C.c_uint32(n_sig), C.c_uint32(i), C.byref(b), C.byref(c)) == 0
+            assert (b.value, c.value) == (int(sb[i]), int(sc[i]))
+    assert lib.cstark_air_shape(C.c_int(4), C.c_uint32(1), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == -5   # rescue chain: CPU only
     out = np.zeros((36, 512), np.uint64)
     assert lib.cstark_schnorr_mask_columns(out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
     assert (out == oracle.schnorr_mask_columns()).all()

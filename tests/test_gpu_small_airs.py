@@ -102,3 +102,29 @@ def test_schnorr_air_trace_and_transitions(oracle, backend, n_sig):
         raise AssertionError("constraints differ: %s" % sorted(set(np.argwhere(got_ev != ref_ev)[:, 1].tolist())))
     part = to_numpy_u64(backend.schnorr_evaluate_transitions(d_lde[3:5].contiguous(), d_aux_lde[3:5].contiguous(), log_b, k0=3))
     assert (part == ref_ev[3:5]).all()
+
+
+@pytest.mark.parametrize("n_sig", [1, 4])
+def test_schnorr_air_merged_evaluations(oracle, backend, n_sig):
+    """SchnorrAir end to end: transitions merged with the 61 periodic / sequence assertions (src/schnorr/air.rs:111-226)."""
+    from certificate_stark_amd.backend import to_numpy_u64
+    w = oracle.SchnorrWitness.generate(n_sig, seed=77 + n_sig)
+    trace = oracle.schnorr_build_trace(w)
+    log_b, log_n = 3, trace.shape[1].bit_length() - 1
+    lde = oracle.lde_columns(oracle.interpolate_columns(trace), log_b)
+    aux_lde = oracle.lde_columns(oracle.interpolate_columns(oracle.schnorr_aux_columns(w)), log_b)
+    ev = oracle.schnorr_evaluate_transitions(lde, aux_lde, oracle.periodic_table(oracle.schnorr_mask_columns(), log_n, log_b))
+    desc = oracle.schnorr_desc(w)
+    polys = oracle.schnorr_assertion_polys(w, log_n)
+    avals = oracle.lde_columns(polys, log_b)
+    ta, tb = oracle.random_elements(56, 1), oracle.random_elements(56, 2)
+    ba, bb = oracle.random_elements(61, 3), oracle.random_elements(61, 4)
+    ref = oracle.air_combine(desc, lde, ev, ta, tb, ba, bb, log_b, avals=avals)
+    backend.upload_schnorr_witness(w.messages, w.sig_rx, w.sig_s)
+    assert backend.air_shape(backend.AIR_SCHNORR, n_sig) == (56, 56, 61, 3)
+    d_polys = backend.schnorr_assertion_polys(log_n)
+    assert (to_numpy_u64(d_polys) == polys).all()
+    d_avals = backend.lde_columns(d_polys, log_b)
+    out = backend.air_combine(backend.AIR_SCHNORR, backend.from_numpy_u64(lde), backend.from_numpy_u64(ev), ta, tb, ba, bb, None, log_b,
+                              n_items=n_sig, avals_lde=d_avals)
+    assert (to_numpy_u64(out) == ref).all()

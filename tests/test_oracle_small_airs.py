@@ -125,3 +125,39 @@ def test_schnorr_air(oracle):
     b2, c2 = oracle.schnorr_constraint_degrees(2)
     assert Counter(zip(b2.tolist(), c2.tolist())) == {(5, 2): 24, (4, 2): 12, (2, 1): 2, (1, 2): 4, (3, 1): 14}
     assert b1[19] == 3 and b2[19] == 5
+
+
+def test_schnorr_merged_evaluations_are_polynomial(oracle):
+    """SchnorrAir with its 61 periodic / sequence assertions (src/schnorr/air.rs:111-226): the merged quotient is a
+    polynomial (interpolated from the 8n-point domain it reproduces the rational function on a different coset of a
+    16-fold extension); perturbing a signature's R.x in the assertions -- the reference's wrong-input test -- breaks it."""
+    w = oracle.SchnorrWitness.generate(2, seed=21)
+    trace = oracle.schnorr_build_trace(w)
+    n = trace.shape[1]; log_n = n.bit_length() - 1
+    desc = oracle.schnorr_desc(w)
+    assert desc.log_ce == 3 and desc.na == 61
+    ta, tb = oracle.random_elements(56, 1), oracle.random_elements(56, 2)
+    ba, bb = oracle.random_elements(61, 3), oracle.random_elements(61, 4)
+    log_b = 4                                        # 16 cosets; the constraint-evaluation domain is the even ones
+    co = oracle.interpolate_columns(trace)
+    lde = oracle.lde_columns(co, log_b)
+    aux_lde = oracle.lde_columns(oracle.interpolate_columns(oracle.schnorr_aux_columns(w)), log_b)
+    ptab = oracle.periodic_table(oracle.schnorr_mask_columns(), log_n, log_b)
+    ev = oracle.schnorr_evaluate_transitions(lde, aux_lde, ptab)
+
+    def off_domain_errors(wit):
+        avals = oracle.lde_columns(oracle.schnorr_assertion_polys(wit, log_n), log_b)
+        full = oracle.air_combine(desc, lde, ev, ta, tb, ba, bb, log_b, all_cosets=True, avals=avals)   # [16][n]
+        nat = np.ascontiguousarray(full[::2].T).ravel()          # the 8n-point evaluation domain, natural order
+        h = oracle.ntt(nat, inverse=True)
+        w16 = oracle.root_of_unity(log_n + log_b); wn = oracle.root_of_unity(log_n)
+        errs = 0
+        for (k, j) in [(1, 0), (3, 77), (15, n - 1)]:
+            y = int(oracle.fp_mul(oracle.fp_pow(np.array([w16], np.uint64), k), oracle.fp_pow(np.array([wn], np.uint64), j))[0])
+            errs += oracle.poly_eval(h, y) != int(full[k, j])
+        return errs
+    assert off_domain_errors(w) == 0
+    bad = oracle.SchnorrWitness(2)
+    bad.messages[...] = w.messages; bad.sig_s[...] = w.sig_s; bad.sig_rx[...] = w.sig_rx
+    bad.sig_rx[1, 2] = oracle.fp_add(bad.sig_rx[1, 2:3], oracle.to_mont([1]))[0]
+    assert off_domain_errors(bad) > 0
