@@ -1,0 +1,111 @@
+"""GPU parity at BASELINE.json's full sizes.  The oracle is too slow to restate 2^20 x 94 x 8 in full, so these tests use
+what the domain offers: sampled transactions against the oracle, the interpolate/evaluate round trip, Merkle paths
+recomputed with the oracle's BLAKE3, and -- end to end -- the verifier's out-of-domain identity: the 2^23 combined
+evaluations produced on the GPU interpolate to a polynomial H with H(z) equal to the constraint expression evaluated
+directly at a random z from the trace polynomials (CPU oracle)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 2**62 + 2**56 + 2**55 + 1
+
+
+@pytest.fixture(scope="module")
+def backend():
+    from certificate_stark_amd.backend import Backend
+    b = Backend()
+    yield b
+    b.close()
+
+
+def _sub_witness(oracle, w, t0, cnt):
+    s = oracle.TxWitness(cnt, w.depth)
+    for f in s.FIELDS:
+        if f != "final_root":
+            getattr(s, f)[...] = getattr(w, f)[t0:t0 + cnt]
+    s.final_root[...] = w.initial_roots[t0 + cnt] if t0 + cnt < w.n_tx else w.final_root
+    return s
+
+
+def test_state_transition_2_20_end_to_end(oracle, backend):
+    import torch
+    from certificate_stark_amd.backend import to_numpy_u64
+    from certificate_stark_amd import _lib
+    w = oracle.TxWitness.load(os.path.join(ROOT, "tests", "golden", "witness_1024_d15.npz"))
+    assert w.n_tx == 1024 and w.depth == 15
+    n, log_n, log_b = 1 << 20, 20, 3
+    backend.upload_witness(w)
+    trace = backend.build_trace()
+    # K1: sampled transactions equal the oracle's fragments; public inputs as get_pub_inputs reads them
+    for t0 in (0, 511, 1022):
+        ref = oracle.tx_build_trace(_sub_witness(oracle, w, t0, 2))
+        got = to_numpy_u64(trace[:, 1024 * t0:1024 * (t0 + 2)])
+        assert (got == ref).all(), t0
+    assert (to_numpy_u64(trace[58:65, 0]) == w.initial_roots[0]).all() and (to_numpy_u64(trace[58:65, -1]) == w.final_root).all()
+    keep = trace[[0, 37, 93]].clone()
+    # K2/K3: round trip on three columns, then the real LDE
+    coeffs = backend.interpolate_columns(trace)
+    one = int(oracle.to_mont([1])[0])
+    back = backend.lde_columns(coeffs[[0, 37, 93]].contiguous(), 0, offset=one)
+    assert torch.equal(back[0], keep)
+    lde = backend.lde_columns(coeffs, log_b)
+    # K4/K5: three authentication paths recomputed with the oracle's BLAKE3
+    L = n << log_b
+    nodes = torch.zeros((2 * L, 32), dtype=torch.uint8, device=backend.device)
+    backend.hash_rows(lde, log_b, leaves=nodes[L:])
+    backend.merkle_build(nodes)
+    root = nodes[1].cpu().numpy().tobytes()
+    for i in (0, 5_000_003, L - 1):
+        k, j = i % 8, i // 8
+        row = to_numpy_u64(lde[k, :, j])
+        h = oracle.blake3(b"".join(int(v).to_bytes(8, "little") for v in row))
+        assert h == nodes[L + i].cpu().numpy().tobytes()
+        idx = L + i
+        while idx > 1:
+            sib = nodes[idx ^ 1].cpu().numpy().tobytes()
+            h = oracle.blake3(h + sib if idx % 2 == 0 else sib + h)
+            idx >>= 1
+        assert h == root
+    # K6: out-of-domain identity at full size
+    cf = oracle.make_coeffs(2024)
+    pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
+    comb = backend.evaluate_constraints(lde, cf, pub, w.depth)                       # [8][n], coset-major
+    nat = comb.t().contiguous().reshape(1, 8 * n)                                     # natural order i = 8 j + k
+    h_poly = to_numpy_u64(backend.interpolate_columns(nat))[0]                        # H(g y) as a polynomial in y (2^23 coefficients)
+    z = int(oracle.to_mont([0x0BADC0FFEE123457 % P])[0])
+    ginv = oracle.fp_inv(np.array([oracle.generator()], np.uint64))
+    zg = int(oracle.fp_mul(np.array([z], np.uint64), ginv)[0])
+    co_host = to_numpy_u64(coeffs)
+    assert oracle.poly_eval(h_poly, zg) == oracle.tx_combined_at(co_host, cf, pub, w.depth, log_b, z)
+
+
+def test_merkle_air_2_18(oracle, backend):
+    """BASELINE config 'merkle, 2^18 steps': 512 transfers at depth 15 -- full trace and a slice of the constraints."""
+    from certificate_stark_amd.backend import to_numpy_u64
+    w = oracle.TxWitness.generate(512, 15, seed=18)
+    ref = oracle.merkle_build_trace(w)
+    backend.upload_witness(w)
+    d_trace = backend.merkle_build_trace()
+    assert (to_numpy_u64(d_trace) == ref).all()
+    lde1 = backend.lde_columns(backend.interpolate_columns(d_trace), 3, k0=6, nk=1)
+    ref_lde1 = oracle.lde_columns(oracle.interpolate_columns(ref), 3, k0=6, nk=1)
+    assert (to_numpy_u64(lde1) == ref_lde1).all()
+    ptab = oracle.periodic_table(oracle.merkle_periodic_columns(15), 18, 3)
+    ref_ev = oracle.air_evaluate_transitions(oracle.AIR_MERKLE, ref_lde1, ptab, 106, k0=6)
+    got_ev = to_numpy_u64(backend.air_evaluate_transitions(backend.AIR_MERKLE, lde1, 15, 3, k0=6))
+    assert (got_ev == ref_ev).all()
+
+
+def test_schnorr_air_2_18(oracle, backend):
+    """BASELINE config 'schnorr, 2^18 steps': 512 signatures -- full trace against the oracle."""
+    from certificate_stark_amd.backend import to_numpy_u64
+    w = oracle.SchnorrWitness.generate(512, seed=218)
+    ref = oracle.schnorr_build_trace(w)
+    backend.upload_schnorr_witness(w.messages, w.sig_rx, w.sig_s)
+    got = to_numpy_u64(backend.schnorr_build_trace())
+    assert (got == ref).all()
+    for t in (0, 255, 511):
+        assert (got[0:6, 512 * t + 511] == w.sig_rx[t]).all()
