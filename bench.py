@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--n-tx", type=int, default=1024, help="transactions per proof (1024 = BASELINE's 2^20 rows)")
     ap.add_argument("--cpu-sample-tx", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-composition", action="store_true",
+                    help="also time the next stage of prove(): composition polynomial columns + their LDE + Blake3 commitment "
+                         "(reported as extra_stage_ms, not part of the hot-path metric)")
     ap.add_argument("--mode", choices=["replica", "coset"], default="replica",
                     help="replica: independent proofs per GPU (weak scaling, no collective); "
                          "coset: ONE proof sharded by LDE coset with RCCL all-gathers (strong scaling)")
@@ -206,6 +209,26 @@ def main():
             acc_ms[s] += ev[i].elapsed_time(ev[i + 1])
     stage_ms = {s: acc_ms[s] / args.steps for s in stages}
 
+    extra = None
+    if args.with_composition and not coset_mode:
+        b = prover.backend
+        comb = prover._bufs["combined"]
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for rep in range(2):
+            e[0].record()
+            cols = b.composition_columns(comb, out=prover._buf("comp_cols", (8, n)))
+            e[1].record()
+            clde = b.lde_columns(cols, LOG_B, out=prover._buf("comp_lde", (8, 8, n)))
+            e[2].record()
+            L = n << LOG_B
+            cnodes = prover._buf("comp_nodes", (2 * L, 32), torch.uint8)
+            b.hash_rows(clde, LOG_B, leaves=cnodes[L:])
+            b.merkle_build(cnodes)
+            e[3].record()
+            torch.cuda.synchronize()
+        extra = {"composition_columns": round(e[0].elapsed_time(e[1]), 3), "composition_lde": round(e[1].elapsed_time(e[2]), 3),
+                 "composition_commit": round(e[2].elapsed_time(e[3]), 3)}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         ab = algorithmic_bytes(n, WIDTH, 1 << LOG_B)
@@ -242,6 +265,8 @@ def main():
                          "note": "integer-VALU bound kernel (~1.4 k modular products per point at 1.85e12 modmul/s) priced against the "
                                  "HBM roofline as BASELINE.json asks; whole-stage figures are in stage_gbs"},
         }
+        if extra:
+            out["extra_stage_ms"] = extra
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(meta_full, min(args.cpu_sample_tx, n_tx))

@@ -223,3 +223,12 @@ class Backend:
         out = self.empty_u64(12, 1 << log_n)
         check(self.lib.cstark_schnorr_assertion_polys(self.ctx, self._ptr(out), C.c_uint32(log_n)))
         return out
+
+    # ---- composition polynomial ----
+    def composition_columns(self, combined, out=None):
+        b, n = combined.shape
+        if out is None:
+            out = self.empty_u64(b, n)
+        check(self.lib.cstark_composition_columns(self.ctx, self._ptr(combined), self._ptr(out), C.c_uint32(n.bit_length() - 1),
+                                                  C.c_uint32(b.bit_length() - 1)))
+        return out

@@ -370,6 +370,27 @@ int cstark_lde_columns(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde,
     return lde_impl(c, d_coeffs, d_lde, width, log_n, log_blowup, domain_offset, k0, nk);
 }
 
+// ---- composition polynomial (first "next" row: engine into_poly + column split) -----------------------------------
+int cstark_composition_columns(cstark_ctx *c, const uint64_t *d_combined, uint64_t *d_cols, uint32_t log_n, uint32_t log_blowup) {
+    if (!c || !d_combined || !d_cols) return fail(CSTARK_ERR_INVALID_ARG, "cstark_composition_columns: null argument");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n + log_blowup > cs::NTT_MAX_LOG_N || log_blowup == 0 || log_blowup > 6)
+        return fail(CSTARK_ERR_UNSUPPORTED, "composition domain must be 2^7 .. 2^24 points");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t N = (size_t)1 << (log_n + log_blowup);
+    RC_TRY(ensure_ws(c, 2 * N * 8));
+    uint64_t *nat = (uint64_t *)c->ws, *h = nat + N;
+    HIP_TRY(cs::interleave_cosets(d_combined, nat, log_n, log_blowup, c->stream));
+    // interpolate over the whole evaluation domain (offset handled by the g^-m scaling of the split)
+    const NttPlan *p;
+    RC_TRY(get_plan(c, log_n + log_blowup, &p));
+    cs::NttArgs a{};
+    a.in = nat; a.scratch = nat; a.out = h; a.width = 1; a.batch = 1; a.log_n = log_n + log_blowup;
+    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true; a.inverse = true;
+    HIP_TRY(cs::ntt_columns(a, c->stream));
+    HIP_TRY(cs::split_columns(h, d_cols, log_n, log_blowup, cs::host::inv(cs::host::generator()), c->stream));
+    return CSTARK_OK;
+}
+
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
 int cstark_hash_rows(cstark_ctx *c, const uint64_t *d_lde, uint8_t *d_leaves, uint32_t width, uint32_t log_n, uint32_t log_blowup,
                      uint32_t k0, uint32_t nk) {

@@ -27,4 +27,8 @@ hipError_t ntt_columns(const NttArgs &a, hipStream_t stream);
 // table[e] = base^e, e < n
 hipError_t ntt_power_table(uint64_t *d_table, size_t n, uint64_t base, hipStream_t stream);
 
+// composition-polynomial helpers: coset-major -> natural order; split of H's coefficients into b columns (with the g^-m scaling)
+hipError_t interleave_cosets(const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned log_b, hipStream_t stream);
+hipError_t split_columns(const uint64_t *d_h, uint64_t *d_out, unsigned log_n, unsigned log_b, uint64_t ginv, hipStream_t stream);
+
 } // namespace cs

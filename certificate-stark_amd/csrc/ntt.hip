@@ -335,6 +335,36 @@ hipError_t launch(const fp *in, fp *scratch, fp *out, unsigned width, unsigned b
 
 } // namespace
 
+// Composition-polynomial column split: h holds the N = b*n coefficients of H(g y) in y; column i of out gets
+// H_i[q] = h[b*q + i] * g^-(b*q + i)  (coefficients of H in x, H(x) = sum_i x^i H_i(x^b)).  One thread per q.
+__global__ void k_split_columns(const fp *__restrict__ h, fp *__restrict__ out, size_t n, unsigned log_b, fp ginv) {
+    const size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const unsigned b = 1u << log_b;
+    fp s = fp_pow(ginv, (uint64_t)q << log_b);
+    for (unsigned i = 0; i < b; i++) {
+        out[(size_t)i * n + q] = fp_mul(h[((size_t)q << log_b) + i], s);
+        s = fp_mul(s, ginv);
+    }
+}
+hipError_t split_columns(const fp *d_h, fp *d_out, unsigned log_n, unsigned log_b, fp ginv, hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_split_columns, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_h, d_out, n, log_b, ginv);
+    return hipGetLastError();
+}
+// natural[b*j + k] = coset_major[k*n + j]
+__global__ void k_interleave_cosets(const fp *__restrict__ in, fp *__restrict__ out, size_t n, unsigned log_b) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= (n << log_b)) return;
+    const size_t k = i & ((1u << log_b) - 1), j = i >> log_b;
+    out[i] = in[k * n + j];
+}
+hipError_t interleave_cosets(const fp *d_in, fp *d_out, unsigned log_n, unsigned log_b, hipStream_t stream) {
+    const size_t N = (size_t)1 << (log_n + log_b);
+    hipLaunchKernelGGL(k_interleave_cosets, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, d_in, d_out, (size_t)1 << log_n, log_b);
+    return hipGetLastError();
+}
+
 hipError_t ntt_power_table(fp *d_table, size_t n, fp base, hipStream_t stream) {
     const size_t threads = (n + CHUNK - 1) / CHUNK;
     hipLaunchKernelGGL(k_power_table, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d_table, n, base);

@@ -154,6 +154,12 @@ int cstark_tx_constraint_part_ms(cstark_ctx *ctx, float *ms /* [9] */);
 int cstark_tx_constraint_degree(uint32_t i, uint32_t *base, uint32_t *cycles);  /* CSTARK_AIR_STATE_TRANSITION */
 int cstark_tx_periodic_columns(uint32_t merkle_depth, uint64_t *out);
 
+/* ---- composition polynomial (engine: evaluations -> H(x) -> column split; first of the "next" rows) ----------
+ * d_combined: [b][n] combined constraint evaluations, coset-major (output of cstark_tx_evaluate_constraints with all b
+ * cosets).  d_cols: [b][n] coefficients of the column polynomials H_i, H(x) = sum_i x^i H_i(x^b); extend and commit
+ * them with cstark_lde_columns / cstark_hash_rows (width b) / cstark_merkle_build. */
+int cstark_composition_columns(cstark_ctx *ctx, const uint64_t *d_combined, uint64_t *d_cols, uint32_t log_n, uint32_t log_blowup);
+
 /* ---- standalone sub-AIRs (reference src/merkle/update, src/range; BASELINE configs 1-2) ---------- */
 /* MerkleProver::build_trace (src/merkle/update/prover.rs:28-80): 65 x (512*n_tx) from the uploaded witness. */
 int cstark_merkle_build_trace(cstark_ctx *ctx, uint64_t *d_trace);

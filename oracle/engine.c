@@ -306,3 +306,20 @@ uint64_t cso_tx_combined_at(const uint64_t *trace_coeffs, const cstark_tx_coeffs
     acc = fp_add(acc, fp_mul(first, fp_inv(fp_sub(z, FP_ONE))));
     return fp_add(acc, fp_mul(last, fp_inv(fp_sub(z, w_last))));
 }
+
+
+/* ---- composition polynomial (engine: ConstraintEvaluationTable::into_poly, CompositionPoly, build_commitment) -------
+ * [UPSTREAM-RECALL winterfell v0.3]  combined: [b][n] coset-major evaluations over g<w_{bn}> (b = ce blowup = LDE blowup).
+ * H(x) = interpolate_poly_with_offset(evaluations, g); its b*n coefficients are split into b column polynomials
+ * H(x) = sum_i x^i H_i(x^b)  (coefficient m goes to column m mod b at position m div b).
+ * out_cols: [b][n] coefficients. */
+void cso_composition_columns(const uint64_t *combined, uint64_t *out_cols, unsigned log_n, unsigned log_b) {
+    const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b, N = n * b;
+    fp *h = malloc(N * sizeof(fp));
+    for (size_t k = 0; k < b; k++) for (size_t j = 0; j < n; j++) h[b * j + k] = combined[k * n + j]; /* natural order */
+    cso_intt(h, log_n + log_b);
+    fp ginv = fp_inv(fp_from_u64(FP_GENERATOR_CAN)), s = FP_ONE;
+    for (size_t m = 0; m < N; m++) { h[m] = fp_mul(h[m], s); s = fp_mul(s, ginv); }
+    for (size_t m = 0; m < N; m++) out_cols[(m % b) * n + m / b] = h[m];
+    free(h);
+}

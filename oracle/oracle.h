@@ -72,6 +72,7 @@ void cso_tx_evaluate_transitions(const uint64_t *lde, uint64_t *out, unsigned de
 void cso_tx_evaluate_constraints(const uint64_t *lde, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4], uint64_t *out,
                                  unsigned depth, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk);
 
+void cso_composition_columns(const uint64_t *combined, uint64_t *out_cols, unsigned log_n, unsigned log_b);
 uint64_t cso_poly_eval(const uint64_t *co, size_t n, uint64_t x);
 uint64_t cso_tx_combined_at(const uint64_t *trace_coeffs, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
                             unsigned depth, unsigned log_n, unsigned log_b, uint64_t z);

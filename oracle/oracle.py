@@ -522,3 +522,12 @@ def schnorr_constraint_degrees(n_sig):
     base = np.zeros(56, np.uint32); cyc = np.zeros(56, np.uint32)
     lib().cso_schnorr_constraint_degrees(C.c_uint32(n_sig), _p(base, u32p), _p(cyc, u32p))
     return base, cyc
+
+
+def composition_columns(combined):
+    """combined [b][n] (coset-major) -> [b][n] coefficient columns H_i of H(x) = sum_i x^i H_i(x^b)."""
+    combined = _u64(combined)
+    b, n = combined.shape
+    out = np.zeros((b, n), np.uint64)
+    lib().cso_composition_columns(_p(combined), _p(out), C.c_uint(n.bit_length() - 1), C.c_uint(b.bit_length() - 1))
+    return out

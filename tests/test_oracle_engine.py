@@ -136,3 +136,23 @@ def test_degree_adjustments(oracle):
     adj = oracle.tx_degree_adjustments(log_n, log_b)
     assert int(adj[0]) == (8 * n - 1 + n - 1) - (5 * (n - 1) + 2 * (n // 1024) * 1023)
     assert int(adj[60]) == (8 * n - 1 + n - 1) - (1 * (n - 1) + (n // 1024) * 1023)
+
+
+def test_composition_columns_recombine(oracle, witness_d3):
+    """H(x) = sum_i x^i H_i(x^8): the column polynomials evaluated at z^8 recombine to the interpolant of the combined
+    evaluations at z, which (previous test) equals the constraint expression at z."""
+    w = witness_d3
+    log_b = 3
+    trace = oracle.tx_build_trace(w)
+    co = oracle.interpolate_columns(trace)
+    lde = oracle.lde_columns(co, log_b)
+    cf = oracle.make_coeffs(3)
+    pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
+    comb = oracle.tx_evaluate_constraints(lde, cf, pub, w.depth, log_b)
+    cols = oracle.composition_columns(comb)
+    z = 0x1234567890ABCDEF % P
+    zm = int(oracle.to_mont([z])[0]); z8 = int(oracle.to_mont([pow(z, 8, P)])[0])
+    acc = 0
+    for i in range(8):
+        acc = (acc + pow(z, i, P) * unmont(oracle.poly_eval(cols[i], z8))) % P
+    assert acc == unmont(oracle.tx_combined_at(co, cf, pub, w.depth, log_b, zm))
