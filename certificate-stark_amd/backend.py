@@ -232,3 +232,24 @@ class Backend:
         check(self.lib.cstark_composition_columns(self.ctx, self._ptr(combined), self._ptr(out), C.c_uint32(n.bit_length() - 1),
                                                   C.c_uint32(b.bit_length() - 1)))
         return out
+
+    # ---- out-of-domain frame + DEEP composition ----
+    def evaluate_polys_at(self, coeffs, points):
+        width, n = coeffs.shape
+        pts = _np_u64(points)
+        out = np.zeros((pts.size, width), np.uint64)
+        check(self.lib.cstark_evaluate_polys_at(self.ctx, self._ptr(coeffs), C.c_uint32(width), C.c_uint32(n.bit_length() - 1),
+                                                pts.ctypes.data_as(u64p), C.c_uint32(pts.size), out.ctypes.data_as(u64p)))
+        return out
+
+    def deep_composition(self, trace_lde, comp_lde, z, ood_trace, ood_comp, alpha, beta, delta, deg_a, deg_b, log_blowup, k0=0, out=None):
+        nk, width, n = trace_lde.shape
+        nb = comp_lde.shape[1]
+        if out is None:
+            out = self.empty_u64(nk, n)
+        arrs = [_np_u64(a) for a in (ood_trace, ood_comp, alpha, beta, delta)]
+        check(self.lib.cstark_deep_composition(self.ctx, self._ptr(trace_lde), self._ptr(comp_lde), C.c_uint32(width), C.c_uint32(nb),
+                                               C.c_uint64(int(z)), *[a.ctypes.data_as(u64p) for a in arrs], C.c_uint64(int(deg_a)),
+                                               C.c_uint64(int(deg_b)), self._ptr(out), C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup),
+                                               C.c_uint32(k0), C.c_uint32(nk)))
+        return out

@@ -11,6 +11,7 @@
 #include "air_tx_host.h"
 #include "blake3.h"
 #include "constraints.h"
+#include "deep.h"
 #include "hostfield.h"
 #include "ntt.h"
 #include "trace_gen.h"
@@ -388,6 +389,60 @@ int cstark_composition_columns(cstark_ctx *c, const uint64_t *d_combined, uint64
     a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true; a.inverse = true;
     HIP_TRY(cs::ntt_columns(a, c->stream));
     HIP_TRY(cs::split_columns(h, d_cols, log_n, log_blowup, cs::host::inv(cs::host::generator()), c->stream));
+    return CSTARK_OK;
+}
+
+// ---- out-of-domain frame and DEEP composition ("next" rows) -----------------------------------------------------------
+int cstark_evaluate_polys_at(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, uint32_t log_n, const uint64_t *points, uint32_t npts,
+                             uint64_t *out /* host [npts][width] */) {
+    if (!c || !d_coeffs || !points || !out || width == 0 || npts == 0 || npts > 16) return fail(CSTARK_ERR_INVALID_ARG, "cstark_evaluate_polys_at: bad argument");
+    if (log_n > 30) return fail(CSTARK_ERR_INVALID_ARG, "bad polynomial size");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t need = (size_t)npts * 8 + (size_t)npts * width * 8;
+    if (need > c->desc_bytes) {
+        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); }
+        HIP_TRY(hipMalloc(&c->desc_buf, need));
+        c->desc_bytes = need;
+    }
+    uint64_t *d_pts = (uint64_t *)c->desc_buf, *d_out = d_pts + npts;
+    HIP_TRY(hipMemcpyAsync(d_pts, points, (size_t)npts * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(cs::poly_eval(d_coeffs, width, log_n, d_pts, npts, d_out, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)npts * width * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return CSTARK_OK;
+}
+
+int cstark_deep_composition(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp,
+                            uint64_t z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
+                            const uint64_t *delta, uint64_t deg_a, uint64_t deg_b, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup,
+                            uint32_t k0, uint32_t nk) {
+    if (!c || !d_trace_lde || !d_comp_lde || !ood_trace || !ood_comp || !alpha || !beta || !delta || !d_out || nk == 0 || width == 0 || n_comp == 0)
+        return fail(CSTARK_ERR_INVALID_ARG, "cstark_deep_composition: bad argument");
+    if (log_n < 8 || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
+    HIP_TRY(hipSetDevice(c->device));
+    const NttPlan *plan;
+    RC_TRY(get_plan(c, log_n, &plan));
+    const size_t b = (size_t)1 << log_blowup, nco = 2 * (size_t)width + n_comp;
+    std::vector<uint64_t> blk(2 * nco + b);
+    memcpy(blk.data(), alpha, width * 8); memcpy(blk.data() + width, beta, width * 8); memcpy(blk.data() + 2 * width, delta, n_comp * 8);
+    memcpy(blk.data() + nco, ood_trace, 2 * (size_t)width * 8); memcpy(blk.data() + nco + 2 * width, ood_comp, n_comp * 8);
+    const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
+    uint64_t shift = cs::host::generator();
+    for (size_t k = 0; k < b; k++) { blk[2 * nco + k] = shift; shift = cs::host::mul(shift, wbn); }
+    const size_t bytes = blk.size() * 8;
+    if (bytes > c->desc_bytes) {
+        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); }
+        HIP_TRY(hipMalloc(&c->desc_buf, bytes));
+        c->desc_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(c->desc_buf, blk.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t *d = (const uint64_t *)c->desc_buf;
+    cs::DeepParams p{};
+    p.trace_lde = d_trace_lde; p.comp_lde = d_comp_lde; p.w = plan->w; p.coef = d; p.ood = d + nco; p.shifts = d + 2 * nco; p.out = d_out;
+    p.z = z; p.zw = cs::host::mul(z, cs::host::root_of_unity(log_n)); p.zb = cs::host::pow(z, n_comp);
+    p.deg_a = deg_a; p.deg_b = deg_b; p.width = width; p.nb = n_comp; p.log_n = log_n; p.k0 = k0;
+    HIP_TRY(cs::deep_composition(p, nk, c->stream));
     return CSTARK_OK;
 }
 

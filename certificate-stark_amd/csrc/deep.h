@@ -1,0 +1,24 @@
+// Host-visible declarations for the out-of-domain / DEEP kernels (deep.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cs {
+
+struct DeepParams {
+    const uint64_t *trace_lde, *comp_lde; // [nk][width][n], [nk][nb][n]
+    const uint64_t *w, *shifts;           // powers of w_n; g * w_{bn}^k per coset
+    const uint64_t *coef;                 // alpha[width] | beta[width] | delta[nb]        (device)
+    const uint64_t *ood;                  // T(z)[width] | T(z w)[width] | H(z^nb)[nb]      (device)
+    uint64_t *out;                        // [nk][n]
+    uint64_t z, zw, zb, deg_a, deg_b;
+    uint32_t width, nb, log_n, k0;
+};
+
+// out[p * width + c] = value of coefficient column c at points[p]  (all device memory)
+hipError_t poly_eval(const uint64_t *d_coeffs, unsigned width, unsigned log_n, const uint64_t *d_points, unsigned npts, uint64_t *d_out,
+                     hipStream_t stream);
+hipError_t deep_composition(const DeepParams &p, unsigned nk, hipStream_t stream);
+
+} // namespace cs

@@ -1,0 +1,76 @@
+// Out-of-domain evaluation and DEEP composition (engine steps after the constraint commitment; "next" rows of SURVEY 8(f)).
+// [UPSTREAM-RECALL winterfell v0.3]: the OOD frame is the trace polynomials at z and z*w_n and the composition columns at
+// z^b; the DEEP composition polynomial is
+//   [ sum_c alpha_c (T_c(x) - T_c(z)) / (x - z) + beta_c (T_c(x) - T_c(z w)) / (x - z w)
+//   + sum_i delta_i (H_i(x) - H_i(z^b)) / (x - z^b) ] * (deg_a + deg_b x)
+// evaluated over the LDE domain.  One lane per LDE point; column loads are contiguous per wave (coset-major layout).
+#include "deep.h"
+#include "fp.cuh"
+
+namespace cs {
+namespace {
+
+// grid = (width, npts), block = 256: value of coefficient column blockIdx.x at points[blockIdx.y]
+__global__ __launch_bounds__(256) void k_poly_eval(const fp *__restrict__ coeffs, unsigned log_n, const fp *__restrict__ points, fp *__restrict__ out,
+                                                   unsigned width) {
+    __shared__ fp part[256];
+    const size_t n = (size_t)1 << log_n;
+    const fp z = points[blockIdx.y];
+    const fp *c = coeffs + (size_t)blockIdx.x * n;
+    const size_t chunk = n >= 256 ? n / 256 : 1, start = threadIdx.x * chunk;
+    fp acc = 0;
+    if (start < n) {
+        for (size_t m = chunk; m-- > 0;) acc = fp_add(fp_mul(acc, z), c[start + m]); // Horner over the chunk
+        acc = fp_mul(acc, fp_pow(z, start));
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] = fp_add(part[threadIdx.x], part[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)blockIdx.y * width + blockIdx.x] = part[0];
+}
+
+// grid = (n / 256, nk)
+__global__ __launch_bounds__(256) void k_deep(DeepParams p) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    const unsigned kk = blockIdx.y;
+    const fp x = fp_mul(p.shifts[p.k0 + kk], p.w[j]);
+    const fp d1 = fp_sub(x, p.z), d2 = fp_sub(x, p.zw), d3 = fp_sub(x, p.zb);
+    const fp inv = fp_inv(fp_mul(fp_mul(d1, d2), d3)); // one inversion for the three divisors
+    const fp i1 = fp_mul(inv, fp_mul(d2, d3)), i2 = fp_mul(inv, fp_mul(d1, d3)), i3 = fp_mul(inv, fp_mul(d1, d2));
+    Acc128 s1 = acc_zero(), s2 = acc_zero(), s3 = acc_zero();
+    const fp *t = p.trace_lde + (size_t)kk * p.width * n + j;
+    for (unsigned c = 0; c < p.width; c++) {
+        const fp v = t[(size_t)c * n];
+        acc_mad(s1, p.coef[c], fp_sub(v, p.ood[c]));
+        acc_mad(s2, p.coef[p.width + c], fp_sub(v, p.ood[p.width + c]));
+        if ((c & 3) == 3) { acc_fold(s1); acc_fold(s2); }
+    }
+    acc_fold(s1); acc_fold(s2);
+    const fp *h = p.comp_lde + (size_t)kk * p.nb * n + j;
+    for (unsigned i = 0; i < p.nb; i++) {
+        acc_mad(s3, p.coef[2 * p.width + i], fp_sub(h[(size_t)i * n], p.ood[2 * p.width + i]));
+        if ((i & 3) == 3) acc_fold(s3);
+    }
+    acc_fold(s3);
+    fp acc = fp_add(fp_add(fp_mul(acc_reduce(s1), i1), fp_mul(acc_reduce(s2), i2)), fp_mul(acc_reduce(s3), i3));
+    p.out[(size_t)kk * n + j] = fp_mul(acc, fp_add(p.deg_a, fp_mul(p.deg_b, x)));
+}
+
+} // namespace
+
+hipError_t poly_eval(const uint64_t *d_coeffs, unsigned width, unsigned log_n, const uint64_t *d_points, unsigned npts, uint64_t *d_out,
+                     hipStream_t stream) {
+    hipLaunchKernelGGL(k_poly_eval, dim3(width, npts), dim3(256), 0, stream, d_coeffs, log_n, d_points, d_out, width);
+    return hipGetLastError();
+}
+hipError_t deep_composition(const DeepParams &p, unsigned nk, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    hipLaunchKernelGGL(k_deep, dim3((unsigned)(n / 256), nk), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace cs

@@ -160,6 +160,18 @@ int cstark_tx_periodic_columns(uint32_t merkle_depth, uint64_t *out);
  * them with cstark_lde_columns / cstark_hash_rows (width b) / cstark_merkle_build. */
 int cstark_composition_columns(cstark_ctx *ctx, const uint64_t *d_combined, uint64_t *d_cols, uint32_t log_n, uint32_t log_blowup);
 
+/* Out-of-domain frame: values of `width` coefficient columns (device) at up to 16 points (host); out[p][c] on the host. */
+int cstark_evaluate_polys_at(cstark_ctx *ctx, const uint64_t *d_coeffs, uint32_t width, uint32_t log_n, const uint64_t *points,
+                             uint32_t npts, uint64_t *out);
+/* DEEP composition over LDE cosets [k0,k0+nk):
+ *   d_out[(k-k0)*n + j] = [ sum_c alpha_c (T_c(x)-T_c(z))/(x-z) + beta_c (T_c(x)-T_c(z w))/(x-z w)
+ *                         + sum_i delta_i (H_i(x)-H_i(z^n_comp))/(x-z^n_comp) ] * (deg_a + deg_b x).
+ * ood_trace = T(z)[width] | T(z w)[width], ood_comp = H_i(z^n_comp); all coefficient / OOD arrays are host memory. */
+int cstark_deep_composition(cstark_ctx *ctx, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp,
+                            uint64_t z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha,
+                            const uint64_t *beta, const uint64_t *delta, uint64_t deg_a, uint64_t deg_b, uint64_t *d_out,
+                            uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+
 /* ---- standalone sub-AIRs (reference src/merkle/update, src/range; BASELINE configs 1-2) ---------- */
 /* MerkleProver::build_trace (src/merkle/update/prover.rs:28-80): 65 x (512*n_tx) from the uploaded witness. */
 int cstark_merkle_build_trace(cstark_ctx *ctx, uint64_t *d_trace);

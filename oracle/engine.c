@@ -323,3 +323,41 @@ void cso_composition_columns(const uint64_t *combined, uint64_t *out_cols, unsig
     for (size_t m = 0; m < N; m++) out_cols[(m % b) * n + m / b] = h[m];
     free(h);
 }
+
+
+/* ---- out-of-domain frame and DEEP composition (engine steps 5 of SURVEY 3.1) [UPSTREAM-RECALL winterfell v0.3] ---------
+ * DEEP(x) = [ sum_c alpha_c (T_c(x) - T_c(z)) / (x - z) + beta_c (T_c(x) - T_c(z w)) / (x - z w)
+ *           + sum_i delta_i (H_i(x) - H_i(z^b)) / (x - z^b) ] * (deg_a + deg_b x)
+ * over the LDE domain (coset-major).  trace_lde [nk][W][n], comp_lde [nk][nb][n]; ood_trace [2][W] = T(z), T(z w);
+ * ood_comp [nb] = H_i(z^nb). */
+void cso_deep_composition(const uint64_t *trace_lde, const uint64_t *comp_lde, uint32_t width, uint32_t nb, uint64_t z,
+                          const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
+                          const uint64_t *delta, uint64_t deg_a, uint64_t deg_b, uint64_t *out, unsigned log_n, unsigned log_b,
+                          uint32_t k0, uint32_t nk) {
+    const size_t n = (size_t)1 << log_n;
+    fp g = fp_from_u64(FP_GENERATOR_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
+    fp zw = fp_mul(z, wn), zb = fp_pow(z, nb);
+#pragma omp parallel for schedule(static) collapse(2)
+    for (uint32_t k = k0; k < k0 + nk; k++)
+        for (size_t j = 0; j < n; j++) {
+            fp x = fp_mul(fp_mul(g, fp_pow(wbn, k)), fp_pow(wn, j));
+            fp i1 = fp_inv(fp_sub(x, z)), i2 = fp_inv(fp_sub(x, zw)), i3 = fp_inv(fp_sub(x, zb));
+            fp s1 = 0, s2 = 0, s3 = 0;
+            for (uint32_t c = 0; c < width; c++) {
+                fp t = trace_lde[((size_t)(k - k0) * width + c) * n + j];
+                s1 = fp_add(s1, fp_mul(alpha[c], fp_sub(t, ood_trace[c])));
+                s2 = fp_add(s2, fp_mul(beta[c], fp_sub(t, ood_trace[width + c])));
+            }
+            for (uint32_t i = 0; i < nb; i++)
+                s3 = fp_add(s3, fp_mul(delta[i], fp_sub(comp_lde[((size_t)(k - k0) * nb + i) * n + j], ood_comp[i])));
+            fp acc = fp_add(fp_add(fp_mul(s1, i1), fp_mul(s2, i2)), fp_mul(s3, i3));
+            out[(size_t)(k - k0) * n + j] = fp_mul(acc, fp_add(deg_a, fp_mul(deg_b, x)));
+        }
+}
+/* values of `width` coefficient columns at `npts` points: out[p][c] */
+void cso_evaluate_polys_at(const uint64_t *coeffs, uint32_t width, unsigned log_n, const uint64_t *points, uint32_t npts, uint64_t *out) {
+    const size_t n = (size_t)1 << log_n;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (uint32_t p = 0; p < npts; p++)
+        for (uint32_t c = 0; c < width; c++) out[(size_t)p * width + c] = cso_poly_eval(coeffs + (size_t)c * n, n, points[p]);
+}

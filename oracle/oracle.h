@@ -73,6 +73,11 @@ void cso_tx_evaluate_constraints(const uint64_t *lde, const cstark_tx_coeffs *cf
                                  unsigned depth, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk);
 
 void cso_composition_columns(const uint64_t *combined, uint64_t *out_cols, unsigned log_n, unsigned log_b);
+void cso_deep_composition(const uint64_t *trace_lde, const uint64_t *comp_lde, uint32_t width, uint32_t nb, uint64_t z,
+                          const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
+                          const uint64_t *delta, uint64_t deg_a, uint64_t deg_b, uint64_t *out, unsigned log_n, unsigned log_b,
+                          uint32_t k0, uint32_t nk);
+void cso_evaluate_polys_at(const uint64_t *coeffs, uint32_t width, unsigned log_n, const uint64_t *points, uint32_t npts, uint64_t *out);
 uint64_t cso_poly_eval(const uint64_t *co, size_t n, uint64_t x);
 uint64_t cso_tx_combined_at(const uint64_t *trace_coeffs, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
                             unsigned depth, unsigned log_n, unsigned log_b, uint64_t z);

@@ -531,3 +531,22 @@ def composition_columns(combined):
     out = np.zeros((b, n), np.uint64)
     lib().cso_composition_columns(_p(combined), _p(out), C.c_uint(n.bit_length() - 1), C.c_uint(b.bit_length() - 1))
     return out
+
+
+def evaluate_polys_at(coeffs, points):
+    coeffs, points = _u64(coeffs), _u64(points)
+    width, n = coeffs.shape
+    out = np.zeros((points.size, width), np.uint64)
+    lib().cso_evaluate_polys_at(_p(coeffs), C.c_uint32(width), C.c_uint(n.bit_length() - 1), _p(points), C.c_uint32(points.size), _p(out))
+    return out
+
+
+def deep_composition(trace_lde, comp_lde, z, ood_trace, ood_comp, alpha, beta, delta, deg_a, deg_b, log_b, k0=0):
+    trace_lde, comp_lde = _u64(trace_lde), _u64(comp_lde)
+    nk, width, n = trace_lde.shape
+    nb = comp_lde.shape[1]
+    out = np.zeros((nk, n), np.uint64)
+    lib().cso_deep_composition(_p(trace_lde), _p(comp_lde), C.c_uint32(width), C.c_uint32(nb), C.c_uint64(z), _p(_u64(ood_trace)),
+                               _p(_u64(ood_comp)), _p(_u64(alpha)), _p(_u64(beta)), _p(_u64(delta)), C.c_uint64(deg_a), C.c_uint64(deg_b),
+                               _p(out), C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_uint32(k0), C.c_uint32(nk))
+    return out

@@ -44,3 +44,35 @@ def test_composition_columns_and_commitment(oracle, backend, log_n):
         x8 = int(oracle.to_mont([pow(x, 8, P)])[0])
         acc = sum(pow(x, c, P) * int(oracle.from_mont([oracle.poly_eval(ref_cols[c], x8)])[0]) for c in range(8)) % P
         assert acc == int(oracle.from_mont(comb[k, j:j + 1])[0])
+
+
+def test_ood_frame_and_deep_composition(oracle, backend):
+    """OOD evaluation and DEEP composition against the oracle on a real trace (2 transfers), plus the low-degree property."""
+    from certificate_stark_amd.backend import to_numpy_u64
+    w = oracle.TxWitness.generate(2, 3, seed=606)
+    trace = oracle.tx_build_trace(w)
+    n = trace.shape[1]; log_n, log_b = n.bit_length() - 1, 3
+    co = oracle.interpolate_columns(trace)
+    lde = oracle.lde_columns(co, log_b)
+    cf = oracle.make_coeffs(3)
+    pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
+    cols = oracle.composition_columns(oracle.tx_evaluate_constraints(lde, cf, pub, w.depth, log_b))
+    comp_lde = oracle.lde_columns(cols, log_b)
+    z = int(oracle.to_mont([0x0FEDCBA987654321 % P])[0])
+    zw = int(oracle.fp_mul(np.array([z], np.uint64), np.array([oracle.root_of_unity(log_n)], np.uint64))[0])
+    z8 = int(oracle.fp_pow(np.array([z], np.uint64), 8)[0])
+    d_co, d_cols = backend.from_numpy_u64(co), backend.from_numpy_u64(cols)
+    ood_t = backend.evaluate_polys_at(d_co, [z, zw])
+    ood_c = backend.evaluate_polys_at(d_cols, [z8])[0]
+    assert (ood_t == oracle.evaluate_polys_at(co, [z, zw])).all()
+    assert (ood_c == oracle.evaluate_polys_at(cols, [z8])[0]).all()
+    al, be, de = oracle.random_elements(94, 1), oracle.random_elements(94, 2), oracle.random_elements(8, 3)
+    da, db = (int(v) for v in oracle.random_elements(2, 4))
+    ref = oracle.deep_composition(lde, comp_lde, z, ood_t, ood_c, al, be, de, da, db, log_b)
+    d_lde, d_clde = backend.from_numpy_u64(lde), backend.from_numpy_u64(comp_lde)
+    got = to_numpy_u64(backend.deep_composition(d_lde, d_clde, z, ood_t, ood_c, al, be, de, da, db, log_b))
+    assert (got == ref).all()
+    part = to_numpy_u64(backend.deep_composition(d_lde[4:6].contiguous(), d_clde[4:6].contiguous(), z, ood_t, ood_c, al, be, de, da, db, log_b, k0=4))
+    assert (part == ref[4:6]).all()
+    nat = np.ascontiguousarray(got.T).ravel()
+    assert not oracle.ntt(nat, inverse=True)[n:].any()        # degree < n: what FRI will test

@@ -156,3 +156,33 @@ def test_composition_columns_recombine(oracle, witness_d3):
     for i in range(8):
         acc = (acc + pow(z, i, P) * unmont(oracle.poly_eval(cols[i], z8))) % P
     assert acc == unmont(oracle.tx_combined_at(co, cf, pub, w.depth, log_b, zm))
+
+
+def test_deep_composition_is_low_degree(oracle, witness_d3):
+    """The DEEP composition polynomial has degree < n when the out-of-domain frame is consistent, i.e. its 8n evaluations
+    interpolate to a polynomial whose coefficients n.. vanish; with a wrong OOD value they do not (this is what FRI tests)."""
+    w = witness_d3
+    log_b = 3
+    trace = oracle.tx_build_trace(w)
+    n = trace.shape[1]; log_n = n.bit_length() - 1
+    co = oracle.interpolate_columns(trace)
+    lde = oracle.lde_columns(co, log_b)
+    cf = oracle.make_coeffs(3)
+    pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
+    cols = oracle.composition_columns(oracle.tx_evaluate_constraints(lde, cf, pub, w.depth, log_b))
+    comp_lde = oracle.lde_columns(cols, log_b)
+    z = int(oracle.to_mont([0x1234567890ABCDEF % P])[0])
+    zw = int(oracle.fp_mul(np.array([z], np.uint64), np.array([oracle.root_of_unity(log_n)], np.uint64))[0])
+    z8 = int(oracle.fp_pow(np.array([z], np.uint64), 8)[0])
+    ood_t = oracle.evaluate_polys_at(co, [z, zw])
+    ood_c = oracle.evaluate_polys_at(cols, [z8])[0]
+    al, be, de = oracle.random_elements(94, 1), oracle.random_elements(94, 2), oracle.random_elements(8, 3)
+    da, db = (int(v) for v in oracle.random_elements(2, 4))
+
+    def high_coeffs(ood_trace):
+        deep = oracle.deep_composition(lde, comp_lde, z, ood_trace, ood_c, al, be, de, da, db, log_b)
+        nat = np.ascontiguousarray(deep.T).ravel()
+        return oracle.ntt(nat, inverse=True)[n:]
+    assert not high_coeffs(ood_t).any()
+    bad = ood_t.copy(); bad[1, 17] = oracle.fp_add(bad[1, 17:18], oracle.to_mont([1]))[0]
+    assert high_coeffs(bad).any()
