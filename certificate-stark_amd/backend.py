@@ -253,3 +253,27 @@ class Backend:
                                                C.c_uint64(int(deg_b)), self._ptr(out), C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup),
                                                C.c_uint32(k0), C.c_uint32(nk)))
         return out
+
+    # ---- FRI ----
+    def interleave_cosets(self, coset_major):
+        b, n = coset_major.shape
+        out = self.empty_u64(b * n)
+        check(self.lib.cstark_interleave_cosets(self.ctx, self._ptr(coset_major), self._ptr(out), C.c_uint32(n.bit_length() - 1),
+                                                C.c_uint32(b.bit_length() - 1)))
+        return out
+
+    def fri_fold4(self, evals, offset, alpha):
+        N = evals.numel()
+        out = self.empty_u64(N // 4)
+        check(self.lib.cstark_fri_fold4(self.ctx, self._ptr(evals), self._ptr(out), C.c_uint32(N.bit_length() - 1), C.c_uint64(int(offset)),
+                                        C.c_uint64(int(alpha))))
+        return out
+
+    def fri_commit_layer(self, evals):
+        """Merkle tree over the rows { e[i + t N/4] } of a layer; returns the node array (nodes[1] = root)."""
+        N = evals.numel()
+        q = N // 4
+        nodes = torch.zeros((2 * q, 32), dtype=torch.uint8, device=self.device)
+        self.hash_rows(evals.view(1, 4, q), 0, leaves=nodes[q:])
+        self.merkle_build(nodes)
+        return nodes

@@ -446,6 +446,25 @@ int cstark_deep_composition(cstark_ctx *c, const uint64_t *d_trace_lde, const ui
     return CSTARK_OK;
 }
 
+// ---- FRI: natural-order view of coset-major evaluations and one folding step ("next" rows) ---------------------------
+int cstark_interleave_cosets(cstark_ctx *c, const uint64_t *d_coset_major, uint64_t *d_natural, uint32_t log_n, uint32_t log_blowup) {
+    if (!c || !d_coset_major || !d_natural || d_coset_major == d_natural) return fail(CSTARK_ERR_INVALID_ARG, "cstark_interleave_cosets: bad argument");
+    if (log_n + log_blowup > 30 || log_blowup > 6) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::interleave_cosets(d_coset_major, d_natural, log_n, log_blowup, c->stream));
+    return CSTARK_OK;
+}
+int cstark_fri_fold4(cstark_ctx *c, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, uint64_t alpha) {
+    if (!c || !d_evals || !d_out || d_evals == d_out) return fail(CSTARK_ERR_INVALID_ARG, "cstark_fri_fold4: bad argument");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "layer size must be 2^6 .. 2^24");
+    if (domain_offset == 0 || domain_offset >= cs::host::P || alpha >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "offset / alpha must be field elements");
+    HIP_TRY(hipSetDevice(c->device));
+    const NttPlan *p;
+    RC_TRY(get_plan(c, log_n, &p));
+    HIP_TRY(cs::fri_fold4(d_evals, d_out, log_n, p->winv, cs::host::inv(domain_offset), alpha, cs::host::inv(cs::host::from_u64(4)), c->stream));
+    return CSTARK_OK;
+}
+
 // ---- K4 / K5 ---------------------------------------------------------------------------------------
 int cstark_hash_rows(cstark_ctx *c, const uint64_t *d_lde, uint8_t *d_leaves, uint32_t width, uint32_t log_n, uint32_t log_blowup,
                      uint32_t k0, uint32_t nk) {

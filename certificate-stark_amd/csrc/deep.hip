@@ -60,7 +60,32 @@ __global__ __launch_bounds__(256) void k_deep(DeepParams p) {
     p.out[(size_t)kk * n + j] = fp_mul(acc, fp_add(p.deg_a, fp_mul(p.deg_b, x)));
 }
 
+// FRI layer folding, factor 4 [UPSTREAM-RECALL winterfell-fri apply_drp]: row i = { f(x_i zeta^t) } = evals[i + t N/4];
+// the cubic through the four points evaluated at alpha:  (1/4) sum_k (alpha / x_i)^k sum_t v_t zeta^(-t k).
+// winv = powers of w_N^-1 (x_i^-1 = offset^-1 * winv[i]); zeta^-1 = winv[N/4] is a primitive 4th root: zeta^-2 = -1.
+__global__ __launch_bounds__(256) void k_fri_fold4(const fp *__restrict__ evals, fp *__restrict__ out, size_t q, const fp *__restrict__ winv,
+                                                   fp offset_inv, fp alpha, fp inv4) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i >= q) return;
+    const fp v0 = evals[i], v1 = evals[i + q], v2 = evals[i + 2 * q], v3 = evals[i + 3 * q];
+    const fp zi = winv[q]; // zeta^-1
+    // size-4 inverse DFT: s_k = sum_t v_t zeta^(-t k)
+    const fp a = fp_add(v0, v2), b = fp_sub(v0, v2), c = fp_add(v1, v3), d = fp_mul(fp_sub(v1, v3), zi);
+    const fp s0 = fp_add(a, c), s2 = fp_sub(a, c), s1 = fp_add(b, d), s3 = fp_sub(b, d);
+    const fp r = fp_mul(alpha, fp_mul(offset_inv, winv[i]));
+    const fp r2 = fp_sqr(r), r3 = fp_mul(r2, r);
+    fp acc = fp_add(fp_add(s0, fp_mul(r, s1)), fp_add(fp_mul(r2, s2), fp_mul(r3, s3)));
+    out[i] = fp_mul(acc, inv4);
+}
+
 } // namespace
+
+hipError_t fri_fold4(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, const uint64_t *d_winv, uint64_t offset_inv, uint64_t alpha,
+                     uint64_t inv4, hipStream_t stream) {
+    const size_t q = ((size_t)1 << log_n) / 4;
+    hipLaunchKernelGGL(k_fri_fold4, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, alpha, inv4);
+    return hipGetLastError();
+}
 
 hipError_t poly_eval(const uint64_t *d_coeffs, unsigned width, unsigned log_n, const uint64_t *d_points, unsigned npts, uint64_t *d_out,
                      hipStream_t stream) {

@@ -172,6 +172,14 @@ int cstark_deep_composition(cstark_ctx *ctx, const uint64_t *d_trace_lde, const 
                             const uint64_t *beta, const uint64_t *delta, uint64_t deg_a, uint64_t deg_b, uint64_t *d_out,
                             uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 
+/* FRI (folding factor 4).  cstark_interleave_cosets: [b][n] coset-major -> natural LDE order (i = b*j + k).
+ * cstark_fri_fold4: N = 2^log_n evaluations over domain_offset * <w_N> (natural order) -> N/4 evaluations of the
+ * alpha-folded polynomial over domain_offset^4 * <w_{N/4}>.  A layer is committed by viewing its N evaluations as the
+ * 4 x (N/4) column-major table of rows { e[i + t N/4] } and calling cstark_hash_rows (width 4, log_blowup 0) and
+ * cstark_merkle_build. */
+int cstark_interleave_cosets(cstark_ctx *ctx, const uint64_t *d_coset_major, uint64_t *d_natural, uint32_t log_n, uint32_t log_blowup);
+int cstark_fri_fold4(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, uint64_t alpha);
+
 /* ---- standalone sub-AIRs (reference src/merkle/update, src/range; BASELINE configs 1-2) ---------- */
 /* MerkleProver::build_trace (src/merkle/update/prover.rs:28-80): 65 x (512*n_tx) from the uploaded witness. */
 int cstark_merkle_build_trace(cstark_ctx *ctx, uint64_t *d_trace);

@@ -361,3 +361,26 @@ void cso_evaluate_polys_at(const uint64_t *coeffs, uint32_t width, unsigned log_
     for (uint32_t p = 0; p < npts; p++)
         for (uint32_t c = 0; c < width; c++) out[(size_t)p * width + c] = cso_poly_eval(coeffs + (size_t)c * n, n, points[p]);
 }
+
+
+/* ---- FRI layer folding (folding factor 4) [UPSTREAM-RECALL winterfell-fri v0.3 apply_drp] --------------------------------
+ * evals: N evaluations of f over offset * <w_N> in natural order.  Output: N/4 evaluations over offset^4 * <w_{N/4}> of
+ * f'(y) = sum_k alpha^k f_k(y) where f(x) = sum_k x^k f_k(x^4): row i = { evals[i + t N/4] } are f at x_i zeta^t
+ * (zeta = w_N^(N/4)), the degree-3 polynomial through them is evaluated at alpha. */
+void cso_fri_fold4(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, uint64_t alpha) {
+    const size_t N = (size_t)1 << log_n, Q = N / 4;
+    fp w = fp_root_of_unity(log_n), zeta_inv = fp_inv(fp_pow(w, Q)), inv4 = fp_inv(fp_from_u64(4));
+    fp winv = fp_inv(w), oinv = fp_inv(offset);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < Q; i++) {
+        fp xinv = fp_mul(oinv, fp_pow(winv, i));      /* 1 / x_i */
+        fp r = fp_mul(alpha, xinv), rk = FP_ONE, acc = 0; /* (alpha / x)^k */
+        for (int k = 0; k < 4; k++) {
+            fp zk = fp_pow(zeta_inv, k), zt = FP_ONE, s = 0; /* sum_t v_t zeta^(-t k) */
+            for (int t = 0; t < 4; t++) { s = fp_add(s, fp_mul(evals[i + t * Q], zt)); zt = fp_mul(zt, zk); }
+            acc = fp_add(acc, fp_mul(rk, s));
+            rk = fp_mul(rk, r);
+        }
+        out[i] = fp_mul(acc, inv4);
+    }
+}

@@ -550,3 +550,10 @@ def deep_composition(trace_lde, comp_lde, z, ood_trace, ood_comp, alpha, beta, d
                                _p(_u64(ood_comp)), _p(_u64(alpha)), _p(_u64(beta)), _p(_u64(delta)), C.c_uint64(deg_a), C.c_uint64(deg_b),
                                _p(out), C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_uint32(k0), C.c_uint32(nk))
     return out
+
+
+def fri_fold4(evals, offset, alpha):
+    evals = _u64(evals)
+    out = np.zeros(evals.size // 4, np.uint64)
+    lib().cso_fri_fold4(_p(evals), _p(out), C.c_uint(evals.size.bit_length() - 1), C.c_uint64(offset), C.c_uint64(alpha))
+    return out

@@ -76,3 +76,35 @@ def test_ood_frame_and_deep_composition(oracle, backend):
     assert (part == ref[4:6]).all()
     nat = np.ascontiguousarray(got.T).ravel()
     assert not oracle.ntt(nat, inverse=True)[n:].any()        # degree < n: what FRI will test
+
+
+def test_fri_layers(oracle, backend):
+    """FRI commit phase on the GPU: natural-order view, layer commitments and folding by 4 down to the remainder, against
+    the oracle; a low-degree input stays low-degree through every layer."""
+    from certificate_stark_amd.backend import to_numpy_u64
+    rng = np.random.default_rng(9)
+    log_n, log_b = 10, 3
+    n = 1 << log_n
+    co = np.zeros((1, n), np.uint64); co[0] = oracle.to_mont(rng.integers(0, P, size=n, dtype=np.uint64))
+    deep_cm = oracle.lde_columns(co, log_b)[:, 0, :]                       # [8][n] coset-major evaluations of a degree < n polynomial
+    d_nat = backend.interleave_cosets(backend.from_numpy_u64(deep_cm))
+    nat = np.ascontiguousarray(deep_cm.T).ravel()
+    assert (to_numpy_u64(d_nat) == nat).all()
+    offset = oracle.generator()
+    layer, d_layer, N = nat, d_nat, nat.size
+    alphas = oracle.random_elements(8, 77)
+    li = 0
+    while N > 256:                                                         # fri_max_remainder = 256 (src/lib.rs:85)
+        q = N // 4
+        ref_nodes = oracle.merkle_build(oracle.hash_rows(layer.reshape(1, 4, q), 0))
+        nodes = backend.fri_commit_layer(d_layer)
+        assert (nodes.cpu().numpy() == ref_nodes).all()
+        alpha = int(alphas[li]); li += 1
+        nxt = oracle.fri_fold4(layer, offset, alpha)
+        d_nxt = backend.fri_fold4(d_layer, offset, alpha)
+        assert (to_numpy_u64(d_nxt) == nxt).all()
+        layer, d_layer, N = nxt, d_nxt, q
+        offset = int(oracle.fp_pow(np.array([offset], np.uint64), 4)[0])
+        # degree bound shrinks with the domain: blowup stays 8
+        assert not oracle.ntt(layer, inverse=True)[N // 8:].any()
+    assert N == 128 and li == 3

@@ -186,3 +186,26 @@ def test_deep_composition_is_low_degree(oracle, witness_d3):
     assert not high_coeffs(ood_t).any()
     bad = ood_t.copy(); bad[1, 17] = oracle.fp_add(bad[1, 17:18], oracle.to_mont([1]))[0]
     assert high_coeffs(bad).any()
+
+
+def test_fri_fold4(oracle):
+    """Folding by 4 maps evaluations of f = sum_k x^k f_k(x^4) over g<w_N> to evaluations of sum_k alpha^k f_k(y) over
+    g^4<w_{N/4}>; in particular degree < d becomes degree < d/4."""
+    rng = np.random.default_rng(8)
+    log_n, d = 10, 256
+    N = 1 << log_n
+    coeffs = np.zeros(N, np.uint64); coeffs[:d] = oracle.to_mont(rng.integers(0, P, size=d, dtype=np.uint64))
+    g = oracle.generator()
+    ev = oracle.lde_columns(coeffs.reshape(1, N), 0, offset=g)[0, 0]            # f over g<w_N>, natural order
+    alpha = int(oracle.to_mont([987654321987654321 % P])[0])
+    folded = oracle.fri_fold4(ev, g, alpha)
+    # direct: g'(y) = sum_k alpha^k f_k(y), f_k = coefficients k, k+4, ...
+    fk = coeffs.reshape(N // 4, 4).T.copy()                                     # [4][N/4]
+    ak = [int(oracle.fp_pow(np.array([alpha], np.uint64), k)[0]) for k in range(4)]
+    gco = np.zeros(N // 4, np.uint64)
+    for k in range(4):
+        gco = oracle.fp_add(gco, oracle.fp_mul(fk[k], np.full(N // 4, ak[k], np.uint64)))
+    g4 = int(oracle.fp_pow(np.array([g], np.uint64), 4)[0])
+    direct = oracle.lde_columns(gco.reshape(1, N // 4), 0, offset=g4)[0, 0]
+    assert (folded == direct).all()
+    assert not gco[d // 4:].any()
