@@ -277,3 +277,22 @@ class Backend:
         self.hash_rows(evals.view(1, 4, q), 0, leaves=nodes[q:])
         self.merkle_build(nodes)
         return nodes
+
+    # ---- whole proof -------------------------------------------------------------------------------------------
+    def prove(self, options):
+        """cstark_tx_prove on the uploaded witness; `options` has the 7 ProofOptions attributes.  Returns proof bytes."""
+        o = _lib.OptionsStruct(options.num_queries, options.blowup_factor, options.grinding_factor, options.hash_fn,
+                               options.field_extension, options.fri_folding_factor, options.fri_max_remainder)
+        self.lib.cstark_tx_proof_size_bound.restype = C.c_size_t
+        cap = self.lib.cstark_tx_proof_size_bound(C.c_uint32(self.n_tx), C.byref(o))
+        buf = (C.c_uint8 * cap)()
+        n = C.c_size_t(0)
+        check(self.lib.cstark_tx_prove(self.ctx, C.byref(o), buf, C.c_size_t(cap), C.byref(n)))
+        return bytes(memoryview(buf)[:n.value])
+
+    PROVE_STAGES = ("trace", "interpolate", "lde", "commit", "constraints", "composition", "ood", "deep", "fri", "queries")
+
+    def prove_stage_ms(self):
+        ms = (C.c_float * len(self.PROVE_STAGES))()
+        check(self.lib.cstark_prove_stage_ms(self.ctx, ms))
+        return dict(zip(self.PROVE_STAGES, [float(v) for v in ms]))

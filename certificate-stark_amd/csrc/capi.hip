@@ -10,76 +10,19 @@
 #include "../../include/cstark.h"
 #include "air_tx_host.h"
 #include "blake3.h"
+#include "ctx.h"
 #include "constraints.h"
 #include "deep.h"
 #include "hostfield.h"
 #include "ntt.h"
 #include "trace_gen.h"
 
-namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char *fmt, const char *detail = "") {
-    snprintf(g_err, sizeof g_err, fmt, detail);
-    return code;
-}
-#define HIP_TRY(expr)                                                                                                              \
-    do {                                                                                                                           \
-        hipError_t e_ = (expr);                                                                                                    \
-        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? CSTARK_ERR_OOM : CSTARK_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
-    } while (0)
-#define RC_TRY(expr)            \
-    do {                        \
-        int rc_ = (expr);       \
-        if (rc_) return rc_;    \
-    } while (0)
-
-struct NttPlan {
-    unsigned log_n;
-    uint64_t *w, *winv; // [n] each: powers of w_n and of its inverse
-    uint64_t n_inv;
-};
-struct CosetTable {
-    unsigned log_n, log_b;
-    uint64_t offset;
-    uint64_t *s; // [b][n]: (offset * w_{bn}^k)^m
-};
-struct PeriodicTable {
-    unsigned depth, log_n, log_b;
-    uint64_t *tab;   // [b][48][1024]
-    uint64_t *coset; // [b][CE_COSET_CONSTS]
-    uint64_t *binv;  // [b][2][n] inverses of the boundary divisors
-    int air = 0;     // cstark_air_id the table belongs to
-};
-
-} // namespace
-
-struct cstark_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t side = nullptr; // internal second stream (forked from / joined into `stream`)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // uploaded witness
-    void *wit_buf = nullptr;
-    size_t wit_bytes = 0;
-    cs::TxWitnessDev wit{};
-    // cached tables (deque: references stay valid as entries are added) and workspace
-    std::deque<NttPlan> plans;
-    std::deque<CosetTable> cosets;
-    std::deque<PeriodicTable> periodic;
-    uint64_t *coef_buf = nullptr; // device copy of the composition coefficients
-    std::deque<PeriodicTable> small_periodic; // standalone sub-AIRs: keyed by (air, depth, log_n, log_b); coset/binv unused
-    void *desc_buf = nullptr;     // device copy of a generic AIR description (cstark_air_combine)
-    hipEvent_t part_ev[cs::CE_NUM_PARTS + 1] = {}; // optional per-launch timing of the fused constraint evaluation
-    bool part_timing = false, part_valid = false;
-    uint64_t *tail_buf = nullptr; // standalone SchnorrAir: message[26..28] per signature
-    std::vector<uint64_t> schnorr_rx; // host copy of the signatures' R.x ([n][6]) for the sequence assertions
-    size_t tail_bytes = 0;
-    size_t desc_bytes = 0;
-    void *ws = nullptr;
-    size_t ws_bytes = 0;
-};
+namespace cs { thread_local char g_err[512] = ""; }
+using cs::fail;
+using cs::NttPlan;
+using cs::CosetTable;
+using cs::PeriodicTable;
+using cs::g_err;
 
 namespace {
 
@@ -272,6 +215,7 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     for (PeriodicTable &t : c->small_periodic) (void)hipFree(t.tab);
     if (c->desc_buf) (void)hipFree(c->desc_buf);
     if (c->tail_buf) (void)hipFree(c->tail_buf);
+    if (c->arena) cs::prove_arena_free(c->arena);
     for (hipEvent_t e : c->part_ev) if (e) (void)hipEventDestroy(e);
     delete c;
 }

@@ -1,0 +1,410 @@
+// Whole-proof orchestrator: cstark_tx_prove = TransactionExample::prove (/root/reference/src/lib.rs:116-141), i.e.
+// TransactionProver::build_trace followed by the engine's Prover::prove, as one C call.  Every stage runs on the GPU through
+// the stage entry points of capi.hip; the host side here is only the Fiat-Shamir channel (a few hundred BLAKE3 calls), the
+// FRI layer loop, and the serialisation of the openings.
+//
+// Protocol [UPSTREAM-RECALL winterfell v0.3, parity unpinned -- the engine is absent from the reference tree]:
+//   coin      seed = H(context || public inputs); reseed(d) = H(seed || d); reseed_int(v) = H(seed || v_le64);
+//             draw: counter += 1, H(seed || counter_le64), first 8 bytes LE as integer, rejected unless < p
+//   order     trace root -> 115+4 coefficient pairs -> constraint root -> z -> H(T(z) || T(z w)), H(H_i(z^b)) ->
+//             DEEP coefficients (alpha, beta, gamma per register; one per composition column; two for the degree
+//             adjustment) -> per FRI layer: root, alpha -> H(remainder) -> proof-of-work nonce -> query positions
+//   FRI       folding factor 4, layers while the domain exceeds fri_max_remainder; layer rows are the 4 evaluations
+//             { e[i + t N/4] } that fold into position i
+// The byte layout of the proof is this library's own (documented in include/cstark.h); the tests check it with a restated verifier.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <algorithm>
+#include <new>
+#include <vector>
+#include "../../include/cstark.h"
+#include "ctx.h"
+#include "hostblake3.h"
+#include "hostfield.h"
+
+namespace cs {
+
+enum { PROVE_EVENTS = CSTARK_PROVE_NUM_STAGES + 1 };
+
+struct ProveArena {
+    unsigned log_n = 0, log_b = 0;
+    uint64_t *trace = nullptr, *coeffs = nullptr, *lde = nullptr, *combined = nullptr, *ccoef = nullptr, *clde = nullptr, *deep = nullptr;
+    uint8_t *tnodes = nullptr, *cnodes = nullptr;
+    std::vector<uint64_t *> layer;   // FRI layer evaluations (layer[0] = DEEP composition in natural order), last = remainder
+    std::vector<uint8_t *> lnodes;   // FRI layer trees
+    uint32_t *d_pos = nullptr;
+    uint8_t *d_open = nullptr;
+    size_t open_bytes = 0;
+    hipEvent_t ev[PROVE_EVENTS] = {};
+    bool timed = false;
+    std::vector<void *> owned;
+};
+
+void prove_arena_free(ProveArena *a) {
+    if (!a) return;
+    for (void *p : a->owned) (void)hipFree(p);
+    for (hipEvent_t e : a->ev) if (e) (void)hipEventDestroy(e);
+    delete a;
+}
+
+namespace {
+
+struct Coin {
+    uint8_t seed[32];
+    uint64_t counter = 0;
+    void init(const uint8_t *p, size_t n) { hostb3::hash(p, n, seed); counter = 0; }
+    void reseed(const uint8_t d[32]) {
+        uint8_t buf[64];
+        memcpy(buf, seed, 32); memcpy(buf + 32, d, 32);
+        hostb3::hash(buf, 64, seed);
+        counter = 0;
+    }
+    static void with_int(const uint8_t s[32], uint64_t v, uint8_t out[32]) {
+        uint8_t buf[40];
+        memcpy(buf, s, 32);
+        for (int i = 0; i < 8; i++) buf[32 + i] = (uint8_t)(v >> (8 * i));
+        hostb3::hash(buf, 40, out);
+    }
+    void reseed_int(uint64_t v) { with_int(seed, v, seed); counter = 0; }
+    uint64_t next_u64() {
+        uint8_t out[32];
+        with_int(seed, ++counter, out);
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
+        return v;
+    }
+    uint64_t draw() { // a field element, memory form
+        for (;;) {
+            const uint64_t v = next_u64();
+            if (v < host::P) return host::from_u64(v);
+        }
+    }
+    void draw_integers(size_t count, uint64_t domain, std::vector<uint32_t> &out) {
+        out.clear();
+        while (out.size() < count) {
+            const uint32_t v = (uint32_t)(next_u64() & (domain - 1));
+            if (std::find(out.begin(), out.end(), v) == out.end()) out.push_back(v);
+        }
+    }
+};
+
+void hash_elements(const uint64_t *e, size_t n, uint8_t out[32]) { hostb3::hash((const uint8_t *)e, 8 * n, out); } // little-endian host
+
+struct Writer {
+    std::vector<uint8_t> b;
+    void raw(const void *p, size_t n) { const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); }
+    void u32(uint32_t v) { raw(&v, 4); }
+    void u64(uint64_t v) { raw(&v, 8); }
+};
+
+// positions folded into the next layer's row indices, first occurrence order
+std::vector<uint32_t> fold_positions(const std::vector<uint32_t> &pos, uint32_t rows) {
+    std::vector<uint32_t> out;
+    for (uint32_t p : pos) {
+        const uint32_t r = p & (rows - 1);
+        if (std::find(out.begin(), out.end(), r) == out.end()) out.push_back(r);
+    }
+    return out;
+}
+
+__global__ void k_gather_rows(const uint64_t *__restrict__ lde, uint32_t width, uint32_t log_n, uint32_t log_b, const uint32_t *__restrict__ pos,
+                              uint64_t *__restrict__ out) {
+    const uint32_t q = blockIdx.x, i = pos[q], k = i & ((1u << log_b) - 1), j = i >> log_b;
+    for (uint32_t c = threadIdx.x; c < width; c += blockDim.x) out[(size_t)q * width + c] = lde[(((size_t)k * width + c) << log_n) + j];
+}
+// authentication path of leaf pos[q]: siblings from the leaf level upwards
+__global__ void k_gather_paths(const uint4 *__restrict__ nodes, uint32_t log_leaves, const uint32_t *__restrict__ pos, uint4 *__restrict__ out) {
+    const uint32_t q = blockIdx.x;
+    for (uint32_t t = threadIdx.x; t < 2 * log_leaves; t += blockDim.x) {
+        const uint32_t lvl = t >> 1, half = t & 1;
+        const size_t node = ((((size_t)1 << log_leaves) + pos[q]) >> lvl) ^ 1;
+        out[((size_t)q * log_leaves + lvl) * 2 + half] = nodes[2 * node + half];
+    }
+}
+__global__ void k_gather_pub(const uint64_t *__restrict__ trace, size_t n, uint64_t *__restrict__ out) {
+    const uint32_t t = threadIdx.x;
+    if (t < 14) out[t] = trace[(size_t)(58 + (t % 7)) * n + (t < 7 ? 0 : n - 1)]; // PREV_TREE_ROOT_POS, src/prover.rs:106-129
+}
+
+template <class T>
+int dev_alloc(ProveArena *a, T **p, size_t bytes) {
+    HIP_TRY(hipMalloc((void **)p, bytes));
+    a->owned.push_back(*p);
+    return CSTARK_OK;
+}
+
+unsigned num_fri_layers(unsigned log_domain, unsigned log_max_remainder) {
+    unsigned l = 0;
+    while (log_domain > log_max_remainder) { log_domain -= 2; l++; }
+    return l;
+}
+
+int get_arena(cstark_ctx *c, unsigned log_n, unsigned log_b, unsigned n_layers, size_t nq, ProveArena **out) {
+    if (c->arena && c->arena->log_n == log_n && c->arena->log_b == log_b && c->arena->layer.size() == n_layers + 1 &&
+        c->arena->open_bytes >= nq) { *out = c->arena; return CSTARK_OK; }
+    if (c->arena) { HIP_TRY(hipStreamSynchronize(c->stream)); prove_arena_free(c->arena); c->arena = nullptr; }
+    ProveArena *a = new (std::nothrow) ProveArena();
+    if (!a) return fail(CSTARK_ERR_OOM, "host allocation failed");
+    c->arena = a; // owned by the context from here on (freed with it, also after a partial failure)
+    a->log_n = log_n; a->log_b = log_b;
+    const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b, N = n * b, W = CSTARK_TX_TRACE_WIDTH;
+    RC_TRY(dev_alloc(a, &a->trace, W * n * 8));
+    RC_TRY(dev_alloc(a, &a->coeffs, W * n * 8));
+    RC_TRY(dev_alloc(a, &a->lde, W * N * 8));
+    RC_TRY(dev_alloc(a, &a->tnodes, 2 * N * 32));
+    RC_TRY(dev_alloc(a, &a->combined, N * 8));
+    RC_TRY(dev_alloc(a, &a->ccoef, N * 8));
+    RC_TRY(dev_alloc(a, &a->clde, b * N * 8)); // [b cosets][b columns][n]
+    RC_TRY(dev_alloc(a, &a->cnodes, 2 * N * 32));
+    RC_TRY(dev_alloc(a, &a->deep, N * 8));
+    size_t sz = N;
+    for (unsigned l = 0; l <= n_layers; l++) {
+        uint64_t *e; uint8_t *t = nullptr;
+        RC_TRY(dev_alloc(a, &e, sz * 8));
+        if (l < n_layers) RC_TRY(dev_alloc(a, &t, 2 * (sz / 4) * 32));
+        a->layer.push_back(e); a->lnodes.push_back(t);
+        sz /= 4;
+    }
+    RC_TRY(dev_alloc(a, &a->d_pos, 4 * 256 * (n_layers + 2)));
+    // openings: per query a trace row + path, a constraint row + path, per layer a row of 4 + path
+    a->open_bytes = nq;
+    const size_t per_q = W * 8 + b * 8 + 2 * (log_n + log_b) * 32 + (size_t)n_layers * (32 + (log_n + log_b) * 32);
+    RC_TRY(dev_alloc(a, &a->d_open, per_q * nq + 256));
+    for (hipEvent_t &e : a->ev) HIP_TRY(hipEventCreate(&e));
+    *out = a;
+    return CSTARK_OK;
+}
+
+} // namespace
+} // namespace cs
+
+using namespace cs;
+
+extern "C" {
+
+int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_t capacity, size_t *proof_len) {
+    if (!c || !opt || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_prove: null argument");
+    if (!c->wit_buf || c->wit.n_tx == 0 || c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no transaction witness uploaded");
+    const uint32_t n_tx = c->wit.n_tx, depth = c->wit.depth;
+    if (n_tx & (n_tx - 1)) return fail(CSTARK_ERR_INVALID_ARG, "the number of transactions must be a power of two");
+    if (opt->blowup_factor != 8) return fail(CSTARK_ERR_UNSUPPORTED, "TransactionAir is proven with blowup factor 8 (src/lib.rs:78-86)");
+    if (opt->hash_fn != 0) return fail(CSTARK_ERR_UNSUPPORTED, "only Blake3_256 is implemented");
+    if (opt->field_extension != 0) return fail(CSTARK_ERR_UNSUPPORTED, "only FieldExtension::None is implemented");
+    if (opt->fri_folding_factor != 4) return fail(CSTARK_ERR_UNSUPPORTED, "only FRI folding factor 4 is implemented");
+    if (opt->num_queries == 0 || opt->num_queries > 128) return fail(CSTARK_ERR_INVALID_ARG, "num_queries must be 1..128");
+    if (opt->grinding_factor > 32) return fail(CSTARK_ERR_INVALID_ARG, "grinding_factor must be at most 32");
+    unsigned log_rem = 0;
+    while ((1u << log_rem) < opt->fri_max_remainder) log_rem++;
+    if ((1u << log_rem) != opt->fri_max_remainder || log_rem < 7 || log_rem > 10) return fail(CSTARK_ERR_INVALID_ARG, "fri_max_remainder must be a power of two in 128..1024");
+    unsigned log_n = 10;
+    while ((1u << (log_n - 10)) < n_tx) log_n++;
+    const unsigned log_b = 3, log_N = log_n + log_b;
+    if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "at most 2^21 trace rows");
+    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = CSTARK_TX_TRACE_WIDTH;
+    const unsigned n_layers = num_fri_layers(log_N, log_rem);
+    const size_t nq = opt->num_queries;
+    if (nq > N / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
+    HIP_TRY(hipSetDevice(c->device));
+    ProveArena *a;
+    RC_TRY(get_arena(c, log_n, log_b, n_layers, nq, &a));
+    hipStream_t st = c->stream;
+    int evi = 0;
+#define STAGE() HIP_TRY(hipEventRecord(a->ev[evi++], st))
+    a->timed = false;
+
+    // ---- trace, public inputs ---------------------------------------------------------------------------------------
+    STAGE();
+    RC_TRY(cstark_tx_build_trace(c, a->trace));
+    uint64_t pub[14];
+    k_gather_pub<<<1, 64, 0, st>>>(a->trace, n, (uint64_t *)a->d_open);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(pub, a->d_open, sizeof pub, hipMemcpyDeviceToHost, st));
+    STAGE();
+    // ---- trace commitment -----------------------------------------------------------------------------------------------
+    RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, (uint32_t)W, log_n));
+    STAGE();
+    RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, (uint32_t)W, log_n, log_b, host::generator(), 0, (uint32_t)b));
+    STAGE();
+    RC_TRY(cstark_hash_rows(c, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, (uint32_t)b));
+    RC_TRY(cstark_merkle_build(c, a->tnodes, log_N));
+    uint8_t trace_root[32], cons_root[32];
+    HIP_TRY(hipMemcpyAsync(trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
+    STAGE();
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // ---- channel ------------------------------------------------------------------------------------------------------------
+    Coin coin;
+    {
+        Writer s;
+        const uint8_t ctxb[2] = {(uint8_t)W, (uint8_t)log_n};
+        s.raw(ctxb, 2);
+        s.u64(host::P);
+        const uint8_t ob[7] = {(uint8_t)opt->num_queries, (uint8_t)log_b, (uint8_t)opt->grinding_factor, (uint8_t)opt->hash_fn,
+                               (uint8_t)opt->field_extension, (uint8_t)opt->fri_folding_factor, (uint8_t)log_rem};
+        s.raw(ob, 7);
+        for (int i = 0; i < 14; i++) s.u64(host::to_u64(pub[i])); // PublicInputs::write_into, src/air.rs:57-62
+        coin.init(s.b.data(), s.b.size());
+    }
+    coin.reseed(trace_root);
+    cstark_tx_coeffs cf;
+    for (int i = 0; i < CSTARK_TX_NUM_CONSTRAINTS; i++) { cf.t_alpha[i] = coin.draw(); cf.t_beta[i] = coin.draw(); }
+    for (int i = 0; i < 4; i++) { cf.b_alpha[i] = coin.draw(); cf.b_beta[i] = coin.draw(); }
+    const uint64_t pub4[4] = {pub[0], pub[1], pub[7], pub[8]}; // get_assertions, src/air.rs:175-184
+
+    // ---- constraint evaluation, composition polynomial, its commitment ----------------------------------------------
+    RC_TRY(cstark_tx_evaluate_constraints(c, a->lde, &cf, pub4, a->combined, depth, log_n, log_b, 0, (uint32_t)b));
+    STAGE();
+    RC_TRY(cstark_composition_columns(c, a->combined, a->ccoef, log_n, log_b));
+    RC_TRY(cstark_lde_columns(c, a->ccoef, a->clde, (uint32_t)b, log_n, log_b, host::generator(), 0, (uint32_t)b));
+    RC_TRY(cstark_hash_rows(c, a->clde, a->cnodes + 32 * N, (uint32_t)b, log_n, log_b, 0, (uint32_t)b));
+    RC_TRY(cstark_merkle_build(c, a->cnodes, log_N));
+    HIP_TRY(hipMemcpyAsync(cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
+    STAGE();
+    HIP_TRY(hipStreamSynchronize(st));
+    coin.reseed(cons_root);
+
+    // ---- out-of-domain frame ----------------------------------------------------------------------------------------------
+    const uint64_t z = coin.draw();
+    const uint64_t zpts[2] = {z, host::mul(z, host::root_of_unity(log_n))};
+    const uint64_t zb = host::pow(z, b);
+    std::vector<uint64_t> ood_trace(2 * W), ood_comp(b);
+    RC_TRY(cstark_evaluate_polys_at(c, a->coeffs, (uint32_t)W, log_n, zpts, 2, ood_trace.data()));
+    RC_TRY(cstark_evaluate_polys_at(c, a->ccoef, (uint32_t)b, log_n, &zb, 1, ood_comp.data()));
+    uint8_t dg[32];
+    hash_elements(ood_trace.data(), 2 * W, dg); coin.reseed(dg);
+    hash_elements(ood_comp.data(), b, dg); coin.reseed(dg);
+    STAGE();
+
+    // ---- DEEP composition -------------------------------------------------------------------------------------------------
+    std::vector<uint64_t> d_alpha(W), d_beta(W), d_delta(b);
+    for (size_t i = 0; i < W; i++) { d_alpha[i] = coin.draw(); d_beta[i] = coin.draw(); (void)coin.draw(); /* conjugate term, extension fields only */ }
+    for (size_t i = 0; i < b; i++) d_delta[i] = coin.draw();
+    const uint64_t deg_a = coin.draw(), deg_b = coin.draw();
+    RC_TRY(cstark_deep_composition(c, a->lde, a->clde, (uint32_t)W, (uint32_t)b, z, ood_trace.data(), ood_comp.data(), d_alpha.data(), d_beta.data(),
+                                   d_delta.data(), deg_a, deg_b, a->deep, log_n, log_b, 0, (uint32_t)b));
+    RC_TRY(cstark_interleave_cosets(c, a->deep, a->layer[0], log_n, log_b));
+    STAGE();
+
+    // ---- FRI commit phase -----------------------------------------------------------------------------------------------------
+    std::vector<uint8_t> layer_roots(32 * (size_t)n_layers);
+    uint64_t offset = host::generator();
+    unsigned lg = log_N;
+    for (unsigned l = 0; l < n_layers; l++) {
+        const size_t rows = (size_t)1 << (lg - 2);
+        RC_TRY(cstark_hash_rows(c, a->layer[l], a->lnodes[l] + 32 * rows, 4, lg - 2, 0, 0, 1));
+        RC_TRY(cstark_merkle_build(c, a->lnodes[l], lg - 2));
+        HIP_TRY(hipMemcpyAsync(&layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        coin.reseed(&layer_roots[32 * l]);
+        const uint64_t alpha = coin.draw();
+        RC_TRY(cstark_fri_fold4(c, a->layer[l], a->layer[l + 1], lg, offset, alpha));
+        offset = host::pow(offset, 4);
+        lg -= 2;
+    }
+    std::vector<uint64_t> remainder((size_t)1 << lg);
+    HIP_TRY(hipMemcpyAsync(remainder.data(), a->layer[n_layers], remainder.size() * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint8_t rem_commit[32];
+    hash_elements(remainder.data(), remainder.size(), rem_commit);
+    coin.reseed(rem_commit);
+    STAGE();
+
+    // ---- proof of work, query positions -------------------------------------------------------------------------------------
+    uint64_t nonce = 1;
+    for (;; nonce++) {
+        uint8_t out[32];
+        Coin::with_int(coin.seed, nonce, out);
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
+        if (opt->grinding_factor == 0 || (v & ((1ull << opt->grinding_factor) - 1)) == 0) break;
+    }
+    coin.reseed_int(nonce);
+    std::vector<uint32_t> positions;
+    coin.draw_integers(nq, N, positions);
+
+    // ---- openings: gather on the device, one copy back ----------------------------------------------------------------------
+    std::vector<std::vector<uint32_t>> lpos(n_layers);
+    {
+        std::vector<uint32_t> cur = positions;
+        unsigned g2 = log_N;
+        for (unsigned l = 0; l < n_layers; l++) { lpos[l] = fold_positions(cur, 1u << (g2 - 2)); cur = lpos[l]; g2 -= 2; }
+    }
+    std::vector<uint32_t> hpos(256 * (n_layers + 1), 0);
+    memcpy(hpos.data(), positions.data(), nq * 4);
+    for (unsigned l = 0; l < n_layers; l++) memcpy(hpos.data() + 256 * (l + 1), lpos[l].data(), lpos[l].size() * 4);
+    HIP_TRY(hipMemcpyAsync(a->d_pos, hpos.data(), hpos.size() * 4, hipMemcpyHostToDevice, st));
+    uint8_t *o = a->d_open;
+    size_t off = 0;
+    const size_t o_trows = off; off += nq * W * 8;
+    const size_t o_tpath = off; off += nq * log_N * 32;
+    const size_t o_crows = off; off += nq * b * 8;
+    const size_t o_cpath = off; off += nq * log_N * 32;
+    k_gather_rows<<<(unsigned)nq, 128, 0, st>>>(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, (uint64_t *)(o + o_trows));
+    k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->tnodes, log_N, a->d_pos, (uint4 *)(o + o_tpath));
+    k_gather_rows<<<(unsigned)nq, 64, 0, st>>>(a->clde, (uint32_t)b, log_n, log_b, a->d_pos, (uint64_t *)(o + o_crows));
+    k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->cnodes, log_N, a->d_pos, (uint4 *)(o + o_cpath));
+    std::vector<size_t> o_lrows(n_layers), o_lpath(n_layers);
+    {
+        unsigned g2 = log_N;
+        for (unsigned l = 0; l < n_layers; l++) {
+            const unsigned np = (unsigned)lpos[l].size(), lr = g2 - 2;
+            o_lrows[l] = off; off += (size_t)np * 32;
+            o_lpath[l] = off; off += (size_t)np * lr * 32;
+            k_gather_rows<<<np, 64, 0, st>>>(a->layer[l], 4, lr, 0, a->d_pos + 256 * (l + 1), (uint64_t *)(o + o_lrows[l]));
+            k_gather_paths<<<np, 64, 0, st>>>((const uint4 *)a->lnodes[l], lr, a->d_pos + 256 * (l + 1), (uint4 *)(o + o_lpath[l]));
+            g2 -= 2;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<uint8_t> open(off);
+    HIP_TRY(hipMemcpyAsync(open.data(), o, off, hipMemcpyDeviceToHost, st));
+    STAGE();
+    HIP_TRY(hipStreamSynchronize(st));
+    a->timed = true;
+#undef STAGE
+
+    // ---- serialise ----------------------------------------------------------------------------------------------------------------
+    Writer wr;
+    wr.raw("CSTK", 4); wr.u32(CSTARK_PROOF_VERSION);
+    wr.u32(CSTARK_AIR_STATE_TRANSITION); wr.u32((uint32_t)W); wr.u32(log_n); wr.u32(depth);
+    wr.u32(opt->num_queries); wr.u32(opt->blowup_factor); wr.u32(opt->grinding_factor); wr.u32(opt->hash_fn); wr.u32(opt->field_extension);
+    wr.u32(opt->fri_folding_factor); wr.u32(opt->fri_max_remainder);
+    wr.raw(trace_root, 32); wr.raw(cons_root, 32);
+    wr.u32(n_layers); wr.raw(layer_roots.data(), layer_roots.size()); wr.raw(rem_commit, 32);
+    wr.raw(ood_trace.data(), ood_trace.size() * 8); wr.raw(ood_comp.data(), ood_comp.size() * 8);
+    wr.u64(nonce);
+    wr.raw(open.data() + o_trows, nq * W * 8); wr.raw(open.data() + o_tpath, nq * log_N * 32);
+    wr.raw(open.data() + o_crows, nq * b * 8); wr.raw(open.data() + o_cpath, nq * log_N * 32);
+    {
+        unsigned g2 = log_N;
+        for (unsigned l = 0; l < n_layers; l++) {
+            const size_t np = lpos[l].size();
+            wr.u32((uint32_t)np);
+            wr.raw(open.data() + o_lrows[l], np * 32);
+            wr.raw(open.data() + o_lpath[l], np * (g2 - 2) * 32);
+            g2 -= 2;
+        }
+    }
+    wr.u32((uint32_t)remainder.size()); wr.raw(remainder.data(), remainder.size() * 8);
+    *proof_len = wr.b.size();
+    if (!proof || capacity < wr.b.size()) return fail(CSTARK_ERR_INVALID_ARG, "proof buffer too small (required size returned in *proof_len)");
+    memcpy(proof, wr.b.data(), wr.b.size());
+    return CSTARK_OK;
+}
+
+size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt) {
+    if (!opt || n_tx == 0) return 0;
+    unsigned log_N = 13;
+    while ((1u << (log_N - 13)) < n_tx) log_N++;
+    const size_t nq = opt->num_queries, layers = log_N / 2 + 1;
+    return 4096 + 32 * layers + (2 * 94 + 8) * 8 + nq * (94 * 8 + 8 * 8 + 2 * log_N * 32) + layers * (4 + nq * (32 + log_N * 32)) + 8 * (size_t)opt->fri_max_remainder;
+}
+
+int cstark_prove_stage_ms(cstark_ctx *c, float *ms /* [CSTARK_PROVE_NUM_STAGES] */) {
+    if (!c || !ms) return fail(CSTARK_ERR_INVALID_ARG, "null argument");
+    if (!c->arena || !c->arena->timed) return fail(CSTARK_ERR_INVALID_ARG, "no proof has been generated on this context");
+    for (int i = 0; i < CSTARK_PROVE_NUM_STAGES; i++) HIP_TRY(hipEventElapsedTime(&ms[i], c->arena->ev[i], c->arena->ev[i + 1]));
+    return CSTARK_OK;
+}
+
+} // extern "C"

@@ -135,3 +135,31 @@ class TransactionProver:
         n = lde.shape[2]
         return self.backend.evaluate_constraints(lde, coeffs_struct, pub_inputs4, self.depth, self.options.log_blowup, k0=k0,
                                                  out=self._buf("combined", (lde.shape[0], n)))
+
+    # -- Prover::prove as called at src/lib.rs:140 (trace generation included: the trace never leaves HBM)
+    def prove(self, tx_metadata=None):
+        """Full proof of the loaded transactions -> serialised proof bytes (layout: include/cstark.h)."""
+        if tx_metadata is not None:
+            self.load_witness(tx_metadata)
+        return self.backend.prove(self.options)
+
+
+def get_example_options():
+    """The options of get_example (src/lib.rs:75-89)."""
+    return ProofOptions(42, 8, 0, ProofOptions.BLAKE3_256, ProofOptions.EXT_NONE, 4, 256)
+
+
+class TransactionExample:
+    """src/lib.rs:92-150 without the random witness synthesis: holds options + metadata, proves on the GPU.
+    Verification is CPU work in the reference (winterfell::verify) and outside this backend; the tests use the
+    restated CPU verifier of the test suite."""
+
+    def __init__(self, options, tx_metadata, backend=None):
+        self.options, self.tx_metadata = options, tx_metadata
+        self.prover = TransactionProver(options, backend)
+
+    def prove(self):
+        return self.prover.prove(self.tx_metadata)
+
+    def pub_inputs(self):
+        return self.tx_metadata.initial_roots[0], self.tx_metadata.final_root

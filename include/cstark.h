@@ -180,6 +180,32 @@ int cstark_deep_composition(cstark_ctx *ctx, const uint64_t *d_trace_lde, const 
 int cstark_interleave_cosets(cstark_ctx *ctx, const uint64_t *d_coset_major, uint64_t *d_natural, uint32_t log_n, uint32_t log_blowup);
 int cstark_fri_fold4(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, uint64_t alpha);
 
+/* ---- whole proof (replaces TransactionExample::prove, src/lib.rs:116-141 = build_trace + Prover::prove) ------------
+ * Proves the uploaded witness (cstark_tx_witness_upload) under `opt` and writes the serialised proof to `proof`
+ * (host, `capacity` bytes; cstark_tx_proof_size_bound gives a sufficient capacity).  *proof_len receives the length; if the
+ * buffer is too small the call fails with CSTARK_ERR_INVALID_ARG and *proof_len still holds the required size.
+ * The public inputs are read from the trace as TransactionProver::get_pub_inputs does (src/prover.rs:106-129).
+ * Supported options: blowup 8, Blake3_256, FieldExtension::None, FRI folding 4, remainder 128..1024 (the reference's
+ * get_example options, src/lib.rs:78-86, qualify).
+ *
+ * Proof layout (little-endian; field elements as 8-byte memory form; this library's own format, the engine's
+ * StarkProof::to_bytes layout is not available in the reference tree):
+ *   "CSTK" u32 version | u32 air, trace_width, log2(trace_length), merkle_depth | u32 x 7 options
+ *   trace_root[32] constraint_root[32] | u32 n_layers, layer_root[n_layers][32], remainder_commitment[32]
+ *   T(z)[94] T(z w)[94] H_i(z^8)[8] | u64 pow_nonce
+ *   trace rows [q][94], paths [q][log N][32] | composition rows [q][8], paths [q][log N][32]      (q = num_queries)
+ *   per layer: u32 n_positions, rows [n_positions][4], paths [n_positions][log rows][32]
+ *   u32 remainder_len, remainder[remainder_len]
+ * Query positions are not stored: the verifier re-derives them from the channel.  Paths list siblings leaf-upwards. */
+#define CSTARK_PROOF_VERSION 1
+#define CSTARK_PROVE_NUM_STAGES 10
+int cstark_tx_prove(cstark_ctx *ctx, const cstark_options *opt, uint8_t *proof, size_t capacity, size_t *proof_len);
+size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt);
+/* Wall-clock of the stages of the last cstark_tx_prove on this context (HIP events on its stream), milliseconds:
+ * trace, interpolate, LDE, row hashes + tree, constraint evaluation, composition polynomial + commitment,
+ * out-of-domain frame, DEEP composition, FRI layers, query openings. */
+int cstark_prove_stage_ms(cstark_ctx *ctx, float *ms /* [CSTARK_PROVE_NUM_STAGES] */);
+
 /* ---- standalone sub-AIRs (reference src/merkle/update, src/range; BASELINE configs 1-2) ---------- */
 /* MerkleProver::build_trace (src/merkle/update/prover.rs:28-80): 65 x (512*n_tx) from the uploaded witness. */
 int cstark_merkle_build_trace(cstark_ctx *ctx, uint64_t *d_trace);

@@ -275,17 +275,13 @@ uint64_t cso_poly_eval(const uint64_t *co, size_t n, uint64_t x) {
     for (size_t i = n; i-- > 0;) acc = fp_add(fp_mul(acc, x), co[i]);
     return acc;
 }
-/* value of the combined constraint expression at an arbitrary point z, from the trace polynomials */
-uint64_t cso_tx_combined_at(const uint64_t *trace_coeffs, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
-                            unsigned depth, unsigned log_n, unsigned log_b, uint64_t z) {
+/* value of the combined constraint expression at an arbitrary point z from an evaluation frame (cur = T(z), next = T(z w)):
+ * what the verifier computes from the out-of-domain frame (engine: evaluate_constraints on the OOD frame) */
+uint64_t cso_tx_combined_from_frame(const uint64_t *cur, const uint64_t *next, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
+                                    unsigned depth, unsigned log_n, unsigned log_b, uint64_t z) {
     size_t n = (size_t)1 << log_n;
     fp wn = fp_root_of_unity(log_n), w_last = fp_inv(wn);
-    fp cur[94], next[94], pv[48], res[115];
-    fp zn = fp_mul(z, wn);
-    for (int c = 0; c < 94; c++) {
-        cur[c] = cso_poly_eval(trace_coeffs + (size_t)c * n, n, z);
-        next[c] = cso_poly_eval(trace_coeffs + (size_t)c * n, n, zn);
-    }
+    fp pv[48], res[115];
     fp *cols = malloc(48 * 1024 * sizeof(fp));
     cso_tx_periodic_columns(depth, cols);
     cso_interpolate_columns(cols, 48, 10);
@@ -305,6 +301,18 @@ uint64_t cso_tx_combined_at(const uint64_t *trace_coeffs, const cstark_tx_coeffs
     }
     acc = fp_add(acc, fp_mul(first, fp_inv(fp_sub(z, FP_ONE))));
     return fp_add(acc, fp_mul(last, fp_inv(fp_sub(z, w_last))));
+}
+/* the same from the trace polynomials */
+uint64_t cso_tx_combined_at(const uint64_t *trace_coeffs, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
+                            unsigned depth, unsigned log_n, unsigned log_b, uint64_t z) {
+    size_t n = (size_t)1 << log_n;
+    fp cur[94], next[94];
+    fp zn = fp_mul(z, fp_root_of_unity(log_n));
+    for (int c = 0; c < 94; c++) {
+        cur[c] = cso_poly_eval(trace_coeffs + (size_t)c * n, n, z);
+        next[c] = cso_poly_eval(trace_coeffs + (size_t)c * n, n, zn);
+    }
+    return cso_tx_combined_from_frame(cur, next, cf, pub_inputs, depth, log_n, log_b, z);
 }
 
 

@@ -80,6 +80,8 @@ void cso_deep_composition(const uint64_t *trace_lde, const uint64_t *comp_lde, u
 void cso_evaluate_polys_at(const uint64_t *coeffs, uint32_t width, unsigned log_n, const uint64_t *points, uint32_t npts, uint64_t *out);
 void cso_fri_fold4(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, uint64_t alpha);
 uint64_t cso_poly_eval(const uint64_t *co, size_t n, uint64_t x);
+uint64_t cso_tx_combined_from_frame(const uint64_t *cur, const uint64_t *next, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
+                                    unsigned depth, unsigned log_n, unsigned log_b, uint64_t z);
 uint64_t cso_tx_combined_at(const uint64_t *trace_coeffs, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
                             unsigned depth, unsigned log_n, unsigned log_b, uint64_t z);
 
