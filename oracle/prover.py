@@ -1,0 +1,112 @@
+"""CPU prover -- TEST INFRASTRUCTURE (part of oracle/; never used by the product).
+
+Restates the whole `TransactionExample::prove` pipeline (/root/reference/src/lib.rs:116-141: build_trace + the engine's
+Prover::prove [UPSTREAM-RECALL winterfell v0.3, parity unpinned]) from the oracle's stage functions and the channel of
+verifier.py, and serialises the proof in the layout of include/cstark.h.  The GPU prover must produce the same bytes."""
+import struct
+
+import numpy as np
+
+from . import oracle as O
+from . import verifier as V
+
+
+def _mont(v):
+    return V.to_mont(v)
+
+
+def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
+    nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
+    assert blowup == 8 and hash_fn == 0 and ext == 0 and folding == 4
+    log_b, b, W = 3, 8, 94
+    trace = O.tx_build_trace(w)
+    n = trace.shape[1]
+    log_n = n.bit_length() - 1
+    log_N, N = log_n + 3, n * 8
+    log_rem = max_rem.bit_length() - 1
+    pub_m = [int(trace[58 + i, 0]) for i in range(7)] + [int(trace[58 + i, n - 1]) for i in range(7)]  # src/prover.rs:106-129
+    pub = [V.from_mont(v) for v in pub_m]
+
+    coeffs = O.interpolate_columns(trace.copy())
+    lde = O.lde_columns(coeffs, log_b)
+    tnodes = O.merkle_build(O.hash_rows(lde, log_b))
+    trace_root = tnodes[1].tobytes()
+
+    seed = bytes([W, log_n]) + struct.pack("<Q", V.P) + bytes([nq, log_b, grinding, hash_fn, ext, folding, log_rem])
+    seed += b"".join(struct.pack("<Q", v) for v in pub)
+    coin = V.Coin(seed)
+    coin.reseed(trace_root)
+    cf = O.TxCoeffsStruct()
+    for i in range(115):
+        cf.t_alpha[i], cf.t_beta[i] = _mont(coin.draw()), _mont(coin.draw())
+    for i in range(4):
+        cf.b_alpha[i], cf.b_beta[i] = _mont(coin.draw()), _mont(coin.draw())
+    pub4 = np.array([pub_m[0], pub_m[1], pub_m[7], pub_m[8]], np.uint64)
+
+    combined = O.tx_evaluate_constraints(lde, cf, pub4, w.depth, log_b)
+    ccoef = O.composition_columns(combined)
+    clde = O.lde_columns(ccoef, log_b)
+    cnodes = O.merkle_build(O.hash_rows(clde, log_b))
+    cons_root = cnodes[1].tobytes()
+    coin.reseed(cons_root)
+
+    z = coin.draw()
+    zm = _mont(z)
+    zw = _mont(z * V.root_of_unity(log_n) % V.P)
+    zb = _mont(pow(z, b, V.P))
+    ood_trace = O.evaluate_polys_at(coeffs, [zm, zw])          # [2][94]
+    ood_comp = O.evaluate_polys_at(ccoef, [zb])[0]             # [8]
+    coin.reseed(O.blake3(ood_trace.tobytes()))
+    coin.reseed(O.blake3(ood_comp.tobytes()))
+    d_alpha, d_beta = [], []
+    for _ in range(W):
+        d_alpha.append(_mont(coin.draw())); d_beta.append(_mont(coin.draw())); coin.draw()
+    d_delta = [_mont(coin.draw()) for _ in range(b)]
+    deg_a, deg_b = _mont(coin.draw()), _mont(coin.draw())
+    deep = O.deep_composition(lde, clde, zm, ood_trace.reshape(-1), ood_comp, d_alpha, d_beta, d_delta, deg_a, deg_b, log_b)
+    layer = np.ascontiguousarray(deep.T).reshape(-1)            # natural order i = 8 j + k
+
+    layers, trees, roots = [], [], []
+    offset, lg = 3, log_N
+    while lg > log_rem:
+        rows = 1 << (lg - 2)
+        nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 4, rows), 0))
+        layers.append(layer); trees.append(nodes); roots.append(nodes[1].tobytes())
+        coin.reseed(roots[-1])
+        alpha = coin.draw()
+        layer = O.fri_fold4(layer, _mont(offset), _mont(alpha))
+        offset = pow(offset, 4, V.P)
+        lg -= 2
+    remainder = layer
+    rem_commit = O.blake3(remainder.tobytes())
+    coin.reseed(rem_commit)
+    nonce = 1
+    while grinding and struct.unpack("<Q", O.blake3(coin.seed + struct.pack("<Q", nonce))[:8])[0] & ((1 << grinding) - 1):
+        nonce += 1
+    coin.reseed_int(nonce)
+    positions = coin.draw_integers(nq, N)
+
+    def path(nodes, leaves_log, pos):
+        L = 1 << leaves_log
+        return b"".join(nodes[((L + pos) >> lvl) ^ 1].tobytes() for lvl in range(leaves_log))
+
+    def row(tab, pos):  # tab [b][width][n] coset-major
+        return np.ascontiguousarray(tab[pos & 7, :, pos >> 3]).tobytes()
+
+    out = [b"CSTK", struct.pack("<IIIII", 1, 0, W, log_n, w.depth), struct.pack("<7I", *options),
+           trace_root, cons_root, struct.pack("<I", len(roots))] + roots + [rem_commit, ood_trace.tobytes(), ood_comp.tobytes(),
+                                                                           struct.pack("<Q", nonce)]
+    out += [row(lde, p) for p in positions] + [path(tnodes, log_N, p) for p in positions]
+    out += [row(clde, p) for p in positions] + [path(cnodes, log_N, p) for p in positions]
+    cur, lg = positions, log_N
+    for l in range(len(layers)):
+        rows = 1 << (lg - 2)
+        fpos = V.fold_positions(cur, rows)
+        out.append(struct.pack("<I", len(fpos)))
+        tab = layers[l].reshape(4, rows)
+        out += [np.ascontiguousarray(tab[:, p]).tobytes() for p in fpos]
+        out += [path(trees[l], lg - 2, p) for p in fpos]
+        cur = fpos
+        lg -= 2
+    out += [struct.pack("<I", remainder.size), remainder.tobytes()]
+    return b"".join(out)

@@ -97,3 +97,20 @@ def test_unsupported_options_are_refused():
         tx = example(2, 3, options=opt)
         with pytest.raises(CstarkError):
             tx.prove()
+
+
+@pytest.mark.parametrize("n_tx,depth,opts", [(2, 3, (42, 8, 0, 0, 0, 4, 256)), (8, 15, (28, 8, 0, 0, 0, 4, 128)),
+                                             (4, 7, (16, 8, 8, 0, 0, 4, 1024))])
+def test_proof_bytes_equal_the_cpu_restatement(n_tx, depth, opts):
+    """Bit-exact whole-pipeline parity (trace -> LDE -> commitments -> constraints -> composition -> DEEP -> FRI -> openings),
+    including a proof-of-work nonce search (grinding 8) and the other remainder sizes."""
+    from oracle import oracle as O
+    from oracle import prover as OP
+    from oracle import verifier as V
+    from certificate_stark_amd.prover import ProofOptions, TransactionExample, TransactionMetadata
+    w = O.TxWitness.generate(n_tx, depth, seed=77 + n_tx)
+    meta = TransactionMetadata(*[getattr(w, f) for f in TransactionMetadata.FIELDS])
+    tx = TransactionExample(ProofOptions(*opts), meta)
+    proof = tx.prove()
+    assert proof == OP.prove(w, opts)
+    assert V.verify(proof, *tx.pub_inputs(), options=list(opts))
