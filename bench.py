@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X hot path for the Topos state-transition AIR (BASELINE.json north_star).
 
-One "step" = one pass of the hot path over one synthetic batch: the witness of 1024 transfers (2^20 trace rows,
-94 registers, Merkle depth 15) is already resident in HBM; the timed region is
+One "step" = one complete proof of one synthetic batch: the witness of 1024 transfers (2^20 trace rows, 94 registers,
+Merkle depth 15) is already resident in HBM; the timed region is one cstark_tx_prove call =
     K1 trace generation -> K2 interpolation -> K3 coset LDE (blowup 8) -> K4 Blake3 row hashing -> K5 Merkle tree
     -> K6 constraint evaluation (115 constraints, fused random linear combination + boundary terms)
-i.e. the region the reference times (TransactionExample::prove = build_trace + Prover::prove, src/lib.rs:116-141) up to
-and including the constraint-evaluation stage; composition/DEEP/FRI are not part of this round's hot path.
+    -> composition polynomial + commitment -> out-of-domain frame -> DEEP composition -> FRI layers -> 96 query openings
+    -> proof bytes on the host,
+i.e. exactly the region the reference times (TransactionExample::prove = build_trace + Prover::prove, src/lib.rs:116-141,
+benches/state_transition.rs:21-24).  --mode hotpath times only K1..K6 (the SURVEY 8(a) rows) stage by stage.
 
 Launch:  python bench.py --gpus N --steps K --warmup W      (N > 1: one rank per GPU via torch.distributed.run)
 Multi-GPU = independent proofs per GPU (replicas, no data-path collective): weak scaling.
@@ -42,7 +44,7 @@ def algorithmic_bytes(n, w, b):
     }
 
 
-def cpu_baseline(meta, sample_tx):
+def cpu_baseline(meta, sample_tx, full_options=None):
     """The oracle (CPU port, OpenMP) on a bounded sample of the same workload, all host cores."""
     from oracle import oracle as O
     w = O.TxWitness(sample_tx, meta.depth)
@@ -50,6 +52,16 @@ def cpu_baseline(meta, sample_tx):
         src = getattr(meta, f)
         getattr(w, f)[...] = src if f == "final_root" else src[:sample_tx]
     w.final_root[...] = meta.initial_roots[sample_tx] if sample_tx < meta.n_tx else meta.final_root
+    if full_options is not None:
+        from oracle import prover as OP
+        t0 = time.perf_counter()
+        proof = OP.prove(w, full_options)
+        total = time.perf_counter() - t0
+        return {
+            "value": round(sample_tx / meta.n_tx / total, 5), "unit": "proofs/s", "cores": O.num_threads(), "kind": "port",
+            "sample": "complete proof of %d of %d transactions (2^%d of 2^20 rows, %d proof bytes) by the OpenMP oracle prover in %.2f s, "
+                      "linearly extrapolated" % (sample_tx, meta.n_tx, (sample_tx * 1024).bit_length() - 1, len(proof), total),
+        }
     cf = O.make_coeffs(17)
     pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
     t0 = time.perf_counter()
@@ -84,9 +96,10 @@ def main():
     ap.add_argument("--with-composition", action="store_true",
                     help="also time the next stage of prove(): composition polynomial columns + their LDE + Blake3 commitment "
                          "(reported as extra_stage_ms, not part of the hot-path metric)")
-    ap.add_argument("--mode", choices=["replica", "coset"], default="replica",
-                    help="replica: independent proofs per GPU (weak scaling, no collective); "
-                         "coset: ONE proof sharded by LDE coset with RCCL all-gathers (strong scaling)")
+    ap.add_argument("--mode", choices=["prove", "hotpath", "coset"], default="prove",
+                    help="prove: complete proofs, independent per GPU (weak scaling, no collective); hotpath: K1..K6 only, "
+                         "independent per GPU; coset: the K1..K6 of ONE proof sharded by LDE coset with RCCL all-gathers (strong scaling)")
+    ap.add_argument("--queries", type=int, default=96, help="FRI queries (BASELINE.json: 96; the reference's get_example: 42)")
     args = ap.parse_args()
 
     import torch
@@ -113,9 +126,9 @@ def main():
     n = n_tx * 1024
     log_n = n.bit_length() - 1
 
-    prover = TransactionProver(ProofOptions(num_queries=96), Backend(local))
+    prover = TransactionProver(ProofOptions(num_queries=args.queries), Backend(local))
     prover.load_witness(meta)  # witness resident in HBM before the timed region
-    rng = np.random.default_rng(1234 + (rank if args.mode == "replica" else 0))  # one proof = one set of coefficients
+    rng = np.random.default_rng(1234 + (rank if args.mode != "coset" else 0))  # one proof = one set of coefficients
     cf = _lib.TxCoeffsStruct()
     for name, k in (("t_alpha", 115), ("t_beta", 115), ("b_alpha", 4), ("b_beta", 4)):
         v = rng.integers(1, P, size=k, dtype=np.uint64)
@@ -156,7 +169,22 @@ def main():
         if timed: ev[6].record()
         return ev
 
+    prove_mode = args.mode == "prove"
+    pstages = list(Backend.PROVE_STAGES)
+    pacc = {k: 0.0 for k in pstages}
+    proof_len = [0]
+
+    def step_prove(timed):
+        proof = prover.prove()
+        proof_len[0] = len(proof)
+        if timed:
+            for k, v in prover.backend.prove_stage_ms().items():
+                pacc[k] += v
+        return None
+
     def step(timed):
+        if prove_mode:
+            return step_prove(timed)
         if coset_mode:
             return step_coset(timed)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if timed else None
@@ -204,13 +232,16 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    for ev in events:
-        for i, s in enumerate(stages):
-            acc_ms[s] += ev[i].elapsed_time(ev[i + 1])
-    stage_ms = {s: acc_ms[s] / args.steps for s in stages}
+    if prove_mode:
+        stage_ms = {k: pacc[k] / args.steps for k in pstages}
+    else:
+        for ev in events:
+            for i, s in enumerate(stages):
+                acc_ms[s] += ev[i].elapsed_time(ev[i + 1])
+        stage_ms = {s: acc_ms[s] / args.steps for s in stages}
 
     extra = None
-    if args.with_composition and not coset_mode:
+    if args.with_composition and args.mode == "hotpath":
         b = prover.backend
         comb = prover._bufs["combined"]
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -241,7 +272,9 @@ def main():
         dom_ms = part_avg["rounds"]
         achieved = rounds_bytes / (dom_ms * 1e-3) / 1e9
         out = {
-            "metric": "proofs/sec, state_transition AIR @ 2^%d steps (hot path: trace gen + LDE + Blake3 commitment + constraint evaluation)" % log_n,
+            "metric": ("proofs/sec, state_transition AIR @ 2^%d steps (complete prove(): trace gen, LDE, Blake3 commitments, constraint "
+                       "evaluation, composition, DEEP, FRI, %d queries)" % (log_n, args.queries)) if prove_mode else
+                      ("proofs/sec, state_transition AIR @ 2^%d steps (hot path only: trace gen + LDE + Blake3 commitment + constraint evaluation)" % log_n),
             "value": round((1 if coset_mode else world) / (ms_per_step * 1e-3), 4),
             "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -250,11 +283,12 @@ def main():
             "dtype": "u64 (63-bit prime field, Montgomery) + u32 (Blake3)", "data": "synthetic",
             "config": {"workload": "benches/state_transition.rs full TransactionAir, %d transactions = 2^%d steps, blowup 8, "
                                    "Merkle depth %d, Blake3_256, no field extension" % (n_tx, log_n, meta.depth),
+                       "queries": args.queries, "proof_bytes": proof_len[0] or None,
                        "parallelism": ("one proof sharded by LDE coset over %d GPUs, RCCL all-gather of digests and evaluations" % world)
                        if coset_mode else ("replica x%d (independent proofs per GPU, no collective)" % world),
                        "trace": "%d x 2^%d" % (WIDTH, log_n)},
             "stage_ms": {s: round(v, 3) for s, v in stage_ms.items()},
-            "stage_gbs": {s: round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1) for s in stages},
+            "stage_gbs": {s: round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1) for s in (["interpolate", "lde", "constraints"] if prove_mode else stages)},
             "constraint_part_ms": {k: round(v, 3) for k, v in part_avg.items()},
             "roofline": {"bound": "hbm", "kernel": "k_eval_fused<0> (Rescue windows of the constraint evaluation)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -269,7 +303,8 @@ def main():
             out["extra_stage_ms"] = extra
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(meta_full, min(args.cpu_sample_tx, n_tx))
+                out["cpu_baseline"] = cpu_baseline(meta_full, min(args.cpu_sample_tx, n_tx),
+                                                   (args.queries, 8, 0, 0, 0, 4, 256) if prove_mode else None)
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

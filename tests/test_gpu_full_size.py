@@ -109,3 +109,22 @@ def test_schnorr_air_2_18(oracle, backend):
     assert (got == ref).all()
     for t in (0, 255, 511):
         assert (got[0:6, 512 * t + 511] == w.sig_rx[t]).all()
+
+
+def test_state_transition_2_20_complete_proof_verifies(oracle):
+    """BASELINE.json's headline configuration end to end: 1024 transfers, 2^20 steps, blowup 8, 96 queries -> proof bytes ->
+    restated verifier (and the reference's negative case, src/lib.rs:152-161)."""
+    import torch
+    from oracle import verifier as V
+    from certificate_stark_amd.prover import ProofOptions, TransactionExample, TransactionMetadata
+    meta = TransactionMetadata.load(os.path.join(ROOT, "tests", "golden", "witness_1024_d15.npz"))
+    tx = TransactionExample(ProofOptions(96, 8, 0, 0, 0, 4, 256), meta)
+    proof = tx.prove()
+    d = V.parse(proof)
+    assert d["log_n"] == 20 and len(d["layer_roots"]) == 8 and len(d["remainder"]) == 128  # layers 2^23 .. 2^9, SURVEY 8(f)
+    assert V.verify(proof, *tx.pub_inputs(), options=[96, 8, 0, 0, 0, 4, 256])
+    with pytest.raises(V.VerifierError):
+        V.verify(proof, meta.initial_roots[0], np.full(7, meta.final_root[0], np.uint64))
+    assert proof == tx.prove()
+    tx.prover.backend.close()
+    torch.cuda.empty_cache()
