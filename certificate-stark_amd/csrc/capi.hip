@@ -444,11 +444,12 @@ int cstark_tx_evaluate_constraints(cstark_ctx *c, const uint64_t *d_lde, const c
     if (!coeffs || !pub_inputs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null argument");
     cs::CeParams p;
     RC_TRY(ce_params(c, d_lde, d_out, merkle_depth, log_n, log_blowup, k0, nk, &p));
-    if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, sizeof(cstark_tx_coeffs)));
+    if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, sizeof(cstark_tx_coeffs) + cs::CE_RTAB_WORDS * 8));
     static_assert(sizeof(cstark_tx_coeffs) == (115 * 2 + 8) * 8, "coefficient block layout");
     HIP_TRY(hipMemcpyAsync(c->coef_buf, coeffs, sizeof(cstark_tx_coeffs), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream)); // the caller's struct may be transient
     p.coef = c->coef_buf;
+    p.rtab = c->coef_buf + sizeof(cstark_tx_coeffs) / 8;
     for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
     HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, c->part_timing ? c->part_ev : nullptr));
     c->part_valid = c->part_timing;

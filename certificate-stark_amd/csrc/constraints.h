@@ -15,6 +15,7 @@ __host__ __device__ constexpr int tx_degree_group(int i) {
 constexpr unsigned TX_GROUP_BASE[5] = {5, 4, 3, 2, 1};
 constexpr unsigned TX_GROUP_CYCLES[5] = {2, 2, 1, 1, 1};
 
+constexpr int CE_RTAB_WORDS = 5 * 2 * 4 * (14 + 64);
 constexpr int CE_COSET_CONSTS = 8; // per coset: shift, 1/(shift^n - 1), shift^adj[0..5), shift^badj
 
 struct CeParams {
@@ -24,6 +25,7 @@ struct CeParams {
     const uint64_t *coset; // [b][CE_COSET_CONSTS]
     const uint64_t *coef;  // alpha[115] | beta[115] | b_alpha[4] | b_beta[4]   (device)
     const uint64_t *binv;  // [b][2][n]: 1/(x-1), 1/(x-w^(n-1)) over the evaluation domain
+    uint64_t *rtab;        // [CE_RTAB_WORDS] scratch: per-proof folded coefficients of the Rescue windows (k_rounds_setup)
     uint64_t *out;
     uint64_t pub[4];       // initial_root[0..2], final_root[0..2]
     uint64_t w_last;       // w_n^(n-1)

@@ -403,17 +403,55 @@ __device__ __forceinline__ fp dot14(const fp *__restrict__ m, const fp (&x)[14])
     return acc_reduce(a);
 }
 
-// the five Rescue windows: {first register, result base A, flag A, result base B, flag B (-1: none)}
+// the five Rescue windows: {first register, result base A, flag A, result base B, flag B (-1: none)}; flag 3 = setup + hash
+// (window 0 writes the same result slots under both flags, so one sum serves both)
 struct RoundWindow { int8_t reg, res_a, flag_a, res_b, flag_b; };
 __constant__ RoundWindow c_windows[5] = {
-    {S_INIT, S_INIT, 0, S_INIT, 1}, {S_UPD, S_UPD - 1, 0, S_UPD, 1}, {R_INIT, R_INIT - 1, 0, R_INIT, 1}, {R_UPD, R_UPD - 2, 0, R_UPD, 1},
+    {S_INIT, S_INIT, 3, 0, -1}, {S_UPD, S_UPD - 1, 0, S_UPD, 1}, {R_INIT, R_INIT - 1, 0, R_INIT, 1}, {R_UPD, R_UPD - 2, 0, R_UPD, 1},
     {42, 42, 2, 0, -1}};
+// degree groups present among the 14 result slots of each (window, flag set); -1 = unused
+__constant__ int8_t c_window_groups[5][2][3] = {
+    {{0, 1, -1}, {-1, -1, -1}}, {{1, 2, 0}, {1, 2, 0}}, {{0, 2, -1}, {0, 2, -1}}, {{2, -1, -1}, {2, -1, -1}}, {{2, -1, -1}, {-1, -1, -1}}};
+constexpr int RT_SECTIONS = 5 * 2 * 4;                 // (window, flag set, {alpha, beta of up to 3 groups})
+constexpr int RT_U = 0, RT_A = RT_SECTIONS * 14;       // offsets into CeParams::rtab
+constexpr int RT_SIZE = RT_SECTIONS * (14 + 64);
 
-__device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f) {
-    const fp flags[3] = {f.pv(P_SETUP), f.pv(P_HASH), f.pv(P_SCHNORR_HASH)};
+// The forward half of the round gadget is linear in cube(cur): sum_i c_i (MDS cube + ark1)_i = (MDS^T c) . cube + c . ark1.
+// With c_i = alpha_i + beta_i x^adj_g(i) this is one 14-term dot product per (alpha | beta restricted to a degree group) instead of
+// one per result slot.  k_rounds_setup folds the coefficients of one proof through MDS (U) and through the round constants, whose
+// extension has period 8 in j on every coset (A[k][j & 7]).  Exact arithmetic: the merged value is unchanged.
+__global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict__ ptab, fp *__restrict__ rtab) {
+    const int sec = blockIdx.x, wdx = sec >> 3, fs = (sec >> 2) & 1, slot = sec & 3;
+    const RoundWindow w = c_windows[wdx];
+    const int res = fs ? w.res_b : w.res_a;
+    const int grp = slot ? c_window_groups[wdx][fs][slot - 1] : -2;
+    const bool used = (fs == 0 || w.flag_b >= 0) && grp != -1;
+    __shared__ fp gam[14];
+    if (threadIdx.x < 14) {
+        const int i = res + threadIdx.x;
+        gam[threadIdx.x] = !used ? 0 : slot == 0 ? coef[i] : (tx_degree_group(i) == grp ? coef[115 + i] : 0);
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 14) {
+        fp u = 0;
+        for (int i = 0; i < 14; i++) u = fp_add(u, fp_mul(gam[i], c_mds[i * 14 + t]));
+        rtab[RT_U + sec * 14 + t] = u;
+    }
+    if (t < 64) {
+        const int k = t >> 3, r = t & 7;
+        fp a = 0;
+        for (int i = 0; i < 14; i++) a = fp_add(a, fp_mul(gam[i], ptab[((size_t)k * 48 + P_ARK + i) * 1024 + r]));
+        rtab[RT_A + sec * 64 + t] = a;
+    }
+}
+
+__device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const fp *__restrict__ rtab, unsigned k, unsigned jr) {
+    const fp flags[4] = {f.pv(P_SETUP), f.pv(P_HASH), f.pv(P_SCHNORR_HASH), fp_add(f.pv(P_SETUP), f.pv(P_HASH))};
     fp ark2[14];
 #pragma unroll
     for (int j = 0; j < 14; j++) ark2[j] = f.pv(P_ARK + 14 + j);
+    const fp *atab = rtab + RT_A + k * 8 + jr;
 #pragma unroll 1
     for (int wdx = 0; wdx < 5; wdx++) {
         const RoundWindow w = c_windows[wdx];
@@ -423,21 +461,35 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f) {
             cube[j] = fp_cube(f.cur(w.reg + j));
             d[j] = fp_sub(f.next(w.reg + j), ark2[j]);
         }
+        // inverse half: cube(INV_MDS (next - ark2))_i against the coefficients of both flag sets
         Acc128 sa = acc_zero(), sb = acc_zero();
 #pragma unroll 1
         for (int i = 0; i < 14; i++) {
-            const fp s1 = fp_add(dot14(c_mds + i * 14, cube), f.pv(P_ARK + i));
             const fp s2 = fp_cube(dot14(c_inv_mds + i * 14, d));
-            const fp diff = fp_sub(s2, s1);
-            acc_mad(sa, acc.coef(w.res_a + i), diff);
-            if (w.flag_b >= 0) acc_mad(sb, acc.coef(w.res_b + i), diff);
+            acc_mad(sa, acc.coef(w.res_a + i), s2);
+            if (w.flag_b >= 0) acc_mad(sb, acc.coef(w.res_b + i), s2);
             if (i == 6) { acc_fold(sa); acc_fold(sb); }
         }
         acc_fold(sa);
         acc_fold(sb);
-        const fp fa = w.flag_a == 0 ? flags[0] : w.flag_a == 1 ? flags[1] : flags[2];
-        acc.total = fp_add(acc.total, fp_mul(fa, acc_reduce(sa)));
-        if (w.flag_b >= 0) acc.total = fp_add(acc.total, fp_mul(flags[1], acc_reduce(sb)));
+        // forward half through the folded vectors
+#pragma unroll 1
+        for (int fs = 0; fs < 2; fs++) {
+            if (fs == 1 && w.flag_b < 0) break;
+            const int sec = (wdx * 2 + fs) * 4;
+            fp fwd = fp_add(dot14(rtab + RT_U + sec * 14, cube), atab[sec * 64]);
+#pragma unroll 1
+            for (int sl = 1; sl < 4; sl++) {
+                const int g = c_window_groups[wdx][fs][sl - 1];
+                if (g < 0) break;
+                const fp v = fp_add(dot14(rtab + RT_U + (sec + sl) * 14, cube), atab[(sec + sl) * 64]);
+                fwd = fp_add(fwd, fp_mul(acc.xp[g * FNT + threadIdx.x], v));
+            }
+            const fp inv_side = acc_reduce(fs ? sb : sa);
+            const int fl = fs ? w.flag_b : w.flag_a;
+            const fp flag = fl == 0 ? flags[0] : fl == 1 ? flags[1] : fl == 2 ? flags[2] : flags[3];
+            acc.total = fp_add(acc.total, fp_mul(flag, fp_sub(inv_side, fwd)));
+        }
     }
 }
 
@@ -647,7 +699,7 @@ __global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : 2) voi
     for (int g = 0; g < 5; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
     Fused acc{p.coef, p.coef + 115, xp_lds, acc_zero(), 0, 0};
 
-    if (PART == PART_ROUNDS) fused_rounds(acc, f);
+    if (PART == PART_ROUNDS) fused_rounds(acc, f, p.rtab, p.k0 + kk, (unsigned)(j & 7));
     if (PART >= PART_DBL0 && PART <= PART_FINAL) {
         const fp scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING);
         if (PART == PART_DBL0) fused_doubling(acc, f, 0, doubling);
@@ -861,6 +913,7 @@ hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t s
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
     // part_events (optional, CE_NUM_PARTS + 1 events): recorded around every part so that callers can time each launch
+    hipLaunchKernelGGL(k_rounds_setup, dim3(RT_SECTIONS), dim3(64), 0, stream, p.coef, p.ptab, p.rtab);
 #define CS_PART(PART)                                                                    \
     if (part_events) (void)hipEventRecord(part_events[PART], stream);                    \
     hipLaunchKernelGGL(k_eval_fused<PART>, grid, block, 0, stream, p);
