@@ -33,21 +33,20 @@ __device__ __forceinline__ fp fp_sub(fp a, fp b) { return a >= b ? a - b : a + (
 __device__ __forceinline__ fp fp_neg(fp a) { return a ? FP_P - a : 0; }
 __device__ __forceinline__ fp fp_dbl(fp a) { return fp_reduce_once(a << 1); }
 
-// Montgomery product without the final conditional subtraction: result in [0, 2p) for a, b < p
-// (and in [0, 2p) as well when a < 2p and b < p).
+// Montgomery product without the final conditional subtraction: result in (0, 2p) for a < 2p, b < p.
+// Word-serial REDC with q = 2^32 - t0 (never 0): (T + q p) / 2^32 = (T >> 32) + q P1 + 1 exactly, and
+// q P1 + 1 = ~t0 * P1 + (P1 + 1), so a reduction step is one NOT folded into one v_mad_u64_u32 whose addend
+// carries the constant -- no carry bit to materialise.  (q = 2^32 when t0 = 0 merely adds p.)
 __device__ __forceinline__ uint64_t fp_mul_lazy(uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
     const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-    uint64_t t = (uint64_t)a0 * b0;
-    uint64_t u = mad_u64_u32(a1, b0, t >> 32);
-    uint32_t t0 = (uint32_t)t;
-    uint32_t m = 0u - t0;
-    uint64_t v = mad_u64_u32(m, FP_P1, u + (t0 != 0u));
-    uint64_t w = mad_u64_u32(a0, b1, (uint32_t)v);
-    uint64_t x = mad_u64_u32(a1, b1, (w >> 32) + (v >> 32));
-    uint32_t w0 = (uint32_t)w;
-    uint32_t m2 = 0u - w0;
-    return mad_u64_u32(m2, FP_P1, x + (w0 != 0u));
+    constexpr uint64_t K = (uint64_t)FP_P1 + 1;
+    const uint64_t t = (uint64_t)a0 * b0;
+    const uint64_t u = mad_u64_u32(a1, b0, (t >> 32) + K);
+    const uint64_t v = mad_u64_u32(~(uint32_t)t, FP_P1, u);        // (a * b0 + q p) / 2^32  < 2^63.6
+    const uint64_t w = mad_u64_u32(a0, b1, (uint32_t)v);
+    const uint64_t x = mad_u64_u32(a1, b1, (w >> 32) + (v >> 32) + K);
+    return mad_u64_u32(~(uint32_t)w, FP_P1, x);                     // < a1 b1 + 2^33 + p < 2p
 }
 __device__ __forceinline__ fp fp_mul(fp a, fp b) { return fp_reduce_once(fp_mul_lazy(a, b)); }
 __device__ __forceinline__ fp fp_sqr(fp a) { return fp_mul(a, a); }
@@ -121,17 +120,11 @@ __device__ __forceinline__ void acc_mad(Acc128 &acc, uint64_t a, uint64_t b) {
 __device__ __forceinline__ void acc_fold(Acc128 &acc) {
     if (acc.hi >= 2 * FP_P) acc.hi -= 2 * FP_P;
 }
-// Montgomery reduction of an accumulator < 2^127.04 to a fully reduced element
+// Montgomery reduction of an accumulator < 2p * 2^64 to a fully reduced element (same two REDC steps as fp_mul_lazy)
 __device__ __forceinline__ fp acc_reduce(const Acc128 &acc) {
-    const uint32_t t0 = (uint32_t)acc.lo, t1 = (uint32_t)(acc.lo >> 32);
-    const uint32_t m = 0u - t0;
-    // (acc + m * p) / 2^32 : the low word cancels, leaving a carry
-    const uint64_t v = mad_u64_u32(m, FP_P1, (uint64_t)t1 + (t0 != 0u)); // words 1.. of the low half
-    const uint32_t v0 = (uint32_t)v;
-    const uint32_t m2 = 0u - v0;
-    // next word: v0 + m2 = 2^32 * (v0 != 0)
-    uint64_t r = acc.hi + (v >> 32) + (v0 != 0u);
-    r = mad_u64_u32(m2, FP_P1, r); // < 2^63.6 + 2^62.04 < 2^64
+    constexpr uint64_t K = (uint64_t)FP_P1 + 1;
+    const uint64_t v = mad_u64_u32(~(uint32_t)acc.lo, FP_P1, (acc.lo >> 32) + K); // (lo + q p) / 2^32 < 2^62.1
+    uint64_t r = mad_u64_u32(~(uint32_t)v, FP_P1, acc.hi + (v >> 32) + K);        // < 2p + p + 2^33 < 2^64
     if (r >= 2 * FP_P) r -= 2 * FP_P;
     return fp_reduce_once(r);
 }

@@ -166,9 +166,15 @@ __host__ __device__ constexpr unsigned cx_brev(unsigned x, int bits) {
 }
 
 #ifndef CS_NTT_L
-#define CS_NTT_L 16
+#define CS_NTT_L 8
 #endif
 constexpr int L2 = CS_NTT_L; // columns / rows per workgroup in the v2 kernels
+// Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  With 64-byte tiles two
+// neighbouring tiles share every 128-byte line, so neighbours are given ids 8 apart: same XCD, dispatched back to back.
+// (The tile counts of the v2 sizes are multiples of 16.)
+__device__ __forceinline__ unsigned xcd_pair_tile(unsigned y) {
+    return L2 >= 16 ? y : ((y & ~15u) | ((y & 7u) << 1) | ((y >> 3) & 1u));
+}
 
 // grid = (batch, C / L2, width): batch (coset) is the fastest grid dimension so that the workgroups re-reading the
 // same coefficient tile for different cosets run close in time (the re-reads are served by L2 / Infinity Cache).
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(L2 << (LA > LB ? LA : LB)) void k_ntt_cols_v2(const
     fp *tw = smem + (size_t)A * (B + 1) * L2;  // [M] powers of w_M
     const unsigned log_c = log_n - LOGM;
     const size_t n = (size_t)1 << log_n;
-    const unsigned c0 = blockIdx.y * L2;
+    const unsigned c0 = xcd_pair_tile(blockIdx.y) * L2;
     const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
     fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
     const fp *ps = prescale ? prescale + blockIdx.x * prescale_batch_stride : nullptr;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(L2 << (LA > LB ? LA : LB)) void k_ntt_rows_v2(const
     fp *tw = smem + (size_t)L2 * A * B;  // [M]
     const unsigned log_r = log_n - LOGM;
     const size_t n = (size_t)1 << log_n;
-    const unsigned k10 = blockIdx.y * L2;
+    const unsigned k10 = xcd_pair_tile(blockIdx.y) * L2;
     const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
     fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
 
