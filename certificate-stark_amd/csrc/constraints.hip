@@ -403,6 +403,30 @@ __device__ __forceinline__ fp dot14(const fp *__restrict__ m, const fp (&x)[14])
     return acc_reduce(a);
 }
 
+// The same dot product against a row of 14 UNIFORM constants that were pre-split into three 21-bit limbs (4 dwords per
+// constant, the 4th unused).  A 32-bit half of x times a limb is < 2^53, so 14 of them accumulate in a plain 64-bit
+// v_mad_u64_u32 chain with no carry handling at all: 6 multiply-adds per term and nothing else (the carry-propagating
+// 128-bit accumulation above costs ~21 VALU instructions per term).  The six column sums are recombined once:
+//   V = sum_l 2^(21 l) (c0l + 2^32 c1l) < 14 p^2 < 2^128.
+__device__ __forceinline__ fp dot14l(const uint32_t *__restrict__ m, const fp (&x)[14]) {
+    uint64_t c00 = 0, c01 = 0, c02 = 0, c10 = 0, c11 = 0, c12 = 0;
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        const uint32_t x0 = (uint32_t)x[j], x1 = (uint32_t)(x[j] >> 32);
+        const uint32_t m0 = m[4 * j], m1 = m[4 * j + 1], m2 = m[4 * j + 2];
+        c00 = mad_u64_u32(x0, m0, c00); c01 = mad_u64_u32(x0, m1, c01); c02 = mad_u64_u32(x0, m2, c02);
+        c10 = mad_u64_u32(x1, m0, c10); c11 = mad_u64_u32(x1, m1, c11); c12 = mad_u64_u32(x1, m2, c12);
+    }
+    typedef unsigned __int128 u128;
+    const u128 v = ((u128)c00 + ((u128)c10 << 32)) + (((u128)c01 + ((u128)c11 << 32)) << 21) + (((u128)c02 + ((u128)c12 << 32)) << 42);
+    Acc128 a{(uint64_t)v, (uint64_t)(v >> 64)};
+    acc_fold(a);
+    return acc_reduce(a);
+}
+__device__ __forceinline__ void split_limbs(fp v, uint32_t *out4) {
+    out4[0] = (uint32_t)v & 0x1fffffu; out4[1] = (uint32_t)(v >> 21) & 0x1fffffu; out4[2] = (uint32_t)(v >> 42); out4[3] = 0;
+}
+
 // the five Rescue windows: {first register, result base A, flag A, result base B, flag B (-1: none)}; flag 3 = setup + hash
 // (window 0 writes the same result slots under both flags, so one sum serves both)
 struct RoundWindow { int8_t reg, res_a, flag_a, res_b, flag_b; };
@@ -413,8 +437,9 @@ __constant__ RoundWindow c_windows[5] = {
 __constant__ int8_t c_window_groups[5][2][3] = {
     {{0, 1, -1}, {-1, -1, -1}}, {{1, 2, 0}, {1, 2, 0}}, {{0, 2, -1}, {0, 2, -1}}, {{2, -1, -1}, {2, -1, -1}}, {{2, -1, -1}, {-1, -1, -1}}};
 constexpr int RT_SECTIONS = 5 * 2 * 4;                 // (window, flag set, {alpha, beta of up to 3 groups})
-constexpr int RT_U = 0, RT_A = RT_SECTIONS * 14;       // offsets into CeParams::rtab
-constexpr int RT_SIZE = RT_SECTIONS * (14 + 64);
+// CeParams::rtab (u64 words): A[sections][64] | limbs of U[sections][14] (4 dwords each) | limbs of INV_MDS[14][14]
+constexpr int RT_A = 0, RT_UL = RT_SECTIONS * 64, RT_ML = RT_UL + RT_SECTIONS * 14 * 2, RT_SIZE = RT_ML + 14 * 14 * 2;
+static_assert(RT_SIZE <= CE_RTAB_WORDS, "rtab size");
 
 // The forward half of the round gadget is linear in cube(cur): sum_i c_i (MDS cube + ark1)_i = (MDS^T c) . cube + c . ark1.
 // With c_i = alpha_i + beta_i x^adj_g(i) this is one 14-term dot product per (alpha | beta restricted to a degree group) instead of
@@ -436,8 +461,10 @@ __global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict
     if (t < 14) {
         fp u = 0;
         for (int i = 0; i < 14; i++) u = fp_add(u, fp_mul(gam[i], c_mds[i * 14 + t]));
-        rtab[RT_U + sec * 14 + t] = u;
+        split_limbs(u, (uint32_t *)(rtab + RT_UL) + (sec * 14 + t) * 4);
     }
+    if (sec == 0) // the constant matrix of the inverse half, in the same limb form
+        for (int e = t; e < 196; e += blockDim.x) split_limbs(c_inv_mds[e], (uint32_t *)(rtab + RT_ML) + e * 4);
     if (t < 64) {
         const int k = t >> 3, r = t & 7;
         fp a = 0;
@@ -452,6 +479,7 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const f
 #pragma unroll
     for (int j = 0; j < 14; j++) ark2[j] = f.pv(P_ARK + 14 + j);
     const fp *atab = rtab + RT_A + k * 8 + jr;
+    const uint32_t *ul = (const uint32_t *)(rtab + RT_UL), *ml = (const uint32_t *)(rtab + RT_ML);
 #pragma unroll 1
     for (int wdx = 0; wdx < 5; wdx++) {
         const RoundWindow w = c_windows[wdx];
@@ -465,7 +493,7 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const f
         Acc128 sa = acc_zero(), sb = acc_zero();
 #pragma unroll 1
         for (int i = 0; i < 14; i++) {
-            const fp s2 = fp_cube(dot14(c_inv_mds + i * 14, d));
+            const fp s2 = fp_cube(dot14l(ml + i * 56, d));
             acc_mad(sa, acc.coef(w.res_a + i), s2);
             if (w.flag_b >= 0) acc_mad(sb, acc.coef(w.res_b + i), s2);
             if (i == 6) { acc_fold(sa); acc_fold(sb); }
@@ -477,12 +505,12 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const f
         for (int fs = 0; fs < 2; fs++) {
             if (fs == 1 && w.flag_b < 0) break;
             const int sec = (wdx * 2 + fs) * 4;
-            fp fwd = fp_add(dot14(rtab + RT_U + sec * 14, cube), atab[sec * 64]);
+            fp fwd = fp_add(dot14l(ul + sec * 56, cube), atab[sec * 64]);
 #pragma unroll 1
             for (int sl = 1; sl < 4; sl++) {
                 const int g = c_window_groups[wdx][fs][sl - 1];
                 if (g < 0) break;
-                const fp v = fp_add(dot14(rtab + RT_U + (sec + sl) * 14, cube), atab[(sec + sl) * 64]);
+                const fp v = fp_add(dot14l(ul + (sec + sl) * 56, cube), atab[(sec + sl) * 64]);
                 fwd = fp_add(fwd, fp_mul(acc.xp[g * FNT + threadIdx.x], v));
             }
             const fp inv_side = acc_reduce(fs ? sb : sa);
