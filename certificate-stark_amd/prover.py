@@ -76,6 +76,24 @@ class TransactionMetadata:
         z = np.load(path)
         return cls(*[z[f] for f in cls.FIELDS])
 
+    @classmethod
+    def build_random(cls, num_transactions, depth=15, seed=0x5EED):
+        """Counterpart of TransactionMetadata::build_random (src/lib.rs:235-465), seeded: cstark_tx_witness_generate
+        (host code of the library; no GPU involved)."""
+        import ctypes as C
+        n, d = int(num_transactions), int(depth)
+        arrays = dict(initial_roots=np.zeros((n, 7), np.uint64), final_root=np.zeros(7, np.uint64),
+                      s_old_values=np.zeros((n, 14), np.uint64), r_old_values=np.zeros((n, 14), np.uint64),
+                      s_indices=np.zeros(n, np.uint64), r_indices=np.zeros(n, np.uint64),
+                      s_paths=np.zeros((n, d + 1, 7), np.uint64), r_paths=np.zeros((n, d + 1, 7), np.uint64),
+                      deltas=np.zeros(n, np.uint64), sig_rx=np.zeros((n, 6), np.uint64), sig_s=np.zeros((n, 32), np.uint8))
+        s = _lib.TxWitnessStruct()
+        s.n_tx, s.merkle_depth = n, d
+        for f, a in arrays.items():
+            setattr(s, f, a.ctypes.data_as(_lib.u8p if f == "sig_s" else _lib.u64p))
+        _lib.check(_lib.load().cstark_tx_witness_generate(C.byref(s), C.c_uint64(seed)))
+        return cls(*[arrays[f] for f in cls.FIELDS])
+
     def save(self, path):
         np.savez_compressed(path, **{f: getattr(self, f) for f in self.FIELDS})
 

@@ -248,6 +248,15 @@ int cstark_air_combine(cstark_ctx *ctx, int air, uint32_t n_items, const uint64_
                        const uint64_t *assertion_values, const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out,
                        uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 
+/* ---- witness synthesis (host; counterpart of TransactionMetadata::build_random, src/lib.rs:235-465, and of
+ * SchnorrExample::new + schnorr::sign, src/schnorr/mod.rs:86-141, :197-217; seeded and deterministic) -----------------
+ * cstark_tx_witness_generate fills the arrays of `w` (every pointer caller-allocated with the sizes documented on
+ * cstark_tx_witness; n_tx and merkle_depth set by the caller).  Like the reference this is CPU work outside the timed
+ * region.  Signatures are produced with integer arithmetic and small secret keys (see csrc/witness_gen.hip). */
+int cstark_tx_witness_generate(cstark_tx_witness *w, uint64_t seed);
+/* n_sig messages [n][28] (public key || 16 elements) with their signatures (R.x [n][6], s [n][32]). */
+int cstark_schnorr_witness_generate(uint32_t n_sig, uint64_t seed, uint64_t *messages, uint64_t *sig_rx, uint8_t *sig_s);
+
 /* ---- device memory helpers for callers without a HIP runtime of their own (the Rust shim) ---- */
 int cstark_malloc(cstark_ctx *ctx, size_t bytes, void **d_ptr);
 int cstark_free(cstark_ctx *ctx, void *d_ptr);

@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -100,3 +101,26 @@ def test_small_air_host_descriptions_match_oracle(oracle):
     out = np.zeros((36, 512), np.uint64)
     assert lib.cstark_schnorr_mask_columns(out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
     assert (out == oracle.schnorr_mask_columns()).all()
+
+
+@pytest.mark.parametrize("n_tx,depth,seed", [(4, 3, 7), (8, 7, 0x5EED)])
+def test_host_witness_generator_matches_oracle(oracle, n_tx, depth, seed):
+    """cstark_tx_witness_generate (product, host C++) against the oracle's generator: same arrays, and the trace built from
+    them satisfies all 115 constraints on every row (known answers 6-9 of SURVEY 8(c))."""
+    from certificate_stark_amd.prover import TransactionMetadata
+    meta = TransactionMetadata.build_random(n_tx, depth, seed)
+    w = oracle.TxWitness.generate(n_tx, depth, seed=seed)
+    for f in TransactionMetadata.FIELDS:
+        assert np.array_equal(getattr(meta, f), getattr(w, f)), f
+    assert oracle.tx_check_trace(oracle.tx_build_trace(w), n_tx, depth) == -1  # -1: no violated row
+
+
+def test_host_schnorr_witness_generator_matches_oracle(oracle):
+    lib = _lib()
+    n = 3
+    msg, rx, s = np.zeros((n, 28), np.uint64), np.zeros((n, 6), np.uint64), np.zeros((n, 32), np.uint8)
+    u64p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+    assert lib.cstark_schnorr_witness_generate(C.c_uint32(n), C.c_uint64(99), msg.ctypes.data_as(u64p), rx.ctypes.data_as(u64p),
+                                               s.ctypes.data_as(u8p)) == 0
+    w = oracle.SchnorrWitness.generate(n, seed=99)
+    assert np.array_equal(msg, w.messages) and np.array_equal(rx, w.sig_rx) and np.array_equal(s, w.sig_s)
