@@ -342,15 +342,15 @@ int cstark_evaluate_polys_at(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t w
     if (!c || !d_coeffs || !points || !out || width == 0 || npts == 0 || npts > 16) return fail(CSTARK_ERR_INVALID_ARG, "cstark_evaluate_polys_at: bad argument");
     if (log_n > 30) return fail(CSTARK_ERR_INVALID_ARG, "bad polynomial size");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t need = (size_t)npts * 8 + (size_t)npts * width * 8;
+    const size_t need = ((size_t)npts + (size_t)npts * width + cs::poly_eval_scratch_words(width, log_n, npts)) * 8;
     if (need > c->desc_bytes) {
-        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); }
+        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); c->desc_buf = nullptr; c->desc_bytes = 0; }
         HIP_TRY(hipMalloc(&c->desc_buf, need));
         c->desc_bytes = need;
     }
-    uint64_t *d_pts = (uint64_t *)c->desc_buf, *d_out = d_pts + npts;
+    uint64_t *d_pts = (uint64_t *)c->desc_buf, *d_out = d_pts + npts, *d_scr = d_out + (size_t)npts * width;
     HIP_TRY(hipMemcpyAsync(d_pts, points, (size_t)npts * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(cs::poly_eval(d_coeffs, width, log_n, d_pts, npts, d_out, c->stream));
+    HIP_TRY(cs::poly_eval(d_coeffs, width, log_n, d_pts, npts, d_out, d_scr, c->stream));
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)npts * width * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CSTARK_OK;

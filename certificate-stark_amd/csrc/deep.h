@@ -17,8 +17,10 @@ struct DeepParams {
 };
 
 // out[p * width + c] = value of coefficient column c at points[p]  (all device memory)
+// d_scratch: poly_eval_scratch_words(width, log_n, npts) words
+size_t poly_eval_scratch_words(unsigned width, unsigned log_n, unsigned npts);
 hipError_t poly_eval(const uint64_t *d_coeffs, unsigned width, unsigned log_n, const uint64_t *d_points, unsigned npts, uint64_t *d_out,
-                     hipStream_t stream);
+                     uint64_t *d_scratch, hipStream_t stream);
 hipError_t deep_composition(const DeepParams &p, unsigned nk, hipStream_t stream);
 // N = 2^log_n evaluations over offset*<w_N> (natural order) -> N/4 evaluations of the alpha-folding over offset^4*<w_{N/4}>
 hipError_t fri_fold4(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, const uint64_t *d_winv, uint64_t offset_inv, uint64_t alpha,

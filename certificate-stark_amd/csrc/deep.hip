@@ -10,26 +10,44 @@
 namespace cs {
 namespace {
 
-// grid = (width, npts), block = 256: value of coefficient column blockIdx.x at points[blockIdx.y]
-__global__ __launch_bounds__(256) void k_poly_eval(const fp *__restrict__ coeffs, unsigned log_n, const fp *__restrict__ points, fp *__restrict__ out,
-                                                   unsigned width) {
-    __shared__ fp part[256];
-    const size_t n = (size_t)1 << log_n;
-    const fp z = points[blockIdx.y];
-    const fp *c = coeffs + (size_t)blockIdx.x * n;
-    const size_t chunk = n >= 256 ? n / 256 : 1, start = threadIdx.x * chunk;
-    fp acc = 0;
-    if (start < n) {
-        for (size_t m = chunk; m-- > 0;) acc = fp_add(fp_mul(acc, z), c[start + m]); // Horner over the chunk
-        acc = fp_mul(acc, fp_pow(z, start));
+// Polynomial evaluation at a few points, two passes.  Pass 1, grid = (segments, width): a workgroup owns SEG consecutive
+// coefficients of one column, every lane reads them with stride 256 (coalesced 2 KB per wave-row) and runs one Horner chain
+// in z^256 per point; the column is read from HBM once for all points.  partial[(p * width + c) * segments + s] =
+// sum over the segment of c_m z_p^m.  Pass 2 adds the segments.
+constexpr int PE_SEG = 16384, PE_MAXPTS = 2;
+template <int NP>
+__global__ __launch_bounds__(256) void k_poly_eval_partial(const fp *__restrict__ coeffs, size_t n, const fp *__restrict__ points, fp *__restrict__ partial,
+                                                           unsigned width, unsigned seg_len) {
+    __shared__ fp part[NP][256];
+    const unsigned segs = gridDim.x, seg = blockIdx.x, col = blockIdx.y, t = threadIdx.x;
+    const fp *c = coeffs + (size_t)col * n + (size_t)seg * seg_len;
+    fp z[NP], z256[NP], acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) { z[p] = points[p]; z256[p] = fp_pow(z[p], 256); acc[p] = 0; }
+    const unsigned per = (seg_len + 255) / 256; // seg_len is a multiple of 256, or the whole (short) column
+    for (unsigned k = per; k-- > 0;) {
+        const fp v = k * 256 + t < seg_len ? c[(size_t)k * 256 + t] : 0;
+#pragma unroll
+        for (int p = 0; p < NP; p++) acc[p] = fp_add(fp_mul(acc[p], z256[p]), v);
     }
-    part[threadIdx.x] = acc;
+#pragma unroll
+    for (int p = 0; p < NP; p++) part[p][t] = fp_mul(acc[p], fp_pow(z[p], (uint64_t)seg * seg_len + t));
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) part[threadIdx.x] = fp_add(part[threadIdx.x], part[threadIdx.x + s]);
+        if ((int)t < s) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) part[p][t] = fp_add(part[p][t], part[p][t + s]);
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[(size_t)blockIdx.y * width + blockIdx.x] = part[0];
+    if (t < NP) partial[((size_t)t * width + col) * segs + seg] = part[t][0];
+}
+__global__ void k_poly_eval_sum(const fp *__restrict__ partial, fp *__restrict__ out, unsigned total, unsigned segs) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    fp a = 0;
+    for (unsigned s = 0; s < segs; s++) a = fp_add(a, partial[(size_t)i * segs + s]);
+    out[i] = a;
 }
 
 // grid = (n / 256, nk)
@@ -87,9 +105,22 @@ hipError_t fri_fold4(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, c
     return hipGetLastError();
 }
 
+size_t poly_eval_scratch_words(unsigned width, unsigned log_n, unsigned npts) {
+    const size_t n = (size_t)1 << log_n, seg = n < (size_t)PE_SEG ? n : (size_t)PE_SEG;
+    return (size_t)npts * width * (n / seg);
+}
 hipError_t poly_eval(const uint64_t *d_coeffs, unsigned width, unsigned log_n, const uint64_t *d_points, unsigned npts, uint64_t *d_out,
-                     hipStream_t stream) {
-    hipLaunchKernelGGL(k_poly_eval, dim3(width, npts), dim3(256), 0, stream, d_coeffs, log_n, d_points, d_out, width);
+                     uint64_t *d_scratch, hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    const unsigned seg_len = (unsigned)(n < (size_t)PE_SEG ? n : (size_t)PE_SEG), segs = (unsigned)(n / seg_len);
+    for (unsigned p0 = 0; p0 < npts; p0 += PE_MAXPTS) { // points in groups of two: one pass over the coefficients per group
+        const unsigned np = npts - p0 >= 2 ? 2 : 1;
+        fp *part = d_scratch + (size_t)p0 * width * segs;
+        if (np == 2) hipLaunchKernelGGL(k_poly_eval_partial<2>, dim3(segs, width), dim3(256), 0, stream, d_coeffs, n, d_points + p0, part, width, seg_len);
+        else hipLaunchKernelGGL(k_poly_eval_partial<1>, dim3(segs, width), dim3(256), 0, stream, d_coeffs, n, d_points + p0, part, width, seg_len);
+    }
+    const unsigned total = npts * width;
+    hipLaunchKernelGGL(k_poly_eval_sum, dim3((total + 255) / 256), dim3(256), 0, stream, d_scratch, d_out, total, segs);
     return hipGetLastError();
 }
 hipError_t deep_composition(const DeepParams &p, unsigned nk, hipStream_t stream) {
