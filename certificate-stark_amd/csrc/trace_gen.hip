@@ -326,19 +326,21 @@ __device__ __forceinline__ void run_point_op(int op, fp (*slot)[6], Fp2 (*prod)[
 
 __device__ __forceinline__ int bit_le(const uint8_t *bytes, int i) { return (bytes[i >> 3] >> (i & 7)) & 1; }
 
+// grid = 2 * n_tx workgroups of ONE wave: workgroup 2t is the ladder s*G of transaction t (registers 0..17), 2t+1 the ladder
+// h*P (registers 19..36).  With a single wave per workgroup the phase barriers of run_point_op cost nothing and the two
+// ladders of a transaction never wait for each other; 2 * n_tx independent waves keep every SIMD busy with two of them.
+// The last step (S += h*P, X <- X/Z) needs both ladders: k_trace_schnorr_final, below.
 template <bool STANDALONE>
-__global__ __launch_bounds__(128) void k_trace_schnorr_ec(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
-    __shared__ fp tile[64][37];
-    __shared__ fp slots[2][NSLOT][6];
-    __shared__ Fp2 prods[2][6][6];
-    __shared__ uint8_t sbytes[2][32];
-    const int t = blockIdx.x;
-    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63; // wave 0: s*G (regs 0..17), wave 1: h*P (regs 19..36)
-    fp(*slot)[6] = slots[g];
+__global__ __launch_bounds__(64) void k_trace_schnorr_ec(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    __shared__ fp tile[64][19];
+    __shared__ fp slots[NSLOT][6];
+    __shared__ Fp2 prods[6][6];
+    __shared__ uint8_t sbytes[32];
+    const int t = blockIdx.x >> 1, g = blockIdx.x & 1, lane = threadIdx.x;
+    fp(*slot)[6] = slots;
 
     // scalars: s from the signature, h from the message hash (little-endian bytes, Lsb0 bit order)
-    if (threadIdx.x < 32) sbytes[0][threadIdx.x] = w.sig_s[32 * (size_t)t + threadIdx.x];
-    else if (threadIdx.x < 64) { int b = threadIdx.x - 32; sbytes[1][b] = (uint8_t)(w.h_limbs[4 * (size_t)t + (b >> 3)] >> (8 * (b & 7))); }
+    if (lane < 32) sbytes[lane] = g == 0 ? w.sig_s[32 * (size_t)t + lane] : (uint8_t)(w.h_limbs[4 * (size_t)t + (lane >> 3)] >> (8 * (lane & 7)));
     // constant slots and the initial point (0 : 1 : 0), src/schnorr/trace.rs:22-27
     if (lane < 6) {
         slot[SX][lane] = 0;
@@ -350,36 +352,45 @@ __global__ __launch_bounds__(128) void k_trace_schnorr_ec(TxWitnessDev w, fp *__
         slot[26][lane] = fp_add(slot[SPX][lane], slot[SPY][lane]); // x2 + y2, operand of the mixed addition
     }
     __syncthreads();
-    if (lane < 18) tile[0][g * 18 + lane] = slot[lane / 6][lane % 6];
+    if (lane < 18) tile[0][lane] = slot[lane / 6][lane % 6];
     const size_t gbase = STANDALONE ? (size_t)t * MERKLE_LEN : (size_t)t * TXC + MERKLE_LEN;
 
     for (int step = 0; step < MERKLE_LEN - 1; step++) {
         if (step < SCALAR_MUL_LEN) {
             if ((step & 1) == 0) {
-                run_point_op(OP_DOUBLE, slot, prods[g], lane, true);
+                run_point_op(OP_DOUBLE, slot, prods, lane, true);
             } else {
-                const int bit = bit_le(sbytes[g], 254 - (step >> 1)); // MSB first, src/schnorr/trace.rs:79-82
-                run_point_op(OP_ADD_MIXED, slot, prods[g], lane, bit != 0);
+                const int bit = bit_le(sbytes, 254 - (step >> 1)); // MSB first, src/schnorr/trace.rs:79-82
+                if (bit) run_point_op(OP_ADD_MIXED, slot, prods, lane, true); // uniform over the wave
             }
-        } else if (step == SCALAR_MUL_LEN) {
-            // S += h*P, then X <- X / Z  (src/schnorr/trace.rs:105-119)
-            if (g == 0 && lane < 18) slot[QX + lane / 6][lane % 6] = slots[1][lane / 6][lane % 6];
-            __syncthreads();
-            run_point_op(OP_ADD_FULL, slot, prods[g], lane, g == 0);
-            if (threadIdx.x == 0) {
-                Fp6 x = fp6_mul(fp6_load(slot[SX]), fp6_inv(fp6_load(slot[SZ])));
-                fp6_store(slot[SX], x);
-            }
-            __syncthreads();
-        }
+        } // step == SCALAR_MUL_LEN: the row is a copy here; k_trace_schnorr_final rewrites registers 0..17 of it
         const int r = (step + 1) & 63;
-        if (lane < 18) tile[r][g * 18 + lane] = slot[lane / 6][lane % 6];
+        if (lane < 18) tile[r][lane] = slot[lane / 6][lane % 6];
         if (r == 63) {
             __syncthreads();
-            if (g == 0) flush_tile<36, 37>(tile, trace, n, gbase + (step + 1 - 63), 0, lane, 18);
+            flush_tile<18, 19>(tile, trace, n, gbase + (step + 1 - 63), g * 19, lane);
             __syncthreads();
         }
     }
+}
+// S += h*P, then X <- X / Z  (src/schnorr/trace.rs:105-119): last row of the Schnorr block, registers 0..17.
+// One wave per transaction; reads both ladders' results from the row before.
+template <bool STANDALONE>
+__global__ __launch_bounds__(64) void k_trace_schnorr_final(fp *__restrict__ trace, size_t n) {
+    __shared__ fp slots[NSLOT][6];
+    __shared__ Fp2 prods[6][6];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const size_t last = (STANDALONE ? (size_t)t * MERKLE_LEN : (size_t)t * TXC + MERKLE_LEN) + MERKLE_LEN - 1;
+    if (lane < 18) {
+        slots[lane / 6][lane % 6] = trace[(size_t)lane * n + last - 1];
+        slots[QX + lane / 6][lane % 6] = trace[(size_t)(19 + lane) * n + last - 1];
+    }
+    if (lane < 6) slots[SB3][lane] = c_b3[lane];
+    __syncthreads();
+    run_point_op(OP_ADD_FULL, slots, prods, lane, true);
+    if (lane == 0) fp6_store(slots[SX], fp6_mul(fp6_load(slots[SX]), fp6_inv(fp6_load(slots[SZ]))));
+    __syncthreads();
+    if (lane < 18) trace[(size_t)lane * n + last] = slots[lane / 6][lane % 6];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -455,7 +466,8 @@ hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stre
     hipLaunchKernelGGL(k_trace_merkle<false>, dim3(w.n_tx), dim3(64), 0, side, w, d_trace, n);
     if ((e = hipEventRecord(join, side)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_trace_schnorr_hash<false>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
-    hipLaunchKernelGGL(k_trace_schnorr_ec<false>, dim3(w.n_tx), dim3(128), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_ec<false>, dim3(2 * w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_final<false>, dim3(w.n_tx), dim3(64), 0, stream, d_trace, n);
     hipLaunchKernelGGL(k_trace_aux, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
     if ((e = hipStreamWaitEvent(stream, join, 0)) != hipSuccess) return e;
     return hipGetLastError();
@@ -507,7 +519,8 @@ __global__ __launch_bounds__(256) void k_schnorr_aux_columns(TxWitnessDev w, fp 
 hipError_t launch_schnorr_trace(const TxWitnessDev &w, fp *d_trace, hipStream_t stream) {
     const size_t n = (size_t)w.n_tx * MERKLE_LEN;
     hipLaunchKernelGGL(k_trace_schnorr_hash<true>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
-    hipLaunchKernelGGL(k_trace_schnorr_ec<true>, dim3(w.n_tx), dim3(128), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_ec<true>, dim3(2 * w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_final<true>, dim3(w.n_tx), dim3(64), 0, stream, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_bits, dim3(w.n_tx, 2), dim3(256), 0, stream, w, d_trace, n);
     return hipGetLastError();
 }
