@@ -48,6 +48,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise CstarkError(-2, "libcstark_hip.so is missing at %s: build it with __graft_entry__.build() "
                                   "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        # torch first: its wheel bundles its own HIP runtime, and the process must end up with ONE libamdhip64 -- if this
+        # library pulled in the system copy before torch loaded, device discovery fails later ("no HIP device visible")
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         lib.cstark_last_error.restype = C.c_char_p
         lib.cstark_version.restype = C.c_char_p
