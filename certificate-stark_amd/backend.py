@@ -296,3 +296,15 @@ class Backend:
         ms = (C.c_float * len(self.PROVE_STAGES))()
         check(self.lib.cstark_prove_stage_ms(self.ctx, ms))
         return dict(zip(self.PROVE_STAGES, [float(v) for v in ms]))
+
+    def air_prove(self, air, options, number=0):
+        """cstark_air_prove: complete proof of the uploaded witness under MerkleAir / SchnorrAir, or of `number` (memory form)
+        under RangeProofAir."""
+        o = _lib.OptionsStruct(options.num_queries, options.blowup_factor, options.grinding_factor, options.hash_fn,
+                               options.field_extension, options.fri_folding_factor, options.fri_max_remainder)
+        self.lib.cstark_tx_proof_size_bound.restype = C.c_size_t
+        cap = 2 * self.lib.cstark_tx_proof_size_bound(C.c_uint32(max(1, self.n_tx)), C.byref(o))
+        buf = (C.c_uint8 * cap)()
+        n = C.c_size_t(0)
+        check(self.lib.cstark_air_prove(self.ctx, C.c_int(air), C.byref(o), C.c_uint64(number), buf, C.c_size_t(cap), C.byref(n)))
+        return bytes(memoryview(buf)[:n.value])

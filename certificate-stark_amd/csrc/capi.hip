@@ -362,7 +362,7 @@ int cstark_deep_composition(cstark_ctx *c, const uint64_t *d_trace_lde, const ui
                             uint32_t k0, uint32_t nk) {
     if (!c || !d_trace_lde || !d_comp_lde || !ood_trace || !ood_comp || !alpha || !beta || !delta || !d_out || nk == 0 || width == 0 || n_comp == 0)
         return fail(CSTARK_ERR_INVALID_ARG, "cstark_deep_composition: bad argument");
-    if (log_n < 8 || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
     HIP_TRY(hipSetDevice(c->device));
     const NttPlan *plan;
     RC_TRY(get_plan(c, log_n, &plan));
@@ -504,6 +504,9 @@ int cstark_schnorr_witness_upload(cstark_ctx *c, uint32_t n_sig, const uint64_t 
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->wit.msg_tail = c->tail_buf;
     c->schnorr_rx.assign(sig_rx, sig_rx + (size_t)n_sig * 6);
+    c->schnorr_pub.assign(messages, messages + (size_t)n_sig * 28);
+    c->schnorr_pub.insert(c->schnorr_pub.end(), sig_rx, sig_rx + (size_t)n_sig * 6);
+    c->schnorr_s.assign(sig_s, sig_s + (size_t)n_sig * 32);
     return CSTARK_OK;
 }
 int cstark_schnorr_build_trace(cstark_ctx *c, uint64_t *d_trace) {

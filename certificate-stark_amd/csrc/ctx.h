@@ -70,6 +70,8 @@ struct cstark_ctx {
     bool part_timing = false, part_valid = false;
     uint64_t *tail_buf = nullptr; // standalone SchnorrAir: message[26..28] per signature
     std::vector<uint64_t> schnorr_rx; // host copy of the signatures' R.x ([n][6]) for the sequence assertions
+    std::vector<uint64_t> schnorr_pub; // messages [n][28] then R.x [n][6]: SchnorrAir's public inputs, for the channel seed
+    std::vector<uint8_t> schnorr_s;    // the s halves [n][32]
     size_t tail_bytes = 0;
     size_t desc_bytes = 0;
     cs::ProveArena *arena = nullptr; // device buffers of cstark_tx_prove (prove.hip)

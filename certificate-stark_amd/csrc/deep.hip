@@ -54,6 +54,7 @@ __global__ void k_poly_eval_sum(const fp *__restrict__ partial, fp *__restrict__
 __global__ __launch_bounds__(256) void k_deep(DeepParams p) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (j >= n) return;
     const unsigned kk = blockIdx.y;
     const fp x = fp_mul(p.shifts[p.k0 + kk], p.w[j]);
     const fp d1 = fp_sub(x, p.z), d2 = fp_sub(x, p.zw), d3 = fp_sub(x, p.zb);
@@ -125,7 +126,7 @@ hipError_t poly_eval(const uint64_t *d_coeffs, unsigned width, unsigned log_n, c
 }
 hipError_t deep_composition(const DeepParams &p, unsigned nk, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    hipLaunchKernelGGL(k_deep, dim3((unsigned)(n / 256), nk), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(k_deep, dim3((unsigned)((n + 255) / 256), nk), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -20,6 +20,7 @@
 #include "../../include/cstark.h"
 #include "ctx.h"
 #include "hostblake3.h"
+#include "air_tx_host.h"
 #include "hostfield.h"
 
 namespace cs {
@@ -27,8 +28,10 @@ namespace cs {
 enum { PROVE_EVENTS = CSTARK_PROVE_NUM_STAGES + 1 };
 
 struct ProveArena {
+    int air = -1;
     unsigned log_n = 0, log_b = 0;
-    uint64_t *trace = nullptr, *coeffs = nullptr, *lde = nullptr, *combined = nullptr, *ccoef = nullptr, *clde = nullptr, *deep = nullptr;
+    uint64_t *trace = nullptr, *coeffs = nullptr, *lde = nullptr, *combined = nullptr, *cegather = nullptr, *ccoef = nullptr, *clde = nullptr, *deep = nullptr;
+    std::vector<void *> extra; // per-AIR buffers (materialised transition evaluations, SchnorrAir's public columns)
     uint8_t *tnodes = nullptr, *cnodes = nullptr;
     std::vector<uint64_t *> layer;   // FRI layer evaluations (layer[0] = DEEP composition in natural order), last = remainder
     std::vector<uint8_t *> lnodes;   // FRI layer trees
@@ -139,22 +142,35 @@ unsigned num_fri_layers(unsigned log_domain, unsigned log_max_remainder) {
     return l;
 }
 
-int get_arena(cstark_ctx *c, unsigned log_n, unsigned log_b, unsigned n_layers, size_t nq, ProveArena **out) {
-    if (c->arena && c->arena->log_n == log_n && c->arena->log_b == log_b && c->arena->layer.size() == n_layers + 1 &&
+// What differs between the AIRs: how the trace is built, what goes into the channel seed, and how the combined constraint
+// evaluations are produced from the extended trace and the drawn coefficients.
+struct AirJob {
+    int air = 0;
+    uint32_t width = 0, log_n = 0, log_ce = 0, n_constraints = 0, n_assertions = 0, item = 0; // item: Merkle depth / signature count / 0
+    std::vector<uint64_t> pub;      // public-input elements (memory form), appended to the seed in canonical form
+    std::vector<uint8_t> pub_bytes; // further public material appended verbatim (Schnorr: the s halves of the signatures)
+    int (*build)(cstark_ctx *, ProveArena *, AirJob &) = nullptr;
+    int (*combine)(cstark_ctx *, ProveArena *, AirJob &, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) = nullptr;
+    uint64_t number = 0;            // RangeProofAir
+};
+
+int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned n_layers, size_t nq, ProveArena **out) {
+    if (c->arena && c->arena->air == job.air && c->arena->log_n == job.log_n && c->arena->log_b == log_b && c->arena->layer.size() == n_layers + 1 &&
         c->arena->open_bytes >= nq) { *out = c->arena; return CSTARK_OK; }
     if (c->arena) { HIP_TRY(hipStreamSynchronize(c->stream)); prove_arena_free(c->arena); c->arena = nullptr; }
     ProveArena *a = new (std::nothrow) ProveArena();
     if (!a) return fail(CSTARK_ERR_OOM, "host allocation failed");
     c->arena = a; // owned by the context from here on (freed with it, also after a partial failure)
-    a->log_n = log_n; a->log_b = log_b;
-    const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b, N = n * b, W = CSTARK_TX_TRACE_WIDTH;
+    a->air = job.air; a->log_n = job.log_n; a->log_b = log_b;
+    const size_t n = (size_t)1 << job.log_n, b = (size_t)1 << log_b, N = n * b, W = job.width, ce = (size_t)1 << job.log_ce;
     RC_TRY(dev_alloc(a, &a->trace, W * n * 8));
     RC_TRY(dev_alloc(a, &a->coeffs, W * n * 8));
     RC_TRY(dev_alloc(a, &a->lde, W * N * 8));
     RC_TRY(dev_alloc(a, &a->tnodes, 2 * N * 32));
     RC_TRY(dev_alloc(a, &a->combined, N * 8));
-    RC_TRY(dev_alloc(a, &a->ccoef, N * 8));
-    RC_TRY(dev_alloc(a, &a->clde, b * N * 8)); // [b cosets][b columns][n]
+    RC_TRY(dev_alloc(a, &a->cegather, ce * n * 8));
+    RC_TRY(dev_alloc(a, &a->ccoef, ce * n * 8));
+    RC_TRY(dev_alloc(a, &a->clde, b * ce * n * 8)); // [b cosets][ce columns][n]
     RC_TRY(dev_alloc(a, &a->cnodes, 2 * N * 32));
     RC_TRY(dev_alloc(a, &a->deep, N * 8));
     size_t sz = N;
@@ -166,28 +182,18 @@ int get_arena(cstark_ctx *c, unsigned log_n, unsigned log_b, unsigned n_layers, 
         sz /= 4;
     }
     RC_TRY(dev_alloc(a, &a->d_pos, 4 * 256 * (n_layers + 2)));
-    // openings: per query a trace row + path, a constraint row + path, per layer a row of 4 + path
+    // openings: per query a trace row + path, a composition row + path, per layer a row of 4 + path
     a->open_bytes = nq;
-    const size_t per_q = W * 8 + b * 8 + 2 * (log_n + log_b) * 32 + (size_t)n_layers * (32 + (log_n + log_b) * 32);
+    const size_t log_N = job.log_n + log_b;
+    const size_t per_q = W * 8 + ce * 8 + 2 * log_N * 32 + (size_t)n_layers * (32 + log_N * 32);
     RC_TRY(dev_alloc(a, &a->d_open, per_q * nq + 256));
     for (hipEvent_t &e : a->ev) HIP_TRY(hipEventCreate(&e));
     *out = a;
     return CSTARK_OK;
 }
 
-} // namespace
-} // namespace cs
-
-using namespace cs;
-
-extern "C" {
-
-int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_t capacity, size_t *proof_len) {
-    if (!c || !opt || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_prove: null argument");
-    if (!c->wit_buf || c->wit.n_tx == 0 || c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no transaction witness uploaded");
-    const uint32_t n_tx = c->wit.n_tx, depth = c->wit.depth;
-    if (n_tx & (n_tx - 1)) return fail(CSTARK_ERR_INVALID_ARG, "the number of transactions must be a power of two");
-    if (opt->blowup_factor != 8) return fail(CSTARK_ERR_UNSUPPORTED, "TransactionAir is proven with blowup factor 8 (src/lib.rs:78-86)");
+int check_options(const cstark_options *opt, unsigned *log_rem_out) {
+    if (opt->blowup_factor != 8) return fail(CSTARK_ERR_UNSUPPORTED, "proofs use blowup factor 8 (src/lib.rs:78-86)");
     if (opt->hash_fn != 0) return fail(CSTARK_ERR_UNSUPPORTED, "only Blake3_256 is implemented");
     if (opt->field_extension != 0) return fail(CSTARK_ERR_UNSUPPORTED, "only FieldExtension::None is implemented");
     if (opt->fri_folding_factor != 4) return fail(CSTARK_ERR_UNSUPPORTED, "only FRI folding factor 4 is implemented");
@@ -196,17 +202,23 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     unsigned log_rem = 0;
     while ((1u << log_rem) < opt->fri_max_remainder) log_rem++;
     if ((1u << log_rem) != opt->fri_max_remainder || log_rem < 7 || log_rem > 10) return fail(CSTARK_ERR_INVALID_ARG, "fri_max_remainder must be a power of two in 128..1024");
-    unsigned log_n = 10;
-    while ((1u << (log_n - 10)) < n_tx) log_n++;
-    const unsigned log_b = 3, log_N = log_n + log_b;
+    *log_rem_out = log_rem;
+    return CSTARK_OK;
+}
+
+// Prover::prove for any of the AIRs.
+int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *proof, size_t capacity, size_t *proof_len) {
+    unsigned log_rem = 0;
+    RC_TRY(check_options(opt, &log_rem));
+    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b, log_ce = job.log_ce;
     if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "at most 2^21 trace rows");
-    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = CSTARK_TX_TRACE_WIDTH;
+    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = job.width, ce = (size_t)1 << log_ce;
     const unsigned n_layers = num_fri_layers(log_N, log_rem);
     const size_t nq = opt->num_queries;
     if (nq > N / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
     HIP_TRY(hipSetDevice(c->device));
     ProveArena *a;
-    RC_TRY(get_arena(c, log_n, log_b, n_layers, nq, &a));
+    RC_TRY(get_arena(c, job, log_b, n_layers, nq, &a));
     hipStream_t st = c->stream;
     int evi = 0;
 #define STAGE() HIP_TRY(hipEventRecord(a->ev[evi++], st))
@@ -214,11 +226,7 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
 
     // ---- trace, public inputs ---------------------------------------------------------------------------------------
     STAGE();
-    RC_TRY(cstark_tx_build_trace(c, a->trace));
-    uint64_t pub[14];
-    k_gather_pub<<<1, 64, 0, st>>>(a->trace, n, (uint64_t *)a->d_open);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(pub, a->d_open, sizeof pub, hipMemcpyDeviceToHost, st));
+    RC_TRY(job.build(c, a, job));
     STAGE();
     // ---- trace commitment -----------------------------------------------------------------------------------------------
     RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, (uint32_t)W, log_n));
@@ -230,7 +238,7 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     uint8_t trace_root[32], cons_root[32];
     HIP_TRY(hipMemcpyAsync(trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(st)); // also completes the public-input copy of job.build
 
     // ---- channel ------------------------------------------------------------------------------------------------------------
     Coin coin;
@@ -242,21 +250,29 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
         const uint8_t ob[7] = {(uint8_t)opt->num_queries, (uint8_t)log_b, (uint8_t)opt->grinding_factor, (uint8_t)opt->hash_fn,
                                (uint8_t)opt->field_extension, (uint8_t)opt->fri_folding_factor, (uint8_t)log_rem};
         s.raw(ob, 7);
-        for (int i = 0; i < 14; i++) s.u64(host::to_u64(pub[i])); // PublicInputs::write_into, src/air.rs:57-62
+        for (uint64_t v : job.pub) s.u64(host::to_u64(v)); // PublicInputs::write_into (src/air.rs:57-62 and the sub-AIRs' equivalents)
+        s.raw(job.pub_bytes.data(), job.pub_bytes.size());
         coin.init(s.b.data(), s.b.size());
     }
     coin.reseed(trace_root);
-    cstark_tx_coeffs cf;
-    for (int i = 0; i < CSTARK_TX_NUM_CONSTRAINTS; i++) { cf.t_alpha[i] = coin.draw(); cf.t_beta[i] = coin.draw(); }
-    for (int i = 0; i < 4; i++) { cf.b_alpha[i] = coin.draw(); cf.b_beta[i] = coin.draw(); }
-    const uint64_t pub4[4] = {pub[0], pub[1], pub[7], pub[8]}; // get_assertions, src/air.rs:175-184
+    const size_t nc = job.n_constraints, na = job.n_assertions;
+    std::vector<uint64_t> ta(nc), tb(nc), ba(na), bb(na);
+    for (size_t i = 0; i < nc; i++) { ta[i] = coin.draw(); tb[i] = coin.draw(); }
+    for (size_t i = 0; i < na; i++) { ba[i] = coin.draw(); bb[i] = coin.draw(); }
 
     // ---- constraint evaluation, composition polynomial, its commitment ----------------------------------------------
-    RC_TRY(cstark_tx_evaluate_constraints(c, a->lde, &cf, pub4, a->combined, depth, log_n, log_b, 0, (uint32_t)b));
+    RC_TRY(job.combine(c, a, job, ta.data(), tb.data(), ba.data(), bb.data()));
     STAGE();
-    RC_TRY(cstark_composition_columns(c, a->combined, a->ccoef, log_n, log_b));
-    RC_TRY(cstark_lde_columns(c, a->ccoef, a->clde, (uint32_t)b, log_n, log_b, host::generator(), 0, (uint32_t)b));
-    RC_TRY(cstark_hash_rows(c, a->clde, a->cnodes + 32 * N, (uint32_t)b, log_n, log_b, 0, (uint32_t)b));
+    const uint64_t *ce_evals = a->combined;
+    if (log_ce < log_b) { // the constraint-evaluation domain is the sub-domain of every (b / ce)-th LDE coset
+        const size_t stride = b >> log_ce;
+        for (size_t k = 0; k < ce; k++)
+            HIP_TRY(hipMemcpyAsync(a->cegather + k * n, a->combined + k * stride * n, n * 8, hipMemcpyDeviceToDevice, st));
+        ce_evals = a->cegather;
+    }
+    RC_TRY(cstark_composition_columns(c, ce_evals, a->ccoef, log_n, log_ce));
+    RC_TRY(cstark_lde_columns(c, a->ccoef, a->clde, (uint32_t)ce, log_n, log_b, host::generator(), 0, (uint32_t)b));
+    RC_TRY(cstark_hash_rows(c, a->clde, a->cnodes + 32 * N, (uint32_t)ce, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build(c, a->cnodes, log_N));
     HIP_TRY(hipMemcpyAsync(cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
@@ -266,21 +282,21 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     // ---- out-of-domain frame ----------------------------------------------------------------------------------------------
     const uint64_t z = coin.draw();
     const uint64_t zpts[2] = {z, host::mul(z, host::root_of_unity(log_n))};
-    const uint64_t zb = host::pow(z, b);
-    std::vector<uint64_t> ood_trace(2 * W), ood_comp(b);
+    const uint64_t zb = host::pow(z, ce);
+    std::vector<uint64_t> ood_trace(2 * W), ood_comp(ce);
     RC_TRY(cstark_evaluate_polys_at(c, a->coeffs, (uint32_t)W, log_n, zpts, 2, ood_trace.data()));
-    RC_TRY(cstark_evaluate_polys_at(c, a->ccoef, (uint32_t)b, log_n, &zb, 1, ood_comp.data()));
+    RC_TRY(cstark_evaluate_polys_at(c, a->ccoef, (uint32_t)ce, log_n, &zb, 1, ood_comp.data()));
     uint8_t dg[32];
     hash_elements(ood_trace.data(), 2 * W, dg); coin.reseed(dg);
-    hash_elements(ood_comp.data(), b, dg); coin.reseed(dg);
+    hash_elements(ood_comp.data(), ce, dg); coin.reseed(dg);
     STAGE();
 
     // ---- DEEP composition -------------------------------------------------------------------------------------------------
-    std::vector<uint64_t> d_alpha(W), d_beta(W), d_delta(b);
+    std::vector<uint64_t> d_alpha(W), d_beta(W), d_delta(ce);
     for (size_t i = 0; i < W; i++) { d_alpha[i] = coin.draw(); d_beta[i] = coin.draw(); (void)coin.draw(); /* conjugate term, extension fields only */ }
-    for (size_t i = 0; i < b; i++) d_delta[i] = coin.draw();
+    for (size_t i = 0; i < ce; i++) d_delta[i] = coin.draw();
     const uint64_t deg_a = coin.draw(), deg_b = coin.draw();
-    RC_TRY(cstark_deep_composition(c, a->lde, a->clde, (uint32_t)W, (uint32_t)b, z, ood_trace.data(), ood_comp.data(), d_alpha.data(), d_beta.data(),
+    RC_TRY(cstark_deep_composition(c, a->lde, a->clde, (uint32_t)W, (uint32_t)ce, z, ood_trace.data(), ood_comp.data(), d_alpha.data(), d_beta.data(),
                                    d_delta.data(), deg_a, deg_b, a->deep, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_interleave_cosets(c, a->deep, a->layer[0], log_n, log_b));
     STAGE();
@@ -337,11 +353,11 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     size_t off = 0;
     const size_t o_trows = off; off += nq * W * 8;
     const size_t o_tpath = off; off += nq * log_N * 32;
-    const size_t o_crows = off; off += nq * b * 8;
+    const size_t o_crows = off; off += nq * ce * 8;
     const size_t o_cpath = off; off += nq * log_N * 32;
     k_gather_rows<<<(unsigned)nq, 128, 0, st>>>(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, (uint64_t *)(o + o_trows));
     k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->tnodes, log_N, a->d_pos, (uint4 *)(o + o_tpath));
-    k_gather_rows<<<(unsigned)nq, 64, 0, st>>>(a->clde, (uint32_t)b, log_n, log_b, a->d_pos, (uint64_t *)(o + o_crows));
+    k_gather_rows<<<(unsigned)nq, 64, 0, st>>>(a->clde, (uint32_t)ce, log_n, log_b, a->d_pos, (uint64_t *)(o + o_crows));
     k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->cnodes, log_N, a->d_pos, (uint4 *)(o + o_cpath));
     std::vector<size_t> o_lrows(n_layers), o_lpath(n_layers);
     {
@@ -366,7 +382,7 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     // ---- serialise ----------------------------------------------------------------------------------------------------------------
     Writer wr;
     wr.raw("CSTK", 4); wr.u32(CSTARK_PROOF_VERSION);
-    wr.u32(CSTARK_AIR_STATE_TRANSITION); wr.u32((uint32_t)W); wr.u32(log_n); wr.u32(depth);
+    wr.u32((uint32_t)job.air); wr.u32((uint32_t)W); wr.u32(log_n); wr.u32(job.item);
     wr.u32(opt->num_queries); wr.u32(opt->blowup_factor); wr.u32(opt->grinding_factor); wr.u32(opt->hash_fn); wr.u32(opt->field_extension);
     wr.u32(opt->fri_folding_factor); wr.u32(opt->fri_max_remainder);
     wr.raw(trace_root, 32); wr.raw(cons_root, 32);
@@ -374,7 +390,7 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     wr.raw(ood_trace.data(), ood_trace.size() * 8); wr.raw(ood_comp.data(), ood_comp.size() * 8);
     wr.u64(nonce);
     wr.raw(open.data() + o_trows, nq * W * 8); wr.raw(open.data() + o_tpath, nq * log_N * 32);
-    wr.raw(open.data() + o_crows, nq * b * 8); wr.raw(open.data() + o_cpath, nq * log_N * 32);
+    wr.raw(open.data() + o_crows, nq * ce * 8); wr.raw(open.data() + o_cpath, nq * log_N * 32);
     {
         unsigned g2 = log_N;
         for (unsigned l = 0; l < n_layers; l++) {
@@ -390,6 +406,132 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     if (!proof || capacity < wr.b.size()) return fail(CSTARK_ERR_INVALID_ARG, "proof buffer too small (required size returned in *proof_len)");
     memcpy(proof, wr.b.data(), wr.b.size());
     return CSTARK_OK;
+}
+
+// first / last row of registers 58..64 -> job.pub (TransactionProver::get_pub_inputs src/prover.rs:106-129; MerkleProver alike)
+int gather_roots(cstark_ctx *c, ProveArena *a, AirJob &job) {
+    const size_t n = (size_t)1 << job.log_n;
+    k_gather_pub<<<1, 64, 0, c->stream>>>(a->trace, n, (uint64_t *)a->d_open);
+    HIP_TRY(hipGetLastError());
+    job.pub.assign(14, 0);
+    HIP_TRY(hipMemcpyAsync(job.pub.data(), a->d_open, 14 * 8, hipMemcpyDeviceToHost, c->stream)); // complete at the commitment sync
+    return CSTARK_OK;
+}
+template <class T>
+int arena_extra(ProveArena *a, size_t slot, T **p, size_t bytes) {
+    if (a->extra.size() <= slot) a->extra.resize(slot + 1, nullptr);
+    if (!a->extra[slot]) { void *q; HIP_TRY(hipMalloc(&q, bytes)); a->owned.push_back(q); a->extra[slot] = q; }
+    *p = (T *)a->extra[slot];
+    return CSTARK_OK;
+}
+
+// ---- TransactionAir ---------------------------------------------------------------------------------------------------------------
+int tx_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
+    RC_TRY(cstark_tx_build_trace(c, a->trace));
+    return gather_roots(c, a, job);
+}
+int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) {
+    cstark_tx_coeffs cf;
+    memcpy(cf.t_alpha, ta, sizeof cf.t_alpha); memcpy(cf.t_beta, tb, sizeof cf.t_beta);
+    memcpy(cf.b_alpha, ba, sizeof cf.b_alpha); memcpy(cf.b_beta, bb, sizeof cf.b_beta);
+    const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]}; // get_assertions, src/air.rs:175-184
+    return cstark_tx_evaluate_constraints(c, a->lde, &cf, pub4, a->combined, job.item, job.log_n, 3, 0, 8);
+}
+// ---- MerkleAir (src/merkle/update) ---------------------------------------------------------------------------------------------
+int merkle_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
+    RC_TRY(cstark_merkle_build_trace(c, a->trace));
+    return gather_roots(c, a, job);
+}
+int merkle_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) {
+    const size_t n = (size_t)1 << job.log_n;
+    uint64_t *evals;
+    RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
+    RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_MERKLE_UPDATE, a->lde, evals, job.item, job.log_n, 3, 0, 8));
+    return cstark_air_combine(c, CSTARK_AIR_MERKLE_UPDATE, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, a->combined, job.log_n, 3, 0, 8);
+}
+// ---- RangeProofAir (src/range) -------------------------------------------------------------------------------------------------------
+int range_build(cstark_ctx *c, ProveArena *a, AirJob &job) { return cstark_range_build_trace(c, job.number, a->trace); }
+int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) {
+    const size_t n = (size_t)1 << job.log_n;
+    uint64_t *evals;
+    RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
+    RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RANGE, a->lde, evals, 0, job.log_n, 3, 0, 8));
+    const uint64_t vals[2] = {0, job.number}; // get_assertions, src/range/air.rs:79-86
+    return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, a->combined, job.log_n, 3, 0, 8);
+}
+// ---- SchnorrAir (src/schnorr) ---------------------------------------------------------------------------------------------------------
+int schnorr_build(cstark_ctx *c, ProveArena *a, AirJob &) { return cstark_schnorr_build_trace(c, a->trace); }
+int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) {
+    const size_t n = (size_t)1 << job.log_n;
+    uint64_t *evals, *aux, *aux_co, *aux_lde, *av_co, *av_lde;
+    RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
+    RC_TRY(arena_extra(a, 1, &aux, 19 * n * 8));
+    RC_TRY(arena_extra(a, 2, &aux_co, 19 * n * 8));
+    RC_TRY(arena_extra(a, 3, &aux_lde, 8 * 19 * n * 8));
+    RC_TRY(arena_extra(a, 4, &av_co, 12 * n * 8));
+    RC_TRY(arena_extra(a, 5, &av_lde, 8 * 12 * n * 8));
+    // the public-input columns (src/schnorr/air.rs:228-290) are not committed: both sides derive them from the messages
+    RC_TRY(cstark_schnorr_aux_columns(c, aux));
+    RC_TRY(cstark_interpolate_columns(c, aux, aux_co, 19, job.log_n));
+    RC_TRY(cstark_lde_columns(c, aux_co, aux_lde, 19, job.log_n, 3, host::generator(), 0, 8));
+    RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
+    RC_TRY(cstark_schnorr_assertion_polys(c, av_co, job.log_n));
+    RC_TRY(cstark_lde_columns(c, av_co, av_lde, 12, job.log_n, 3, host::generator(), 0, 8));
+    return cstark_air_combine(c, CSTARK_AIR_SCHNORR, job.item, a->lde, evals, ta, tb, ba, bb, nullptr, av_lde, 12, a->combined, job.log_n, 3, 0, 8);
+}
+
+unsigned ceil_log2(uint64_t x) { unsigned l = 0; while ((1ull << l) < x) l++; return l; }
+
+} // namespace
+} // namespace cs
+
+using namespace cs;
+
+extern "C" {
+
+int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_t capacity, size_t *proof_len) {
+    if (!c || !opt || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_prove: null argument");
+    if (!c->wit_buf || c->wit.n_tx == 0 || c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no transaction witness uploaded");
+    if (c->wit.n_tx & (c->wit.n_tx - 1)) return fail(CSTARK_ERR_INVALID_ARG, "the number of transactions must be a power of two");
+    AirJob job;
+    job.air = CSTARK_AIR_STATE_TRANSITION; job.width = CSTARK_TX_TRACE_WIDTH; job.log_n = 10 + ceil_log2(c->wit.n_tx); job.log_ce = 3;
+    job.n_constraints = CSTARK_TX_NUM_CONSTRAINTS; job.n_assertions = 4; job.item = c->wit.depth;
+    job.build = tx_build; job.combine = tx_combine;
+    return prove_core(c, opt, job, proof, capacity, proof_len);
+}
+
+int cstark_air_prove(cstark_ctx *c, int air, const cstark_options *opt, uint64_t number, uint8_t *proof, size_t capacity, size_t *proof_len) {
+    if (!c || !opt || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_prove: null argument");
+    if (air == CSTARK_AIR_STATE_TRANSITION) return cstark_tx_prove(c, opt, proof, capacity, proof_len);
+    AirJob job;
+    job.air = air;
+    host::AirShape s;
+    if (air == CSTARK_AIR_MERKLE_UPDATE) {
+        if (!c->wit_buf || c->wit.n_tx == 0 || c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no transaction witness uploaded");
+        if (c->wit.n_tx & (c->wit.n_tx - 1)) return fail(CSTARK_ERR_INVALID_ARG, "the number of transactions must be a power of two");
+        host::air_shape(air, s, 0);
+        job.log_n = 9 + ceil_log2(c->wit.n_tx); job.item = c->wit.depth;
+        job.build = merkle_build; job.combine = merkle_combine;
+    } else if (air == CSTARK_AIR_RANGE) {
+        if (number >= host::P || (host::to_u64(number) >> 63)) return fail(CSTARK_ERR_INVALID_ARG, "range proofs cover 63-bit field elements (src/range/tests.rs:54-62)");
+        host::air_shape(air, s, 0);
+        job.log_n = 6; job.item = 0; job.number = number; // RANGE_LOG = 64 rows, src/range/mod.rs:34
+        job.pub = {number};
+        job.build = range_build; job.combine = range_combine;
+    } else if (air == CSTARK_AIR_SCHNORR) {
+        if (!c->wit_buf || c->wit.n_tx == 0 || !c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no Schnorr witness uploaded");
+        const uint32_t ns = c->wit.n_tx;
+        if (ns & (ns - 1)) return fail(CSTARK_ERR_INVALID_ARG, "the number of signatures must be a power of two");
+        host::air_shape(air, s, ns);
+        job.log_n = 9 + ceil_log2(ns); job.item = ns;
+        job.pub = c->schnorr_pub; // messages [ns][28] then R.x [ns][6] (src/schnorr/air.rs:29-38)
+        job.pub_bytes = c->schnorr_s;
+        job.build = schnorr_build; job.combine = schnorr_combine;
+    } else {
+        return fail(CSTARK_ERR_UNSUPPORTED, "no prover for this AIR");
+    }
+    job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
+    return prove_core(c, opt, job, proof, capacity, proof_len);
 }
 
 size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt) {

@@ -181,3 +181,53 @@ class TransactionExample:
 
     def pub_inputs(self):
         return self.tx_metadata.initial_roots[0], self.tx_metadata.final_root
+
+
+# ---- the standalone examples of the reference: same prove() surface over cstark_air_prove ---------------------------------------
+class MerkleExample:
+    """merkle::update::MerkleExample (src/merkle/update/mod.rs:36-127): proves the Merkle-update half of the transfers with the
+    65-register MerkleAir."""
+
+    def __init__(self, options, tx_metadata, backend=None):
+        self.options, self.tx_metadata = options, tx_metadata
+        self.backend = backend or Backend()
+
+    def prove(self):
+        self.backend.upload_witness(self.tx_metadata)
+        return self.backend.air_prove(Backend.AIR_MERKLE, self.options)
+
+    def pub_inputs(self):
+        return self.tx_metadata.initial_roots[0], self.tx_metadata.final_root
+
+
+class SchnorrExample:
+    """schnorr::SchnorrExample (src/schnorr/mod.rs:52-186): messages [n][28] (public key || 16 elements) with signatures."""
+
+    def __init__(self, options, messages, sig_rx, sig_s, backend=None):
+        self.options, self.messages, self.sig_rx, self.sig_s = options, messages, sig_rx, sig_s
+        self.backend = backend or Backend()
+
+    @classmethod
+    def build_random(cls, options, num_signatures, seed=0x5EED, backend=None):
+        import ctypes as C
+        n = int(num_signatures)
+        msg, rx, s = np.zeros((n, 28), np.uint64), np.zeros((n, 6), np.uint64), np.zeros((n, 32), np.uint8)
+        _lib.check(_lib.load().cstark_schnorr_witness_generate(C.c_uint32(n), C.c_uint64(seed), msg.ctypes.data_as(_lib.u64p),
+                                                               rx.ctypes.data_as(_lib.u64p), s.ctypes.data_as(_lib.u8p)))
+        return cls(options, msg, rx, s, backend)
+
+    def prove(self):
+        self.backend.upload_schnorr_witness(self.messages, self.sig_rx, self.sig_s)
+        return self.backend.air_prove(Backend.AIR_SCHNORR, self.options)
+
+
+class RangeProofExample:
+    """range::RangeProofExample (src/range/mod.rs:28-110): `number` is a field element in memory form whose canonical value is
+    below 2^63 (larger inputs are refused, src/range/tests.rs:54-62)."""
+
+    def __init__(self, options, number, backend=None):
+        self.options, self.number = options, int(number)
+        self.backend = backend or Backend()
+
+    def prove(self):
+        return self.backend.air_prove(Backend.AIR_RANGE, self.options, self.number)

@@ -200,6 +200,12 @@ int cstark_fri_fold4(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, 
 #define CSTARK_PROOF_VERSION 1
 #define CSTARK_PROVE_NUM_STAGES 10
 int cstark_tx_prove(cstark_ctx *ctx, const cstark_options *opt, uint8_t *proof, size_t capacity, size_t *proof_len);
+/* The same for the standalone AIRs (MerkleExample / SchnorrExample / RangeProofExample ::prove, src/merkle/update/mod.rs:84-107,
+ * src/schnorr/mod.rs:150-173, src/range/mod.rs:78-101): CSTARK_AIR_MERKLE_UPDATE proves the uploaded transaction witness with the
+ * 65-register MerkleAir, CSTARK_AIR_SCHNORR the uploaded Schnorr witness, CSTARK_AIR_RANGE the field element `number` (ignored
+ * otherwise).  Same proof layout with the AIR's width and its number of composition columns (4 / 8 / 2); the header's 4th word
+ * holds the Merkle depth / the number of signatures / 0.  Use cstark_tx_proof_size_bound(rows / 1024 rounded up, opt) * 2 as capacity. */
+int cstark_air_prove(cstark_ctx *ctx, int air, const cstark_options *opt, uint64_t number, uint8_t *proof, size_t capacity, size_t *proof_len);
 size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt);
 /* Wall-clock of the stages of the last cstark_tx_prove on this context (HIP events on its stream), milliseconds:
  * trace, interpolate, LDE, row hashes + tree, constraint evaluation, composition polynomial + commitment,

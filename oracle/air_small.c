@@ -252,6 +252,13 @@ void cso_schnorr_evaluate_transitions(const uint64_t *lde, const uint64_t *aux, 
             for (int i = 0; i < 56; i++) out[((size_t)(k - k0) * 56 + i) * n + j] = res[i];
         }
 }
+/* the same at one point (what a verifier evaluates on the out-of-domain frame): m = the 36 mask / round-constant values, pk / inp =
+ * values of the public-input columns */
+void cso_schnorr_evaluate_transition_at(const uint64_t *cur, const uint64_t *next, const uint64_t *m, const uint64_t *pk, const uint64_t *inp, uint64_t *res) {
+    memset(res, 0, 56 * sizeof(fp));
+    fp copy_hash = fp_mul(c_not(m[7]), m[0]), final_add = fp_mul(c_not(m[1]), m[0]), addition = fp_mul(c_not(m[2]), m[1]);
+    cso_schnorr_constraints(res, cur, next, m + 8, m[2], addition, m + 3, pk, final_add, m[7], copy_hash, inp);
+}
 /* schnorr::transition_constraint_degrees(num_sig, 512), src/schnorr/air.rs:533-585 */
 void cso_schnorr_constraint_degrees(uint32_t n_sig, uint32_t *base, uint32_t *cycles) {
     const uint32_t bit_degree = n_sig == 1 ? 3 : 5;

@@ -112,6 +112,7 @@ int cso_schnorr_build_trace(uint32_t n_sig, const uint64_t *messages, const uint
 void cso_schnorr_aux_columns(uint32_t n_sig, const uint64_t *messages, uint64_t *out);
 void cso_schnorr_mask_columns(uint64_t *out);
 void cso_schnorr_evaluate_transitions(const uint64_t *lde, const uint64_t *aux, const uint64_t *ptab, uint64_t *out, unsigned log_n, uint32_t k0, uint32_t nk);
+void cso_schnorr_evaluate_transition_at(const uint64_t *cur, const uint64_t *next, const uint64_t *m, const uint64_t *pk, const uint64_t *inp, uint64_t *res);
 void cso_schnorr_constraint_degrees(uint32_t n_sig, uint32_t *base, uint32_t *cycles);
 int cso_schnorr_witness_generate(uint32_t n_sig, uint64_t seed, uint64_t *messages, uint64_t *sig_rx, uint8_t *sig_s);
 void cso_air_combine(const cso_air_desc *d, const uint64_t *lde, const uint64_t *evals, const uint64_t *t_alpha, const uint64_t *t_beta,

@@ -113,10 +113,13 @@ def parse(proof):
         raise VerifierError("bad magic")
     d = {"version": r.u32(), "air": r.u32(), "width": r.u32(), "log_n": r.u32(), "depth": r.u32()}
     d["options"] = [r.u32() for _ in range(7)]
-    if d["version"] != 1 or d["air"] != 0 or d["width"] != 94:
+    shapes = {0: (94, 8), 1: (65, 4), 2: (56, 8), 3: (2, 2)}  # air id -> (trace width, composition columns)
+    if d["version"] != 1 or d["air"] not in shapes or d["width"] != shapes[d["air"]][0]:
         raise VerifierError("unsupported proof header")
+    W, ce = shapes[d["air"]]
+    d["ce"] = ce
     nq, blowup = d["options"][0], d["options"][1]
-    if blowup != 8 or not (10 <= d["log_n"] <= 21) or not (1 <= nq <= 128):
+    if blowup != 8 or not (6 <= d["log_n"] <= 21) or not (1 <= nq <= 128):
         raise VerifierError("unsupported parameters")
     log_N = d["log_n"] + 3
     d["trace_root"], d["cons_root"] = r.take(32), r.take(32)
@@ -125,11 +128,11 @@ def parse(proof):
         raise VerifierError("bad layer count")
     d["layer_roots"] = [r.take(32) for _ in range(nl)]
     d["rem_commit"] = r.take(32)
-    d["ood_cur"], d["ood_next"], d["ood_comp"] = r.elems(94), r.elems(94), r.elems(8)
+    d["ood_cur"], d["ood_next"], d["ood_comp"] = r.elems(W), r.elems(W), r.elems(ce)
     d["nonce"] = r.u64()
-    d["trace_rows"] = r.elems(nq * 94).reshape(nq, 94)
+    d["trace_rows"] = r.elems(nq * W).reshape(nq, W)
     d["trace_paths"] = [[r.take(32) for _ in range(log_N)] for _ in range(nq)]
-    d["cons_rows"] = r.elems(nq * 8).reshape(nq, 8)
+    d["cons_rows"] = r.elems(nq * ce).reshape(nq, ce)
     d["cons_paths"] = [[r.take(32) for _ in range(log_N)] for _ in range(nq)]
     d["layers"] = []
     lg = log_N
@@ -152,19 +155,170 @@ def parse(proof):
     return d
 
 
+def _poly_at(coeff_cols, x):
+    """values of coefficient columns (memory form) at the canonical point x -> canonical integers"""
+    cols = np.ascontiguousarray(coeff_cols, np.uint64)
+    pts = np.array([to_mont(x)], np.uint64)
+    return [from_mont(v) for v in O.evaluate_polys_at(cols, pts)[0]]
+
+
+class _TxAir:
+    """TransactionAir: 115 transition constraints in 5 degree groups, 4 single assertions (src/air.rs:76-108, :175-184)."""
+    air, width, ce = 0, 94, 8
+
+    def __init__(self, d, initial_root, final_root):
+        self.depth = d["depth"]
+        self.pub = [from_mont(v) for v in list(initial_root) + list(final_root)]
+        self.pub_bytes = b""
+        self.nc, self.na = 115, 4
+
+    def ood_combined(self, d, log_n, z, ta, tb, ba, bb):
+        cf = O.TxCoeffsStruct()
+        for i in range(115):
+            cf.t_alpha[i], cf.t_beta[i] = to_mont(ta[i]), to_mont(tb[i])
+        for i in range(4):
+            cf.b_alpha[i], cf.b_beta[i] = to_mont(ba[i]), to_mont(bb[i])
+        pub4 = np.array([to_mont(self.pub[0]), to_mont(self.pub[1]), to_mont(self.pub[7]), to_mont(self.pub[8])], np.uint64)
+        lib = O.lib()
+        lib.cso_tx_combined_from_frame.restype = C.c_uint64
+        cur, nxt = np.ascontiguousarray(d["ood_cur"]), np.ascontiguousarray(d["ood_next"])
+        return from_mont(lib.cso_tx_combined_from_frame(O._p(cur), O._p(nxt), C.byref(cf), O._p(pub4), C.c_uint(self.depth), C.c_uint(log_n),
+                                                        C.c_uint(3), C.c_uint64(to_mont(z))))
+
+
+class _GenericAir:
+    """Standalone AIRs through the generic description: transition values from the oracle's pointwise evaluators, merge restated here."""
+
+    def _merge(self, log_n, z, res, ta, tb, ba, bb, cur, assertions):
+        n = 1 << log_n
+        ce_size = n * self.ce
+        wn = root_of_unity(log_n)
+        acc = 0
+        for i in range(self.nc):
+            ev = int(self.base[i]) * (n - 1) + (int(self.cycles[i]) * (n // self.cycle_len) * (self.cycle_len - 1) if self.cycle_len else 0)
+            acc += res[i] * ((ta[i] + tb[i] * pow(z, (ce_size - 1 + n - 1) - ev, P)) % P)
+        acc = acc % P * ((z - pow(wn, n - 1, P)) % P) % P * pow(pow(z, n, P) - 1, -1, P) % P
+        for a, (reg, first, stride, value) in enumerate(assertions):
+            m = n // stride if stride else 1
+            div = (pow(z, m, P) - pow(wn, (first * m) % n, P)) % P
+            term = (cur[reg] - value) % P * ((ba[a] + bb[a] * pow(z, ce_size - 1 + m - (n - 1), P)) % P) % P
+            acc = (acc + term * pow(div, -1, P)) % P
+        return acc
+
+
+class _MerkleAir(_GenericAir):
+    air, width, ce = 1, 65, 4
+
+    def __init__(self, d, initial_root, final_root):
+        self.depth = d["depth"]
+        self.pub = [from_mont(v) for v in list(initial_root) + list(final_root)]
+        self.pub_bytes = b""
+        self.base = np.zeros(106, np.uint32); self.cycles = np.zeros(106, np.uint32)
+        O.lib().cso_merkle_constraint_degrees(O._p(self.base, O.u32p), O._p(self.cycles, O.u32p))
+        self.cycle_len, self.nc, self.na = 512, 106, 14
+
+    def ood_combined(self, d, log_n, z, ta, tb, ba, bb):
+        n = 1 << log_n
+        pcols = O.interpolate_columns(O.merkle_periodic_columns(self.depth))
+        pv = np.array([to_mont(v) for v in _poly_at(pcols, pow(z, n // 512, P))], np.uint64)
+        cur, nxt = np.ascontiguousarray(d["ood_cur"]), np.ascontiguousarray(d["ood_next"])
+        res = np.zeros(128, np.uint64)
+        O.lib().cso_merkle_evaluate_transition(O._p(cur), O._p(nxt), O._p(pv), O._p(res))
+        assertions = [(58 + a % 7, (n - 1) if a >= 7 else 0, 0, self.pub[a]) for a in range(14)]  # src/merkle/update/air.rs:142-170
+        return self._merge(log_n, z, [from_mont(v) for v in res[:106]], ta, tb, ba, bb, [from_mont(v) for v in cur], assertions)
+
+
+class _RangeAir(_GenericAir):
+    air, width, ce = 3, 2, 2
+
+    def __init__(self, d, number):
+        self.pub = [from_mont(number)]
+        self.pub_bytes = b""
+        self.base, self.cycles, self.cycle_len, self.nc, self.na = [2, 1], [0, 0], 0, 2, 2
+
+    def ood_combined(self, d, log_n, z, ta, tb, ba, bb):
+        n = 1 << log_n
+        cur, nxt = np.ascontiguousarray(d["ood_cur"]), np.ascontiguousarray(d["ood_next"])
+        res = np.zeros(8, np.uint64)
+        O.lib().cso_range_evaluate_transition(O._p(cur), O._p(nxt), None, O._p(res))
+        assertions = [(1, 0, 0, 0), (1, n - 1, 0, self.pub[0])]  # src/range/air.rs:79-86
+        return self._merge(log_n, z, [from_mont(v) for v in res[:2]], ta, tb, ba, bb, [from_mont(v) for v in cur], assertions)
+
+
+class _SchnorrAir(_GenericAir):
+    air, width, ce = 2, 56, 8
+
+    def __init__(self, d, w):
+        self.w = w
+        self.pub = [from_mont(v) for v in list(w.messages.reshape(-1)) + list(w.sig_rx.reshape(-1))]
+        self.pub_bytes = w.sig_s.tobytes()
+        self.base, self.cycles = O.schnorr_constraint_degrees(w.n_sig)
+        self.cycle_len, self.nc, self.na = 512, 56, 61
+        if d["depth"] != w.n_sig:
+            raise VerifierError("proof is for a different number of signatures")
+
+    def ood_combined(self, d, log_n, z, ta, tb, ba, bb):
+        n = 1 << log_n
+        w = self.w
+        masks = np.array([to_mont(v) for v in _poly_at(O.interpolate_columns(O.schnorr_mask_columns()), pow(z, n // 512, P))], np.uint64)
+        aux = np.array([to_mont(v) for v in _poly_at(O.interpolate_columns(O.schnorr_aux_columns(w)), z)], np.uint64)
+        cur, nxt = np.ascontiguousarray(d["ood_cur"]), np.ascontiguousarray(d["ood_next"])
+        res = np.zeros(56, np.uint64)
+        pk, inp = np.ascontiguousarray(aux[:12]), np.ascontiguousarray(aux[12:19])
+        O.lib().cso_schnorr_evaluate_transition_at(O._p(cur), O._p(nxt), O._p(masks), O._p(pk), O._p(inp), O._p(res))
+        desc = O.schnorr_desc(w)
+        seq_at_z = _poly_at(O.schnorr_assertion_polys(w, log_n), z)
+        assertions = []
+        for a in range(desc.na):
+            q = int(desc.a_seq[a])
+            assertions.append((int(desc.a_reg[a]), int(desc.a_first[a]), int(desc.a_stride[a]),
+                               seq_at_z[q] if q >= 0 else from_mont(desc.a_value[a])))
+        return self._merge(log_n, z, [from_mont(v) for v in res], ta, tb, ba, bb, [from_mont(v) for v in cur], assertions)
+
+
 def verify(proof, initial_root, final_root, options=None):
-    """Raises VerifierError unless `proof` shows that a valid 94-register trace links initial_root to final_root.
+    """TransactionAir.  Raises VerifierError unless `proof` shows that a valid 94-register trace links initial_root to final_root.
     initial_root / final_root: 7 field elements each, memory form (as TransactionMetadata holds them).
     options: the 7 ProofOptions values the verifier expects (None = accept what the proof states)."""
     d = parse(proof)
+    if d["air"] != 0:
+        raise VerifierError("not a TransactionAir proof")
+    return _verify(d, _TxAir(d, initial_root, final_root), options)
+
+
+def verify_merkle(proof, initial_root, final_root, options=None):
+    """MerkleAir (src/merkle/update/mod.rs:109-127)."""
+    d = parse(proof)
+    if d["air"] != 1:
+        raise VerifierError("not a MerkleAir proof")
+    return _verify(d, _MerkleAir(d, initial_root, final_root), options)
+
+
+def verify_range(proof, number, options=None):
+    """RangeProofAir (src/range/mod.rs:103-110); number in memory form."""
+    d = parse(proof)
+    if d["air"] != 3:
+        raise VerifierError("not a RangeProofAir proof")
+    return _verify(d, _RangeAir(d, number), options)
+
+
+def verify_schnorr(proof, witness, options=None):
+    """SchnorrAir (src/schnorr/mod.rs:175-186); witness: messages [n][28], sig_rx [n][6], sig_s [n][32] (all public)."""
+    d = parse(proof)
+    if d["air"] != 2:
+        raise VerifierError("not a SchnorrAir proof")
+    return _verify(d, _SchnorrAir(d, witness), options)
+
+
+def _verify(d, air, options):
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = d["options"]
     if options is not None and list(options) != d["options"]:
         raise VerifierError("proof options differ from the expected ones")
     if hash_fn != 0 or ext != 0 or folding != 4 or max_rem & (max_rem - 1) or not (128 <= max_rem <= 1024):
         raise VerifierError("unsupported options")
-    log_n, depth = d["log_n"], d["depth"]
+    log_n = d["log_n"]
     log_b, log_N = 3, log_n + 3
-    n, N, W, b = 1 << log_n, 1 << log_N, 94, 8
+    n, N, W, b, ce = 1 << log_n, 1 << log_N, air.width, 8, air.ce
     log_rem = max_rem.bit_length() - 1
     n_layers, lg = 0, log_N
     while lg > log_rem:
@@ -172,28 +326,23 @@ def verify(proof, initial_root, final_root, options=None):
         n_layers += 1
     if n_layers != len(d["layer_roots"]) or len(d["remainder"]) != 1 << lg:
         raise VerifierError("FRI layer structure does not match the options")
-    pub = [from_mont(v) for v in list(initial_root) + list(final_root)]
 
     # 1. channel
     seed = bytes([W, log_n]) + struct.pack("<Q", P) + bytes([nq, log_b, grinding, hash_fn, ext, folding, log_rem])
-    seed += b"".join(struct.pack("<Q", v) for v in pub)
+    seed += b"".join(struct.pack("<Q", v) for v in air.pub) + air.pub_bytes
     coin = Coin(seed)
     coin.reseed(d["trace_root"])
-    cf = O.TxCoeffsStruct()
-    for i in range(115):
-        cf.t_alpha[i], cf.t_beta[i] = to_mont(coin.draw()), to_mont(coin.draw())
-    for i in range(4):
-        cf.b_alpha[i], cf.b_beta[i] = to_mont(coin.draw()), to_mont(coin.draw())
+    ta, tb, ba, bb = [], [], [], []
+    for _ in range(air.nc):
+        ta.append(coin.draw()); tb.append(coin.draw())
+    for _ in range(air.na):
+        ba.append(coin.draw()); bb.append(coin.draw())
     coin.reseed(d["cons_root"])
     z = coin.draw()
 
     # 2. out-of-domain consistency
-    pub4 = np.array([to_mont(pub[0]), to_mont(pub[1]), to_mont(pub[7]), to_mont(pub[8])], np.uint64)
-    lib = O.lib()
-    lib.cso_tx_combined_from_frame.restype = C.c_uint64
+    lhs = air.ood_combined(d, log_n, z, ta, tb, ba, bb)
     cur, nxt = np.ascontiguousarray(d["ood_cur"]), np.ascontiguousarray(d["ood_next"])
-    lhs = from_mont(lib.cso_tx_combined_from_frame(O._p(cur), O._p(nxt), C.byref(cf), O._p(pub4), C.c_uint(depth), C.c_uint(log_n),
-                                                   C.c_uint(log_b), C.c_uint64(to_mont(z))))
     hz = [from_mont(v) for v in d["ood_comp"]]
     rhs = sum(h * pow(z, i, P) for i, h in enumerate(hz)) % P
     if lhs != rhs:
@@ -203,7 +352,7 @@ def verify(proof, initial_root, final_root, options=None):
     d_alpha, d_beta = [], []
     for _ in range(W):
         d_alpha.append(coin.draw()); d_beta.append(coin.draw()); coin.draw()
-    d_delta = [coin.draw() for _ in range(b)]
+    d_delta = [coin.draw() for _ in range(ce)]
     deg_a, deg_b = coin.draw(), coin.draw()
     alphas = []
     for root in d["layer_roots"]:
@@ -230,7 +379,7 @@ def verify(proof, initial_root, final_root, options=None):
     wN, wn = root_of_unity(log_N), root_of_unity(log_n)
     tz = [from_mont(v) for v in d["ood_cur"]]
     tzw = [from_mont(v) for v in d["ood_next"]]
-    zw, zb = z * wn % P, pow(z, b, P)
+    zw, zb = z * wn % P, pow(z, ce, P)
     deep = []
     for q, pos in enumerate(positions):
         x = GEN * pow(wN, pos, P) % P
@@ -240,7 +389,7 @@ def verify(proof, initial_root, final_root, options=None):
         acc = 0
         for c in range(W):
             acc += d_alpha[c] * (row[c] - tz[c]) % P * i1 + d_beta[c] * (row[c] - tzw[c]) % P * i2
-        for i in range(b):
+        for i in range(ce):
             acc += d_delta[i] * (crow[i] - hz[i]) % P * i3
         deep.append(acc % P * ((deg_a + deg_b * x) % P) % P)
 
@@ -284,8 +433,6 @@ def verify(proof, initial_root, final_root, options=None):
     # remainder degree: evaluations over offset * <w_R> must interpolate to degree < R / blowup
     R = len(rem)
     co = O.ntt(np.array([to_mont(v) for v in rem], np.uint64), inverse=True)
-    off_inv = pow(offset, -1, P)
-    max_deg_plus_1 = R // blowup
-    if any(int(v) != 0 for v in co[max_deg_plus_1:]):  # the offset scaling does not change which coefficients vanish
+    if any(int(v) != 0 for v in co[R // blowup:]):  # the offset scaling does not change which coefficients vanish
         raise VerifierError("FRI remainder is not a low-degree polynomial")
     return True

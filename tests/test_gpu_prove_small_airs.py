@@ -1,0 +1,87 @@
+"""Complete proofs of the standalone AIRs through cstark_air_prove, accepted by the restated verifier.  Mirrors the reference's
+acceptance tests: src/range/tests.rs (17, 42, max input, too-large input, wrong public input), src/schnorr/tests.rs,
+src/merkle/update/tests.rs (prove -> verify; verify with wrong inputs -> error)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 2**62 + 2**56 + 2**55 + 1
+OPTS = (42, 8, 0, 0, 0, 4, 256)  # build_options(1) of the reference's tests
+
+
+@pytest.fixture(scope="module")
+def backend():
+    from certificate_stark_amd.backend import Backend
+    b = Backend()
+    yield b
+    b.close()
+
+
+def options():
+    from certificate_stark_amd.prover import ProofOptions
+    return ProofOptions(*OPTS)
+
+
+@pytest.mark.parametrize("value", [17, 42, 2**63 - 1, 0])
+def test_range_proof_verification(oracle, backend, value):
+    from oracle import verifier as V
+    from certificate_stark_amd.prover import RangeProofExample
+    number = int(oracle.to_mont([value % P])[0])      # BaseElement::from reduces
+    proof = RangeProofExample(options(), number, backend).prove()
+    assert V.verify_range(proof, number, options=list(OPTS))
+    with pytest.raises(V.VerifierError):              # range_test_basic_proof_verification_fail: another number
+        V.verify_range(proof, int(oracle.to_mont([(value + 1) % P])[0]))
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 4
+    with pytest.raises(V.VerifierError):
+        V.verify_range(bytes(bad), number)
+
+
+def test_range_proof_input_too_large(backend):
+    from certificate_stark_amd import CstarkError
+    from certificate_stark_amd.prover import RangeProofExample
+    with pytest.raises(CstarkError):                  # src/range/tests.rs:54-62 (should_panic): raw M is not an element
+        RangeProofExample(options(), P, backend).prove()
+
+
+@pytest.mark.parametrize("n_tx,depth", [(2, 3), (8, 15)])
+def test_merkle_proof_verification(oracle, backend, n_tx, depth):
+    from oracle import verifier as V
+    from certificate_stark_amd.prover import MerkleExample, TransactionMetadata
+    meta = TransactionMetadata.build_random(n_tx, depth, seed=31 + n_tx)
+    ex = MerkleExample(options(), meta, backend)
+    proof = ex.prove()
+    assert V.verify_merkle(proof, *ex.pub_inputs(), options=list(OPTS))
+    r0, r1 = ex.pub_inputs()
+    with pytest.raises(V.VerifierError):              # verify_with_wrong_inputs (src/merkle/update/mod.rs:129-138)
+        V.verify_merkle(proof, r0, np.full(7, r1[0], np.uint64))
+    with pytest.raises(V.VerifierError):
+        V.verify(proof, r0, r1)                       # not a TransactionAir proof
+
+
+@pytest.mark.parametrize("n_sig", [1, 2, 8])
+def test_schnorr_proof_verification(oracle, backend, n_sig):
+    from oracle import verifier as V
+    from certificate_stark_amd.prover import SchnorrExample
+    ex = SchnorrExample.build_random(options(), n_sig, seed=500 + n_sig, backend=backend)
+    proof = ex.prove()
+    w = oracle.SchnorrWitness(n_sig)
+    w.messages[...], w.sig_rx[...], w.sig_s[...] = ex.messages, ex.sig_rx, ex.sig_s
+    assert V.verify_schnorr(proof, w, options=list(OPTS))
+    w2 = oracle.SchnorrWitness(n_sig)                 # wrong message (src/schnorr/mod.rs verify_with_wrong_inputs)
+    w2.messages[...], w2.sig_rx[...], w2.sig_s[...] = ex.messages, ex.sig_rx, ex.sig_s
+    w2.messages[0, 20] ^= np.uint64(1)
+    with pytest.raises(V.VerifierError):
+        V.verify_schnorr(proof, w2)
+
+
+def test_invalid_signature_gives_unverifiable_proof(oracle, backend):
+    from oracle import verifier as V
+    from certificate_stark_amd.prover import SchnorrExample
+    ex = SchnorrExample.build_random(options(), 2, seed=9, backend=backend)
+    ex.sig_s[1, 3] ^= 1
+    proof = ex.prove()
+    w = oracle.SchnorrWitness(2)
+    w.messages[...], w.sig_rx[...], w.sig_s[...] = ex.messages, ex.sig_rx, ex.sig_s
+    with pytest.raises(V.VerifierError):
+        V.verify_schnorr(proof, w)
