@@ -661,44 +661,62 @@ int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t 
     const NttPlan *plan;
     RC_TRY(get_plan(c, log_n, &plan));
     const uint64_t wn = cs::host::root_of_unity(log_n);
-    // one device block of u64: t_alpha | t_beta | adj | b_alpha | b_beta | a_value | a_badj | a_m | a_zc | shifts, then u32: a_reg | a_seq
-    std::vector<uint64_t> blk(3 * nc + 6 * na + b + na);
+    // one device block of u64: t_alpha | t_beta | b_alpha | b_beta | a_value | shifts, then u32: a_reg | a_seq | t_grp | a_grp
+    cs::AirCombineParams p{};
+    std::vector<uint32_t> t_grp(nc), a_grp(na);
+    for (size_t i = 0; i < nc; i++) { // distinct degree adjustments
+        const uint64_t adj = (ce - 1 + n - 1) - s.eval_degree(i, n);
+        uint32_t g = 0;
+        while (g < p.n_tgrp && p.tgrp_adj[g] != adj) g++;
+        if (g == p.n_tgrp) {
+            if (g == cs::AIR_MAX_GROUPS) return fail(CSTARK_ERR_UNSUPPORTED, "too many distinct constraint degrees");
+            p.tgrp_adj[p.n_tgrp++] = adj;
+        }
+        t_grp[i] = g;
+    }
+    for (size_t a = 0; a < na; a++) { // distinct assertion divisors x^m - w^(first m)
+        const uint64_t first = s.a_stride.empty() ? (s.a_last[a] ? n - 1 : 0) : s.a_first[a];
+        const uint64_t m = (!s.a_stride.empty() && s.a_stride[a]) ? n / s.a_stride[a] : 1;
+        const uint64_t zc = cs::host::pow(wn, (first * m) % n);
+        uint32_t g = 0;
+        while (g < p.n_agrp && !(p.agrp_m[g] == m && p.agrp_zc[g] == zc)) g++;
+        if (g == p.n_agrp) {
+            if (g == cs::AIR_MAX_GROUPS) return fail(CSTARK_ERR_UNSUPPORTED, "too many distinct assertion divisors");
+            p.agrp_m[g] = m; p.agrp_zc[g] = zc; p.agrp_badj[g] = ce - 1 + m - (n - 1);
+            p.n_agrp++;
+        }
+        a_grp[a] = g;
+    }
+    std::vector<uint64_t> blk(2 * nc + 3 * na + b + 2 * na + (nc + 1) / 2 + 1);
     uint64_t *q = blk.data();
     memcpy(q, t_alpha, nc * 8); q += nc;
     memcpy(q, t_beta, nc * 8); q += nc;
-    for (size_t i = 0; i < nc; i++) *q++ = (ce - 1 + n - 1) - s.eval_degree(i, n);
     memcpy(q, b_alpha, na * 8); q += na;
     memcpy(q, b_beta, na * 8); q += na;
     for (size_t a = 0; a < na; a++) *q++ = s.a_const.empty() ? assertion_values[a] : s.a_const[a];
-    std::vector<uint64_t> am(na), afirst(na);
-    for (size_t a = 0; a < na; a++) {
-        afirst[a] = s.a_stride.empty() ? (s.a_last[a] ? n - 1 : 0) : s.a_first[a];
-        am[a] = (!s.a_stride.empty() && s.a_stride[a]) ? n / s.a_stride[a] : 1;
-    }
-    for (size_t a = 0; a < na; a++) *q++ = ce - 1 + am[a] - (n - 1);                       // a_badj
-    for (size_t a = 0; a < na; a++) *q++ = am[a];                                          // a_m
-    for (size_t a = 0; a < na; a++) *q++ = cs::host::pow(wn, (afirst[a] * am[a]) % n);     // a_zc
     const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
     uint64_t shift = cs::host::generator();
     for (uint64_t k = 0; k < b; k++) { *q++ = shift; shift = cs::host::mul(shift, wbn); }
     uint32_t *q32 = (uint32_t *)q;
     for (size_t a = 0; a < na; a++) q32[a] = s.a_reg[a];
     for (size_t a = 0; a < na; a++) ((int32_t *)q32)[na + a] = s.a_seq.empty() ? -1 : s.a_seq[a];
+    for (size_t a = 0; a < na; a++) q32[2 * na + a] = a_grp[a];
+    for (size_t i = 0; i < nc; i++) q32[3 * na + i] = t_grp[i];
     const size_t bytes = blk.size() * 8;
     if (bytes > c->desc_bytes) {
-        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); }
+        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); c->desc_buf = nullptr; c->desc_bytes = 0; }
         HIP_TRY(hipMalloc(&c->desc_buf, bytes));
         c->desc_bytes = bytes;
     }
     HIP_TRY(hipMemcpyAsync(c->desc_buf, blk.data(), bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t *d = (const uint64_t *)c->desc_buf;
-    cs::AirCombineParams p{};
     p.lde = d_lde; p.evals = d_evals; p.w = plan->w; p.out = d_out; p.avals = d_avals_lde; p.n_avals = n_avals;
-    p.t_alpha = d; p.t_beta = d + nc; p.adj = d + 2 * nc;
-    const uint64_t *e = d + 3 * nc;
-    p.b_alpha = e; p.b_beta = e + na; p.a_value = e + 2 * na; p.a_badj = e + 3 * na; p.a_m = e + 4 * na; p.a_zc = e + 5 * na; p.shifts = e + 6 * na;
-    p.a_reg = (const uint32_t *)(e + 6 * na + b); p.a_seq = (const int32_t *)(p.a_reg + na);
+    p.t_alpha = d; p.t_beta = d + nc;
+    const uint64_t *e = d + 2 * nc;
+    p.b_alpha = e; p.b_beta = e + na; p.a_value = e + 2 * na; p.shifts = e + 3 * na;
+    p.a_reg = (const uint32_t *)(e + 3 * na + b); p.a_seq = (const int32_t *)(p.a_reg + na);
+    p.a_grp = p.a_reg + 2 * na; p.t_grp = p.a_reg + 3 * na;
     p.w_last = cs::host::inv(wn);
     p.width = s.width; p.n_constraints = (uint32_t)nc; p.n_assertions = (uint32_t)na;
     p.stride = 1u << (log_blowup - log_ce); p.log_n = log_n; p.k0 = k0;

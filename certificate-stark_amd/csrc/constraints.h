@@ -34,18 +34,22 @@ struct CeParams {
     uint32_t log_n, log_b, k0;
 };
 
+constexpr int AIR_MAX_GROUPS = 8;
 // generic merge of materialised constraint evaluations (standalone sub-AIRs); all pointers are device memory
 struct AirCombineParams {
     const uint64_t *lde, *evals, *w, *shifts; // shifts[k] = g * w_{bn}^k for every LDE coset
-    const uint64_t *t_alpha, *t_beta, *adj;   // [n_constraints]; adj = degree adjustment exponent
+    const uint64_t *t_alpha, *t_beta;         // [n_constraints]
     const uint64_t *b_alpha, *b_beta, *a_value;
     const uint32_t *a_reg;                    // [n_assertions]
-    const uint64_t *a_badj, *a_m, *a_zc;      // per assertion: x-power of its adjustment, number of asserted steps m, w^(first*m)
     const int32_t *a_seq;                     // column of `avals` holding the asserted values, or -1 for the constant a_value
     const uint64_t *avals;                    // [nk][n_avals][n] LDE of the sequence-value polynomials (may be null)
     uint64_t *out;
     uint64_t w_last;
     uint32_t width, n_constraints, n_assertions, n_avals, stride, log_n, k0;
+    // grouping (host-built): constraint i uses x^tgrp_adj[t_grp[i]]; assertion a uses divisor / adjustment group a_grp[a]
+    const uint32_t *t_grp, *a_grp; // device
+    uint32_t n_tgrp, n_agrp;
+    uint64_t tgrp_adj[AIR_MAX_GROUPS], agrp_m[AIR_MAX_GROUPS], agrp_zc[AIR_MAX_GROUPS], agrp_badj[AIR_MAX_GROUPS];
 };
 hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_t stream);
 hipError_t launch_eval_transitions_merkle(const uint64_t *lde, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0, unsigned nk,

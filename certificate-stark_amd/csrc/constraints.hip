@@ -883,20 +883,26 @@ __global__ void k_air_combine(AirCombineParams p) {
     if (k % p.stride) { *o = 0; return; }
     const fp shift = p.shifts[k];
     const fp x = fp_mul(shift, p.w[j]);
-    fp acc = 0;
-    for (unsigned i = 0; i < p.n_constraints; i++) {
-        const fp xp = fp_pow(x, p.adj[i]);
-        acc = fp_add(acc, fp_mul(p.evals[((size_t)kk * p.n_constraints + i) * n + j], fp_add(p.t_alpha[i], fp_mul(p.t_beta[i], xp))));
+    // the degree adjustments take a handful of distinct values, and the assertions share a few divisors: one power /
+    // inversion per group and point, not per constraint
+    fp xp[AIR_MAX_GROUPS], zi[AIR_MAX_GROUPS], xb[AIR_MAX_GROUPS];
+    for (unsigned g = 0; g < p.n_tgrp; g++) xp[g] = fp_pow(x, p.tgrp_adj[g]);
+    for (unsigned g = 0; g < p.n_agrp; g++) {
+        zi[g] = fp_inv(fp_sub(fp_pow(x, p.agrp_m[g]), p.agrp_zc[g]));
+        xb[g] = fp_pow(x, p.agrp_badj[g]);
     }
+    fp acc = 0;
+    for (unsigned i = 0; i < p.n_constraints; i++)
+        acc = fp_add(acc, fp_mul(p.evals[((size_t)kk * p.n_constraints + i) * n + j], fp_add(p.t_alpha[i], fp_mul(p.t_beta[i], xp[p.t_grp[i]]))));
     const fp zinv = fp_mul(fp_sub(x, p.w_last), fp_inv(fp_sub(fp_pow(x, n), FP_ONE)));
     acc = fp_mul(acc, zinv);
     // boundary constraints (single, periodic and sequence assertions): divisor x^m - w^(first*m)
     for (unsigned a = 0; a < p.n_assertions; a++) {
+        const unsigned g = p.a_grp[a];
         const fp tv = p.lde[((size_t)kk * p.width + p.a_reg[a]) * n + j];
         const fp cv = p.a_seq[a] >= 0 ? p.avals[((size_t)kk * p.n_avals + p.a_seq[a]) * n + j] : p.a_value[a];
-        const fp z = fp_sub(fp_pow(x, p.a_m[a]), p.a_zc[a]);
-        const fp term = fp_mul(fp_sub(tv, cv), fp_add(p.b_alpha[a], fp_mul(p.b_beta[a], fp_pow(x, p.a_badj[a]))));
-        acc = fp_add(acc, fp_mul(term, fp_inv(z)));
+        const fp term = fp_mul(fp_sub(tv, cv), fp_add(p.b_alpha[a], fp_mul(p.b_beta[a], xb[g])));
+        acc = fp_add(acc, fp_mul(term, zi[g]));
     }
     *o = acc;
 }
