@@ -244,17 +244,34 @@ __constant__ Instr c_pre[3][NROLE] = {
 #undef NONE
 #undef NOPS6
 
+// phase kinds of the three programs, known at compile time: 1 product phase, 0 linear phase, -1 end
+constexpr int8_t PHASE_KIND[3][NPHASE] = {{1, 1, 0, 1, 0, -1}, {1, 0, 1, 0, 1, 0}, {1, 0, 1, 0, 1, 0}};
+// the programs live in LDS while a ladder runs: every lane fetches its own instruction each phase, and a divergent read
+// of __constant__ memory is a vector load with global-memory latency.  small[c + 4] = the field element c for |c| <= 4:
+// integer coefficients are applied as one multiplication, the same code for every lane (a switch over the coefficient
+// would run all of its cases serially in a wave whose lanes hold different instructions).
+struct ProgLds { Instr prog[3][NPHASE][NROLE]; Instr pre[3][NROLE]; fp small[9]; };
+__device__ __forceinline__ void load_programs(ProgLds &p, int tid, int nthreads) {
+    Instr *dst = &p.prog[0][0][0];
+    const Instr *src = &c_prog[0][0][0];
+    for (int i = tid; i < 3 * NPHASE * NROLE; i += nthreads) dst[i] = src[i];
+    for (int i = tid; i < 3 * NROLE; i += nthreads) (&p.pre[0][0])[i] = (&c_pre[0][0])[i];
+    if (tid < 9) {
+        const int c = tid - 4;
+        const fp m = fp_mul((uint64_t)(c < 0 ? -c : c), FP_R2); // |c| in Montgomery form
+        p.small[tid] = c < 0 ? fp_neg(m) : m;
+    }
+}
+
 // F_p2 component `comp` (0..2) of an integer combination of slots; comp2 >= 0 adds a second component
 // (the Karatsuba operand sums c_i + c_j)
-__device__ __forceinline__ Fp2 lincomb2(const fp (*slot)[6], const Term (&t)[3], int comp, int comp2) {
+__device__ __forceinline__ Fp2 lincomb2(const fp (*slot)[6], const Term (&t)[3], int comp, const fp *small) {
     Fp2 r = {0, 0};
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (t[k].coef == 0) continue;
+    for (int k = 0; k < 3; k++) { // unused terms have coefficient 0 (and slot 0): they add 0
         const fp *s = slot[t[k].slot];
-        Fp2 v = {s[2 * comp], s[2 * comp + 1]};
-        if (comp2 >= 0) v = fp2_add(v, {s[2 * comp2], s[2 * comp2 + 1]});
-        r = fp2_add(r, {fp_mul_small(v.a, t[k].coef), fp_mul_small(v.b, t[k].coef)});
+        const fp c = small[t[k].coef + 4];
+        r = fp2_add(r, {fp_mul(s[2 * comp], c), fp_mul(s[2 * comp + 1], c)});
     }
     return r;
 }
@@ -273,31 +290,30 @@ __device__ __forceinline__ Fp2 operand2(const fp (*slot)[6], const Term t, int c
 //   recombination  lane (m, r), r < 3: F_p2 coefficient r of the F_p6 result of instruction m
 //   linear phase   lane (m, r): coefficient r of an integer combination of slots
 // Called by all lanes of the workgroup (barriers inside).  prod = this point's [6][6] F_p2 scratch.
-__device__ __forceinline__ void run_linear_phase(const Instr (&prog)[NROLE], fp (*slot)[6], int lane, bool enabled) {
+__device__ __forceinline__ void run_linear_phase(const Instr (&prog)[NROLE], const fp *small, fp (*slot)[6], int lane, bool enabled) {
     const int m = lane / 3, r = lane % 3;
     Fp2 c = {0, 0};
     int out = -1;
     if (enabled && m < NROLE) {
         const Instr ins = prog[m];
         out = ins.out;
-        if (out >= 0) c = lincomb2(slot, ins.a, r, -1);
+        if (out >= 0) c = lincomb2(slot, ins.a, r, small);
     }
     __syncthreads();
     if (out >= 0) { slot[out][2 * r] = c.a; slot[out][2 * r + 1] = c.b; }
     __syncthreads();
 }
 
-__device__ __forceinline__ void run_point_op(int op, fp (*slot)[6], Fp2 (*prod)[6], int lane, bool enabled) {
-    if (op != OP_DOUBLE) run_linear_phase(c_pre[op], slot, lane, enabled);
-#pragma unroll 1
+template <int OP>
+__device__ __forceinline__ void run_point_op(const ProgLds &pg, fp (*slot)[6], Fp2 (*prod)[6], int lane, bool enabled) {
+    if (OP != OP_DOUBLE) run_linear_phase(pg.pre[OP], pg.small, slot, lane, enabled);
+#pragma unroll
     for (int ph = 0; ph < NPHASE; ph++) {
-        const bool is_nop = c_prog[op][ph][0].out < 0;
-        if (is_nop) break;
-        const bool is_mul = c_prog[op][ph][0].b[0].coef != 0; // phases are homogeneous
-        if (is_mul) {
+        if (PHASE_KIND[OP][ph] < 0) break;
+        if (PHASE_KIND[OP][ph] == 1) {
             const int m = lane / 6, q = lane % 6;
             if (enabled && m < NROLE) {
-                const Instr ins = c_prog[op][ph][m];
+                const Instr ins = pg.prog[OP][ph][m];
                 if (ins.out >= 0) {
                     const int c1 = q < 3 ? q : (q == 5 ? 1 : 0), c2 = q < 3 ? -1 : (q == 3 ? 1 : 2);
                     prod[m][q] = fp2_mul(operand2(slot, ins.a[0], c1, c2), operand2(slot, ins.b[0], c1, c2));
@@ -306,7 +322,7 @@ __device__ __forceinline__ void run_point_op(int op, fp (*slot)[6], Fp2 (*prod)[
             __syncthreads();
             const int m2 = lane / 3, r = lane % 3;
             if (enabled && m2 < NROLE) {
-                const int out = c_prog[op][ph][m2].out;
+                const int out = pg.prog[OP][ph][m2].out;
                 if (out >= 0) {
                     const Fp2 d0 = prod[m2][0], d1 = prod[m2][1], d2 = prod[m2][2];
                     Fp2 c;
@@ -319,7 +335,7 @@ __device__ __forceinline__ void run_point_op(int op, fp (*slot)[6], Fp2 (*prod)[
             }
             __syncthreads();
         } else {
-            run_linear_phase(c_prog[op][ph], slot, lane, enabled);
+            run_linear_phase(pg.prog[OP][ph], pg.small, slot, lane, enabled);
         }
     }
 }
@@ -336,8 +352,10 @@ __global__ __launch_bounds__(64) void k_trace_schnorr_ec(TxWitnessDev w, fp *__r
     __shared__ fp slots[NSLOT][6];
     __shared__ Fp2 prods[6][6];
     __shared__ uint8_t sbytes[32];
+    __shared__ ProgLds pg;
     const int t = blockIdx.x >> 1, g = blockIdx.x & 1, lane = threadIdx.x;
     fp(*slot)[6] = slots;
+    load_programs(pg, lane, 64);
 
     // scalars: s from the signature, h from the message hash (little-endian bytes, Lsb0 bit order)
     if (lane < 32) sbytes[lane] = g == 0 ? w.sig_s[32 * (size_t)t + lane] : (uint8_t)(w.h_limbs[4 * (size_t)t + (lane >> 3)] >> (8 * (lane & 7)));
@@ -358,10 +376,10 @@ __global__ __launch_bounds__(64) void k_trace_schnorr_ec(TxWitnessDev w, fp *__r
     for (int step = 0; step < MERKLE_LEN - 1; step++) {
         if (step < SCALAR_MUL_LEN) {
             if ((step & 1) == 0) {
-                run_point_op(OP_DOUBLE, slot, prods, lane, true);
+                run_point_op<OP_DOUBLE>(pg, slot, prods, lane, true);
             } else {
                 const int bit = bit_le(sbytes, 254 - (step >> 1)); // MSB first, src/schnorr/trace.rs:79-82
-                if (bit) run_point_op(OP_ADD_MIXED, slot, prods, lane, true); // uniform over the wave
+                if (bit) run_point_op<OP_ADD_MIXED>(pg, slot, prods, lane, true); // uniform over the wave
             }
         } // step == SCALAR_MUL_LEN: the row is a copy here; k_trace_schnorr_final rewrites registers 0..17 of it
         const int r = (step + 1) & 63;
@@ -379,7 +397,9 @@ template <bool STANDALONE>
 __global__ __launch_bounds__(64) void k_trace_schnorr_final(fp *__restrict__ trace, size_t n) {
     __shared__ fp slots[NSLOT][6];
     __shared__ Fp2 prods[6][6];
+    __shared__ ProgLds pg;
     const int t = blockIdx.x, lane = threadIdx.x;
+    load_programs(pg, lane, 64);
     const size_t last = (STANDALONE ? (size_t)t * MERKLE_LEN : (size_t)t * TXC + MERKLE_LEN) + MERKLE_LEN - 1;
     if (lane < 18) {
         slots[lane / 6][lane % 6] = trace[(size_t)lane * n + last - 1];
@@ -387,7 +407,7 @@ __global__ __launch_bounds__(64) void k_trace_schnorr_final(fp *__restrict__ tra
     }
     if (lane < 6) slots[SB3][lane] = c_b3[lane];
     __syncthreads();
-    run_point_op(OP_ADD_FULL, slots, prods, lane, true);
+    run_point_op<OP_ADD_FULL>(pg, slots, prods, lane, true);
     if (lane == 0) fp6_store(slots[SX], fp6_mul(fp6_load(slots[SX]), fp6_inv(fp6_load(slots[SZ]))));
     __syncthreads();
     if (lane < 18) trace[(size_t)lane * n + last] = slots[lane / 6][lane % 6];
