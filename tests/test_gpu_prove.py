@@ -114,3 +114,33 @@ def test_proof_bytes_equal_the_cpu_restatement(n_tx, depth, opts):
     proof = tx.prove()
     assert proof == OP.prove(w, opts)
     assert V.verify(proof, *tx.pub_inputs(), options=list(opts))
+
+
+def test_smallest_and_largest_traces():
+    """One transfer (2^10 rows, 2^13-point domain) and 2048 transfers (2^21 rows: the 2^24-point domain is the library's maximum)."""
+    import torch
+    from oracle import verifier as V
+    from certificate_stark_amd.prover import TransactionExample, TransactionMetadata
+    tx = example(1, 3, seed=123)
+    proof = tx.prove()
+    assert V.verify(proof, *tx.pub_inputs())
+    tx.prover.backend.close()
+    meta = TransactionMetadata.build_random(2048, 15, seed=2048)
+    big = TransactionExample(build_options(), meta)
+    proof = big.prove()
+    d = V.parse(proof)
+    assert d["log_n"] == 21 and len(d["remainder"]) == 256
+    assert V.verify(proof, *big.pub_inputs())
+    big.prover.backend.close()
+    torch.cuda.empty_cache()
+
+
+def test_transaction_count_must_be_a_power_of_two():
+    from certificate_stark_amd._lib import CstarkError
+    tx = example(3, 3)
+    with pytest.raises(ValueError):            # the host mirror checks first
+        tx.prove()
+    b = tx.prover.backend
+    b.upload_witness(tx.tx_metadata)
+    with pytest.raises(CstarkError):           # and so does the library
+        b.prove(build_options())
