@@ -14,7 +14,8 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libcstark_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-const-variable", "-Wno-unused-variable"]
+         "-Wno-unused-const-variable", "-Wno-unused-variable",
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]  # MFMA results land in VGPRs: the recombination reads them without v_accvgpr_read
 
 
 def hipcc():

@@ -15,7 +15,7 @@ __host__ __device__ constexpr int tx_degree_group(int i) {
 constexpr unsigned TX_GROUP_BASE[5] = {5, 4, 3, 2, 1};
 constexpr unsigned TX_GROUP_CYCLES[5] = {2, 2, 1, 1, 1};
 
-constexpr int CE_RTAB_WORDS = 4096;
+constexpr int CE_RTAB_WORDS = 8192;
 constexpr int CE_COSET_CONSTS = 8; // per coset: shift, 1/(shift^n - 1), shift^adj[0..5), shift^badj
 
 struct CeParams {

@@ -22,6 +22,7 @@
 //    random linear combination (the index aliasing of src/constants.rs:56-68 is reproduced because every
 //    contribution still uses the coefficient of the slot the reference adds it to).
 #include "constraints.h"
+#include "mds_mfma.cuh"
 #include "rescue.cuh"
 #include "tower.cuh"
 
@@ -437,15 +438,27 @@ __constant__ RoundWindow c_windows[5] = {
 __constant__ int8_t c_window_groups[5][2][3] = {
     {{0, 1, -1}, {-1, -1, -1}}, {{1, 2, 0}, {1, 2, 0}}, {{0, 2, -1}, {0, 2, -1}}, {{2, -1, -1}, {2, -1, -1}}, {{2, -1, -1}, {-1, -1, -1}}};
 constexpr int RT_SECTIONS = 5 * 2 * 4;                 // (window, flag set, {alpha, beta of up to 3 groups})
-// CeParams::rtab (u64 words): A[sections][64] | limbs of U[sections][14] (4 dwords each) | limbs of INV_MDS[14][14]
-constexpr int RT_A = 0, RT_UL = RT_SECTIONS * 64, RT_ML = RT_UL + RT_SECTIONS * 14 * 2, RT_SIZE = RT_ML + 14 * 14 * 2;
+// CeParams::rtab (u64 words): A[sections][64] | limbs of U[sections][14] (4 dwords each) | matrix-core table of INV_MDS
+constexpr int RT_A = 0, RT_UL = RT_SECTIONS * 64, RT_ML = RT_UL + RT_SECTIONS * 14 * 2, RT_MT = RT_ML + 14 * 14 * 2;
+constexpr size_t MT_BYTES = (mdsmfma::table_bytes(14) + 15) & ~(size_t)15;
+constexpr int RT_SIZE = RT_MT + (int)(MT_BYTES / 8);
 static_assert(RT_SIZE <= CE_RTAB_WORDS, "rtab size");
+constexpr size_t ROUNDS_LDS = MT_BYTES + (FNT / 64) * 64 * mdsmfma::ROW_BYTES; // table + one staging image per wave
+#ifdef CS_ROUNDS_MFMA
+constexpr size_t ROUNDS_DYN_LDS = ROUNDS_LDS;
+#else
+constexpr size_t ROUNDS_DYN_LDS = 0;
+#endif
 
 // The forward half of the round gadget is linear in cube(cur): sum_i c_i (MDS cube + ark1)_i = (MDS^T c) . cube + c . ark1.
 // With c_i = alpha_i + beta_i x^adj_g(i) this is one 14-term dot product per (alpha | beta restricted to a degree group) instead of
 // one per result slot.  k_rounds_setup folds the coefficients of one proof through MDS (U) and through the round constants, whose
 // extension has period 8 in j on every coset (A[k][j & 7]).  Exact arithmetic: the merged value is unchanged.
 __global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict__ ptab, fp *__restrict__ rtab) {
+    if (blockIdx.x >= RT_SECTIONS) { // the constant matrix of the inverse half as a matrix-core table (region zero-filled by the launcher)
+        if (threadIdx.x < 16) mdsmfma::build_table_entry((uint8_t *)(rtab + RT_MT), c_inv_mds, 14, blockIdx.x - RT_SECTIONS, threadIdx.x);
+        return;
+    }
     const int sec = blockIdx.x, wdx = sec >> 3, fs = (sec >> 2) & 1, slot = sec & 3;
     const RoundWindow w = c_windows[wdx];
     const int res = fs ? w.res_b : w.res_a;
@@ -463,7 +476,7 @@ __global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict
         for (int i = 0; i < 14; i++) u = fp_add(u, fp_mul(gam[i], c_mds[i * 14 + t]));
         split_limbs(u, (uint32_t *)(rtab + RT_UL) + (sec * 14 + t) * 4);
     }
-    if (sec == 0) // the constant matrix of the inverse half, in the same limb form
+    if (sec == 0) // limb form of the inverse matrix (VALU variant of the inverse half)
         for (int e = t; e < 196; e += blockDim.x) split_limbs(c_inv_mds[e], (uint32_t *)(rtab + RT_ML) + e * 4);
     if (t < 64) {
         const int k = t >> 3, r = t & 7;
@@ -473,13 +486,15 @@ __global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict
     }
 }
 
-__device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const fp *__restrict__ rtab, unsigned k, unsigned jr) {
+__device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const fp *__restrict__ rtab, unsigned k, unsigned jr, const uint8_t *mtab,
+                                             uint8_t *stage) {
+    const int lane = threadIdx.x & 63;
     const fp flags[4] = {f.pv(P_SETUP), f.pv(P_HASH), f.pv(P_SCHNORR_HASH), fp_add(f.pv(P_SETUP), f.pv(P_HASH))};
     fp ark2[14];
 #pragma unroll
     for (int j = 0; j < 14; j++) ark2[j] = f.pv(P_ARK + 14 + j);
     const fp *atab = rtab + RT_A + k * 8 + jr;
-    const uint32_t *ul = (const uint32_t *)(rtab + RT_UL), *ml = (const uint32_t *)(rtab + RT_ML);
+    const uint32_t *ul = (const uint32_t *)(rtab + RT_UL);
 #pragma unroll 1
     for (int wdx = 0; wdx < 5; wdx++) {
         const RoundWindow w = c_windows[wdx];
@@ -489,11 +504,45 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const f
             cube[j] = fp_cube(f.cur(w.reg + j));
             d[j] = fp_sub(f.next(w.reg + j), ark2[j]);
         }
-        // inverse half: cube(INV_MDS (next - ark2))_i against the coefficients of both flag sets
+        // inverse half: cube(INV_MDS (next - ark2))_i against the coefficients of both flag sets.  Default: limb dot products on
+        // the vector ALU.  With -DCS_ROUNDS_MFMA the 14x14 product runs on the matrix cores for the 64 points of the wave
+        // (mds_mfma.cuh; the staging image is private to the wave, whose LDS operations execute in order, so no workgroup
+        // barrier is involved) -- bit-identical, and measured at the SAME kernel time on MI355X this round (6.65 ms): the
+        // recombination of the byte diagonals and the serialisation of MFMA and dependent VALU work inside a wave eat the gain.
+#ifdef CS_ROUNDS_MFMA
+        fp yv[14];
+        {
+            mdsmfma::stage_vector(stage, lane, d);
+            __builtin_amdgcn_wave_barrier();
+            mdsmfma::BFrags bf;
+            mdsmfma::load_bfrags(bf, stage, lane);
+            __builtin_amdgcn_wave_barrier();
+            uint64_t *img = (uint64_t *)stage;
+            constexpr int RW = mdsmfma::ROW_BYTES / 8;
+#pragma unroll
+            for (int T = 0; T < 7; T++) { // lane (n, g) gets output 2T + g of points n and 32 + n: hand them back to the points' own lanes
+                fp y2[2];
+                mdsmfma::tile_product(mtab, 7, T, bf, lane, y2);
+                img[(lane & 31) * RW + 2 * T + (lane >> 5)] = y2[0];
+                img[(32 + (lane & 31)) * RW + 2 * T + (lane >> 5)] = y2[1];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 14; i++) yv[i] = img[lane * RW + i];
+            __builtin_amdgcn_wave_barrier();
+        }
+#endif
         Acc128 sa = acc_zero(), sb = acc_zero();
+#ifdef CS_ROUNDS_MFMA
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const fp s2 = fp_cube(yv[i]);
+#else
+        const uint32_t *ml = (const uint32_t *)(rtab + RT_ML);
 #pragma unroll 1
         for (int i = 0; i < 14; i++) {
             const fp s2 = fp_cube(dot14l(ml + i * 56, d));
+#endif
             acc_mad(sa, acc.coef(w.res_a + i), s2);
             if (w.flag_b >= 0) acc_mad(sb, acc.coef(w.res_b + i), s2);
             if (i == 6) { acc_fold(sa); acc_fold(sb); }
@@ -708,7 +757,11 @@ __device__ __forceinline__ void fused_linear_c(Fused &acc, const Frame &f) {
 
 // grid = (n / FNT, nk)
 #ifndef CS_ROUNDS_WAVES
+#ifdef CS_ROUNDS_MFMA
+#define CS_ROUNDS_WAVES 2
+#else
 #define CS_ROUNDS_WAVES 3
+#endif
 #endif
 #ifndef CS_ROUNDS_UNROLL
 #define CS_ROUNDS_UNROLL 1
@@ -716,6 +769,14 @@ __device__ __forceinline__ void fused_linear_c(Fused &acc, const Frame &f) {
 template <int PART>
 __global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : 2) void k_eval_fused(CeParams p) {
     __shared__ fp xp_lds[5 * FNT];
+    extern __shared__ __attribute__((aligned(16))) uint8_t rounds_lds[]; // PART_ROUNDS only: ROUNDS_LDS bytes
+#ifdef CS_ROUNDS_MFMA
+    if (PART == PART_ROUNDS) {
+        const uint4 *src = (const uint4 *)(p.rtab + RT_MT);
+        for (unsigned i = threadIdx.x; i < MT_BYTES / 16; i += FNT) ((uint4 *)rounds_lds)[i] = src[i];
+        __syncthreads();
+    }
+#endif
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kk = blockIdx.y;
@@ -727,7 +788,8 @@ __global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : 2) voi
     for (int g = 0; g < 5; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
     Fused acc{p.coef, p.coef + 115, xp_lds, acc_zero(), 0, 0};
 
-    if (PART == PART_ROUNDS) fused_rounds(acc, f, p.rtab, p.k0 + kk, (unsigned)(j & 7));
+    if (PART == PART_ROUNDS)
+        fused_rounds(acc, f, p.rtab, p.k0 + kk, (unsigned)(j & 7), rounds_lds, rounds_lds + MT_BYTES + (size_t)(threadIdx.x >> 6) * 64 * mdsmfma::ROW_BYTES);
     if (PART >= PART_DBL0 && PART <= PART_FINAL) {
         const fp scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING);
         if (PART == PART_DBL0) fused_doubling(acc, f, 0, doubling);
@@ -947,10 +1009,12 @@ hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t s
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
     // part_events (optional, CE_NUM_PARTS + 1 events): recorded around every part so that callers can time each launch
-    hipLaunchKernelGGL(k_rounds_setup, dim3(RT_SECTIONS), dim3(64), 0, stream, p.coef, p.ptab, p.rtab);
+    (void)hipMemsetAsync(p.rtab + RT_MT, 0, MT_BYTES, stream);
+    hipLaunchKernelGGL(k_rounds_setup, dim3(RT_SECTIONS + 14), dim3(64), 0, stream, p.coef, p.ptab, p.rtab);
+    (void)hipFuncSetAttribute((const void *)k_eval_fused<PART_ROUNDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROUNDS_LDS);
 #define CS_PART(PART)                                                                    \
     if (part_events) (void)hipEventRecord(part_events[PART], stream);                    \
-    hipLaunchKernelGGL(k_eval_fused<PART>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(k_eval_fused<PART>, grid, block, PART == PART_ROUNDS ? ROUNDS_DYN_LDS : 0, stream, p);
     CS_PART(PART_ROUNDS) CS_PART(PART_DBL0) CS_PART(PART_ADD0) CS_PART(PART_DBL1) CS_PART(PART_ADD1) CS_PART(PART_FINAL)
     CS_PART(PART_LIN_A) CS_PART(PART_LIN_B) CS_PART(PART_LIN_C)
 #undef CS_PART

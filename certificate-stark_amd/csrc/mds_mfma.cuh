@@ -65,18 +65,29 @@ __device__ inline void build_table_entry(uint8_t *tab, const fp *m, int nrows, i
     }
 }
 
-// the 16 non-negative 24-bit diagonals of one output -> Montgomery-reduced field element
+// the 15 non-negative 24-bit diagonals of one output -> Montgomery-reduced field element.
+// Diagonals d, d+3, d+6, ... are disjoint 24-bit fields, so the three residue classes are packed without carries -- directly at
+// their bit offsets 0 / 8 / 16 -- and the 128-bit value is three word-wise additions (plus the row constant).  32-bit
+// operations throughout: v_lshl_or_b32 / v_lshrrev_b32 for the packing, v_add_co / v_addc chains for the sums.
+__device__ __forceinline__ void add128(uint32_t (&a)[4], const uint32_t (&b)[4]) {
+    unsigned c;
+    a[0] = __builtin_addc(a[0], b[0], 0u, &c);
+    a[1] = __builtin_addc(a[1], b[1], c, &c);
+    a[2] = __builtin_addc(a[2], b[2], c, &c);
+    a[3] = a[3] + b[3] + c;
+}
 __device__ __forceinline__ fp recombine(const v16i &acc, uint64_t klo, uint64_t khi) {
-    // diagonals d, d+3, d+6, ... are disjoint 24-bit fields: three carry-free concatenations, then two shifted additions
-    u128 g[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const uint32_t f0 = (uint32_t)acc[r], f1 = (uint32_t)acc[r + 3], f2 = (uint32_t)acc[r + 6], f3 = (uint32_t)acc[r + 9], f4 = (uint32_t)acc[r + 12];
-        const uint32_t w0 = f0 | (f1 << 24), w1 = (f1 >> 8) | (f2 << 16), w2 = (f2 >> 16) | (f3 << 8), w3 = f4;
-        g[r] = ((u128)(((uint64_t)w3 << 32) | w2) << 64) | (((uint64_t)w1 << 32) | w0);
-    }
-    const u128 v = g[0] + (g[1] << 8) + (g[2] << 16) + (((u128)khi << 64) | klo);
-    Acc128 a{(uint64_t)v, (uint64_t)(v >> 64)};
+    const uint32_t a0 = acc[0], a3 = acc[3], a6 = acc[6], a9 = acc[9], a12 = acc[12];   // offset 0:  bits 0, 24, 48, 72, 96
+    const uint32_t b1 = acc[1], b4 = acc[4], b7 = acc[7], b10 = acc[10], b13 = acc[13]; // offset 8:  bits 8, 32, 56, 80, 104
+    const uint32_t c2 = acc[2], c5 = acc[5], c8 = acc[8], c11 = acc[11], c14 = acc[14]; // offset 16: bits 16, 40, 64, 88, 112
+    uint32_t v[4] = {a0 | (a3 << 24), (a3 >> 8) | (a6 << 16), (a6 >> 16) | (a9 << 8), a12};
+    const uint32_t g1[4] = {b1 << 8, b4 | (b7 << 24), (b7 >> 8) | (b10 << 16), (b10 >> 16) | (b13 << 8)};
+    const uint32_t g2[4] = {c2 << 16, (c2 >> 16) | (c5 << 8), c8 | (c11 << 24), (c11 >> 8) | (c14 << 16)};
+    const uint32_t kk[4] = {(uint32_t)klo, (uint32_t)(klo >> 32), (uint32_t)khi, (uint32_t)(khi >> 32)};
+    add128(v, g1);
+    add128(v, g2);
+    add128(v, kk);
+    Acc128 a{((uint64_t)v[1] << 32) | v[0], ((uint64_t)v[3] << 32) | v[2]};
     acc_fold(a);
     return acc_reduce(a);
 }

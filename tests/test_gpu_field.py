@@ -66,3 +66,28 @@ def test_fp6_ops(oracle, backend):
     assert (_run(backend, "cstark_debug_fp6_op", a, b, n, 0, 6 * n) == exp_mul).all()
     assert (_run(backend, "cstark_debug_fp6_op", a, None, n, 1, 6 * n) == exp_sqr).all()
     assert (_run(backend, "cstark_debug_fp6_op", a, None, n, 2, 6 * n) == exp_inv).all()
+
+
+def test_matrix_core_mds_product_is_exact(backend):
+    """mds_mfma.cuh: INV_MDS times a vector through the int8 matrix cores (byte-diagonal GEMM with signed digits and offsets)
+    equals the 128-bit carry-propagating scalar code bit for bit, including the extreme operand patterns."""
+    import ctypes as C
+    from certificate_stark_amd.backend import to_numpy_u64
+    npts = 1 << 14
+    rng = np.random.default_rng(99)
+    x = rng.integers(0, P, size=(14, npts), dtype=np.uint64)
+    x[:, 0] = 0
+    x[:, 1] = P - 1
+    x[:, 2] = 0x0080808080808080
+    x[:, 3] = 0x417fffffffffffff
+    x[:, 4] = 0x007f7f7f7f7f7f7f
+    x[:, 5] = np.arange(14, dtype=np.uint64)
+    d_in = backend.from_numpy_u64(x)
+    outs = []
+    for use_mfma in (0, 1):
+        d_out = backend.empty_u64(14, npts)
+        ms = C.c_float()
+        assert backend.lib.cstark_debug_mds(C.c_void_p(backend.stream.cuda_stream), backend._ptr(d_in), backend._ptr(d_out), C.c_size_t(npts),
+                                            use_mfma, 1, C.byref(ms)) == 0
+        outs.append(to_numpy_u64(d_out))
+    assert (outs[0] == outs[1]).all()

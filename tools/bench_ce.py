@@ -34,3 +34,6 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 print("constraints: %.3f ms per evaluation (2^%d x 8 points)" % (e0.elapsed_time(e1) / reps, log_n))
+b.set_part_timing(True)
+b.evaluate_constraints(lde, cf, pub, 15, out=out)
+print("parts:", {k: round(v, 3) for k, v in b.constraint_part_ms().items()})
