@@ -487,23 +487,21 @@ __global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict
 }
 
 __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const fp *__restrict__ rtab, unsigned k, unsigned jr, const uint8_t *mtab,
-                                             uint8_t *stage) {
+                                             uint8_t *stage, const fp *ark2_lds) {
     const int lane = threadIdx.x & 63;
+    const fp *ark2 = ark2_lds + jr * 14;
     const fp flags[4] = {f.pv(P_SETUP), f.pv(P_HASH), f.pv(P_SCHNORR_HASH), fp_add(f.pv(P_SETUP), f.pv(P_HASH))};
-    fp ark2[14];
-#pragma unroll
-    for (int j = 0; j < 14; j++) ark2[j] = f.pv(P_ARK + 14 + j);
     const fp *atab = rtab + RT_A + k * 8 + jr;
     const uint32_t *ul = (const uint32_t *)(rtab + RT_UL);
 #pragma unroll 1
     for (int wdx = 0; wdx < 5; wdx++) {
         const RoundWindow w = c_windows[wdx];
-        fp cube[14], d[14];
+        // register budget (168 VGPRs at 3 waves per SIMD): the 14 round constants of the inverse half are re-read per window
+        // from LDS (their extension has period 8 in j: 8 x 14 values per workgroup) and the cubes of the forward half are
+        // formed after the inverse half, not before
+        fp d[14];
 #pragma unroll
-        for (int j = 0; j < 14; j++) {
-            cube[j] = fp_cube(f.cur(w.reg + j));
-            d[j] = fp_sub(f.next(w.reg + j), ark2[j]);
-        }
+        for (int j = 0; j < 14; j++) d[j] = fp_sub(f.next(w.reg + j), ark2[j]);
         // inverse half: cube(INV_MDS (next - ark2))_i against the coefficients of both flag sets.  Default: limb dot products on
         // the vector ALU.  With -DCS_ROUNDS_MFMA the 14x14 product runs on the matrix cores for the 64 points of the wave
         // (mds_mfma.cuh; the staging image is private to the wave, whose LDS operations execute in order, so no workgroup
@@ -550,6 +548,9 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const f
         acc_fold(sa);
         acc_fold(sb);
         // forward half through the folded vectors
+        fp cube[14];
+#pragma unroll
+        for (int j = 0; j < 14; j++) cube[j] = fp_cube(f.cur(w.reg + j));
 #pragma unroll 1
         for (int fs = 0; fs < 2; fs++) {
             if (fs == 1 && w.flag_b < 0) break;
@@ -757,11 +758,7 @@ __device__ __forceinline__ void fused_linear_c(Fused &acc, const Frame &f) {
 
 // grid = (n / FNT, nk)
 #ifndef CS_ROUNDS_WAVES
-#ifdef CS_ROUNDS_MFMA
-#define CS_ROUNDS_WAVES 2
-#else
 #define CS_ROUNDS_WAVES 3
-#endif
 #endif
 #ifndef CS_ROUNDS_UNROLL
 #define CS_ROUNDS_UNROLL 1
@@ -788,8 +785,16 @@ __global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : 2) voi
     for (int g = 0; g < 5; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
     Fused acc{p.coef, p.coef + 115, xp_lds, acc_zero(), 0, 0};
 
-    if (PART == PART_ROUNDS)
-        fused_rounds(acc, f, p.rtab, p.k0 + kk, (unsigned)(j & 7), rounds_lds, rounds_lds + MT_BYTES + (size_t)(threadIdx.x >> 6) * 64 * mdsmfma::ROW_BYTES);
+    if (PART == PART_ROUNDS) {
+        __shared__ fp ark2_lds[8 * 14];
+        if (threadIdx.x < 8 * 14) { // row r = j mod 8 of the workgroup's first rows (FNT is a multiple of 8), constant c
+            const unsigned r = threadIdx.x / 14, c = threadIdx.x % 14;
+            ark2_lds[threadIdx.x] = p.ptab[((size_t)(p.k0 + kk) * 48 + P_ARK + 14 + c) * 1024 + ((blockIdx.x * (size_t)FNT + r) & 1023)];
+        }
+        __syncthreads();
+        fused_rounds(acc, f, p.rtab, p.k0 + kk, (unsigned)(j & 7), rounds_lds, rounds_lds + MT_BYTES + (size_t)(threadIdx.x >> 6) * 64 * mdsmfma::ROW_BYTES,
+                     ark2_lds);
+    }
     if (PART >= PART_DBL0 && PART <= PART_FINAL) {
         const fp scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING);
         if (PART == PART_DBL0) fused_doubling(acc, f, 0, doubling);
