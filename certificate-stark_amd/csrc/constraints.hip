@@ -623,6 +623,28 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &
     acc.term(base + 14, c_is_binary(bit));
     acc.end(tx_hash);
     Acc128 s_copy = acc_zero(), s_init = acc_zero(); // two sections accumulated side by side (7 + 28 terms)
+#ifndef CS_LINB_UNROLLED // rolled: a small register footprint and more resident waves beat the unrolled form (2.35 -> 2.0 ms)
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        const int b = base + 15 * k;
+#pragma unroll 1
+        for (int i = 0; i < 7; i++) {
+            const fp ci = f.cur(b + i), dd = fp_sub(ci, f.next(b + i));
+            const fp c0 = acc.coef(b + i);
+            acc_mad(s_copy, c0, dd);
+            acc_mad(s_init, c0, fp_mul(not_bit, dd));
+            acc_mad(s_init, acc.coef(b + 7 + i), fp_mul(bit, fp_sub(ci, f.next(b + 7 + i))));
+            if (i & 1) acc_fold(s_init);
+        }
+        acc_fold(s_copy);
+        acc_fold(s_init);
+    }
+#pragma unroll 1
+    for (int i = 0; i < 14; i++) {
+        acc_mad(s_init, acc.coef(base + i), fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i))));
+        if ((i & 3) == 3) acc_fold(s_init);
+    }
+#else
     int cnt = 0;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -644,6 +666,7 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &
         acc_mad(s_init, acc.coef(base + i), fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i))));
         if ((i & 3) == 3) acc_fold(s_init);
     }
+#endif
     acc_fold(s_init);
     acc.total = fp_add(acc.total, fp_add(fp_mul(hash_copy, acc_reduce(s_copy)), fp_mul(hash_init, acc_reduce(s_init))));
 }
@@ -763,8 +786,14 @@ __device__ __forceinline__ void fused_linear_c(Fused &acc, const Frame &f) {
 #ifndef CS_ROUNDS_UNROLL
 #define CS_ROUNDS_UNROLL 1
 #endif
+#ifndef CS_EC_WAVES
+#define CS_EC_WAVES 2
+#endif
+#ifndef CS_LIN_WAVES
+#define CS_LIN_WAVES 4
+#endif
 template <int PART>
-__global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : 2) void k_eval_fused(CeParams p) {
+__global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : (PART >= PART_DBL0 && PART <= PART_FINAL) ? CS_EC_WAVES : PART == PART_LIN_C ? 2 : CS_LIN_WAVES) void k_eval_fused(CeParams p) {
     __shared__ fp xp_lds[5 * FNT];
     extern __shared__ __attribute__((aligned(16))) uint8_t rounds_lds[]; // PART_ROUNDS only: ROUNDS_LDS bytes
 #ifdef CS_ROUNDS_MFMA
