@@ -16,7 +16,29 @@ __device__ __forceinline__ Fp2 fp2_dbl(Fp2 x) { return {fp_dbl(x.a), fp_dbl(x.b)
 __device__ __forceinline__ Fp2 fp2_neg(Fp2 x) { return {fp_neg(x.a), fp_neg(x.b)}; }
 
 // (a0 + a1 u)(b0 + b1 u) with u^2 = 2u + 2:  c0 = a0 b0 + 2 a1 b1,  c1 = a0 b1 + a1 b0 + 2 a1 b1.
-// Three products: a0 b1 + a1 b0 = a0 b0 + a1 b1 - (a0 - a1)(b0 - b1).
+// Karatsuba on UNREDUCED 128-bit products: V0 = a0 b0, V1 = a1 b1, V2 = (a0 + a1)(b0 + b1) (the operand sums stay below 2p
+// and need no reduction), C0 = V0 + 2 V1 < 3 p^2, C1 = V2 - V0 + V1 in [0, 5 p^2): two Montgomery reductions instead of three,
+// and the linear steps are plain 128-bit additions.  Same field values as the reference's form (ecc.rs:424-439).
+#ifndef CS_FP2_EAGER
+typedef unsigned __int128 u128_t;
+__device__ __forceinline__ u128_t mul_wide(uint64_t a, uint64_t b) { // full 128-bit product, four v_mad_u64_u32
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t t0 = (uint64_t)a0 * b0;
+    const uint64_t t1 = mad_u64_u32(a1, b0, t0 >> 32);
+    const uint64_t t2 = mad_u64_u32(a0, b1, (uint32_t)t1);
+    const uint64_t t3 = mad_u64_u32(a1, b1, (t1 >> 32) + (t2 >> 32));
+    return ((u128_t)t3 << 64) | ((t2 << 32) | (uint32_t)t0);
+}
+__device__ __forceinline__ fp reduce_wide(u128_t v) { return acc_reduce(Acc128{(uint64_t)v, (uint64_t)(v >> 64)}); } // v < 2p 2^64
+__device__ __forceinline__ Fp2 fp2_mul(Fp2 x, Fp2 y) {
+    const u128_t v0 = mul_wide(x.a, y.a), v1 = mul_wide(x.b, y.b), v2 = mul_wide(x.a + x.b, y.a + y.b);
+    return {reduce_wide(v0 + (v1 << 1)), reduce_wide(v2 - v0 + v1)};
+}
+__device__ __forceinline__ Fp2 fp2_sqr(Fp2 x) {
+    const u128_t v0 = mul_wide(x.a, x.a), v1 = mul_wide(x.b, x.b), v2 = mul_wide(x.a + x.b, x.a + x.b);
+    return {reduce_wide(v0 + (v1 << 1)), reduce_wide(v2 - v0 + v1)};
+}
+#else
 __device__ __forceinline__ Fp2 fp2_mul(Fp2 x, Fp2 y) {
     fp p0 = fp_mul(x.a, y.a), p1 = fp_mul(x.b, y.b);
     fp cross = fp_mul(fp_sub(x.a, x.b), fp_sub(y.b, y.a)); // -(a0-a1)(b0-b1)
@@ -29,6 +51,7 @@ __device__ __forceinline__ Fp2 fp2_sqr(Fp2 x) {
     fp c0 = fp_add(p0, fp_dbl(p1));
     return {c0, fp_sub(fp_add(c0, p1), d)};
 }
+#endif
 // 1/(a + b u) = (a + 2b - b u) / (a^2 + 2ab - 2b^2)
 __device__ inline Fp2 fp2_inv(Fp2 x) {
     fp n = fp_sub(fp_add(fp_sqr(x.a), fp_mul(fp_dbl(x.a), x.b)), fp_dbl(fp_sqr(x.b)));
