@@ -144,3 +144,50 @@ def test_transaction_count_must_be_a_power_of_two():
     b.upload_witness(tx.tx_metadata)
     with pytest.raises(CstarkError):           # and so does the library
         b.prove(build_options())
+
+
+def test_two_contexts_prove_concurrently():
+    """The library is re-entrant per context (include/cstark.h): two host threads, each with its own context and stream, prove
+    different witnesses at the same time; both proofs verify and equal the proofs made alone."""
+    import threading
+    import torch
+    from oracle import verifier as V
+    from certificate_stark_amd.backend import Backend
+    from certificate_stark_amd.prover import TransactionExample
+    jobs = [example(4, 7, seed=41), example(8, 15, seed=42)]
+    alone = [tx.prove() for tx in jobs]
+    for tx in jobs:
+        tx.prover.backend.close()
+    results = [None, None]
+
+    def work(i):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            tx = TransactionExample(build_options(), jobs[i].tx_metadata, Backend())
+            for _ in range(3):
+                results[i] = tx.prove()
+            tx.prover.backend.close()
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i, tx in enumerate(jobs):
+        assert results[i] == alone[i]
+        assert V.verify(results[i], *tx.pub_inputs())
+
+
+def test_proof_buffer_too_small_reports_required_size():
+    import ctypes as C
+    from certificate_stark_amd import _lib
+    tx = example(2, 3)
+    b = tx.prover.backend
+    b.upload_witness(tx.tx_metadata)
+    o = _lib.OptionsStruct(42, 8, 0, 0, 0, 4, 256)
+    need = C.c_size_t(0)
+    small = (C.c_uint8 * 16)()
+    rc = b.lib.cstark_tx_prove(b.ctx, C.byref(o), small, C.c_size_t(16), C.byref(need))
+    assert rc == -1 and need.value > 100000
+    buf = (C.c_uint8 * need.value)()
+    n2 = C.c_size_t(0)
+    assert b.lib.cstark_tx_prove(b.ctx, C.byref(o), buf, C.c_size_t(need.value), C.byref(n2)) == 0 and n2.value == need.value
