@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--mode", choices=["prove", "hotpath", "coset"], default="prove",
                     help="prove: complete proofs, independent per GPU (weak scaling, no collective); hotpath: K1..K6 only, "
                          "independent per GPU; coset: the K1..K6 of ONE proof sharded by LDE coset with RCCL all-gathers (strong scaling)")
+    ap.add_argument("--hash-fn", choices=["blake3", "sha3"], default="blake3", help="ProofOptions hash (the headline metric uses Blake3_256, src/lib.rs:82)")
     ap.add_argument("--queries", type=int, default=96, help="FRI queries (BASELINE.json: 96; the reference's get_example: 42)")
     args = ap.parse_args()
 
@@ -126,7 +127,8 @@ def main():
     n = n_tx * 1024
     log_n = n.bit_length() - 1
 
-    prover = TransactionProver(ProofOptions(num_queries=args.queries), Backend(local))
+    hash_fn = 1 if args.hash_fn == "sha3" else 0
+    prover = TransactionProver(ProofOptions(num_queries=args.queries, hash_fn=hash_fn), Backend(local))
     prover.load_witness(meta)  # witness resident in HBM before the timed region
     rng = np.random.default_rng(1234 + (rank if args.mode != "coset" else 0))  # one proof = one set of coefficients
     cf = _lib.TxCoeffsStruct()
@@ -282,7 +284,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if coset_mode else "weak", "vs_baseline": None,
             "dtype": "u64 (63-bit prime field, Montgomery) + u32 (Blake3)", "data": "synthetic",
             "config": {"workload": "benches/state_transition.rs full TransactionAir, %d transactions = 2^%d steps, blowup 8, "
-                                   "Merkle depth %d, Blake3_256, no field extension" % (n_tx, log_n, meta.depth),
+                                   "Merkle depth %d, %s, no field extension" % (n_tx, log_n, meta.depth, "Sha3_256" if hash_fn else "Blake3_256"),
                        "queries": args.queries, "proof_bytes": proof_len[0] or None,
                        "parallelism": ("one proof sharded by LDE coset over %d GPUs, RCCL all-gather of digests and evaluations" % world)
                        if coset_mode else ("replica x%d (independent proofs per GPU, no collective)" % world),
@@ -305,7 +307,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(meta_full, min(args.cpu_sample_tx, n_tx),
-                                                   (args.queries, 8, 0, 0, 0, 4, 256) if prove_mode else None)
+                                                   (args.queries, 8, 0, hash_fn, 0, 4, 256) if prove_mode else None)
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

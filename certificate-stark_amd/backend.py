@@ -112,6 +112,18 @@ class Backend:
     def empty_u8(self, *shape):
         return torch.empty(shape, dtype=torch.uint8, device=self.device)
 
+    def hash_rows_fn(self, hash_fn, lde, log_blowup, k0=0):
+        """cstark_hash_rows_fn: row hashes with Blake3_256 (0) or Sha3_256 (1)"""
+        nk, width, n = lde.shape
+        leaves = self.empty_u8(n << log_blowup, 32)
+        check(self.lib.cstark_hash_rows_fn(self.ctx, C.c_uint32(hash_fn), self._ptr(lde), self._ptr(leaves, u8p), C.c_uint32(width),
+                                           C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
+        return leaves
+
+    def merkle_build_fn(self, hash_fn, nodes):
+        check(self.lib.cstark_merkle_build_fn(self.ctx, C.c_uint32(hash_fn), self._ptr(nodes, u8p), C.c_uint32((nodes.shape[0] // 2).bit_length() - 1)))
+        return nodes
+
     def hash_rows(self, lde, log_blowup, k0=0, leaves=None):
         """lde: [nk, width, n]. leaves: uint8 [(n << log_blowup), 32]; rows of cosets [k0, k0+nk) are written."""
         nk, width, n = lde.shape

@@ -10,4 +10,8 @@ hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, u
                      hipStream_t stream);
 // d_nodes: 2 * 2^log_leaves digests, leaves in the upper half; fills nodes[1 .. 2^log_leaves)
 hipError_t merkle_build(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream);
+// the same two stages with SHA3-256 (sha3.hip)
+hipError_t hash_rows_sha3(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, unsigned log_n, unsigned log_b, unsigned k0, unsigned nk,
+                          hipStream_t stream);
+hipError_t merkle_build_sha3(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream);
 } // namespace cs

@@ -421,6 +421,29 @@ int cstark_hash_rows(cstark_ctx *c, const uint64_t *d_lde, uint8_t *d_leaves, ui
     return CSTARK_OK;
 }
 
+int cstark_hash_rows_fn(cstark_ctx *c, uint32_t hash_fn, const uint64_t *d_lde, uint8_t *d_leaves, uint32_t width, uint32_t log_n, uint32_t log_blowup,
+                        uint32_t k0, uint32_t nk) {
+    if (hash_fn == 0) return cstark_hash_rows(c, d_lde, d_leaves, width, log_n, log_blowup, k0, nk);
+    if (hash_fn != 1) return fail(CSTARK_ERR_UNSUPPORTED, "hash_fn must be 0 (Blake3_256) or 1 (Sha3_256)");
+    if (!c || !d_lde || !d_leaves) return fail(CSTARK_ERR_INVALID_ARG, "cstark_hash_rows_fn: null argument");
+    if (width == 0 || width > 128) return fail(CSTARK_ERR_UNSUPPORTED, "row width must be 1..128 elements");
+    if (log_n > 30 || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
+    if (((uintptr_t)d_leaves & 15) != 0) return fail(CSTARK_ERR_INVALID_ARG, "d_leaves must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::hash_rows_sha3(d_lde, d_leaves, width, log_n, log_blowup, k0, nk, c->stream));
+    return CSTARK_OK;
+}
+int cstark_merkle_build_fn(cstark_ctx *c, uint32_t hash_fn, uint8_t *d_nodes, uint32_t log_leaves) {
+    if (hash_fn == 0) return cstark_merkle_build(c, d_nodes, log_leaves);
+    if (hash_fn != 1) return fail(CSTARK_ERR_UNSUPPORTED, "hash_fn must be 0 (Blake3_256) or 1 (Sha3_256)");
+    if (!c || !d_nodes) return fail(CSTARK_ERR_INVALID_ARG, "cstark_merkle_build_fn: null argument");
+    if (log_leaves == 0 || log_leaves > 30) return fail(CSTARK_ERR_INVALID_ARG, "tree must have 2 .. 2^30 leaves");
+    if (((uintptr_t)d_nodes & 15) != 0) return fail(CSTARK_ERR_INVALID_ARG, "d_nodes must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::merkle_build_sha3(d_nodes, log_leaves, c->stream));
+    return CSTARK_OK;
+}
+
 int cstark_merkle_build(cstark_ctx *c, uint8_t *d_nodes, uint32_t log_leaves) {
     if (!c || !d_nodes) return fail(CSTARK_ERR_INVALID_ARG, "cstark_merkle_build: null argument");
     if (log_leaves == 0 || log_leaves > 30) return fail(CSTARK_ERR_INVALID_ARG, "tree must have 2 .. 2^30 leaves");

@@ -20,6 +20,7 @@
 #include "../../include/cstark.h"
 #include "ctx.h"
 #include "hostblake3.h"
+#include "keccak.cuh"
 #include "air_tx_host.h"
 #include "hostfield.h"
 
@@ -52,21 +53,28 @@ void prove_arena_free(ProveArena *a) {
 
 namespace {
 
+// the proof's hash function on the host (channel, small commitments): 0 = Blake3_256, 1 = Sha3_256
+void digest(uint32_t hash_fn, const uint8_t *p, size_t n, uint8_t out[32]) {
+    if (hash_fn == 1) keccak::sha3_256(p, n, out);
+    else hostb3::hash(p, n, out);
+}
+
 struct Coin {
     uint8_t seed[32];
     uint64_t counter = 0;
-    void init(const uint8_t *p, size_t n) { hostb3::hash(p, n, seed); counter = 0; }
+    uint32_t hash_fn = 0;
+    void init(const uint8_t *p, size_t n) { digest(hash_fn, p, n, seed); counter = 0; }
     void reseed(const uint8_t d[32]) {
         uint8_t buf[64];
         memcpy(buf, seed, 32); memcpy(buf + 32, d, 32);
-        hostb3::hash(buf, 64, seed);
+        digest(hash_fn, buf, 64, seed);
         counter = 0;
     }
-    static void with_int(const uint8_t s[32], uint64_t v, uint8_t out[32]) {
+    void with_int(const uint8_t s[32], uint64_t v, uint8_t out[32]) const {
         uint8_t buf[40];
         memcpy(buf, s, 32);
         for (int i = 0; i < 8; i++) buf[32 + i] = (uint8_t)(v >> (8 * i));
-        hostb3::hash(buf, 40, out);
+        digest(hash_fn, buf, 40, out);
     }
     void reseed_int(uint64_t v) { with_int(seed, v, seed); counter = 0; }
     uint64_t next_u64() {
@@ -91,7 +99,7 @@ struct Coin {
     }
 };
 
-void hash_elements(const uint64_t *e, size_t n, uint8_t out[32]) { hostb3::hash((const uint8_t *)e, 8 * n, out); } // little-endian host
+void hash_elements(uint32_t hash_fn, const uint64_t *e, size_t n, uint8_t out[32]) { digest(hash_fn, (const uint8_t *)e, 8 * n, out); } // little-endian host
 
 struct Writer {
     std::vector<uint8_t> b;
@@ -194,7 +202,7 @@ int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned n_layer
 
 int check_options(const cstark_options *opt, unsigned *log_rem_out) {
     if (opt->blowup_factor != 8) return fail(CSTARK_ERR_UNSUPPORTED, "proofs use blowup factor 8 (src/lib.rs:78-86)");
-    if (opt->hash_fn != 0) return fail(CSTARK_ERR_UNSUPPORTED, "only Blake3_256 is implemented");
+    if (opt->hash_fn > 1) return fail(CSTARK_ERR_UNSUPPORTED, "hash_fn must be Blake3_256 (0) or Sha3_256 (1)");
     if (opt->field_extension != 0) return fail(CSTARK_ERR_UNSUPPORTED, "only FieldExtension::None is implemented");
     if (opt->fri_folding_factor != 4) return fail(CSTARK_ERR_UNSUPPORTED, "only FRI folding factor 4 is implemented");
     if (opt->num_queries == 0 || opt->num_queries > 128) return fail(CSTARK_ERR_INVALID_ARG, "num_queries must be 1..128");
@@ -233,8 +241,9 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     STAGE();
     RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, (uint32_t)W, log_n, log_b, host::generator(), 0, (uint32_t)b));
     STAGE();
-    RC_TRY(cstark_hash_rows(c, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, (uint32_t)b));
-    RC_TRY(cstark_merkle_build(c, a->tnodes, log_N));
+    const uint32_t hf = opt->hash_fn;
+    RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, (uint32_t)b));
+    RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
     uint8_t trace_root[32], cons_root[32];
     HIP_TRY(hipMemcpyAsync(trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
@@ -242,6 +251,7 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
 
     // ---- channel ------------------------------------------------------------------------------------------------------------
     Coin coin;
+    coin.hash_fn = hf;
     {
         Writer s;
         const uint8_t ctxb[2] = {(uint8_t)W, (uint8_t)log_n};
@@ -272,8 +282,8 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     }
     RC_TRY(cstark_composition_columns(c, ce_evals, a->ccoef, log_n, log_ce));
     RC_TRY(cstark_lde_columns(c, a->ccoef, a->clde, (uint32_t)ce, log_n, log_b, host::generator(), 0, (uint32_t)b));
-    RC_TRY(cstark_hash_rows(c, a->clde, a->cnodes + 32 * N, (uint32_t)ce, log_n, log_b, 0, (uint32_t)b));
-    RC_TRY(cstark_merkle_build(c, a->cnodes, log_N));
+    RC_TRY(cstark_hash_rows_fn(c, hf, a->clde, a->cnodes + 32 * N, (uint32_t)ce, log_n, log_b, 0, (uint32_t)b));
+    RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
     HIP_TRY(hipMemcpyAsync(cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(hipStreamSynchronize(st));
@@ -287,8 +297,8 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     RC_TRY(cstark_evaluate_polys_at(c, a->coeffs, (uint32_t)W, log_n, zpts, 2, ood_trace.data()));
     RC_TRY(cstark_evaluate_polys_at(c, a->ccoef, (uint32_t)ce, log_n, &zb, 1, ood_comp.data()));
     uint8_t dg[32];
-    hash_elements(ood_trace.data(), 2 * W, dg); coin.reseed(dg);
-    hash_elements(ood_comp.data(), ce, dg); coin.reseed(dg);
+    hash_elements(hf, ood_trace.data(), 2 * W, dg); coin.reseed(dg);
+    hash_elements(hf, ood_comp.data(), ce, dg); coin.reseed(dg);
     STAGE();
 
     // ---- DEEP composition -------------------------------------------------------------------------------------------------
@@ -307,8 +317,8 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     unsigned lg = log_N;
     for (unsigned l = 0; l < n_layers; l++) {
         const size_t rows = (size_t)1 << (lg - 2);
-        RC_TRY(cstark_hash_rows(c, a->layer[l], a->lnodes[l] + 32 * rows, 4, lg - 2, 0, 0, 1));
-        RC_TRY(cstark_merkle_build(c, a->lnodes[l], lg - 2));
+        RC_TRY(cstark_hash_rows_fn(c, hf, a->layer[l], a->lnodes[l] + 32 * rows, 4, lg - 2, 0, 0, 1));
+        RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - 2));
         HIP_TRY(hipMemcpyAsync(&layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         coin.reseed(&layer_roots[32 * l]);
@@ -321,7 +331,7 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     HIP_TRY(hipMemcpyAsync(remainder.data(), a->layer[n_layers], remainder.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     uint8_t rem_commit[32];
-    hash_elements(remainder.data(), remainder.size(), rem_commit);
+    hash_elements(hf, remainder.data(), remainder.size(), rem_commit);
     coin.reseed(rem_commit);
     STAGE();
 
@@ -329,7 +339,7 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     uint64_t nonce = 1;
     for (;; nonce++) {
         uint8_t out[32];
-        Coin::with_int(coin.seed, nonce, out);
+        coin.with_int(coin.seed, nonce, out);
         uint64_t v = 0;
         for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
         if (opt->grinding_factor == 0 || (v & ((1ull << opt->grinding_factor) - 1)) == 0) break;

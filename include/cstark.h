@@ -74,7 +74,7 @@ typedef struct cstark_options {
     uint32_t num_queries;      /* 42 */
     uint32_t blowup_factor;    /* 8 */
     uint32_t grinding_factor;  /* 0 */
-    uint32_t hash_fn;          /* 0 = Blake3_256 (only one implemented), 1 = Sha3_256 */
+    uint32_t hash_fn;          /* 0 = Blake3_256, 1 = Sha3_256 */
     uint32_t field_extension;  /* 0 = None (only one implemented), 1 = Quadratic, 2 = Cubic */
     uint32_t fri_folding_factor; /* 4 */
     uint32_t fri_max_remainder;  /* 256 */
@@ -129,6 +129,11 @@ int cstark_hash_rows(cstark_ctx *ctx, const uint64_t *d_lde, uint8_t *d_leaves, 
 /* d_nodes: 2 * n_leaves digests; nodes[n_leaves + i] = leaf i on input; on return nodes[1] is the
  * root and nodes[i] = Blake3(nodes[2i] || nodes[2i+1]). nodes[0] is zero. */
 int cstark_merkle_build(cstark_ctx *ctx, uint8_t *d_nodes, uint32_t log_leaves);
+/* The same two stages with the hash function chosen as in cstark_options::hash_fn: 0 = Blake3_256 (identical to the calls above),
+ * 1 = Sha3_256 (FIPS 202; a row is absorbed as its 8-byte little-endian words, a parent is SHA3-256 of its two 32-byte children). */
+int cstark_hash_rows_fn(cstark_ctx *ctx, uint32_t hash_fn, const uint64_t *d_lde, uint8_t *d_leaves, uint32_t width, uint32_t log_n,
+                        uint32_t log_blowup, uint32_t k0, uint32_t nk);
+int cstark_merkle_build_fn(cstark_ctx *ctx, uint32_t hash_fn, uint8_t *d_nodes, uint32_t log_leaves);
 
 /* ---- K6/K7: constraint evaluation (Air::evaluate_transition, src/air.rs:114-173, + driver) --- */
 /* d_lde: cosets [k0,k0+nk) of the extended 94-column trace, coset-major as cstark_lde_columns writes them.
@@ -185,7 +190,7 @@ int cstark_fri_fold4(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, 
  * (host, `capacity` bytes; cstark_tx_proof_size_bound gives a sufficient capacity).  *proof_len receives the length; if the
  * buffer is too small the call fails with CSTARK_ERR_INVALID_ARG and *proof_len still holds the required size.
  * The public inputs are read from the trace as TransactionProver::get_pub_inputs does (src/prover.rs:106-129).
- * Supported options: blowup 8, Blake3_256, FieldExtension::None, FRI folding 4, remainder 128..1024 (the reference's
+ * Supported options: blowup 8, Blake3_256 or Sha3_256, FieldExtension::None, FRI folding 4, remainder 128..1024 (the reference's
  * get_example options, src/lib.rs:78-86, qualify).
  *
  * Proof layout (little-endian; field elements as 8-byte memory form; this library's own format, the engine's

@@ -392,3 +392,68 @@ void cso_fri_fold4(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_
         out[i] = fp_mul(acc, inv4);
     }
 }
+
+/* ---- SHA3-256 (FIPS 202): HashFunction::Sha3_256 of the reference's ProofOptions (examples/state-transition.rs:67-71) ------ */
+static const uint64_t KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL, 0x0000000080000001ULL,
+    0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+    0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+static const int KECCAK_ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+static inline uint64_t rotl64(uint64_t x, int r) { return r ? (x << r) | (x >> (64 - r)) : x; }
+static void keccak_f(uint64_t s[25]) { /* lane (x, y) at s[x + 5 y] */
+    for (int rnd = 0; rnd < 24; rnd++) {
+        uint64_t c[5], b[25];
+        for (int x = 0; x < 5; x++) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+        for (int x = 0; x < 5; x++) {
+            uint64_t d = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+            for (int y = 0; y < 5; y++) s[x + 5 * y] ^= d;
+        }
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(s[x + 5 * y], KECCAK_ROT[x + 5 * y]);
+        for (int y = 0; y < 5; y++)
+            for (int x = 0; x < 5; x++) s[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        s[0] ^= KECCAK_RC[rnd];
+    }
+}
+void cso_sha3_256(const uint8_t *in, size_t len, uint8_t out[32]) {
+    uint64_t s[25] = {0};
+    uint8_t blk[136];
+    while (len >= 136) {
+        for (int i = 0; i < 17; i++) { uint64_t w = 0; for (int b = 0; b < 8; b++) w |= (uint64_t)in[8 * i + b] << (8 * b); s[i] ^= w; }
+        keccak_f(s);
+        in += 136; len -= 136;
+    }
+    memset(blk, 0, sizeof blk);
+    memcpy(blk, in, len);
+    blk[len] ^= 0x06;
+    blk[135] ^= 0x80;
+    for (int i = 0; i < 17; i++) { uint64_t w = 0; for (int b = 0; b < 8; b++) w |= (uint64_t)blk[8 * i + b] << (8 * b); s[i] ^= w; }
+    keccak_f(s);
+    for (int i = 0; i < 4; i++) for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(s[i] >> (8 * b));
+}
+/* the generic digest: hash_fn 0 = Blake3_256, 1 = Sha3_256 */
+void cso_digest(int hash_fn, const uint8_t *in, size_t len, uint8_t out[32]) {
+    if (hash_fn == 1) cso_sha3_256(in, len, out); else cso_blake3(in, len, out);
+}
+void cso_hash_rows_fn(int hash_fn, const uint64_t *lde, uint8_t *leaves, uint32_t width, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk) {
+    size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (uint32_t k = k0; k < k0 + nk; k++)
+        for (size_t j = 0; j < n; j++) {
+            uint8_t buf[8 * 256];
+            for (uint32_t c = 0; c < width; c++) {
+                uint64_t v = lde[((size_t)(k - k0) * width + c) * n + j];
+                for (int t = 0; t < 8; t++) buf[8 * c + t] = v >> (8 * t);
+            }
+            cso_digest(hash_fn, buf, 8 * (size_t)width, leaves + 32 * (b * j + k));
+        }
+}
+void cso_merkle_build_fn(int hash_fn, uint8_t *nodes, unsigned log_leaves) {
+    size_t L = (size_t)1 << log_leaves;
+    memset(nodes, 0, 32);
+    for (size_t lvl = L >> 1; lvl >= 1; lvl >>= 1) {
+#pragma omp parallel for schedule(static)
+        for (size_t i = lvl; i < 2 * lvl; i++) cso_digest(hash_fn, nodes + 64 * i, 64, nodes + 32 * i);
+    }
+}

@@ -64,6 +64,10 @@ void cso_interpolate_columns(uint64_t *cols, uint32_t width, unsigned log_n);
 void cso_lde_columns(const uint64_t *coeffs, uint64_t *lde, uint32_t width, unsigned log_n, unsigned log_b, uint64_t offset,
                      uint32_t k0, uint32_t nk);
 void cso_blake3(const uint8_t *in, size_t len, uint8_t out[32]);
+void cso_sha3_256(const uint8_t *in, size_t len, uint8_t out[32]);
+void cso_digest(int hash_fn, const uint8_t *in, size_t len, uint8_t out[32]);
+void cso_hash_rows_fn(int hash_fn, const uint64_t *lde, uint8_t *leaves, uint32_t width, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk);
+void cso_merkle_build_fn(int hash_fn, uint8_t *nodes, unsigned log_leaves);
 void cso_hash_rows(const uint64_t *lde, uint8_t *leaves, uint32_t width, unsigned log_n, unsigned log_b, uint32_t k0, uint32_t nk);
 void cso_merkle_build(uint8_t *nodes, unsigned log_leaves);
 void cso_tx_periodic_table(unsigned depth, unsigned log_n, unsigned log_b, uint64_t *out /*[b][48][1024]*/);

@@ -235,21 +235,34 @@ def blake3(data):
     return out.tobytes()
 
 
-def hash_rows(lde, log_b, k0=0):
+def digest(data, hash_fn=0):
+    """hash_fn 0 = Blake3_256, 1 = Sha3_256 (winterfell::HashFunction)"""
+    data = bytes(data)
+    buf = np.frombuffer(data, np.uint8) if data else np.zeros(1, np.uint8)
+    out = np.zeros(32, np.uint8)
+    lib().cso_digest(C.c_int(hash_fn), _p(np.ascontiguousarray(buf), u8p), C.c_size_t(len(data)), _p(out, u8p))
+    return out.tobytes()
+
+
+def sha3_256(data):
+    return digest(data, 1)
+
+
+def hash_rows(lde, log_b, k0=0, hash_fn=0):
     lde = _u64(lde)
     nk, width, n = lde.shape
     leaves = np.zeros((n << log_b, 32), np.uint8)
-    lib().cso_hash_rows(_p(lde), _p(leaves, u8p), C.c_uint32(width), C.c_uint(n.bit_length() - 1), C.c_uint(log_b),
-                        C.c_uint32(k0), C.c_uint32(nk))
+    lib().cso_hash_rows_fn(C.c_int(hash_fn), _p(lde), _p(leaves, u8p), C.c_uint32(width), C.c_uint(n.bit_length() - 1), C.c_uint(log_b),
+                           C.c_uint32(k0), C.c_uint32(nk))
     return leaves
 
 
-def merkle_build(leaves):
+def merkle_build(leaves, hash_fn=0):
     leaves = np.ascontiguousarray(leaves, np.uint8)
     L = leaves.shape[0]
     nodes = np.zeros((2 * L, 32), np.uint8)
     nodes[L:] = leaves
-    lib().cso_merkle_build(_p(nodes, u8p), C.c_uint(L.bit_length() - 1))
+    lib().cso_merkle_build_fn(C.c_int(hash_fn), _p(nodes, u8p), C.c_uint(L.bit_length() - 1))
     return nodes
 
 

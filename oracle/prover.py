@@ -17,7 +17,8 @@ def _mont(v):
 
 def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
-    assert blowup == 8 and hash_fn == 0 and ext == 0 and folding == 4
+    assert blowup == 8 and hash_fn in (0, 1) and ext == 0 and folding == 4
+    H = lambda data: O.digest(data, hash_fn)
     log_b, b, W = 3, 8, 94
     trace = O.tx_build_trace(w)
     n = trace.shape[1]
@@ -29,12 +30,12 @@ def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
 
     coeffs = O.interpolate_columns(trace.copy())
     lde = O.lde_columns(coeffs, log_b)
-    tnodes = O.merkle_build(O.hash_rows(lde, log_b))
+    tnodes = O.merkle_build(O.hash_rows(lde, log_b, hash_fn=hash_fn), hash_fn)
     trace_root = tnodes[1].tobytes()
 
     seed = bytes([W, log_n]) + struct.pack("<Q", V.P) + bytes([nq, log_b, grinding, hash_fn, ext, folding, log_rem])
     seed += b"".join(struct.pack("<Q", v) for v in pub)
-    coin = V.Coin(seed)
+    coin = V.Coin(seed, hash_fn)
     coin.reseed(trace_root)
     cf = O.TxCoeffsStruct()
     for i in range(115):
@@ -46,7 +47,7 @@ def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
     combined = O.tx_evaluate_constraints(lde, cf, pub4, w.depth, log_b)
     ccoef = O.composition_columns(combined)
     clde = O.lde_columns(ccoef, log_b)
-    cnodes = O.merkle_build(O.hash_rows(clde, log_b))
+    cnodes = O.merkle_build(O.hash_rows(clde, log_b, hash_fn=hash_fn), hash_fn)
     cons_root = cnodes[1].tobytes()
     coin.reseed(cons_root)
 
@@ -56,8 +57,8 @@ def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
     zb = _mont(pow(z, b, V.P))
     ood_trace = O.evaluate_polys_at(coeffs, [zm, zw])          # [2][94]
     ood_comp = O.evaluate_polys_at(ccoef, [zb])[0]             # [8]
-    coin.reseed(O.blake3(ood_trace.tobytes()))
-    coin.reseed(O.blake3(ood_comp.tobytes()))
+    coin.reseed(H(ood_trace.tobytes()))
+    coin.reseed(H(ood_comp.tobytes()))
     d_alpha, d_beta = [], []
     for _ in range(W):
         d_alpha.append(_mont(coin.draw())); d_beta.append(_mont(coin.draw())); coin.draw()
@@ -70,7 +71,7 @@ def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
     offset, lg = 3, log_N
     while lg > log_rem:
         rows = 1 << (lg - 2)
-        nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 4, rows), 0))
+        nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 4, rows), 0, hash_fn=hash_fn), hash_fn)
         layers.append(layer); trees.append(nodes); roots.append(nodes[1].tobytes())
         coin.reseed(roots[-1])
         alpha = coin.draw()
@@ -78,10 +79,10 @@ def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
         offset = pow(offset, 4, V.P)
         lg -= 2
     remainder = layer
-    rem_commit = O.blake3(remainder.tobytes())
+    rem_commit = H(remainder.tobytes())
     coin.reseed(rem_commit)
     nonce = 1
-    while grinding and struct.unpack("<Q", O.blake3(coin.seed + struct.pack("<Q", nonce))[:8])[0] & ((1 << grinding) - 1):
+    while grinding and struct.unpack("<Q", H(coin.seed + struct.pack("<Q", nonce))[:8])[0] & ((1 << grinding) - 1):
         nonce += 1
     coin.reseed_int(nonce)
     positions = coin.draw_integers(nq, N)

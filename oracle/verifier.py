@@ -40,18 +40,22 @@ def root_of_unity(log_n):
 
 
 class Coin:
-    def __init__(self, seed_bytes):
-        self.seed, self.counter = O.blake3(seed_bytes), 0
+    def __init__(self, seed_bytes, hash_fn=0):
+        self.hash_fn = hash_fn
+        self.seed, self.counter = self.h(seed_bytes), 0
+
+    def h(self, data):
+        return O.digest(data, self.hash_fn)
 
     def reseed(self, digest):
-        self.seed, self.counter = O.blake3(self.seed + bytes(digest)), 0
+        self.seed, self.counter = self.h(self.seed + bytes(digest)), 0
 
     def reseed_int(self, v):
-        self.seed, self.counter = O.blake3(self.seed + struct.pack("<Q", v)), 0
+        self.seed, self.counter = self.h(self.seed + struct.pack("<Q", v)), 0
 
     def _next(self):
         self.counter += 1
-        return struct.unpack("<Q", O.blake3(self.seed + struct.pack("<Q", self.counter))[:8])[0]
+        return struct.unpack("<Q", self.h(self.seed + struct.pack("<Q", self.counter))[:8])[0]
 
     def draw(self):
         """a field element (canonical integer)"""
@@ -99,10 +103,10 @@ def fold_positions(pos, rows):
     return out
 
 
-def merkle_root_from_path(leaf, index, path):
+def merkle_root_from_path(leaf, index, path, hash_fn=0):
     h = leaf
     for sib in path:
-        h = O.blake3(sib + h) if index & 1 else O.blake3(h + sib)
+        h = O.digest(sib + h, hash_fn) if index & 1 else O.digest(h + sib, hash_fn)
         index >>= 1
     return h
 
@@ -314,7 +318,7 @@ def _verify(d, air, options):
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = d["options"]
     if options is not None and list(options) != d["options"]:
         raise VerifierError("proof options differ from the expected ones")
-    if hash_fn != 0 or ext != 0 or folding != 4 or max_rem & (max_rem - 1) or not (128 <= max_rem <= 1024):
+    if hash_fn not in (0, 1) or ext != 0 or folding != 4 or max_rem & (max_rem - 1) or not (128 <= max_rem <= 1024):
         raise VerifierError("unsupported options")
     log_n = d["log_n"]
     log_b, log_N = 3, log_n + 3
@@ -330,7 +334,8 @@ def _verify(d, air, options):
     # 1. channel
     seed = bytes([W, log_n]) + struct.pack("<Q", P) + bytes([nq, log_b, grinding, hash_fn, ext, folding, log_rem])
     seed += b"".join(struct.pack("<Q", v) for v in air.pub) + air.pub_bytes
-    coin = Coin(seed)
+    coin = Coin(seed, hash_fn)
+    H = coin.h
     coin.reseed(d["trace_root"])
     ta, tb, ba, bb = [], [], [], []
     for _ in range(air.nc):
@@ -347,8 +352,8 @@ def _verify(d, air, options):
     rhs = sum(h * pow(z, i, P) for i, h in enumerate(hz)) % P
     if lhs != rhs:
         raise VerifierError("out-of-domain constraint evaluations are inconsistent")
-    coin.reseed(O.blake3(cur.tobytes() + nxt.tobytes()))
-    coin.reseed(O.blake3(np.ascontiguousarray(d["ood_comp"]).tobytes()))
+    coin.reseed(H(cur.tobytes() + nxt.tobytes()))
+    coin.reseed(H(np.ascontiguousarray(d["ood_comp"]).tobytes()))
     d_alpha, d_beta = [], []
     for _ in range(W):
         d_alpha.append(coin.draw()); d_beta.append(coin.draw()); coin.draw()
@@ -358,11 +363,11 @@ def _verify(d, air, options):
     for root in d["layer_roots"]:
         coin.reseed(root)
         alphas.append(coin.draw())
-    if O.blake3(np.ascontiguousarray(d["remainder"]).tobytes()) != d["rem_commit"]:
+    if H(np.ascontiguousarray(d["remainder"]).tobytes()) != d["rem_commit"]:
         raise VerifierError("remainder does not match its commitment")
     coin.reseed(d["rem_commit"])
     if grinding:
-        v = struct.unpack("<Q", O.blake3(coin.seed + struct.pack("<Q", d["nonce"]))[:8])[0]
+        v = struct.unpack("<Q", H(coin.seed + struct.pack("<Q", d["nonce"]))[:8])[0]
         if v & ((1 << grinding) - 1):
             raise VerifierError("proof of work not satisfied")
     coin.reseed_int(d["nonce"])
@@ -370,9 +375,9 @@ def _verify(d, air, options):
 
     # 3. trace / composition openings
     for q, pos in enumerate(positions):
-        if merkle_root_from_path(O.blake3(d["trace_rows"][q].tobytes()), pos, d["trace_paths"][q]) != d["trace_root"]:
+        if merkle_root_from_path(H(d["trace_rows"][q].tobytes()), pos, d["trace_paths"][q], hash_fn) != d["trace_root"]:
             raise VerifierError("trace opening %d does not match the trace commitment" % q)
-        if merkle_root_from_path(O.blake3(d["cons_rows"][q].tobytes()), pos, d["cons_paths"][q]) != d["cons_root"]:
+        if merkle_root_from_path(H(d["cons_rows"][q].tobytes()), pos, d["cons_paths"][q], hash_fn) != d["cons_root"]:
             raise VerifierError("composition opening %d does not match the constraint commitment" % q)
 
     # 4. DEEP composition at the queried points
@@ -404,7 +409,7 @@ def _verify(d, air, options):
         if len(fpos) != len(rows):
             raise VerifierError("layer %d: wrong number of openings" % l)
         for t, rp in enumerate(fpos):
-            if merkle_root_from_path(O.blake3(rows[t].tobytes()), rp, paths[t]) != d["layer_roots"][l]:
+            if merkle_root_from_path(H(rows[t].tobytes()), rp, paths[t], hash_fn) != d["layer_roots"][l]:
                 raise VerifierError("layer %d opening does not match its commitment" % l)
         for p, v in zip(cur_pos, cur_val):
             if from_mont(rows[fpos.index(p & (rows_n - 1))][p >> (lgl - 2)]) != v:

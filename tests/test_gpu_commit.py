@@ -59,3 +59,27 @@ def test_large_tree_2_20_leaves_root(oracle, backend):
     backend.merkle_build(nodes)
     ref = oracle.merkle_build(leaves)
     assert (nodes[:4096].cpu().numpy() == ref[:4096]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width", [1, 4, 8, 16, 17, 18, 34, 94, 128])
+def test_sha3_row_hashes_and_tree(oracle, width):
+    """Sha3_256 variants of K4 / K5 against the oracle (itself pinned by FIPS 202 vectors and hashlib): ragged widths around the
+    17-word rate boundary, a coset subset, and the tree."""
+    import torch
+    from certificate_stark_amd.backend import Backend
+    b = Backend()
+    rng = np.random.default_rng(width)
+    n, log_b = 256, 3
+    lde = rng.integers(0, 2**62, size=(8, width, n), dtype=np.uint64)
+    d_lde = b.from_numpy_u64(lde)
+    leaves = b.hash_rows_fn(1, d_lde, log_b)
+    ref = oracle.hash_rows(lde, log_b, hash_fn=1)
+    assert (leaves.cpu().numpy() == ref).all()
+    part = b.hash_rows_fn(1, d_lde[2:5].contiguous(), log_b, k0=2).cpu().numpy().reshape(n, 8, 32)
+    assert (part[:, 2:5] == ref.reshape(n, 8, 32)[:, 2:5]).all()
+    nodes = torch.zeros((2 * n * 8, 32), dtype=torch.uint8, device=b.device)
+    nodes[n * 8:] = leaves
+    b.merkle_build_fn(1, nodes)
+    assert (nodes.cpu().numpy() == oracle.merkle_build(ref, 1)).all()
+    b.close()

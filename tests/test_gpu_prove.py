@@ -93,7 +93,7 @@ def test_production_depth_proofs(n_tx, depth, queries):
 def test_unsupported_options_are_refused():
     from certificate_stark_amd._lib import CstarkError
     from certificate_stark_amd.prover import ProofOptions
-    for opt in (ProofOptions(42, 16), ProofOptions(42, 8, 0, 1), ProofOptions(42, 8, 0, 0, 1), ProofOptions(42, 8, 0, 0, 0, 8)):
+    for opt in (ProofOptions(42, 16), ProofOptions(42, 8, 0, 2), ProofOptions(42, 8, 0, 0, 1), ProofOptions(42, 8, 0, 0, 0, 8)):
         tx = example(2, 3, options=opt)
         with pytest.raises(CstarkError):
             tx.prove()
@@ -191,3 +191,24 @@ def test_proof_buffer_too_small_reports_required_size():
     buf = (C.c_uint8 * need.value)()
     n2 = C.c_size_t(0)
     assert b.lib.cstark_tx_prove(b.ctx, C.byref(o), buf, C.c_size_t(need.value), C.byref(n2)) == 0 and n2.value == need.value
+
+
+@pytest.mark.parametrize("n_tx,depth", [(2, 3), (8, 15)])
+def test_sha3_proofs(n_tx, depth):
+    """HashFunction::Sha3_256 (the reference's other ProofOptions hash, examples/state-transition.rs:67-71): commitments, channel
+    and openings all switch; bytes equal the CPU restatement, the verifier accepts, a Blake3 reading of the same proof fails."""
+    from oracle import oracle as O
+    from oracle import prover as OP
+    from oracle import verifier as V
+    from certificate_stark_amd.prover import ProofOptions, TransactionExample, TransactionMetadata
+    opts = (42, 8, 0, 1, 0, 4, 256)
+    w = O.TxWitness.generate(n_tx, depth, seed=300 + n_tx)
+    meta = TransactionMetadata(*[getattr(w, f) for f in TransactionMetadata.FIELDS])
+    tx = TransactionExample(ProofOptions(*opts), meta)
+    proof = tx.prove()
+    assert proof == OP.prove(w, opts)
+    assert V.verify(proof, *tx.pub_inputs(), options=list(opts))
+    as_blake = bytearray(proof)
+    as_blake[4 + 4 + 16 + 12] = 0   # the hash_fn word of the header
+    with pytest.raises(V.VerifierError):
+        V.verify(bytes(as_blake), *tx.pub_inputs())

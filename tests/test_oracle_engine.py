@@ -209,3 +209,19 @@ def test_fri_fold4(oracle):
     direct = oracle.lde_columns(gco.reshape(1, N // 4), 0, offset=g4)[0, 0]
     assert (folded == direct).all()
     assert not gco[d // 4:].any()
+
+
+def test_sha3_256_known_answers(oracle):
+    """FIPS 202 vectors and Python's own implementation: pins the second hash of ProofOptions (HashFunction::Sha3_256)."""
+    import hashlib
+    assert oracle.sha3_256(b"").hex() == "a7ffc6f8bf1ed76651c14756a061d662f580ff4de43b49fa82d80a4b80f8434a"
+    assert oracle.sha3_256(b"abc").hex() == "3a985da74fe225b2045c172d6bd390bd855f086e3e9d525b46bfe24511431532"
+    for n in (1, 71, 72, 135, 136, 137, 272, 752, 1000):
+        m = bytes((7 * i + n) & 0xff for i in range(n))
+        assert oracle.sha3_256(m) == hashlib.sha3_256(m).digest()
+    rng = np.random.default_rng(1)
+    lde = rng.integers(0, 2**62, size=(2, 17, 8), dtype=np.uint64)       # width 17: the padding gets a block of its own
+    leaves = oracle.hash_rows(lde, 1, hash_fn=1)
+    assert leaves[2 * 3 + 1].tobytes() == hashlib.sha3_256(np.ascontiguousarray(lde[1, :, 3]).tobytes()).digest()
+    nodes = oracle.merkle_build(leaves, 1)
+    assert nodes[1].tobytes() == hashlib.sha3_256(nodes[2].tobytes() + nodes[3].tobytes()).digest()
