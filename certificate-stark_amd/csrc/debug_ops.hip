@@ -22,6 +22,7 @@ __global__ void k_fp_op(const fp *a, const fp *b, fp *out, size_t n, int op) {
         case 6: r = fp_to_u64(x); break;
         case 7: r = fp_neg(x); break;
         case 8: r = fp_dbl(x); break;
+        case 9: r = wave_next(x, y); break; // lane l + 1's x, lane 63: its own y
     }
     out[i] = r;
 }

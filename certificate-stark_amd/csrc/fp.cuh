@@ -92,6 +92,16 @@ __device__ __forceinline__ fp fp_mul_small(fp a, int c) {
 
 } // namespace cs
 
+// value of the next lane (lane l reads lane l + 1; lane 63 gets `last`): one DPP wave shift per dword.  With the coset-major
+// layout the next row of a column IS the next lane's current row, so a kernel that needs both loads each column once.
+namespace cs {
+__device__ __forceinline__ uint64_t wave_next(uint64_t v, uint64_t last) {
+    const unsigned lo = __builtin_amdgcn_update_dpp((unsigned)last, (unsigned)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp((unsigned)(last >> 32), (unsigned)(v >> 32), 0x130, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+} // namespace cs
+
 // ---- lazy (unreduced) 128-bit accumulation ------------------------------------------------------------
 // Sums of products of reduced elements are accumulated in 128 bits and Montgomery-reduced once.  A product
 // of two reduced elements is < p^2 < 2^124.07, so seven of them fit below 2^126.9; `fold()` brings the

@@ -91,3 +91,13 @@ def test_matrix_core_mds_product_is_exact(backend):
                                             use_mfma, 1, C.byref(ms)) == 0
         outs.append(to_numpy_u64(d_out))
     assert (outs[0] == outs[1]).all()
+
+
+def test_wave_next_shift(backend):
+    """fp.cuh wave_next: lane l receives lane l+1's value, the last lane of the wave its fallback operand."""
+    n = 256
+    a = np.arange(1000, 1000 + n, dtype=np.uint64) * np.uint64(0x100000001)
+    b = np.arange(5000, 5000 + n, dtype=np.uint64) * np.uint64(0x300000007)
+    got = _run(backend, "cstark_debug_fp_op", a, b, n, 9, n)
+    exp = np.where(np.arange(n) % 64 == 63, b, np.roll(a, -1))
+    assert (got == exp).all()
