@@ -16,6 +16,8 @@ def _mont(v):
 
 
 def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
+    if options[4] == 1:
+        return prove_quadratic(w, options)
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
     assert blowup == 8 and hash_fn in (0, 1) and ext == 0 and folding == 4
     H = lambda data: O.digest(data, hash_fn)
@@ -110,4 +112,115 @@ def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
         cur = fpos
         lg -= 2
     out += [struct.pack("<I", remainder.size), remainder.tobytes()]
+    return b"".join(out)
+
+
+def prove_quadratic(w, options):
+    """FieldExtension::Quadratic: base-field trace, everything drawn from the coin in E = F_p[u]/(u^2 - 2u - 2) (oracle/ext.c).
+    Layout differences: out-of-domain values are pairs; composition rows hold 8 pairs (16 words); FRI rows and the remainder are
+    component-major (a-parts then b-parts)."""
+    nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
+    assert blowup == 8 and hash_fn in (0, 1) and ext == 1 and folding == 4
+    H = lambda data: O.digest(data, hash_fn)
+    log_b, b, W = 3, 8, 94
+    trace = O.tx_build_trace(w)
+    n = trace.shape[1]
+    log_n = n.bit_length() - 1
+    log_N, N = log_n + 3, n * 8
+    log_rem = max_rem.bit_length() - 1
+    pub_m = [int(trace[58 + i, 0]) for i in range(7)] + [int(trace[58 + i, n - 1]) for i in range(7)]
+    pub = [V.from_mont(v) for v in pub_m]
+    coeffs = O.interpolate_columns(trace.copy())
+    lde = O.lde_columns(coeffs, log_b)
+    tnodes = O.merkle_build(O.hash_rows(lde, log_b, hash_fn=hash_fn), hash_fn)
+    trace_root = tnodes[1].tobytes()
+    seed = bytes([W, log_n]) + struct.pack("<Q", V.P) + bytes([nq, log_b, grinding, hash_fn, ext, folding, log_rem])
+    seed += b"".join(struct.pack("<Q", v) for v in pub)
+    coin = V.Coin(seed, hash_fn)
+    coin.reseed(trace_root)
+    cfs = [O.TxCoeffsStruct(), O.TxCoeffsStruct()]
+    for i in range(115):
+        a, bt = coin.draw_e(), coin.draw_e()
+        for k in range(2):
+            cfs[k].t_alpha[i], cfs[k].t_beta[i] = _mont(a[k]), _mont(bt[k])
+    for i in range(4):
+        a, bt = coin.draw_e(), coin.draw_e()
+        for k in range(2):
+            cfs[k].b_alpha[i], cfs[k].b_beta[i] = _mont(a[k]), _mont(bt[k])
+    pub4 = np.array([pub_m[0], pub_m[1], pub_m[7], pub_m[8]], np.uint64)
+    # coefficients multiply base-field values: the two components of the merged evaluations are independent base-field merges
+    cc = [O.composition_columns(O.tx_evaluate_constraints(lde, cfs[k], pub4, w.depth, log_b)) for k in range(2)]
+    ccoef = np.ascontiguousarray(np.stack(cc, axis=1).reshape(16, n))     # column 2i + k = component k of H_i
+    clde = O.lde_columns(ccoef, log_b)
+    cnodes = O.merkle_build(O.hash_rows(clde, log_b, hash_fn=hash_fn), hash_fn)
+    cons_root = cnodes[1].tobytes()
+    coin.reseed(cons_root)
+
+    z = coin.draw_e()
+    zw = V.e_scale(z, V.root_of_unity(log_n))
+    zb = V.e_pow(z, b)
+    ood_cur = O.evaluate_polys_at_ext(coeffs, V.e_mont(z))
+    ood_next = O.evaluate_polys_at_ext(coeffs, V.e_mont(zw))
+    raw = O.evaluate_polys_at_ext(ccoef, V.e_mont(zb))                     # each component polynomial at z^8
+    ood_comp = np.zeros((b, 2), np.uint64)
+    for i in range(b):
+        e0 = (V.from_mont(raw[2 * i, 0]), V.from_mont(raw[2 * i, 1]))
+        e1 = (V.from_mont(raw[2 * i + 1, 0]), V.from_mont(raw[2 * i + 1, 1]))
+        h = V.e_add(e0, V.e_mul((0, 1), e1))                               # H_i = H_i,a + u H_i,b
+        ood_comp[i] = V.e_mont(h)
+    ood_trace = np.concatenate([ood_cur, ood_next])                         # [188][2]
+    coin.reseed(H(ood_trace.tobytes()))
+    coin.reseed(H(ood_comp.tobytes()))
+    d_alpha, d_beta = np.zeros((W, 2), np.uint64), np.zeros((W, 2), np.uint64)
+    for c in range(W):
+        d_alpha[c], d_beta[c] = V.e_mont(coin.draw_e()), V.e_mont(coin.draw_e())
+        coin.draw_e()
+    d_delta = np.array([V.e_mont(coin.draw_e()) for _ in range(b)], np.uint64)
+    deg_a, deg_b = V.e_mont(coin.draw_e()), V.e_mont(coin.draw_e())
+    deep = O.deep_composition_ext(lde, clde, V.e_mont(z), ood_trace, ood_comp, d_alpha, d_beta, d_delta, deg_a, deg_b, log_b)
+    layer = np.ascontiguousarray(np.stack([np.ascontiguousarray(deep[k].T).reshape(-1) for k in range(2)]))  # [2][N] natural order
+
+    layers, trees, roots = [], [], []
+    offset, lg = 3, log_N
+    while lg > log_rem:
+        rows = 1 << (lg - 2)
+        nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 8, rows), 0, hash_fn=hash_fn), hash_fn)
+        layers.append(layer); trees.append(nodes); roots.append(nodes[1].tobytes())
+        coin.reseed(roots[-1])
+        alpha = coin.draw_e()
+        layer = O.fri_fold4_ext(layer, _mont(offset), V.e_mont(alpha))
+        offset = pow(offset, 4, V.P)
+        lg -= 2
+    remainder = layer
+    rem_commit = H(remainder.tobytes())
+    coin.reseed(rem_commit)
+    nonce = 1
+    while grinding and struct.unpack("<Q", H(coin.seed + struct.pack("<Q", nonce))[:8])[0] & ((1 << grinding) - 1):
+        nonce += 1
+    coin.reseed_int(nonce)
+    positions = coin.draw_integers(nq, N)
+
+    def path(nodes, leaves_log, pos):
+        L = 1 << leaves_log
+        return b"".join(nodes[((L + pos) >> lvl) ^ 1].tobytes() for lvl in range(leaves_log))
+
+    def row(tab, pos):
+        return np.ascontiguousarray(tab[pos & 7, :, pos >> 3]).tobytes()
+
+    out = [b"CSTK", struct.pack("<IIIII", 1, 0, W, log_n, w.depth), struct.pack("<7I", *options),
+           trace_root, cons_root, struct.pack("<I", len(roots))] + roots + [rem_commit, ood_trace.tobytes(), ood_comp.tobytes(),
+                                                                           struct.pack("<Q", nonce)]
+    out += [row(lde, p) for p in positions] + [path(tnodes, log_N, p) for p in positions]
+    out += [row(clde, p) for p in positions] + [path(cnodes, log_N, p) for p in positions]
+    cur, lg = positions, log_N
+    for l in range(len(layers)):
+        rows = 1 << (lg - 2)
+        fpos = V.fold_positions(cur, rows)
+        out.append(struct.pack("<I", len(fpos)))
+        tab = layers[l].reshape(8, rows)
+        out += [np.ascontiguousarray(tab[:, p]).tobytes() for p in fpos]
+        out += [path(trees[l], lg - 2, p) for p in fpos]
+        cur = fpos
+        lg -= 2
+    out += [struct.pack("<I", remainder.shape[1]), remainder.tobytes()]
     return b"".join(out)

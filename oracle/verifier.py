@@ -39,6 +39,44 @@ def root_of_unity(log_n):
     return pow(TWO_ADIC_ROOT, 1 << (55 - log_n), P)
 
 
+# ---- E = F_p[u]/(u^2 - 2u - 2): pairs of canonical integers (FieldExtension::Quadratic; see oracle/ext.c for the assumption) ----
+def e_add(x, y):
+    return ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
+
+
+def e_sub(x, y):
+    return ((x[0] - y[0]) % P, (x[1] - y[1]) % P)
+
+
+def e_mul(x, y):
+    bd = x[1] * y[1]
+    return ((x[0] * y[0] + 2 * bd) % P, (x[0] * y[1] + x[1] * y[0] + 2 * bd) % P)
+
+
+def e_scale(x, s):
+    return (x[0] * s % P, x[1] * s % P)
+
+
+def e_inv(x):  # 1/(a + b u) = (a + 2b - b u) / (a^2 + 2ab - 2b^2)
+    a, b = x
+    t = pow((a * a + 2 * a * b - 2 * b * b) % P, -1, P)
+    return ((a + 2 * b) * t % P, (-b) * t % P)
+
+
+def e_pow(x, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = e_mul(r, x)
+        x = e_mul(x, x)
+        e >>= 1
+    return r
+
+
+def e_mont(x):
+    return [to_mont(x[0]), to_mont(x[1])]
+
+
 class Coin:
     def __init__(self, seed_bytes, hash_fn=0):
         self.hash_fn = hash_fn
@@ -63,6 +101,11 @@ class Coin:
             v = self._next()
             if v < P:
                 return v
+
+    def draw_e(self):
+        """an element of the quadratic extension: two base draws"""
+        a = self.draw()
+        return (a, self.draw())
 
     def draw_integers(self, count, domain):
         out = []
@@ -125,6 +168,10 @@ def parse(proof):
     nq, blowup = d["options"][0], d["options"][1]
     if blowup != 8 or not (6 <= d["log_n"] <= 21) or not (1 <= nq <= 128):
         raise VerifierError("unsupported parameters")
+    ext = d["options"][4]
+    if ext not in (0, 1) or (ext == 1 and d["air"] != 0):
+        raise VerifierError("unsupported field extension")
+    em = 2 if ext else 1  # words per element of the field the coin draws from
     log_N = d["log_n"] + 3
     d["trace_root"], d["cons_root"] = r.take(32), r.take(32)
     nl = r.u32()
@@ -132,11 +179,11 @@ def parse(proof):
         raise VerifierError("bad layer count")
     d["layer_roots"] = [r.take(32) for _ in range(nl)]
     d["rem_commit"] = r.take(32)
-    d["ood_cur"], d["ood_next"], d["ood_comp"] = r.elems(W), r.elems(W), r.elems(ce)
+    d["ood_cur"], d["ood_next"], d["ood_comp"] = r.elems(W * em), r.elems(W * em), r.elems(ce * em)
     d["nonce"] = r.u64()
     d["trace_rows"] = r.elems(nq * W).reshape(nq, W)
     d["trace_paths"] = [[r.take(32) for _ in range(log_N)] for _ in range(nq)]
-    d["cons_rows"] = r.elems(nq * ce).reshape(nq, ce)
+    d["cons_rows"] = r.elems(nq * ce * em).reshape(nq, ce * em)
     d["cons_paths"] = [[r.take(32) for _ in range(log_N)] for _ in range(nq)]
     d["layers"] = []
     lg = log_N
@@ -146,14 +193,14 @@ def parse(proof):
         npos = r.u32()
         if npos > nq:
             raise VerifierError("bad layer opening count")
-        rows = r.elems(npos * 4).reshape(npos, 4)
+        rows = r.elems(npos * 4 * em).reshape(npos, 4 * em)
         paths = [[r.take(32) for _ in range(lg - 2)] for _ in range(npos)]
         d["layers"].append((rows, paths))
         lg -= 2
     rl = r.u32()
     if rl > 1024:
         raise VerifierError("bad remainder length")
-    d["remainder"] = r.elems(rl)
+    d["remainder"] = r.elems(rl * em)
     if r.o != len(r.b):
         raise VerifierError("trailing bytes")
     return d
@@ -287,6 +334,8 @@ def verify(proof, initial_root, final_root, options=None):
     d = parse(proof)
     if d["air"] != 0:
         raise VerifierError("not a TransactionAir proof")
+    if d["options"][4] == 1:
+        return _verify_quadratic(d, _TxAir(d, initial_root, final_root), options)
     return _verify(d, _TxAir(d, initial_root, final_root), options)
 
 
@@ -440,4 +489,187 @@ def _verify(d, air, options):
     co = O.ntt(np.array([to_mont(v) for v in rem], np.uint64), inverse=True)
     if any(int(v) != 0 for v in co[R // blowup:]):  # the offset scaling does not change which coefficients vanish
         raise VerifierError("FRI remainder is not a low-degree polynomial")
+    return True
+
+
+def _pairs(words):
+    w = [from_mont(v) for v in words]
+    return [(w[2 * i], w[2 * i + 1]) for i in range(len(w) // 2)]
+
+
+def _tx_constraints_over_e(cur, nxt, per):
+    """The 115 transition constraints on a frame with entries in E, WITHOUT an E-valued AIR: each constraint is a polynomial with
+    base-field coefficients in the frame and periodic values, so t -> C(a + t b) is a base-field polynomial of degree <= 7 (the
+    declared maximum, src/air.rs:76-100); it is sampled with the base-field evaluator at 16 integer points t and read off at t = u by
+    Lagrange interpolation (the map t -> u is a ring homomorphism F_p[t] -> E)."""
+    K = 16
+    ys = []
+    for t in range(K):
+        c = np.array([to_mont((a + t * b) % P) for a, b in cur], np.uint64)
+        nx = np.array([to_mont((a + t * b) % P) for a, b in nxt], np.uint64)
+        pv = np.array([to_mont((a + t * b) % P) for a, b in per], np.uint64)
+        ys.append([from_mont(v) for v in O.tx_evaluate_transition(c, nx, pv)])
+    u = (0, 1)
+    lag = []
+    for j in range(K):
+        num, den = (1, 0), 1
+        for m in range(K):
+            if m != j:
+                num = e_mul(num, e_sub(u, (m, 0)))
+                den = den * (j - m) % P
+        lag.append(e_scale(num, pow(den, -1, P)))
+    out = []
+    for i in range(115):
+        acc = (0, 0)
+        for j in range(K):
+            acc = e_add(acc, e_scale(lag[j], ys[j][i]))
+        out.append(acc)
+    return out
+
+
+def _verify_quadratic(d, air, options):
+    """FieldExtension::Quadratic proofs of TransactionAir (layout: oracle/prover.py prove_quadratic)."""
+    nq, blowup, grinding, hash_fn, ext, folding, max_rem = d["options"]
+    if options is not None and list(options) != d["options"]:
+        raise VerifierError("proof options differ from the expected ones")
+    if hash_fn not in (0, 1) or folding != 4 or max_rem & (max_rem - 1) or not (128 <= max_rem <= 1024):
+        raise VerifierError("unsupported options")
+    log_n, log_b = d["log_n"], 3
+    log_N = log_n + 3
+    n, N, W, b = 1 << log_n, 1 << log_N, 94, 8
+    log_rem = max_rem.bit_length() - 1
+    n_layers, lg = 0, log_N
+    while lg > log_rem:
+        lg -= 2
+        n_layers += 1
+    if n_layers != len(d["layer_roots"]) or len(d["remainder"]) != 2 << lg:
+        raise VerifierError("FRI layer structure does not match the options")
+    seed = bytes([W, log_n]) + struct.pack("<Q", P) + bytes([nq, log_b, grinding, hash_fn, ext, folding, log_rem])
+    seed += b"".join(struct.pack("<Q", v) for v in air.pub)
+    coin = Coin(seed, hash_fn)
+    H = coin.h
+    coin.reseed(d["trace_root"])
+    ta, tb, ba, bb = [], [], [], []
+    for _ in range(115):
+        ta.append(coin.draw_e()); tb.append(coin.draw_e())
+    for _ in range(4):
+        ba.append(coin.draw_e()); bb.append(coin.draw_e())
+    coin.reseed(d["cons_root"])
+    z = coin.draw_e()
+
+    # out-of-domain consistency over E
+    wn = root_of_unity(log_n)
+    cur, nxt, hz = _pairs(d["ood_cur"]), _pairs(d["ood_next"]), _pairs(d["ood_comp"])
+    pco = O.interpolate_columns(O.tx_periodic_columns(air.depth))
+    per = _pairs(O.evaluate_polys_at_ext(pco, e_mont(e_pow(z, n // 1024))).reshape(-1))
+    cvals = _tx_constraints_over_e(cur, nxt, per)
+    adj = [int(v) for v in O.tx_degree_adjustments(log_n, log_b)]
+    zpow = {}
+    acc = (0, 0)
+    for i in range(115):
+        if adj[i] not in zpow:
+            zpow[adj[i]] = e_pow(z, adj[i])
+        acc = e_add(acc, e_mul(cvals[i], e_add(ta[i], e_mul(tb[i], zpow[adj[i]]))))
+    w_last = pow(wn, n - 1, P)
+    zinv = e_mul(e_sub(z, (w_last, 0)), e_inv(e_sub(e_pow(z, n), (1, 0))))
+    acc = e_mul(acc, zinv)
+    xb = e_pow(z, (n << log_b) - n + 1)
+    first = last = (0, 0)
+    for a in range(2):
+        first = e_add(first, e_mul(e_sub(cur[58 + a], (air.pub[a], 0)), e_add(ba[a], e_mul(bb[a], xb))))
+        last = e_add(last, e_mul(e_sub(cur[58 + a], (air.pub[7 + a], 0)), e_add(ba[2 + a], e_mul(bb[2 + a], xb))))
+    lhs = e_add(acc, e_add(e_mul(first, e_inv(e_sub(z, (1, 0)))), e_mul(last, e_inv(e_sub(z, (w_last, 0))))))
+    rhs, zi = (0, 0), (1, 0)
+    for h in hz:
+        rhs = e_add(rhs, e_mul(h, zi))
+        zi = e_mul(zi, z)
+    if lhs != rhs:
+        raise VerifierError("out-of-domain constraint evaluations are inconsistent")
+    coin.reseed(H(np.ascontiguousarray(d["ood_cur"]).tobytes() + np.ascontiguousarray(d["ood_next"]).tobytes()))
+    coin.reseed(H(np.ascontiguousarray(d["ood_comp"]).tobytes()))
+    d_alpha, d_beta = [], []
+    for _ in range(W):
+        d_alpha.append(coin.draw_e()); d_beta.append(coin.draw_e()); coin.draw_e()
+    d_delta = [coin.draw_e() for _ in range(b)]
+    deg_a, deg_b = coin.draw_e(), coin.draw_e()
+    alphas = []
+    for root in d["layer_roots"]:
+        coin.reseed(root)
+        alphas.append(coin.draw_e())
+    if H(np.ascontiguousarray(d["remainder"]).tobytes()) != d["rem_commit"]:
+        raise VerifierError("remainder does not match its commitment")
+    coin.reseed(d["rem_commit"])
+    if grinding:
+        v = struct.unpack("<Q", H(coin.seed + struct.pack("<Q", d["nonce"]))[:8])[0]
+        if v & ((1 << grinding) - 1):
+            raise VerifierError("proof of work not satisfied")
+    coin.reseed_int(d["nonce"])
+    positions = coin.draw_integers(nq, N)
+    for q, pos in enumerate(positions):
+        if merkle_root_from_path(H(d["trace_rows"][q].tobytes()), pos, d["trace_paths"][q], hash_fn) != d["trace_root"]:
+            raise VerifierError("trace opening %d does not match the trace commitment" % q)
+        if merkle_root_from_path(H(d["cons_rows"][q].tobytes()), pos, d["cons_paths"][q], hash_fn) != d["cons_root"]:
+            raise VerifierError("composition opening %d does not match the constraint commitment" % q)
+    # DEEP composition over E at the queried points
+    wN = root_of_unity(log_N)
+    zw, zb = e_scale(z, wn), e_pow(z, b)
+    deep = []
+    for q, pos in enumerate(positions):
+        x = GEN * pow(wN, pos, P) % P
+        i1, i2, i3 = e_inv(e_sub((x, 0), z)), e_inv(e_sub((x, 0), zw)), e_inv(e_sub((x, 0), zb))
+        row = [from_mont(v) for v in d["trace_rows"][q]]
+        crow = _pairs(d["cons_rows"][q])
+        s1 = s2 = s3 = (0, 0)
+        for c in range(W):
+            s1 = e_add(s1, e_mul(d_alpha[c], e_sub((row[c], 0), cur[c])))
+            s2 = e_add(s2, e_mul(d_beta[c], e_sub((row[c], 0), nxt[c])))
+        for i in range(b):
+            s3 = e_add(s3, e_mul(d_delta[i], e_sub(crow[i], hz[i])))
+        t = e_add(e_add(e_mul(s1, i1), e_mul(s2, i2)), e_mul(s3, i3))
+        deep.append(e_mul(t, e_add(deg_a, e_scale(deg_b, x))))
+    # FRI over E (rows and remainder component-major)
+    cur_pos, cur_val = positions, deep
+    offset, lgl = GEN, log_N
+    inv4 = pow(4, -1, P)
+    for l in range(n_layers):
+        rows_n = 1 << (lgl - 2)
+        rows, paths = d["layers"][l]
+        fpos = fold_positions(cur_pos, rows_n)
+        if len(fpos) != len(rows):
+            raise VerifierError("layer %d: wrong number of openings" % l)
+        vals = []
+        for t, rp in enumerate(fpos):
+            if merkle_root_from_path(H(rows[t].tobytes()), rp, paths[t], hash_fn) != d["layer_roots"][l]:
+                raise VerifierError("layer %d opening does not match its commitment" % l)
+            r8 = [from_mont(e) for e in rows[t]]
+            vals.append([(r8[k], r8[4 + k]) for k in range(4)])
+        for p, v in zip(cur_pos, cur_val):
+            if vals[fpos.index(p & (rows_n - 1))][p >> (lgl - 2)] != v:
+                raise VerifierError("layer %d: evaluation differs from the previous layer's folding" % l)
+        wl = root_of_unity(lgl)
+        zeta_inv = pow(pow(wl, rows_n, P), -1, P)
+        nxt_val = []
+        for t, rp in enumerate(fpos):
+            x = offset * pow(wl, rp, P) % P
+            r = e_scale(alphas[l], pow(x, -1, P))
+            acc, rs = (0, 0), (1, 0)
+            for s_ in range(4):
+                cs = (0, 0)
+                for k in range(4):
+                    cs = e_add(cs, e_scale(vals[t][k], pow(zeta_inv, s_ * k, P)))
+                acc = e_add(acc, e_mul(e_scale(cs, inv4), rs))
+                rs = e_mul(rs, r)
+            nxt_val.append(acc)
+        cur_pos, cur_val = fpos, nxt_val
+        offset = pow(offset, 4, P)
+        lgl -= 2
+    R = len(d["remainder"]) // 2
+    rem_a, rem_b = d["remainder"][:R], d["remainder"][R:]
+    for p, v in zip(cur_pos, cur_val):
+        if (from_mont(rem_a[p]), from_mont(rem_b[p])) != v:
+            raise VerifierError("remainder differs from the last layer's folding")
+    for comp in (rem_a, rem_b):
+        co = O.ntt(np.ascontiguousarray(comp, np.uint64).copy(), inverse=True)
+        if any(int(v) != 0 for v in co[R // blowup:]):
+            raise VerifierError("FRI remainder is not a low-degree polynomial")
     return True
