@@ -36,6 +36,21 @@ inline uint64_t root_of_unity(unsigned log_n) {
     return g;
 }
 
+// E = F_p[u]/(u^2 - 2u - 2) on the host (FieldExtension::Quadratic; ext.hip has the assumption)
+struct E2 { uint64_t a, b; };
+inline E2 e_add(E2 x, E2 y) { return {add(x.a, y.a), add(x.b, y.b)}; }
+inline E2 e_sub(E2 x, E2 y) { return {sub(x.a, y.a), sub(x.b, y.b)}; }
+inline E2 e_mul(E2 x, E2 y) {
+    const uint64_t bd = mul(x.b, y.b), bd2 = add(bd, bd);
+    return {add(mul(x.a, y.a), bd2), add(add(mul(x.a, y.b), mul(x.b, y.a)), bd2)};
+}
+inline E2 e_scale(E2 x, uint64_t s) { return {mul(x.a, s), mul(x.b, s)}; }
+inline E2 e_pow(E2 x, uint64_t e) {
+    E2 r{ONE, 0};
+    while (e) { if (e & 1) r = e_mul(r, x); x = e_mul(x, x); e >>= 1; }
+    return r;
+}
+
 // in-place inverse transform of a short sequence (m = 2^log_m values over the m-th roots of unity) -> coefficients
 inline void intt_small(uint64_t *a, unsigned log_m) {
     const size_t m = (size_t)1 << log_m;

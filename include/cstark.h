@@ -75,7 +75,7 @@ typedef struct cstark_options {
     uint32_t blowup_factor;    /* 8 */
     uint32_t grinding_factor;  /* 0 */
     uint32_t hash_fn;          /* 0 = Blake3_256, 1 = Sha3_256 */
-    uint32_t field_extension;  /* 0 = None (only one implemented), 1 = Quadratic, 2 = Cubic */
+    uint32_t field_extension;  /* 0 = None, 1 = Quadratic (TransactionAir proofs), 2 = Cubic (not implemented) */
     uint32_t fri_folding_factor; /* 4 */
     uint32_t fri_max_remainder;  /* 256 */
 } cstark_options;
@@ -120,6 +120,20 @@ int cstark_interpolate_columns(cstark_ctx *ctx, uint64_t *d_evals, uint64_t *d_c
  * Sharding by coset is what distributes one proof over several GPUs. */
 int cstark_lde_columns(cstark_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t log_n,
                        uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);
+
+/* FieldExtension::Quadratic: the same three stages over E = F_p[u]/(u^2 - 2u - 2) [assumption: the quadratic extension the
+ * reference uses under its curve tower, src/utils/ecc.rs:407-466; the fork's own choice for f63 is not in the tree].  An element of
+ * E is a pair (a, b) = a + b u of base elements, stored consecutively.  The trace stays in the base field.
+ *   cstark_evaluate_polys_at_ext: base-coefficient columns at one point of E; out[c][2] on the host.
+ *   cstark_deep_composition_ext: all cosets; d_comp_lde holds 2 n_comp base columns per coset (column 2i + k = component k of
+ *     composition column i); coefficient / OOD arrays are host arrays of pairs; d_out = [2][b][n], component-major.
+ *   cstark_fri_fold4_ext: d_evals = [2][N] component-major -> d_out = [2][N/4]. */
+int cstark_evaluate_polys_at_ext(cstark_ctx *ctx, const uint64_t *d_coeffs, uint32_t width, uint32_t log_n, const uint64_t z[2], uint64_t *out);
+int cstark_deep_composition_ext(cstark_ctx *ctx, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp,
+                                const uint64_t z[2], const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha,
+                                const uint64_t *beta, const uint64_t *delta, const uint64_t deg_a[2], const uint64_t deg_b[2], uint64_t *d_out,
+                                uint32_t log_n, uint32_t log_blowup);
+int cstark_fri_fold4_ext(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, const uint64_t alpha[2]);
 
 /* ---- K4/K5: Blake3 row hashing + Merkle tree (engine: build_commitment) ---------------------- */
 /* Hash row j of coset k (width elements, 8 bytes LE each, memory form) into leaf i = b*j + k:
