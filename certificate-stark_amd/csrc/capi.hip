@@ -410,41 +410,43 @@ int cstark_fri_fold4(cstark_ctx *c, const uint64_t *d_evals, uint64_t *d_out, ui
     return CSTARK_OK;
 }
 
-// ---- FieldExtension::Quadratic: the same three stages over E = F_p[u]/(u^2 - 2u - 2) (ext.hip) --------------------------------
-int cstark_evaluate_polys_at_ext(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, uint32_t log_n, const uint64_t z[2], uint64_t *out) {
-    if (!c || !d_coeffs || !z || !out || width == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_evaluate_polys_at_ext: bad argument");
-    if (log_n > 30 || z[0] >= cs::host::P || z[1] >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "bad polynomial size / point");
+// ---- FieldExtension::Quadratic / Cubic: the same three stages over the degree-m extension (ext.hip) ---------------------------
+int cstark_evaluate_polys_at_ext(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, uint32_t log_n, uint32_t m, const uint64_t *z, uint64_t *out) {
+    if (!c || !d_coeffs || !z || !out || width == 0 || (m != 2 && m != 3)) return fail(CSTARK_ERR_INVALID_ARG, "cstark_evaluate_polys_at_ext: bad argument");
+    if (log_n > 30) return fail(CSTARK_ERR_INVALID_ARG, "bad polynomial size");
+    for (uint32_t i = 0; i < m; i++) if (z[i] >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "the point is not an extension element");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t need = ((size_t)2 * width + cs::poly_eval_ext_scratch_words(width, log_n)) * 8;
+    const size_t need = ((size_t)m * width + cs::poly_eval_ext_scratch_words(width, log_n, m)) * 8;
     if (need > c->desc_bytes) {
         if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); c->desc_buf = nullptr; c->desc_bytes = 0; }
         HIP_TRY(hipMalloc(&c->desc_buf, need));
         c->desc_bytes = need;
     }
-    uint64_t *d_out = (uint64_t *)c->desc_buf, *d_scr = d_out + 2 * (size_t)width;
-    HIP_TRY(cs::poly_eval_ext(d_coeffs, width, log_n, z[0], z[1], d_out, d_scr, c->stream));
-    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)2 * width * 8, hipMemcpyDeviceToHost, c->stream));
+    uint64_t *d_out = (uint64_t *)c->desc_buf, *d_scr = d_out + (size_t)m * width;
+    HIP_TRY(cs::poly_eval_ext(d_coeffs, width, log_n, z, m, d_out, d_scr, c->stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)m * width * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CSTARK_OK;
 }
-int cstark_deep_composition_ext(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, const uint64_t z[2],
-                                const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta, const uint64_t *delta,
-                                const uint64_t deg_a[2], const uint64_t deg_b[2], uint64_t *d_out, uint32_t log_n, uint32_t log_blowup) {
-    if (!c || !d_trace_lde || !d_comp_lde || !z || !ood_trace || !ood_comp || !alpha || !beta || !delta || !deg_a || !deg_b || !d_out || width == 0 || n_comp == 0)
+int cstark_deep_composition_ext(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
+                                const uint64_t *z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
+                                const uint64_t *delta, const uint64_t *deg_a, const uint64_t *deg_b, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup) {
+    if (!c || !d_trace_lde || !d_comp_lde || !z || !ood_trace || !ood_comp || !alpha || !beta || !delta || !deg_a || !deg_b || !d_out || width == 0 || n_comp == 0 ||
+        (m != 2 && m != 3))
         return fail(CSTARK_ERR_INVALID_ARG, "cstark_deep_composition_ext: bad argument");
     if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
-    using cs::host::E2;
+    using namespace cs::host;
     HIP_TRY(hipSetDevice(c->device));
     const NttPlan *plan;
     RC_TRY(get_plan(c, log_n, &plan));
-    const size_t b = (size_t)1 << log_blowup, nco = 2 * ((size_t)2 * width + n_comp);
+    const size_t b = (size_t)1 << log_blowup, nco = (size_t)m * (2 * (size_t)width + n_comp);
     std::vector<uint64_t> blk(nco + b);
-    memcpy(blk.data(), alpha, 2 * (size_t)width * 8);
-    memcpy(blk.data() + 2 * width, beta, 2 * (size_t)width * 8);
-    memcpy(blk.data() + 4 * width, delta, 2 * (size_t)n_comp * 8);
-    const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
-    uint64_t shift = cs::host::generator();
-    for (size_t k = 0; k < b; k++) { blk[nco + k] = shift; shift = cs::host::mul(shift, wbn); }
+    memcpy(blk.data(), alpha, (size_t)m * width * 8);
+    memcpy(blk.data() + (size_t)m * width, beta, (size_t)m * width * 8);
+    memcpy(blk.data() + (size_t)2 * m * width, delta, (size_t)m * n_comp * 8);
+    const uint64_t wbn = root_of_unity(log_n + log_blowup);
+    uint64_t shift = generator();
+    for (size_t k = 0; k < b; k++) { blk[nco + k] = shift; shift = mul(shift, wbn); }
     const size_t bytes = blk.size() * 8;
     if (bytes > c->desc_bytes) {
         if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); c->desc_buf = nullptr; c->desc_bytes = 0; }
@@ -455,28 +457,30 @@ int cstark_deep_composition_ext(cstark_ctx *c, const uint64_t *d_trace_lde, cons
     HIP_TRY(hipStreamSynchronize(c->stream));
     cs::DeepExtParams p{};
     p.trace_lde = d_trace_lde; p.comp_lde = d_comp_lde; p.w = plan->w; p.coef = (const uint64_t *)c->desc_buf; p.shifts = p.coef + nco; p.out = d_out;
-    const E2 zz{z[0], z[1]}, zw = cs::host::e_scale(zz, cs::host::root_of_unity(log_n)), zb = cs::host::e_pow(zz, n_comp);
-    p.z[0] = zz.a; p.z[1] = zz.b; p.zw[0] = zw.a; p.zw[1] = zw.b; p.zb[0] = zb.a; p.zb[1] = zb.b;
-    p.deg_a[0] = deg_a[0]; p.deg_a[1] = deg_a[1]; p.deg_b[0] = deg_b[0]; p.deg_b[1] = deg_b[1];
-    E2 k1{0, 0}, k2{0, 0}, k3{0, 0};
+    const EX zz = ex_load(z, m), zw = ex_scale(zz, root_of_unity(log_n)), zb = ex_pow(zz, n_comp, m), da = ex_load(deg_a, m), db = ex_load(deg_b, m);
+    EX k1 = ex_zero(), k2 = ex_zero(), k3 = ex_zero();
     for (uint32_t i = 0; i < width; i++) {
-        k1 = cs::host::e_add(k1, cs::host::e_mul({alpha[2 * i], alpha[2 * i + 1]}, {ood_trace[2 * i], ood_trace[2 * i + 1]}));
-        k2 = cs::host::e_add(k2, cs::host::e_mul({beta[2 * i], beta[2 * i + 1]}, {ood_trace[2 * (width + i)], ood_trace[2 * (width + i) + 1]}));
+        k1 = ex_add(k1, ex_mul(ex_load(alpha + (size_t)m * i, m), ex_load(ood_trace + (size_t)m * i, m), m));
+        k2 = ex_add(k2, ex_mul(ex_load(beta + (size_t)m * i, m), ex_load(ood_trace + (size_t)m * (width + i), m), m));
     }
-    for (uint32_t i = 0; i < n_comp; i++) k3 = cs::host::e_add(k3, cs::host::e_mul({delta[2 * i], delta[2 * i + 1]}, {ood_comp[2 * i], ood_comp[2 * i + 1]}));
-    p.k1[0] = k1.a; p.k1[1] = k1.b; p.k2[0] = k2.a; p.k2[1] = k2.b; p.k3[0] = k3.a; p.k3[1] = k3.b;
-    p.width = width; p.nb = n_comp; p.log_n = log_n; p.log_b = log_blowup;
+    for (uint32_t i = 0; i < n_comp; i++) k3 = ex_add(k3, ex_mul(ex_load(delta + (size_t)m * i, m), ex_load(ood_comp + (size_t)m * i, m), m));
+    for (int q = 0; q < 3; q++) {
+        p.z[q] = zz.c[q]; p.zw[q] = zw.c[q]; p.zb[q] = zb.c[q]; p.deg_a[q] = da.c[q]; p.deg_b[q] = db.c[q];
+        p.k1[q] = k1.c[q]; p.k2[q] = k2.c[q]; p.k3[q] = k3.c[q];
+    }
+    p.width = width; p.nb = n_comp; p.log_n = log_n; p.log_b = log_blowup; p.m = m;
     HIP_TRY(cs::deep_composition_ext(p, c->stream));
     return CSTARK_OK;
 }
-int cstark_fri_fold4_ext(cstark_ctx *c, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, const uint64_t alpha[2]) {
-    if (!c || !d_evals || !d_out || !alpha || d_evals == d_out) return fail(CSTARK_ERR_INVALID_ARG, "cstark_fri_fold4_ext: bad argument");
+int cstark_fri_fold4_ext(cstark_ctx *c, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, uint32_t m, const uint64_t *alpha) {
+    if (!c || !d_evals || !d_out || !alpha || d_evals == d_out || (m != 2 && m != 3)) return fail(CSTARK_ERR_INVALID_ARG, "cstark_fri_fold4_ext: bad argument");
     if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "layer size must be 2^6 .. 2^24");
-    if (domain_offset == 0 || domain_offset >= cs::host::P || alpha[0] >= cs::host::P || alpha[1] >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "offset / alpha must be field elements");
+    if (domain_offset == 0 || domain_offset >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "offset must be a nonzero field element");
+    for (uint32_t i = 0; i < m; i++) if (alpha[i] >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "alpha is not an extension element");
     HIP_TRY(hipSetDevice(c->device));
     const NttPlan *p;
     RC_TRY(get_plan(c, log_n, &p));
-    HIP_TRY(cs::fri_fold4_ext(d_evals, d_out, log_n, p->winv, cs::host::inv(domain_offset), alpha[0], alpha[1], cs::host::inv(cs::host::from_u64(4)), c->stream));
+    HIP_TRY(cs::fri_fold4_ext(d_evals, d_out, log_n, p->winv, cs::host::inv(domain_offset), alpha, m, cs::host::inv(cs::host::from_u64(4)), c->stream));
     return CSTARK_OK;
 }
 

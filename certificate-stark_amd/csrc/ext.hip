@@ -1,64 +1,92 @@
-// FieldExtension::Quadratic: the stages after the constraint evaluation over E = F_p[u]/(u^2 - 2u - 2).
-// [UPSTREAM-RECALL winterfell v0.3; the extension the fork defines for f63 is not in the reference tree -- parity unpinned.
-// Assumed: the quadratic extension the reference uses as the base of its curve tower, src/utils/ecc.rs:407-466 = Fp2 of tower.cuh.]
-// The trace is base-field; coefficients, the out-of-domain point, the DEEP composition and FRI are in E.
+// FieldExtension::Quadratic / Cubic: the stages after the constraint evaluation over an extension of f63.
+// [UPSTREAM-RECALL winterfell v0.3; the extensions the fork defines for f63 are not in the reference tree -- parity unpinned.
+// Assumed: the two polynomials of the reference's own curve tower (src/utils/ecc.rs:407-648): E2 = F_p[u]/(u^2 - 2u - 2) (= Fp2 of
+// tower.cuh) and E3 = F_p[v]/(v^3 + v + 1).]  The trace is base-field; coefficients, the out-of-domain point, the DEEP composition
+// and FRI are in the extension.
 #include "ext.h"
 #include "tower.cuh"
 
 namespace cs {
 namespace {
 
-__device__ __forceinline__ Fp2 e_scale(Fp2 x, fp s) { return {fp_mul(x.a, s), fp_mul(x.b, s)}; }
-__device__ inline Fp2 e_pow(Fp2 x, uint64_t e) {
-    Fp2 r = {FP_ONE, 0};
+template <int M> struct Ext { fp c[M]; };
+template <int M> __device__ __forceinline__ Ext<M> x_zero() { Ext<M> r; for (int i = 0; i < M; i++) r.c[i] = 0; return r; }
+template <int M> __device__ __forceinline__ Ext<M> x_one() { Ext<M> r = x_zero<M>(); r.c[0] = FP_ONE; return r; }
+template <int M> __device__ __forceinline__ Ext<M> x_load(const uint64_t *p) { Ext<M> r; for (int i = 0; i < M; i++) r.c[i] = p[i]; return r; }
+template <int M> __device__ __forceinline__ Ext<M> x_add(Ext<M> x, Ext<M> y) { Ext<M> r; for (int i = 0; i < M; i++) r.c[i] = fp_add(x.c[i], y.c[i]); return r; }
+template <int M> __device__ __forceinline__ Ext<M> x_sub(Ext<M> x, Ext<M> y) { Ext<M> r; for (int i = 0; i < M; i++) r.c[i] = fp_sub(x.c[i], y.c[i]); return r; }
+template <int M> __device__ __forceinline__ Ext<M> x_scale(Ext<M> x, fp s) { Ext<M> r; for (int i = 0; i < M; i++) r.c[i] = fp_mul(x.c[i], s); return r; }
+__device__ __forceinline__ Ext<2> x_mul(Ext<2> x, Ext<2> y) {
+    const Fp2 r = fp2_mul({x.c[0], x.c[1]}, {y.c[0], y.c[1]});
+    return {{r.a, r.b}};
+}
+__device__ __forceinline__ Ext<3> x_mul(Ext<3> x, Ext<3> y) { // v^3 = -v - 1, v^4 = -v^2 - v
+    const fp d0 = fp_mul(x.c[0], y.c[0]);
+    const fp d1 = fp_add(fp_mul(x.c[0], y.c[1]), fp_mul(x.c[1], y.c[0]));
+    const fp d2 = fp_add(fp_add(fp_mul(x.c[0], y.c[2]), fp_mul(x.c[1], y.c[1])), fp_mul(x.c[2], y.c[0]));
+    const fp d3 = fp_add(fp_mul(x.c[1], y.c[2]), fp_mul(x.c[2], y.c[1]));
+    const fp d4 = fp_mul(x.c[2], y.c[2]);
+    return {{fp_sub(d0, d3), fp_sub(fp_sub(d1, d3), d4), fp_sub(d2, d4)}};
+}
+template <int M> __device__ inline Ext<M> x_pow(Ext<M> x, uint64_t e) {
+    Ext<M> r = x_one<M>();
     while (e) {
-        if (e & 1) r = fp2_mul(r, x);
-        x = fp2_sqr(x);
+        if (e & 1) r = x_mul(r, x);
+        x = x_mul(x, x);
         e >>= 1;
     }
     return r;
 }
+// 1 / (x - z) for base x as adjugate / norm (the norm is a base-field element, so several inverses share one inversion)
+template <int M> struct XInv { Ext<M> adj; fp norm; };
+__device__ __forceinline__ XInv<2> x_inv_parts(fp x, const uint64_t *zc, Ext<2> *) {
+    const fp a = fp_sub(x, zc[0]), b = fp_neg(zc[1]); // (a + b u)^-1 = (a + 2b - b u) / (a^2 + 2ab - 2b^2)
+    return {{{fp_add(a, fp_dbl(b)), fp_neg(b)}}, fp_sub(fp_add(fp_sqr(a), fp_mul(fp_dbl(a), b)), fp_dbl(fp_sqr(b)))};
+}
+__device__ __forceinline__ XInv<3> x_inv_parts(fp x, const uint64_t *zc, Ext<3> *) {
+    const fp a = fp_sub(x, zc[0]), b = fp_neg(zc[1]), c = fp_neg(zc[2]); // adjugate modulo v^3 + v + 1 (cubic layer of ecc.rs:551-591)
+    const fp s0 = fp_sqr(a), s1 = fp_sqr(b), s2 = fp_sqr(c);
+    const fp r0 = fp_sub(fp_add(fp_add(s0, s1), s2), fp_mul(fp_sub(fp_dbl(a), b), c));
+    const fp r1 = fp_neg(fp_add(fp_mul(a, b), s2));
+    const fp r2 = fp_add(fp_sub(s1, fp_mul(a, c)), s2);
+    return {{{r0, r1, r2}}, fp_sub(fp_mul(a, r0), fp_add(fp_mul(b, r2), fp_mul(c, r1)))};
+}
 
 constexpr int PE_SEG = 16384;
-// grid = (segments, width): Horner in z^256 over one segment of one column, E accumulator, base coefficients
-__global__ __launch_bounds__(256) void k_poly_eval_ext_partial(const fp *__restrict__ coeffs, size_t n, Fp2 z, fp *__restrict__ partial, unsigned seg_len) {
-    __shared__ Fp2 part[256];
+// grid = (segments, width): Horner in z^256 over one segment of one column, extension accumulator, base coefficients
+template <int M>
+__global__ __launch_bounds__(256) void k_poly_eval_ext_partial(const fp *__restrict__ coeffs, size_t n, Ext<M> z, fp *__restrict__ partial, unsigned seg_len) {
+    __shared__ Ext<M> part[256];
     const unsigned segs = gridDim.x, seg = blockIdx.x, col = blockIdx.y, t = threadIdx.x;
     const fp *c = coeffs + (size_t)col * n + (size_t)seg * seg_len;
-    const Fp2 z256 = e_pow(z, 256);
-    Fp2 acc = {0, 0};
+    const Ext<M> z256 = x_pow(z, 256);
+    Ext<M> acc = x_zero<M>();
     const unsigned per = (seg_len + 255) / 256;
     for (unsigned k = per; k-- > 0;) {
         const fp v = k * 256 + t < seg_len ? c[(size_t)k * 256 + t] : 0;
-        acc = fp2_mul(acc, z256);
-        acc.a = fp_add(acc.a, v);
+        acc = x_mul(acc, z256);
+        acc.c[0] = fp_add(acc.c[0], v);
     }
-    part[t] = fp2_mul(acc, e_pow(z, (uint64_t)seg * seg_len + t));
+    part[t] = x_mul(acc, x_pow(z, (uint64_t)seg * seg_len + t));
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)t < s) part[t] = fp2_add(part[t], part[t + s]);
+        if ((int)t < s) part[t] = x_add(part[t], part[t + s]);
         __syncthreads();
     }
-    if (t == 0) { partial[2 * ((size_t)col * segs + seg)] = part[0].a; partial[2 * ((size_t)col * segs + seg) + 1] = part[0].b; }
+    if (t == 0)
+        for (int q = 0; q < M; q++) partial[M * ((size_t)col * segs + seg) + q] = part[0].c[q];
 }
-__global__ void k_poly_eval_ext_sum(const fp *__restrict__ partial, fp *__restrict__ out, unsigned width, unsigned segs) {
+__global__ void k_poly_eval_ext_sum(const fp *__restrict__ partial, fp *__restrict__ out, unsigned width, unsigned segs, unsigned m) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x; // (column, component)
-    if (i >= 2 * width) return;
-    const unsigned col = i >> 1, k = i & 1;
+    if (i >= m * width) return;
+    const unsigned col = i / m, k = i % m;
     fp a = 0;
-    for (unsigned s = 0; s < segs; s++) a = fp_add(a, partial[2 * ((size_t)col * segs + s) + k]);
+    for (unsigned s = 0; s < segs; s++) a = fp_add(a, partial[m * ((size_t)col * segs + s) + k]);
     out[i] = a;
 }
 
-// 1 / (x - z) for base x: (a, b) = (x - z.a, -z.b); inverse = (a + 2b, -b) / (a^2 + 2ab - 2b^2)
-struct EInv { Fp2 num; fp norm; };
-__device__ __forceinline__ EInv e_inv_parts(fp x, const uint64_t zc[2]) {
-    const fp a = fp_sub(x, zc[0]), b = fp_neg(zc[1]);
-    const fp norm = fp_sub(fp_add(fp_sqr(a), fp_mul(fp_dbl(a), b)), fp_dbl(fp_sqr(b)));
-    return {{fp_add(a, fp_dbl(b)), fp_neg(b)}, norm};
-}
-
 // grid = (ceil(n / 256), b)
+template <int M>
 __global__ __launch_bounds__(256) void k_deep_ext(DeepExtParams p) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
@@ -66,82 +94,102 @@ __global__ __launch_bounds__(256) void k_deep_ext(DeepExtParams p) {
     const unsigned k = blockIdx.y, b = 1u << p.log_b;
     const fp x = fp_mul(p.shifts[k], p.w[j]);
     // the three divisors with one base-field inversion
-    const EInv q1 = e_inv_parts(x, p.z), q2 = e_inv_parts(x, p.zw), q3 = e_inv_parts(x, p.zb);
+    const XInv<M> q1 = x_inv_parts(x, p.z, (Ext<M> *)nullptr), q2 = x_inv_parts(x, p.zw, (Ext<M> *)nullptr), q3 = x_inv_parts(x, p.zb, (Ext<M> *)nullptr);
     const fp n12 = fp_mul(q1.norm, q2.norm);
     const fp inv = fp_inv(fp_mul(n12, q3.norm));
-    const Fp2 i1 = e_scale(q1.num, fp_mul(inv, fp_mul(q2.norm, q3.norm))), i2 = e_scale(q2.num, fp_mul(inv, fp_mul(q1.norm, q3.norm))),
-              i3 = e_scale(q3.num, fp_mul(inv, n12));
-    // sum_c alpha_c T_c(x) and sum_c beta_c T_c(x): base values against E coefficients = component-wise dot products
-    Acc128 s1a = acc_zero(), s1b = acc_zero(), s2a = acc_zero(), s2b = acc_zero();
+    const Ext<M> i1 = x_scale(q1.adj, fp_mul(inv, fp_mul(q2.norm, q3.norm))), i2 = x_scale(q2.adj, fp_mul(inv, fp_mul(q1.norm, q3.norm))),
+                 i3 = x_scale(q3.adj, fp_mul(inv, n12));
+    // sum_c alpha_c T_c(x), sum_c beta_c T_c(x): base values against extension coefficients = component-wise dot products
+    Acc128 s1[M], s2[M];
+#pragma unroll
+    for (int q = 0; q < M; q++) { s1[q] = acc_zero(); s2[q] = acc_zero(); }
     const fp *t = p.trace_lde + (size_t)k * p.width * n + j;
-    const fp *al = p.coef, *be = p.coef + 2 * p.width, *de = p.coef + 4 * p.width;
+    const fp *al = p.coef, *be = p.coef + (size_t)M * p.width, *de = p.coef + (size_t)2 * M * p.width;
     for (unsigned c = 0; c < p.width; c++) {
         const fp v = t[(size_t)c * n];
-        acc_mad(s1a, al[2 * c], v); acc_mad(s1b, al[2 * c + 1], v);
-        acc_mad(s2a, be[2 * c], v); acc_mad(s2b, be[2 * c + 1], v);
-        if ((c & 3) == 3) { acc_fold(s1a); acc_fold(s1b); acc_fold(s2a); acc_fold(s2b); }
+#pragma unroll
+        for (int q = 0; q < M; q++) { acc_mad(s1[q], al[M * c + q], v); acc_mad(s2[q], be[M * c + q], v); }
+        if ((c & 3) == 3) {
+#pragma unroll
+            for (int q = 0; q < M; q++) { acc_fold(s1[q]); acc_fold(s2[q]); }
+        }
     }
-    acc_fold(s1a); acc_fold(s1b); acc_fold(s2a); acc_fold(s2b);
-    const Fp2 s1 = fp2_sub({acc_reduce(s1a), acc_reduce(s1b)}, {p.k1[0], p.k1[1]});
-    const Fp2 s2 = fp2_sub({acc_reduce(s2a), acc_reduce(s2b)}, {p.k2[0], p.k2[1]});
-    Fp2 s3 = {0, 0};
-    const fp *h = p.comp_lde + (size_t)k * 2 * p.nb * n + j;
-    for (unsigned i = 0; i < p.nb; i++) s3 = fp2_add(s3, fp2_mul({de[2 * i], de[2 * i + 1]}, {h[(size_t)(2 * i) * n], h[(size_t)(2 * i + 1) * n]}));
-    s3 = fp2_sub(s3, {p.k3[0], p.k3[1]});
-    Fp2 acc = fp2_add(fp2_add(fp2_mul(s1, i1), fp2_mul(s2, i2)), fp2_mul(s3, i3));
-    acc = fp2_mul(acc, fp2_add({p.deg_a[0], p.deg_a[1]}, e_scale({p.deg_b[0], p.deg_b[1]}, x)));
-    p.out[(size_t)k * n + j] = acc.a;
-    p.out[((size_t)b + k) * n + j] = acc.b;
+    Ext<M> e1, e2;
+#pragma unroll
+    for (int q = 0; q < M; q++) {
+        acc_fold(s1[q]); acc_fold(s2[q]);
+        e1.c[q] = fp_sub(acc_reduce(s1[q]), p.k1[q]);
+        e2.c[q] = fp_sub(acc_reduce(s2[q]), p.k2[q]);
+    }
+    Ext<M> e3 = x_zero<M>();
+    const fp *h = p.comp_lde + (size_t)k * M * p.nb * n + j;
+    for (unsigned i = 0; i < p.nb; i++) {
+        Ext<M> hv;
+#pragma unroll
+        for (int q = 0; q < M; q++) hv.c[q] = h[(size_t)(M * i + q) * n];
+        e3 = x_add(e3, x_mul(x_load<M>(de + M * i), hv));
+    }
+    e3 = x_sub(e3, x_load<M>(p.k3));
+    Ext<M> acc = x_add(x_add(x_mul(e1, i1), x_mul(e2, i2)), x_mul(e3, i3));
+    acc = x_mul(acc, x_add(x_load<M>(p.deg_a), x_scale(x_load<M>(p.deg_b), x)));
+#pragma unroll
+    for (int q = 0; q < M; q++) p.out[((size_t)q * b + k) * n + j] = acc.c[q];
 }
 
+template <int M>
 __global__ __launch_bounds__(256) void k_fri_fold4_ext(const fp *__restrict__ evals, fp *__restrict__ out, size_t q, const fp *__restrict__ winv,
-                                                       fp offset_inv, Fp2 alpha, fp inv4) {
+                                                       fp offset_inv, Ext<M> alpha, fp inv4) {
     const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
     if (i >= q) return;
     const size_t N = 4 * q;
     const fp zi = winv[q]; // zeta^-1
-    Fp2 s[4];
+    Ext<M> s[4];
 #pragma unroll
-    for (int comp = 0; comp < 2; comp++) { // the size-4 inverse DFT is linear over the base field: per component
+    for (int comp = 0; comp < M; comp++) { // the size-4 inverse DFT is linear over the base field: per component
         const fp *e = evals + comp * N;
         const fp v0 = e[i], v1 = e[i + q], v2 = e[i + 2 * q], v3 = e[i + 3 * q];
         const fp a = fp_add(v0, v2), b = fp_sub(v0, v2), c = fp_add(v1, v3), d = fp_mul(fp_sub(v1, v3), zi);
-        const fp r0 = fp_add(a, c), r2 = fp_sub(a, c), r1 = fp_add(b, d), r3 = fp_sub(b, d);
-        if (comp == 0) { s[0].a = r0; s[1].a = r1; s[2].a = r2; s[3].a = r3; }
-        else { s[0].b = r0; s[1].b = r1; s[2].b = r2; s[3].b = r3; }
+        s[0].c[comp] = fp_add(a, c); s[2].c[comp] = fp_sub(a, c); s[1].c[comp] = fp_add(b, d); s[3].c[comp] = fp_sub(b, d);
     }
-    const Fp2 r = e_scale(alpha, fp_mul(offset_inv, winv[i]));
-    const Fp2 r2 = fp2_sqr(r), r3 = fp2_mul(r2, r);
-    Fp2 acc = fp2_add(fp2_add(s[0], fp2_mul(r, s[1])), fp2_add(fp2_mul(r2, s[2]), fp2_mul(r3, s[3])));
-    acc = e_scale(acc, inv4);
-    out[i] = acc.a;
-    out[q + i] = acc.b;
+    const Ext<M> r = x_scale(alpha, fp_mul(offset_inv, winv[i]));
+    const Ext<M> r2 = x_mul(r, r), r3 = x_mul(r2, r);
+    Ext<M> acc = x_add(x_add(s[0], x_mul(r, s[1])), x_add(x_mul(r2, s[2]), x_mul(r3, s[3])));
+    acc = x_scale(acc, inv4);
+#pragma unroll
+    for (int comp = 0; comp < M; comp++) out[comp * q + i] = acc.c[comp];
 }
 
 } // namespace
 
-size_t poly_eval_ext_scratch_words(unsigned width, unsigned log_n) {
+size_t poly_eval_ext_scratch_words(unsigned width, unsigned log_n, unsigned m) {
     const size_t n = (size_t)1 << log_n, seg = n < (size_t)PE_SEG ? n : (size_t)PE_SEG;
-    return 2 * (size_t)width * (n / seg);
+    return (size_t)m * width * (n / seg);
 }
-hipError_t poly_eval_ext(const uint64_t *d_coeffs, unsigned width, unsigned log_n, uint64_t za, uint64_t zb, uint64_t *d_out, uint64_t *d_scratch,
+hipError_t poly_eval_ext(const uint64_t *d_coeffs, unsigned width, unsigned log_n, const uint64_t *z, unsigned m, uint64_t *d_out, uint64_t *d_scratch,
                          hipStream_t stream) {
     const size_t n = (size_t)1 << log_n;
     const unsigned seg_len = (unsigned)(n < (size_t)PE_SEG ? n : (size_t)PE_SEG), segs = (unsigned)(n / seg_len);
-    hipLaunchKernelGGL(k_poly_eval_ext_partial, dim3(segs, width), dim3(256), 0, stream, d_coeffs, n, Fp2{za, zb}, d_scratch, seg_len);
-    hipLaunchKernelGGL(k_poly_eval_ext_sum, dim3((2 * width + 255) / 256), dim3(256), 0, stream, d_scratch, d_out, width, segs);
+    if (m == 2) hipLaunchKernelGGL(k_poly_eval_ext_partial<2>, dim3(segs, width), dim3(256), 0, stream, d_coeffs, n, Ext<2>{{z[0], z[1]}}, d_scratch, seg_len);
+    else if (m == 3) hipLaunchKernelGGL(k_poly_eval_ext_partial<3>, dim3(segs, width), dim3(256), 0, stream, d_coeffs, n, Ext<3>{{z[0], z[1], z[2]}}, d_scratch, seg_len);
+    else return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_poly_eval_ext_sum, dim3((m * width + 255) / 256), dim3(256), 0, stream, d_scratch, d_out, width, segs, m);
     return hipGetLastError();
 }
 hipError_t deep_composition_ext(const DeepExtParams &p, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    hipLaunchKernelGGL(k_deep_ext, dim3((unsigned)((n + 255) / 256), 1u << p.log_b), dim3(256), 0, stream, p);
+    const dim3 grid((unsigned)((n + 255) / 256), 1u << p.log_b);
+    if (p.m == 2) hipLaunchKernelGGL(k_deep_ext<2>, grid, dim3(256), 0, stream, p);
+    else if (p.m == 3) hipLaunchKernelGGL(k_deep_ext<3>, grid, dim3(256), 0, stream, p);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t fri_fold4_ext(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, const uint64_t *d_winv, uint64_t offset_inv, uint64_t alpha_a,
-                         uint64_t alpha_b, uint64_t inv4, hipStream_t stream) {
+hipError_t fri_fold4_ext(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, const uint64_t *d_winv, uint64_t offset_inv, const uint64_t *alpha,
+                         unsigned m, uint64_t inv4, hipStream_t stream) {
     const size_t q = ((size_t)1 << log_n) / 4;
-    hipLaunchKernelGGL(k_fri_fold4_ext, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv,
-                       Fp2{alpha_a, alpha_b}, inv4);
+    const dim3 grid((unsigned)((q + 255) / 256));
+    if (m == 2) hipLaunchKernelGGL(k_fri_fold4_ext<2>, grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, Ext<2>{{alpha[0], alpha[1]}}, inv4);
+    else if (m == 3) hipLaunchKernelGGL(k_fri_fold4_ext<3>, grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, Ext<3>{{alpha[0], alpha[1], alpha[2]}}, inv4);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -36,18 +36,27 @@ inline uint64_t root_of_unity(unsigned log_n) {
     return g;
 }
 
-// E = F_p[u]/(u^2 - 2u - 2) on the host (FieldExtension::Quadratic; ext.hip has the assumption)
-struct E2 { uint64_t a, b; };
-inline E2 e_add(E2 x, E2 y) { return {add(x.a, y.a), add(x.b, y.b)}; }
-inline E2 e_sub(E2 x, E2 y) { return {sub(x.a, y.a), sub(x.b, y.b)}; }
-inline E2 e_mul(E2 x, E2 y) {
-    const uint64_t bd = mul(x.b, y.b), bd2 = add(bd, bd);
-    return {add(mul(x.a, y.a), bd2), add(add(mul(x.a, y.b), mul(x.b, y.a)), bd2)};
+// Extension fields on the host (FieldExtension::Quadratic / Cubic; ext.hip has the assumed polynomials):
+// m = 2: F_p[u]/(u^2 - 2u - 2), m = 3: F_p[v]/(v^3 + v + 1); unused high coefficients stay zero
+struct EX { uint64_t c[3]; };
+inline EX ex_zero() { return {{0, 0, 0}}; }
+inline EX ex_one() { return {{ONE, 0, 0}}; }
+inline EX ex_load(const uint64_t *p, unsigned m) { EX r = ex_zero(); for (unsigned i = 0; i < m; i++) r.c[i] = p[i]; return r; }
+inline EX ex_add(EX x, EX y) { return {{add(x.c[0], y.c[0]), add(x.c[1], y.c[1]), add(x.c[2], y.c[2])}}; }
+inline EX ex_scale(EX x, uint64_t s) { return {{mul(x.c[0], s), mul(x.c[1], s), mul(x.c[2], s)}}; }
+inline EX ex_mul(EX x, EX y, unsigned m) {
+    if (m == 2) {
+        const uint64_t bd = mul(x.c[1], y.c[1]), bd2 = add(bd, bd);
+        return {{add(mul(x.c[0], y.c[0]), bd2), add(add(mul(x.c[0], y.c[1]), mul(x.c[1], y.c[0])), bd2), 0}};
+    }
+    const uint64_t d0 = mul(x.c[0], y.c[0]), d1 = add(mul(x.c[0], y.c[1]), mul(x.c[1], y.c[0]));
+    const uint64_t d2 = add(add(mul(x.c[0], y.c[2]), mul(x.c[1], y.c[1])), mul(x.c[2], y.c[0]));
+    const uint64_t d3 = add(mul(x.c[1], y.c[2]), mul(x.c[2], y.c[1])), d4 = mul(x.c[2], y.c[2]);
+    return {{sub(d0, d3), sub(sub(d1, d3), d4), sub(d2, d4)}};
 }
-inline E2 e_scale(E2 x, uint64_t s) { return {mul(x.a, s), mul(x.b, s)}; }
-inline E2 e_pow(E2 x, uint64_t e) {
-    E2 r{ONE, 0};
-    while (e) { if (e & 1) r = e_mul(r, x); x = e_mul(x, x); e >>= 1; }
+inline EX ex_pow(EX x, uint64_t e, unsigned m) {
+    EX r = ex_one();
+    while (e) { if (e & 1) r = ex_mul(r, x, m); x = ex_mul(x, x, m); e >>= 1; }
     return r;
 }
 

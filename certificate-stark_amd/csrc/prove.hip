@@ -203,7 +203,7 @@ int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned n_layer
 int check_options(const cstark_options *opt, unsigned *log_rem_out) {
     if (opt->blowup_factor != 8) return fail(CSTARK_ERR_UNSUPPORTED, "proofs use blowup factor 8 (src/lib.rs:78-86)");
     if (opt->hash_fn > 1) return fail(CSTARK_ERR_UNSUPPORTED, "hash_fn must be Blake3_256 (0) or Sha3_256 (1)");
-    if (opt->field_extension > 1) return fail(CSTARK_ERR_UNSUPPORTED, "FieldExtension::Cubic is not implemented");
+    if (opt->field_extension > 2) return fail(CSTARK_ERR_INVALID_ARG, "field_extension must be None (0), Quadratic (1) or Cubic (2)");
     if (opt->fri_folding_factor != 4) return fail(CSTARK_ERR_UNSUPPORTED, "only FRI folding factor 4 is implemented");
     if (opt->num_queries == 0 || opt->num_queries > 128) return fail(CSTARK_ERR_INVALID_ARG, "num_queries must be 1..128");
     if (opt->grinding_factor > 32) return fail(CSTARK_ERR_INVALID_ARG, "grinding_factor must be at most 32");
@@ -493,13 +493,14 @@ int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *t
 }
 
 
-// ---- TransactionAir with FieldExtension::Quadratic ---------------------------------------------------------------------------------
-// Base-field trace; everything the coin draws lives in E = F_p[u]/(u^2 - 2u - 2) (ext.hip).  Coefficients multiply base-field
-// constraint values, so the merged evaluations are two independent runs of the fused evaluator (components a, b).  Layout
-// differences of the proof: out-of-domain values are pairs, composition rows hold 8 pairs, FRI rows and the remainder are
-// component-major (a-parts, then b-parts).
-int prove_tx_quadratic(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_t capacity, size_t *proof_len) {
-    using host::E2;
+// ---- TransactionAir with FieldExtension::Quadratic / Cubic ------------------------------------------------------------------------
+// Base-field trace; everything the coin draws lives in the degree-m extension (ext.hip).  Coefficients multiply base-field
+// constraint values, so the merged evaluations are m independent runs of the fused evaluator (one per component).  Layout
+// differences of the proof: out-of-domain values are m-tuples, composition rows hold 8 m-tuples, FRI rows and the remainder are
+// component-major.
+int prove_tx_ext(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_t capacity, size_t *proof_len) {
+    using namespace host;
+    const unsigned m = opt->field_extension + 1;
     unsigned log_rem = 0;
     RC_TRY(check_options(opt, &log_rem));
     AirJob job;
@@ -507,25 +508,25 @@ int prove_tx_quadratic(cstark_ctx *c, const cstark_options *opt, uint8_t *proof,
     job.n_constraints = CSTARK_TX_NUM_CONSTRAINTS; job.n_assertions = 4; job.item = c->wit.depth;
     const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b;
     if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "at most 2^21 trace rows");
-    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = job.width;
+    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = job.width, CW = m * b; // CW: base columns of the composition table
     const unsigned n_layers = num_fri_layers(log_N, log_rem);
     const size_t nq = opt->num_queries;
     if (nq > N / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
     HIP_TRY(hipSetDevice(c->device));
     ProveArena *a;
     RC_TRY(get_arena(c, job, log_b, n_layers, nq, &a));
-    uint64_t *combined_b, *ccoef_b, *ccoef16, *clde16, *deep2;
+    uint64_t *combined_x, *ccoef_x, *ccoefs, *cldes, *deepx;
     uint8_t *d_open;
-    RC_TRY(arena_extra(a, 0, &combined_b, N * 8));
-    RC_TRY(arena_extra(a, 1, &ccoef_b, N * 8));
-    RC_TRY(arena_extra(a, 2, &ccoef16, 2 * N * 8));
-    RC_TRY(arena_extra(a, 3, &clde16, 2 * b * N * 8));
-    RC_TRY(arena_extra(a, 4, &deep2, 2 * N * 8));
-    RC_TRY(arena_extra(a, 5, &d_open, nq * (W * 8 + 128 + 2 * log_N * 32 + (size_t)n_layers * (64 + log_N * 32)) + 256));
+    RC_TRY(arena_extra(a, 0, &combined_x, 2 * N * 8));   // components 1, 2 of the merged evaluations
+    RC_TRY(arena_extra(a, 1, &ccoef_x, 2 * N * 8));      // their column coefficients
+    RC_TRY(arena_extra(a, 2, &ccoefs, 3 * N * 8));       // interleaved: column m i + k
+    RC_TRY(arena_extra(a, 3, &cldes, 3 * b * N * 8));
+    RC_TRY(arena_extra(a, 4, &deepx, 3 * N * 8));
+    RC_TRY(arena_extra(a, 5, &d_open, nq * (W * 8 + 192 + 2 * log_N * 32 + (size_t)n_layers * (96 + log_N * 32)) + 256));
     std::vector<uint64_t *> layer(n_layers + 1);
     {
         size_t sz = N;
-        for (unsigned l = 0; l <= n_layers; l++) { RC_TRY(arena_extra(a, 6 + l, &layer[l], 2 * sz * 8)); sz /= 4; }
+        for (unsigned l = 0; l <= n_layers; l++) { RC_TRY(arena_extra(a, 6 + l, &layer[l], 3 * sz * 8)); sz /= 4; }
     }
     hipStream_t st = c->stream;
     int evi = 0;
@@ -538,7 +539,7 @@ int prove_tx_quadratic(cstark_ctx *c, const cstark_options *opt, uint8_t *proof,
     STAGE();
     RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, (uint32_t)W, log_n));
     STAGE();
-    RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, (uint32_t)W, log_n, log_b, host::generator(), 0, (uint32_t)b));
+    RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, (uint32_t)W, log_n, log_b, generator(), 0, (uint32_t)b));
     STAGE();
     RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
@@ -553,91 +554,91 @@ int prove_tx_quadratic(cstark_ctx *c, const cstark_options *opt, uint8_t *proof,
         Writer s;
         const uint8_t ctxb[2] = {(uint8_t)W, (uint8_t)log_n};
         s.raw(ctxb, 2);
-        s.u64(host::P);
+        s.u64(P);
         const uint8_t ob[7] = {(uint8_t)opt->num_queries, (uint8_t)log_b, (uint8_t)opt->grinding_factor, (uint8_t)opt->hash_fn,
                                (uint8_t)opt->field_extension, (uint8_t)opt->fri_folding_factor, (uint8_t)log_rem};
         s.raw(ob, 7);
-        for (uint64_t v : job.pub) s.u64(host::to_u64(v));
+        for (uint64_t v : job.pub) s.u64(to_u64(v));
         coin.init(s.b.data(), s.b.size());
     }
     coin.reseed(trace_root);
-    auto draw_e = [&coin]() { const uint64_t x = coin.draw(); return E2{x, coin.draw()}; };
-    cstark_tx_coeffs cf[2];
+    auto draw_e = [&coin, m]() { EX x = ex_zero(); for (unsigned q = 0; q < m; q++) x.c[q] = coin.draw(); return x; };
+    cstark_tx_coeffs cf[3];
     for (int i = 0; i < CSTARK_TX_NUM_CONSTRAINTS; i++) {
-        const E2 al = draw_e(), be = draw_e();
-        cf[0].t_alpha[i] = al.a; cf[1].t_alpha[i] = al.b; cf[0].t_beta[i] = be.a; cf[1].t_beta[i] = be.b;
+        const EX al = draw_e(), be = draw_e();
+        for (unsigned q = 0; q < m; q++) { cf[q].t_alpha[i] = al.c[q]; cf[q].t_beta[i] = be.c[q]; }
     }
     for (int i = 0; i < 4; i++) {
-        const E2 al = draw_e(), be = draw_e();
-        cf[0].b_alpha[i] = al.a; cf[1].b_alpha[i] = al.b; cf[0].b_beta[i] = be.a; cf[1].b_beta[i] = be.b;
+        const EX al = draw_e(), be = draw_e();
+        for (unsigned q = 0; q < m; q++) { cf[q].b_alpha[i] = al.c[q]; cf[q].b_beta[i] = be.c[q]; }
     }
     const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]};
-    RC_TRY(cstark_tx_evaluate_constraints(c, a->lde, &cf[0], pub4, a->combined, job.item, log_n, log_b, 0, (uint32_t)b));
-    RC_TRY(cstark_tx_evaluate_constraints(c, a->lde, &cf[1], pub4, combined_b, job.item, log_n, log_b, 0, (uint32_t)b));
+    uint64_t *comb[3] = {a->combined, combined_x, combined_x + N}, *cco[3] = {a->ccoef, ccoef_x, ccoef_x + N};
+    for (unsigned q = 0; q < m; q++) RC_TRY(cstark_tx_evaluate_constraints(c, a->lde, &cf[q], pub4, comb[q], job.item, log_n, log_b, 0, (uint32_t)b));
     STAGE();
-    RC_TRY(cstark_composition_columns(c, a->combined, a->ccoef, log_n, log_b));
-    RC_TRY(cstark_composition_columns(c, combined_b, ccoef_b, log_n, log_b));
-    for (size_t i = 0; i < b; i++) { // column 2i + k = component k of composition column i
-        HIP_TRY(hipMemcpyAsync(ccoef16 + (2 * i) * n, a->ccoef + i * n, n * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ccoef16 + (2 * i + 1) * n, ccoef_b + i * n, n * 8, hipMemcpyDeviceToDevice, st));
-    }
-    RC_TRY(cstark_lde_columns(c, ccoef16, clde16, 16, log_n, log_b, host::generator(), 0, (uint32_t)b));
-    RC_TRY(cstark_hash_rows_fn(c, hf, clde16, a->cnodes + 32 * N, 16, log_n, log_b, 0, (uint32_t)b));
+    for (unsigned q = 0; q < m; q++) RC_TRY(cstark_composition_columns(c, comb[q], cco[q], log_n, log_b));
+    for (size_t i = 0; i < b; i++) // column m i + q = component q of composition column i
+        for (unsigned q = 0; q < m; q++) HIP_TRY(hipMemcpyAsync(ccoefs + (m * i + q) * n, cco[q] + i * n, n * 8, hipMemcpyDeviceToDevice, st));
+    RC_TRY(cstark_lde_columns(c, ccoefs, cldes, (uint32_t)CW, log_n, log_b, generator(), 0, (uint32_t)b));
+    RC_TRY(cstark_hash_rows_fn(c, hf, cldes, a->cnodes + 32 * N, (uint32_t)CW, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
     HIP_TRY(hipMemcpyAsync(cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(hipStreamSynchronize(st));
     coin.reseed(cons_root);
 
-    const E2 z = draw_e(), zw = host::e_scale(z, host::root_of_unity(log_n)), zb = host::e_pow(z, b);
-    std::vector<uint64_t> ood_trace(4 * W), raw(32), ood_comp(16);
-    const uint64_t zv[2] = {z.a, z.b}, zwv[2] = {zw.a, zw.b}, zbv[2] = {zb.a, zb.b};
-    RC_TRY(cstark_evaluate_polys_at_ext(c, a->coeffs, (uint32_t)W, log_n, zv, ood_trace.data()));
-    RC_TRY(cstark_evaluate_polys_at_ext(c, a->coeffs, (uint32_t)W, log_n, zwv, ood_trace.data() + 2 * W));
-    RC_TRY(cstark_evaluate_polys_at_ext(c, ccoef16, 16, log_n, zbv, raw.data()));
-    for (size_t i = 0; i < b; i++) { // H_i = H_i,a + u H_i,b, each component polynomial evaluated at z^8 in E
-        const E2 e0{raw[4 * i], raw[4 * i + 1]}, e1{raw[4 * i + 2], raw[4 * i + 3]};
-        const E2 h = host::e_add(e0, host::e_mul(E2{0, host::ONE}, e1));
-        ood_comp[2 * i] = h.a; ood_comp[2 * i + 1] = h.b;
+    const EX z = draw_e(), zw = ex_scale(z, root_of_unity(log_n)), zb = ex_pow(z, b, m);
+    std::vector<uint64_t> ood_trace(2 * m * W), raw(m * CW), ood_comp(m * b);
+    RC_TRY(cstark_evaluate_polys_at_ext(c, a->coeffs, (uint32_t)W, log_n, m, z.c, ood_trace.data()));
+    RC_TRY(cstark_evaluate_polys_at_ext(c, a->coeffs, (uint32_t)W, log_n, m, zw.c, ood_trace.data() + m * W));
+    RC_TRY(cstark_evaluate_polys_at_ext(c, ccoefs, (uint32_t)CW, log_n, m, zb.c, raw.data()));
+    {
+        EX gen = ex_zero();
+        gen.c[1] = ONE; // the adjoined root
+        for (size_t i = 0; i < b; i++) { // H_i = sum_q root^q H_i,q, each component polynomial evaluated at z^8
+            EX h = ex_zero(), gq = ex_one();
+            for (unsigned q = 0; q < m; q++) {
+                h = ex_add(h, ex_mul(gq, ex_load(raw.data() + m * (m * i + q), m), m));
+                gq = ex_mul(gq, gen, m);
+            }
+            for (unsigned q = 0; q < m; q++) ood_comp[m * i + q] = h.c[q];
+        }
     }
     uint8_t dg[32];
     hash_elements(hf, ood_trace.data(), ood_trace.size(), dg); coin.reseed(dg);
     hash_elements(hf, ood_comp.data(), ood_comp.size(), dg); coin.reseed(dg);
     STAGE();
 
-    std::vector<uint64_t> d_alpha(2 * W), d_beta(2 * W), d_delta(16);
+    std::vector<uint64_t> d_alpha(m * W), d_beta(m * W), d_delta(m * b);
     for (size_t i = 0; i < W; i++) {
-        const E2 al = draw_e(), be = draw_e();
+        const EX al = draw_e(), be = draw_e();
         (void)draw_e(); // conjugate-term coefficient of the engine, unused here
-        d_alpha[2 * i] = al.a; d_alpha[2 * i + 1] = al.b; d_beta[2 * i] = be.a; d_beta[2 * i + 1] = be.b;
+        for (unsigned q = 0; q < m; q++) { d_alpha[m * i + q] = al.c[q]; d_beta[m * i + q] = be.c[q]; }
     }
-    for (size_t i = 0; i < b; i++) { const E2 dl = draw_e(); d_delta[2 * i] = dl.a; d_delta[2 * i + 1] = dl.b; }
-    const E2 dga = draw_e(), dgb = draw_e();
-    const uint64_t dgav[2] = {dga.a, dga.b}, dgbv[2] = {dgb.a, dgb.b};
-    RC_TRY(cstark_deep_composition_ext(c, a->lde, clde16, (uint32_t)W, (uint32_t)b, zv, ood_trace.data(), ood_comp.data(), d_alpha.data(), d_beta.data(),
-                                       d_delta.data(), dgav, dgbv, deep2, log_n, log_b));
-    RC_TRY(cstark_interleave_cosets(c, deep2, layer[0], log_n, log_b));
-    RC_TRY(cstark_interleave_cosets(c, deep2 + N, layer[0] + N, log_n, log_b));
+    for (size_t i = 0; i < b; i++) { const EX dl = draw_e(); for (unsigned q = 0; q < m; q++) d_delta[m * i + q] = dl.c[q]; }
+    const EX dga = draw_e(), dgb = draw_e();
+    RC_TRY(cstark_deep_composition_ext(c, a->lde, cldes, (uint32_t)W, (uint32_t)b, m, z.c, ood_trace.data(), ood_comp.data(), d_alpha.data(), d_beta.data(),
+                                       d_delta.data(), dga.c, dgb.c, deepx, log_n, log_b));
+    for (unsigned q = 0; q < m; q++) RC_TRY(cstark_interleave_cosets(c, deepx + q * N, layer[0] + q * N, log_n, log_b));
     STAGE();
 
     std::vector<uint8_t> layer_roots(32 * (size_t)n_layers);
-    uint64_t offset = host::generator();
+    uint64_t offset = generator();
     unsigned lg = log_N;
     for (unsigned l = 0; l < n_layers; l++) {
         const size_t rows = (size_t)1 << (lg - 2);
-        RC_TRY(cstark_hash_rows_fn(c, hf, layer[l], a->lnodes[l] + 32 * rows, 8, lg - 2, 0, 0, 1)); // [2][4][rows]: row = a0..a3, b0..b3
+        RC_TRY(cstark_hash_rows_fn(c, hf, layer[l], a->lnodes[l] + 32 * rows, 4 * m, lg - 2, 0, 0, 1)); // [m][4][rows]: component-major rows
         RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - 2));
         HIP_TRY(hipMemcpyAsync(&layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         coin.reseed(&layer_roots[32 * l]);
-        const E2 alpha = draw_e();
-        const uint64_t av[2] = {alpha.a, alpha.b};
-        RC_TRY(cstark_fri_fold4_ext(c, layer[l], layer[l + 1], lg, offset, av));
-        offset = host::pow(offset, 4);
+        const EX alpha = draw_e();
+        RC_TRY(cstark_fri_fold4_ext(c, layer[l], layer[l + 1], lg, offset, m, alpha.c));
+        offset = pow(offset, 4);
         lg -= 2;
     }
     const size_t R = (size_t)1 << lg;
-    std::vector<uint64_t> remainder(2 * R);
+    std::vector<uint64_t> remainder(m * R);
     HIP_TRY(hipMemcpyAsync(remainder.data(), layer[n_layers], remainder.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     uint8_t rem_commit[32];
@@ -670,20 +671,20 @@ int prove_tx_quadratic(cstark_ctx *c, const cstark_options *opt, uint8_t *proof,
     size_t off = 0;
     const size_t o_trows = off; off += nq * W * 8;
     const size_t o_tpath = off; off += nq * log_N * 32;
-    const size_t o_crows = off; off += nq * 16 * 8;
+    const size_t o_crows = off; off += nq * CW * 8;
     const size_t o_cpath = off; off += nq * log_N * 32;
     k_gather_rows<<<(unsigned)nq, 128, 0, st>>>(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, (uint64_t *)(o + o_trows));
     k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->tnodes, log_N, a->d_pos, (uint4 *)(o + o_tpath));
-    k_gather_rows<<<(unsigned)nq, 64, 0, st>>>(clde16, 16, log_n, log_b, a->d_pos, (uint64_t *)(o + o_crows));
+    k_gather_rows<<<(unsigned)nq, 64, 0, st>>>(cldes, (uint32_t)CW, log_n, log_b, a->d_pos, (uint64_t *)(o + o_crows));
     k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->cnodes, log_N, a->d_pos, (uint4 *)(o + o_cpath));
     std::vector<size_t> o_lrows(n_layers), o_lpath(n_layers);
     {
         unsigned g2 = log_N;
         for (unsigned l = 0; l < n_layers; l++) {
             const unsigned np = (unsigned)lpos[l].size(), lr = g2 - 2;
-            o_lrows[l] = off; off += (size_t)np * 64;
+            o_lrows[l] = off; off += (size_t)np * 32 * m;
             o_lpath[l] = off; off += (size_t)np * lr * 32;
-            k_gather_rows<<<np, 64, 0, st>>>(layer[l], 8, lr, 0, a->d_pos + 256 * (l + 1), (uint64_t *)(o + o_lrows[l]));
+            k_gather_rows<<<np, 64, 0, st>>>(layer[l], 4 * m, lr, 0, a->d_pos + 256 * (l + 1), (uint64_t *)(o + o_lrows[l]));
             k_gather_paths<<<np, 64, 0, st>>>((const uint4 *)a->lnodes[l], lr, a->d_pos + 256 * (l + 1), (uint4 *)(o + o_lpath[l]));
             g2 -= 2;
         }
@@ -706,13 +707,13 @@ int prove_tx_quadratic(cstark_ctx *c, const cstark_options *opt, uint8_t *proof,
     wr.raw(ood_trace.data(), ood_trace.size() * 8); wr.raw(ood_comp.data(), ood_comp.size() * 8);
     wr.u64(nonce);
     wr.raw(open.data() + o_trows, nq * W * 8); wr.raw(open.data() + o_tpath, nq * log_N * 32);
-    wr.raw(open.data() + o_crows, nq * 16 * 8); wr.raw(open.data() + o_cpath, nq * log_N * 32);
+    wr.raw(open.data() + o_crows, nq * CW * 8); wr.raw(open.data() + o_cpath, nq * log_N * 32);
     {
         unsigned g2 = log_N;
         for (unsigned l = 0; l < n_layers; l++) {
             const size_t np = lpos[l].size();
             wr.u32((uint32_t)np);
-            wr.raw(open.data() + o_lrows[l], np * 64);
+            wr.raw(open.data() + o_lrows[l], np * 32 * m);
             wr.raw(open.data() + o_lpath[l], np * (g2 - 2) * 32);
             g2 -= 2;
         }
@@ -735,7 +736,7 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     if (!c || !opt || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_prove: null argument");
     if (!c->wit_buf || c->wit.n_tx == 0 || c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no transaction witness uploaded");
     if (c->wit.n_tx & (c->wit.n_tx - 1)) return fail(CSTARK_ERR_INVALID_ARG, "the number of transactions must be a power of two");
-    if (opt->field_extension == 1) return prove_tx_quadratic(c, opt, proof, capacity, proof_len);
+    if (opt->field_extension == 1 || opt->field_extension == 2) return prove_tx_ext(c, opt, proof, capacity, proof_len);
     AirJob job;
     job.air = CSTARK_AIR_STATE_TRANSITION; job.width = CSTARK_TX_TRACE_WIDTH; job.log_n = 10 + ceil_log2(c->wit.n_tx); job.log_ce = 3;
     job.n_constraints = CSTARK_TX_NUM_CONSTRAINTS; job.n_assertions = 4; job.item = c->wit.depth;
@@ -782,7 +783,7 @@ size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt) {
     if (!opt || n_tx == 0) return 0;
     unsigned log_N = 13;
     while ((1u << (log_N - 13)) < n_tx) log_N++;
-    const size_t nq = opt->num_queries, layers = log_N / 2 + 1, em = opt->field_extension ? 2 : 1; // em: words per drawn-field element
+    const size_t nq = opt->num_queries, layers = log_N / 2 + 1, em = opt->field_extension + 1; // em: words per drawn-field element
     return 4096 + 32 * layers + (2 * 94 + 8) * 8 * em + nq * (94 * 8 + 8 * 8 * em + 2 * log_N * 32) + layers * (4 + nq * (32 * em + log_N * 32)) +
            8 * em * (size_t)opt->fri_max_remainder;
 }

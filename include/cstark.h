@@ -75,7 +75,7 @@ typedef struct cstark_options {
     uint32_t blowup_factor;    /* 8 */
     uint32_t grinding_factor;  /* 0 */
     uint32_t hash_fn;          /* 0 = Blake3_256, 1 = Sha3_256 */
-    uint32_t field_extension;  /* 0 = None, 1 = Quadratic (TransactionAir proofs), 2 = Cubic (not implemented) */
+    uint32_t field_extension;  /* 0 = None, 1 = Quadratic, 2 = Cubic (extensions: TransactionAir proofs) */
     uint32_t fri_folding_factor; /* 4 */
     uint32_t fri_max_remainder;  /* 256 */
 } cstark_options;
@@ -121,19 +121,21 @@ int cstark_interpolate_columns(cstark_ctx *ctx, uint64_t *d_evals, uint64_t *d_c
 int cstark_lde_columns(cstark_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t log_n,
                        uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);
 
-/* FieldExtension::Quadratic: the same three stages over E = F_p[u]/(u^2 - 2u - 2) [assumption: the quadratic extension the
- * reference uses under its curve tower, src/utils/ecc.rs:407-466; the fork's own choice for f63 is not in the tree].  An element of
- * E is a pair (a, b) = a + b u of base elements, stored consecutively.  The trace stays in the base field.
- *   cstark_evaluate_polys_at_ext: base-coefficient columns at one point of E; out[c][2] on the host.
- *   cstark_deep_composition_ext: all cosets; d_comp_lde holds 2 n_comp base columns per coset (column 2i + k = component k of
- *     composition column i); coefficient / OOD arrays are host arrays of pairs; d_out = [2][b][n], component-major.
- *   cstark_fri_fold4_ext: d_evals = [2][N] component-major -> d_out = [2][N/4]. */
-int cstark_evaluate_polys_at_ext(cstark_ctx *ctx, const uint64_t *d_coeffs, uint32_t width, uint32_t log_n, const uint64_t z[2], uint64_t *out);
-int cstark_deep_composition_ext(cstark_ctx *ctx, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp,
-                                const uint64_t z[2], const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha,
-                                const uint64_t *beta, const uint64_t *delta, const uint64_t deg_a[2], const uint64_t deg_b[2], uint64_t *d_out,
+/* FieldExtension::Quadratic / Cubic: the same three stages over the degree-m extension, m = 2: F_p[u]/(u^2 - 2u - 2), m = 3:
+ * F_p[v]/(v^3 + v + 1) [assumption: the two polynomials of the reference's own curve tower, src/utils/ecc.rs:407-648; the fork's
+ * choices for f63 are not in the tree].  An element is m consecutive base elements (coefficients of 1, x, x^2).  The trace stays
+ * in the base field.
+ *   cstark_evaluate_polys_at_ext: base-coefficient columns at one point; out[c][m] on the host.
+ *   cstark_deep_composition_ext: all cosets; d_comp_lde holds m n_comp base columns per coset (column m i + k = component k of
+ *     composition column i); coefficient / OOD arrays are host arrays of m-tuples; d_out = [m][b][n], component-major.
+ *   cstark_fri_fold4_ext: d_evals = [m][N] component-major -> d_out = [m][N/4]. */
+int cstark_evaluate_polys_at_ext(cstark_ctx *ctx, const uint64_t *d_coeffs, uint32_t width, uint32_t log_n, uint32_t m, const uint64_t *z, uint64_t *out);
+int cstark_deep_composition_ext(cstark_ctx *ctx, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
+                                const uint64_t *z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha,
+                                const uint64_t *beta, const uint64_t *delta, const uint64_t *deg_a, const uint64_t *deg_b, uint64_t *d_out,
                                 uint32_t log_n, uint32_t log_blowup);
-int cstark_fri_fold4_ext(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, const uint64_t alpha[2]);
+int cstark_fri_fold4_ext(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, uint32_t m,
+                         const uint64_t *alpha);
 
 /* ---- K4/K5: Blake3 row hashing + Merkle tree (engine: build_commitment) ---------------------- */
 /* Hash row j of coset k (width elements, 8 bytes LE each, memory form) into leaf i = b*j + k:

@@ -82,11 +82,11 @@ void cso_deep_composition(const uint64_t *trace_lde, const uint64_t *comp_lde, u
                           const uint64_t *delta, uint64_t deg_a, uint64_t deg_b, uint64_t *out, unsigned log_n, unsigned log_b,
                           uint32_t k0, uint32_t nk);
 void cso_evaluate_polys_at(const uint64_t *coeffs, uint32_t width, unsigned log_n, const uint64_t *points, uint32_t npts, uint64_t *out);
-void cso_evaluate_polys_at_ext(const uint64_t *coeffs, uint32_t width, unsigned log_n, const uint64_t *z2, uint64_t *out);
+void cso_evaluate_polys_at_ext(const uint64_t *coeffs, uint32_t width, unsigned log_n, const uint64_t *zp, uint64_t *out, int m);
 void cso_deep_composition_ext(const uint64_t *trace_lde, const uint64_t *comp_lde, uint32_t width, uint32_t nb, const uint64_t *z2,
                               const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
-                              const uint64_t *delta, const uint64_t *deg_a2, const uint64_t *deg_b2, uint64_t *out, unsigned log_n, unsigned log_b);
-void cso_fri_fold4_ext(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, const uint64_t *alpha2);
+                              const uint64_t *delta, const uint64_t *deg_ap, const uint64_t *deg_bp, uint64_t *out, unsigned log_n, unsigned log_b, int m);
+void cso_fri_fold4_ext(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, const uint64_t *alphap, int m);
 void cso_fri_fold4(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, uint64_t alpha);
 uint64_t cso_poly_eval(const uint64_t *co, size_t n, uint64_t x);
 uint64_t cso_tx_combined_from_frame(const uint64_t *cur, const uint64_t *next, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],

@@ -572,29 +572,31 @@ def fri_fold4(evals, offset, alpha):
     return out
 
 
-# ---- FieldExtension::Quadratic (oracle/ext.c): E = F_p[u]/(u^2 - 2u - 2), elements as pairs of memory-form base elements --------
-def evaluate_polys_at_ext(coeffs, z2):
-    coeffs = _u64(coeffs)
+# ---- FieldExtension::Quadratic / Cubic (oracle/ext.c): elements as m-tuples of memory-form base elements ---------------------------
+def evaluate_polys_at_ext(coeffs, zp):
+    coeffs, zp = _u64(coeffs), _u64(zp)
     width, n = coeffs.shape
-    out = np.zeros((width, 2), np.uint64)
-    lib().cso_evaluate_polys_at_ext(_p(coeffs), C.c_uint32(width), C.c_uint(n.bit_length() - 1), _p(_u64(z2)), _p(out))
+    m = zp.size
+    out = np.zeros((width, m), np.uint64)
+    lib().cso_evaluate_polys_at_ext(_p(coeffs), C.c_uint32(width), C.c_uint(n.bit_length() - 1), _p(zp), _p(out), C.c_int(m))
     return out
 
 
-def deep_composition_ext(trace_lde, comp_lde, z2, ood_trace, ood_comp, alpha, beta, delta, deg_a2, deg_b2, log_b):
-    trace_lde, comp_lde = _u64(trace_lde), _u64(comp_lde)
+def deep_composition_ext(trace_lde, comp_lde, zp, ood_trace, ood_comp, alpha, beta, delta, deg_a, deg_b, log_b):
+    trace_lde, comp_lde, zp = _u64(trace_lde), _u64(comp_lde), _u64(zp)
     b, width, n = trace_lde.shape
-    nb = comp_lde.shape[1] // 2
-    out = np.zeros((2, b, n), np.uint64)
-    lib().cso_deep_composition_ext(_p(trace_lde), _p(comp_lde), C.c_uint32(width), C.c_uint32(nb), _p(_u64(z2)), _p(_u64(ood_trace)),
-                                   _p(_u64(ood_comp)), _p(_u64(alpha)), _p(_u64(beta)), _p(_u64(delta)), _p(_u64(deg_a2)), _p(_u64(deg_b2)),
-                                   _p(out), C.c_uint(n.bit_length() - 1), C.c_uint(log_b))
+    m = zp.size
+    nb = comp_lde.shape[1] // m
+    out = np.zeros((m, b, n), np.uint64)
+    lib().cso_deep_composition_ext(_p(trace_lde), _p(comp_lde), C.c_uint32(width), C.c_uint32(nb), _p(zp), _p(_u64(ood_trace)),
+                                   _p(_u64(ood_comp)), _p(_u64(alpha)), _p(_u64(beta)), _p(_u64(delta)), _p(_u64(deg_a)), _p(_u64(deg_b)),
+                                   _p(out), C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_int(m))
     return out
 
 
-def fri_fold4_ext(evals, offset, alpha2):
-    evals = _u64(evals)
-    N = evals.shape[1]
-    out = np.zeros((2, N // 4), np.uint64)
-    lib().cso_fri_fold4_ext(_p(evals), _p(out), C.c_uint(N.bit_length() - 1), C.c_uint64(offset), _p(_u64(alpha2)))
+def fri_fold4_ext(evals, offset, alphap):
+    evals, alphap = _u64(evals), _u64(alphap)
+    m, N = evals.shape
+    out = np.zeros((m, N // 4), np.uint64)
+    lib().cso_fri_fold4_ext(_p(evals), _p(out), C.c_uint(N.bit_length() - 1), C.c_uint64(offset), _p(alphap), C.c_int(m))
     return out

@@ -16,8 +16,8 @@ def _mont(v):
 
 
 def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
-    if options[4] == 1:
-        return prove_quadratic(w, options)
+    if options[4] in (1, 2):
+        return prove_ext(w, options)
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
     assert blowup == 8 and hash_fn in (0, 1) and ext == 0 and folding == 4
     H = lambda data: O.digest(data, hash_fn)
@@ -115,12 +115,13 @@ def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
     return b"".join(out)
 
 
-def prove_quadratic(w, options):
-    """FieldExtension::Quadratic: base-field trace, everything drawn from the coin in E = F_p[u]/(u^2 - 2u - 2) (oracle/ext.c).
-    Layout differences: out-of-domain values are pairs; composition rows hold 8 pairs (16 words); FRI rows and the remainder are
-    component-major (a-parts then b-parts)."""
+def prove_ext(w, options):
+    """FieldExtension::Quadratic / Cubic: base-field trace, everything drawn from the coin in the degree-m extension (oracle/ext.c).
+    Layout differences: out-of-domain values are m-tuples; composition rows hold 8 m-tuples; FRI rows and the remainder are
+    component-major (component 0 of the four points, then component 1, ...)."""
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
-    assert blowup == 8 and hash_fn in (0, 1) and ext == 1 and folding == 4
+    assert blowup == 8 and hash_fn in (0, 1) and ext in (1, 2) and folding == 4
+    m = ext + 1
     H = lambda data: O.digest(data, hash_fn)
     log_b, b, W = 3, 8, 94
     trace = O.tx_build_trace(w)
@@ -138,56 +139,57 @@ def prove_quadratic(w, options):
     seed += b"".join(struct.pack("<Q", v) for v in pub)
     coin = V.Coin(seed, hash_fn)
     coin.reseed(trace_root)
-    cfs = [O.TxCoeffsStruct(), O.TxCoeffsStruct()]
+    cfs = [O.TxCoeffsStruct() for _ in range(m)]
     for i in range(115):
-        a, bt = coin.draw_e(), coin.draw_e()
-        for k in range(2):
+        a, bt = coin.draw_e(m), coin.draw_e(m)
+        for k in range(m):
             cfs[k].t_alpha[i], cfs[k].t_beta[i] = _mont(a[k]), _mont(bt[k])
     for i in range(4):
-        a, bt = coin.draw_e(), coin.draw_e()
-        for k in range(2):
+        a, bt = coin.draw_e(m), coin.draw_e(m)
+        for k in range(m):
             cfs[k].b_alpha[i], cfs[k].b_beta[i] = _mont(a[k]), _mont(bt[k])
     pub4 = np.array([pub_m[0], pub_m[1], pub_m[7], pub_m[8]], np.uint64)
-    # coefficients multiply base-field values: the two components of the merged evaluations are independent base-field merges
-    cc = [O.composition_columns(O.tx_evaluate_constraints(lde, cfs[k], pub4, w.depth, log_b)) for k in range(2)]
-    ccoef = np.ascontiguousarray(np.stack(cc, axis=1).reshape(16, n))     # column 2i + k = component k of H_i
+    # coefficients multiply base-field values: the components of the merged evaluations are independent base-field merges
+    cc = [O.composition_columns(O.tx_evaluate_constraints(lde, cfs[k], pub4, w.depth, log_b)) for k in range(m)]
+    ccoef = np.ascontiguousarray(np.stack(cc, axis=1).reshape(m * b, n))  # column m i + k = component k of H_i
     clde = O.lde_columns(ccoef, log_b)
     cnodes = O.merkle_build(O.hash_rows(clde, log_b, hash_fn=hash_fn), hash_fn)
     cons_root = cnodes[1].tobytes()
     coin.reseed(cons_root)
 
-    z = coin.draw_e()
+    z = coin.draw_e(m)
     zw = V.e_scale(z, V.root_of_unity(log_n))
     zb = V.e_pow(z, b)
     ood_cur = O.evaluate_polys_at_ext(coeffs, V.e_mont(z))
     ood_next = O.evaluate_polys_at_ext(coeffs, V.e_mont(zw))
     raw = O.evaluate_polys_at_ext(ccoef, V.e_mont(zb))                     # each component polynomial at z^8
-    ood_comp = np.zeros((b, 2), np.uint64)
+    ood_comp = np.zeros((b, m), np.uint64)
     for i in range(b):
-        e0 = (V.from_mont(raw[2 * i, 0]), V.from_mont(raw[2 * i, 1]))
-        e1 = (V.from_mont(raw[2 * i + 1, 0]), V.from_mont(raw[2 * i + 1, 1]))
-        h = V.e_add(e0, V.e_mul((0, 1), e1))                               # H_i = H_i,a + u H_i,b
+        h, gk = V.e_base(0, m), V.e_base(1, m)
+        for k in range(m):                                                  # H_i = sum_k root^k H_i,k
+            h = V.e_add(h, V.e_mul(gk, tuple(V.from_mont(v) for v in raw[m * i + k])))
+            gk = V.e_mul(gk, V.e_gen(m))
         ood_comp[i] = V.e_mont(h)
-    ood_trace = np.concatenate([ood_cur, ood_next])                         # [188][2]
+    ood_trace = np.concatenate([ood_cur, ood_next])
     coin.reseed(H(ood_trace.tobytes()))
     coin.reseed(H(ood_comp.tobytes()))
-    d_alpha, d_beta = np.zeros((W, 2), np.uint64), np.zeros((W, 2), np.uint64)
+    d_alpha, d_beta = np.zeros((W, m), np.uint64), np.zeros((W, m), np.uint64)
     for c in range(W):
-        d_alpha[c], d_beta[c] = V.e_mont(coin.draw_e()), V.e_mont(coin.draw_e())
-        coin.draw_e()
-    d_delta = np.array([V.e_mont(coin.draw_e()) for _ in range(b)], np.uint64)
-    deg_a, deg_b = V.e_mont(coin.draw_e()), V.e_mont(coin.draw_e())
+        d_alpha[c], d_beta[c] = V.e_mont(coin.draw_e(m)), V.e_mont(coin.draw_e(m))
+        coin.draw_e(m)
+    d_delta = np.array([V.e_mont(coin.draw_e(m)) for _ in range(b)], np.uint64)
+    deg_a, deg_b = V.e_mont(coin.draw_e(m)), V.e_mont(coin.draw_e(m))
     deep = O.deep_composition_ext(lde, clde, V.e_mont(z), ood_trace, ood_comp, d_alpha, d_beta, d_delta, deg_a, deg_b, log_b)
-    layer = np.ascontiguousarray(np.stack([np.ascontiguousarray(deep[k].T).reshape(-1) for k in range(2)]))  # [2][N] natural order
+    layer = np.ascontiguousarray(np.stack([np.ascontiguousarray(deep[k].T).reshape(-1) for k in range(m)]))  # [m][N] natural order
 
     layers, trees, roots = [], [], []
     offset, lg = 3, log_N
     while lg > log_rem:
         rows = 1 << (lg - 2)
-        nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 8, rows), 0, hash_fn=hash_fn), hash_fn)
+        nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 4 * m, rows), 0, hash_fn=hash_fn), hash_fn)
         layers.append(layer); trees.append(nodes); roots.append(nodes[1].tobytes())
         coin.reseed(roots[-1])
-        alpha = coin.draw_e()
+        alpha = coin.draw_e(m)
         layer = O.fri_fold4_ext(layer, _mont(offset), V.e_mont(alpha))
         offset = pow(offset, 4, V.P)
         lg -= 2
@@ -217,7 +219,7 @@ def prove_quadratic(w, options):
         rows = 1 << (lg - 2)
         fpos = V.fold_positions(cur, rows)
         out.append(struct.pack("<I", len(fpos)))
-        tab = layers[l].reshape(8, rows)
+        tab = layers[l].reshape(4 * m, rows)
         out += [np.ascontiguousarray(tab[:, p]).tobytes() for p in fpos]
         out += [path(trees[l], lg - 2, p) for p in fpos]
         cur = fpos

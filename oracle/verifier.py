@@ -39,32 +39,43 @@ def root_of_unity(log_n):
     return pow(TWO_ADIC_ROOT, 1 << (55 - log_n), P)
 
 
-# ---- E = F_p[u]/(u^2 - 2u - 2): pairs of canonical integers (FieldExtension::Quadratic; see oracle/ext.c for the assumption) ----
+# ---- extension fields (FieldExtension::Quadratic / Cubic; see oracle/ext.c for the assumed polynomials): tuples of canonical
+# integers of length m; E2 = F_p[u]/(u^2 - 2u - 2), E3 = F_p[v]/(v^3 + v + 1) -------------------------------------------------------
 def e_add(x, y):
-    return ((x[0] + y[0]) % P, (x[1] + y[1]) % P)
+    return tuple((a + b) % P for a, b in zip(x, y))
 
 
 def e_sub(x, y):
-    return ((x[0] - y[0]) % P, (x[1] - y[1]) % P)
+    return tuple((a - b) % P for a, b in zip(x, y))
 
 
 def e_mul(x, y):
-    bd = x[1] * y[1]
-    return ((x[0] * y[0] + 2 * bd) % P, (x[0] * y[1] + x[1] * y[0] + 2 * bd) % P)
+    if len(x) == 2:
+        bd = x[1] * y[1]
+        return ((x[0] * y[0] + 2 * bd) % P, (x[0] * y[1] + x[1] * y[0] + 2 * bd) % P)
+    d0 = x[0] * y[0]
+    d1 = x[0] * y[1] + x[1] * y[0]
+    d2 = x[0] * y[2] + x[1] * y[1] + x[2] * y[0]
+    d3 = x[1] * y[2] + x[2] * y[1]
+    d4 = x[2] * y[2]
+    return ((d0 - d3) % P, (d1 - d3 - d4) % P, (d2 - d4) % P)  # v^3 = -v - 1, v^4 = -v^2 - v
 
 
 def e_scale(x, s):
-    return (x[0] * s % P, x[1] * s % P)
+    return tuple(a * s % P for a in x)
 
 
-def e_inv(x):  # 1/(a + b u) = (a + 2b - b u) / (a^2 + 2ab - 2b^2)
-    a, b = x
-    t = pow((a * a + 2 * a * b - 2 * b * b) % P, -1, P)
-    return ((a + 2 * b) * t % P, (-b) * t % P)
+def e_base(v, m):
+    return (v % P,) + (0,) * (m - 1)
+
+
+def e_gen(m):
+    """the adjoined root (u or v) as an element"""
+    return (0, 1) + (0,) * (m - 2)
 
 
 def e_pow(x, e):
-    r = (1, 0)
+    r = e_base(1, len(x))
     while e:
         if e & 1:
             r = e_mul(r, x)
@@ -73,8 +84,23 @@ def e_pow(x, e):
     return r
 
 
+def e_inv(x):
+    # Fermat would need p^m - 2; use the adjugate: x^-1 = adj(x) / norm(x) with the norm in the base field
+    m = len(x)
+    if m == 2:  # 1/(a + b u) = (a + 2b - b u) / (a^2 + 2ab - 2b^2)
+        a, b = x
+        t = pow((a * a + 2 * a * b - 2 * b * b) % P, -1, P)
+        return ((a + 2 * b) * t % P, (-b) * t % P)
+    a, b, c = x
+    r0 = (a * a + b * b + c * c - (2 * a - b) * c) % P
+    r1 = (-(a * b + c * c)) % P
+    r2 = (b * b - a * c + c * c) % P
+    t = pow((a * r0 - b * r2 - c * r1) % P, -1, P)
+    return (r0 * t % P, r1 * t % P, r2 * t % P)
+
+
 def e_mont(x):
-    return [to_mont(x[0]), to_mont(x[1])]
+    return [to_mont(v) for v in x]
 
 
 class Coin:
@@ -102,10 +128,9 @@ class Coin:
             if v < P:
                 return v
 
-    def draw_e(self):
-        """an element of the quadratic extension: two base draws"""
-        a = self.draw()
-        return (a, self.draw())
+    def draw_e(self, m=2):
+        """an element of the degree-m extension: m base draws"""
+        return tuple(self.draw() for _ in range(m))
 
     def draw_integers(self, count, domain):
         out = []
@@ -169,9 +194,9 @@ def parse(proof):
     if blowup != 8 or not (6 <= d["log_n"] <= 21) or not (1 <= nq <= 128):
         raise VerifierError("unsupported parameters")
     ext = d["options"][4]
-    if ext not in (0, 1) or (ext == 1 and d["air"] != 0):
+    if ext not in (0, 1, 2) or (ext and d["air"] != 0):
         raise VerifierError("unsupported field extension")
-    em = 2 if ext else 1  # words per element of the field the coin draws from
+    em = ext + 1  # words per element of the field the coin draws from
     log_N = d["log_n"] + 3
     d["trace_root"], d["cons_root"] = r.take(32), r.take(32)
     nl = r.u32()
@@ -334,8 +359,8 @@ def verify(proof, initial_root, final_root, options=None):
     d = parse(proof)
     if d["air"] != 0:
         raise VerifierError("not a TransactionAir proof")
-    if d["options"][4] == 1:
-        return _verify_quadratic(d, _TxAir(d, initial_root, final_root), options)
+    if d["options"][4] in (1, 2):
+        return _verify_ext(d, _TxAir(d, initial_root, final_root), options)
     return _verify(d, _TxAir(d, initial_root, final_root), options)
 
 
@@ -492,44 +517,48 @@ def _verify(d, air, options):
     return True
 
 
-def _pairs(words):
+def _tuples(words, m):
     w = [from_mont(v) for v in words]
-    return [(w[2 * i], w[2 * i + 1]) for i in range(len(w) // 2)]
+    return [tuple(w[m * i:m * i + m]) for i in range(len(w) // m)]
 
 
-def _tx_constraints_over_e(cur, nxt, per):
-    """The 115 transition constraints on a frame with entries in E, WITHOUT an E-valued AIR: each constraint is a polynomial with
-    base-field coefficients in the frame and periodic values, so t -> C(a + t b) is a base-field polynomial of degree <= 7 (the
-    declared maximum, src/air.rs:76-100); it is sampled with the base-field evaluator at 16 integer points t and read off at t = u by
-    Lagrange interpolation (the map t -> u is a ring homomorphism F_p[t] -> E)."""
-    K = 16
+def _tx_constraints_over_e(cur, nxt, per, m):
+    """The 115 transition constraints on a frame with entries in the extension, WITHOUT an extension-valued AIR: each constraint is
+    a polynomial with base-field coefficients in the frame and periodic values, of total degree <= 7 (the declared maximum,
+    src/air.rs:76-100).  Writing every entry as e(t) = a + b t (+ c t^2) makes t -> C(e(t)) a base-field polynomial of degree
+    <= 7 (m - 1); it is sampled with the base-field evaluator at integer points t and read off at t = (the adjoined root) by
+    Lagrange interpolation (t -> root is a ring homomorphism F_p[t] -> E)."""
+    K = 7 * (m - 1) + 4
     ys = []
     for t in range(K):
-        c = np.array([to_mont((a + t * b) % P) for a, b in cur], np.uint64)
-        nx = np.array([to_mont((a + t * b) % P) for a, b in nxt], np.uint64)
-        pv = np.array([to_mont((a + t * b) % P) for a, b in per], np.uint64)
+        pw = [pow(t, q, P) for q in range(m)]
+        ev = lambda e: to_mont(sum(c * w_ for c, w_ in zip(e, pw)) % P)
+        c = np.array([ev(e) for e in cur], np.uint64)
+        nx = np.array([ev(e) for e in nxt], np.uint64)
+        pv = np.array([ev(e) for e in per], np.uint64)
         ys.append([from_mont(v) for v in O.tx_evaluate_transition(c, nx, pv)])
-    u = (0, 1)
+    g = e_gen(m)
     lag = []
     for j in range(K):
-        num, den = (1, 0), 1
-        for m in range(K):
-            if m != j:
-                num = e_mul(num, e_sub(u, (m, 0)))
-                den = den * (j - m) % P
+        num, den = e_base(1, m), 1
+        for q in range(K):
+            if q != j:
+                num = e_mul(num, e_sub(g, e_base(q, m)))
+                den = den * (j - q) % P
         lag.append(e_scale(num, pow(den, -1, P)))
     out = []
     for i in range(115):
-        acc = (0, 0)
+        acc = e_base(0, m)
         for j in range(K):
             acc = e_add(acc, e_scale(lag[j], ys[j][i]))
         out.append(acc)
     return out
 
 
-def _verify_quadratic(d, air, options):
-    """FieldExtension::Quadratic proofs of TransactionAir (layout: oracle/prover.py prove_quadratic)."""
+def _verify_ext(d, air, options):
+    """FieldExtension::Quadratic / Cubic proofs of TransactionAir (layout: oracle/prover.py prove_ext)."""
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = d["options"]
+    m = ext + 1
     if options is not None and list(options) != d["options"]:
         raise VerifierError("proof options differ from the expected ones")
     if hash_fn not in (0, 1) or folding != 4 or max_rem & (max_rem - 1) or not (128 <= max_rem <= 1024):
@@ -542,8 +571,9 @@ def _verify_quadratic(d, air, options):
     while lg > log_rem:
         lg -= 2
         n_layers += 1
-    if n_layers != len(d["layer_roots"]) or len(d["remainder"]) != 2 << lg:
+    if n_layers != len(d["layer_roots"]) or len(d["remainder"]) != m << lg:
         raise VerifierError("FRI layer structure does not match the options")
+    B = lambda v: e_base(v, m)
     seed = bytes([W, log_n]) + struct.pack("<Q", P) + bytes([nq, log_b, grinding, hash_fn, ext, folding, log_rem])
     seed += b"".join(struct.pack("<Q", v) for v in air.pub)
     coin = Coin(seed, hash_fn)
@@ -551,35 +581,35 @@ def _verify_quadratic(d, air, options):
     coin.reseed(d["trace_root"])
     ta, tb, ba, bb = [], [], [], []
     for _ in range(115):
-        ta.append(coin.draw_e()); tb.append(coin.draw_e())
+        ta.append(coin.draw_e(m)); tb.append(coin.draw_e(m))
     for _ in range(4):
-        ba.append(coin.draw_e()); bb.append(coin.draw_e())
+        ba.append(coin.draw_e(m)); bb.append(coin.draw_e(m))
     coin.reseed(d["cons_root"])
-    z = coin.draw_e()
+    z = coin.draw_e(m)
 
-    # out-of-domain consistency over E
+    # out-of-domain consistency over the extension
     wn = root_of_unity(log_n)
-    cur, nxt, hz = _pairs(d["ood_cur"]), _pairs(d["ood_next"]), _pairs(d["ood_comp"])
+    cur, nxt, hz = _tuples(d["ood_cur"], m), _tuples(d["ood_next"], m), _tuples(d["ood_comp"], m)
     pco = O.interpolate_columns(O.tx_periodic_columns(air.depth))
-    per = _pairs(O.evaluate_polys_at_ext(pco, e_mont(e_pow(z, n // 1024))).reshape(-1))
-    cvals = _tx_constraints_over_e(cur, nxt, per)
+    per = _tuples(O.evaluate_polys_at_ext(pco, e_mont(e_pow(z, n // 1024))).reshape(-1), m)
+    cvals = _tx_constraints_over_e(cur, nxt, per, m)
     adj = [int(v) for v in O.tx_degree_adjustments(log_n, log_b)]
     zpow = {}
-    acc = (0, 0)
+    acc = B(0)
     for i in range(115):
         if adj[i] not in zpow:
             zpow[adj[i]] = e_pow(z, adj[i])
         acc = e_add(acc, e_mul(cvals[i], e_add(ta[i], e_mul(tb[i], zpow[adj[i]]))))
     w_last = pow(wn, n - 1, P)
-    zinv = e_mul(e_sub(z, (w_last, 0)), e_inv(e_sub(e_pow(z, n), (1, 0))))
+    zinv = e_mul(e_sub(z, B(w_last)), e_inv(e_sub(e_pow(z, n), B(1))))
     acc = e_mul(acc, zinv)
     xb = e_pow(z, (n << log_b) - n + 1)
-    first = last = (0, 0)
+    first = last = B(0)
     for a in range(2):
-        first = e_add(first, e_mul(e_sub(cur[58 + a], (air.pub[a], 0)), e_add(ba[a], e_mul(bb[a], xb))))
-        last = e_add(last, e_mul(e_sub(cur[58 + a], (air.pub[7 + a], 0)), e_add(ba[2 + a], e_mul(bb[2 + a], xb))))
-    lhs = e_add(acc, e_add(e_mul(first, e_inv(e_sub(z, (1, 0)))), e_mul(last, e_inv(e_sub(z, (w_last, 0))))))
-    rhs, zi = (0, 0), (1, 0)
+        first = e_add(first, e_mul(e_sub(cur[58 + a], B(air.pub[a])), e_add(ba[a], e_mul(bb[a], xb))))
+        last = e_add(last, e_mul(e_sub(cur[58 + a], B(air.pub[7 + a])), e_add(ba[2 + a], e_mul(bb[2 + a], xb))))
+    lhs = e_add(acc, e_add(e_mul(first, e_inv(e_sub(z, B(1)))), e_mul(last, e_inv(e_sub(z, B(w_last))))))
+    rhs, zi = B(0), B(1)
     for h in hz:
         rhs = e_add(rhs, e_mul(h, zi))
         zi = e_mul(zi, z)
@@ -589,13 +619,13 @@ def _verify_quadratic(d, air, options):
     coin.reseed(H(np.ascontiguousarray(d["ood_comp"]).tobytes()))
     d_alpha, d_beta = [], []
     for _ in range(W):
-        d_alpha.append(coin.draw_e()); d_beta.append(coin.draw_e()); coin.draw_e()
-    d_delta = [coin.draw_e() for _ in range(b)]
-    deg_a, deg_b = coin.draw_e(), coin.draw_e()
+        d_alpha.append(coin.draw_e(m)); d_beta.append(coin.draw_e(m)); coin.draw_e(m)
+    d_delta = [coin.draw_e(m) for _ in range(b)]
+    deg_a, deg_b = coin.draw_e(m), coin.draw_e(m)
     alphas = []
     for root in d["layer_roots"]:
         coin.reseed(root)
-        alphas.append(coin.draw_e())
+        alphas.append(coin.draw_e(m))
     if H(np.ascontiguousarray(d["remainder"]).tobytes()) != d["rem_commit"]:
         raise VerifierError("remainder does not match its commitment")
     coin.reseed(d["rem_commit"])
@@ -610,24 +640,24 @@ def _verify_quadratic(d, air, options):
             raise VerifierError("trace opening %d does not match the trace commitment" % q)
         if merkle_root_from_path(H(d["cons_rows"][q].tobytes()), pos, d["cons_paths"][q], hash_fn) != d["cons_root"]:
             raise VerifierError("composition opening %d does not match the constraint commitment" % q)
-    # DEEP composition over E at the queried points
+    # DEEP composition over the extension at the queried points
     wN = root_of_unity(log_N)
     zw, zb = e_scale(z, wn), e_pow(z, b)
     deep = []
     for q, pos in enumerate(positions):
         x = GEN * pow(wN, pos, P) % P
-        i1, i2, i3 = e_inv(e_sub((x, 0), z)), e_inv(e_sub((x, 0), zw)), e_inv(e_sub((x, 0), zb))
+        i1, i2, i3 = e_inv(e_sub(B(x), z)), e_inv(e_sub(B(x), zw)), e_inv(e_sub(B(x), zb))
         row = [from_mont(v) for v in d["trace_rows"][q]]
-        crow = _pairs(d["cons_rows"][q])
-        s1 = s2 = s3 = (0, 0)
+        crow = _tuples(d["cons_rows"][q], m)
+        s1 = s2 = s3 = B(0)
         for c in range(W):
-            s1 = e_add(s1, e_mul(d_alpha[c], e_sub((row[c], 0), cur[c])))
-            s2 = e_add(s2, e_mul(d_beta[c], e_sub((row[c], 0), nxt[c])))
+            s1 = e_add(s1, e_mul(d_alpha[c], e_sub(B(row[c]), cur[c])))
+            s2 = e_add(s2, e_mul(d_beta[c], e_sub(B(row[c]), nxt[c])))
         for i in range(b):
             s3 = e_add(s3, e_mul(d_delta[i], e_sub(crow[i], hz[i])))
         t = e_add(e_add(e_mul(s1, i1), e_mul(s2, i2)), e_mul(s3, i3))
         deep.append(e_mul(t, e_add(deg_a, e_scale(deg_b, x))))
-    # FRI over E (rows and remainder component-major)
+    # FRI over the extension (rows and remainder component-major)
     cur_pos, cur_val = positions, deep
     offset, lgl = GEN, log_N
     inv4 = pow(4, -1, P)
@@ -641,8 +671,8 @@ def _verify_quadratic(d, air, options):
         for t, rp in enumerate(fpos):
             if merkle_root_from_path(H(rows[t].tobytes()), rp, paths[t], hash_fn) != d["layer_roots"][l]:
                 raise VerifierError("layer %d opening does not match its commitment" % l)
-            r8 = [from_mont(e) for e in rows[t]]
-            vals.append([(r8[k], r8[4 + k]) for k in range(4)])
+            r = [from_mont(e) for e in rows[t]]
+            vals.append([tuple(r[4 * q + k] for q in range(m)) for k in range(4)])
         for p, v in zip(cur_pos, cur_val):
             if vals[fpos.index(p & (rows_n - 1))][p >> (lgl - 2)] != v:
                 raise VerifierError("layer %d: evaluation differs from the previous layer's folding" % l)
@@ -652,9 +682,9 @@ def _verify_quadratic(d, air, options):
         for t, rp in enumerate(fpos):
             x = offset * pow(wl, rp, P) % P
             r = e_scale(alphas[l], pow(x, -1, P))
-            acc, rs = (0, 0), (1, 0)
+            acc, rs = B(0), B(1)
             for s_ in range(4):
-                cs = (0, 0)
+                cs = B(0)
                 for k in range(4):
                     cs = e_add(cs, e_scale(vals[t][k], pow(zeta_inv, s_ * k, P)))
                 acc = e_add(acc, e_mul(e_scale(cs, inv4), rs))
@@ -663,12 +693,12 @@ def _verify_quadratic(d, air, options):
         cur_pos, cur_val = fpos, nxt_val
         offset = pow(offset, 4, P)
         lgl -= 2
-    R = len(d["remainder"]) // 2
-    rem_a, rem_b = d["remainder"][:R], d["remainder"][R:]
+    R = len(d["remainder"]) // m
+    comps = [d["remainder"][q * R:(q + 1) * R] for q in range(m)]
     for p, v in zip(cur_pos, cur_val):
-        if (from_mont(rem_a[p]), from_mont(rem_b[p])) != v:
+        if tuple(from_mont(comp[p]) for comp in comps) != v:
             raise VerifierError("remainder differs from the last layer's folding")
-    for comp in (rem_a, rem_b):
+    for comp in comps:
         co = O.ntt(np.ascontiguousarray(comp, np.uint64).copy(), inverse=True)
         if any(int(v) != 0 for v in co[R // blowup:]):
             raise VerifierError("FRI remainder is not a low-degree polynomial")

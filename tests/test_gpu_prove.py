@@ -93,7 +93,7 @@ def test_production_depth_proofs(n_tx, depth, queries):
 def test_unsupported_options_are_refused():
     from certificate_stark_amd._lib import CstarkError
     from certificate_stark_amd.prover import ProofOptions
-    for opt in (ProofOptions(42, 16), ProofOptions(42, 8, 0, 2), ProofOptions(42, 8, 0, 0, 2), ProofOptions(42, 8, 0, 0, 0, 8)):
+    for opt in (ProofOptions(42, 16), ProofOptions(42, 8, 0, 2), ProofOptions(42, 8, 0, 0, 3), ProofOptions(42, 8, 0, 0, 0, 8)):
         tx = example(2, 3, options=opt)
         with pytest.raises(CstarkError):
             tx.prove()
@@ -214,16 +214,16 @@ def test_sha3_proofs(n_tx, depth):
         V.verify(bytes(as_blake), *tx.pub_inputs())
 
 
-@pytest.mark.parametrize("n_tx,depth,hash_fn", [(2, 3, 0), (8, 15, 0), (4, 7, 1)])
-def test_quadratic_extension_proofs(n_tx, depth, hash_fn):
-    """transaction_test_basic_proof_verification_quadratic_extension (src/tests.rs:18-23): FieldExtension::Quadratic.  The proof
-    bytes equal the CPU restatement's, the restated verifier accepts them (evaluating the AIR over the extension by interpolation),
-    wrong public inputs and tampering are rejected."""
+@pytest.mark.parametrize("n_tx,depth,hash_fn,ext", [(2, 3, 0, 1), (8, 15, 0, 1), (4, 7, 1, 1), (2, 3, 0, 2), (8, 15, 0, 2), (4, 7, 1, 2)])
+def test_extension_field_proofs(n_tx, depth, hash_fn, ext):
+    """transaction_test_basic_proof_verification_quadratic_extension / _cubic_extension (src/tests.rs:18-30): FieldExtension::
+    Quadratic and ::Cubic.  The proof bytes equal the CPU restatement's, the restated verifier accepts them (evaluating the AIR over
+    the extension by interpolation), wrong public inputs and tampering are rejected."""
     from oracle import oracle as O
     from oracle import prover as OP
     from oracle import verifier as V
     from certificate_stark_amd.prover import ProofOptions, TransactionExample, TransactionMetadata
-    opts = (42, 8, 0, hash_fn, 1, 4, 256)
+    opts = (42, 8, 0, hash_fn, ext, 4, 256)
     w = O.TxWitness.generate(n_tx, depth, seed=600 + n_tx)
     meta = TransactionMetadata(*[getattr(w, f) for f in TransactionMetadata.FIELDS])
     tx = TransactionExample(ProofOptions(*opts), meta)
