@@ -158,7 +158,8 @@ struct AirJob {
     std::vector<uint64_t> pub;      // public-input elements (memory form), appended to the seed in canonical form
     std::vector<uint8_t> pub_bytes; // further public material appended verbatim (Schnorr: the s halves of the signatures)
     int (*build)(cstark_ctx *, ProveArena *, AirJob &) = nullptr;
-    int (*combine)(cstark_ctx *, ProveArena *, AirJob &, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) = nullptr;
+    // merged constraint evaluations [b][n] for ONE set of (base-field) coefficients -> out
+    int (*combine)(cstark_ctx *, ProveArena *, AirJob &, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) = nullptr;
     uint64_t number = 0;            // RangeProofAir
 };
 
@@ -271,7 +272,7 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     for (size_t i = 0; i < na; i++) { ba[i] = coin.draw(); bb[i] = coin.draw(); }
 
     // ---- constraint evaluation, composition polynomial, its commitment ----------------------------------------------
-    RC_TRY(job.combine(c, a, job, ta.data(), tb.data(), ba.data(), bb.data()));
+    RC_TRY(job.combine(c, a, job, ta.data(), tb.data(), ba.data(), bb.data(), a->combined));
     STAGE();
     const uint64_t *ce_evals = a->combined;
     if (log_ce < log_b) { // the constraint-evaluation domain is the sub-domain of every (b / ce)-th LDE coset
@@ -442,38 +443,38 @@ int tx_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
     RC_TRY(cstark_tx_build_trace(c, a->trace));
     return gather_roots(c, a, job);
 }
-int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) {
+int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     cstark_tx_coeffs cf;
     memcpy(cf.t_alpha, ta, sizeof cf.t_alpha); memcpy(cf.t_beta, tb, sizeof cf.t_beta);
     memcpy(cf.b_alpha, ba, sizeof cf.b_alpha); memcpy(cf.b_beta, bb, sizeof cf.b_beta);
     const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]}; // get_assertions, src/air.rs:175-184
-    return cstark_tx_evaluate_constraints(c, a->lde, &cf, pub4, a->combined, job.item, job.log_n, 3, 0, 8);
+    return cstark_tx_evaluate_constraints(c, a->lde, &cf, pub4, out, job.item, job.log_n, 3, 0, 8);
 }
 // ---- MerkleAir (src/merkle/update) ---------------------------------------------------------------------------------------------
 int merkle_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
     RC_TRY(cstark_merkle_build_trace(c, a->trace));
     return gather_roots(c, a, job);
 }
-int merkle_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) {
+int merkle_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals;
     RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
     RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_MERKLE_UPDATE, a->lde, evals, job.item, job.log_n, 3, 0, 8));
-    return cstark_air_combine(c, CSTARK_AIR_MERKLE_UPDATE, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, a->combined, job.log_n, 3, 0, 8);
+    return cstark_air_combine(c, CSTARK_AIR_MERKLE_UPDATE, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, out, job.log_n, 3, 0, 8);
 }
 // ---- RangeProofAir (src/range) -------------------------------------------------------------------------------------------------------
 int range_build(cstark_ctx *c, ProveArena *a, AirJob &job) { return cstark_range_build_trace(c, job.number, a->trace); }
-int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) {
+int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals;
     RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
     RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RANGE, a->lde, evals, 0, job.log_n, 3, 0, 8));
     const uint64_t vals[2] = {0, job.number}; // get_assertions, src/range/air.rs:79-86
-    return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, a->combined, job.log_n, 3, 0, 8);
+    return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, out, job.log_n, 3, 0, 8);
 }
 // ---- SchnorrAir (src/schnorr) ---------------------------------------------------------------------------------------------------------
 int schnorr_build(cstark_ctx *c, ProveArena *a, AirJob &) { return cstark_schnorr_build_trace(c, a->trace); }
-int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb) {
+int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals, *aux, *aux_co, *aux_lde, *av_co, *av_lde;
     RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
@@ -489,26 +490,23 @@ int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *t
     RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
     RC_TRY(cstark_schnorr_assertion_polys(c, av_co, job.log_n));
     RC_TRY(cstark_lde_columns(c, av_co, av_lde, 12, job.log_n, 3, host::generator(), 0, 8));
-    return cstark_air_combine(c, CSTARK_AIR_SCHNORR, job.item, a->lde, evals, ta, tb, ba, bb, nullptr, av_lde, 12, a->combined, job.log_n, 3, 0, 8);
+    return cstark_air_combine(c, CSTARK_AIR_SCHNORR, job.item, a->lde, evals, ta, tb, ba, bb, nullptr, av_lde, 12, out, job.log_n, 3, 0, 8);
 }
 
 
-// ---- TransactionAir with FieldExtension::Quadratic / Cubic ------------------------------------------------------------------------
+// ---- any AIR with FieldExtension::Quadratic / Cubic ------------------------------------------------------------------------------
 // Base-field trace; everything the coin draws lives in the degree-m extension (ext.hip).  Coefficients multiply base-field
-// constraint values, so the merged evaluations are m independent runs of the fused evaluator (one per component).  Layout
+// constraint values, so the merged evaluations are m independent runs of the AIR's evaluator (one per component).  Layout
 // differences of the proof: out-of-domain values are m-tuples, composition rows hold 8 m-tuples, FRI rows and the remainder are
 // component-major.
-int prove_tx_ext(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_t capacity, size_t *proof_len) {
+int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *proof, size_t capacity, size_t *proof_len) {
     using namespace host;
     const unsigned m = opt->field_extension + 1;
     unsigned log_rem = 0;
     RC_TRY(check_options(opt, &log_rem));
-    AirJob job;
-    job.air = CSTARK_AIR_STATE_TRANSITION; job.width = CSTARK_TX_TRACE_WIDTH; job.log_n = 10 + ceil_log2(c->wit.n_tx); job.log_ce = 3;
-    job.n_constraints = CSTARK_TX_NUM_CONSTRAINTS; job.n_assertions = 4; job.item = c->wit.depth;
-    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b;
+    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b, log_ce = job.log_ce;
     if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "at most 2^21 trace rows");
-    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = job.width, CW = m * b; // CW: base columns of the composition table
+    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = job.width, ce = (size_t)1 << log_ce, CW = m * ce; // CW: base columns of the composition table
     const unsigned n_layers = num_fri_layers(log_N, log_rem);
     const size_t nq = opt->num_queries;
     if (nq > N / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
@@ -517,16 +515,16 @@ int prove_tx_ext(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_
     RC_TRY(get_arena(c, job, log_b, n_layers, nq, &a));
     uint64_t *combined_x, *ccoef_x, *ccoefs, *cldes, *deepx;
     uint8_t *d_open;
-    RC_TRY(arena_extra(a, 0, &combined_x, 2 * N * 8));   // components 1, 2 of the merged evaluations
-    RC_TRY(arena_extra(a, 1, &ccoef_x, 2 * N * 8));      // their column coefficients
-    RC_TRY(arena_extra(a, 2, &ccoefs, 3 * N * 8));       // interleaved: column m i + k
-    RC_TRY(arena_extra(a, 3, &cldes, 3 * b * N * 8));
-    RC_TRY(arena_extra(a, 4, &deepx, 3 * N * 8));
-    RC_TRY(arena_extra(a, 5, &d_open, nq * (W * 8 + 192 + 2 * log_N * 32 + (size_t)n_layers * (96 + log_N * 32)) + 256));
+    RC_TRY(arena_extra(a, 16, &combined_x, 2 * N * 8));   // components 1, 2 of the merged evaluations
+    RC_TRY(arena_extra(a, 17, &ccoef_x, 2 * N * 8));      // their column coefficients
+    RC_TRY(arena_extra(a, 18, &ccoefs, 3 * N * 8));       // interleaved: column m i + k
+    RC_TRY(arena_extra(a, 19, &cldes, 3 * b * N * 8));
+    RC_TRY(arena_extra(a, 20, &deepx, 3 * N * 8));
+    RC_TRY(arena_extra(a, 21, &d_open, nq * (W * 8 + 192 + 2 * log_N * 32 + (size_t)n_layers * (96 + log_N * 32)) + 256));
     std::vector<uint64_t *> layer(n_layers + 1);
     {
         size_t sz = N;
-        for (unsigned l = 0; l <= n_layers; l++) { RC_TRY(arena_extra(a, 6 + l, &layer[l], 3 * sz * 8)); sz /= 4; }
+        for (unsigned l = 0; l <= n_layers; l++) { RC_TRY(arena_extra(a, 22 + l, &layer[l], 3 * sz * 8)); sz /= 4; }
     }
     hipStream_t st = c->stream;
     int evi = 0;
@@ -535,7 +533,7 @@ int prove_tx_ext(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_
     const uint32_t hf = opt->hash_fn;
 
     STAGE();
-    RC_TRY(tx_build(c, a, job));
+    RC_TRY(job.build(c, a, job));
     STAGE();
     RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, (uint32_t)W, log_n));
     STAGE();
@@ -559,25 +557,35 @@ int prove_tx_ext(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_
                                (uint8_t)opt->field_extension, (uint8_t)opt->fri_folding_factor, (uint8_t)log_rem};
         s.raw(ob, 7);
         for (uint64_t v : job.pub) s.u64(to_u64(v));
+        s.raw(job.pub_bytes.data(), job.pub_bytes.size());
         coin.init(s.b.data(), s.b.size());
     }
     coin.reseed(trace_root);
     auto draw_e = [&coin, m]() { EX x = ex_zero(); for (unsigned q = 0; q < m; q++) x.c[q] = coin.draw(); return x; };
-    cstark_tx_coeffs cf[3];
-    for (int i = 0; i < CSTARK_TX_NUM_CONSTRAINTS; i++) {
+    const size_t nc = job.n_constraints, na = job.n_assertions;
+    std::vector<uint64_t> ta[3], tb[3], ba[3], bb[3];
+    for (unsigned q = 0; q < m; q++) { ta[q].resize(nc); tb[q].resize(nc); ba[q].resize(na); bb[q].resize(na); }
+    for (size_t i = 0; i < nc; i++) {
         const EX al = draw_e(), be = draw_e();
-        for (unsigned q = 0; q < m; q++) { cf[q].t_alpha[i] = al.c[q]; cf[q].t_beta[i] = be.c[q]; }
+        for (unsigned q = 0; q < m; q++) { ta[q][i] = al.c[q]; tb[q][i] = be.c[q]; }
     }
-    for (int i = 0; i < 4; i++) {
+    for (size_t i = 0; i < na; i++) {
         const EX al = draw_e(), be = draw_e();
-        for (unsigned q = 0; q < m; q++) { cf[q].b_alpha[i] = al.c[q]; cf[q].b_beta[i] = be.c[q]; }
+        for (unsigned q = 0; q < m; q++) { ba[q][i] = al.c[q]; bb[q][i] = be.c[q]; }
     }
-    const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]};
     uint64_t *comb[3] = {a->combined, combined_x, combined_x + N}, *cco[3] = {a->ccoef, ccoef_x, ccoef_x + N};
-    for (unsigned q = 0; q < m; q++) RC_TRY(cstark_tx_evaluate_constraints(c, a->lde, &cf[q], pub4, comb[q], job.item, log_n, log_b, 0, (uint32_t)b));
+    for (unsigned q = 0; q < m; q++) RC_TRY(job.combine(c, a, job, ta[q].data(), tb[q].data(), ba[q].data(), bb[q].data(), comb[q]));
     STAGE();
-    for (unsigned q = 0; q < m; q++) RC_TRY(cstark_composition_columns(c, comb[q], cco[q], log_n, log_b));
-    for (size_t i = 0; i < b; i++) // column m i + q = component q of composition column i
+    for (unsigned q = 0; q < m; q++) {
+        const uint64_t *ce_evals = comb[q];
+        if (log_ce < log_b) { // the constraint-evaluation domain is the sub-domain of every (b / ce)-th LDE coset
+            const size_t stride = b >> log_ce;
+            for (size_t k = 0; k < ce; k++) HIP_TRY(hipMemcpyAsync(a->cegather + k * n, comb[q] + k * stride * n, n * 8, hipMemcpyDeviceToDevice, st));
+            ce_evals = a->cegather;
+        }
+        RC_TRY(cstark_composition_columns(c, ce_evals, cco[q], log_n, log_ce));
+    }
+    for (size_t i = 0; i < ce; i++) // column m i + q = component q of composition column i
         for (unsigned q = 0; q < m; q++) HIP_TRY(hipMemcpyAsync(ccoefs + (m * i + q) * n, cco[q] + i * n, n * 8, hipMemcpyDeviceToDevice, st));
     RC_TRY(cstark_lde_columns(c, ccoefs, cldes, (uint32_t)CW, log_n, log_b, generator(), 0, (uint32_t)b));
     RC_TRY(cstark_hash_rows_fn(c, hf, cldes, a->cnodes + 32 * N, (uint32_t)CW, log_n, log_b, 0, (uint32_t)b));
@@ -587,15 +595,15 @@ int prove_tx_ext(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_
     HIP_TRY(hipStreamSynchronize(st));
     coin.reseed(cons_root);
 
-    const EX z = draw_e(), zw = ex_scale(z, root_of_unity(log_n)), zb = ex_pow(z, b, m);
-    std::vector<uint64_t> ood_trace(2 * m * W), raw(m * CW), ood_comp(m * b);
+    const EX z = draw_e(), zw = ex_scale(z, root_of_unity(log_n)), zb = ex_pow(z, ce, m);
+    std::vector<uint64_t> ood_trace(2 * m * W), raw(m * CW), ood_comp(m * ce);
     RC_TRY(cstark_evaluate_polys_at_ext(c, a->coeffs, (uint32_t)W, log_n, m, z.c, ood_trace.data()));
     RC_TRY(cstark_evaluate_polys_at_ext(c, a->coeffs, (uint32_t)W, log_n, m, zw.c, ood_trace.data() + m * W));
     RC_TRY(cstark_evaluate_polys_at_ext(c, ccoefs, (uint32_t)CW, log_n, m, zb.c, raw.data()));
     {
         EX gen = ex_zero();
         gen.c[1] = ONE; // the adjoined root
-        for (size_t i = 0; i < b; i++) { // H_i = sum_q root^q H_i,q, each component polynomial evaluated at z^8
+        for (size_t i = 0; i < ce; i++) { // H_i = sum_q root^q H_i,q, each component polynomial evaluated at z^ce
             EX h = ex_zero(), gq = ex_one();
             for (unsigned q = 0; q < m; q++) {
                 h = ex_add(h, ex_mul(gq, ex_load(raw.data() + m * (m * i + q), m), m));
@@ -609,15 +617,15 @@ int prove_tx_ext(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, size_
     hash_elements(hf, ood_comp.data(), ood_comp.size(), dg); coin.reseed(dg);
     STAGE();
 
-    std::vector<uint64_t> d_alpha(m * W), d_beta(m * W), d_delta(m * b);
+    std::vector<uint64_t> d_alpha(m * W), d_beta(m * W), d_delta(m * ce);
     for (size_t i = 0; i < W; i++) {
         const EX al = draw_e(), be = draw_e();
         (void)draw_e(); // conjugate-term coefficient of the engine, unused here
         for (unsigned q = 0; q < m; q++) { d_alpha[m * i + q] = al.c[q]; d_beta[m * i + q] = be.c[q]; }
     }
-    for (size_t i = 0; i < b; i++) { const EX dl = draw_e(); for (unsigned q = 0; q < m; q++) d_delta[m * i + q] = dl.c[q]; }
+    for (size_t i = 0; i < ce; i++) { const EX dl = draw_e(); for (unsigned q = 0; q < m; q++) d_delta[m * i + q] = dl.c[q]; }
     const EX dga = draw_e(), dgb = draw_e();
-    RC_TRY(cstark_deep_composition_ext(c, a->lde, cldes, (uint32_t)W, (uint32_t)b, m, z.c, ood_trace.data(), ood_comp.data(), d_alpha.data(), d_beta.data(),
+    RC_TRY(cstark_deep_composition_ext(c, a->lde, cldes, (uint32_t)W, (uint32_t)ce, m, z.c, ood_trace.data(), ood_comp.data(), d_alpha.data(), d_beta.data(),
                                        d_delta.data(), dga.c, dgb.c, deepx, log_n, log_b));
     for (unsigned q = 0; q < m; q++) RC_TRY(cstark_interleave_cosets(c, deepx + q * N, layer[0] + q * N, log_n, log_b));
     STAGE();
@@ -736,18 +744,17 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     if (!c || !opt || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_prove: null argument");
     if (!c->wit_buf || c->wit.n_tx == 0 || c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no transaction witness uploaded");
     if (c->wit.n_tx & (c->wit.n_tx - 1)) return fail(CSTARK_ERR_INVALID_ARG, "the number of transactions must be a power of two");
-    if (opt->field_extension == 1 || opt->field_extension == 2) return prove_tx_ext(c, opt, proof, capacity, proof_len);
     AirJob job;
     job.air = CSTARK_AIR_STATE_TRANSITION; job.width = CSTARK_TX_TRACE_WIDTH; job.log_n = 10 + ceil_log2(c->wit.n_tx); job.log_ce = 3;
     job.n_constraints = CSTARK_TX_NUM_CONSTRAINTS; job.n_assertions = 4; job.item = c->wit.depth;
     job.build = tx_build; job.combine = tx_combine;
+    if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);
 }
 
 int cstark_air_prove(cstark_ctx *c, int air, const cstark_options *opt, uint64_t number, uint8_t *proof, size_t capacity, size_t *proof_len) {
     if (!c || !opt || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_prove: null argument");
     if (air == CSTARK_AIR_STATE_TRANSITION) return cstark_tx_prove(c, opt, proof, capacity, proof_len);
-    if (opt->field_extension != 0) return fail(CSTARK_ERR_UNSUPPORTED, "field extensions are implemented for TransactionAir only");
     AirJob job;
     job.air = air;
     host::AirShape s;
@@ -776,6 +783,7 @@ int cstark_air_prove(cstark_ctx *c, int air, const cstark_options *opt, uint64_t
         return fail(CSTARK_ERR_UNSUPPORTED, "no prover for this AIR");
     }
     job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
+    if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);
 }
 

@@ -194,7 +194,7 @@ def parse(proof):
     if blowup != 8 or not (6 <= d["log_n"] <= 21) or not (1 <= nq <= 128):
         raise VerifierError("unsupported parameters")
     ext = d["options"][4]
-    if ext not in (0, 1, 2) or (ext and d["air"] != 0):
+    if ext not in (0, 1, 2):
         raise VerifierError("unsupported field extension")
     em = ext + 1  # words per element of the field the coin draws from
     log_N = d["log_n"] + 3
@@ -262,6 +262,34 @@ class _TxAir:
                                                         C.c_uint(3), C.c_uint64(to_mont(z))))
 
 
+def _tx_ood_combined_ext(self, d, log_n, z, ta, tb, ba, bb, m):
+    n, log_b = 1 << log_n, 3
+    B = lambda v: e_base(v, m)
+    wn = root_of_unity(log_n)
+    cur, nxt = _tuples(d["ood_cur"], m), _tuples(d["ood_next"], m)
+    pco = O.interpolate_columns(O.tx_periodic_columns(self.depth))
+    per = _tuples(O.evaluate_polys_at_ext(pco, e_mont(e_pow(z, n // 1024))).reshape(-1), m)
+    cvals = _tx_constraints_over_e(cur, nxt, per, m)
+    adj = [int(v) for v in O.tx_degree_adjustments(log_n, log_b)]
+    zpow = {}
+    acc = B(0)
+    for i in range(115):
+        if adj[i] not in zpow:
+            zpow[adj[i]] = e_pow(z, adj[i])
+        acc = e_add(acc, e_mul(cvals[i], e_add(ta[i], e_mul(tb[i], zpow[adj[i]]))))
+    w_last = pow(wn, n - 1, P)
+    acc = e_mul(acc, e_mul(e_sub(z, B(w_last)), e_inv(e_sub(e_pow(z, n), B(1)))))
+    xb = e_pow(z, (n << log_b) - n + 1)
+    first = last = B(0)
+    for a in range(2):
+        first = e_add(first, e_mul(e_sub(cur[58 + a], B(self.pub[a])), e_add(ba[a], e_mul(bb[a], xb))))
+        last = e_add(last, e_mul(e_sub(cur[58 + a], B(self.pub[7 + a])), e_add(ba[2 + a], e_mul(bb[2 + a], xb))))
+    return e_add(acc, e_add(e_mul(first, e_inv(e_sub(z, B(1)))), e_mul(last, e_inv(e_sub(z, B(w_last))))))
+
+
+_TxAir.ood_combined_ext = _tx_ood_combined_ext
+
+
 class _GenericAir:
     """Standalone AIRs through the generic description: transition values from the oracle's pointwise evaluators, merge restated here."""
 
@@ -280,6 +308,52 @@ class _GenericAir:
             term = (cur[reg] - value) % P * ((ba[a] + bb[a] * pow(z, ce_size - 1 + m - (n - 1), P)) % P) % P
             acc = (acc + term * pow(div, -1, P)) % P
         return acc
+
+
+def _constraints_over_e(evalfn, frames, n_out, m):
+    """Generic form of _tx_constraints_over_e: `frames` is a list of lists of m-tuples (current row, next row, periodic values,
+    ...); evalfn(list of uint64 arrays in memory form) -> base-field constraint values.  Total degree <= 8."""
+    K = 8 * (m - 1) + 4
+    ys = []
+    for t in range(K):
+        pw = [pow(t, q, P) for q in range(m)]
+        arrs = [np.array([to_mont(sum(c * w_ for c, w_ in zip(e, pw)) % P) for e in fr], np.uint64) for fr in frames]
+        ys.append([from_mont(v) for v in evalfn(arrs)[:n_out]])
+    g = e_gen(m)
+    lag = []
+    for j in range(K):
+        num, den = e_base(1, m), 1
+        for q in range(K):
+            if q != j:
+                num = e_mul(num, e_sub(g, e_base(q, m)))
+                den = den * (j - q) % P
+        lag.append(e_scale(num, pow(den, -1, P)))
+    out = []
+    for i in range(n_out):
+        acc = e_base(0, m)
+        for j in range(K):
+            acc = e_add(acc, e_scale(lag[j], ys[j][i]))
+        out.append(acc)
+    return out
+
+
+def _merge_e(air, log_n, z, res, ta, tb, ba, bb, cur, assertions, m):
+    """_GenericAir._merge over the extension: res / cur / coefficients are m-tuples; assertion values are m-tuples."""
+    n = 1 << log_n
+    ce_size = n * air.ce
+    wn = root_of_unity(log_n)
+    B = lambda v: e_base(v, m)
+    acc = B(0)
+    for i in range(air.nc):
+        ev = int(air.base[i]) * (n - 1) + (int(air.cycles[i]) * (n // air.cycle_len) * (air.cycle_len - 1) if air.cycle_len else 0)
+        acc = e_add(acc, e_mul(res[i], e_add(ta[i], e_mul(tb[i], e_pow(z, (ce_size - 1 + n - 1) - ev)))))
+    acc = e_mul(acc, e_mul(e_sub(z, B(pow(wn, n - 1, P))), e_inv(e_sub(e_pow(z, n), B(1)))))
+    for a, (reg, first, stride, value) in enumerate(assertions):
+        mm = n // stride if stride else 1
+        div = e_sub(e_pow(z, mm), B(pow(wn, (first * mm) % n, P)))
+        term = e_mul(e_sub(cur[reg], value), e_add(ba[a], e_mul(bb[a], e_pow(z, ce_size - 1 + mm - (n - 1)))))
+        acc = e_add(acc, e_mul(term, e_inv(div)))
+    return acc
 
 
 class _MerkleAir(_GenericAir):
@@ -304,6 +378,21 @@ class _MerkleAir(_GenericAir):
         return self._merge(log_n, z, [from_mont(v) for v in res[:106]], ta, tb, ba, bb, [from_mont(v) for v in cur], assertions)
 
 
+    def ood_combined_ext(self, d, log_n, z, ta, tb, ba, bb, m):
+        n = 1 << log_n
+        pco = O.interpolate_columns(O.merkle_periodic_columns(self.depth))
+        per = _tuples(O.evaluate_polys_at_ext(pco, e_mont(e_pow(z, n // 512))).reshape(-1), m)
+        cur, nxt = _tuples(d["ood_cur"], m), _tuples(d["ood_next"], m)
+
+        def evalfn(arrs):
+            res = np.zeros(128, np.uint64)
+            O.lib().cso_merkle_evaluate_transition(O._p(arrs[0]), O._p(arrs[1]), O._p(arrs[2]), O._p(res))
+            return res
+        res = _constraints_over_e(evalfn, [cur, nxt, per], 106, m)
+        assertions = [(58 + a % 7, (n - 1) if a >= 7 else 0, 0, e_base(self.pub[a], m)) for a in range(14)]
+        return _merge_e(self, log_n, z, res, ta, tb, ba, bb, cur, assertions, m)
+
+
 class _RangeAir(_GenericAir):
     air, width, ce = 3, 2, 2
 
@@ -319,6 +408,19 @@ class _RangeAir(_GenericAir):
         O.lib().cso_range_evaluate_transition(O._p(cur), O._p(nxt), None, O._p(res))
         assertions = [(1, 0, 0, 0), (1, n - 1, 0, self.pub[0])]  # src/range/air.rs:79-86
         return self._merge(log_n, z, [from_mont(v) for v in res[:2]], ta, tb, ba, bb, [from_mont(v) for v in cur], assertions)
+
+
+    def ood_combined_ext(self, d, log_n, z, ta, tb, ba, bb, m):
+        n = 1 << log_n
+        cur, nxt = _tuples(d["ood_cur"], m), _tuples(d["ood_next"], m)
+
+        def evalfn(arrs):
+            res = np.zeros(8, np.uint64)
+            O.lib().cso_range_evaluate_transition(O._p(arrs[0]), O._p(arrs[1]), None, O._p(res))
+            return res
+        res = _constraints_over_e(evalfn, [cur, nxt], 2, m)
+        assertions = [(1, 0, 0, e_base(0, m)), (1, n - 1, 0, e_base(self.pub[0], m))]
+        return _merge_e(self, log_n, z, res, ta, tb, ba, bb, cur, assertions, m)
 
 
 class _SchnorrAir(_GenericAir):
@@ -352,6 +454,33 @@ class _SchnorrAir(_GenericAir):
         return self._merge(log_n, z, [from_mont(v) for v in res], ta, tb, ba, bb, [from_mont(v) for v in cur], assertions)
 
 
+def _schnorr_ood_combined_ext(self, d, log_n, z, ta, tb, ba, bb, m):
+    n = 1 << log_n
+    w = self.w
+    masks = _tuples(O.evaluate_polys_at_ext(O.interpolate_columns(O.schnorr_mask_columns()), e_mont(e_pow(z, n // 512))).reshape(-1), m)
+    aux = _tuples(O.evaluate_polys_at_ext(O.interpolate_columns(O.schnorr_aux_columns(w)), e_mont(z)).reshape(-1), m)
+    cur, nxt = _tuples(d["ood_cur"], m), _tuples(d["ood_next"], m)
+
+    def evalfn(arrs):
+        res = np.zeros(56, np.uint64)
+        ax = arrs[3]
+        O.lib().cso_schnorr_evaluate_transition_at(O._p(arrs[0]), O._p(arrs[1]), O._p(arrs[2]), O._p(np.ascontiguousarray(ax[:12])),
+                                                   O._p(np.ascontiguousarray(ax[12:19])), O._p(res))
+        return res
+    res = _constraints_over_e(evalfn, [cur, nxt, masks, aux], 56, m)
+    desc = O.schnorr_desc(w)
+    seq_at_z = _tuples(O.evaluate_polys_at_ext(O.schnorr_assertion_polys(w, log_n), e_mont(z)).reshape(-1), m)
+    assertions = []
+    for a in range(desc.na):
+        q = int(desc.a_seq[a])
+        assertions.append((int(desc.a_reg[a]), int(desc.a_first[a]), int(desc.a_stride[a]),
+                           seq_at_z[q] if q >= 0 else e_base(from_mont(desc.a_value[a]), m)))
+    return _merge_e(self, log_n, z, res, ta, tb, ba, bb, cur, assertions, m)
+
+
+_SchnorrAir.ood_combined_ext = _schnorr_ood_combined_ext
+
+
 def verify(proof, initial_root, final_root, options=None):
     """TransactionAir.  Raises VerifierError unless `proof` shows that a valid 94-register trace links initial_root to final_root.
     initial_root / final_root: 7 field elements each, memory form (as TransactionMetadata holds them).
@@ -369,6 +498,8 @@ def verify_merkle(proof, initial_root, final_root, options=None):
     d = parse(proof)
     if d["air"] != 1:
         raise VerifierError("not a MerkleAir proof")
+    if d["options"][4] in (1, 2):
+        return _verify_ext(d, _MerkleAir(d, initial_root, final_root), options)
     return _verify(d, _MerkleAir(d, initial_root, final_root), options)
 
 
@@ -377,6 +508,8 @@ def verify_range(proof, number, options=None):
     d = parse(proof)
     if d["air"] != 3:
         raise VerifierError("not a RangeProofAir proof")
+    if d["options"][4] in (1, 2):
+        return _verify_ext(d, _RangeAir(d, number), options)
     return _verify(d, _RangeAir(d, number), options)
 
 
@@ -385,6 +518,8 @@ def verify_schnorr(proof, witness, options=None):
     d = parse(proof)
     if d["air"] != 2:
         raise VerifierError("not a SchnorrAir proof")
+    if d["options"][4] in (1, 2):
+        return _verify_ext(d, _SchnorrAir(d, witness), options)
     return _verify(d, _SchnorrAir(d, witness), options)
 
 
@@ -556,7 +691,7 @@ def _tx_constraints_over_e(cur, nxt, per, m):
 
 
 def _verify_ext(d, air, options):
-    """FieldExtension::Quadratic / Cubic proofs of TransactionAir (layout: oracle/prover.py prove_ext)."""
+    """FieldExtension::Quadratic / Cubic proofs of any of the AIRs (layout: oracle/prover.py prove_ext)."""
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = d["options"]
     m = ext + 1
     if options is not None and list(options) != d["options"]:
@@ -565,7 +700,7 @@ def _verify_ext(d, air, options):
         raise VerifierError("unsupported options")
     log_n, log_b = d["log_n"], 3
     log_N = log_n + 3
-    n, N, W, b = 1 << log_n, 1 << log_N, 94, 8
+    n, N, W, b, ce = 1 << log_n, 1 << log_N, air.width, 8, air.ce
     log_rem = max_rem.bit_length() - 1
     n_layers, lg = 0, log_N
     while lg > log_rem:
@@ -575,14 +710,14 @@ def _verify_ext(d, air, options):
         raise VerifierError("FRI layer structure does not match the options")
     B = lambda v: e_base(v, m)
     seed = bytes([W, log_n]) + struct.pack("<Q", P) + bytes([nq, log_b, grinding, hash_fn, ext, folding, log_rem])
-    seed += b"".join(struct.pack("<Q", v) for v in air.pub)
+    seed += b"".join(struct.pack("<Q", v) for v in air.pub) + air.pub_bytes
     coin = Coin(seed, hash_fn)
     H = coin.h
     coin.reseed(d["trace_root"])
     ta, tb, ba, bb = [], [], [], []
-    for _ in range(115):
+    for _ in range(air.nc):
         ta.append(coin.draw_e(m)); tb.append(coin.draw_e(m))
-    for _ in range(4):
+    for _ in range(air.na):
         ba.append(coin.draw_e(m)); bb.append(coin.draw_e(m))
     coin.reseed(d["cons_root"])
     z = coin.draw_e(m)
@@ -590,25 +725,7 @@ def _verify_ext(d, air, options):
     # out-of-domain consistency over the extension
     wn = root_of_unity(log_n)
     cur, nxt, hz = _tuples(d["ood_cur"], m), _tuples(d["ood_next"], m), _tuples(d["ood_comp"], m)
-    pco = O.interpolate_columns(O.tx_periodic_columns(air.depth))
-    per = _tuples(O.evaluate_polys_at_ext(pco, e_mont(e_pow(z, n // 1024))).reshape(-1), m)
-    cvals = _tx_constraints_over_e(cur, nxt, per, m)
-    adj = [int(v) for v in O.tx_degree_adjustments(log_n, log_b)]
-    zpow = {}
-    acc = B(0)
-    for i in range(115):
-        if adj[i] not in zpow:
-            zpow[adj[i]] = e_pow(z, adj[i])
-        acc = e_add(acc, e_mul(cvals[i], e_add(ta[i], e_mul(tb[i], zpow[adj[i]]))))
-    w_last = pow(wn, n - 1, P)
-    zinv = e_mul(e_sub(z, B(w_last)), e_inv(e_sub(e_pow(z, n), B(1))))
-    acc = e_mul(acc, zinv)
-    xb = e_pow(z, (n << log_b) - n + 1)
-    first = last = B(0)
-    for a in range(2):
-        first = e_add(first, e_mul(e_sub(cur[58 + a], B(air.pub[a])), e_add(ba[a], e_mul(bb[a], xb))))
-        last = e_add(last, e_mul(e_sub(cur[58 + a], B(air.pub[7 + a])), e_add(ba[2 + a], e_mul(bb[2 + a], xb))))
-    lhs = e_add(acc, e_add(e_mul(first, e_inv(e_sub(z, B(1)))), e_mul(last, e_inv(e_sub(z, B(w_last))))))
+    lhs = air.ood_combined_ext(d, log_n, z, ta, tb, ba, bb, m)
     rhs, zi = B(0), B(1)
     for h in hz:
         rhs = e_add(rhs, e_mul(h, zi))
@@ -620,7 +737,7 @@ def _verify_ext(d, air, options):
     d_alpha, d_beta = [], []
     for _ in range(W):
         d_alpha.append(coin.draw_e(m)); d_beta.append(coin.draw_e(m)); coin.draw_e(m)
-    d_delta = [coin.draw_e(m) for _ in range(b)]
+    d_delta = [coin.draw_e(m) for _ in range(ce)]
     deg_a, deg_b = coin.draw_e(m), coin.draw_e(m)
     alphas = []
     for root in d["layer_roots"]:
@@ -642,7 +759,7 @@ def _verify_ext(d, air, options):
             raise VerifierError("composition opening %d does not match the constraint commitment" % q)
     # DEEP composition over the extension at the queried points
     wN = root_of_unity(log_N)
-    zw, zb = e_scale(z, wn), e_pow(z, b)
+    zw, zb = e_scale(z, wn), e_pow(z, ce)
     deep = []
     for q, pos in enumerate(positions):
         x = GEN * pow(wN, pos, P) % P
@@ -653,7 +770,7 @@ def _verify_ext(d, air, options):
         for c in range(W):
             s1 = e_add(s1, e_mul(d_alpha[c], e_sub(B(row[c]), cur[c])))
             s2 = e_add(s2, e_mul(d_beta[c], e_sub(B(row[c]), nxt[c])))
-        for i in range(b):
+        for i in range(ce):
             s3 = e_add(s3, e_mul(d_delta[i], e_sub(crow[i], hz[i])))
         t = e_add(e_add(e_mul(s1, i1), e_mul(s2, i2)), e_mul(s3, i3))
         deep.append(e_mul(t, e_add(deg_a, e_scale(deg_b, x))))

@@ -85,3 +85,34 @@ def test_invalid_signature_gives_unverifiable_proof(oracle, backend):
     w.messages[...], w.sig_rx[...], w.sig_s[...] = ex.messages, ex.sig_rx, ex.sig_s
     with pytest.raises(V.VerifierError):
         V.verify_schnorr(proof, w)
+
+
+@pytest.mark.parametrize("ext", [1, 2])
+def test_sub_air_proofs_over_extension_fields(oracle, backend, ext):
+    """The quadratic / cubic variants of the sub-AIR acceptance tests (src/range/tests.rs:25-43, src/schnorr/tests.rs:19-31,
+    src/merkle/update/tests.rs:19-31): one generic extension prover serves every AIR; the restated verifier evaluates each AIR over
+    the extension by interpolation."""
+    from oracle import verifier as V
+    from certificate_stark_amd.prover import MerkleExample, ProofOptions, RangeProofExample, SchnorrExample, TransactionMetadata
+    opts = (42, 8, 0, 0, ext, 4, 256)
+    po = ProofOptions(*opts)
+    number = int(oracle.to_mont([42])[0])
+    proof = RangeProofExample(po, number, backend).prove()
+    assert V.verify_range(proof, number, options=list(opts))
+    with pytest.raises(V.VerifierError):
+        V.verify_range(proof, int(oracle.to_mont([43])[0]))
+    meta = TransactionMetadata.build_random(4, 7, seed=70 + ext)
+    mex = MerkleExample(po, meta, backend)
+    proof = mex.prove()
+    assert V.verify_merkle(proof, *mex.pub_inputs(), options=list(opts))
+    r0, r1 = mex.pub_inputs()
+    with pytest.raises(V.VerifierError):
+        V.verify_merkle(proof, r0, np.full(7, r1[0], np.uint64))
+    sex = SchnorrExample.build_random(po, 2, seed=80 + ext, backend=backend)
+    proof = sex.prove()
+    w = oracle.SchnorrWitness(2)
+    w.messages[...], w.sig_rx[...], w.sig_s[...] = sex.messages, sex.sig_rx, sex.sig_s
+    assert V.verify_schnorr(proof, w, options=list(opts))
+    w.messages[1, 15] ^= np.uint64(2)
+    with pytest.raises(V.VerifierError):
+        V.verify_schnorr(proof, w)
