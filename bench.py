@@ -55,7 +55,7 @@ def cpu_baseline(meta, sample_tx, full_options=None):
     if full_options is not None:
         from oracle import prover as OP
         t0 = time.perf_counter()
-        proof = OP.prove(w, full_options)
+        proof = (OP.prove_ext if full_options[4] else OP.prove)(w, full_options)
         total = time.perf_counter() - t0
         return {
             "value": round(sample_tx / meta.n_tx / total, 5), "unit": "proofs/s", "cores": O.num_threads(), "kind": "port",
@@ -100,6 +100,8 @@ def main():
                     help="prove: complete proofs, independent per GPU (weak scaling, no collective); hotpath: K1..K6 only, "
                          "independent per GPU; coset: the K1..K6 of ONE proof sharded by LDE coset with RCCL all-gathers (strong scaling)")
     ap.add_argument("--hash-fn", choices=["blake3", "sha3"], default="blake3", help="ProofOptions hash (the headline metric uses Blake3_256, src/lib.rs:82)")
+    ap.add_argument("--field-extension", choices=["none", "quadratic", "cubic"], default="none",
+                    help="ProofOptions field extension (the headline metric uses None; the reference's CLI defaults to cubic)")
     ap.add_argument("--queries", type=int, default=96, help="FRI queries (BASELINE.json: 96; the reference's get_example: 42)")
     args = ap.parse_args()
 
@@ -128,7 +130,8 @@ def main():
     log_n = n.bit_length() - 1
 
     hash_fn = 1 if args.hash_fn == "sha3" else 0
-    prover = TransactionProver(ProofOptions(num_queries=args.queries, hash_fn=hash_fn), Backend(local))
+    field_ext = {"none": 0, "quadratic": 1, "cubic": 2}[args.field_extension]
+    prover = TransactionProver(ProofOptions(num_queries=args.queries, hash_fn=hash_fn, field_extension=field_ext), Backend(local))
     prover.load_witness(meta)  # witness resident in HBM before the timed region
     rng = np.random.default_rng(1234 + (rank if args.mode != "coset" else 0))  # one proof = one set of coefficients
     cf = _lib.TxCoeffsStruct()
@@ -284,7 +287,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if coset_mode else "weak", "vs_baseline": None,
             "dtype": "u64 (63-bit prime field, Montgomery) + u32 (Blake3)", "data": "synthetic",
             "config": {"workload": "benches/state_transition.rs full TransactionAir, %d transactions = 2^%d steps, blowup 8, "
-                                   "Merkle depth %d, %s, no field extension" % (n_tx, log_n, meta.depth, "Sha3_256" if hash_fn else "Blake3_256"),
+                                   "Merkle depth %d, %s, %s" % (n_tx, log_n, meta.depth, "Sha3_256" if hash_fn else "Blake3_256",
+                                                                      ["no field extension", "quadratic extension", "cubic extension"][field_ext]),
                        "queries": args.queries, "proof_bytes": proof_len[0] or None,
                        "parallelism": ("one proof sharded by LDE coset over %d GPUs, RCCL all-gather of digests and evaluations" % world)
                        if coset_mode else ("replica x%d (independent proofs per GPU, no collective)" % world),
@@ -307,7 +311,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(meta_full, min(args.cpu_sample_tx, n_tx),
-                                                   (args.queries, 8, 0, hash_fn, 0, 4, 256) if prove_mode else None)
+                                                   (args.queries, 8, 0, hash_fn, field_ext, 4, 256) if prove_mode else None)
             except Exception as e:  # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "proofs/s", "cores": len(os.sched_getaffinity(0)), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

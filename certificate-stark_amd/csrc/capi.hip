@@ -537,21 +537,45 @@ int cstark_tx_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, uint64_
     return CSTARK_OK;
 }
 
-int cstark_tx_evaluate_constraints(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, const uint64_t pub_inputs[4],
-                                   uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
-    if (!coeffs || !pub_inputs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null argument");
+} // extern "C"
+// m coefficient sets over the same frame (the components of an extension-field proof): the constraint values are computed once.
+// (internal: declared in ctx.h for the prover)
+int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
+                                 uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!coeffs || !pub_inputs || !d_outs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null argument");
+    if (m < 1 || m > (uint32_t)cs::CE_MAX_SETS) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: 1..3 coefficient sets");
+    for (uint32_t q = 1; q < m; q++)
+        if (!d_outs[q]) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null output");
     cs::CeParams p;
-    RC_TRY(ce_params(c, d_lde, d_out, merkle_depth, log_n, log_blowup, k0, nk, &p));
-    if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, sizeof(cstark_tx_coeffs) + cs::CE_RTAB_WORDS * 8));
-    static_assert(sizeof(cstark_tx_coeffs) == (115 * 2 + 8) * 8, "coefficient block layout");
-    HIP_TRY(hipMemcpyAsync(c->coef_buf, coeffs, sizeof(cstark_tx_coeffs), hipMemcpyHostToDevice, c->stream));
+    RC_TRY(ce_params(c, d_lde, d_outs[0], merkle_depth, log_n, log_blowup, k0, nk, &p));
+    static_assert(sizeof(cstark_tx_coeffs) == cs::CE_COEF_WORDS * 8, "coefficient block layout");
+    constexpr size_t COEF_WORDS = (size_t)cs::CE_MAX_SETS * cs::CE_COEF_WORDS;
+    if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, (COEF_WORDS + (size_t)cs::CE_MAX_SETS * cs::CE_RTAB_WORDS) * 8));
+    HIP_TRY(hipMemcpyAsync(c->coef_buf, coeffs, (size_t)m * sizeof(cstark_tx_coeffs), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream)); // the caller's struct may be transient
     p.coef = c->coef_buf;
-    p.rtab = c->coef_buf + sizeof(cstark_tx_coeffs) / 8;
+    p.rtab = c->coef_buf + COEF_WORDS;
+    p.m = m;
+    for (uint32_t q = 1; q < m; q++) p.out_ext[q - 1] = d_outs[q];
     for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
     HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, c->part_timing ? c->part_ev : nullptr));
     c->part_valid = c->part_timing;
     return CSTARK_OK;
+}
+extern "C" {
+
+int cstark_tx_evaluate_constraints(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, const uint64_t pub_inputs[4],
+                                   uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    uint64_t *outs[1] = {d_out};
+    return tx_evaluate_constraints_sets(c, d_lde, coeffs, 1, pub_inputs, outs, merkle_depth, log_n, log_blowup, k0, nk);
+}
+
+int cstark_tx_evaluate_constraints_ext(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
+                                       uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!d_out || m < 1 || m > 3) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints_ext: bad argument");
+    const size_t comp = (size_t)nk << log_n;
+    uint64_t *outs[3] = {d_out, d_out + comp, d_out + 2 * comp};
+    return tx_evaluate_constraints_sets(c, d_lde, coeffs, m, pub_inputs, outs, merkle_depth, log_n, log_blowup, k0, nk);
 }
 
 // ---- standalone sub-AIRs -------------------------------------------------------------

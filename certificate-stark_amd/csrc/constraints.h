@@ -16,6 +16,8 @@ constexpr unsigned TX_GROUP_BASE[5] = {5, 4, 3, 2, 1};
 constexpr unsigned TX_GROUP_CYCLES[5] = {2, 2, 1, 1, 1};
 
 constexpr int CE_RTAB_WORDS = 8192;
+constexpr int CE_COEF_WORDS = 115 * 2 + 8; // one coefficient set: alpha[115] | beta[115] | b_alpha[4] | b_beta[4]
+constexpr int CE_MAX_SETS = 3;             // coefficient sets merged in one pass (the components of an extension proof)
 constexpr int CE_COSET_CONSTS = 8; // per coset: shift, 1/(shift^n - 1), shift^adj[0..5), shift^badj
 
 struct CeParams {
@@ -23,10 +25,12 @@ struct CeParams {
     const uint64_t *ptab;  // periodic table [b][48][1024]
     const uint64_t *w;     // [n] powers of w_n
     const uint64_t *coset; // [b][CE_COSET_CONSTS]
-    const uint64_t *coef;  // alpha[115] | beta[115] | b_alpha[4] | b_beta[4]   (device)
+    const uint64_t *coef;  // m sets of CE_COEF_WORDS: alpha[115] | beta[115] | b_alpha[4] | b_beta[4]   (device)
     const uint64_t *binv;  // [b][2][n]: 1/(x-1), 1/(x-w^(n-1)) over the evaluation domain
-    uint64_t *rtab;        // [CE_RTAB_WORDS] scratch: per-proof folded coefficients of the Rescue windows (k_rounds_setup)
-    uint64_t *out;
+    uint64_t *rtab;        // [m][CE_RTAB_WORDS] scratch: per-proof folded coefficients of the Rescue windows (k_rounds_setup)
+    uint64_t *out;         // merged evaluations of coefficient set 0
+    uint64_t *out_ext[CE_MAX_SETS - 1]; // ... of sets 1, 2 (m > 1)
+    uint32_t m;            // number of coefficient sets (0 reads as 1)
     uint64_t pub[4];       // initial_root[0..2], final_root[0..2]
     uint64_t w_last;       // w_n^(n-1)
     uint32_t adj_mod_n[5]; // degree adjustments reduced mod n (x^adj = shift^adj * w^(j*adj mod n))

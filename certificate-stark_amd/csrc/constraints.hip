@@ -374,22 +374,41 @@ constexpr int FNT = 256;
 constexpr int ROUNDS_UNROLL = CS_ROUNDS_UNROLL;
 enum { PART_ROUNDS = 0, PART_DBL0, PART_ADD0, PART_DBL1, PART_ADD1, PART_FINAL, PART_LIN_A, PART_LIN_B, PART_LIN_C, NUM_PARTS };
 
+// M = number of coefficient sets merged in one pass (1 for base-field proofs; 2 / 3 = the components of a quadratic / cubic
+// extension proof, whose coefficients multiply the same base-field constraint values: the values are computed once).
+template <int M>
 struct Fused {
-    const fp *alpha, *beta; // uniform
-    const fp *xp;           // LDS [5][FNT]: x^adj_g of this lane's point
-    Acc128 s;
+    const fp *coefs; // uniform: M blocks of CE_COEF_WORDS (alpha[115] | beta[115] | boundary)
+    const fp *xp;    // LDS [5][FNT]: x^adj_g of this lane's point
+    Acc128 s[M];
     int cnt;
-    fp total;
-    __device__ __forceinline__ fp coef(int i) const { return fp_add(alpha[i], fp_mul(beta[i], xp[tx_degree_group(i) * FNT + threadIdx.x])); }
-    __device__ __forceinline__ void begin() { s = acc_zero(); cnt = 0; }
+    fp total[M];
+    __device__ __forceinline__ fp coef(int c, int i) const {
+        const fp *a = coefs + c * CE_COEF_WORDS;
+        return fp_add(a[i], fp_mul(a[115 + i], xp[tx_degree_group(i) * FNT + threadIdx.x]));
+    }
+    __device__ __forceinline__ void begin() {
+#pragma unroll
+        for (int c = 0; c < M; c++) s[c] = acc_zero();
+        cnt = 0;
+    }
     __device__ __forceinline__ void term(int i, fp v) {
-        acc_mad(s, coef(i), v);
-        if (++cnt == 7) { acc_fold(s); cnt = 0; }
+        ++cnt;
+#pragma unroll
+        for (int c = 0; c < M; c++) {
+            acc_mad(s[c], coef(c, i), v);
+            if (cnt == 7) acc_fold(s[c]);
+        }
+        if (cnt == 7) cnt = 0;
     }
     __device__ __forceinline__ void end(fp flag) {
-        acc_fold(s);
-        total = fp_add(total, fp_mul(flag, acc_reduce(s)));
+#pragma unroll
+        for (int c = 0; c < M; c++) {
+            acc_fold(s[c]);
+            total[c] = fp_add(total[c], fp_mul(flag, acc_reduce(s[c])));
+        }
     }
+    __device__ __forceinline__ void add(int c, fp v) { total[c] = fp_add(total[c], v); }
 };
 
 // sum_j m[j] * x[j] for a row of 14 uniform constants, one reduction
@@ -455,6 +474,8 @@ constexpr size_t ROUNDS_DYN_LDS = 0;
 // one per result slot.  k_rounds_setup folds the coefficients of one proof through MDS (U) and through the round constants, whose
 // extension has period 8 in j on every coset (A[k][j & 7]).  Exact arithmetic: the merged value is unchanged.
 __global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict__ ptab, fp *__restrict__ rtab) {
+    coef += (size_t)blockIdx.y * CE_COEF_WORDS; // grid.y = coefficient set
+    rtab += (size_t)blockIdx.y * CE_RTAB_WORDS;
     if (blockIdx.x >= RT_SECTIONS) { // the constant matrix of the inverse half as a matrix-core table (region zero-filled by the launcher)
         if (threadIdx.x < 16) mdsmfma::build_table_entry((uint8_t *)(rtab + RT_MT), c_inv_mds, 14, blockIdx.x - RT_SECTIONS, threadIdx.x);
         return;
@@ -486,7 +507,8 @@ __global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict
     }
 }
 
-__device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const fp *__restrict__ rtab, unsigned k, unsigned jr, const uint8_t *mtab,
+template <int M>
+__device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, const fp *__restrict__ rtab, unsigned k, unsigned jr, const uint8_t *mtab,
                                              uint8_t *stage, const fp *ark2_lds) {
     const int lane = threadIdx.x & 63;
     const fp *ark2 = ark2_lds + jr * 14;
@@ -530,7 +552,9 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const f
             __builtin_amdgcn_wave_barrier();
         }
 #endif
-        Acc128 sa = acc_zero(), sb = acc_zero();
+        Acc128 sa[M], sb[M];
+#pragma unroll
+        for (int c = 0; c < M; c++) sa[c] = sb[c] = acc_zero();
 #ifdef CS_ROUNDS_MFMA
 #pragma unroll
         for (int i = 0; i < 14; i++) {
@@ -541,12 +565,15 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const f
         for (int i = 0; i < 14; i++) {
             const fp s2 = fp_cube(dot14l(ml + i * 56, d));
 #endif
-            acc_mad(sa, acc.coef(w.res_a + i), s2);
-            if (w.flag_b >= 0) acc_mad(sb, acc.coef(w.res_b + i), s2);
-            if (i == 6) { acc_fold(sa); acc_fold(sb); }
+#pragma unroll
+            for (int c = 0; c < M; c++) {
+                acc_mad(sa[c], acc.coef(c, w.res_a + i), s2);
+                if (w.flag_b >= 0) acc_mad(sb[c], acc.coef(c, w.res_b + i), s2);
+                if (i == 6) { acc_fold(sa[c]); acc_fold(sb[c]); }
+            }
         }
-        acc_fold(sa);
-        acc_fold(sb);
+#pragma unroll
+        for (int c = 0; c < M; c++) { acc_fold(sa[c]); acc_fold(sb[c]); }
         // forward half through the folded vectors
         fp cube[14];
 #pragma unroll
@@ -555,24 +582,30 @@ __device__ __forceinline__ void fused_rounds(Fused &acc, const Frame &f, const f
         for (int fs = 0; fs < 2; fs++) {
             if (fs == 1 && w.flag_b < 0) break;
             const int sec = (wdx * 2 + fs) * 4;
-            fp fwd = fp_add(dot14l(ul + sec * 56, cube), atab[sec * 64]);
-#pragma unroll 1
-            for (int sl = 1; sl < 4; sl++) {
-                const int g = c_window_groups[wdx][fs][sl - 1];
-                if (g < 0) break;
-                const fp v = fp_add(dot14l(ul + (sec + sl) * 56, cube), atab[(sec + sl) * 64]);
-                fwd = fp_add(fwd, fp_mul(acc.xp[g * FNT + threadIdx.x], v));
-            }
-            const fp inv_side = acc_reduce(fs ? sb : sa);
             const int fl = fs ? w.flag_b : w.flag_a;
             const fp flag = fl == 0 ? flags[0] : fl == 1 ? flags[1] : fl == 2 ? flags[2] : flags[3];
-            acc.total = fp_add(acc.total, fp_mul(flag, fp_sub(inv_side, fwd)));
+#pragma unroll
+            for (int c = 0; c < M; c++) {
+                const uint32_t *ulc = ul + (size_t)c * CE_RTAB_WORDS * 2;
+                const fp *atc = atab + (size_t)c * CE_RTAB_WORDS;
+                fp fwd = fp_add(dot14l(ulc + sec * 56, cube), atc[sec * 64]);
+#pragma unroll 1
+                for (int sl = 1; sl < 4; sl++) {
+                    const int g = c_window_groups[wdx][fs][sl - 1];
+                    if (g < 0) break;
+                    const fp v = fp_add(dot14l(ulc + (sec + sl) * 56, cube), atc[(sec + sl) * 64]);
+                    fwd = fp_add(fwd, fp_mul(acc.xp[g * FNT + threadIdx.x], v));
+                }
+                const fp inv_side = acc_reduce(fs ? sb[c] : sa[c]);
+                acc.add(c, fp_mul(flag, fp_sub(inv_side, fwd)));
+            }
         }
     }
 }
 
 // doubling gadget for the point at registers [reg, reg + 19)  (ecc.rs:73-98)
-__device__ __forceinline__ void fused_doubling(Fused &acc, const Frame &f, int reg, fp doubling) {
+template <int M>
+__device__ __forceinline__ void fused_doubling(Fused<M> &acc, const Frame &f, int reg, fp doubling) {
     const Point p = {load6(f, reg, false), load6(f, reg + 6, false), load6(f, reg + 12, false)};
     const Point d = ec_double<false>(p);
     acc.begin();
@@ -587,7 +620,8 @@ __device__ __forceinline__ void fused_doubling(Fused &acc, const Frame &f, int r
 }
 // conditional mixed addition gadget (ecc.rs:102-138):
 //   next - (bit * (p+q) + (1-bit) * p)  =  (next - p) - bit * ((p+q) - p)
-__device__ __forceinline__ void fused_addition(Fused &acc, const Frame &f, int reg, const Fp6 &qx, const Fp6 &qy, fp addition) {
+template <int M>
+__device__ __forceinline__ void fused_addition(Fused<M> &acc, const Frame &f, int reg, const Fp6 &qx, const Fp6 &qy, fp addition) {
     const Point p = {load6(f, reg, false), load6(f, reg + 6, false), load6(f, reg + 12, false)};
     const fp bit = f.cur(reg + 18);
     const Point a = ec_add_mixed<false>(p, qx, qy);
@@ -602,7 +636,8 @@ __device__ __forceinline__ void fused_addition(Fused &acc, const Frame &f, int r
     acc.end(addition);
 }
 // final addition S + h*P with X reduced to affine (ecc.rs:146-172)
-__device__ __forceinline__ void fused_final_addition(Fused &acc, const Frame &f, fp final_add) {
+template <int M>
+__device__ __forceinline__ void fused_final_addition(Fused<M> &acc, const Frame &f, fp final_add) {
     const Point sp = {load6(f, 0, false), load6(f, 6, false), load6(f, 12, false)};
     const Point hp = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
     const Point r = ec_add<false>(sp, hp);
@@ -617,12 +652,15 @@ __device__ __forceinline__ void fused_final_addition(Fused &acc, const Frame &f,
     acc.end(final_add);
 }
 
-__device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &f, int base, fp tx_hash, fp hash_copy, fp hash_init) {
+template <int M>
+__device__ __forceinline__ void fused_merkle_auth_rest(Fused<M> &acc, const Frame &f, int base, fp tx_hash, fp hash_copy, fp hash_init) {
     const fp bit = f.next(base + 14), not_bit = c_not(bit);
     acc.begin();
     acc.term(base + 14, c_is_binary(bit));
     acc.end(tx_hash);
-    Acc128 s_copy = acc_zero(), s_init = acc_zero(); // two sections accumulated side by side (7 + 28 terms)
+    Acc128 s_copy[M], s_init[M]; // two sections accumulated side by side (7 + 28 terms)
+#pragma unroll
+    for (int c = 0; c < M; c++) s_copy[c] = s_init[c] = acc_zero();
 #ifndef CS_LINB_UNROLLED // rolled: a small register footprint and more resident waves beat the unrolled form (2.35 -> 2.0 ms)
 #pragma unroll 1
     for (int k = 0; k < 2; k++) {
@@ -630,19 +668,27 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &
 #pragma unroll 1
         for (int i = 0; i < 7; i++) {
             const fp ci = f.cur(b + i), dd = fp_sub(ci, f.next(b + i));
-            const fp c0 = acc.coef(b + i);
-            acc_mad(s_copy, c0, dd);
-            acc_mad(s_init, c0, fp_mul(not_bit, dd));
-            acc_mad(s_init, acc.coef(b + 7 + i), fp_mul(bit, fp_sub(ci, f.next(b + 7 + i))));
-            if (i & 1) acc_fold(s_init);
+            const fp v1 = fp_mul(not_bit, dd), v2 = fp_mul(bit, fp_sub(ci, f.next(b + 7 + i)));
+#pragma unroll
+            for (int c = 0; c < M; c++) {
+                const fp c0 = acc.coef(c, b + i);
+                acc_mad(s_copy[c], c0, dd);
+                acc_mad(s_init[c], c0, v1);
+                acc_mad(s_init[c], acc.coef(c, b + 7 + i), v2);
+                if (i & 1) acc_fold(s_init[c]);
+            }
         }
-        acc_fold(s_copy);
-        acc_fold(s_init);
+#pragma unroll
+        for (int c = 0; c < M; c++) { acc_fold(s_copy[c]); acc_fold(s_init[c]); }
     }
 #pragma unroll 1
     for (int i = 0; i < 14; i++) {
-        acc_mad(s_init, acc.coef(base + i), fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i))));
-        if ((i & 3) == 3) acc_fold(s_init);
+        const fp v = fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i)));
+#pragma unroll
+        for (int c = 0; c < M; c++) {
+            acc_mad(s_init[c], acc.coef(c, base + i), v);
+            if ((i & 3) == 3) acc_fold(s_init[c]);
+        }
     }
 #else
     int cnt = 0;
@@ -652,27 +698,41 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused &acc, const Frame &
 #pragma unroll
         for (int i = 0; i < 7; i++) {
             const fp ci = f.cur(b + i), dd = fp_sub(ci, f.next(b + i));
-            const fp c0 = acc.coef(b + i);
-            acc_mad(s_copy, c0, dd);
-            acc_mad(s_init, c0, fp_mul(not_bit, dd));
-            acc_mad(s_init, acc.coef(b + 7 + i), fp_mul(bit, fp_sub(ci, f.next(b + 7 + i))));
+            const fp v1 = fp_mul(not_bit, dd), v2 = fp_mul(bit, fp_sub(ci, f.next(b + 7 + i)));
             cnt += 2;
-            if (cnt >= 6) { acc_fold(s_init); cnt = 0; }
+#pragma unroll
+            for (int c = 0; c < M; c++) {
+                const fp c0 = acc.coef(c, b + i);
+                acc_mad(s_copy[c], c0, dd);
+                acc_mad(s_init[c], c0, v1);
+                acc_mad(s_init[c], acc.coef(c, b + 7 + i), v2);
+                if (cnt >= 6) acc_fold(s_init[c]);
+            }
+            if (cnt >= 6) cnt = 0;
         }
-        acc_fold(s_copy);
+#pragma unroll
+        for (int c = 0; c < M; c++) acc_fold(s_copy[c]);
     }
 #pragma unroll
     for (int i = 0; i < 14; i++) {
-        acc_mad(s_init, acc.coef(base + i), fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i))));
-        if ((i & 3) == 3) acc_fold(s_init);
+        const fp v = fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i)));
+#pragma unroll
+        for (int c = 0; c < M; c++) {
+            acc_mad(s_init[c], acc.coef(c, base + i), v);
+            if ((i & 3) == 3) acc_fold(s_init[c]);
+        }
     }
 #endif
-    acc_fold(s_init);
-    acc.total = fp_add(acc.total, fp_add(fp_mul(hash_copy, acc_reduce(s_copy)), fp_mul(hash_init, acc_reduce(s_init))));
+#pragma unroll
+    for (int c = 0; c < M; c++) {
+        acc_fold(s_init[c]);
+        acc.add(c, fp_add(fp_mul(hash_copy, acc_reduce(s_copy[c])), fp_mul(hash_init, acc_reduce(s_init[c]))));
+    }
 }
 
 // setup + value-copy constraints (src/air.rs:406-529)
-__device__ __forceinline__ void fused_linear_a(Fused &acc, const Frame &f) {
+template <int M>
+__device__ __forceinline__ void fused_linear_a(Fused<M> &acc, const Frame &f) {
     const fp setup = f.pv(P_SETUP), copy_values = f.pv(P_VALUE_COPY);
     // ---- flag: setup (src/air.rs:406-503)
     const fp s_spent = fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12));
@@ -704,7 +764,8 @@ __device__ __forceinline__ void fused_linear_a(Fused &acc, const Frame &f) {
     acc.end(copy_values);
 }
 // merkle::update without its rounds (src/merkle/update/air.rs:215-369)
-__device__ __forceinline__ void fused_linear_b(Fused &acc, const Frame &f) {
+template <int M>
+__device__ __forceinline__ void fused_linear_b(Fused<M> &acc, const Frame &f) {
     const fp tx_hash = f.pv(P_MERKLE), hash_input = f.pv(P_HASH_INPUT), finish = f.pv(P_FINISH), hash_flag = f.pv(P_HASH);
     // ---- merkle::update without its rounds (src/merkle/update/air.rs:215-369)
     {
@@ -714,24 +775,35 @@ __device__ __forceinline__ void fused_linear_b(Fused &acc, const Frame &f) {
         for (int blk = 0; blk < 2; blk++) fused_merkle_auth_rest(acc, f, blk == 0 ? S_INIT : R_INIT, tx_hash, hash_copy, hash_init);
     }
     {
-        Acc128 s_nf = acc_zero(), s_f = acc_zero();
+        Acc128 s_nf[M], s_f[M];
+#pragma unroll
+        for (int c = 0; c < M; c++) s_nf[c] = s_f[c] = acc_zero();
 #pragma unroll
         for (int i = 0; i < 7; i++) {
             const fp nr = f.next(PREV_ROOT + i), cr = f.cur(PREV_ROOT + i);
-            const fp c0 = acc.coef(PREV_ROOT + i);
-            acc_mad(s_nf, c0, fp_sub(nr, cr));
-            acc_mad(s_f, c0, fp_sub(nr, f.next(R_UPD + i)));
-            acc_mad(s_f, acc.coef(INT_ROOT_RES + i), fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)));
-            acc_mad(s_f, acc.coef(PREV_MATCH_RES + i), fp_sub(f.next(S_INIT + i), cr));
-            if (i & 1) acc_fold(s_f);
+            const fp v0 = fp_sub(nr, cr), v1 = fp_sub(nr, f.next(R_UPD + i)), v2 = fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)),
+                     v3 = fp_sub(f.next(S_INIT + i), cr);
+#pragma unroll
+            for (int c = 0; c < M; c++) {
+                const fp c0 = acc.coef(c, PREV_ROOT + i);
+                acc_mad(s_nf[c], c0, v0);
+                acc_mad(s_f[c], c0, v1);
+                acc_mad(s_f[c], acc.coef(c, INT_ROOT_RES + i), v2);
+                acc_mad(s_f[c], acc.coef(c, PREV_MATCH_RES + i), v3);
+                if (i & 1) acc_fold(s_f[c]);
+            }
         }
-        acc_fold(s_nf);
-        acc_fold(s_f);
-        acc.total = fp_add(acc.total, fp_add(fp_mul(c_not(finish), acc_reduce(s_nf)), fp_mul(finish, acc_reduce(s_f))));
+#pragma unroll
+        for (int c = 0; c < M; c++) {
+            acc_fold(s_nf[c]);
+            acc_fold(s_f[c]);
+            acc.add(c, fp_add(fp_mul(c_not(finish), acc_reduce(s_nf[c])), fp_mul(finish, acc_reduce(s_f[c]))));
+        }
     }
 }
 // schnorr linear parts, hash copy, range proofs (src/schnorr/air.rs:451-530, src/air.rs:543-609)
-__device__ __forceinline__ void fused_linear_c(Fused &acc, const Frame &f) {
+template <int M>
+__device__ __forceinline__ void fused_linear_c(Fused<M> &acc, const Frame &f) {
     const fp schnorr_mask = f.pv(P_SCHNORR), scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING), schnorr_hash = f.pv(P_SCHNORR_HASH);
     const fp range_flag = f.pv(P_RANGE_STEP), range_finish = f.pv(P_RANGE_FINISH);
     const fp copy_hash = fp_mul(c_not(schnorr_hash), schnorr_mask);
@@ -742,12 +814,10 @@ __device__ __forceinline__ void fused_linear_c(Fused &acc, const Frame &f) {
     for (int i = 0; i < 4; i++) {
         const fp dflag = f.pv(P_DIGEST + i);
         const fp c = f.cur(41 - i), nx = f.next(41 - i);
-        const fp k41 = acc.coef(41 - i), k38 = acc.coef(38 + i);
-        fp t = fp_mul(fp_mul(dflag, doubling), fp_mul(k41, fp_sub(nx, fp_add(fp_dbl(c), f.next(37)))));
-        t = fp_add(t, fp_mul(fp_mul(c_not(dflag), doubling), fp_mul(k41, fp_sub(c, nx))));
-        t = fp_add(t, fp_mul(addition, fp_mul(k38, fp_sub(f.cur(38 + i), f.next(38 + i)))));
-        t = fp_add(t, fp_mul(final_add, fp_mul(k38, fp_sub(f.cur(38 + i), f.cur(42 + i)))));
-        acc.total = fp_add(acc.total, t);
+        const fp u41 = fp_add(fp_mul(fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37)))), fp_mul(fp_mul(c_not(dflag), doubling), fp_sub(c, nx)));
+        const fp u38 = fp_add(fp_mul(addition, fp_sub(f.cur(38 + i), f.next(38 + i))), fp_mul(final_add, fp_sub(f.cur(38 + i), f.cur(42 + i))));
+#pragma unroll
+        for (int q = 0; q < M; q++) acc.add(q, fp_add(fp_mul(acc.coef(q, 41 - i), u41), fp_mul(acc.coef(q, 38 + i), u38)));
     }
     acc.begin(); // enforce_hash_copy (:309-330) with the internal inputs of src/air.rs:543-565
 #pragma unroll
@@ -792,8 +862,11 @@ __device__ __forceinline__ void fused_linear_c(Fused &acc, const Frame &f) {
 #ifndef CS_LIN_WAVES
 #define CS_LIN_WAVES 4
 #endif
-template <int PART>
-__global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : (PART >= PART_DBL0 && PART <= PART_FINAL) ? CS_EC_WAVES : PART == PART_LIN_C ? 2 : CS_LIN_WAVES) void k_eval_fused(CeParams p) {
+constexpr int part_waves(int part, int m) {
+    return part == PART_ROUNDS ? (m == 1 ? CS_ROUNDS_WAVES : 2) : (part >= PART_DBL0 && part <= PART_FINAL) ? CS_EC_WAVES : part == PART_LIN_C ? 2 : (m == 1 ? CS_LIN_WAVES : 2);
+}
+template <int PART, int M>
+__global__ __launch_bounds__(FNT, part_waves(PART, M)) void k_eval_fused(CeParams p) {
     __shared__ fp xp_lds[5 * FNT];
     extern __shared__ __attribute__((aligned(16))) uint8_t rounds_lds[]; // PART_ROUNDS only: ROUNDS_LDS bytes
 #ifdef CS_ROUNDS_MFMA
@@ -812,7 +885,12 @@ __global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : (PART 
     const fp x = fp_mul(cc[0], p.w[j]);
 #pragma unroll
     for (int g = 0; g < 5; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
-    Fused acc{p.coef, p.coef + 115, xp_lds, acc_zero(), 0, 0};
+    Fused<M> acc;
+    acc.coefs = p.coef;
+    acc.xp = xp_lds;
+    acc.cnt = 0;
+#pragma unroll
+    for (int c = 0; c < M; c++) acc.total[c] = 0;
 
     if (PART == PART_ROUNDS) {
         __shared__ fp ark2_lds[8 * 14];
@@ -838,21 +916,25 @@ __global__ __launch_bounds__(FNT, PART == PART_ROUNDS ? CS_ROUNDS_WAVES : (PART 
     if (PART == PART_LIN_C) fused_linear_c(acc, f);
 
     // transition divisor (x^n - 1) / (x - w^(n-1)); x^n is constant on a coset
-    fp t = fp_mul(acc.total, fp_mul(fp_sub(x, p.w_last), cc[1]));
-    fp *o = p.out + (size_t)kk * n + j;
-    if (PART == PART_LIN_C) {
-        // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184)
-        const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
-        const fp *ba = p.coef + 230, *bb = p.coef + 234;
-        const fp r58 = f.cur(58), r59 = f.cur(59);
-        const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
-        const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
-        // 1/(x - 1) and 1/(x - w^(n-1)) depend on the domain only: cached tables
-        const fp *bi = p.binv + (size_t)(p.k0 + kk) * 2 * n + j;
-        t = fp_add(t, fp_mul(first, bi[0]));
-        t = fp_add(t, fp_mul(last, bi[n]));
+    const fp divisor = fp_mul(fp_sub(x, p.w_last), cc[1]);
+#pragma unroll
+    for (int c = 0; c < M; c++) {
+        fp t = fp_mul(acc.total[c], divisor);
+        fp *o = (c == 0 ? p.out : p.out_ext[c == 0 ? 0 : c - 1]) + (size_t)kk * n + j;
+        if (PART == PART_LIN_C) {
+            // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184)
+            const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
+            const fp *ba = p.coef + c * CE_COEF_WORDS + 230, *bb = ba + 4;
+            const fp r58 = f.cur(58), r59 = f.cur(59);
+            const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
+            const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
+            // 1/(x - 1) and 1/(x - w^(n-1)) depend on the domain only: cached tables
+            const fp *bi = p.binv + (size_t)(p.k0 + kk) * 2 * n + j;
+            t = fp_add(t, fp_mul(first, bi[0]));
+            t = fp_add(t, fp_mul(last, bi[n]));
+        }
+        *o = PART == PART_ROUNDS ? t : fp_add(*o, t); // ROUNDS is launched first, the others accumulate in stream order
     }
-    *o = PART == PART_ROUNDS ? t : fp_add(*o, t); // ROUNDS is launched first, the others accumulate in stream order
 }
 
 // =====================================================================================================
@@ -1044,11 +1126,24 @@ hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t s
     const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
     // part_events (optional, CE_NUM_PARTS + 1 events): recorded around every part so that callers can time each launch
     (void)hipMemsetAsync(p.rtab + RT_MT, 0, MT_BYTES, stream);
-    hipLaunchKernelGGL(k_rounds_setup, dim3(RT_SECTIONS + 14), dim3(64), 0, stream, p.coef, p.ptab, p.rtab);
-    (void)hipFuncSetAttribute((const void *)k_eval_fused<PART_ROUNDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROUNDS_LDS);
-#define CS_PART(PART)                                                                    \
-    if (part_events) (void)hipEventRecord(part_events[PART], stream);                    \
-    hipLaunchKernelGGL(k_eval_fused<PART>, grid, block, PART == PART_ROUNDS ? ROUNDS_DYN_LDS : 0, stream, p);
+    const unsigned m = p.m ? p.m : 1;
+    if (m > 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_rounds_setup, dim3(RT_SECTIONS + 14, m), dim3(64), 0, stream, p.coef, p.ptab, p.rtab);
+#define CS_PART(PART)                                                                                                                   \
+    if (part_events) (void)hipEventRecord(part_events[PART], stream);                                                                   \
+    if (m == 1) {                                                                                                                       \
+        if (PART == PART_ROUNDS && ROUNDS_DYN_LDS)                                                                                      \
+            (void)hipFuncSetAttribute((const void *)k_eval_fused<PART, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROUNDS_LDS); \
+        hipLaunchKernelGGL((k_eval_fused<PART, 1>), grid, block, PART == PART_ROUNDS ? ROUNDS_DYN_LDS : 0, stream, p);                    \
+    } else if (m == 2) {                                                                                                                \
+        if (PART == PART_ROUNDS && ROUNDS_DYN_LDS)                                                                                      \
+            (void)hipFuncSetAttribute((const void *)k_eval_fused<PART, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROUNDS_LDS); \
+        hipLaunchKernelGGL((k_eval_fused<PART, 2>), grid, block, PART == PART_ROUNDS ? ROUNDS_DYN_LDS : 0, stream, p);                    \
+    } else {                                                                                                                            \
+        if (PART == PART_ROUNDS && ROUNDS_DYN_LDS)                                                                                      \
+            (void)hipFuncSetAttribute((const void *)k_eval_fused<PART, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROUNDS_LDS); \
+        hipLaunchKernelGGL((k_eval_fused<PART, 3>), grid, block, PART == PART_ROUNDS ? ROUNDS_DYN_LDS : 0, stream, p);                    \
+    }
     CS_PART(PART_ROUNDS) CS_PART(PART_DBL0) CS_PART(PART_ADD0) CS_PART(PART_DBL1) CS_PART(PART_ADD1) CS_PART(PART_FINAL)
     CS_PART(PART_LIN_A) CS_PART(PART_LIN_B) CS_PART(PART_LIN_C)
 #undef CS_PART

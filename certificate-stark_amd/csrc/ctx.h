@@ -78,3 +78,8 @@ struct cstark_ctx {
     void *ws = nullptr;
     size_t ws_bytes = 0;
 };
+
+// internal (capi.hip): merged TransactionAir constraint evaluations for m coefficient sets in one pass over the frame
+struct cstark_tx_coeffs;
+int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
+                                 uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);

@@ -160,6 +160,10 @@ struct AirJob {
     int (*build)(cstark_ctx *, ProveArena *, AirJob &) = nullptr;
     // merged constraint evaluations [b][n] for ONE set of (base-field) coefficients -> out
     int (*combine)(cstark_ctx *, ProveArena *, AirJob &, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) = nullptr;
+    // optional: the merged evaluations of m coefficient sets in one pass over the frame (extension proofs); falls back to m calls
+    int (*combine_sets)(cstark_ctx *, ProveArena *, AirJob &, unsigned m, const uint64_t *const *ta, const uint64_t *const *tb, const uint64_t *const *ba,
+                        const uint64_t *const *bb, uint64_t *const *outs) = nullptr;
+    bool evals_ready = false;       // sub-AIRs: the materialised transition evaluations of this proof are already in the arena
     uint64_t number = 0;            // RangeProofAir
 };
 
@@ -450,6 +454,16 @@ int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, co
     const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]}; // get_assertions, src/air.rs:175-184
     return cstark_tx_evaluate_constraints(c, a->lde, &cf, pub4, out, job.item, job.log_n, 3, 0, 8);
 }
+int tx_combine_sets(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned m, const uint64_t *const *ta, const uint64_t *const *tb, const uint64_t *const *ba,
+                    const uint64_t *const *bb, uint64_t *const *outs) {
+    cstark_tx_coeffs cf[3];
+    for (unsigned q = 0; q < m; q++) {
+        memcpy(cf[q].t_alpha, ta[q], sizeof cf[q].t_alpha); memcpy(cf[q].t_beta, tb[q], sizeof cf[q].t_beta);
+        memcpy(cf[q].b_alpha, ba[q], sizeof cf[q].b_alpha); memcpy(cf[q].b_beta, bb[q], sizeof cf[q].b_beta);
+    }
+    const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]};
+    return tx_evaluate_constraints_sets(c, a->lde, cf, m, pub4, outs, job.item, job.log_n, 3, 0, 8);
+}
 // ---- MerkleAir (src/merkle/update) ---------------------------------------------------------------------------------------------
 int merkle_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
     RC_TRY(cstark_merkle_build_trace(c, a->trace));
@@ -459,7 +473,8 @@ int merkle_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals;
     RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
-    RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_MERKLE_UPDATE, a->lde, evals, job.item, job.log_n, 3, 0, 8));
+    if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_MERKLE_UPDATE, a->lde, evals, job.item, job.log_n, 3, 0, 8));
+    job.evals_ready = true;
     return cstark_air_combine(c, CSTARK_AIR_MERKLE_UPDATE, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, out, job.log_n, 3, 0, 8);
 }
 // ---- RangeProofAir (src/range) -------------------------------------------------------------------------------------------------------
@@ -468,7 +483,8 @@ int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta,
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals;
     RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
-    RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RANGE, a->lde, evals, 0, job.log_n, 3, 0, 8));
+    if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RANGE, a->lde, evals, 0, job.log_n, 3, 0, 8));
+    job.evals_ready = true;
     const uint64_t vals[2] = {0, job.number}; // get_assertions, src/range/air.rs:79-86
     return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, out, job.log_n, 3, 0, 8);
 }
@@ -483,20 +499,24 @@ int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *t
     RC_TRY(arena_extra(a, 3, &aux_lde, 8 * 19 * n * 8));
     RC_TRY(arena_extra(a, 4, &av_co, 12 * n * 8));
     RC_TRY(arena_extra(a, 5, &av_lde, 8 * 12 * n * 8));
-    // the public-input columns (src/schnorr/air.rs:228-290) are not committed: both sides derive them from the messages
-    RC_TRY(cstark_schnorr_aux_columns(c, aux));
-    RC_TRY(cstark_interpolate_columns(c, aux, aux_co, 19, job.log_n));
-    RC_TRY(cstark_lde_columns(c, aux_co, aux_lde, 19, job.log_n, 3, host::generator(), 0, 8));
-    RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
-    RC_TRY(cstark_schnorr_assertion_polys(c, av_co, job.log_n));
-    RC_TRY(cstark_lde_columns(c, av_co, av_lde, 12, job.log_n, 3, host::generator(), 0, 8));
+    if (!job.evals_ready) { // once per proof (extension proofs merge the same evaluations with m coefficient sets)
+        // the public-input columns (src/schnorr/air.rs:228-290) are not committed: both sides derive them from the messages
+        RC_TRY(cstark_schnorr_aux_columns(c, aux));
+        RC_TRY(cstark_interpolate_columns(c, aux, aux_co, 19, job.log_n));
+        RC_TRY(cstark_lde_columns(c, aux_co, aux_lde, 19, job.log_n, 3, host::generator(), 0, 8));
+        RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
+        RC_TRY(cstark_schnorr_assertion_polys(c, av_co, job.log_n));
+        RC_TRY(cstark_lde_columns(c, av_co, av_lde, 12, job.log_n, 3, host::generator(), 0, 8));
+        job.evals_ready = true;
+    }
     return cstark_air_combine(c, CSTARK_AIR_SCHNORR, job.item, a->lde, evals, ta, tb, ba, bb, nullptr, av_lde, 12, out, job.log_n, 3, 0, 8);
 }
 
 
 // ---- any AIR with FieldExtension::Quadratic / Cubic ------------------------------------------------------------------------------
 // Base-field trace; everything the coin draws lives in the degree-m extension (ext.hip).  Coefficients multiply base-field
-// constraint values, so the merged evaluations are m independent runs of the AIR's evaluator (one per component).  Layout
+// constraint values, so the merged evaluations are the AIR's evaluator applied with m coefficient sets (one per component):
+// TransactionAir merges all sets in one pass over the frame, the sub-AIRs merge their materialised evaluations m times.  Layout
 // differences of the proof: out-of-domain values are m-tuples, composition rows hold 8 m-tuples, FRI rows and the remainder are
 // component-major.
 int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *proof, size_t capacity, size_t *proof_len) {
@@ -574,7 +594,13 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
         for (unsigned q = 0; q < m; q++) { ba[q][i] = al.c[q]; bb[q][i] = be.c[q]; }
     }
     uint64_t *comb[3] = {a->combined, combined_x, combined_x + N}, *cco[3] = {a->ccoef, ccoef_x, ccoef_x + N};
-    for (unsigned q = 0; q < m; q++) RC_TRY(job.combine(c, a, job, ta[q].data(), tb[q].data(), ba[q].data(), bb[q].data(), comb[q]));
+    if (job.combine_sets) {
+        const uint64_t *pa[3], *pb[3], *qa[3], *qb[3];
+        for (unsigned q = 0; q < m; q++) { pa[q] = ta[q].data(); pb[q] = tb[q].data(); qa[q] = ba[q].data(); qb[q] = bb[q].data(); }
+        RC_TRY(job.combine_sets(c, a, job, m, pa, pb, qa, qb, comb));
+    } else {
+        for (unsigned q = 0; q < m; q++) RC_TRY(job.combine(c, a, job, ta[q].data(), tb[q].data(), ba[q].data(), bb[q].data(), comb[q]));
+    }
     STAGE();
     for (unsigned q = 0; q < m; q++) {
         const uint64_t *ce_evals = comb[q];
@@ -747,7 +773,7 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     AirJob job;
     job.air = CSTARK_AIR_STATE_TRANSITION; job.width = CSTARK_TX_TRACE_WIDTH; job.log_n = 10 + ceil_log2(c->wit.n_tx); job.log_ce = 3;
     job.n_constraints = CSTARK_TX_NUM_CONSTRAINTS; job.n_assertions = 4; job.item = c->wit.depth;
-    job.build = tx_build; job.combine = tx_combine;
+    job.build = tx_build; job.combine = tx_combine; job.combine_sets = tx_combine_sets;
     if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);
 }

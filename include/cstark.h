@@ -165,6 +165,12 @@ int cstark_tx_evaluate_transitions(cstark_ctx *ctx, const uint64_t *d_lde, uint6
 int cstark_tx_evaluate_constraints(cstark_ctx *ctx, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs,
                                    const uint64_t pub_inputs[4], uint64_t *d_out, uint32_t merkle_depth,
                                    uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* The same for m = 1..3 coefficient sets in ONE pass over the frame (the components of a FieldExtension::Quadratic / Cubic
+ * proof: extension coefficients multiply base-field constraint values, so the values are computed once and merged m times).
+ * coeffs: m consecutive blocks; d_out[(q * nk + (k - k0)) * n + j] = the merged evaluations for block q. */
+int cstark_tx_evaluate_constraints_ext(cstark_ctx *ctx, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m,
+                                       const uint64_t pub_inputs[4], uint64_t *d_out, uint32_t merkle_depth,
+                                       uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 /* Measurement aid: when enabled, cstark_tx_evaluate_constraints records HIP events around each of its 9 launches
  * (Rescue windows; doubling / mixed addition of s*G; of h*P; final addition; three linear groups) on the context's
  * stream; cstark_tx_constraint_part_ms waits for the last one and returns the 9 durations in milliseconds. */
