@@ -157,6 +157,18 @@ class Backend:
                                                       C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out
 
+    def evaluate_constraints_ext(self, lde, coeff_sets, pub_inputs, depth, log_blowup=3, k0=0):
+        """The merged evaluations for 1..3 coefficient sets in one pass over the frame (cstark_tx_evaluate_constraints_ext):
+        returns [m][nk][n]."""
+        nk, width, n = lde.shape
+        m = len(coeff_sets)
+        out = self.empty_u64(m, nk, n)
+        arr = (type(coeff_sets[0]) * m)(*coeff_sets)
+        pub = (C.c_uint64 * 4)(*[int(v) for v in pub_inputs])
+        check(self.lib.cstark_tx_evaluate_constraints_ext(self.ctx, self._ptr(lde), arr, C.c_uint32(m), pub, self._ptr(out), C.c_uint32(depth),
+                                                          C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
+        return out
+
     # ---- standalone sub-AIRs (MerkleAir, RangeProofAir) ----
     AIR_MERKLE, AIR_SCHNORR, AIR_RANGE = 1, 2, 3
 

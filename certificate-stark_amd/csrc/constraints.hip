@@ -368,6 +368,9 @@ __global__ __launch_bounds__(NT) void k_eval_transitions(CeParams p) {
 // using one 128-bit lazy accumulator per (gadget, flag) section, multiplies by 1/Z(x) and adds its share to
 // the output.  Exact arithmetic: the sum of the parts equals the reference's merged evaluation.
 constexpr int FNT = 256;
+#ifndef CS_LINA_UNROLL
+#define CS_LINA_UNROLL 1
+#endif
 #ifndef CS_ROUNDS_UNROLL
 #define CS_ROUNDS_UNROLL 1
 #endif
@@ -376,15 +379,22 @@ enum { PART_ROUNDS = 0, PART_DBL0, PART_ADD0, PART_DBL1, PART_ADD1, PART_FINAL, 
 
 // M = number of coefficient sets merged in one pass (1 for base-field proofs; 2 / 3 = the components of a quadratic / cubic
 // extension proof, whose coefficients multiply the same base-field constraint values: the values are computed once).
+// Tables every lane reads at the same address, written before the launch and never during it (coefficients, folded round
+// tables): addressed through the constant address space, so that they stay scalar loads (s_load) whatever else the kernel does
+// to memory (inline-asm waits, LDS-DMA) -- as vector loads they would also sit on the same in-order counter as the LDS-DMA.
+#define CS_CONST __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const CS_CONST T *as_const(const T *p) { return (const CS_CONST T *)(uintptr_t)p; }
+
 template <int M>
 struct Fused {
-    const fp *coefs; // uniform: M blocks of CE_COEF_WORDS (alpha[115] | beta[115] | boundary)
+    const CS_CONST fp *coefs; // uniform: M blocks of CE_COEF_WORDS (alpha[115] | beta[115] | boundary)
     const fp *xp;    // LDS [5][FNT]: x^adj_g of this lane's point
     Acc128 s[M];
     int cnt;
     fp total[M];
     __device__ __forceinline__ fp coef(int c, int i) const {
-        const fp *a = coefs + c * CE_COEF_WORDS;
+        const CS_CONST fp *a = coefs + c * CE_COEF_WORDS;
         return fp_add(a[i], fp_mul(a[115 + i], xp[tx_degree_group(i) * FNT + threadIdx.x]));
     }
     __device__ __forceinline__ void begin() {
@@ -428,7 +438,7 @@ __device__ __forceinline__ fp dot14(const fp *__restrict__ m, const fp (&x)[14])
 // v_mad_u64_u32 chain with no carry handling at all: 6 multiply-adds per term and nothing else (the carry-propagating
 // 128-bit accumulation above costs ~21 VALU instructions per term).  The six column sums are recombined once:
 //   V = sum_l 2^(21 l) (c0l + 2^32 c1l) < 14 p^2 < 2^128.
-__device__ __forceinline__ fp dot14l(const uint32_t *__restrict__ m, const fp (&x)[14]) {
+__device__ __forceinline__ fp dot14l(const CS_CONST uint32_t *m, const fp (&x)[14]) {
     uint64_t c00 = 0, c01 = 0, c02 = 0, c10 = 0, c11 = 0, c12 = 0;
 #pragma unroll
     for (int j = 0; j < 14; j++) {
@@ -449,12 +459,12 @@ __device__ __forceinline__ void split_limbs(fp v, uint32_t *out4) {
 
 // the five Rescue windows: {first register, result base A, flag A, result base B, flag B (-1: none)}; flag 3 = setup + hash
 // (window 0 writes the same result slots under both flags, so one sum serves both)
-struct RoundWindow { int8_t reg, res_a, flag_a, res_b, flag_b; };
+struct RoundWindow { int reg, res_a, flag_a, res_b, flag_b; }; // dwords: sub-dword constants cannot be scalar loads
 __constant__ RoundWindow c_windows[5] = {
     {S_INIT, S_INIT, 3, 0, -1}, {S_UPD, S_UPD - 1, 0, S_UPD, 1}, {R_INIT, R_INIT - 1, 0, R_INIT, 1}, {R_UPD, R_UPD - 2, 0, R_UPD, 1},
     {42, 42, 2, 0, -1}};
 // degree groups present among the 14 result slots of each (window, flag set); -1 = unused
-__constant__ int8_t c_window_groups[5][2][3] = {
+__constant__ int c_window_groups[5][2][3] = {
     {{0, 1, -1}, {-1, -1, -1}}, {{1, 2, 0}, {1, 2, 0}}, {{0, 2, -1}, {0, 2, -1}}, {{2, -1, -1}, {2, -1, -1}}, {{2, -1, -1}, {-1, -1, -1}}};
 constexpr int RT_SECTIONS = 5 * 2 * 4;                 // (window, flag set, {alpha, beta of up to 3 groups})
 // CeParams::rtab (u64 words): A[sections][64] | limbs of U[sections][14] (4 dwords each) | matrix-core table of INV_MDS
@@ -507,23 +517,43 @@ __global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict
     }
 }
 
+// Window image of one wave: 14 columns x 66 rows (rows j0 .. j0 + 65 of the wave's 64 points; 65 are used), filled by LDS-DMA
+// (global_load_lds_dwordx4: lane l < 33 moves rows j0 + 2l, j0 + 2l + 1 of a column straight into LDS, no VGPR staging).  A lane's
+// current row is element `lane`, its next row element `lane + 1`: every LDE cell is fetched from memory once.
+constexpr int RW_ROWS = 66, RW_IMG = 14 * RW_ROWS;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+// rows: this lane's source rows (lane 32 of the last wave of a coset wraps to rows 0, 1); img: the wave's image (wave-uniform)
+__device__ __forceinline__ void rounds_fetch_window(const fp *rows, size_t n, int reg, int lane, fp *img) {
+    if (lane < 33) {
+#pragma unroll
+        for (int j = 0; j < 14; j++)
+            __builtin_amdgcn_global_load_lds((glb_void *)(rows + (size_t)(reg + j) * n), (lds_void *)(img + j * RW_ROWS), 16, 0, 0);
+    }
+}
 template <int M>
 __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, const fp *__restrict__ rtab, unsigned k, unsigned jr, const uint8_t *mtab,
-                                             uint8_t *stage, const fp *ark2_lds) {
+                                             uint8_t *stage, const fp *ark2_lds, const fp *atab_lds, fp *img, const fp *colbase) {
     const int lane = threadIdx.x & 63;
     const fp *ark2 = ark2_lds + jr * 14;
     const fp flags[4] = {f.pv(P_SETUP), f.pv(P_HASH), f.pv(P_SCHNORR_HASH), fp_add(f.pv(P_SETUP), f.pv(P_HASH))};
-    const fp *atab = rtab + RT_A + k * 8 + jr;
-    const uint32_t *ul = (const uint32_t *)(rtab + RT_UL);
+    const fp *atab = atab_lds + jr; // [M][RT_SECTIONS][8]: this coset's A[section][j & 7]
+    const CS_CONST uint32_t *ul = as_const((const uint32_t *)(rtab + RT_UL));
+    // source rows of this lane's 16-byte piece: rows j0 + 2 lane, + 1 (j0 = the wave's first row); rows n, n + 1 wrap to 0, 1
+    const fp *rows = f.cur_p + lane;
+    if (lane == 32 && ((size_t)(f.cur_p - lane + 64 - colbase) & (f.n - 1)) == 0) rows -= f.n;
+    rounds_fetch_window(rows, f.n, c_windows[0].reg, lane, img);
 #pragma unroll 1
     for (int wdx = 0; wdx < 5; wdx++) {
         const RoundWindow w = c_windows[wdx];
         // register budget (168 VGPRs at 3 waves per SIMD): the 14 round constants of the inverse half are re-read per window
         // from LDS (their extension has period 8 in j: 8 x 14 values per workgroup) and the cubes of the forward half are
         // formed after the inverse half, not before
+        // the window's cells arrive by LDS-DMA (issued during the previous window's forward half)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         fp d[14];
 #pragma unroll
-        for (int j = 0; j < 14; j++) d[j] = fp_sub(f.next(w.reg + j), ark2[j]);
+        for (int j = 0; j < 14; j++) d[j] = fp_sub(img[j * RW_ROWS + lane + 1], ark2[j]);
         // inverse half: cube(INV_MDS (next - ark2))_i against the coefficients of both flag sets.  Default: limb dot products on
         // the vector ALU.  With -DCS_ROUNDS_MFMA the 14x14 product runs on the matrix cores for the 64 points of the wave
         // (mds_mfma.cuh; the staging image is private to the wave, whose LDS operations execute in order, so no workgroup
@@ -560,7 +590,7 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
         for (int i = 0; i < 14; i++) {
             const fp s2 = fp_cube(yv[i]);
 #else
-        const uint32_t *ml = (const uint32_t *)(rtab + RT_ML);
+        const CS_CONST uint32_t *ml = as_const((const uint32_t *)(rtab + RT_ML));
 #pragma unroll 1
         for (int i = 0; i < 14; i++) {
             const fp s2 = fp_cube(dot14l(ml + i * 56, d));
@@ -577,7 +607,11 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
         // forward half through the folded vectors
         fp cube[14];
 #pragma unroll
-        for (int j = 0; j < 14; j++) cube[j] = fp_cube(f.cur(w.reg + j));
+        for (int j = 0; j < 14; j++) cube[j] = fp_cube(img[j * RW_ROWS + lane]);
+        if (wdx < 4) { // the image is free again: fetch the next window behind the forward half
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            rounds_fetch_window(rows, f.n, c_windows[wdx + 1].reg, lane, img);
+        }
 #pragma unroll 1
         for (int fs = 0; fs < 2; fs++) {
             if (fs == 1 && w.flag_b < 0) break;
@@ -586,14 +620,14 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
             const fp flag = fl == 0 ? flags[0] : fl == 1 ? flags[1] : fl == 2 ? flags[2] : flags[3];
 #pragma unroll
             for (int c = 0; c < M; c++) {
-                const uint32_t *ulc = ul + (size_t)c * CE_RTAB_WORDS * 2;
-                const fp *atc = atab + (size_t)c * CE_RTAB_WORDS;
-                fp fwd = fp_add(dot14l(ulc + sec * 56, cube), atc[sec * 64]);
+                const CS_CONST uint32_t *ulc = ul + (size_t)c * CE_RTAB_WORDS * 2;
+                const fp *atc = atab + c * RT_SECTIONS * 8;
+                fp fwd = fp_add(dot14l(ulc + sec * 56, cube), atc[sec * 8]);
 #pragma unroll 1
                 for (int sl = 1; sl < 4; sl++) {
                     const int g = c_window_groups[wdx][fs][sl - 1];
                     if (g < 0) break;
-                    const fp v = fp_add(dot14l(ulc + (sec + sl) * 56, cube), atc[(sec + sl) * 64]);
+                    const fp v = fp_add(dot14l(ulc + (sec + sl) * 56, cube), atc[(sec + sl) * 8]);
                     fwd = fp_add(fwd, fp_mul(acc.xp[g * FNT + threadIdx.x], v));
                 }
                 const fp inv_side = acc_reduce(fs ? sb[c] : sa[c]);
@@ -658,74 +692,39 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused<M> &acc, const Fram
     acc.begin();
     acc.term(base + 14, c_is_binary(bit));
     acc.end(tx_hash);
-    Acc128 s_copy[M], s_init[M]; // two sections accumulated side by side (7 + 28 terms)
+    // Two sections accumulated side by side.  One pass over i = 0..6 touches every cell of the two Rescue states exactly once
+    // (the current and next row of a column are loaded back to back, so the second load is served from cache; the earlier
+    // form walked the columns three times and moved 2.7x the algorithmic bytes -- this part is bandwidth-bound):
+    //   copy (no hash, no input):  cur[b + i] - next[b + i]                                     b = base, base + 15
+    //   init (hash input row):     not_bit (cur[b + i] - next[b + i]),  bit (cur[b + i] - next[b + 7 + i]),
+    //                              bit (next[base + 15 + i] - next[base + i]),  not_bit (next[base + 22 + i] - next[base + 7 + i])
+    Acc128 s_copy[M], s_init[M];
 #pragma unroll
     for (int c = 0; c < M; c++) s_copy[c] = s_init[c] = acc_zero();
-#ifndef CS_LINB_UNROLLED // rolled: a small register footprint and more resident waves beat the unrolled form (2.35 -> 2.0 ms)
 #pragma unroll 1
-    for (int k = 0; k < 2; k++) {
-        const int b = base + 15 * k;
-#pragma unroll 1
-        for (int i = 0; i < 7; i++) {
-            const fp ci = f.cur(b + i), dd = fp_sub(ci, f.next(b + i));
-            const fp v1 = fp_mul(not_bit, dd), v2 = fp_mul(bit, fp_sub(ci, f.next(b + 7 + i)));
-#pragma unroll
-            for (int c = 0; c < M; c++) {
-                const fp c0 = acc.coef(c, b + i);
-                acc_mad(s_copy[c], c0, dd);
-                acc_mad(s_init[c], c0, v1);
-                acc_mad(s_init[c], acc.coef(c, b + 7 + i), v2);
-                if (i & 1) acc_fold(s_init[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < M; c++) { acc_fold(s_copy[c]); acc_fold(s_init[c]); }
-    }
-#pragma unroll 1
-    for (int i = 0; i < 14; i++) {
-        const fp v = fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i)));
+    for (int i = 0; i < 7; i++) {
+        const fp ca = f.cur(base + i), na0 = f.next(base + i), cb = f.cur(base + 15 + i), nb0 = f.next(base + 15 + i);
+        const fp na7 = f.next(base + 7 + i), nb7 = f.next(base + 22 + i);
+        const fp da = fp_sub(ca, na0), db = fp_sub(cb, nb0);
+        const fp u0 = fp_add(fp_mul(not_bit, da), fp_mul(bit, fp_sub(nb0, na0)));               // slot base + i
+        const fp u7 = fp_add(fp_mul(bit, fp_sub(ca, na7)), fp_mul(not_bit, fp_sub(nb7, na7)));  // slot base + 7 + i
+        const fp u15 = fp_mul(not_bit, db), u22 = fp_mul(bit, fp_sub(cb, nb7));                 // slots base + 15 + i, base + 22 + i
 #pragma unroll
         for (int c = 0; c < M; c++) {
-            acc_mad(s_init[c], acc.coef(c, base + i), v);
-            if ((i & 3) == 3) acc_fold(s_init[c]);
+            const fp c0 = acc.coef(c, base + i), c15 = acc.coef(c, base + 15 + i);
+            acc_mad(s_copy[c], c0, da);
+            acc_mad(s_copy[c], c15, db);
+            acc_mad(s_init[c], c0, u0);
+            acc_mad(s_init[c], acc.coef(c, base + 7 + i), u7);
+            acc_mad(s_init[c], c15, u15);
+            acc_mad(s_init[c], acc.coef(c, base + 22 + i), u22);
+            acc_fold(s_init[c]);
+            if (i == 2 || i == 5) acc_fold(s_copy[c]);
         }
     }
-#else
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int b = base + 15 * k;
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const fp ci = f.cur(b + i), dd = fp_sub(ci, f.next(b + i));
-            const fp v1 = fp_mul(not_bit, dd), v2 = fp_mul(bit, fp_sub(ci, f.next(b + 7 + i)));
-            cnt += 2;
-#pragma unroll
-            for (int c = 0; c < M; c++) {
-                const fp c0 = acc.coef(c, b + i);
-                acc_mad(s_copy[c], c0, dd);
-                acc_mad(s_init[c], c0, v1);
-                acc_mad(s_init[c], acc.coef(c, b + 7 + i), v2);
-                if (cnt >= 6) acc_fold(s_init[c]);
-            }
-            if (cnt >= 6) cnt = 0;
-        }
-#pragma unroll
-        for (int c = 0; c < M; c++) acc_fold(s_copy[c]);
-    }
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        const fp v = fp_mul(i < 7 ? bit : not_bit, fp_sub(f.next(base + 15 + i), f.next(base + i)));
-#pragma unroll
-        for (int c = 0; c < M; c++) {
-            acc_mad(s_init[c], acc.coef(c, base + i), v);
-            if ((i & 3) == 3) acc_fold(s_init[c]);
-        }
-    }
-#endif
 #pragma unroll
     for (int c = 0; c < M; c++) {
-        acc_fold(s_init[c]);
+        acc_fold(s_copy[c]);
         acc.add(c, fp_add(fp_mul(hash_copy, acc_reduce(s_copy[c])), fp_mul(hash_init, acc_reduce(s_init[c]))));
     }
 }
@@ -734,34 +733,51 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused<M> &acc, const Fram
 template <int M>
 __device__ __forceinline__ void fused_linear_a(Fused<M> &acc, const Frame &f) {
     const fp setup = f.pv(P_SETUP), copy_values = f.pv(P_VALUE_COPY);
-    // ---- flag: setup (src/air.rs:406-503)
-    const fp s_spent = fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12));
-    acc.begin();
+    // The two sections (flag setup, src/air.rs:406-503; flag copy_values, :506-529) share the key-copy columns: one pass,
+    // two accumulators, every cell loaded once (this part is bandwidth-bound).
+    Acc128 s_set[M], s_cp[M];
 #pragma unroll
+    for (int c = 0; c < M; c++) s_set[c] = s_cp[c] = acc_zero();
+#pragma unroll CS_LINA_UNROLL
     for (int i = 0; i < 12; i++) {
-        acc.term(VALUE_RES + i, fp_sub(f.cur(S_INIT + i), f.cur(S_UPD + i)));
-        acc.term(VALUE_RES + 12 + i, fp_sub(f.cur(R_INIT + i), f.cur(R_UPD + i)));
-        acc.term(S_KEY_RES + i, fp_sub(f.next(S_KEY + i), f.cur(S_INIT + i)));
-        acc.term(R_KEY_RES + i, fp_sub(f.next(R_KEY + i), f.cur(R_INIT + i)));
-    }
-    acc.term(VALUE_RES + 24, fp_sub(f.cur(R_INIT + 13), f.cur(R_UPD + 13)));
-    acc.term(BALANCE_RES, fp_sub(s_spent, fp_sub(f.cur(R_UPD + 12), f.cur(R_INIT + 12))));
-    acc.term(NONCE_UPD_RES, fp_sub(f.cur(S_UPD + 13), fp_add(f.cur(S_INIT + 13), FP_ONE)));
-    acc.term(DELTA_COPY_RES, fp_sub(f.next(DELTA_COPY), s_spent));
-    acc.term(SIGMA_COPY_RES, fp_sub(f.next(SIGMA_COPY), f.cur(S_UPD + 12)));
-    acc.term(NONCE_COPY_RES, fp_sub(f.next(NONCE_COPY), f.cur(S_INIT + 13)));
-    acc.end(setup);
-    // ---- flag: copy_values (src/air.rs:506-529)
-    acc.begin();
+        const fp si = f.cur(S_INIT + i), su = f.cur(S_UPD + i), ri = f.cur(R_INIT + i), ru = f.cur(R_UPD + i);
+        const fp skn = f.next(S_KEY + i), skc = f.cur(S_KEY + i), rkn = f.next(R_KEY + i), rkc = f.cur(R_KEY + i);
+        const fp v0 = fp_sub(si, su), v1 = fp_sub(ri, ru), v2 = fp_sub(skn, si), v3 = fp_sub(rkn, ri), w0 = fp_sub(skn, skc), w1 = fp_sub(rkn, rkc);
 #pragma unroll
-    for (int o = 0; o < 12; o++) {
-        acc.term(S_KEY_RES + o, fp_sub(f.next(S_KEY + o), f.cur(S_KEY + o)));
-        acc.term(R_KEY_RES + o, fp_sub(f.next(R_KEY + o), f.cur(R_KEY + o)));
+        for (int c = 0; c < M; c++) {
+            const fp ks = acc.coef(c, S_KEY_RES + i), kr = acc.coef(c, R_KEY_RES + i);
+            acc_mad(s_set[c], acc.coef(c, VALUE_RES + i), v0);
+            acc_mad(s_set[c], acc.coef(c, VALUE_RES + 12 + i), v1);
+            acc_mad(s_set[c], ks, v2);
+            acc_mad(s_set[c], kr, v3);
+            acc_fold(s_set[c]);
+            acc_mad(s_cp[c], ks, w0);
+            acc_mad(s_cp[c], kr, w1);
+            if (i % 3 == 2) acc_fold(s_cp[c]);
+        }
     }
-    acc.term(DELTA_COPY_RES, fp_sub(f.next(DELTA_COPY), f.cur(DELTA_COPY)));
-    acc.term(SIGMA_COPY_RES, fp_sub(f.next(SIGMA_COPY), f.cur(SIGMA_COPY)));
-    acc.term(NONCE_COPY_RES, fp_sub(f.next(NONCE_COPY), f.cur(NONCE_COPY)));
-    acc.end(copy_values);
+    const fp s_spent = fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12));
+    const fp nd = f.next(DELTA_COPY), ns = f.next(SIGMA_COPY), nn = f.next(NONCE_COPY);
+    const fp t0 = fp_sub(f.cur(R_INIT + 13), f.cur(R_UPD + 13)), t1 = fp_sub(s_spent, fp_sub(f.cur(R_UPD + 12), f.cur(R_INIT + 12)));
+    const fp t2 = fp_sub(f.cur(S_UPD + 13), fp_add(f.cur(S_INIT + 13), FP_ONE));
+    const fp t3 = fp_sub(nd, s_spent), t4 = fp_sub(ns, f.cur(S_UPD + 12)), t5 = fp_sub(nn, f.cur(S_INIT + 13));
+    const fp x0 = fp_sub(nd, f.cur(DELTA_COPY)), x1 = fp_sub(ns, f.cur(SIGMA_COPY)), x2 = fp_sub(nn, f.cur(NONCE_COPY));
+#pragma unroll
+    for (int c = 0; c < M; c++) {
+        const fp kd = acc.coef(c, DELTA_COPY_RES), ksg = acc.coef(c, SIGMA_COPY_RES), kn = acc.coef(c, NONCE_COPY_RES);
+        acc_mad(s_set[c], acc.coef(c, VALUE_RES + 24), t0);
+        acc_mad(s_set[c], acc.coef(c, BALANCE_RES), t1);
+        acc_mad(s_set[c], acc.coef(c, NONCE_UPD_RES), t2);
+        acc_mad(s_set[c], kd, t3);
+        acc_mad(s_set[c], ksg, t4);
+        acc_mad(s_set[c], kn, t5);
+        acc_fold(s_set[c]);
+        acc_mad(s_cp[c], kd, x0);
+        acc_mad(s_cp[c], ksg, x1);
+        acc_mad(s_cp[c], kn, x2);
+        acc_fold(s_cp[c]);
+        acc.add(c, fp_add(fp_mul(setup, acc_reduce(s_set[c])), fp_mul(copy_values, acc_reduce(s_cp[c]))));
+    }
 }
 // merkle::update without its rounds (src/merkle/update/air.rs:215-369)
 template <int M>
@@ -886,7 +902,7 @@ __global__ __launch_bounds__(FNT, part_waves(PART, M)) void k_eval_fused(CeParam
 #pragma unroll
     for (int g = 0; g < 5; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
     Fused<M> acc;
-    acc.coefs = p.coef;
+    acc.coefs = as_const(p.coef);
     acc.xp = xp_lds;
     acc.cnt = 0;
 #pragma unroll
@@ -894,13 +910,19 @@ __global__ __launch_bounds__(FNT, part_waves(PART, M)) void k_eval_fused(CeParam
 
     if (PART == PART_ROUNDS) {
         __shared__ fp ark2_lds[8 * 14];
+        __shared__ __attribute__((aligned(16))) fp img_lds[(FNT / 64) * RW_IMG];
+        __shared__ fp atab_lds[M * RT_SECTIONS * 8];
+        for (unsigned e = threadIdx.x; e < M * RT_SECTIONS * 8; e += FNT) { // (set, section, r) <- A[set][section][k][r]
+            const unsigned r = e & 7, sec = (e >> 3) % RT_SECTIONS, c = e / (8 * RT_SECTIONS);
+            atab_lds[e] = p.rtab[(size_t)c * CE_RTAB_WORDS + RT_A + sec * 64 + (p.k0 + kk) * 8 + r];
+        }
         if (threadIdx.x < 8 * 14) { // row r = j mod 8 of the workgroup's first rows (FNT is a multiple of 8), constant c
             const unsigned r = threadIdx.x / 14, c = threadIdx.x % 14;
             ark2_lds[threadIdx.x] = p.ptab[((size_t)(p.k0 + kk) * 48 + P_ARK + 14 + c) * 1024 + ((blockIdx.x * (size_t)FNT + r) & 1023)];
         }
         __syncthreads();
         fused_rounds(acc, f, p.rtab, p.k0 + kk, (unsigned)(j & 7), rounds_lds, rounds_lds + MT_BYTES + (size_t)(threadIdx.x >> 6) * 64 * mdsmfma::ROW_BYTES,
-                     ark2_lds);
+                     ark2_lds, atab_lds, img_lds + (threadIdx.x >> 6) * RW_IMG, p.lde + (size_t)kk * 94 * n);
     }
     if (PART >= PART_DBL0 && PART <= PART_FINAL) {
         const fp scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING);

@@ -53,3 +53,32 @@ def test_fused_combined_evaluations_match_oracle(oracle, backend, n_tx, depth):
     ref2 = oracle.tx_evaluate_constraints(lde2, cf, pub, depth, 3)
     got2 = to_numpy_u64(backend.evaluate_constraints(backend.from_numpy_u64(lde2), cf, pub, depth))
     assert (got2 == ref2).all()
+
+
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_merged_evaluations_for_several_coefficient_sets(oracle, backend, m):
+    """cstark_tx_evaluate_constraints_ext: the components of an extension-field proof.  Each coefficient set must give exactly
+    what a single-set evaluation (and the oracle) gives for it; also on a sub-range of cosets."""
+    from certificate_stark_amd.backend import to_numpy_u64
+    n_tx, depth = 2, 15
+    w = oracle.TxWitness.generate(n_tx, depth, seed=77)
+    lde = _lde(oracle, w)
+    sets = [oracle.make_coeffs(100 + q) for q in range(m)]
+    pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
+    d_lde = backend.from_numpy_u64(lde)
+    got = to_numpy_u64(backend.evaluate_constraints_ext(d_lde, sets, pub, depth))
+    assert got.shape == (m, 8, lde.shape[2])
+    for q in range(m):
+        assert (got[q] == oracle.tx_evaluate_constraints(lde, sets[q], pub, depth, 3)).all(), "coefficient set %d" % q
+    part = to_numpy_u64(backend.evaluate_constraints_ext(d_lde[4:6].contiguous(), sets, pub, depth, k0=4))
+    assert (part == got[:, 4:6]).all()
+
+
+def test_coefficient_set_count_is_checked(backend):
+    from certificate_stark_amd._lib import CstarkError
+    import torch
+    lde = backend.empty_u64(1, 94, 1024)
+    lde.zero_()
+    from oracle import oracle as O
+    with pytest.raises(CstarkError):
+        backend.evaluate_constraints_ext(lde, [O.make_coeffs(1)] * 4, [0, 0, 0, 0], 3)
