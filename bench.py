@@ -299,10 +299,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_eval_fused<0> (Rescue windows of the constraint evaluation)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": 10.555e9 if (n_tx == 1024 and not coset_mode) else None,
+                         "traffic": 5.705e9 if (n_tx == 1024 and not coset_mode) else None,
                          "algorithmic_bytes": rounds_bytes, "kernel_ms": round(dom_ms, 3),
-                         "traffic_source": "profiles/r01_v9_hbm_traffic_pmc.csv: 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE correction, calibrated on k_hash_rows); "
-                                           "counts Infinity-Cache hits: the current and next rows of a column are loaded at different times (register budget) and the second read is served on-die",
+                         "traffic_source": "profiles/r01_v10_hbm_traffic_pmc.csv: 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE correction, calibrated on k_hash_rows). "
+                                           "Each window's 14 columns arrive once by LDS-DMA (66 rows per 64 points); the five windows overlap in 12 columns, which are "
+                                           "fetched once per window (70 column reads for 58 distinct columns = 1.21x), the rest is the periodic table and tables of w",
                          "note": "integer-multiplier bound kernel (~1.1e4 v_mad_u64_u32 per point; the chip sustains 1.39e13/s = 2.3e12 field products/s) priced against the "
                                  "HBM roofline as BASELINE.json asks; whole-stage figures are in stage_gbs"},
         }

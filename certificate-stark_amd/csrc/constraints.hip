@@ -115,7 +115,11 @@ template <bool CALL>
 __device__ __forceinline__ Point ec_double(const Point &p) {
 #define mul6 MUL6_SEL<CALL> // complete doubling, ecc.rs:177-242
     const Fp6 b3 = const6(c_b3);
+#ifdef CS_EC_SQR
+    Fp6 t0 = fp6_sqr(p.x), t1 = fp6_sqr(p.y), t2 = fp6_sqr(p.z);
+#else
     Fp6 t0 = mul6(p.x, p.x), t1 = mul6(p.y, p.y), t2 = mul6(p.z, p.z);
+#endif
     Fp6 t3 = fp6_dbl(mul6(p.x, p.y));
     Fp6 z3 = fp6_dbl(mul6(p.x, p.z));
     Fp6 y3 = fp6_add(z3, mul6(b3, t2));
@@ -371,6 +375,9 @@ constexpr int FNT = 256;
 #ifndef CS_LINA_UNROLL
 #define CS_LINA_UNROLL 1
 #endif
+#ifndef CS_ROUNDS_INV_UNROLL
+#define CS_ROUNDS_INV_UNROLL 1
+#endif
 #ifndef CS_ROUNDS_UNROLL
 #define CS_ROUNDS_UNROLL 1
 #endif
@@ -591,7 +598,7 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
             const fp s2 = fp_cube(yv[i]);
 #else
         const CS_CONST uint32_t *ml = as_const((const uint32_t *)(rtab + RT_ML));
-#pragma unroll 1
+#pragma unroll CS_ROUNDS_INV_UNROLL
         for (int i = 0; i < 14; i++) {
             const fp s2 = fp_cube(dot14l(ml + i * 56, d));
 #endif
