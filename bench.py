@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--hash-fn", choices=["blake3", "sha3"], default="blake3", help="ProofOptions hash (the headline metric uses Blake3_256, src/lib.rs:82)")
     ap.add_argument("--field-extension", choices=["none", "quadratic", "cubic"], default="none",
                     help="ProofOptions field extension (the headline metric uses None; the reference's CLI defaults to cubic)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="prove mode: independent proofs in flight per GPU, one context + stream + host thread each (default 1: one proof "
+                         "at a time, the reference benchmark's shape; 2 was measured +7%% proofs/s, see DESIGN.md). --steps must be a multiple")
     ap.add_argument("--queries", type=int, default=96, help="FRI queries (BASELINE.json: 96; the reference's get_example: 42)")
     args = ap.parse_args()
 
@@ -219,15 +222,39 @@ def main():
     part_ms = {k: 0.0 for k in prover.backend.CE_PARTS}
     for _ in range(args.warmup):
         step(False)
+    inflight = args.inflight if prove_mode else 1
+    if inflight > 1 and args.steps % inflight:
+        raise SystemExit("--steps must be a multiple of --inflight")
+    others = []
+    for _ in range(inflight - 1):  # further provers: own context, own stream, witness resident, warmed up
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            pr = TransactionProver(ProofOptions(num_queries=args.queries, hash_fn=hash_fn, field_extension=field_ext), Backend(local))
+            pr.load_witness(meta)
+            for _ in range(max(args.warmup, 1)):
+                pr.prove()
+        others.append((st, pr))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     events = []
-    for _ in range(args.steps):
+
+    def run_other(st, pr):
+        with torch.cuda.stream(st):
+            for _ in range(args.steps // inflight):
+                pr.prove()
+
+    import threading
+    threads = [threading.Thread(target=run_other, args=o) for o in others]
+    for t in threads:
+        t.start()
+    for _ in range(args.steps // inflight):
         events.append(step(True))
         collect_parts()  # waits for this step's last constraint launch: the steps are serialised on one stream anyway
+    for t in threads:
+        t.join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -238,7 +265,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if prove_mode:
-        stage_ms = {k: pacc[k] / args.steps for k in pstages}
+        stage_ms = {k: pacc[k] / (args.steps // inflight) for k in pstages}
     else:
         for ev in events:
             for i, s in enumerate(stages):
@@ -268,7 +295,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         ab = algorithmic_bytes(n, WIDTH, 1 << LOG_B)
-        part_avg = {k: v / args.steps for k, v in part_ms.items()}
+        part_avg = {k: v / (args.steps // inflight) for k, v in part_ms.items()}
         # dominant single KERNEL: the Rescue-window launch of the constraint stage (k_eval_fused<0>).  Its algorithmic bytes:
         # the 58 hash-state registers of every LDE row read once (current and next row share cache lines), the 28 round-
         # constant values per point from the 3 MB periodic table (cache resident, not counted), one 8-byte result.
@@ -291,7 +318,8 @@ def main():
                                                                       ["no field extension", "quadratic extension", "cubic extension"][field_ext]),
                        "queries": args.queries, "proof_bytes": proof_len[0] or None,
                        "parallelism": ("one proof sharded by LDE coset over %d GPUs, RCCL all-gather of digests and evaluations" % world)
-                       if coset_mode else ("replica x%d (independent proofs per GPU, no collective)" % world),
+                       if coset_mode else ("replica x%d (independent proofs per GPU, no collective)%s" % (
+                           world, ", %d proofs in flight per GPU" % inflight if inflight > 1 else "")),
                        "trace": "%d x 2^%d" % (WIDTH, log_n)},
             "stage_ms": {s: round(v, 3) for s, v in stage_ms.items()},
             "stage_gbs": {s: round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1) for s in (["interpolate", "lde", "constraints"] if prove_mode else stages)},
