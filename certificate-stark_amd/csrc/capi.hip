@@ -85,9 +85,9 @@ int interpolate_impl(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint3
 }
 
 constexpr uint32_t LDE_COLUMN_GROUP = 1u << 30; // columns per group of the LDE (see lde_impl); 2^30 = all columns at once
-int lde_impl(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t log_n, uint32_t log_blowup,
+int lde_impl(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n, uint32_t log_blowup,
              uint64_t domain_offset, uint32_t k0, uint32_t nk) {
-    if (!c || !d_coeffs || !d_lde || width == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_lde_columns: bad argument");
+    if (!c || !d_coeffs || !d_lde || width == 0 || ncols == 0 || (uint64_t)col0 + ncols > width) return fail(CSTARK_ERR_INVALID_ARG, "cstark_lde_columns: bad argument");
     if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6) return fail(CSTARK_ERR_UNSUPPORTED, "unsupported domain size");
     if (domain_offset == 0 || domain_offset >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "domain offset must be a nonzero field element");
     if ((uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "coset range exceeds the blowup factor");
@@ -104,8 +104,8 @@ int lde_impl(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t 
     // multiplications (11 per element for 20 butterfly levels), not by HBM, so the default stays one launch pair per coset.
     static const uint32_t group_env = [] { const char *e = getenv("CSTARK_NTT_GROUP"); return e ? (uint32_t)atoi(e) : 0u; }();
     const uint32_t group = group_env ? group_env : LDE_COLUMN_GROUP;
-    for (uint32_t g0 = 0; g0 < width; g0 += group) {
-        const uint32_t gw = width - g0 < group ? width - g0 : group;
+    for (uint32_t g0 = col0; g0 < col0 + ncols; g0 += group) {
+        const uint32_t gw = col0 + ncols - g0 < group ? col0 + ncols - g0 : group;
         for (uint32_t k = k0; k < k0 + nk; k++) {
             cs::NttArgs a{};
             a.in = d_coeffs + (size_t)g0 * n; a.scratch = (uint64_t *)c->ws; a.out = d_lde + ((size_t)(k - k0) * width + g0) * n;
@@ -136,7 +136,7 @@ int get_periodic(cstark_ctx *c, unsigned depth, unsigned log_n, unsigned log_b, 
     RC_TRY(interpolate_impl(c, d_cols, d_poly, (uint32_t)NP, 10));
     // a column of period 1024 is a polynomial in x^(n/1024): evaluate it over offset' * <w_{b*1024}>, offset' = g^(n/1024)
     const uint64_t g = cs::host::generator();
-    RC_TRY(lde_impl(c, d_poly, t.tab, (uint32_t)NP, 10, log_b, cs::host::pow(g, n / C), 0, (uint32_t)b));
+    RC_TRY(lde_impl(c, d_poly, t.tab, (uint32_t)NP, 0, (uint32_t)NP, 10, log_b, cs::host::pow(g, n / C), 0, (uint32_t)b));
     // per-coset scalars: shift_k = g w_{bn}^k, 1/(shift^n - 1), shift^adj_g, shift^badj
     std::vector<uint64_t> cc(b * cs::CE_COSET_CONSTS);
     const uint64_t wbn = cs::host::root_of_unity(log_n + log_b);
@@ -202,8 +202,9 @@ int cstark_ctx_create(int device, void *stream, cstark_ctx **out) {
     if (!c) return fail(CSTARK_ERR_OOM, "host allocation failed");
     c->device = device;
     c->stream = (hipStream_t)stream; // NULL is HIP's default stream
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return fail(CSTARK_ERR_HIP, "could not create the internal stream / events");
     }
@@ -216,6 +217,8 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->wit_buf) (void)hipFree(c->wit_buf);
@@ -324,7 +327,7 @@ int cstark_interpolate_columns(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coe
 }
 int cstark_lde_columns(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t log_n, uint32_t log_blowup,
                        uint64_t domain_offset, uint32_t k0, uint32_t nk) {
-    return lde_impl(c, d_coeffs, d_lde, width, log_n, log_blowup, domain_offset, k0, nk);
+    return lde_impl(c, d_coeffs, d_lde, width, 0, width, log_n, log_blowup, domain_offset, k0, nk);
 }
 
 // ---- composition polynomial (first "next" row: engine into_poly + column split) -----------------------------------
@@ -549,6 +552,17 @@ int cstark_tx_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, uint64_
 }
 
 } // extern "C"
+int lde_column_range(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n,
+                     uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk) {
+    return lde_impl(c, d_coeffs, d_lde, width, col0, ncols, log_n, log_blowup, domain_offset, k0, nk);
+}
+int tx_build_trace_split(cstark_ctx *c, uint64_t *d_trace) {
+    if (!c || !d_trace) return fail(CSTARK_ERR_INVALID_ARG, "tx_build_trace_split: null argument");
+    if (!c->wit_buf || c->wit.n_tx == 0) return fail(CSTARK_ERR_INVALID_ARG, "no witness uploaded");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::launch_trace_gen_split(c->wit, d_trace, c->stream, c->side, c->side2, c->ev_fork, c->ev_join, c->ev_join2));
+    return CSTARK_OK;
+}
 // m coefficient sets over the same frame (the components of an extension-field proof): the constraint values are computed once.
 // (internal: declared in ctx.h for the prover)
 int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
@@ -682,7 +696,7 @@ int cstark_schnorr_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, co
         HIP_TRY(hipMalloc((void **)&t.tab, b * cols.size() * 8));
         HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), cols.size() * 8, hipMemcpyHostToDevice, c->stream));
         RC_TRY(interpolate_impl(c, d_cols, d_poly, 36, 9));
-        RC_TRY(lde_impl(c, d_poly, t.tab, 36, 9, log_blowup, cs::host::pow(cs::host::generator(), n / 512), 0, (uint32_t)b));
+        RC_TRY(lde_impl(c, d_poly, t.tab, 36, 0, 36, 9, log_blowup, cs::host::pow(cs::host::generator(), n / 512), 0, (uint32_t)b));
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipFree(d_cols));
         HIP_TRY(hipFree(d_poly));
@@ -738,7 +752,7 @@ int cstark_air_evaluate_transitions(cstark_ctx *c, int air, const uint64_t *d_ld
         HIP_TRY(hipMalloc((void **)&t.tab, b * cols.size() * 8));
         HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), cols.size() * 8, hipMemcpyHostToDevice, c->stream));
         RC_TRY(interpolate_impl(c, d_cols, d_poly, 33, 9));
-        RC_TRY(lde_impl(c, d_poly, t.tab, 33, 9, log_blowup, cs::host::pow(cs::host::generator(), n / 512), 0, (uint32_t)b));
+        RC_TRY(lde_impl(c, d_poly, t.tab, 33, 0, 33, 9, log_blowup, cs::host::pow(cs::host::generator(), n / 512), 0, (uint32_t)b));
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipFree(d_cols));
         HIP_TRY(hipFree(d_poly));

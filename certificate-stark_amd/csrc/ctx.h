@@ -53,8 +53,8 @@ void prove_arena_free(ProveArena *a);
 struct cstark_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr; // internal second stream (forked from / joined into `stream`)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr; // internal streams (forked from / joined into `stream`)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     // uploaded witness
     void *wit_buf = nullptr;
     size_t wit_bytes = 0;
@@ -83,3 +83,10 @@ struct cstark_ctx {
 struct cstark_tx_coeffs;
 int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
                                  uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+// internal (capi.hip): TransactionAir trace with the curve ladders left running on an internal stream.  On return `stream` has
+// every column >= TX_LATE_COLS complete in stream order; the caller makes `stream` wait for c->ev_join2 before touching the rest.
+constexpr uint32_t TX_LATE_COLS = 37; // registers 0..36: the two curve points and the s-bit register between them
+int tx_build_trace_split(cstark_ctx *c, uint64_t *d_trace);
+// LDE of columns [col0, col0 + ncols) of a table of `width` columns (same layout and arguments as cstark_lde_columns)
+int lde_column_range(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n,
+                     uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);

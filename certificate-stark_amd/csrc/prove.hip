@@ -163,6 +163,10 @@ struct AirJob {
     // optional: the merged evaluations of m coefficient sets in one pass over the frame (extension proofs); falls back to m calls
     int (*combine_sets)(cstark_ctx *, ProveArena *, AirJob &, unsigned m, const uint64_t *const *ta, const uint64_t *const *tb, const uint64_t *const *ba,
                         const uint64_t *const *bb, uint64_t *const *outs) = nullptr;
+    // Columns [0, late_cols) of the trace are still being written on an internal stream when build() returns (TransactionAir:
+    // the curve ladders); the prover commits the other columns first and waits for late_event before it touches these.
+    uint32_t late_cols = 0;
+    hipEvent_t late_event = nullptr;
     bool evals_ready = false;       // sub-AIRs: the materialised transition evaluations of this proof are already in the arena
     uint64_t number = 0;            // RangeProofAir
 };
@@ -220,6 +224,29 @@ int check_options(const cstark_options *opt, unsigned *log_rem_out) {
 }
 
 // Prover::prove for any of the AIRs.
+// Interpolation and extension of the trace columns; records the two stage events (after the interpolation, after the extension).
+// With late columns (AirJob::late_cols) the complete columns go first -- interpolated AND extended while the internal stream still
+// writes the late ones -- so the "interpolate" stage time then also holds the extension of the early columns.
+int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hipStream_t st, int &evi) {
+    const uint32_t W = job.width, log_n = job.log_n, b = 1u << log_b, late = job.late_cols;
+    const size_t n = (size_t)1 << log_n;
+    if (late == 0 || late >= W) {
+        RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, W, log_n));
+        HIP_TRY(hipEventRecord(a->ev[evi++], st));
+        RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, W, log_n, log_b, host::generator(), 0, b));
+        HIP_TRY(hipEventRecord(a->ev[evi++], st));
+        return CSTARK_OK;
+    }
+    RC_TRY(cstark_interpolate_columns(c, a->trace + (size_t)late * n, a->coeffs + (size_t)late * n, W - late, log_n));
+    RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, late, W - late, log_n, log_b, host::generator(), 0, b));
+    HIP_TRY(hipStreamWaitEvent(st, job.late_event, 0));
+    RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, late, log_n));
+    HIP_TRY(hipEventRecord(a->ev[evi++], st));
+    RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, 0, late, log_n, log_b, host::generator(), 0, b));
+    HIP_TRY(hipEventRecord(a->ev[evi++], st));
+    return CSTARK_OK;
+}
+
 int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *proof, size_t capacity, size_t *proof_len) {
     unsigned log_rem = 0;
     RC_TRY(check_options(opt, &log_rem));
@@ -242,10 +269,7 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     RC_TRY(job.build(c, a, job));
     STAGE();
     // ---- trace commitment -----------------------------------------------------------------------------------------------
-    RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, (uint32_t)W, log_n));
-    STAGE();
-    RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, (uint32_t)W, log_n, log_b, host::generator(), 0, (uint32_t)b));
-    STAGE();
+    RC_TRY(commit_columns(c, a, job, log_b, st, evi));
     const uint32_t hf = opt->hash_fn;
     RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
@@ -444,7 +468,20 @@ unsigned ceil_log2(uint64_t x) { unsigned l = 0; while ((1ull << l) < x) l++; re
 
 // ---- TransactionAir ---------------------------------------------------------------------------------------------------------------
 int tx_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
-    RC_TRY(cstark_tx_build_trace(c, a->trace));
+    // the curve ladders are latency-bound (two waves per SIMD for ~2.8 ms): they run beside the interpolation and extension of
+    // the 57 registers that do not depend on them
+    static const int mode = [] { const char *e = getenv("CSTARK_TRACE_OVERLAP"); return e ? atoi(e) : 1; }(); // tuning / debugging: 0 = no overlap, 2 = split launch joined at once
+    if (mode == 0) {
+        RC_TRY(cstark_tx_build_trace(c, a->trace));
+        return gather_roots(c, a, job);
+    }
+    RC_TRY(tx_build_trace_split(c, a->trace));
+    if (mode == 2) {
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+        return gather_roots(c, a, job);
+    }
+    job.late_cols = TX_LATE_COLS;
+    job.late_event = c->ev_join2;
     return gather_roots(c, a, job);
 }
 int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
@@ -555,10 +592,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     STAGE();
     RC_TRY(job.build(c, a, job));
     STAGE();
-    RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, (uint32_t)W, log_n));
-    STAGE();
-    RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, (uint32_t)W, log_n, log_b, generator(), 0, (uint32_t)b));
-    STAGE();
+    RC_TRY(commit_columns(c, a, job, log_b, st, evi));
     RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
     uint8_t trace_root[32], cons_root[32];

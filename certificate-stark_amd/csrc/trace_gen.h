@@ -17,6 +17,10 @@ struct TxWitnessDev {
 // `side` is a second stream used for the part of the trace that is independent of the rest; `fork`/`join` are events
 // owned by the caller (fork: stream -> side, join: side -> stream)
 hipError_t launch_trace_gen(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t join);
+// The same trace, with the curve ladders (registers 0..17, 19..36 of the Schnorr rows) on `side_b` and NOT joined: `join_b` is
+// recorded behind them.  `stream` returns with every other register complete (Merkle recurrence joined from `side_a`).
+hipError_t launch_trace_gen_split(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream, hipStream_t side_a, hipStream_t side_b,
+                                  hipEvent_t fork, hipEvent_t join_a, hipEvent_t join_b);
 
 // standalone sub-AIR traces
 hipError_t launch_merkle_trace(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream); // 65 x 512*n_tx

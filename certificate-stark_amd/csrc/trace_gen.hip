@@ -15,6 +15,7 @@
 //                         src/range/prover.rs:65-84, src/utils/field.rs:16-22)
 // Rows are staged in LDS 64 at a time and written column-wise, so every global store is a
 // contiguous 512-byte line of one column (the trace is column-major, 94 x N).
+#include <stdlib.h>
 #include "trace_gen.h"
 #include "rescue.cuh"
 #include "tower.cuh"
@@ -25,6 +26,7 @@ namespace {
 
 constexpr int TXC = 1024;       // TRANSACTION_CYCLE_LENGTH, src/constants.rs:83
 constexpr int MERKLE_LEN = 512; // src/merkle/constants.rs:29
+constexpr unsigned LADDER_LDS_PAD = 0;
 constexpr int SCALAR_MUL_LEN = 510; // src/schnorr/constants.rs:30
 
 // One Rescue round on a 14-element state held one element per lane (rescue.rs:246-263).
@@ -346,9 +348,13 @@ __device__ __forceinline__ int bit_le(const uint8_t *bytes, int i) { return (byt
 // h*P (registers 19..36).  With a single wave per workgroup the phase barriers of run_point_op cost nothing and the two
 // ladders of a transaction never wait for each other; 2 * n_tx independent waves keep every SIMD busy with two of them.
 // The last step (S += h*P, X <- X/Z) needs both ladders: k_trace_schnorr_final, below.
-template <bool STANDALONE>
+// TR = rows of the staging tile (rows per flush).  64 is the fastest alone (3.99 ms of trace generation against 5.77 ms with 16);
+// 16 leaves room in LDS for a transform workgroup beside the eight resident ladders of a CU and is the fastest when the
+// ladders run beside the interpolation / extension of the other registers (prove.hip commit_columns: 43.1 vs 43.8 ms per proof).
+template <bool STANDALONE, int TR>
 __global__ __launch_bounds__(64) void k_trace_schnorr_ec(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
-    __shared__ fp tile[64][19];
+    constexpr int TG = 64 / TR; // column groups of a flush
+    __shared__ fp tile[TR][19];
     __shared__ fp slots[NSLOT][6];
     __shared__ Fp2 prods[6][6];
     __shared__ uint8_t sbytes[32];
@@ -382,11 +388,11 @@ __global__ __launch_bounds__(64) void k_trace_schnorr_ec(TxWitnessDev w, fp *__r
                 if (bit) run_point_op<OP_ADD_MIXED>(pg, slot, prods, lane, true); // uniform over the wave
             }
         } // step == SCALAR_MUL_LEN: the row is a copy here; k_trace_schnorr_final rewrites registers 0..17 of it
-        const int r = (step + 1) & 63;
+        const int r = (step + 1) & (TR - 1);
         if (lane < 18) tile[r][lane] = slot[lane / 6][lane % 6];
-        if (r == 63) {
+        if (r == TR - 1) {
             __syncthreads();
-            flush_tile<18, 19>(tile, trace, n, gbase + (step + 1 - 63), g * 19, lane);
+            for (int c = lane / TR; c < 18; c += TG) trace[(size_t)(g * 19 + c) * n + gbase + (step + 1 - (TR - 1)) + (lane & (TR - 1))] = tile[lane & (TR - 1)][c];
             __syncthreads();
         }
     }
@@ -476,6 +482,11 @@ __global__ __launch_bounds__(256) void k_trace_aux(TxWitnessDev w, fp *__restric
 
 } // namespace
 
+// Unused dynamic LDS added to every ladder workgroup of the overlapped path (tuning: CSTARK_EC_LDS_PAD); measured best at 0.
+static unsigned ladder_lds_pad() {
+    static const unsigned pad = [] { const char *e = getenv("CSTARK_EC_LDS_PAD"); return e ? (unsigned)atoi(e) : LADDER_LDS_PAD; }();
+    return pad;
+}
 hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
     const size_t n = (size_t)w.n_tx * TXC;
     // the Merkle-phase recurrence is independent of the Schnorr half: run it beside the curve ladders (both are
@@ -486,10 +497,30 @@ hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stre
     hipLaunchKernelGGL(k_trace_merkle<false>, dim3(w.n_tx), dim3(64), 0, side, w, d_trace, n);
     if ((e = hipEventRecord(join, side)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_trace_schnorr_hash<false>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
-    hipLaunchKernelGGL(k_trace_schnorr_ec<false>, dim3(2 * w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL((k_trace_schnorr_ec<false, 64>), dim3(2 * w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_final<false>, dim3(w.n_tx), dim3(64), 0, stream, d_trace, n);
     hipLaunchKernelGGL(k_trace_aux, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
     if ((e = hipStreamWaitEvent(stream, join, 0)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_gen_split(const TxWitnessDev &w, fp *d_trace, hipStream_t stream, hipStream_t side_a, hipStream_t side_b, hipEvent_t fork,
+                                  hipEvent_t join_a, hipEvent_t join_b) {
+    const size_t n = (size_t)w.n_tx * TXC;
+    hipError_t e;
+    if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(side_a, fork, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_trace_merkle<false>, dim3(w.n_tx), dim3(64), 0, side_a, w, d_trace, n);
+    if ((e = hipEventRecord(join_a, side_a)) != hipSuccess) return e;
+    // the message hash produces the scalar h of the second ladder (w.h_limbs): the ladders start behind it
+    hipLaunchKernelGGL(k_trace_schnorr_hash<false>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(side_b, fork, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL((k_trace_schnorr_ec<false, 16>), dim3(2 * w.n_tx), dim3(64), ladder_lds_pad(), side_b, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_final<false>, dim3(w.n_tx), dim3(64), 0, side_b, d_trace, n);
+    if ((e = hipEventRecord(join_b, side_b)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_trace_aux, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
+    if ((e = hipStreamWaitEvent(stream, join_a, 0)) != hipSuccess) return e;
     return hipGetLastError();
 }
 
@@ -539,7 +570,7 @@ __global__ __launch_bounds__(256) void k_schnorr_aux_columns(TxWitnessDev w, fp 
 hipError_t launch_schnorr_trace(const TxWitnessDev &w, fp *d_trace, hipStream_t stream) {
     const size_t n = (size_t)w.n_tx * MERKLE_LEN;
     hipLaunchKernelGGL(k_trace_schnorr_hash<true>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
-    hipLaunchKernelGGL(k_trace_schnorr_ec<true>, dim3(2 * w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL((k_trace_schnorr_ec<true, 64>), dim3(2 * w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_final<true>, dim3(w.n_tx), dim3(64), 0, stream, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_bits, dim3(w.n_tx, 2), dim3(256), 0, stream, w, d_trace, n);
     return hipGetLastError();

@@ -236,7 +236,11 @@ int cstark_air_prove(cstark_ctx *ctx, int air, const cstark_options *opt, uint64
 size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt);
 /* Wall-clock of the stages of the last cstark_tx_prove on this context (HIP events on its stream), milliseconds:
  * trace, interpolate, LDE, row hashes + tree, constraint evaluation, composition polynomial + commitment,
- * out-of-domain frame, DEEP composition, FRI layers, query openings. */
+ * out-of-domain frame, DEEP composition, FRI layers, query openings.
+ * cstark_tx_prove runs the curve ladders of the trace (registers 0..36) on an internal stream beside the interpolation AND
+ * extension of the other 57 registers; its first three figures are therefore: trace = the rest of the trace on the context's
+ * stream; interpolate = registers 37..93 interpolated and extended, the wait for the ladders, registers 0..36 interpolated;
+ * LDE = extension of registers 0..36.  Their sum is the time from the start of the proof to the complete extended trace. */
 int cstark_prove_stage_ms(cstark_ctx *ctx, float *ms /* [CSTARK_PROVE_NUM_STAGES] */);
 
 /* ---- standalone sub-AIRs (reference src/merkle/update, src/range; BASELINE configs 1-2) ---------- */
