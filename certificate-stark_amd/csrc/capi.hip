@@ -202,9 +202,14 @@ int cstark_ctx_create(int device, void *stream, cstark_ctx **out) {
     if (!c) return fail(CSTARK_ERR_OOM, "host allocation failed");
     c->device = device;
     c->stream = (hipStream_t)stream; // NULL is HIP's default stream
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
+    // the internal streams carry latency-bound recurrences (one wave per transaction and chain) that run beside chip-filling
+    // transforms on the caller's stream: highest dispatch priority, so that their workgroups are placed as soon as they are ready
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return fail(CSTARK_ERR_HIP, "could not create the internal stream / events");
     }
@@ -219,6 +224,7 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
     if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+    if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->wit_buf) (void)hipFree(c->wit_buf);
@@ -560,7 +566,7 @@ int tx_build_trace_split(cstark_ctx *c, uint64_t *d_trace) {
     if (!c || !d_trace) return fail(CSTARK_ERR_INVALID_ARG, "tx_build_trace_split: null argument");
     if (!c->wit_buf || c->wit.n_tx == 0) return fail(CSTARK_ERR_INVALID_ARG, "no witness uploaded");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(cs::launch_trace_gen_split(c->wit, d_trace, c->stream, c->side, c->side2, c->ev_fork, c->ev_join, c->ev_join2));
+    HIP_TRY(cs::launch_trace_gen_split(c->wit, d_trace, c->stream, c->side, c->side2, c->ev_fork, c->ev_join, c->ev_mid, c->ev_join2));
     return CSTARK_OK;
 }
 // m coefficient sets over the same frame (the components of an extension-field proof): the constraint values are computed once.

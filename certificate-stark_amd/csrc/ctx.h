@@ -54,7 +54,7 @@ struct cstark_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr, side2 = nullptr; // internal streams (forked from / joined into `stream`)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mid = nullptr;
     // uploaded witness
     void *wit_buf = nullptr;
     size_t wit_bytes = 0;
@@ -83,9 +83,12 @@ struct cstark_ctx {
 struct cstark_tx_coeffs;
 int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
                                  uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
-// internal (capi.hip): TransactionAir trace with the curve ladders left running on an internal stream.  On return `stream` has
-// every column >= TX_LATE_COLS complete in stream order; the caller makes `stream` wait for c->ev_join2 before touching the rest.
+// internal (capi.hip): TransactionAir trace spread over the context's streams, nothing joined.  In stream order `stream` holds
+// registers >= TX_COPY_COLS (closed forms); c->side: the Merkle recurrence, c->ev_join recorded behind it; c->side2: message hash
+// (c->ev_mid behind it), then the curve ladders (c->ev_join2 behind them).  Registers [TX_LATE_COLS, TX_COPY_COLS) are complete
+// after ev_join and ev_mid, registers [0, TX_LATE_COLS) after ev_join2 as well.
 constexpr uint32_t TX_LATE_COLS = 37; // registers 0..36: the two curve points and the s-bit register between them
+constexpr uint32_t TX_COPY_COLS = 65; // registers 65..93: key / amount copies and the sigma range accumulator
 int tx_build_trace_split(cstark_ctx *c, uint64_t *d_trace);
 // LDE of columns [col0, col0 + ncols) of a table of `width` columns (same layout and arguments as cstark_lde_columns)
 int lde_column_range(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n,

@@ -38,6 +38,7 @@ struct ProveArena {
     std::vector<uint8_t *> lnodes;   // FRI layer trees
     uint32_t *d_pos = nullptr;
     uint8_t *d_open = nullptr;
+    uint64_t *h_pub = nullptr; // pinned
     size_t open_bytes = 0;
     hipEvent_t ev[PROVE_EVENTS] = {};
     bool timed = false;
@@ -47,6 +48,7 @@ struct ProveArena {
 void prove_arena_free(ProveArena *a) {
     if (!a) return;
     for (void *p : a->owned) (void)hipFree(p);
+    if (a->h_pub) (void)hipHostFree(a->h_pub);
     for (hipEvent_t e : a->ev) if (e) (void)hipEventDestroy(e);
     delete a;
 }
@@ -163,10 +165,12 @@ struct AirJob {
     // optional: the merged evaluations of m coefficient sets in one pass over the frame (extension proofs); falls back to m calls
     int (*combine_sets)(cstark_ctx *, ProveArena *, AirJob &, unsigned m, const uint64_t *const *ta, const uint64_t *const *tb, const uint64_t *const *ba,
                         const uint64_t *const *bb, uint64_t *const *outs) = nullptr;
-    // Columns [0, late_cols) of the trace are still being written on an internal stream when build() returns (TransactionAir:
-    // the curve ladders); the prover commits the other columns first and waits for late_event before it touches these.
-    uint32_t late_cols = 0;
-    hipEvent_t late_event = nullptr;
+    // Optional: the order in which the trace columns become complete when build() returns with parts of the trace still being
+    // written on internal streams (TransactionAir).  The prover interpolates and extends batch after batch, waiting for a batch's
+    // events first; empty = all columns at once.
+    struct ColumnBatch { uint32_t col0, ncols; hipEvent_t wait[2]; };
+    std::vector<ColumnBatch> batches;
+    const uint64_t *pub_staging = nullptr; // pinned host copy of the public inputs, valid once every batch has been waited for
     bool evals_ready = false;       // sub-AIRs: the materialised transition evaluations of this proof are already in the arena
     uint64_t number = 0;            // RangeProofAir
 };
@@ -225,24 +229,26 @@ int check_options(const cstark_options *opt, unsigned *log_rem_out) {
 
 // Prover::prove for any of the AIRs.
 // Interpolation and extension of the trace columns; records the two stage events (after the interpolation, after the extension).
-// With late columns (AirJob::late_cols) the complete columns go first -- interpolated AND extended while the internal stream still
-// writes the late ones -- so the "interpolate" stage time then also holds the extension of the early columns.
+// With column batches (AirJob::batches) the complete columns go first -- interpolated AND extended while the internal streams still
+// write the later ones -- so the "interpolate" stage time then also holds the extension of the earlier batches.
 int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hipStream_t st, int &evi) {
-    const uint32_t W = job.width, log_n = job.log_n, b = 1u << log_b, late = job.late_cols;
+    const uint32_t W = job.width, log_n = job.log_n, b = 1u << log_b;
     const size_t n = (size_t)1 << log_n;
-    if (late == 0 || late >= W) {
+    if (job.batches.empty()) {
         RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, W, log_n));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
         RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, W, log_n, log_b, host::generator(), 0, b));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
         return CSTARK_OK;
     }
-    RC_TRY(cstark_interpolate_columns(c, a->trace + (size_t)late * n, a->coeffs + (size_t)late * n, W - late, log_n));
-    RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, late, W - late, log_n, log_b, host::generator(), 0, b));
-    HIP_TRY(hipStreamWaitEvent(st, job.late_event, 0));
-    RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, late, log_n));
-    HIP_TRY(hipEventRecord(a->ev[evi++], st));
-    RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, 0, late, log_n, log_b, host::generator(), 0, b));
+    for (size_t i = 0; i < job.batches.size(); i++) {
+        const AirJob::ColumnBatch &cb = job.batches[i];
+        for (hipEvent_t e : cb.wait)
+            if (e) HIP_TRY(hipStreamWaitEvent(st, e, 0));
+        RC_TRY(cstark_interpolate_columns(c, a->trace + (size_t)cb.col0 * n, a->coeffs + (size_t)cb.col0 * n, cb.ncols, log_n));
+        if (i + 1 == job.batches.size()) HIP_TRY(hipEventRecord(a->ev[evi++], st));
+        RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, cb.col0, cb.ncols, log_n, log_b, host::generator(), 0, b));
+    }
     HIP_TRY(hipEventRecord(a->ev[evi++], st));
     return CSTARK_OK;
 }
@@ -277,6 +283,7 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     HIP_TRY(hipMemcpyAsync(trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(hipStreamSynchronize(st)); // also completes the public-input copy of job.build
+    if (job.pub_staging) job.pub.assign(job.pub_staging, job.pub_staging + 14);
 
     // ---- channel ------------------------------------------------------------------------------------------------------------
     Coin coin;
@@ -477,12 +484,25 @@ int tx_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
     }
     RC_TRY(tx_build_trace_split(c, a->trace));
     if (mode == 2) {
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+        for (hipEvent_t e : {c->ev_join, c->ev_mid, c->ev_join2}) HIP_TRY(hipStreamWaitEvent(c->stream, e, 0));
         return gather_roots(c, a, job);
     }
-    job.late_cols = TX_LATE_COLS;
-    job.late_event = c->ev_join2;
-    return gather_roots(c, a, job);
+    // public inputs (tree roots in registers 58..64, written by the Merkle recurrence): gathered on its stream, before the event the
+    // second batch waits for, into pinned memory; collected after the commitment sync
+    const size_t n = (size_t)1 << job.log_n;
+    if (!a->h_pub) HIP_TRY(hipHostMalloc((void **)&a->h_pub, 14 * 8, hipHostMallocDefault));
+    k_gather_pub<<<1, 64, 0, c->side>>>(a->trace, n, (uint64_t *)a->d_open);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(a->h_pub, a->d_open, 14 * 8, hipMemcpyDeviceToHost, c->side));
+    HIP_TRY(hipEventRecord(c->ev_join, c->side));
+    job.pub_staging = a->h_pub;
+    if (mode == 3) // two batches: everything but the curve registers once the Merkle recurrence and the message hash are done
+        job.batches = {{TX_LATE_COLS, job.width - TX_LATE_COLS, {c->ev_join, c->ev_mid}}, {0, TX_LATE_COLS, {c->ev_join2, nullptr}}};
+    else
+        job.batches = {{TX_COPY_COLS, job.width - TX_COPY_COLS, {nullptr, nullptr}},
+                       {TX_LATE_COLS, TX_COPY_COLS - TX_LATE_COLS, {c->ev_join, c->ev_mid}},
+                       {0, TX_LATE_COLS, {c->ev_join2, nullptr}}};
+    return CSTARK_OK;
 }
 int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     cstark_tx_coeffs cf;
@@ -599,6 +619,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     HIP_TRY(hipMemcpyAsync(trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(hipStreamSynchronize(st));
+    if (job.pub_staging) job.pub.assign(job.pub_staging, job.pub_staging + 14);
 
     Coin coin;
     coin.hash_fn = hf;

@@ -17,10 +17,11 @@ struct TxWitnessDev {
 // `side` is a second stream used for the part of the trace that is independent of the rest; `fork`/`join` are events
 // owned by the caller (fork: stream -> side, join: side -> stream)
 hipError_t launch_trace_gen(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t join);
-// The same trace, with the curve ladders (registers 0..17, 19..36 of the Schnorr rows) on `side_b` and NOT joined: `join_b` is
-// recorded behind them.  `stream` returns with every other register complete (Merkle recurrence joined from `side_a`).
+// The same trace spread over three streams, nothing joined: `stream` gets the closed-form registers (k_trace_aux: 65..93 and the
+// bit / accumulator registers of the Schnorr rows); side_a the Merkle recurrence (join_a recorded behind it); side_b the message
+// hash (mid_b behind it: registers 42..55 and the scalar h) and then the curve ladders (join_b behind them).
 hipError_t launch_trace_gen_split(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream, hipStream_t side_a, hipStream_t side_b,
-                                  hipEvent_t fork, hipEvent_t join_a, hipEvent_t join_b);
+                                  hipEvent_t fork, hipEvent_t join_a, hipEvent_t mid_b, hipEvent_t join_b);
 
 // standalone sub-AIR traces
 hipError_t launch_merkle_trace(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream); // 65 x 512*n_tx

@@ -69,6 +69,7 @@ __device__ __forceinline__ void flush_tile(const fp (*tile)[LD], fp *__restrict_
 // STANDALONE: the 65-register, 512-rows-per-transaction trace of MerkleProver (src/merkle/update/prover.rs:28-80)
 template <bool STANDALONE>
 __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    __builtin_amdgcn_s_setprio(3); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
     __shared__ fp tile[64][65];
     __shared__ fp st[4][14];
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restr
 // ---------------------------------------------------------------------------------------------------
 template <bool STANDALONE>
 __global__ __launch_bounds__(64) void k_trace_schnorr_hash(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    __builtin_amdgcn_s_setprio(3); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
     __shared__ fp tile[64][15];
     __shared__ fp st[14];
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -353,6 +355,7 @@ __device__ __forceinline__ int bit_le(const uint8_t *bytes, int i) { return (byt
 // ladders run beside the interpolation / extension of the other registers (prove.hip commit_columns: 43.1 vs 43.8 ms per proof).
 template <bool STANDALONE, int TR>
 __global__ __launch_bounds__(64) void k_trace_schnorr_ec(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    __builtin_amdgcn_s_setprio(3); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
     constexpr int TG = 64 / TR; // column groups of a flush
     __shared__ fp tile[TR][19];
     __shared__ fp slots[NSLOT][6];
@@ -423,7 +426,11 @@ __global__ __launch_bounds__(64) void k_trace_schnorr_final(fp *__restrict__ tra
 // Closed-form registers.  grid = (n_tx, 4), block = 256: one lane per row.
 __device__ __forceinline__ fp small_to_fp(uint64_t x) { return fp_mul(x, FP_R2); } // x < p
 
+// WHICH: 0 = every closed-form register; 1 = those that need the witness only; 2 = those that need the message hash h
+// (register 37 and the h-limb accumulators 38..41), which k_trace_schnorr_hash leaves in w.h_limbs.
+template <int WHICH>
 __global__ __launch_bounds__(256) void k_trace_aux(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
+    constexpr bool PLAIN = WHICH != 2, WITH_H = WHICH != 1;
     const int t = blockIdx.x;
     const int r = blockIdx.y * 256 + threadIdx.x; // row inside the transaction
     const size_t g = (size_t)t * TXC + r;
@@ -431,22 +438,26 @@ __global__ __launch_bounds__(256) void k_trace_aux(TxWitnessDev w, fp *__restric
     const fp delta = w.deltas[t];
     const fp sigma = fp_sub(sv[12], delta);
     // copies: src/trace.rs:43-53 (constant over the whole transaction)
-    for (int i = 0; i < 12; i++) {
-        trace[(size_t)(65 + i) * n + g] = sv[i];
-        trace[(size_t)(77 + i) * n + g] = rv[i];
+    if (PLAIN) {
+        for (int i = 0; i < 12; i++) {
+            trace[(size_t)(65 + i) * n + g] = sv[i];
+            trace[(size_t)(77 + i) * n + g] = rv[i];
+        }
+        trace[(size_t)89 * n + g] = delta;
+        trace[(size_t)90 * n + g] = sigma;
+        trace[(size_t)91 * n + g] = sv[13];
     }
-    trace[(size_t)89 * n + g] = delta;
-    trace[(size_t)90 * n + g] = sigma;
-    trace[(size_t)91 * n + g] = sv[13];
     if (r < MERKLE_LEN) {
-        trace[(size_t)92 * n + g] = 0;
-        trace[(size_t)93 * n + g] = 0;
+        if (PLAIN) {
+            trace[(size_t)92 * n + g] = 0;
+            trace[(size_t)93 * n + g] = 0;
+        }
         return;
     }
     const int q = r - MERKLE_LEN; // q = 0 is the Schnorr init row; row q is produced by step q-1
     const uint64_t dv = fp_to_u64(delta), sg = fp_to_u64(sigma);
     // range accumulators, src/range/prover.rs:65-84: after k = min(q,64) steps acc = value >> (64-k)
-    {
+    if (PLAIN) {
         const int k = q < 64 ? q : 64;
         uint64_t dacc = k == 0 ? 0 : dv >> (64 - k), sacc = k == 0 ? 0 : sg >> (64 - k);
         trace[(size_t)56 * n + g] = (dacc & 1) ? FP_ONE : 0;
@@ -465,7 +476,8 @@ __global__ __launch_bounds__(256) void k_trace_aux(TxWitnessDev w, fp *__restric
         bh = ((h[bi >> 6] >> (bi & 63)) & 1) ? FP_ONE : 0;
         if (q == SCALAR_MUL_LEN + 1) bs = FP_ONE;
     }
-    trace[(size_t)18 * n + g] = bs;
+    if (PLAIN) trace[(size_t)18 * n + g] = bs;
+    if (!WITH_H) return;
     trace[(size_t)37 * n + g] = bh;
     // h-limb accumulators 38..41: k bits consumed MSB-first; chunk 0 = 63 bits into reg 41, then 64-bit chunks
     const int k = (q + 1) / 2 < 255 ? (q + 1) / 2 : 255;
@@ -499,28 +511,28 @@ hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stre
     hipLaunchKernelGGL(k_trace_schnorr_hash<false>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL((k_trace_schnorr_ec<false, 64>), dim3(2 * w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_final<false>, dim3(w.n_tx), dim3(64), 0, stream, d_trace, n);
-    hipLaunchKernelGGL(k_trace_aux, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_aux<0>, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
     if ((e = hipStreamWaitEvent(stream, join, 0)) != hipSuccess) return e;
     return hipGetLastError();
 }
 
 hipError_t launch_trace_gen_split(const TxWitnessDev &w, fp *d_trace, hipStream_t stream, hipStream_t side_a, hipStream_t side_b, hipEvent_t fork,
-                                  hipEvent_t join_a, hipEvent_t join_b) {
+                                  hipEvent_t join_a, hipEvent_t mid_b, hipEvent_t join_b) {
     const size_t n = (size_t)w.n_tx * TXC;
     hipError_t e;
     if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side_a, fork, 0)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(side_b, fork, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_trace_merkle<false>, dim3(w.n_tx), dim3(64), 0, side_a, w, d_trace, n);
     if ((e = hipEventRecord(join_a, side_a)) != hipSuccess) return e;
-    // the message hash produces the scalar h of the second ladder (w.h_limbs): the ladders start behind it
-    hipLaunchKernelGGL(k_trace_schnorr_hash<false>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
-    if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(side_b, fork, 0)) != hipSuccess) return e;
+    // the message hash produces the scalar h of the second ladder (w.h_limbs): the ladders run behind it
+    hipLaunchKernelGGL(k_trace_schnorr_hash<false>, dim3(w.n_tx), dim3(64), 0, side_b, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_aux<2>, dim3(w.n_tx, 4), dim3(256), 0, side_b, w, d_trace, n);
+    if ((e = hipEventRecord(mid_b, side_b)) != hipSuccess) return e;
     hipLaunchKernelGGL((k_trace_schnorr_ec<false, 16>), dim3(2 * w.n_tx), dim3(64), ladder_lds_pad(), side_b, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_final<false>, dim3(w.n_tx), dim3(64), 0, side_b, d_trace, n);
     if ((e = hipEventRecord(join_b, side_b)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace_aux, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
-    if ((e = hipStreamWaitEvent(stream, join_a, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_trace_aux<1>, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
     return hipGetLastError();
 }
 
