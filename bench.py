@@ -322,7 +322,13 @@ def main():
                            world, ", %d proofs in flight per GPU" % inflight if inflight > 1 else "")),
                        "trace": "%d x 2^%d" % (WIDTH, log_n)},
             "stage_ms": {s: round(v, 3) for s, v in stage_ms.items()},
-            "stage_gbs": {s: round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1) for s in (["interpolate", "lde", "constraints"] if prove_mode else stages)},
+            "stage_gbs": ({"trace+interpolate+lde": round((ab["trace_gen"] + ab["interpolate"] + ab["lde"]) / ((stage_ms["trace"] + stage_ms["interpolate"] + stage_ms["lde"]) * 1e-3) / 1e9, 1),
+                           "constraints": round(ab["constraints"] / (stage_ms["constraints"] * 1e-3) / 1e9, 1)} if prove_mode else
+                          {s: round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1) for s in stages}),
+            "stage_note": ("cstark_tx_prove overlaps trace generation with the transforms: 'trace' = launch of the closed-form registers, "
+                           "'interpolate' = registers 65..93 and 37..64 interpolated AND extended while the recurrences / curve ladders still run, "
+                           "then registers 0..36 interpolated, 'lde' = their extension; the three add up to the time to the complete extended trace "
+                           "(include/cstark.h, cstark_prove_stage_ms)") if prove_mode else None,
             "constraint_part_ms": {k: round(v, 3) for k, v in part_avg.items()},
             "roofline": {"bound": "hbm", "kernel": "k_eval_fused<0> (Rescue windows of the constraint evaluation)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
