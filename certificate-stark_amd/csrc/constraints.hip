@@ -558,8 +558,9 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
         const RoundWindow w = c_windows[wdx];
         // register budget (168 VGPRs at 3 waves per SIMD): the 14 round constants of the inverse half are re-read per window
         // from LDS (their extension has period 8 in j: 8 x 14 values per workgroup) and the cubes of the forward half are
-        // formed after the inverse half, not before
-        // the window's cells arrive by LDS-DMA (issued during the previous window's forward half)
+        // formed after the inverse half, not before.
+        // The window's cells arrive by LDS-DMA (issued during the previous window's forward half); the DMA is the only vector
+        // memory operation of the loop (tables: scalar loads or LDS), so this wait concerns nothing else.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         fp d[14];
 #pragma unroll
