@@ -568,8 +568,10 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
         // inverse half: cube(INV_MDS (next - ark2))_i against the coefficients of both flag sets.  Default: limb dot products on
         // the vector ALU.  With -DCS_ROUNDS_MFMA the 14x14 product runs on the matrix cores for the 64 points of the wave
         // (mds_mfma.cuh; the staging image is private to the wave, whose LDS operations execute in order, so no workgroup
-        // barrier is involved) -- bit-identical, and measured at the SAME kernel time on MI355X this round (6.65 ms): the
-        // recombination of the byte diagonals and the serialisation of MFMA and dependent VALU work inside a wave eat the gain.
+        // barrier is involved) -- bit-identical, and measured at the SAME kernel time on MI355X as the limb products when both staged
+        // their rows through registers (6.65 ms): the recombination of the byte diagonals and the serialisation of MFMA and dependent
+        // VALU work inside a wave eat the gain.  Since the LDS-DMA window images the variant is slower (9.1 vs 5.8 ms): its tables and
+        // staging images no longer fit beside them at three workgroups per CU.
 #ifdef CS_ROUNDS_MFMA
         fp yv[14];
         {
