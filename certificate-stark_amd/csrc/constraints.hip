@@ -705,6 +705,8 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused<M> &acc, const Fram
     acc.begin();
     acc.term(base + 14, c_is_binary(bit));
     acc.end(tx_hash);
+    // (Current and next row of a column from ONE load -- next = DPP wave shift of the neighbour's current row, lane 63 fetching its
+    // own -- was measured slower, 1.84 vs 1.69 ms: the exec-masked edge loads cost more than the saved traffic.)
     // Two sections accumulated side by side.  One pass over i = 0..6 touches every cell of the two Rescue states exactly once
     // (the current and next row of a column are loaded back to back, so the second load is served from cache; the earlier
     // form walked the columns three times and moved 2.7x the algorithmic bytes -- this part is bandwidth-bound):
