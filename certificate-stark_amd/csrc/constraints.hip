@@ -706,7 +706,10 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused<M> &acc, const Fram
     acc.term(base + 14, c_is_binary(bit));
     acc.end(tx_hash);
     // (Current and next row of a column from ONE load -- next = DPP wave shift of the neighbour's current row, lane 63 fetching its
-    // own -- was measured slower, 1.84 vs 1.69 ms: the exec-masked edge loads cost more than the saved traffic.)
+    // own -- was measured slower, 1.84 vs 1.69 ms: the exec-masked edge loads cost more than the saved traffic.  Fetching each
+    // step's 4-5 columns once by LDS-DMA into wave-private images, as the Rescue-window part does, was bit-identical and no
+    // faster either: 1.73 ms with one step per batch, 2.09 / 2.37 ms with two / three (LDS footprint -> occupancy).  This part is
+    // bound by request latency x bytes in flight per CU, not by the byte count.)
     // Two sections accumulated side by side.  One pass over i = 0..6 touches every cell of the two Rescue states exactly once
     // (the current and next row of a column are loaded back to back, so the second load is served from cache; the earlier
     // form walked the columns three times and moved 2.7x the algorithmic bytes -- this part is bandwidth-bound):
