@@ -165,6 +165,7 @@ int get_periodic(cstark_ctx *c, unsigned depth, unsigned log_n, unsigned log_b, 
 int ce_params(cstark_ctx *c, const uint64_t *d_lde, uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0,
               uint32_t nk, cs::CeParams *p) {
     if (!c || !d_lde || !d_out) return fail(CSTARK_ERR_INVALID_ARG, "constraint evaluation: null argument");
+    if (((uintptr_t)d_lde & 15) != 0) return fail(CSTARK_ERR_INVALID_ARG, "constraint evaluation: d_lde must be 16-byte aligned (16-byte LDS-DMA pieces)");
     if (log_n < 10 || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_INVALID_ARG, "trace length must be 2^10 .. 2^24");
     if (log_blowup != 3) return fail(CSTARK_ERR_UNSUPPORTED, "TransactionAir needs a constraint-evaluation blowup of 8 (max degree 7, src/air.rs:76-108)");
     if ((uint64_t)k0 + nk > (1ull << log_blowup) || nk == 0) return fail(CSTARK_ERR_INVALID_ARG, "coset range exceeds the blowup factor");

@@ -152,7 +152,7 @@ int cstark_hash_rows_fn(cstark_ctx *ctx, uint32_t hash_fn, const uint64_t *d_lde
 int cstark_merkle_build_fn(cstark_ctx *ctx, uint32_t hash_fn, uint8_t *d_nodes, uint32_t log_leaves);
 
 /* ---- K6/K7: constraint evaluation (Air::evaluate_transition, src/air.rs:114-173, + driver) --- */
-/* d_lde: cosets [k0,k0+nk) of the extended 94-column trace, coset-major as cstark_lde_columns writes them.
+/* d_lde: cosets [k0,k0+nk) of the extended 94-column trace, coset-major as cstark_lde_columns writes them; 16-byte aligned.
  * merkle_depth selects the mask columns (src/merkle/constants.rs:21-27).  log_blowup must be 3.
  *
  * All 115 transition-constraint values at every point:  d_out[((k - k0) * 115 + i) * n + j].

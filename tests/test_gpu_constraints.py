@@ -82,3 +82,16 @@ def test_coefficient_set_count_is_checked(backend):
     from oracle import oracle as O
     with pytest.raises(CstarkError):
         backend.evaluate_constraints_ext(lde, [O.make_coeffs(1)] * 4, [0, 0, 0, 0], 3)
+
+
+def test_misaligned_lde_is_refused(backend):
+    """The Rescue-window kernel moves 16-byte pieces by LDS-DMA: an LDE base that is only 8-byte aligned is an argument error."""
+    import ctypes as C
+    from certificate_stark_amd._lib import CstarkError
+    from oracle import oracle as O
+    buf = backend.empty_u64(94 * 1024 + 1)
+    buf.zero_()
+    lde = buf[1:].view(1, 94, 1024)
+    assert lde.data_ptr() % 16 == 8
+    with pytest.raises(CstarkError):
+        backend.evaluate_constraints(lde, O.make_coeffs(1), [0, 0, 0, 0], 3)
