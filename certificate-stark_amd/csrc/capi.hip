@@ -84,6 +84,7 @@ int interpolate_impl(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint3
     return CSTARK_OK;
 }
 
+constexpr size_t LDE_BATCH_WS_BYTES = (size_t)1 << 30; // batched-coset launches when their intermediate is at most this large
 constexpr uint32_t LDE_COLUMN_GROUP = 1u << 30; // columns per group of the LDE (see lde_impl); 2^30 = all columns at once
 int lde_impl(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n, uint32_t log_blowup,
              uint64_t domain_offset, uint32_t k0, uint32_t nk) {
@@ -104,6 +105,18 @@ int lde_impl(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t 
     // multiplications (11 per element for 20 butterfly levels), not by HBM, so the default stays one launch pair per coset.
     static const uint32_t group_env = [] { const char *e = getenv("CSTARK_NTT_GROUP"); return e ? (uint32_t)atoi(e) : 0u; }();
     const uint32_t group = group_env ? group_env : LDE_COLUMN_GROUP;
+    // narrow tables (composition columns, periodic columns): all cosets in one launch pair -- the grid's batch dimension -- when the
+    // intermediate of every coset fits the workspace budget; 2 launches of nk x the workgroups instead of 2 nk small ones
+    if (!group_env && nk > 1 && (size_t)nk * ncols * n * 8 <= LDE_BATCH_WS_BYTES) {
+        RC_TRY(ensure_ws(c, (size_t)nk * ncols * n * 8));
+        cs::NttArgs a{};
+        a.in = d_coeffs + (size_t)col0 * n; a.scratch = (uint64_t *)c->ws; a.out = d_lde + (size_t)col0 * n;
+        a.width = ncols; a.batch = nk; a.log_n = log_n;
+        a.w = p->w; a.prescale = t->s + (size_t)k0 * n; a.prescale_batch_stride = n; a.do_scale = false;
+        a.in_batch_stride = 0; a.scratch_batch_stride = (size_t)ncols * n; a.out_batch_stride = (size_t)width * n;
+        HIP_TRY(cs::ntt_columns(a, c->stream));
+        return CSTARK_OK;
+    }
     for (uint32_t g0 = col0; g0 < col0 + ncols; g0 += group) {
         const uint32_t gw = col0 + ncols - g0 < group ? col0 + ncols - g0 : group;
         for (uint32_t k = k0; k < k0 + nk; k++) {
