@@ -359,6 +359,22 @@ int cstark_composition_columns(cstark_ctx *c, const uint64_t *d_combined, uint64
     const size_t N = (size_t)1 << (log_n + log_blowup);
     RC_TRY(ensure_ws(c, 2 * N * 8));
     uint64_t *nat = (uint64_t *)c->ws, *h = nat + N;
+    if (log_blowup <= 3) {
+        // The evaluation domain is the union of b cosets of the n-point domain and the table is coset-major: b interpolations of
+        // size n (the register-tiled kernels, cosets as columns), then per row a twist and a b-point inverse DFT across the cosets
+        // -- instead of a transposition and one transform of size b n.  Same coefficients (exact arithmetic).
+        const NttPlan *pn, *pN;
+        RC_TRY(get_plan(c, log_n, &pn));
+        RC_TRY(get_plan(c, log_n + log_blowup, &pN));
+        cs::NttArgs a{};
+        a.in = d_combined; a.scratch = h; a.out = nat; a.width = 1u << log_blowup; a.batch = 1; a.log_n = log_n;
+        a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true;
+        HIP_TRY(cs::ntt_columns(a, c->stream));
+        const uint64_t b_inv = cs::host::inv(cs::host::from_u64(1ull << log_blowup));
+        HIP_TRY(cs::coset_combine(nat, h, log_n, log_blowup, pN->winv, b_inv, c->stream));
+        HIP_TRY(cs::split_columns(h, d_cols, log_n, log_blowup, cs::host::inv(cs::host::generator()), c->stream));
+        return CSTARK_OK;
+    }
     HIP_TRY(cs::interleave_cosets(d_combined, nat, log_n, log_blowup, c->stream));
     // interpolate over the whole evaluation domain (offset handled by the g^-m scaling of the split)
     const NttPlan *p;

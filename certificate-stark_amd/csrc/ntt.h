@@ -29,6 +29,11 @@ hipError_t ntt_power_table(uint64_t *d_table, size_t n, uint64_t base, hipStream
 
 // composition-polynomial helpers: coset-major -> natural order; split of H's coefficients into b columns (with the g^-m scaling)
 hipError_t interleave_cosets(const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned log_b, hipStream_t stream);
+// Second half of the interpolation over the whole b n-point domain from per-coset interpolants (B cosets = 2^log_b <= 8):
+// d_b [B][n] = iNTT_n of every coset of a coset-major table; d_h [B n] = coefficients a_t in natural order.  With t = q + n i:
+//   a_{q + n i} = (1 / B) sum_k w_B^(-k i) (w_N^(-k q) B_k[q]),   N = B n;  winv_N = powers of w_N^-1.
+hipError_t coset_combine(const uint64_t *d_b, uint64_t *d_h, unsigned log_n, unsigned log_b, const uint64_t *d_winv_N, uint64_t b_inv,
+                         hipStream_t stream);
 hipError_t split_columns(const uint64_t *d_h, uint64_t *d_out, unsigned log_n, unsigned log_b, uint64_t ginv, hipStream_t stream);
 
 } // namespace cs

@@ -371,6 +371,41 @@ hipError_t interleave_cosets(const fp *d_in, fp *d_out, unsigned log_n, unsigned
     return hipGetLastError();
 }
 
+// one thread per q: the B values of row q across the cosets, twisted and put through a B-point inverse DFT (B <= 8: B^2 products)
+template <int LOGB>
+__global__ __launch_bounds__(256) void k_coset_combine(const fp *__restrict__ in, fp *__restrict__ out, size_t n, const fp *__restrict__ winv, fp b_inv) {
+    constexpr int B = 1 << LOGB;
+    const size_t q = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (q >= n) return;
+    fp v[B], wb[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        wb[k] = winv[(size_t)k * n];                                   // w_B^-k
+        const fp x = in[(size_t)k * n + q];
+        v[k] = k == 0 ? fp_mul(x, b_inv) : fp_mul(fp_mul(x, b_inv), winv[(size_t)k * q]); // (1 / B) w_N^(-k q) B_k[q]
+    }
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        Acc128 a = acc_zero();
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+            acc_mad(a, v[k], wb[(k * i) & (B - 1)]);
+            if (k == 6) acc_fold(a);
+        }
+        acc_fold(a);
+        out[(size_t)i * n + q] = acc_reduce(a);
+    }
+}
+hipError_t coset_combine(const fp *d_b, fp *d_h, unsigned log_n, unsigned log_b, const fp *d_winv_N, fp b_inv, hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (log_b == 1) hipLaunchKernelGGL(k_coset_combine<1>, grid, block, 0, stream, d_b, d_h, n, d_winv_N, b_inv);
+    else if (log_b == 2) hipLaunchKernelGGL(k_coset_combine<2>, grid, block, 0, stream, d_b, d_h, n, d_winv_N, b_inv);
+    else if (log_b == 3) hipLaunchKernelGGL(k_coset_combine<3>, grid, block, 0, stream, d_b, d_h, n, d_winv_N, b_inv);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t ntt_power_table(fp *d_table, size_t n, fp base, hipStream_t stream) {
     const size_t threads = (n + CHUNK - 1) / CHUNK;
     hipLaunchKernelGGL(k_power_table, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, d_table, n, base);
