@@ -478,9 +478,12 @@ int cstark_evaluate_polys_at_ext(cstark_ctx *c, const uint64_t *d_coeffs, uint32
     HIP_TRY(hipStreamSynchronize(c->stream));
     return CSTARK_OK;
 }
-int cstark_deep_composition_ext(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
+} // extern "C"
+// internal (ctx.h): the first nk cosets only, d_out = [m][nk][n]
+int deep_composition_ext_cosets(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
                                 const uint64_t *z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
-                                const uint64_t *delta, const uint64_t *deg_a, const uint64_t *deg_b, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup) {
+                                const uint64_t *delta, const uint64_t *deg_a, const uint64_t *deg_b, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup,
+                                uint32_t nk) {
     if (!c || !d_trace_lde || !d_comp_lde || !z || !ood_trace || !ood_comp || !alpha || !beta || !delta || !deg_a || !deg_b || !d_out || width == 0 || n_comp == 0 ||
         (m != 2 && m != 3))
         return fail(CSTARK_ERR_INVALID_ARG, "cstark_deep_composition_ext: bad argument");
@@ -519,8 +522,18 @@ int cstark_deep_composition_ext(cstark_ctx *c, const uint64_t *d_trace_lde, cons
         p.k1[q] = k1.c[q]; p.k2[q] = k2.c[q]; p.k3[q] = k3.c[q];
     }
     p.width = width; p.nb = n_comp; p.log_n = log_n; p.log_b = log_blowup; p.m = m;
+    if (nk > b) return fail(CSTARK_ERR_INVALID_ARG, "coset range exceeds the blowup factor");
+    p.nk = nk == b ? 0 : nk;
     HIP_TRY(cs::deep_composition_ext(p, c->stream));
     return CSTARK_OK;
+}
+extern "C" {
+int cstark_deep_composition_ext(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
+                                const uint64_t *z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
+                                const uint64_t *delta, const uint64_t *deg_a, const uint64_t *deg_b, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup) {
+    if (log_blowup > 6) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
+    return deep_composition_ext_cosets(c, d_trace_lde, d_comp_lde, width, n_comp, m, z, ood_trace, ood_comp, alpha, beta, delta, deg_a, deg_b, d_out, log_n,
+                                       log_blowup, 1u << log_blowup);
 }
 int cstark_fri_fold4_ext(cstark_ctx *c, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, uint32_t m, const uint64_t *alpha) {
     if (!c || !d_evals || !d_out || !alpha || d_evals == d_out || (m != 2 && m != 3)) return fail(CSTARK_ERR_INVALID_ARG, "cstark_fri_fold4_ext: bad argument");

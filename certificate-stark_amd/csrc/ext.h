@@ -20,6 +20,7 @@ struct DeepExtParams {
     uint64_t z[3], zw[3], zb[3], deg_a[3], deg_b[3];
     uint64_t k1[3], k2[3], k3[3];         // sum alpha_c T_c(z), sum beta_c T_c(z w), sum delta_i H_i(z^nb)
     uint32_t width, nb, log_n, log_b, m;
+    uint32_t nk;                          // cosets to evaluate (the first nk; 0 = all b): out is then [m][nk][n]
 };
 hipError_t deep_composition_ext(const DeepExtParams &p, hipStream_t stream);
 // evals [m][N] component-major over offset * <w_N> -> [m][N/4]

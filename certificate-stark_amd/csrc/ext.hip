@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_deep_ext(DeepExtParams p) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
     if (j >= n) return;
-    const unsigned k = blockIdx.y, b = 1u << p.log_b;
+    const unsigned k = blockIdx.y, b = p.nk ? p.nk : 1u << p.log_b; // b: cosets in the output
     const fp x = fp_mul(p.shifts[k], p.w[j]);
     // the three divisors with one base-field inversion
     const XInv<M> q1 = x_inv_parts(x, p.z, (Ext<M> *)nullptr), q2 = x_inv_parts(x, p.zw, (Ext<M> *)nullptr), q3 = x_inv_parts(x, p.zb, (Ext<M> *)nullptr);
@@ -177,7 +177,7 @@ hipError_t poly_eval_ext(const uint64_t *d_coeffs, unsigned width, unsigned log_
 }
 hipError_t deep_composition_ext(const DeepExtParams &p, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    const dim3 grid((unsigned)((n + 255) / 256), 1u << p.log_b);
+    const dim3 grid((unsigned)((n + 255) / 256), p.nk ? p.nk : 1u << p.log_b);
     if (p.m == 2) hipLaunchKernelGGL(k_deep_ext<2>, grid, dim3(256), 0, stream, p);
     else if (p.m == 3) hipLaunchKernelGGL(k_deep_ext<3>, grid, dim3(256), 0, stream, p);
     else return hipErrorInvalidValue;

@@ -146,6 +146,14 @@ int dev_alloc(ProveArena *a, T **p, size_t bytes) {
     return CSTARK_OK;
 }
 
+template <class T>
+int arena_extra(ProveArena *a, size_t slot, T **p, size_t bytes) {
+    if (a->extra.size() <= slot) a->extra.resize(slot + 1, nullptr);
+    if (!a->extra[slot]) { void *q; HIP_TRY(hipMalloc(&q, bytes)); a->owned.push_back(q); a->extra[slot] = q; }
+    *p = (T *)a->extra[slot];
+    return CSTARK_OK;
+}
+
 unsigned num_fri_layers(unsigned log_domain, unsigned log_max_remainder) {
     unsigned l = 0;
     while (log_domain > log_max_remainder) { log_domain -= 2; l++; }
@@ -342,8 +350,17 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     for (size_t i = 0; i < W; i++) { d_alpha[i] = coin.draw(); d_beta[i] = coin.draw(); (void)coin.draw(); /* conjugate term, extension fields only */ }
     for (size_t i = 0; i < ce; i++) d_delta[i] = coin.draw();
     const uint64_t deg_a = coin.draw(), deg_b = coin.draw();
-    RC_TRY(cstark_deep_composition(c, a->lde, a->clde, (uint32_t)W, (uint32_t)ce, z, ood_trace.data(), ood_comp.data(), d_alpha.data(), d_beta.data(),
-                                   d_delta.data(), deg_a, deg_b, a->deep, log_n, log_b, 0, (uint32_t)b));
+    // The DEEP composition polynomial has degree < n (quotients of degree n - 2 times the linear degree adjustment): its values on
+    // ONE coset determine it.  Evaluate the quotient sums on coset 0 only (1/8 of the extended trace read), interpolate there (the
+    // coefficients of P(g y)) and extend to all cosets with offset 1 -- the same values as evaluating the sums at every point.
+    {
+        uint64_t *dcoef;
+        RC_TRY(arena_extra(a, 40, &dcoef, n * 8));
+        RC_TRY(cstark_deep_composition(c, a->lde, a->clde, (uint32_t)W, (uint32_t)ce, z, ood_trace.data(), ood_comp.data(), d_alpha.data(),
+                                       d_beta.data(), d_delta.data(), deg_a, deg_b, a->deep, log_n, log_b, 0, 1));
+        RC_TRY(cstark_interpolate_columns(c, a->deep, dcoef, 1, log_n));
+        RC_TRY(cstark_lde_columns(c, dcoef, a->deep, 1, log_n, log_b, host::from_u64(1), 0, (uint32_t)b));
+    }
     RC_TRY(cstark_interleave_cosets(c, a->deep, a->layer[0], log_n, log_b));
     STAGE();
 
@@ -461,13 +478,6 @@ int gather_roots(cstark_ctx *c, ProveArena *a, AirJob &job) {
     HIP_TRY(hipGetLastError());
     job.pub.assign(14, 0);
     HIP_TRY(hipMemcpyAsync(job.pub.data(), a->d_open, 14 * 8, hipMemcpyDeviceToHost, c->stream)); // complete at the commitment sync
-    return CSTARK_OK;
-}
-template <class T>
-int arena_extra(ProveArena *a, size_t slot, T **p, size_t bytes) {
-    if (a->extra.size() <= slot) a->extra.resize(slot + 1, nullptr);
-    if (!a->extra[slot]) { void *q; HIP_TRY(hipMalloc(&q, bytes)); a->owned.push_back(q); a->extra[slot] = q; }
-    *p = (T *)a->extra[slot];
     return CSTARK_OK;
 }
 
@@ -706,9 +716,18 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     }
     for (size_t i = 0; i < ce; i++) { const EX dl = draw_e(); for (unsigned q = 0; q < m; q++) d_delta[m * i + q] = dl.c[q]; }
     const EX dga = draw_e(), dgb = draw_e();
-    RC_TRY(cstark_deep_composition_ext(c, a->lde, cldes, (uint32_t)W, (uint32_t)ce, m, z.c, ood_trace.data(), ood_comp.data(), d_alpha.data(), d_beta.data(),
-                                       d_delta.data(), dga.c, dgb.c, deepx, log_n, log_b));
-    for (unsigned q = 0; q < m; q++) RC_TRY(cstark_interleave_cosets(c, deepx + q * N, layer[0] + q * N, log_n, log_b));
+    {   // degree < n in every component: coset 0 only, then interpolation and extension per component (see prove_core)
+        uint64_t *dev0, *dcoef;
+        RC_TRY(arena_extra(a, 40, &dev0, 3 * n * 8));
+        RC_TRY(arena_extra(a, 41, &dcoef, 3 * n * 8));
+        RC_TRY(deep_composition_ext_cosets(c, a->lde, cldes, (uint32_t)W, (uint32_t)ce, m, z.c, ood_trace.data(), ood_comp.data(), d_alpha.data(),
+                                           d_beta.data(), d_delta.data(), dga.c, dgb.c, dev0, log_n, log_b, 1));
+        RC_TRY(cstark_interpolate_columns(c, dev0, dcoef, m, log_n));
+        for (unsigned q = 0; q < m; q++) {
+            RC_TRY(cstark_lde_columns(c, dcoef + q * n, deepx + q * N, 1, log_n, log_b, from_u64(1), 0, (uint32_t)b));
+            RC_TRY(cstark_interleave_cosets(c, deepx + q * N, layer[0] + q * N, log_n, log_b));
+        }
+    }
     STAGE();
 
     std::vector<uint8_t> layer_roots(32 * (size_t)n_layers);
