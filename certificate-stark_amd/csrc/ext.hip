@@ -53,21 +53,43 @@ __device__ __forceinline__ XInv<3> x_inv_parts(fp x, const uint64_t *zc, Ext<3> 
 }
 
 constexpr int PE_SEG = 16384;
-// grid = (segments, width): Horner in z^256 over one segment of one column, extension accumulator, base coefficients
+// grid = (segments, width): one segment of one column at an extension point.  Lane t owns the coefficients t, t + 256, ... of the
+// segment: sum_k c[256 k + t] (z^256)^k is a dot product of BASE coefficients with the components of the powers (z^256)^k, which
+// are the same for every lane -- tabulated once per workgroup in LDS, M lazily accumulated base products per coefficient instead
+// of an extension multiplication (9 base products for M = 3).  The lane's sum is then moved into place by z^t and z^(segment start).
 template <int M>
 __global__ __launch_bounds__(256) void k_poly_eval_ext_partial(const fp *__restrict__ coeffs, size_t n, Ext<M> z, fp *__restrict__ partial, unsigned seg_len) {
     __shared__ Ext<M> part[256];
+    __shared__ fp pk[M][PE_SEG / 256];
+    __shared__ Ext<M> zseg;
     const unsigned segs = gridDim.x, seg = blockIdx.x, col = blockIdx.y, t = threadIdx.x;
     const fp *c = coeffs + (size_t)col * n + (size_t)seg * seg_len;
-    const Ext<M> z256 = x_pow(z, 256);
-    Ext<M> acc = x_zero<M>();
     const unsigned per = (seg_len + 255) / 256;
-    for (unsigned k = per; k-- > 0;) {
-        const fp v = k * 256 + t < seg_len ? c[(size_t)k * 256 + t] : 0;
-        acc = x_mul(acc, z256);
-        acc.c[0] = fp_add(acc.c[0], v);
+    {
+        const Ext<M> z256 = x_pow(z, 256);
+        if (t < per) {
+            const Ext<M> pw = x_pow(z256, t);
+#pragma unroll
+            for (int q = 0; q < M; q++) pk[q][t] = pw.c[q];
+        }
+        if (t == 255) zseg = x_pow(z, (uint64_t)seg * seg_len);
     }
-    part[t] = x_mul(acc, x_pow(z, (uint64_t)seg * seg_len + t));
+    __syncthreads();
+    Acc128 a[M];
+#pragma unroll
+    for (int q = 0; q < M; q++) a[q] = acc_zero();
+    for (unsigned k = 0; k < per; k++) {
+        const fp v = k * 256 + t < seg_len ? c[(size_t)k * 256 + t] : 0;
+#pragma unroll
+        for (int q = 0; q < M; q++) {
+            acc_mad(a[q], v, pk[q][k]);
+            if (k % 7 == 6) acc_fold(a[q]);
+        }
+    }
+    Ext<M> acc;
+#pragma unroll
+    for (int q = 0; q < M; q++) { acc_fold(a[q]); acc.c[q] = acc_reduce(a[q]); }
+    part[t] = x_mul(x_mul(acc, x_pow(z, t)), zseg);
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)t < s) part[t] = x_add(part[t], part[t + s]);
