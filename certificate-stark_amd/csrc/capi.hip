@@ -615,7 +615,8 @@ int tx_build_trace_split(cstark_ctx *c, uint64_t *d_trace) {
 // m coefficient sets over the same frame (the components of an extension-field proof): the constraint values are computed once.
 // (internal: declared in ctx.h for the prover)
 int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
-                                 uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+                                 uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
+                                 bool input_is_lde) {
     if (!coeffs || !pub_inputs || !d_outs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null argument");
     if (m < 1 || m > (uint32_t)cs::CE_MAX_SETS) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: 1..3 coefficient sets");
     for (uint32_t q = 1; q < m; q++)
@@ -632,7 +633,41 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
     p.m = m;
     for (uint32_t q = 1; q < m; q++) p.out_ext[q - 1] = d_outs[q];
     for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
-    HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, c->part_timing ? c->part_ev : nullptr));
+    static const bool split_env = [] { const char *e = getenv("CSTARK_ROUNDS_SPLIT"); return !e || atoi(e) != 0; }(); // tuning / debugging
+    hipEvent_t *pev = c->part_timing ? c->part_ev : nullptr;
+    // input_is_lde: d_lde is the extension of columns of degree < n (the prover's own table), which the split evaluation relies on;
+    // the public stage entry points evaluate every point directly and are exact for ANY table
+    if (split_env && input_is_lde && m == 1 && k0 == 0 && nk == 8) {
+        // Rescue windows on the even cosets only (their four merged polynomials have degree < 4n, constraints.hip k_rounds_split),
+        // interpolated over that 4n-point sub-domain and extended to the odd cosets by four-column transforms.
+        const size_t n = (size_t)1 << log_n;
+        const NttPlan *pn, *p4, *p8;
+        const CosetTable *t1;
+        RC_TRY(get_plan(c, log_n, &pn));
+        RC_TRY(get_plan(c, log_n + 2, &p4));
+        RC_TRY(get_plan(c, log_n + 3, &p8));
+        RC_TRY(get_coset_table(c, log_n, 3, cs::host::from_u64(1), &t1));
+        RC_TRY(ensure_ws(c, 80 * n * 8));
+        uint64_t *even = (uint64_t *)c->ws, *sa = even + 16 * n, *sb = sa + 16 * n, *sc = sb + 16 * n, *odd = sc + 16 * n;
+        if (pev) HIP_TRY(hipEventRecord(pev[0], c->stream));
+        HIP_TRY(cs::launch_rounds_setup(p, c->stream));
+        HIP_TRY(cs::launch_rounds_split(p, even, c->stream));
+        cs::NttArgs a{};
+        a.in = even; a.scratch = sa; a.out = sb; a.width = 16; a.batch = 1; a.log_n = log_n; // 4 polynomials x 4 cosets, per coset
+        a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true;
+        HIP_TRY(cs::ntt_columns(a, c->stream));
+        HIP_TRY(cs::coset_combine(sb, sa, log_n, 2, p4->winv, cs::host::inv(cs::host::from_u64(4)), c->stream, 4)); // sa = coefficients [4][4n]
+        HIP_TRY(cs::coset_spread_odd(sa, sb, log_n, 4, p8->w, c->stream));                                            // sb = [4 odd cosets][4][n]
+        cs::NttArgs f{};
+        f.in = sb; f.scratch = sc; f.out = odd; f.width = 4; f.batch = 4; f.log_n = log_n;
+        f.w = pn->w; f.prescale = t1->s + n; f.prescale_batch_stride = 2 * n; f.do_scale = false; f.inverse = false;
+        f.in_batch_stride = 4 * n; f.scratch_batch_stride = 4 * n; f.out_batch_stride = 4 * n;
+        HIP_TRY(cs::ntt_columns(f, c->stream));
+        HIP_TRY(cs::launch_rounds_finish(p, even, odd, c->stream));
+        HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev, true));
+    } else {
+        HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev));
+    }
     c->part_valid = c->part_timing;
     return CSTARK_OK;
 }
@@ -641,7 +676,7 @@ extern "C" {
 int cstark_tx_evaluate_constraints(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, const uint64_t pub_inputs[4],
                                    uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
     uint64_t *outs[1] = {d_out};
-    return tx_evaluate_constraints_sets(c, d_lde, coeffs, 1, pub_inputs, outs, merkle_depth, log_n, log_blowup, k0, nk);
+    return tx_evaluate_constraints_sets(c, d_lde, coeffs, 1, pub_inputs, outs, merkle_depth, log_n, log_blowup, k0, nk, false);
 }
 
 int cstark_tx_evaluate_constraints_ext(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
@@ -649,7 +684,7 @@ int cstark_tx_evaluate_constraints_ext(cstark_ctx *c, const uint64_t *d_lde, con
     if (!d_out || m < 1 || m > 3) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints_ext: bad argument");
     const size_t comp = (size_t)nk << log_n;
     uint64_t *outs[3] = {d_out, d_out + comp, d_out + 2 * comp};
-    return tx_evaluate_constraints_sets(c, d_lde, coeffs, m, pub_inputs, outs, merkle_depth, log_n, log_blowup, k0, nk);
+    return tx_evaluate_constraints_sets(c, d_lde, coeffs, m, pub_inputs, outs, merkle_depth, log_n, log_blowup, k0, nk, false);
 }
 
 // ---- standalone sub-AIRs -------------------------------------------------------------

@@ -15,7 +15,7 @@ __host__ __device__ constexpr int tx_degree_group(int i) {
 constexpr unsigned TX_GROUP_BASE[5] = {5, 4, 3, 2, 1};
 constexpr unsigned TX_GROUP_CYCLES[5] = {2, 2, 1, 1, 1};
 
-constexpr int CE_RTAB_WORDS = 8192;
+constexpr int CE_RTAB_WORDS = 12288;
 constexpr int CE_COEF_WORDS = 115 * 2 + 8; // one coefficient set: alpha[115] | beta[115] | b_alpha[4] | b_beta[4]
 constexpr int CE_MAX_SETS = 3;             // coefficient sets merged in one pass (the components of an extension proof)
 constexpr int CE_COSET_CONSTS = 8; // per coset: shift, 1/(shift^n - 1), shift^adj[0..5), shift^badj
@@ -64,7 +64,13 @@ hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, uns
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);
 constexpr int CE_NUM_PARTS = 9; // launches of the fused evaluation: rounds, dbl0, add0, dbl1, add1, final, lin_a, lin_b, lin_c
-hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events = nullptr);
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events = nullptr, bool rounds_done = false);
+// Split evaluation of the Rescue windows (m = 1, all 8 cosets, k0 = 0; constraints.hip): setup of the per-proof tables; the four
+// low-degree polynomials on the even cosets, d_even = [4][4][n]; recombination over all cosets from d_even and their extension to
+// the odd cosets d_odd = [4 cosets][4][n] (writes p.out, like the first part of launch_eval_constraints).
+hipError_t launch_rounds_setup(const CeParams &p, hipStream_t stream);
+hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t stream);
+hipError_t launch_rounds_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream);
 hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,
                                    hipStream_t stream);
 

@@ -480,7 +480,8 @@ constexpr int RT_SECTIONS = 5 * 2 * 4;                 // (window, flag set, {al
 // CeParams::rtab (u64 words): A[sections][64] | limbs of U[sections][14] (4 dwords each) | matrix-core table of INV_MDS
 constexpr int RT_A = 0, RT_UL = RT_SECTIONS * 64, RT_ML = RT_UL + RT_SECTIONS * 14 * 2, RT_MT = RT_ML + 14 * 14 * 2;
 constexpr size_t MT_BYTES = (mdsmfma::table_bytes(14) + 15) & ~(size_t)15;
-constexpr int RT_SIZE = RT_MT + (int)(MT_BYTES / 8);
+constexpr int RT_G = RT_MT + (int)(MT_BYTES / 8);       // the sections' coefficient vectors themselves (split evaluation)
+constexpr int RT_SIZE = RT_G + RT_SECTIONS * 14;
 static_assert(RT_SIZE <= CE_RTAB_WORDS, "rtab size");
 constexpr size_t ROUNDS_LDS = MT_BYTES + (FNT / 64) * 64 * mdsmfma::ROW_BYTES; // table + one staging image per wave
 #ifdef CS_ROUNDS_MFMA
@@ -512,6 +513,7 @@ __global__ void k_rounds_setup(const fp *__restrict__ coef, const fp *__restrict
     }
     __syncthreads();
     const int t = threadIdx.x;
+    if (t < 14) rtab[RT_G + sec * 14 + t] = gam[t];
     if (t < 14) {
         fp u = 0;
         for (int i = 0; i < 14; i++) u = fp_add(u, fp_mul(gam[i], c_mds[i * 14 + t]));
@@ -648,6 +650,123 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
             }
         }
     }
+}
+
+// =====================================================================================================
+// Split evaluation of the Rescue windows.  Every Rescue term flag(x) * (forward_i - inverse_i^3) is a polynomial of degree
+// <= 3 (n - 1) + (n - 1) < 4n (trace columns: degree < n; periodic flags and round constants: degree < n), whatever degree class its
+// result slot is declared in.  The merged contribution of the windows is therefore
+//     R_alpha(x) + sum_g x^adj_g R_beta,g(x),   R_alpha = sum_i alpha_i F_i,  R_beta,g = sum_{i in g} beta_i F_i   (g = 0, 1, 2)
+// with four polynomials of degree < 4n: they are evaluated on the 4n-point sub-domain of the even cosets only (half the work of
+// the windows), interpolated there, extended to the odd cosets by transforms of four columns (capi.hip), and recombined with
+// x^adj_g and the transition divisor at every point (k_rounds_finish).  Exact arithmetic: the same merged evaluations.
+// out = [4 polynomials][4 even cosets][n].  grid = (n / FNT, 4)
+__global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restrict__ out) {
+    __shared__ fp ark2_lds[8 * 14];
+    __shared__ __attribute__((aligned(16))) fp img_lds[(FNT / 64) * RW_IMG];
+    __shared__ fp atab_lds[RT_SECTIONS * 8];
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kc = blockIdx.y, kk = 2 * kc; // the launcher guarantees k0 = 0 and all cosets present
+    const Frame f = make_frame(p, kk, j);
+    if (threadIdx.x < 8 * 14) {
+        const unsigned r = threadIdx.x / 14, c = threadIdx.x % 14;
+        ark2_lds[threadIdx.x] = p.ptab[((size_t)kk * 48 + P_ARK + 14 + c) * 1024 + ((blockIdx.x * (size_t)FNT + r) & 1023)];
+    }
+    for (unsigned e = threadIdx.x; e < RT_SECTIONS * 8; e += FNT) atab_lds[e] = p.rtab[RT_A + (e >> 3) * 64 + kk * 8 + (e & 7)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const unsigned jr = (unsigned)(j & 7);
+    fp *img = img_lds + (threadIdx.x >> 6) * RW_IMG;
+    const fp *ark2 = ark2_lds + jr * 14, *atab = atab_lds + jr;
+    const fp flags[4] = {f.pv(P_SETUP), f.pv(P_HASH), f.pv(P_SCHNORR_HASH), fp_add(f.pv(P_SETUP), f.pv(P_HASH))};
+    const CS_CONST uint32_t *ul = as_const((const uint32_t *)(p.rtab + RT_UL)), *ml = as_const((const uint32_t *)(p.rtab + RT_ML));
+    const CS_CONST fp *gt = as_const((const fp *)(p.rtab + RT_G));
+    const fp *colbase = p.lde + (size_t)kk * 94 * n;
+    const fp *rows = f.cur_p + lane;
+    if (lane == 32 && ((size_t)(f.cur_p - lane + 64 - colbase) & (n - 1)) == 0) rows -= n;
+    rounds_fetch_window(rows, n, c_windows[0].reg, lane, img);
+    fp tot[4] = {0, 0, 0, 0}; // R_alpha, R_beta of groups 0, 1, 2
+#pragma unroll 1
+    for (int wdx = 0; wdx < 5; wdx++) {
+        const RoundWindow w = c_windows[wdx];
+        const int g0[2] = {c_window_groups[wdx][0][0], c_window_groups[wdx][1][0]}, g1[2] = {c_window_groups[wdx][0][1], c_window_groups[wdx][1][1]},
+                  g2[2] = {c_window_groups[wdx][0][2], c_window_groups[wdx][1][2]};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fp d[14];
+#pragma unroll
+        for (int jj = 0; jj < 14; jj++) d[jj] = fp_sub(img[jj * RW_ROWS + lane + 1], ark2[jj]);
+        // inverse half: cube(INV_MDS d)_i against the coefficient vector of every section (alpha, beta of each group present)
+        Acc128 s[2][4];
+#pragma unroll
+        for (int fs = 0; fs < 2; fs++)
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) s[fs][sl] = acc_zero();
+#pragma unroll 1
+        for (int i = 0; i < 14; i++) {
+            const fp s2 = fp_cube(dot14l(ml + i * 56, d));
+#pragma unroll
+            for (int fs = 0; fs < 2; fs++) {
+                if (fs == 1 && w.flag_b < 0) continue;
+                const CS_CONST fp *gs = gt + (wdx * 2 + fs) * 4 * 14 + i;
+                acc_mad(s[fs][0], gs[0], s2);
+                if (g0[fs] >= 0) acc_mad(s[fs][1], gs[14], s2);
+                if (g1[fs] >= 0) acc_mad(s[fs][2], gs[28], s2);
+                if (g2[fs] >= 0) acc_mad(s[fs][3], gs[42], s2);
+                if (i == 6) {
+#pragma unroll
+                    for (int sl = 0; sl < 4; sl++) acc_fold(s[fs][sl]);
+                }
+            }
+        }
+        fp cube[14];
+#pragma unroll
+        for (int jj = 0; jj < 14; jj++) cube[jj] = fp_cube(img[jj * RW_ROWS + lane]);
+        if (wdx < 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            rounds_fetch_window(rows, n, c_windows[wdx + 1].reg, lane, img);
+        }
+#pragma unroll
+        for (int fs = 0; fs < 2; fs++) {
+            if (fs == 1 && w.flag_b < 0) continue;
+            const int sec = (wdx * 2 + fs) * 4;
+            const int fl = fs ? w.flag_b : w.flag_a;
+            const fp flag = fl == 0 ? flags[0] : fl == 1 ? flags[1] : fl == 2 ? flags[2] : flags[3];
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) {
+                const int g = sl == 0 ? -2 : sl == 1 ? g0[fs] : sl == 2 ? g1[fs] : g2[fs];
+                if (g == -1) continue;
+                acc_fold(s[fs][sl]);
+                const fp fwd = fp_add(dot14l(ul + (sec + sl) * 56, cube), atab[(sec + sl) * 8]);
+                const fp v = fp_mul(flag, fp_sub(acc_reduce(s[fs][sl]), fwd));
+                if (sl == 0) tot[0] = fp_add(tot[0], v);
+                else {
+                    if (g == 0) tot[1] = fp_add(tot[1], v);
+                    if (g == 1) tot[2] = fp_add(tot[2], v);
+                    if (g == 2) tot[3] = fp_add(tot[3], v);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) out[((size_t)q * 4 + kc) * n + j] = tot[q];
+}
+
+// grid = (n / 256, 8): out[k][j] = (R_alpha + sum_g x^adj_g R_beta,g) * (x - w^(n-1)) / (x^n - 1); the polynomials' values come from the
+// split evaluation (even cosets, [4][4][n]) or from their extension (odd cosets, [4 cosets][4][n])
+__global__ __launch_bounds__(256) void k_rounds_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    const unsigned k = blockIdx.y;
+    const fp *cc = p.coset + (size_t)k * CE_COSET_CONSTS;
+    const fp x = fp_mul(cc[0], p.w[j]);
+    fp r[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = (k & 1) ? odd[((size_t)(k >> 1) * 4 + q) * n + j] : even[((size_t)q * 4 + (k >> 1)) * n + j];
+    fp t = r[0];
+#pragma unroll
+    for (int g = 0; g < 3; g++) t = fp_add(t, fp_mul(r[1 + g], fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)])));
+    p.out[(size_t)k * n + j] = fp_mul(t, fp_mul(fp_sub(x, p.w_last), cc[1]));
 }
 
 // doubling gadget for the point at registers [reg, reg + 19)  (ecc.rs:73-98)
@@ -1161,17 +1280,40 @@ hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events) {
+hipError_t launch_rounds_setup(const CeParams &p, hipStream_t stream) {
+    const unsigned m = p.m ? p.m : 1;
+    if (m > 3) return hipErrorInvalidValue;
+    (void)hipMemsetAsync(p.rtab + RT_MT, 0, MT_BYTES, stream);
+    hipLaunchKernelGGL(k_rounds_setup, dim3(RT_SECTIONS + 14, m), dim3(64), 0, stream, p.coef, p.ptab, p.rtab);
+    return hipGetLastError();
+}
+hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    hipLaunchKernelGGL(k_rounds_split, dim3((unsigned)(n / FNT), 4), dim3(FNT), 0, stream, p, d_even);
+    return hipGetLastError();
+}
+hipError_t launch_rounds_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    hipLaunchKernelGGL(k_rounds_finish, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd);
+    return hipGetLastError();
+}
+
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events, bool rounds_done) {
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
     // part_events (optional, CE_NUM_PARTS + 1 events): recorded around every part so that callers can time each launch
-    (void)hipMemsetAsync(p.rtab + RT_MT, 0, MT_BYTES, stream);
     const unsigned m = p.m ? p.m : 1;
     if (m > 3) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_rounds_setup, dim3(RT_SECTIONS + 14, m), dim3(64), 0, stream, p.coef, p.ptab, p.rtab);
+    // rounds_done: the caller ran launch_rounds_setup and the split evaluation of the Rescue windows (and recorded part_events[0])
+    if (!rounds_done) {
+        const hipError_t e = launch_rounds_setup(p, stream);
+        if (e != hipSuccess) return e;
+    }
 #define CS_PART(PART)                                                                                                                   \
-    if (part_events) (void)hipEventRecord(part_events[PART], stream);                                                                   \
-    if (m == 1) {                                                                                                                       \
+    if (PART == PART_ROUNDS && rounds_done) {                                                                                           \
+    } else if (part_events) (void)hipEventRecord(part_events[PART], stream);                                                            \
+    if (PART == PART_ROUNDS && rounds_done) {                                                                                           \
+    } else if (m == 1) {                                                                                                                       \
         if (PART == PART_ROUNDS && ROUNDS_DYN_LDS)                                                                                      \
             (void)hipFuncSetAttribute((const void *)k_eval_fused<PART, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROUNDS_LDS); \
         hipLaunchKernelGGL((k_eval_fused<PART, 1>), grid, block, PART == PART_ROUNDS ? ROUNDS_DYN_LDS : 0, stream, p);                    \

@@ -81,8 +81,11 @@ struct cstark_ctx {
 
 // internal (capi.hip): merged TransactionAir constraint evaluations for m coefficient sets in one pass over the frame
 struct cstark_tx_coeffs;
+// input_is_lde: the table is the low-degree extension of columns of degree < n (true for the prover's own table): allows the split
+// evaluation of the Rescue windows on half of the cosets
 int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
-                                 uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+                                 uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
+                                 bool input_is_lde);
 // internal (capi.hip): TransactionAir trace spread over the context's streams, nothing joined.  In stream order `stream` holds
 // registers >= TX_COPY_COLS (closed forms); c->side: the Merkle recurrence, c->ev_join recorded behind it; c->side2: message hash
 // (c->ev_mid behind it), then the curve ladders (c->ev_join2 behind them).  Registers [TX_LATE_COLS, TX_COPY_COLS) are complete

@@ -519,7 +519,8 @@ int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, co
     memcpy(cf.t_alpha, ta, sizeof cf.t_alpha); memcpy(cf.t_beta, tb, sizeof cf.t_beta);
     memcpy(cf.b_alpha, ba, sizeof cf.b_alpha); memcpy(cf.b_beta, bb, sizeof cf.b_beta);
     const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]}; // get_assertions, src/air.rs:175-184
-    return cstark_tx_evaluate_constraints(c, a->lde, &cf, pub4, out, job.item, job.log_n, 3, 0, 8);
+    uint64_t *outs[1] = {out};
+    return tx_evaluate_constraints_sets(c, a->lde, &cf, 1, pub4, outs, job.item, job.log_n, 3, 0, 8, true);
 }
 int tx_combine_sets(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned m, const uint64_t *const *ta, const uint64_t *const *tb, const uint64_t *const *ba,
                     const uint64_t *const *bb, uint64_t *const *outs) {
@@ -529,7 +530,7 @@ int tx_combine_sets(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned m, const
         memcpy(cf[q].b_alpha, ba[q], sizeof cf[q].b_alpha); memcpy(cf[q].b_beta, bb[q], sizeof cf[q].b_beta);
     }
     const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]};
-    return tx_evaluate_constraints_sets(c, a->lde, cf, m, pub4, outs, job.item, job.log_n, 3, 0, 8);
+    return tx_evaluate_constraints_sets(c, a->lde, cf, m, pub4, outs, job.item, job.log_n, 3, 0, 8, true);
 }
 // ---- MerkleAir (src/merkle/update) ---------------------------------------------------------------------------------------------
 int merkle_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
