@@ -638,33 +638,43 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
     // input_is_lde: d_lde is the extension of columns of degree < n (the prover's own table), which the split evaluation relies on;
     // the public stage entry points evaluate every point directly and are exact for ANY table
     if (split_env && input_is_lde && m == 1 && k0 == 0 && nk == 8) {
-        // Rescue windows on the even cosets only (their four merged polynomials have degree < 4n, constraints.hip k_rounds_split),
-        // interpolated over that 4n-point sub-domain and extended to the odd cosets by four-column transforms.
+        // Parts whose merged polynomials have degree < 4n (constraints.hip: the Rescue windows with their flags; the doublings and the
+        // addition of the generator with the flag factored out) run on the even cosets only; their twelve polynomials are
+        // interpolated over that 4n-point sub-domain, extended to the odd cosets by transforms of twelve columns and recombined
+        // at every point.  (Part timing: the extension and the recombination are counted with the third of these parts.)
         const size_t n = (size_t)1 << log_n;
+        constexpr unsigned T = cs::CE_SPLIT_TABLES;
         const NttPlan *pn, *p4, *p8;
         const CosetTable *t1;
         RC_TRY(get_plan(c, log_n, &pn));
         RC_TRY(get_plan(c, log_n + 2, &p4));
         RC_TRY(get_plan(c, log_n + 3, &p8));
         RC_TRY(get_coset_table(c, log_n, 3, cs::host::from_u64(1), &t1));
-        RC_TRY(ensure_ws(c, 80 * n * 8));
-        uint64_t *even = (uint64_t *)c->ws, *sa = even + 16 * n, *sb = sa + 16 * n, *sc = sb + 16 * n, *odd = sc + 16 * n;
+        const size_t region = (size_t)T * 4 * n; // words per array of T x 4 columns
+        RC_TRY(ensure_ws(c, 5 * region * 8));
+        uint64_t *even = (uint64_t *)c->ws, *sa = even + region, *sb = sa + region, *sc = sb + region, *odd = sc + region;
         if (pev) HIP_TRY(hipEventRecord(pev[0], c->stream));
         HIP_TRY(cs::launch_rounds_setup(p, c->stream));
         HIP_TRY(cs::launch_rounds_split(p, even, c->stream));
+        if (pev) HIP_TRY(hipEventRecord(pev[1], c->stream));
+        HIP_TRY(cs::launch_ec_split(p, 1, even + 16 * n, c->stream)); // doubling family: tables 4..7
+        if (pev) HIP_TRY(hipEventRecord(pev[2], c->stream));
+        HIP_TRY(cs::launch_ec_split(p, 2, even + 32 * n, c->stream)); // addition family: tables 8..11
+        if (pev) HIP_TRY(hipEventRecord(pev[3], c->stream));
+        HIP_TRY(cs::launch_ec_split(p, 3, even + 16 * n, c->stream));
         cs::NttArgs a{};
-        a.in = even; a.scratch = sa; a.out = sb; a.width = 16; a.batch = 1; a.log_n = log_n; // 4 polynomials x 4 cosets, per coset
+        a.in = even; a.scratch = sa; a.out = sb; a.width = 4 * T; a.batch = 1; a.log_n = log_n; // every polynomial on every even coset
         a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true;
         HIP_TRY(cs::ntt_columns(a, c->stream));
-        HIP_TRY(cs::coset_combine(sb, sa, log_n, 2, p4->winv, cs::host::inv(cs::host::from_u64(4)), c->stream, 4)); // sa = coefficients [4][4n]
-        HIP_TRY(cs::coset_spread_odd(sa, sb, log_n, 4, p8->w, c->stream));                                            // sb = [4 odd cosets][4][n]
+        HIP_TRY(cs::coset_combine(sb, sa, log_n, 2, p4->winv, cs::host::inv(cs::host::from_u64(4)), c->stream, T)); // sa = coefficients [T][4n]
+        HIP_TRY(cs::coset_spread_odd(sa, sb, log_n, T, p8->w, c->stream));                                            // sb = [4 odd cosets][T][n]
         cs::NttArgs f{};
-        f.in = sb; f.scratch = sc; f.out = odd; f.width = 4; f.batch = 4; f.log_n = log_n;
+        f.in = sb; f.scratch = sc; f.out = odd; f.width = T; f.batch = 4; f.log_n = log_n;
         f.w = pn->w; f.prescale = t1->s + n; f.prescale_batch_stride = 2 * n; f.do_scale = false; f.inverse = false;
-        f.in_batch_stride = 4 * n; f.scratch_batch_stride = 4 * n; f.out_batch_stride = 4 * n;
+        f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
         HIP_TRY(cs::ntt_columns(f, c->stream));
-        HIP_TRY(cs::launch_rounds_finish(p, even, odd, c->stream));
-        HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev, true));
+        HIP_TRY(cs::launch_split_finish(p, even, odd, c->stream));
+        HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev, 0xFu)); // parts 0..3 done
     } else {
         HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev));
     }

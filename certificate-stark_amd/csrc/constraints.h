@@ -64,13 +64,17 @@ hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, uns
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);
 constexpr int CE_NUM_PARTS = 9; // launches of the fused evaluation: rounds, dbl0, add0, dbl1, add1, final, lin_a, lin_b, lin_c
-hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events = nullptr, bool rounds_done = false);
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events = nullptr, unsigned done_mask = 0);
 // Split evaluation of the Rescue windows (m = 1, all 8 cosets, k0 = 0; constraints.hip): setup of the per-proof tables; the four
 // low-degree polynomials on the even cosets, d_even = [4][4][n]; recombination over all cosets from d_even and their extension to
 // the odd cosets d_odd = [4 cosets][4][n] (writes p.out, like the first part of launch_eval_constraints).
 hipError_t launch_rounds_setup(const CeParams &p, hipStream_t stream);
 hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t stream);
-hipError_t launch_rounds_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream);
+// split evaluation of a curve gadget (part 1 = doubling of s*G, 2 = addition of G, 3 = doubling of h*P; 1 and 2 write their family's
+// four polynomials, 3 adds to the doubling family): d_even_family = [4][4][n]
+hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, hipStream_t stream);
+constexpr int CE_SPLIT_TABLES = 12; // Rescue windows | doubling | addition: four polynomials each
+hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream);
 hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,
                                    hipStream_t stream);
 

@@ -752,26 +752,43 @@ __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restr
     for (int q = 0; q < 4; q++) out[((size_t)q * 4 + kc) * n + j] = tot[q];
 }
 
-// grid = (n / 256, 8): out[k][j] = (R_alpha + sum_g x^adj_g R_beta,g) * (x - w^(n-1)) / (x^n - 1); the polynomials' values come from the
-// split evaluation (even cosets, [4][4][n]) or from their extension (odd cosets, [4 cosets][4][n])
-__global__ __launch_bounds__(256) void k_rounds_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd) {
+// grid = (n / 256, 8): out[k][j] = [ (R_a + sum_g x^adj_g R_b,g) + doubling(x) (D_a + sum_g x^adj_g D_b,g) + addition(x) (A_a + ...) ]
+//                                  * (x - w^(n-1)) / (x^n - 1).
+// The twelve polynomials' values come from the split evaluations (even cosets, [12][4][n]: Rescue windows, doubling, addition
+// families of four) or from their extension (odd cosets, [4 cosets][12][n]).
+constexpr int SPLIT_TABLES = 12;
+__global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
     const unsigned k = blockIdx.y;
     const fp *cc = p.coset + (size_t)k * CE_COSET_CONSTS;
     const fp x = fp_mul(cc[0], p.w[j]);
-    fp r[4];
+    fp xp[3];
 #pragma unroll
-    for (int q = 0; q < 4; q++) r[q] = (k & 1) ? odd[((size_t)(k >> 1) * 4 + q) * n + j] : even[((size_t)q * 4 + (k >> 1)) * n + j];
-    fp t = r[0];
+    for (int g = 0; g < 3; g++) xp[g] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
+    const fp *per = p.ptab + (size_t)k * 48 * 1024 + (j & 1023);
+    const fp doubling = per[(size_t)P_DOUBLING * 1024], scalar_mult = per[(size_t)P_SCALAR_MULT * 1024];
+    const fp fam_flag[3] = {FP_ONE, doubling, fp_mul(c_not(doubling), scalar_mult)};
+    fp total = 0;
 #pragma unroll
-    for (int g = 0; g < 3; g++) t = fp_add(t, fp_mul(r[1 + g], fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)])));
-    p.out[(size_t)k * n + j] = fp_mul(t, fp_mul(fp_sub(x, p.w_last), cc[1]));
+    for (int fam = 0; fam < 3; fam++) {
+        fp r[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int tb = fam * 4 + q;
+            r[q] = (k & 1) ? odd[((size_t)(k >> 1) * SPLIT_TABLES + tb) * n + j] : even[((size_t)tb * 4 + (k >> 1)) * n + j];
+        }
+        fp t = r[0];
+#pragma unroll
+        for (int g = 0; g < 3; g++) t = fp_add(t, fp_mul(r[1 + g], xp[g]));
+        total = fp_add(total, fam == 0 ? t : fp_mul(fam_flag[fam], t));
+    }
+    p.out[(size_t)k * n + j] = fp_mul(total, fp_mul(fp_sub(x, p.w_last), cc[1]));
 }
 
 // doubling gadget for the point at registers [reg, reg + 19)  (ecc.rs:73-98)
-template <int M>
-__device__ __forceinline__ void fused_doubling(Fused<M> &acc, const Frame &f, int reg, fp doubling) {
+template <class A>
+__device__ __forceinline__ void fused_doubling(A &acc, const Frame &f, int reg, fp doubling) {
     const Point p = {load6(f, reg, false), load6(f, reg + 6, false), load6(f, reg + 12, false)};
     const Point d = ec_double<CS_EC_CALL>(p);
     acc.begin();
@@ -786,8 +803,8 @@ __device__ __forceinline__ void fused_doubling(Fused<M> &acc, const Frame &f, in
 }
 // conditional mixed addition gadget (ecc.rs:102-138):
 //   next - (bit * (p+q) + (1-bit) * p)  =  (next - p) - bit * ((p+q) - p)
-template <int M>
-__device__ __forceinline__ void fused_addition(Fused<M> &acc, const Frame &f, int reg, const Fp6 &qx, const Fp6 &qy, fp addition) {
+template <class A>
+__device__ __forceinline__ void fused_addition(A &acc, const Frame &f, int reg, const Fp6 &qx, const Fp6 &qy, fp addition) {
     const Point p = {load6(f, reg, false), load6(f, reg + 6, false), load6(f, reg + 12, false)};
     const fp bit = f.cur(reg + 18);
     const Point a = ec_add_mixed<CS_EC_CALL>(p, qx, qy);
@@ -816,6 +833,61 @@ __device__ __forceinline__ void fused_final_addition(Fused<M> &acc, const Frame 
         acc.term(12 + i, fp_sub(f.next(12 + i), r.z.c[i]));
     }
     acc.end(final_add);
+}
+
+// ---- split evaluation of the curve gadgets whose terms have degree < 4n WITHOUT their flag ----------------------------------
+// Doubling: next - double(cur) has degree 4 (n - 1) in x (the complete doubling formulas are quartic in the coordinates); mixed
+// addition of the constant generator: (next - cur) - bit (add(cur, G) - cur) has degree 3 (n - 1) (the formulas are quadratic in
+// the coordinates when the second point is a constant).  With the periodic flag factored out of the section,
+//     flag(x) * [ S_alpha(x) + sum_g x^adj_g S_beta,g(x) ],   S_alpha = sum_i alpha_i term_i,  S_beta,g = sum_{i in g} beta_i term_i,
+// the S are polynomials of degree < 4n: evaluated on the even cosets only, extended like the Rescue-window polynomials and
+// multiplied by the flag at every point in k_split_finish.  (The addition of the public key and the final addition reach degree
+// 5 (n - 1) and stay on all eight cosets.)  Accumulator with the interface of Fused: slots of the curve registers are in groups 0..2.
+struct SplitAcc {
+    const CS_CONST fp *coefs; // alpha[115] | beta[115]
+    Acc128 sa, sb[3];
+    int ca, cb[3];
+    __device__ __forceinline__ void begin() {
+        sa = acc_zero(); ca = 0;
+#pragma unroll
+        for (int g = 0; g < 3; g++) { sb[g] = acc_zero(); cb[g] = 0; }
+    }
+    __device__ __forceinline__ void term(int i, fp v) { // i is a compile-time constant after unrolling
+        acc_mad(sa, coefs[i], v);
+        if (++ca == 7) { acc_fold(sa); ca = 0; }
+        const int g = tx_degree_group(i);
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            if (g == q) {
+                acc_mad(sb[q], coefs[115 + i], v);
+                if (++cb[q] == 7) { acc_fold(sb[q]); cb[q] = 0; }
+            }
+    }
+    __device__ __forceinline__ void end(fp) {}
+    __device__ __forceinline__ fp result(int q) { // 0: alpha, 1..3: beta of groups 0..2
+        Acc128 &a = q == 0 ? sa : sb[q == 0 ? 0 : q - 1];
+        acc_fold(a);
+        return acc_reduce(a);
+    }
+};
+// out = [4][4 even cosets][n] of this flag's family; ACCUMULATE: add to what an earlier part of the same family wrote.  grid = (n / FNT, 4)
+template <int PART, bool ACCUMULATE>
+__global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict__ out) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kc = blockIdx.y;
+    const Frame f = make_frame(p, 2 * kc, j); // the launcher guarantees k0 = 0 and all cosets present
+    SplitAcc acc;
+    acc.coefs = as_const(p.coef);
+    if (PART == PART_DBL0) fused_doubling(acc, f, 0, (fp)0);
+    if (PART == PART_DBL1) fused_doubling(acc, f, 19, (fp)0);
+    if (PART == PART_ADD0) fused_addition(acc, f, 0, const6(c_generator), const6(c_generator + 6), (fp)0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        fp *o = out + ((size_t)q * 4 + kc) * n + j;
+        const fp v = acc.result(q);
+        *o = ACCUMULATE ? fp_add(*o, v) : v;
+    }
 }
 
 template <int M>
@@ -1292,13 +1364,23 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
     hipLaunchKernelGGL(k_rounds_split, dim3((unsigned)(n / FNT), 4), dim3(FNT), 0, stream, p, d_even);
     return hipGetLastError();
 }
-hipError_t launch_rounds_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream) {
+hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    hipLaunchKernelGGL(k_rounds_finish, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd);
+    const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
+    if (part == PART_DBL0) hipLaunchKernelGGL((k_ec_split<PART_DBL0, false>), grid, block, 0, stream, p, d_even_family);
+    else if (part == PART_DBL1) hipLaunchKernelGGL((k_ec_split<PART_DBL1, true>), grid, block, 0, stream, p, d_even_family);
+    else if (part == PART_ADD0) hipLaunchKernelGGL((k_ec_split<PART_ADD0, false>), grid, block, 0, stream, p, d_even_family);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    hipLaunchKernelGGL(k_split_finish, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd);
     return hipGetLastError();
 }
 
-hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events, bool rounds_done) {
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events, unsigned done_mask) {
+    const bool rounds_done = done_mask & 1u; // done_mask: bit PART = that part was evaluated by the caller (split evaluation), its event recorded
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
     // part_events (optional, CE_NUM_PARTS + 1 events): recorded around every part so that callers can time each launch
@@ -1310,9 +1392,9 @@ hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t s
         if (e != hipSuccess) return e;
     }
 #define CS_PART(PART)                                                                                                                   \
-    if (PART == PART_ROUNDS && rounds_done) {                                                                                           \
+    if ((done_mask >> PART) & 1u) {                                                                                                     \
     } else if (part_events) (void)hipEventRecord(part_events[PART], stream);                                                            \
-    if (PART == PART_ROUNDS && rounds_done) {                                                                                           \
+    if ((done_mask >> PART) & 1u) {                                                                                                     \
     } else if (m == 1) {                                                                                                                       \
         if (PART == PART_ROUNDS && ROUNDS_DYN_LDS)                                                                                      \
             (void)hipFuncSetAttribute((const void *)k_eval_fused<PART, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROUNDS_LDS); \
