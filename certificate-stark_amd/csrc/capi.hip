@@ -641,7 +641,7 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         // Parts whose merged polynomials have degree < 4n (constraints.hip: the Rescue windows with their flags; the doublings and the
         // addition of the generator with the flag factored out) run on the even cosets only; their twelve polynomials are
         // interpolated over that 4n-point sub-domain, extended to the odd cosets by transforms of twelve columns and recombined
-        // at every point.  (Part timing: the extension and the recombination are counted with the third of these parts.)
+        // at every point.  (Part timing: the extension and the recombination are counted with the last of these parts.)
         const size_t n = (size_t)1 << log_n;
         constexpr unsigned T = cs::CE_SPLIT_TABLES;
         const NttPlan *pn, *p4, *p8;
@@ -657,11 +657,13 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         HIP_TRY(cs::launch_rounds_setup(p, c->stream));
         HIP_TRY(cs::launch_rounds_split(p, even, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[1], c->stream));
-        HIP_TRY(cs::launch_ec_split(p, 1, even + 16 * n, c->stream)); // doubling family: tables 4..7
+        HIP_TRY(cs::launch_ec_split(p, 1, even + 16 * n, nullptr, c->stream)); // doubling family: tables 4..7
         if (pev) HIP_TRY(hipEventRecord(pev[2], c->stream));
-        HIP_TRY(cs::launch_ec_split(p, 2, even + 32 * n, c->stream)); // addition family: tables 8..11
+        HIP_TRY(cs::launch_ec_split(p, 2, even + 32 * n, nullptr, c->stream)); // addition family: tables 8..11
         if (pev) HIP_TRY(hipEventRecord(pev[3], c->stream));
-        HIP_TRY(cs::launch_ec_split(p, 3, even + 16 * n, c->stream));
+        HIP_TRY(cs::launch_ec_split(p, 3, even + 16 * n, nullptr, c->stream));
+        if (pev) HIP_TRY(hipEventRecord(pev[4], c->stream));
+        HIP_TRY(cs::launch_ec_split(p, 4, even + 48 * n, even + 32 * n, c->stream)); // addition x bit family: tables 12..15
         cs::NttArgs a{};
         a.in = even; a.scratch = sa; a.out = sb; a.width = 4 * T; a.batch = 1; a.log_n = log_n; // every polynomial on every even coset
         a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true;
@@ -674,7 +676,7 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
         HIP_TRY(cs::ntt_columns(f, c->stream));
         HIP_TRY(cs::launch_split_finish(p, even, odd, c->stream));
-        HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev, 0xFu)); // parts 0..3 done
+        HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev, 0x1Fu)); // parts 0..4 done
     } else {
         HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev));
     }

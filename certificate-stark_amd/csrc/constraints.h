@@ -72,8 +72,10 @@ hipError_t launch_rounds_setup(const CeParams &p, hipStream_t stream);
 hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t stream);
 // split evaluation of a curve gadget (part 1 = doubling of s*G, 2 = addition of G, 3 = doubling of h*P; 1 and 2 write their family's
 // four polynomials, 3 adds to the doubling family): d_even_family = [4][4][n]
-hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, hipStream_t stream);
-constexpr int CE_SPLIT_TABLES = 12; // Rescue windows | doubling | addition: four polynomials each
+// part 4 = addition of the public key: its quartic half is a family of its own (d_even_family), its linear half is ADDED to the
+// addition family d_even_linear (after part 2 wrote it)
+hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, uint64_t *d_even_linear, hipStream_t stream);
+constexpr int CE_SPLIT_TABLES = 16; // Rescue windows | doubling | addition | addition x bit: four polynomials each
 hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream);
 hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,
                                    hipStream_t stream);

@@ -754,9 +754,9 @@ __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restr
 
 // grid = (n / 256, 8): out[k][j] = [ (R_a + sum_g x^adj_g R_b,g) + doubling(x) (D_a + sum_g x^adj_g D_b,g) + addition(x) (A_a + ...) ]
 //                                  * (x - w^(n-1)) / (x^n - 1).
-// The twelve polynomials' values come from the split evaluations (even cosets, [12][4][n]: Rescue windows, doubling, addition
-// families of four) or from their extension (odd cosets, [4 cosets][12][n]).
-constexpr int SPLIT_TABLES = 12;
+// (+ the fourth family with the "flag" -addition(x) * register 37, see k_ec_split).  The sixteen polynomials' values come from the
+// split evaluations (even cosets, [16][4][n]: families of four) or from their extension (odd cosets, [4 cosets][16][n]).
+constexpr int SPLIT_TABLES = 16;
 __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
@@ -768,10 +768,11 @@ __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__re
     for (int g = 0; g < 3; g++) xp[g] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
     const fp *per = p.ptab + (size_t)k * 48 * 1024 + (j & 1023);
     const fp doubling = per[(size_t)P_DOUBLING * 1024], scalar_mult = per[(size_t)P_SCALAR_MULT * 1024];
-    const fp fam_flag[3] = {FP_ONE, doubling, fp_mul(c_not(doubling), scalar_mult)};
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
+    const fp fam_flag[4] = {FP_ONE, doubling, addition, fp_neg(fp_mul(addition, p.lde[((size_t)k * 94 + 37) * n + j]))};
     fp total = 0;
 #pragma unroll
-    for (int fam = 0; fam < 3; fam++) {
+    for (int fam = 0; fam < 4; fam++) {
         fp r[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -870,9 +871,13 @@ struct SplitAcc {
         return acc_reduce(a);
     }
 };
+// The addition of the public key (a variable point: add(cur, P) is quartic, bit * add quintic) splits once more:
+//     (next - cur) - bit (add(cur, P) - cur)  =  L - bit * Q,   L = next - cur (degree n - 1),  Q = add(cur, P) - cur (degree 4 (n - 1)):
+// sum coef_i L_i joins the addition family, sum coef_i Q_i is a family of its own whose "flag" is -addition(x) * bit(x), the bit
+// being register 37 of the extended trace itself.
 // out = [4][4 even cosets][n] of this flag's family; ACCUMULATE: add to what an earlier part of the same family wrote.  grid = (n / FNT, 4)
 template <int PART, bool ACCUMULATE>
-__global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict__ out) {
+__global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict__ out, fp *__restrict__ out_linear) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kc = blockIdx.y;
@@ -882,6 +887,26 @@ __global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict_
     if (PART == PART_DBL0) fused_doubling(acc, f, 0, (fp)0);
     if (PART == PART_DBL1) fused_doubling(acc, f, 19, (fp)0);
     if (PART == PART_ADD0) fused_addition(acc, f, 0, const6(c_generator), const6(c_generator + 6), (fp)0);
+    if (PART == PART_ADD1) {
+        acc.begin(); // the linear half first: its four sums leave the registers before the curve arithmetic starts
+#pragma unroll
+        for (int i = 0; i < 18; i++) acc.term(19 + i, fp_sub(f.next(19 + i), f.cur(19 + i)));
+        acc.term(37, fp_sub(f.cur(37), f.next(37)));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            fp *o = out_linear + ((size_t)q * 4 + kc) * n + j;
+            *o = fp_add(*o, acc.result(q));
+        }
+        const Point pt = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
+        const Point a = ec_add_mixed<CS_EC_CALL>(pt, load6(f, S_KEY, true), load6(f, S_KEY + 6, true)); // pkey = next[S_KEY..], src/air.rs:575
+        acc.begin();
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc.term(19 + i, fp_sub(a.x.c[i], pt.x.c[i]));
+            acc.term(25 + i, fp_sub(a.y.c[i], pt.y.c[i]));
+            acc.term(31 + i, fp_sub(a.z.c[i], pt.z.c[i]));
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         fp *o = out + ((size_t)q * 4 + kc) * n + j;
@@ -1364,12 +1389,13 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
     hipLaunchKernelGGL(k_rounds_split, dim3((unsigned)(n / FNT), 4), dim3(FNT), 0, stream, p, d_even);
     return hipGetLastError();
 }
-hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, hipStream_t stream) {
+hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, uint64_t *d_even_linear, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
-    if (part == PART_DBL0) hipLaunchKernelGGL((k_ec_split<PART_DBL0, false>), grid, block, 0, stream, p, d_even_family);
-    else if (part == PART_DBL1) hipLaunchKernelGGL((k_ec_split<PART_DBL1, true>), grid, block, 0, stream, p, d_even_family);
-    else if (part == PART_ADD0) hipLaunchKernelGGL((k_ec_split<PART_ADD0, false>), grid, block, 0, stream, p, d_even_family);
+    if (part == PART_DBL0) hipLaunchKernelGGL((k_ec_split<PART_DBL0, false>), grid, block, 0, stream, p, d_even_family, d_even_linear);
+    else if (part == PART_DBL1) hipLaunchKernelGGL((k_ec_split<PART_DBL1, true>), grid, block, 0, stream, p, d_even_family, d_even_linear);
+    else if (part == PART_ADD0) hipLaunchKernelGGL((k_ec_split<PART_ADD0, false>), grid, block, 0, stream, p, d_even_family, d_even_linear);
+    else if (part == PART_ADD1) hipLaunchKernelGGL((k_ec_split<PART_ADD1, false>), grid, block, 0, stream, p, d_even_family, d_even_linear);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
