@@ -668,10 +668,10 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         a.in = even; a.scratch = sa; a.out = sb; a.width = 4 * T; a.batch = 1; a.log_n = log_n; // every polynomial on every even coset
         a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true;
         HIP_TRY(cs::ntt_columns(a, c->stream));
-        HIP_TRY(cs::coset_combine(sb, sa, log_n, 2, p4->winv, cs::host::inv(cs::host::from_u64(4)), c->stream, T)); // sa = coefficients [T][4n]
-        HIP_TRY(cs::coset_spread_odd(sa, sb, log_n, T, p8->w, c->stream));                                            // sb = [4 odd cosets][T][n]
+        // interpolants of the even cosets -> inputs of the odd cosets' transforms (the 4n coefficients are never written)
+        HIP_TRY(cs::coset_even_to_odd(sb, sa, log_n, T, p4->winv, p8->w, cs::host::inv(cs::host::from_u64(4)), c->stream)); // sa = [4 odd cosets][T][n]
         cs::NttArgs f{};
-        f.in = sb; f.scratch = sc; f.out = odd; f.width = T; f.batch = 4; f.log_n = log_n;
+        f.in = sa; f.scratch = sc; f.out = odd; f.width = T; f.batch = 4; f.log_n = log_n;
         f.w = pn->w; f.prescale = t1->s + n; f.prescale_batch_stride = 2 * n; f.do_scale = false; f.inverse = false;
         f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
         HIP_TRY(cs::ntt_columns(f, c->stream));

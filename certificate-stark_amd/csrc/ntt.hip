@@ -416,6 +416,42 @@ __global__ __launch_bounds__(256) void k_coset_spread_odd(const fp *__restrict__
         out[((size_t)kc * tables + tb) * n + q] = v;
     }
 }
+__global__ __launch_bounds__(256) void k_coset_even_to_odd(const fp *__restrict__ in, fp *__restrict__ out, size_t n, unsigned tables,
+                                                           const fp *__restrict__ winv4n, const fp *__restrict__ w8n, fp quarter) {
+    const size_t q = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (q >= n) return;
+    const unsigned tb = blockIdx.y;
+    fp v[4], w4[4], w8[8], a[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        w4[k] = winv4n[(size_t)k * n]; // w_4^-k
+        const fp x = fp_mul(in[((size_t)tb * 4 + k) * n + q], quarter);
+        v[k] = k == 0 ? x : fp_mul(x, winv4n[(size_t)k * q]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) w8[e] = w8n[(size_t)e * n]; // w_8^e
+#pragma unroll
+    for (int i = 0; i < 4; i++) { // coefficient a_{q + n i}
+        fp s = v[0];
+#pragma unroll
+        for (int k = 1; k < 4; k++) s = fp_add(s, fp_mul(v[k], w4[(k * i) & 3]));
+        a[i] = s;
+    }
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) {
+        const int k = 2 * kc + 1;
+        fp s = a[0];
+#pragma unroll
+        for (int i = 1; i < 4; i++) s = fp_add(s, fp_mul(a[i], w8[(k * i) & 7]));
+        out[((size_t)kc * tables + tb) * n + q] = s;
+    }
+}
+hipError_t coset_even_to_odd(const fp *d_b, fp *d_out, unsigned log_n, unsigned tables, const fp *d_winv_4n, const fp *d_w_8n, fp quarter,
+                             hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_coset_even_to_odd, dim3((unsigned)((n + 255) / 256), tables), dim3(256), 0, stream, d_b, d_out, n, tables, d_winv_4n, d_w_8n, quarter);
+    return hipGetLastError();
+}
 hipError_t coset_spread_odd(const fp *d_a, fp *d_out, unsigned log_n, unsigned tables, const fp *d_w_8n, hipStream_t stream) {
     const size_t n = (size_t)1 << log_n;
     hipLaunchKernelGGL(k_coset_spread_odd, dim3((unsigned)((n + 255) / 256), tables), dim3(256), 0, stream, d_a, d_out, n, tables, d_w_8n);
