@@ -657,13 +657,21 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         HIP_TRY(cs::launch_rounds_setup(p, c->stream));
         HIP_TRY(cs::launch_rounds_split(p, even, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[1], c->stream));
-        HIP_TRY(cs::launch_ec_split(p, 1, even + 16 * n, nullptr, c->stream)); // doubling family: tables 4..7
+        uint64_t *fam_dbl = even + (size_t)cs::CE_SPLIT_FAM0 * 4 * n, *fam_add = fam_dbl + 16 * n, *fam_addbit = fam_add + 16 * n;
+        HIP_TRY(cs::launch_ec_split(p, 1, fam_dbl, nullptr, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[2], c->stream));
-        HIP_TRY(cs::launch_ec_split(p, 2, even + 32 * n, nullptr, c->stream)); // addition family: tables 8..11
+        HIP_TRY(cs::launch_ec_split(p, 2, fam_add, nullptr, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[3], c->stream));
-        HIP_TRY(cs::launch_ec_split(p, 3, even + 16 * n, nullptr, c->stream));
+        HIP_TRY(cs::launch_ec_split(p, 3, fam_dbl, nullptr, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[4], c->stream));
-        HIP_TRY(cs::launch_ec_split(p, 4, even + 48 * n, even + 32 * n, c->stream)); // addition x bit family: tables 12..15
+        HIP_TRY(cs::launch_ec_split(p, 4, fam_addbit, fam_add, c->stream));
+        // the final addition reaches degree 5 (n - 1): all cosets, accumulated into the zero-filled output first
+        HIP_TRY(hipMemsetAsync(p.out, 0, 8 * n * 8, c->stream));
+        HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev, 0x1FFu & ~(1u << 5), false));
+        for (int part = 6; part <= 8; part++) {
+            if (pev) HIP_TRY(hipEventRecord(pev[part], c->stream));
+            HIP_TRY(cs::launch_lin_split(p, part, even, c->stream));
+        }
         cs::NttArgs a{};
         a.in = even; a.scratch = sa; a.out = sb; a.width = 4 * T; a.batch = 1; a.log_n = log_n; // every polynomial on every even coset
         a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true;
@@ -676,7 +684,7 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
         HIP_TRY(cs::ntt_columns(f, c->stream));
         HIP_TRY(cs::launch_split_finish(p, even, odd, c->stream));
-        HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev, 0x1Fu)); // parts 0..4 done
+        if (pev) HIP_TRY(hipEventRecord(pev[cs::CE_NUM_PARTS], c->stream));
     } else {
         HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev));
     }

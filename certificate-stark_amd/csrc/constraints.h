@@ -64,7 +64,8 @@ hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, uns
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);
 constexpr int CE_NUM_PARTS = 9; // launches of the fused evaluation: rounds, dbl0, add0, dbl1, add1, final, lin_a, lin_b, lin_c
-hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events = nullptr, unsigned done_mask = 0);
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events = nullptr, unsigned done_mask = 0,
+                                   bool record_end = true);
 // Split evaluation of the Rescue windows (m = 1, all 8 cosets, k0 = 0; constraints.hip): setup of the per-proof tables; the four
 // low-degree polynomials on the even cosets, d_even = [4][4][n]; recombination over all cosets from d_even and their extension to
 // the odd cosets d_odd = [4 cosets][4][n] (writes p.out, like the first part of launch_eval_constraints).
@@ -75,7 +76,9 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
 // part 4 = addition of the public key: its quartic half is a family of its own (d_even_family), its linear half is ADDED to the
 // addition family d_even_linear (after part 2 wrote it)
 hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, uint64_t *d_even_linear, hipStream_t stream);
-constexpr int CE_SPLIT_TABLES = 16; // Rescue windows | doubling | addition | addition x bit: four polynomials each
+constexpr int CE_SPLIT_TABLES = 18, CE_SPLIT_FAM0 = 6; // first family (Rescue windows + linear groups): six polynomials; doubling | addition | addition x bit: four each
+// split evaluation of a linear group (part 6, 7, 8): adds to the first family, d_even_family0 = [6][4][n]
+hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream);
 hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream);
 hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,
                                    hipStream_t stream);

@@ -660,7 +660,7 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
 // with four polynomials of degree < 4n: they are evaluated on the 4n-point sub-domain of the even cosets only (half the work of
 // the windows), interpolated there, extended to the odd cosets by transforms of four columns (capi.hip), and recombined with
 // x^adj_g and the transition divisor at every point (k_rounds_finish).  Exact arithmetic: the same merged evaluations.
-// out = [4 polynomials][4 even cosets][n].  grid = (n / FNT, 4)
+// out = [6 polynomials][4 even cosets][n] (alpha, beta of groups 0..4; this kernel initialises all six).  grid = (n / FNT, 4)
 __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restrict__ out) {
     __shared__ fp ark2_lds[8 * 14];
     __shared__ __attribute__((aligned(16))) fp img_lds[(FNT / 64) * RW_IMG];
@@ -749,42 +749,52 @@ __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restr
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) out[((size_t)q * 4 + kc) * n + j] = tot[q];
+    for (int q = 0; q < 6; q++) out[((size_t)q * 4 + kc) * n + j] = q < 4 ? tot[q] : 0; // groups 3, 4: written by the linear groups
 }
 
 // grid = (n / 256, 8): out[k][j] = [ (R_a + sum_g x^adj_g R_b,g) + doubling(x) (D_a + sum_g x^adj_g D_b,g) + addition(x) (A_a + ...) ]
 //                                  * (x - w^(n-1)) / (x^n - 1).
-// (+ the fourth family with the "flag" -addition(x) * register 37, see k_ec_split).  The sixteen polynomials' values come from the
-// split evaluations (even cosets, [16][4][n]: families of four) or from their extension (odd cosets, [4 cosets][16][n]).
-constexpr int SPLIT_TABLES = 16;
+// (+ the fourth family with the "flag" -addition(x) * register 37, see k_ec_split; + the boundary terms).  The eighteen polynomials'
+// values come from the split evaluations (even cosets, [18][4][n]: the first family of six -- alpha, beta of groups 0..4 -- then
+// three families of four) or from their extension (odd cosets, [4 cosets][18][n]).  ADDS to p.out.
+constexpr int SPLIT_TABLES = 18, SPLIT_FAM0 = 6; // first family: alpha, beta of groups 0..4 (Rescue windows + linear groups, flags inside)
 __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
     const unsigned k = blockIdx.y;
     const fp *cc = p.coset + (size_t)k * CE_COSET_CONSTS;
     const fp x = fp_mul(cc[0], p.w[j]);
-    fp xp[3];
+    fp xp[5];
 #pragma unroll
-    for (int g = 0; g < 3; g++) xp[g] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
+    for (int g = 0; g < 5; g++) xp[g] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
     const fp *per = p.ptab + (size_t)k * 48 * 1024 + (j & 1023);
     const fp doubling = per[(size_t)P_DOUBLING * 1024], scalar_mult = per[(size_t)P_SCALAR_MULT * 1024];
     const fp addition = fp_mul(c_not(doubling), scalar_mult);
-    const fp fam_flag[4] = {FP_ONE, doubling, addition, fp_neg(fp_mul(addition, p.lde[((size_t)k * 94 + 37) * n + j]))};
-    fp total = 0;
+    const fp *col = p.lde + (size_t)k * 94 * n + j;
+    auto value = [&](int tb) { return (k & 1) ? odd[((size_t)(k >> 1) * SPLIT_TABLES + tb) * n + j] : even[((size_t)tb * 4 + (k >> 1)) * n + j]; };
+    fp total = value(0);
 #pragma unroll
-    for (int fam = 0; fam < 4; fam++) {
-        fp r[4];
+    for (int g = 0; g < 5; g++) total = fp_add(total, fp_mul(value(1 + g), xp[g]));
+    const fp fam_flag[3] = {doubling, addition, fp_neg(fp_mul(addition, col[(size_t)37 * n]))};
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int tb = fam * 4 + q;
-            r[q] = (k & 1) ? odd[((size_t)(k >> 1) * SPLIT_TABLES + tb) * n + j] : even[((size_t)tb * 4 + (k >> 1)) * n + j];
-        }
-        fp t = r[0];
+    for (int fam = 0; fam < 3; fam++) {
+        fp t = value(SPLIT_FAM0 + fam * 4);
 #pragma unroll
-        for (int g = 0; g < 3; g++) t = fp_add(t, fp_mul(r[1 + g], xp[g]));
-        total = fp_add(total, fam == 0 ? t : fp_mul(fam_flag[fam], t));
+        for (int g = 0; g < 3; g++) t = fp_add(t, fp_mul(value(SPLIT_FAM0 + fam * 4 + 1 + g), xp[g]));
+        total = fp_add(total, fp_mul(fam_flag[fam], t));
     }
-    p.out[(size_t)k * n + j] = fp_mul(total, fp_mul(fp_sub(x, p.w_last), cc[1]));
+    fp t = fp_mul(total, fp_mul(fp_sub(x, p.w_last), cc[1]));
+    {   // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184), as in the last linear group
+        const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
+        const fp *ba = p.coef + 230, *bb = ba + 4;
+        const fp r58 = col[(size_t)58 * n], r59 = col[(size_t)59 * n];
+        const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
+        const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
+        const fp *bi = p.binv + (size_t)k * 2 * n + j;
+        t = fp_add(t, fp_add(fp_mul(first, bi[0]), fp_mul(last, bi[n])));
+    }
+    fp *o = p.out + (size_t)k * n + j;
+    *o = fp_add(*o, t); // the final addition (all cosets) was accumulated into the zero-filled table before
 }
 
 // doubling gadget for the point at registers [reg, reg + 19)  (ecc.rs:73-98)
@@ -1099,6 +1109,183 @@ __device__ __forceinline__ void fused_linear_c(Fused<M> &acc, const Frame &f) {
     }
 }
 
+// ---- split evaluation of the linear groups (flags inside: every term has degree < 4n, see the degree table in DESIGN.md) ---------
+// Section accumulator for slots of any degree group: alpha-weighted sum and one beta-weighted sum per group.  The slot may be a
+// run-time value (rolled loops): its group is then a uniform condition.
+struct SectionAcc {
+    const CS_CONST fp *coefs;
+    Acc128 sa, sb[5];
+    int ca, cb[5];
+    __device__ __forceinline__ void begin() {
+        sa = acc_zero(); ca = 0;
+#pragma unroll
+        for (int g = 0; g < 5; g++) { sb[g] = acc_zero(); cb[g] = 0; }
+    }
+    __device__ __forceinline__ void term(int i, fp v) {
+        acc_mad(sa, coefs[i], v);
+        if (++ca == 7) { acc_fold(sa); ca = 0; }
+        const int g = tx_degree_group(i);
+#pragma unroll
+        for (int q = 0; q < 5; q++)
+            if (g == q) {
+                acc_mad(sb[q], coefs[115 + i], v);
+                if (++cb[q] == 7) { acc_fold(sb[q]); cb[q] = 0; }
+            }
+    }
+    // tot[0] += flag * alpha sum, tot[1 + g] += flag * beta sum of group g, for the groups in GMASK (the others received nothing)
+    template <unsigned GMASK>
+    __device__ __forceinline__ void flush(fp flag, fp (&tot)[6]) {
+        acc_fold(sa);
+        tot[0] = fp_add(tot[0], fp_mul(flag, acc_reduce(sa)));
+#pragma unroll
+        for (int g = 0; g < 5; g++)
+            if ((GMASK >> g) & 1u) {
+                acc_fold(sb[g]);
+                tot[1 + g] = fp_add(tot[1 + g], fp_mul(flag, acc_reduce(sb[g])));
+            }
+    }
+};
+constexpr unsigned G0 = 1, G1 = 2, G2 = 4, G3 = 8, G4 = 16;
+
+// setup + value-copy constraints: every slot is in group 4
+__device__ __forceinline__ void lin_a_split(const CS_CONST fp *coefs, const Frame &f, fp (&tot)[6]) {
+    const fp setup = f.pv(P_SETUP), copy_values = f.pv(P_VALUE_COPY);
+    SectionAcc s_set, s_cp;
+    s_set.coefs = s_cp.coefs = coefs;
+    s_set.begin(); s_cp.begin();
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        const fp si = f.cur(S_INIT + i), su = f.cur(S_UPD + i), ri = f.cur(R_INIT + i), ru = f.cur(R_UPD + i);
+        const fp skn = f.next(S_KEY + i), skc = f.cur(S_KEY + i), rkn = f.next(R_KEY + i), rkc = f.cur(R_KEY + i);
+        s_set.term(VALUE_RES + i, fp_sub(si, su));
+        s_set.term(VALUE_RES + 12 + i, fp_sub(ri, ru));
+        s_set.term(S_KEY_RES + i, fp_sub(skn, si));
+        s_set.term(R_KEY_RES + i, fp_sub(rkn, ri));
+        s_cp.term(S_KEY_RES + i, fp_sub(skn, skc));
+        s_cp.term(R_KEY_RES + i, fp_sub(rkn, rkc));
+    }
+    const fp s_spent = fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12));
+    const fp nd = f.next(DELTA_COPY), ns = f.next(SIGMA_COPY), nn = f.next(NONCE_COPY);
+    s_set.term(VALUE_RES + 24, fp_sub(f.cur(R_INIT + 13), f.cur(R_UPD + 13)));
+    s_set.term(BALANCE_RES, fp_sub(s_spent, fp_sub(f.cur(R_UPD + 12), f.cur(R_INIT + 12))));
+    s_set.term(NONCE_UPD_RES, fp_sub(f.cur(S_UPD + 13), fp_add(f.cur(S_INIT + 13), FP_ONE)));
+    s_set.term(DELTA_COPY_RES, fp_sub(nd, s_spent));
+    s_set.term(SIGMA_COPY_RES, fp_sub(ns, f.cur(S_UPD + 12)));
+    s_set.term(NONCE_COPY_RES, fp_sub(nn, f.cur(S_INIT + 13)));
+    s_cp.term(DELTA_COPY_RES, fp_sub(nd, f.cur(DELTA_COPY)));
+    s_cp.term(SIGMA_COPY_RES, fp_sub(ns, f.cur(SIGMA_COPY)));
+    s_cp.term(NONCE_COPY_RES, fp_sub(nn, f.cur(NONCE_COPY)));
+    s_set.flush<G4>(setup, tot);
+    s_cp.flush<G4>(copy_values, tot);
+}
+// merkle::update without its rounds
+__device__ __forceinline__ void lin_b_split(const CS_CONST fp *coefs, const Frame &f, fp (&tot)[6]) {
+    const fp tx_hash = f.pv(P_MERKLE), hash_input = f.pv(P_HASH_INPUT), finish = f.pv(P_FINISH), hash_flag = f.pv(P_HASH);
+    const fp hash_copy = fp_mul(tx_hash, c_not(fp_add(hash_flag, hash_input)));
+    const fp hash_init = fp_mul(tx_hash, hash_input);
+    SectionAcc sa, sb;
+    sa.coefs = sb.coefs = coefs;
+#pragma unroll 1
+    for (int blk = 0; blk < 2; blk++) {
+        const int base = blk == 0 ? S_INIT : R_INIT;
+        const fp bit = f.next(base + 14), not_bit = c_not(bit);
+        sa.begin();
+        sa.term(base + 14, c_is_binary(bit));
+        sa.flush<G1 | G2>(tx_hash, tot); // slot 14: group 1, slot 43: group 2
+        sa.begin(); sb.begin();
+#pragma unroll 1
+        for (int i = 0; i < 7; i++) {
+            const fp ca = f.cur(base + i), na0 = f.next(base + i), cb = f.cur(base + 15 + i), nb0 = f.next(base + 15 + i);
+            const fp na7 = f.next(base + 7 + i), nb7 = f.next(base + 22 + i);
+            const fp da = fp_sub(ca, na0), db = fp_sub(cb, nb0);
+            sa.term(base + i, da);
+            sa.term(base + 15 + i, db);
+            sb.term(base + i, fp_add(fp_mul(not_bit, da), fp_mul(bit, fp_sub(nb0, na0))));
+            sb.term(base + 7 + i, fp_add(fp_mul(bit, fp_sub(ca, na7)), fp_mul(not_bit, fp_sub(nb7, na7))));
+            sb.term(base + 15 + i, fp_mul(not_bit, db));
+            sb.term(base + 22 + i, fp_mul(bit, fp_sub(cb, nb7)));
+        }
+        sa.flush<G0 | G1 | G2>(hash_copy, tot);
+        sb.flush<G0 | G1 | G2>(hash_init, tot);
+    }
+    sa.begin(); sb.begin();
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) {
+        const fp nr = f.next(PREV_ROOT + i), cr = f.cur(PREV_ROOT + i);
+        sa.term(PREV_ROOT + i, fp_sub(nr, cr));
+        sb.term(PREV_ROOT + i, fp_sub(nr, f.next(R_UPD + i)));
+        sb.term(INT_ROOT_RES + i, fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)));
+        sb.term(PREV_MATCH_RES + i, fp_sub(f.next(S_INIT + i), cr));
+    }
+    sa.flush<G4>(c_not(finish), tot);
+    sb.flush<G3 | G4>(finish, tot);
+}
+// schnorr linear parts, hash copy, range proofs (the boundary terms are added in k_split_finish)
+__device__ __forceinline__ void lin_c_split(const CS_CONST fp *coefs, const Frame &f, fp (&tot)[6]) {
+    const fp schnorr_mask = f.pv(P_SCHNORR), scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING), schnorr_hash = f.pv(P_SCHNORR_HASH);
+    const fp range_flag = f.pv(P_RANGE_STEP), range_finish = f.pv(P_RANGE_FINISH);
+    const fp copy_hash = fp_mul(c_not(schnorr_hash), schnorr_mask);
+    const fp final_add = fp_mul(c_not(scalar_mult), schnorr_mask);
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
+    SectionAcc s;
+    s.coefs = coefs;
+    s.begin(); // flags are part of the values here
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const fp dflag = f.pv(P_DIGEST + i);
+        const fp c = f.cur(41 - i), nx = f.next(41 - i);
+        s.term(41 - i, fp_add(fp_mul(fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37)))), fp_mul(fp_mul(c_not(dflag), doubling), fp_sub(c, nx))));
+        s.term(38 + i, fp_add(fp_mul(addition, fp_sub(f.cur(38 + i), f.next(38 + i))), fp_mul(final_add, fp_sub(f.cur(38 + i), f.cur(42 + i)))));
+    }
+    s.flush<G2>(FP_ONE, tot);
+    s.begin();
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        s.term(42 + i, fp_sub(f.cur(42 + i), f.next(42 + i)));
+        fp inp = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int m = k * 7 + i;
+            const fp cell = m < 12 ? f.next(S_KEY + m) : m < 24 ? f.next(R_KEY + m - 12) : m == 24 ? f.next(DELTA_COPY) : m == 25 ? f.next(NONCE_COPY) : 0;
+            inp = fp_add(inp, fp_mul(f.pv(P_HASH_INTERNAL + k), cell));
+        }
+        s.term(49 + i, fp_sub(f.next(49 + i), inp));
+    }
+    s.flush<G2>(copy_hash, tot);
+    const fp db = f.next(DELTA_BIT), sbit = f.next(SIGMA_BIT);
+    s.begin();
+    s.term(DELTA_ACC, fp_sub(f.next(DELTA_ACC), fp_add(fp_dbl(f.cur(DELTA_ACC)), db)));
+    s.term(DELTA_BIT, c_is_binary(db));
+    s.term(SIGMA_ACC, fp_sub(f.next(SIGMA_ACC), fp_add(fp_dbl(f.cur(SIGMA_ACC)), sbit)));
+    s.term(SIGMA_BIT, c_is_binary(sbit));
+    s.flush<G2 | G3 | G4>(range_flag, tot);
+    const fp dr = fp_sub(f.next(DELTA_ACC), f.next(DELTA_COPY));
+    s.begin();
+    s.term(DELTA_RANGE_RES, dr);
+    s.term(SIGMA_RANGE_RES, dr);
+    s.flush<G4>(range_finish, tot);
+}
+// adds to the six polynomials of the first family (alpha, beta of groups 0..4): out = [6][4 even cosets][n].  grid = (n / FNT, 4)
+template <int PART>
+__global__ __launch_bounds__(FNT, PART == PART_LIN_C ? 2 : 4) void k_lin_split(CeParams p, fp *__restrict__ out) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kc = blockIdx.y;
+    const Frame f = make_frame(p, 2 * kc, j);
+    fp tot[6] = {0, 0, 0, 0, 0, 0};
+    if (PART == PART_LIN_A) lin_a_split(as_const(p.coef), f, tot);
+    if (PART == PART_LIN_B) lin_b_split(as_const(p.coef), f, tot);
+    if (PART == PART_LIN_C) lin_c_split(as_const(p.coef), f, tot);
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const bool touched = PART == PART_LIN_A ? (q == 0 || q == 5) : true;
+        if (touched) {
+            fp *o = out + ((size_t)q * 4 + kc) * n + j;
+            *o = fp_add(*o, tot[q]);
+        }
+    }
+}
+
 // grid = (n / FNT, nk)
 #ifndef CS_ROUNDS_WAVES
 #define CS_ROUNDS_WAVES 3
@@ -1399,13 +1586,22 @@ hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family,
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
+    if (part == PART_LIN_A) hipLaunchKernelGGL(k_lin_split<PART_LIN_A>, grid, block, 0, stream, p, d_even_family0);
+    else if (part == PART_LIN_B) hipLaunchKernelGGL(k_lin_split<PART_LIN_B>, grid, block, 0, stream, p, d_even_family0);
+    else if (part == PART_LIN_C) hipLaunchKernelGGL(k_lin_split<PART_LIN_C>, grid, block, 0, stream, p, d_even_family0);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
 hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
     hipLaunchKernelGGL(k_split_finish, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd);
     return hipGetLastError();
 }
 
-hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events, unsigned done_mask) {
+hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t stream, hipEvent_t *part_events, unsigned done_mask, bool record_end) {
     const bool rounds_done = done_mask & 1u; // done_mask: bit PART = that part was evaluated by the caller (split evaluation), its event recorded
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
@@ -1437,7 +1633,7 @@ hipError_t launch_eval_constraints(const CeParams &p, unsigned nk, hipStream_t s
     CS_PART(PART_ROUNDS) CS_PART(PART_DBL0) CS_PART(PART_ADD0) CS_PART(PART_DBL1) CS_PART(PART_ADD1) CS_PART(PART_FINAL)
     CS_PART(PART_LIN_A) CS_PART(PART_LIN_B) CS_PART(PART_LIN_C)
 #undef CS_PART
-    if (part_events) (void)hipEventRecord(part_events[NUM_PARTS], stream);
+    if (part_events && record_end) (void)hipEventRecord(part_events[NUM_PARTS], stream);
     static_assert(NUM_PARTS == CE_NUM_PARTS, "part count");
     return hipGetLastError();
 }
