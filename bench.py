@@ -300,7 +300,10 @@ def main():
         # the 58 hash-state registers of every LDE row read once (current and next row share cache lines), the 28 round-
         # constant values per point from the 3 MB periodic table (cache resident, not counted), one 8-byte result.
         nb = (nk if coset_mode else (1 << LOG_B))
-        rounds_bytes = nb * n * (58 * 8 + 8)
+        # In prove mode the windows run as k_rounds_split: the even cosets only (their merged polynomials have degree < 4n and are
+        # extended to the odd cosets afterwards), six 8-byte polynomial values per point out.
+        split = prove_mode and field_ext == 0
+        rounds_bytes = (nb // 2) * n * (58 * 8 + 6 * 8) if split else nb * n * (58 * 8 + 8)
         dom_ms = part_avg["rounds"]
         achieved = rounds_bytes / (dom_ms * 1e-3) / 1e9
         out = {
@@ -330,12 +333,15 @@ def main():
                            "then registers 0..36 interpolated, 'lde' = their extension; the three add up to the time to the complete extended trace "
                            "(include/cstark.h, cstark_prove_stage_ms)") if prove_mode else None,
             "constraint_part_ms": {k: round(v, 3) for k, v in part_avg.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_eval_fused<0> (Rescue windows of the constraint evaluation)",
+            "constraint_part_note": ("all parts except final_add run on the even cosets only (split evaluation); lin_c includes the extension of their "
+                                     "18 polynomials to the odd cosets and the recombination over all cosets") if (prove_mode and field_ext == 0) else None,
+            "roofline": {"bound": "hbm", "kernel": ("k_rounds_split (Rescue windows of the constraint evaluation, on the even cosets)" if split else
+                                                    "k_eval_fused<0> (Rescue windows of the constraint evaluation)"),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": 5.705e9 if (n_tx == 1024 and not coset_mode) else None,
+                         "traffic": (2.598e9 if split else 5.705e9) if (n_tx == 1024 and not coset_mode) else None,
                          "algorithmic_bytes": rounds_bytes, "kernel_ms": round(dom_ms, 3),
-                         "traffic_source": "profiles/r01_v10_hbm_traffic_pmc.csv: 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE correction, calibrated on k_hash_rows). "
+                         "traffic_source": "profiles/r01_v12_hbm_traffic_pmc.csv (k_rounds_split) / r01_v10_hbm_traffic_pmc.csv (k_eval_fused<0>): 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE correction, calibrated on k_hash_rows). "
                                            "Each window's 14 columns arrive once by LDS-DMA (66 rows per 64 points); the five windows overlap in 12 columns, which are "
                                            "fetched once per window (70 column reads for 58 distinct columns = 1.21x), the rest is the periodic table and tables of w",
                          "note": "integer-multiplier bound kernel (~1.1e4 v_mad_u64_u32 per point; the chip sustains 1.39e13/s = 2.3e12 field products/s) priced against the "
