@@ -174,6 +174,9 @@ int cstark_tx_evaluate_constraints_ext(cstark_ctx *ctx, const uint64_t *d_lde, c
 /* Measurement aid: when enabled, cstark_tx_evaluate_constraints records HIP events around each of its 9 launches
  * (Rescue windows; doubling / mixed addition of s*G; of h*P; final addition; three linear groups) on the context's
  * stream; cstark_tx_constraint_part_ms waits for the last one and returns the 9 durations in milliseconds. */
+/* Inside cstark_tx_prove (base field) the parts run as the degree-split evaluation: every part except the final
+ * addition on the even cosets only; the last figure (third linear group) then also holds the extension of the 18 merged
+ * polynomials to the odd cosets and the recombination over all cosets. */
 int cstark_ctx_set_part_timing(cstark_ctx *ctx, int enable);
 int cstark_tx_constraint_part_ms(cstark_ctx *ctx, float *ms /* [9] */);
 /* Host-side AIR description (no GPU needed): degree (base; number of 1024-row cycles) of transition constraint i
