@@ -657,7 +657,7 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         HIP_TRY(cs::launch_rounds_setup(p, c->stream));
         HIP_TRY(cs::launch_rounds_split(p, even, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[1], c->stream));
-        uint64_t *fam_dbl = even + (size_t)cs::CE_SPLIT_FAM0 * 4 * n, *fam_add = fam_dbl + 16 * n, *fam_addbit = fam_add + 16 * n;
+        uint64_t *fam_dbl = even + (size_t)cs::CE_SPLIT_FAM0 * 4 * n, *fam_add = fam_dbl + 12 * n, *fam_addbit = fam_add + 12 * n;
         HIP_TRY(cs::launch_ec_split(p, 1, fam_dbl, nullptr, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[2], c->stream));
         HIP_TRY(cs::launch_ec_split(p, 2, fam_add, nullptr, c->stream));

@@ -76,7 +76,7 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
 // part 4 = addition of the public key: its quartic half is a family of its own (d_even_family), its linear half is ADDED to the
 // addition family d_even_linear (after part 2 wrote it)
 hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, uint64_t *d_even_linear, hipStream_t stream);
-constexpr int CE_SPLIT_TABLES = 18, CE_SPLIT_FAM0 = 6; // first family (Rescue windows + linear groups): six polynomials; doubling | addition | addition x bit: four each
+constexpr int CE_SPLIT_TABLES = 14, CE_SPLIT_FAM0 = 6; // first family (Rescue windows + linear groups): six polynomials; doubling 3 | addition 3 | addition x bit 2
 // split evaluation of a linear group (part 6, 7, 8): adds to the first family, d_even_family0 = [6][4][n]
 hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream);
 hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream);

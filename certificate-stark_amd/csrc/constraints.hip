@@ -764,9 +764,10 @@ __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restr
 // grid = (n / 256, 8): out[k][j] = [ (R_a + sum_g x^adj_g R_b,g) + doubling(x) (D_a + sum_g x^adj_g D_b,g) + addition(x) (A_a + ...) ]
 //                                  * (x - w^(n-1)) / (x^n - 1).
 // (+ the fourth family with the "flag" -addition(x) * register 37, see k_ec_split; + the boundary terms).  The eighteen polynomials'
-// values come from the split evaluations (even cosets, [18][4][n]: the first family of six -- alpha, beta of groups 0..4 -- then
-// three families of four) or from their extension (odd cosets, [4 cosets][18][n]).  ADDS to p.out.
-constexpr int SPLIT_TABLES = 18, SPLIT_FAM0 = 6; // first family: alpha, beta of groups 0..4 (Rescue windows + linear groups, flags inside)
+// values come from the split evaluations (even cosets, [14][4][n]: the first family of six -- alpha, beta of groups 0..4 -- then
+// doubling (3), addition (3), addition x bit (2)) or from their extension (odd cosets, [4 cosets][14][n]).  ADDS to p.out.
+constexpr int SPLIT_TABLES = 14, SPLIT_FAM0 = 6; // first family: alpha, beta of groups 0..4 (Rescue windows + linear groups, flags inside);
+                                                 // doubling: 3, addition: 3 (alpha, beta of groups 0, 1), addition x bit: 2 (alpha, beta of group 0)
 __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
@@ -784,14 +785,11 @@ __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__re
     fp total = value(0);
 #pragma unroll
     for (int g = 0; g < 5; g++) total = fp_add(total, fp_mul(value(1 + g), xp[g]));
-    const fp fam_flag[3] = {doubling, addition, fp_neg(fp_mul(addition, col[(size_t)37 * n]))};
-#pragma unroll
-    for (int fam = 0; fam < 3; fam++) {
-        fp t = value(SPLIT_FAM0 + fam * 4);
-#pragma unroll
-        for (int g = 0; g < 3; g++) t = fp_add(t, fp_mul(value(SPLIT_FAM0 + fam * 4 + 1 + g), xp[g]));
-        total = fp_add(total, fp_mul(fam_flag[fam], t));
-    }
+    const fp dbl = fp_add(value(6), fp_add(fp_mul(value(7), xp[0]), fp_mul(value(8), xp[1])));
+    const fp add = fp_add(value(9), fp_add(fp_mul(value(10), xp[0]), fp_mul(value(11), xp[1])));
+    const fp addbit = fp_add(value(12), fp_mul(value(13), xp[0]));
+    total = fp_add(total, fp_mul(doubling, dbl));
+    total = fp_add(total, fp_mul(addition, fp_sub(add, fp_mul(col[(size_t)37 * n], addbit))));
     fp t = fp_mul(total, fp_mul(fp_sub(x, p.w_last), cc[1]));
     {   // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184), as in the last linear group
         const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
@@ -863,28 +861,31 @@ __device__ __forceinline__ void fused_final_addition(Fused<M> &acc, const Frame 
 // the S are polynomials of degree < 4n: evaluated on the even cosets only, extended like the Rescue-window polynomials and
 // multiplied by the flag at every point in k_split_finish.  (The addition of the public key and the final addition reach degree
 // 5 (n - 1) and stay on all eight cosets.)  Accumulator with the interface of Fused: slots of the curve registers are in groups 0..2.
+// The two bit registers (slots 18 and 37, the only curve slots of group 2) are left out here: their terms are quadratic at most and
+// join the flags-inside family in lin_c_split, which keeps the curve families at three (alpha, beta of groups 0, 1) / two tables.
 struct SplitAcc {
     const CS_CONST fp *coefs; // alpha[115] | beta[115]
-    Acc128 sa, sb[3];
-    int ca, cb[3];
+    Acc128 sa, sb[2];
+    int ca, cb[2];
     __device__ __forceinline__ void begin() {
         sa = acc_zero(); ca = 0;
 #pragma unroll
-        for (int g = 0; g < 3; g++) { sb[g] = acc_zero(); cb[g] = 0; }
+        for (int g = 0; g < 2; g++) { sb[g] = acc_zero(); cb[g] = 0; }
     }
     __device__ __forceinline__ void term(int i, fp v) { // i is a compile-time constant after unrolling
+        if (i == 18 || i == 37) return;
         acc_mad(sa, coefs[i], v);
         if (++ca == 7) { acc_fold(sa); ca = 0; }
         const int g = tx_degree_group(i);
 #pragma unroll
-        for (int q = 0; q < 3; q++)
+        for (int q = 0; q < 2; q++)
             if (g == q) {
                 acc_mad(sb[q], coefs[115 + i], v);
                 if (++cb[q] == 7) { acc_fold(sb[q]); cb[q] = 0; }
             }
     }
     __device__ __forceinline__ void end(fp) {}
-    __device__ __forceinline__ fp result(int q) { // 0: alpha, 1..3: beta of groups 0..2
+    __device__ __forceinline__ fp result(int q) { // 0: alpha, 1, 2: beta of groups 0, 1
         Acc128 &a = q == 0 ? sa : sb[q == 0 ? 0 : q - 1];
         acc_fold(a);
         return acc_reduce(a);
@@ -894,7 +895,8 @@ struct SplitAcc {
 //     (next - cur) - bit (add(cur, P) - cur)  =  L - bit * Q,   L = next - cur (degree n - 1),  Q = add(cur, P) - cur (degree 4 (n - 1)):
 // sum coef_i L_i joins the addition family, sum coef_i Q_i is a family of its own whose "flag" is -addition(x) * bit(x), the bit
 // being register 37 of the extended trace itself.
-// out = [4][4 even cosets][n] of this flag's family; ACCUMULATE: add to what an earlier part of the same family wrote.  grid = (n / FNT, 4)
+// out = [3 (2 for the quartic half above)][4 even cosets][n] of this flag's family; ACCUMULATE: add to what an earlier part of the same
+// family wrote.  grid = (n / FNT, 4)
 template <int PART, bool ACCUMULATE>
 __global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict__ out, fp *__restrict__ out_linear) {
     const size_t n = (size_t)1 << p.log_n;
@@ -910,9 +912,8 @@ __global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict_
         acc.begin(); // the linear half first: its four sums leave the registers before the curve arithmetic starts
 #pragma unroll
         for (int i = 0; i < 18; i++) acc.term(19 + i, fp_sub(f.next(19 + i), f.cur(19 + i)));
-        acc.term(37, fp_sub(f.cur(37), f.next(37)));
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < 2; q++) { // registers 19..36 are all in group 0
             fp *o = out_linear + ((size_t)q * 4 + kc) * n + j;
             *o = fp_add(*o, acc.result(q));
         }
@@ -926,8 +927,9 @@ __global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict_
             acc.term(31 + i, fp_sub(a.z.c[i], pt.z.c[i]));
         }
     }
+    constexpr int NQ = PART == PART_ADD1 ? 2 : 3; // the h*P registers 19..36 are all in group 0 (PART_DBL1 adds zero for group 1)
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NQ; q++) {
         fp *o = out + ((size_t)q * 4 + kc) * n + j;
         const fp v = acc.result(q);
         *o = ACCUMULATE ? fp_add(*o, v) : v;
@@ -1245,6 +1247,13 @@ __device__ __forceinline__ void lin_c_split(const CS_CONST fp *coefs, const Fram
         const fp c = f.cur(41 - i), nx = f.next(41 - i);
         s.term(41 - i, fp_add(fp_mul(fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37)))), fp_mul(fp_mul(c_not(dflag), doubling), fp_sub(c, nx))));
         s.term(38 + i, fp_add(fp_mul(addition, fp_sub(f.cur(38 + i), f.next(38 + i))), fp_mul(final_add, fp_sub(f.cur(38 + i), f.cur(42 + i)))));
+    }
+    // the bit registers of the curve gadgets (slots 18, 37: group 2), left out of the curve families: binary under `doubling`
+    // (ecc.rs:96), copied under `addition` (ecc.rs:136)
+    {
+        const fp b18 = f.cur(18), b37 = f.cur(37);
+        s.term(18, fp_add(fp_mul(doubling, c_is_binary(b18)), fp_mul(addition, fp_sub(b18, f.next(18)))));
+        s.term(37, fp_add(fp_mul(doubling, c_is_binary(b37)), fp_mul(addition, fp_sub(b37, f.next(37)))));
     }
     s.flush<G2>(FP_ONE, tot);
     s.begin();
