@@ -239,3 +239,22 @@ def test_extension_field_proofs(n_tx, depth, hash_fn, ext):
     bad[len(bad) - 40] ^= 2
     with pytest.raises(V.VerifierError):
         V.verify(bytes(bad), r0, r1)
+
+
+def test_direct_and_split_prover_paths_give_the_same_bytes():
+    """Inside cstark_tx_prove the constraints run as the degree-split evaluation and the trace is committed in overlapped column
+    batches; CSTARK_ROUNDS_SPLIT=0 / CSTARK_TRACE_OVERLAP=0 select the direct forms (read once per process, hence the child
+    process).  Both must produce the default path's proof, byte for byte."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_gpu_prove import example\n"
+            "print(hashlib.sha256(example(4, 15, seed=77).prove()).hexdigest())\n") % (root, os.path.join(root, "tests"))
+    want = hashlib.sha256(example(4, 15, seed=77).prove()).hexdigest()
+    env = dict(os.environ, CSTARK_ROUNDS_SPLIT="0", CSTARK_TRACE_OVERLAP="0")
+    got = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert got.returncode == 0, got.stderr[-2000:]
+    assert got.stdout.strip().splitlines()[-1] == want
