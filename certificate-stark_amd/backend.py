@@ -147,12 +147,19 @@ class Backend:
                                                       C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out
 
-    def evaluate_constraints(self, lde, coeffs, pub_inputs, depth, log_blowup=3, k0=0, out=None):
-        """coeffs: _lib.TxCoeffsStruct (or any ctypes struct of the same layout); pub_inputs: 4 uint64."""
+    def evaluate_constraints(self, lde, coeffs, pub_inputs, depth, log_blowup=3, k0=0, out=None, input_is_lde=False):
+        """coeffs: _lib.TxCoeffsStruct (or any ctypes struct of the same layout); pub_inputs: 4 uint64.
+        input_is_lde: the table is the extension of columns of degree < n over all 8 cosets (cstark_tx_evaluate_constraints_lde:
+        same output, degree-split evaluation)."""
         nk, width, n = lde.shape
         if out is None:
             out = self.empty_u64(nk, n)
         pub = (C.c_uint64 * 4)(*[int(v) for v in pub_inputs])
+        if input_is_lde:
+            assert k0 == 0 and nk == 8 and log_blowup == 3
+            check(self.lib.cstark_tx_evaluate_constraints_lde(self.ctx, self._ptr(lde), C.byref(coeffs), pub, self._ptr(out), C.c_uint32(depth),
+                                                              C.c_uint32(n.bit_length() - 1)))
+            return out
         check(self.lib.cstark_tx_evaluate_constraints(self.ctx, self._ptr(lde), C.byref(coeffs), pub, self._ptr(out), C.c_uint32(depth),
                                                       C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out

@@ -699,6 +699,12 @@ int cstark_tx_evaluate_constraints(cstark_ctx *c, const uint64_t *d_lde, const c
     return tx_evaluate_constraints_sets(c, d_lde, coeffs, 1, pub_inputs, outs, merkle_depth, log_n, log_blowup, k0, nk, false);
 }
 
+int cstark_tx_evaluate_constraints_lde(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, const uint64_t pub_inputs[4],
+                                       uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n) {
+    uint64_t *outs[1] = {d_out};
+    return tx_evaluate_constraints_sets(c, d_lde, coeffs, 1, pub_inputs, outs, merkle_depth, log_n, 3, 0, 8, true);
+}
+
 int cstark_tx_evaluate_constraints_ext(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
                                        uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
     if (!d_out || m < 1 || m > 3) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints_ext: bad argument");

@@ -149,10 +149,11 @@ class TransactionProver:
     def build_tree(self, nodes):
         return self.backend.merkle_build(nodes)
 
-    def evaluate_constraints(self, lde, coeffs_struct, pub_inputs4, k0=0):
+    def evaluate_constraints(self, lde, coeffs_struct, pub_inputs4, k0=0, input_is_lde=False):
+        """input_is_lde: `lde` is this prover's own extension of the whole trace (all cosets): degree-split evaluation, same values."""
         n = lde.shape[2]
         return self.backend.evaluate_constraints(lde, coeffs_struct, pub_inputs4, self.depth, self.options.log_blowup, k0=k0,
-                                                 out=self._buf("combined", (lde.shape[0], n)))
+                                                 out=self._buf("combined", (lde.shape[0], n)), input_is_lde=input_is_lde)
 
     # -- Prover::prove as called at src/lib.rs:140 (trace generation included: the trace never leaves HBM)
     def prove(self, tx_metadata=None):

@@ -165,6 +165,12 @@ int cstark_tx_evaluate_transitions(cstark_ctx *ctx, const uint64_t *d_lde, uint6
 int cstark_tx_evaluate_constraints(cstark_ctx *ctx, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs,
                                    const uint64_t pub_inputs[4], uint64_t *d_out, uint32_t merkle_depth,
                                    uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* The same result for a table that IS the low-degree extension of 94 columns of degree < n over all 8 cosets (k0 = 0, nk = 8), e.g.
+ * the output of cstark_lde_columns: allows the degree-split evaluation the prover uses (every part except the final
+ * addition on the even cosets only, their merged polynomials extended to the odd cosets).  On such a table the output equals
+ * cstark_tx_evaluate_constraints bit for bit; on any other table it is undefined (use cstark_tx_evaluate_constraints). */
+int cstark_tx_evaluate_constraints_lde(cstark_ctx *ctx, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs,
+                                       const uint64_t pub_inputs[4], uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n);
 /* The same for m = 1..3 coefficient sets in ONE pass over the frame (the components of a FieldExtension::Quadratic / Cubic
  * proof: extension coefficients multiply base-field constraint values, so the values are computed once and merged m times).
  * coeffs: m consecutive blocks; d_out[(q * nk + (k - k0)) * n + j] = the merged evaluations for block q. */

@@ -95,3 +95,24 @@ def test_misaligned_lde_is_refused(backend):
     assert lde.data_ptr() % 16 == 8
     with pytest.raises(CstarkError):
         backend.evaluate_constraints(lde, O.make_coeffs(1), [0, 0, 0, 0], 3)
+
+
+@pytest.mark.parametrize("n_tx,depth", [(1, 3), (4, 15)])
+def test_degree_split_evaluation_matches_on_a_genuine_extension(oracle, backend, n_tx, depth):
+    """cstark_tx_evaluate_constraints_lde: on the extension of a real trace the degree-split evaluation (even cosets, extension of
+    the merged polynomials, recombination) gives the oracle's values bit for bit -- also for a trace that violates the constraints
+    (a perturbed TRACE cell: still columns of degree < n, which is all the split relies on)."""
+    from certificate_stark_amd.backend import to_numpy_u64
+    w = oracle.TxWitness.generate(n_tx, depth, seed=91 + n_tx)
+    trace = oracle.tx_build_trace(w)
+    cf = oracle.make_coeffs(23)
+    pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
+    for perturb in (False, True):
+        t = trace.copy()
+        if perturb:
+            t[17, 5] ^= np.uint64(1)
+            t[70, 900] ^= np.uint64(3)
+        lde = oracle.lde_columns(oracle.interpolate_columns(t), 3)
+        ref = oracle.tx_evaluate_constraints(lde, cf, pub, depth, 3)
+        got = to_numpy_u64(backend.evaluate_constraints(backend.from_numpy_u64(lde), cf, pub, depth, input_is_lde=True))
+        assert (got == ref).all(), "perturbed" if perturb else "valid"
