@@ -637,13 +637,14 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
     hipEvent_t *pev = c->part_timing ? c->part_ev : nullptr;
     // input_is_lde: d_lde is the extension of columns of degree < n (the prover's own table), which the split evaluation relies on;
     // the public stage entry points evaluate every point directly and are exact for ANY table
-    if (split_env && input_is_lde && m == 1 && k0 == 0 && nk == 8) {
+    static const bool split_ext_env = [] { const char *e = getenv("CSTARK_ROUNDS_SPLIT_EXT"); return !e || atoi(e) != 0; }();
+    if (split_env && input_is_lde && (m == 1 || split_ext_env) && k0 == 0 && nk == 8) {
         // Parts whose merged polynomials have degree < 4n (constraints.hip: the Rescue windows with their flags; the doublings and the
         // addition of the generator with the flag factored out) run on the even cosets only; their twelve polynomials are
         // interpolated over that 4n-point sub-domain, extended to the odd cosets by transforms of twelve columns and recombined
         // at every point.  (Part timing: the extension and the recombination are counted with the last of these parts.)
         const size_t n = (size_t)1 << log_n;
-        constexpr unsigned T = cs::CE_SPLIT_TABLES;
+        const unsigned T = cs::CE_SPLIT_TABLES * m; // every coefficient set has its own block of polynomials
         const NttPlan *pn, *p4, *p8;
         const CosetTable *t1;
         RC_TRY(get_plan(c, log_n, &pn));
@@ -666,7 +667,7 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         if (pev) HIP_TRY(hipEventRecord(pev[4], c->stream));
         HIP_TRY(cs::launch_ec_split(p, 4, fam_addbit, fam_add, c->stream));
         // the final addition reaches degree 5 (n - 1): all cosets, accumulated into the zero-filled output first
-        HIP_TRY(hipMemsetAsync(p.out, 0, 8 * n * 8, c->stream));
+        for (uint32_t q = 0; q < m; q++) HIP_TRY(hipMemsetAsync(d_outs[q], 0, 8 * n * 8, c->stream));
         HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev, 0x1FFu & ~(1u << 5), false));
         for (int part = 6; part <= 8; part++) {
             if (pev) HIP_TRY(hipEventRecord(pev[part], c->stream));

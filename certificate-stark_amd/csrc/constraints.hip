@@ -670,10 +670,16 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
 // the windows), interpolated there, extended to the odd cosets by transforms of four columns (capi.hip), and recombined with
 // x^adj_g and the transition divisor at every point (k_rounds_finish).  Exact arithmetic: the same merged evaluations.
 // out = [6 polynomials][4 even cosets][n] (alpha, beta of groups 0..4; this kernel initialises all six).  grid = (n / FNT, 4)
-__global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restrict__ out) {
+constexpr int SPLIT_TABLES = 14, SPLIT_FAM0 = 6; // first family: alpha, beta of groups 0..4 (Rescue windows + linear groups, flags inside);
+                                                 // doubling: 3, addition: 3 (alpha, beta of groups 0, 1), addition x bit: 2 (alpha, beta of group 0)
+// M coefficient sets (the components of an extension proof): the windows' values are computed once, every set has its own tables
+// (rtab + c * CE_RTAB_WORDS) and its own block of SPLIT_TABLES output polynomials (out + c * SPLIT_TABLES * 4 n).
+template <int M>
+__global__ __launch_bounds__(FNT, M == 1 ? 3 : 2) void k_rounds_split(CeParams p, fp *__restrict__ out) {
     __shared__ fp ark2_lds[8 * 14];
     __shared__ __attribute__((aligned(16))) fp img_lds[(FNT / 64) * RW_IMG];
-    __shared__ fp atab_lds[RT_SECTIONS * 8];
+    __shared__ fp atab_lds[M * RT_SECTIONS * 8];
+    __shared__ fp s2_lds[M == 1 ? 1 : (FNT / 64) * 14 * 64]; // several sets: the window's cubes, one column per lane
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kc = blockIdx.y, kk = 2 * kc; // the launcher guarantees k0 = 0 and all cosets present
@@ -682,7 +688,10 @@ __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restr
         const unsigned r = threadIdx.x / 14, c = threadIdx.x % 14;
         ark2_lds[threadIdx.x] = p.ptab[((size_t)kk * 48 + P_ARK + 14 + c) * 1024 + ((blockIdx.x * (size_t)FNT + r) & 1023)];
     }
-    for (unsigned e = threadIdx.x; e < RT_SECTIONS * 8; e += FNT) atab_lds[e] = p.rtab[RT_A + (e >> 3) * 64 + kk * 8 + (e & 7)];
+    for (unsigned e = threadIdx.x; e < M * RT_SECTIONS * 8; e += FNT) {
+        const unsigned c = e / (RT_SECTIONS * 8), r = e % (RT_SECTIONS * 8);
+        atab_lds[e] = p.rtab[(size_t)c * CE_RTAB_WORDS + RT_A + (r >> 3) * 64 + kk * 8 + (r & 7)];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const unsigned jr = (unsigned)(j & 7);
@@ -695,7 +704,11 @@ __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restr
     const fp *rows = f.cur_p + lane;
     if (lane == 32 && ((size_t)(f.cur_p - lane + 64 - colbase) & (n - 1)) == 0) rows -= n;
     rounds_fetch_window(rows, n, c_windows[0].reg, lane, img);
-    fp tot[4] = {0, 0, 0, 0}; // R_alpha, R_beta of groups 0, 1, 2
+    fp tot[M][4]; // per set: R_alpha, R_beta of groups 0, 1, 2
+#pragma unroll
+    for (int c = 0; c < M; c++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) tot[c][q] = 0;
 #pragma unroll 1
     for (int wdx = 0; wdx < 5; wdx++) {
         const RoundWindow w = c_windows[wdx];
@@ -705,15 +718,21 @@ __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restr
         fp d[14];
 #pragma unroll
         for (int jj = 0; jj < 14; jj++) d[jj] = fp_sub(img[jj * RW_ROWS + lane + 1], ark2[jj]);
-        // inverse half: cube(INV_MDS d)_i against the coefficient vector of every section (alpha, beta of each group present)
+        // inverse half: cube(INV_MDS d)_i against the coefficient vector of every section (alpha, beta of each group present).
+        // One set: accumulated as the cubes are produced.  Several sets: the 14 cubes are parked in a wave-private LDS column and
+        // every set runs its own pass over them (8 accumulators live at a time instead of 8 M: no spills).
         Acc128 s[2][4];
+        fp *s2w = s2_lds + (threadIdx.x >> 6) * 14 * 64 + lane;
+        if (M == 1) {
 #pragma unroll
-        for (int fs = 0; fs < 2; fs++)
+            for (int fs = 0; fs < 2; fs++)
 #pragma unroll
-            for (int sl = 0; sl < 4; sl++) s[fs][sl] = acc_zero();
+                for (int sl = 0; sl < 4; sl++) s[fs][sl] = acc_zero();
+        }
 #pragma unroll 1
         for (int i = 0; i < 14; i++) {
             const fp s2 = fp_cube(dot14l(ml + i * 56, d));
+            if (M > 1) { s2w[i * 64] = s2; continue; }
 #pragma unroll
             for (int fs = 0; fs < 2; fs++) {
                 if (fs == 1 && w.flag_b < 0) continue;
@@ -736,29 +755,58 @@ __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restr
             rounds_fetch_window(rows, n, c_windows[wdx + 1].reg, lane, img);
         }
 #pragma unroll
-        for (int fs = 0; fs < 2; fs++) {
-            if (fs == 1 && w.flag_b < 0) continue;
-            const int sec = (wdx * 2 + fs) * 4;
-            const int fl = fs ? w.flag_b : w.flag_a;
-            const fp flag = fl == 0 ? flags[0] : fl == 1 ? flags[1] : fl == 2 ? flags[2] : flags[3];
+        for (int c = 0; c < M; c++) {
+            if (M > 1) {
 #pragma unroll
-            for (int sl = 0; sl < 4; sl++) {
-                const int g = sl == 0 ? -2 : sl == 1 ? g0[fs] : sl == 2 ? g1[fs] : g2[fs];
-                if (g == -1) continue;
-                acc_fold(s[fs][sl]);
-                const fp fwd = fp_add(dot14l(ul + (sec + sl) * 56, cube), atab[(sec + sl) * 8]);
-                const fp v = fp_mul(flag, fp_sub(acc_reduce(s[fs][sl]), fwd));
-                if (sl == 0) tot[0] = fp_add(tot[0], v);
-                else {
-                    if (g == 0) tot[1] = fp_add(tot[1], v);
-                    if (g == 1) tot[2] = fp_add(tot[2], v);
-                    if (g == 2) tot[3] = fp_add(tot[3], v);
+                for (int fs = 0; fs < 2; fs++)
+#pragma unroll
+                    for (int sl = 0; sl < 4; sl++) s[fs][sl] = acc_zero();
+#pragma unroll 1
+                for (int i = 0; i < 14; i++) {
+                    const fp s2 = s2w[i * 64];
+#pragma unroll
+                    for (int fs = 0; fs < 2; fs++) {
+                        if (fs == 1 && w.flag_b < 0) continue;
+                        const CS_CONST fp *gs = gt + (size_t)c * CE_RTAB_WORDS + (wdx * 2 + fs) * 4 * 14 + i;
+                        acc_mad(s[fs][0], gs[0], s2);
+                        if (g0[fs] >= 0) acc_mad(s[fs][1], gs[14], s2);
+                        if (g1[fs] >= 0) acc_mad(s[fs][2], gs[28], s2);
+                        if (g2[fs] >= 0) acc_mad(s[fs][3], gs[42], s2);
+                        if (i == 6) {
+#pragma unroll
+                            for (int sl = 0; sl < 4; sl++) acc_fold(s[fs][sl]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int fs = 0; fs < 2; fs++) {
+                if (fs == 1 && w.flag_b < 0) continue;
+                const int sec = (wdx * 2 + fs) * 4;
+                const int fl = fs ? w.flag_b : w.flag_a;
+                const fp flag = fl == 0 ? flags[0] : fl == 1 ? flags[1] : fl == 2 ? flags[2] : flags[3];
+#pragma unroll
+                for (int sl = 0; sl < 4; sl++) {
+                    const int g = sl == 0 ? -2 : sl == 1 ? g0[fs] : sl == 2 ? g1[fs] : g2[fs];
+                    if (g == -1) continue;
+                    acc_fold(s[fs][sl]);
+                    const fp fwd = fp_add(dot14l(ul + (size_t)c * CE_RTAB_WORDS * 2 + (sec + sl) * 56, cube), atab[(c * RT_SECTIONS + sec + sl) * 8]);
+                    const fp v = fp_mul(flag, fp_sub(acc_reduce(s[fs][sl]), fwd));
+                    if (sl == 0) tot[c][0] = fp_add(tot[c][0], v);
+                    else {
+                        if (g == 0) tot[c][1] = fp_add(tot[c][1], v);
+                        if (g == 1) tot[c][2] = fp_add(tot[c][2], v);
+                        if (g == 2) tot[c][3] = fp_add(tot[c][3], v);
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int q = 0; q < 6; q++) out[((size_t)q * 4 + kc) * n + j] = q < 4 ? tot[q] : 0; // groups 3, 4: written by the linear groups
+    for (int c = 0; c < M; c++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) // groups 3, 4: zero here, written by the linear groups
+            out[(((size_t)c * SPLIT_TABLES + q) * 4 + kc) * n + j] = q < 4 ? tot[c][q] : 0;
 }
 
 // grid = (n / 256, 8): out[k][j] = [ (R_a + sum_g x^adj_g R_b,g) + doubling(x) (D_a + sum_g x^adj_g D_b,g) + addition(x) (A_a + ...) ]
@@ -766,8 +814,7 @@ __global__ __launch_bounds__(FNT, 3) void k_rounds_split(CeParams p, fp *__restr
 // (+ the fourth family with the "flag" -addition(x) * register 37, see k_ec_split; + the boundary terms).  The eighteen polynomials'
 // values come from the split evaluations (even cosets, [14][4][n]: the first family of six -- alpha, beta of groups 0..4 -- then
 // doubling (3), addition (3), addition x bit (2)) or from their extension (odd cosets, [4 cosets][14][n]).  ADDS to p.out.
-constexpr int SPLIT_TABLES = 14, SPLIT_FAM0 = 6; // first family: alpha, beta of groups 0..4 (Rescue windows + linear groups, flags inside);
-                                                 // doubling: 3, addition: 3 (alpha, beta of groups 0, 1), addition x bit: 2 (alpha, beta of group 0)
+template <int M>
 __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
@@ -781,27 +828,35 @@ __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__re
     const fp doubling = per[(size_t)P_DOUBLING * 1024], scalar_mult = per[(size_t)P_SCALAR_MULT * 1024];
     const fp addition = fp_mul(c_not(doubling), scalar_mult);
     const fp *col = p.lde + (size_t)k * 94 * n + j;
-    auto value = [&](int tb) { return (k & 1) ? odd[((size_t)(k >> 1) * SPLIT_TABLES + tb) * n + j] : even[((size_t)tb * 4 + (k >> 1)) * n + j]; };
-    fp total = value(0);
+    const fp bit37 = col[(size_t)37 * n], r58 = col[(size_t)58 * n], r59 = col[(size_t)59 * n];
+    const fp divisor = fp_mul(fp_sub(x, p.w_last), cc[1]);
+    const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
+    const fp *bi = p.binv + (size_t)k * 2 * n + j;
+    const fp bi0 = bi[0], bi1 = bi[n];
+    constexpr int T = M * SPLIT_TABLES; // tables per coset in `odd`
 #pragma unroll
-    for (int g = 0; g < 5; g++) total = fp_add(total, fp_mul(value(1 + g), xp[g]));
-    const fp dbl = fp_add(value(6), fp_add(fp_mul(value(7), xp[0]), fp_mul(value(8), xp[1])));
-    const fp add = fp_add(value(9), fp_add(fp_mul(value(10), xp[0]), fp_mul(value(11), xp[1])));
-    const fp addbit = fp_add(value(12), fp_mul(value(13), xp[0]));
-    total = fp_add(total, fp_mul(doubling, dbl));
-    total = fp_add(total, fp_mul(addition, fp_sub(add, fp_mul(col[(size_t)37 * n], addbit))));
-    fp t = fp_mul(total, fp_mul(fp_sub(x, p.w_last), cc[1]));
-    {   // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184), as in the last linear group
-        const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
-        const fp *ba = p.coef + 230, *bb = ba + 4;
-        const fp r58 = col[(size_t)58 * n], r59 = col[(size_t)59 * n];
+    for (int c = 0; c < M; c++) {
+        auto value = [&](int tb) {
+            const int t = c * SPLIT_TABLES + tb;
+            return (k & 1) ? odd[((size_t)(k >> 1) * T + t) * n + j] : even[((size_t)t * 4 + (k >> 1)) * n + j];
+        };
+        fp total = value(0);
+#pragma unroll
+        for (int g = 0; g < 5; g++) total = fp_add(total, fp_mul(value(1 + g), xp[g]));
+        const fp dbl = fp_add(value(6), fp_add(fp_mul(value(7), xp[0]), fp_mul(value(8), xp[1])));
+        const fp add = fp_add(value(9), fp_add(fp_mul(value(10), xp[0]), fp_mul(value(11), xp[1])));
+        const fp addbit = fp_add(value(12), fp_mul(value(13), xp[0]));
+        total = fp_add(total, fp_mul(doubling, dbl));
+        total = fp_add(total, fp_mul(addition, fp_sub(add, fp_mul(bit37, addbit))));
+        fp t = fp_mul(total, divisor);
+        // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184), as in the last linear group
+        const fp *ba = p.coef + c * CE_COEF_WORDS + 230, *bb = ba + 4;
         const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
         const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
-        const fp *bi = p.binv + (size_t)k * 2 * n + j;
-        t = fp_add(t, fp_add(fp_mul(first, bi[0]), fp_mul(last, bi[n])));
+        t = fp_add(t, fp_add(fp_mul(first, bi0), fp_mul(last, bi1)));
+        fp *o = (c == 0 ? p.out : p.out_ext[c == 0 ? 0 : c - 1]) + (size_t)k * n + j;
+        *o = fp_add(*o, t); // the final addition (all cosets) was accumulated into the zero-filled table before
     }
-    fp *o = p.out + (size_t)k * n + j;
-    *o = fp_add(*o, t); // the final addition (all cosets) was accumulated into the zero-filled table before
 }
 
 // doubling gadget for the point at registers [reg, reg + 19)  (ecc.rs:73-98)
@@ -863,30 +918,41 @@ __device__ __forceinline__ void fused_final_addition(Fused<M> &acc, const Frame 
 // 5 (n - 1) and stay on all eight cosets.)  Accumulator with the interface of Fused: slots of the curve registers are in groups 0..2.
 // The two bit registers (slots 18 and 37, the only curve slots of group 2) are left out here: their terms are quadratic at most and
 // join the flags-inside family in lin_c_split, which keeps the curve families at three (alpha, beta of groups 0, 1) / two tables.
+template <int M>
 struct SplitAcc {
-    const CS_CONST fp *coefs; // alpha[115] | beta[115]
-    Acc128 sa, sb[2];
+    const CS_CONST fp *coefs; // M blocks of CE_COEF_WORDS: alpha[115] | beta[115] | ...
+    Acc128 sa[M], sb[M][2];
     int ca, cb[2];
     __device__ __forceinline__ void begin() {
-        sa = acc_zero(); ca = 0;
+        ca = cb[0] = cb[1] = 0;
 #pragma unroll
-        for (int g = 0; g < 2; g++) { sb[g] = acc_zero(); cb[g] = 0; }
+        for (int c = 0; c < M; c++) sa[c] = sb[c][0] = sb[c][1] = acc_zero();
     }
     __device__ __forceinline__ void term(int i, fp v) { // i is a compile-time constant after unrolling
         if (i == 18 || i == 37) return;
-        acc_mad(sa, coefs[i], v);
-        if (++ca == 7) { acc_fold(sa); ca = 0; }
+        const bool fa = ++ca == 7;
+#pragma unroll
+        for (int c = 0; c < M; c++) {
+            acc_mad(sa[c], coefs[c * CE_COEF_WORDS + i], v);
+            if (fa) acc_fold(sa[c]);
+        }
+        if (fa) ca = 0;
         const int g = tx_degree_group(i);
 #pragma unroll
         for (int q = 0; q < 2; q++)
             if (g == q) {
-                acc_mad(sb[q], coefs[115 + i], v);
-                if (++cb[q] == 7) { acc_fold(sb[q]); cb[q] = 0; }
+                const bool fb = ++cb[q] == 7;
+#pragma unroll
+                for (int c = 0; c < M; c++) {
+                    acc_mad(sb[c][q], coefs[c * CE_COEF_WORDS + 115 + i], v);
+                    if (fb) acc_fold(sb[c][q]);
+                }
+                if (fb) cb[q] = 0;
             }
     }
     __device__ __forceinline__ void end(fp) {}
-    __device__ __forceinline__ fp result(int q) { // 0: alpha, 1, 2: beta of groups 0, 1
-        Acc128 &a = q == 0 ? sa : sb[q == 0 ? 0 : q - 1];
+    __device__ __forceinline__ fp result(int c, int q) { // 0: alpha, 1, 2: beta of groups 0, 1
+        Acc128 &a = q == 0 ? sa[c] : sb[c][q == 0 ? 0 : q - 1];
         acc_fold(a);
         return acc_reduce(a);
     }
@@ -897,14 +963,15 @@ struct SplitAcc {
 // being register 37 of the extended trace itself.
 // out = [3 (2 for the quartic half above)][4 even cosets][n] of this flag's family; ACCUMULATE: add to what an earlier part of the same
 // family wrote.  grid = (n / FNT, 4)
-template <int PART, bool ACCUMULATE>
+template <int PART, bool ACCUMULATE, int M>
 __global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict__ out, fp *__restrict__ out_linear) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kc = blockIdx.y;
     const Frame f = make_frame(p, 2 * kc, j); // the launcher guarantees k0 = 0 and all cosets present
-    SplitAcc acc;
+    SplitAcc<M> acc;
     acc.coefs = as_const(p.coef);
+    constexpr size_t SET = (size_t)SPLIT_TABLES * 4; // tables (x n words) between the blocks of two coefficient sets
     if (PART == PART_DBL0) fused_doubling(acc, f, 0, (fp)0);
     if (PART == PART_DBL1) fused_doubling(acc, f, 19, (fp)0);
     if (PART == PART_ADD0) fused_addition(acc, f, 0, const6(c_generator), const6(c_generator + 6), (fp)0);
@@ -913,10 +980,12 @@ __global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict_
 #pragma unroll
         for (int i = 0; i < 18; i++) acc.term(19 + i, fp_sub(f.next(19 + i), f.cur(19 + i)));
 #pragma unroll
-        for (int q = 0; q < 2; q++) { // registers 19..36 are all in group 0
-            fp *o = out_linear + ((size_t)q * 4 + kc) * n + j;
-            *o = fp_add(*o, acc.result(q));
-        }
+        for (int c = 0; c < M; c++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) { // registers 19..36 are all in group 0
+                fp *o = out_linear + (c * SET + (size_t)q * 4 + kc) * n + j;
+                *o = fp_add(*o, acc.result(c, q));
+            }
         const Point pt = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
         const Point a = ec_add_mixed<CS_EC_CALL>(pt, load6(f, S_KEY, true), load6(f, S_KEY + 6, true)); // pkey = next[S_KEY..], src/air.rs:575
         acc.begin();
@@ -929,11 +998,13 @@ __global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict_
     }
     constexpr int NQ = PART == PART_ADD1 ? 2 : 3; // the h*P registers 19..36 are all in group 0 (PART_DBL1 adds zero for group 1)
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        fp *o = out + ((size_t)q * 4 + kc) * n + j;
-        const fp v = acc.result(q);
-        *o = ACCUMULATE ? fp_add(*o, v) : v;
-    }
+    for (int c = 0; c < M; c++)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            fp *o = out + (c * SET + (size_t)q * 4 + kc) * n + j;
+            const fp v = acc.result(c, q);
+            *o = ACCUMULATE ? fp_add(*o, v) : v;
+        }
 }
 
 template <int M>
@@ -1284,16 +1355,19 @@ __device__ __forceinline__ void lin_c_split(const CS_CONST fp *coefs, const Fram
     s.flush<G4>(range_finish, tot);
 }
 // adds to the six polynomials of the first family (alpha, beta of groups 0..4): out = [6][4 even cosets][n].  grid = (n / FNT, 4)
+// (extension proofs: one launch per coefficient set `set`; these groups are cheap and bandwidth-bound, nothing is worth sharing)
 template <int PART>
-__global__ __launch_bounds__(FNT, PART == PART_LIN_C ? 2 : 4) void k_lin_split(CeParams p, fp *__restrict__ out) {
+__global__ __launch_bounds__(FNT, PART == PART_LIN_C ? 2 : 4) void k_lin_split(CeParams p, fp *__restrict__ out, unsigned set) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kc = blockIdx.y;
     const Frame f = make_frame(p, 2 * kc, j);
+    out += (size_t)set * SPLIT_TABLES * 4 * n;
+    const CS_CONST fp *coefs = as_const(p.coef + (size_t)set * CE_COEF_WORDS);
     fp tot[6] = {0, 0, 0, 0, 0, 0};
-    if (PART == PART_LIN_A) lin_a_split(as_const(p.coef), f, tot);
-    if (PART == PART_LIN_B) lin_b_split(as_const(p.coef), f, tot);
-    if (PART == PART_LIN_C) lin_c_split(as_const(p.coef), f, tot);
+    if (PART == PART_LIN_A) lin_a_split(coefs, f, tot);
+    if (PART == PART_LIN_B) lin_b_split(coefs, f, tot);
+    if (PART == PART_LIN_C) lin_c_split(coefs, f, tot);
 #pragma unroll
     for (int q = 0; q < 6; q++) {
         const bool touched = PART == PART_LIN_A ? (q == 0 || q == 5) : true;
@@ -1591,31 +1665,48 @@ hipError_t launch_rounds_setup(const CeParams &p, hipStream_t stream) {
 }
 hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    hipLaunchKernelGGL(k_rounds_split, dim3((unsigned)(n / FNT), 4), dim3(FNT), 0, stream, p, d_even);
+    const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
+    const unsigned m = p.m ? p.m : 1;
+    if (m == 1) hipLaunchKernelGGL(k_rounds_split<1>, grid, block, 0, stream, p, d_even);
+    else if (m == 2) hipLaunchKernelGGL(k_rounds_split<2>, grid, block, 0, stream, p, d_even);
+    else if (m == 3) hipLaunchKernelGGL(k_rounds_split<3>, grid, block, 0, stream, p, d_even);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, uint64_t *d_even_linear, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
-    if (part == PART_DBL0) hipLaunchKernelGGL((k_ec_split<PART_DBL0, false>), grid, block, 0, stream, p, d_even_family, d_even_linear);
-    else if (part == PART_DBL1) hipLaunchKernelGGL((k_ec_split<PART_DBL1, true>), grid, block, 0, stream, p, d_even_family, d_even_linear);
-    else if (part == PART_ADD0) hipLaunchKernelGGL((k_ec_split<PART_ADD0, false>), grid, block, 0, stream, p, d_even_family, d_even_linear);
-    else if (part == PART_ADD1) hipLaunchKernelGGL((k_ec_split<PART_ADD1, false>), grid, block, 0, stream, p, d_even_family, d_even_linear);
+    const unsigned m = p.m ? p.m : 1;
+#define CS_EC(M)                                                                                                                                      \
+    if (part == PART_DBL0) hipLaunchKernelGGL((k_ec_split<PART_DBL0, false, M>), grid, block, 0, stream, p, d_even_family, d_even_linear);           \
+    else if (part == PART_DBL1) hipLaunchKernelGGL((k_ec_split<PART_DBL1, true, M>), grid, block, 0, stream, p, d_even_family, d_even_linear);       \
+    else if (part == PART_ADD0) hipLaunchKernelGGL((k_ec_split<PART_ADD0, false, M>), grid, block, 0, stream, p, d_even_family, d_even_linear);      \
+    else if (part == PART_ADD1) hipLaunchKernelGGL((k_ec_split<PART_ADD1, false, M>), grid, block, 0, stream, p, d_even_family, d_even_linear);      \
     else return hipErrorInvalidValue;
+    if (m == 1) { CS_EC(1) } else if (m == 2) { CS_EC(2) } else if (m == 3) { CS_EC(3) } else return hipErrorInvalidValue;
+#undef CS_EC
     return hipGetLastError();
 }
 hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
-    if (part == PART_LIN_A) hipLaunchKernelGGL(k_lin_split<PART_LIN_A>, grid, block, 0, stream, p, d_even_family0);
-    else if (part == PART_LIN_B) hipLaunchKernelGGL(k_lin_split<PART_LIN_B>, grid, block, 0, stream, p, d_even_family0);
-    else if (part == PART_LIN_C) hipLaunchKernelGGL(k_lin_split<PART_LIN_C>, grid, block, 0, stream, p, d_even_family0);
-    else return hipErrorInvalidValue;
+    const unsigned m = p.m ? p.m : 1;
+    for (unsigned set = 0; set < m; set++) {
+        if (part == PART_LIN_A) hipLaunchKernelGGL(k_lin_split<PART_LIN_A>, grid, block, 0, stream, p, d_even_family0, set);
+        else if (part == PART_LIN_B) hipLaunchKernelGGL(k_lin_split<PART_LIN_B>, grid, block, 0, stream, p, d_even_family0, set);
+        else if (part == PART_LIN_C) hipLaunchKernelGGL(k_lin_split<PART_LIN_C>, grid, block, 0, stream, p, d_even_family0, set);
+        else return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    hipLaunchKernelGGL(k_split_finish, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd);
+    const dim3 grid((unsigned)(n / 256), 8), block(256);
+    const unsigned m = p.m ? p.m : 1;
+    if (m == 1) hipLaunchKernelGGL(k_split_finish<1>, grid, block, 0, stream, p, d_even, d_odd);
+    else if (m == 2) hipLaunchKernelGGL(k_split_finish<2>, grid, block, 0, stream, p, d_even, d_odd);
+    else if (m == 3) hipLaunchKernelGGL(k_split_finish<3>, grid, block, 0, stream, p, d_even, d_odd);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
