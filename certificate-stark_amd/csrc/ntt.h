@@ -34,14 +34,12 @@ hipError_t interleave_cosets(const uint64_t *d_in, uint64_t *d_out, unsigned log
 //   a_{q + n i} = (1 / B) sum_k w_B^(-k i) (w_N^(-k q) B_k[q]),   N = B n;  winv_N = powers of w_N^-1.
 hipError_t coset_combine(const uint64_t *d_b, uint64_t *d_h, unsigned log_n, unsigned log_b, const uint64_t *d_winv_N, uint64_t b_inv,
                          hipStream_t stream, unsigned tables = 1);
-// The way back for a polynomial of degree < 4n given by its coefficients a[4n] (of P(g y)): the inputs of the n-point transforms
-// that evaluate it on the ODD cosets of the 8n-point domain, d_out[k'][table][q] = sum_{i<4} w_8^((2k'+1) i) a[table][q + n i]
-// (the coset twist w_8n^((2k'+1) q) is the transform's prescale table).  d_w_8n = powers of w_8n.
-// coset_combine (log_b = 2) and coset_spread_odd in one pass, the 4n coefficients never written: d_b [tables][4][n] (interpolants of
-// the even cosets) -> d_out [4 odd cosets][tables][n].  d_winv_4n = powers of w_4n^-1, d_w_8n = powers of w_8n, quarter = 1/4.
+// The way to the odd cosets for polynomials of degree < 4n given by the interpolants of the four even cosets (d_b [tables][4][n]):
+// coset_combine with log_b = 2 (coefficients a_t of P(g y), t = q + n i) followed by b_k'[q] = sum_{i<4} w_8^((2k'+1) i) a_{q + n i}, the
+// inputs of the n-point transforms over the odd cosets (whose prescale table supplies the twist w_8n^((2k'+1) q)), in one pass: the
+// 4n coefficients are never written.  d_out [4 odd cosets][tables][n]; d_winv_4n = powers of w_4n^-1, d_w_8n = powers of w_8n, quarter = 1/4.
 hipError_t coset_even_to_odd(const uint64_t *d_b, uint64_t *d_out, unsigned log_n, unsigned tables, const uint64_t *d_winv_4n, const uint64_t *d_w_8n,
                              uint64_t quarter, hipStream_t stream);
-hipError_t coset_spread_odd(const uint64_t *d_a, uint64_t *d_out, unsigned log_n, unsigned tables, const uint64_t *d_w_8n, hipStream_t stream);
 hipError_t split_columns(const uint64_t *d_h, uint64_t *d_out, unsigned log_n, unsigned log_b, uint64_t ginv, hipStream_t stream);
 
 } // namespace cs

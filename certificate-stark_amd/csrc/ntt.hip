@@ -398,24 +398,6 @@ __global__ __launch_bounds__(256) void k_coset_combine(const fp *__restrict__ in
         out[(size_t)i * n + q] = acc_reduce(a);
     }
 }
-__global__ __launch_bounds__(256) void k_coset_spread_odd(const fp *__restrict__ a, fp *__restrict__ out, size_t n, unsigned tables, const fp *__restrict__ w8n) {
-    const size_t q = blockIdx.x * (size_t)256 + threadIdx.x;
-    if (q >= n) return;
-    const unsigned tb = blockIdx.y;
-    fp c[4], w8[8];
-#pragma unroll
-    for (int i = 0; i < 4; i++) c[i] = a[((size_t)tb * 4 + i) * n + q];
-#pragma unroll
-    for (int e = 0; e < 8; e++) w8[e] = w8n[(size_t)e * n]; // w_8^e
-#pragma unroll
-    for (int kc = 0; kc < 4; kc++) {
-        const int k = 2 * kc + 1;
-        fp v = c[0];
-#pragma unroll
-        for (int i = 1; i < 4; i++) v = fp_add(v, fp_mul(c[i], w8[(k * i) & 7]));
-        out[((size_t)kc * tables + tb) * n + q] = v;
-    }
-}
 __global__ __launch_bounds__(256) void k_coset_even_to_odd(const fp *__restrict__ in, fp *__restrict__ out, size_t n, unsigned tables,
                                                            const fp *__restrict__ winv4n, const fp *__restrict__ w8n, fp quarter) {
     const size_t q = blockIdx.x * (size_t)256 + threadIdx.x;
@@ -450,11 +432,6 @@ hipError_t coset_even_to_odd(const fp *d_b, fp *d_out, unsigned log_n, unsigned 
                              hipStream_t stream) {
     const size_t n = (size_t)1 << log_n;
     hipLaunchKernelGGL(k_coset_even_to_odd, dim3((unsigned)((n + 255) / 256), tables), dim3(256), 0, stream, d_b, d_out, n, tables, d_winv_4n, d_w_8n, quarter);
-    return hipGetLastError();
-}
-hipError_t coset_spread_odd(const fp *d_a, fp *d_out, unsigned log_n, unsigned tables, const fp *d_w_8n, hipStream_t stream) {
-    const size_t n = (size_t)1 << log_n;
-    hipLaunchKernelGGL(k_coset_spread_odd, dim3((unsigned)((n + 255) / 256), tables), dim3(256), 0, stream, d_a, d_out, n, tables, d_w_8n);
     return hipGetLastError();
 }
 hipError_t coset_combine(const fp *d_b, fp *d_h, unsigned log_n, unsigned log_b, const fp *d_winv_N, fp b_inv, hipStream_t stream, unsigned tables) {
