@@ -27,6 +27,9 @@ namespace {
 constexpr int TXC = 1024;       // TRANSACTION_CYCLE_LENGTH, src/constants.rs:83
 constexpr int MERKLE_LEN = 512; // src/merkle/constants.rs:29
 constexpr unsigned LADDER_LDS_PAD = 0;
+#ifndef CS_RECUR_TILE_ROWS
+#define CS_RECUR_TILE_ROWS 16 // staging rows of the Merkle / message-hash recurrences in the overlapped path
+#endif
 constexpr int SCALAR_MUL_LEN = 510; // src/schnorr/constants.rs:30
 
 // One Rescue round on a 14-element state held one element per lane (rescue.rs:246-263).
@@ -65,12 +68,20 @@ __device__ __forceinline__ void flush_tile(const fp (*tile)[LD], fp *__restrict_
     }
 }
 
+// TR-row staging tile (TR | 64): lane = (row, column group); one wave
+template <int NCOLS, int LD, int TR>
+__device__ __forceinline__ void flush_rows(const fp (*tile)[LD], fp *__restrict__ trace, size_t n, size_t row0, int c0, int lane) {
+    for (int c = lane / TR; c < NCOLS; c += 64 / TR) trace[(size_t)(c0 + c) * n + row0 + (lane & (TR - 1))] = tile[lane & (TR - 1)][c];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // STANDALONE: the 65-register, 512-rows-per-transaction trace of MerkleProver (src/merkle/update/prover.rs:28-80)
-template <bool STANDALONE>
+// TR = rows of the staging tile: 64 alone; 16 when the recurrence runs beside the transforms (prove.hip), whose workgroups need the
+// LDS (a 64-row tile is 33 KB: four resident recurrences per CU leave no room for a 75 KB transform workgroup)
+template <bool STANDALONE, int TR>
 __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
     __builtin_amdgcn_s_setprio(3); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
-    __shared__ fp tile[64][65];
+    __shared__ fp tile[TR][65];
     __shared__ fp st[4][14];
     const int t = blockIdx.x, lane = threadIdx.x;
     const int hash_len = 8 * (int)w.depth + 7; // TRANSACTION_HASH_LENGTH
@@ -128,12 +139,12 @@ __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restr
                 __syncthreads();
             }
         }
-        const int r = (step + 1) & 63;
+        const int r = (step + 1) & (TR - 1);
         tile[r][col] = v;
         if (lane == 56) tile[r][43] = v2;
-        if (r == 63) {
+        if (r == TR - 1) {
             __syncthreads();
-            flush_tile<65, 65>(tile, trace, n, gbase + (step + 1 - 63), 0, lane);
+            flush_rows<65, 65, TR>(tile, trace, n, gbase + (step + 1 - (TR - 1)), 0, lane);
             __syncthreads();
         }
     }
@@ -143,18 +154,17 @@ __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restr
         return;
     }
     // registers 58..64 keep the new root through the Schnorr half (rows 512..1023)
-    if (lane >= 57)
-        for (int r = 0; r < 64; r++) tile[r][col] = v;
+    if (lane >= 57) st[0][lane - 57] = v;
     __syncthreads();
     for (int k = 0; k < 8; k++)
-        for (int c = 58; c < 65; c++) trace[(size_t)c * n + gbase + MERKLE_LEN + 64 * k + lane] = tile[lane][c];
+        for (int c = 58; c < 65; c++) trace[(size_t)c * n + gbase + MERKLE_LEN + 64 * k + lane] = st[0][c - 58];
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <bool STANDALONE>
+template <bool STANDALONE, int TR>
 __global__ __launch_bounds__(64) void k_trace_schnorr_hash(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
     __builtin_amdgcn_s_setprio(3); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
-    __shared__ fp tile[64][15];
+    __shared__ fp tile[TR][15];
     __shared__ fp st[14];
     const int t = blockIdx.x, lane = threadIdx.x;
     const bool active = lane < 14;
@@ -183,11 +193,11 @@ __global__ __launch_bounds__(64) void k_trace_schnorr_hash(TxWitnessDev w, fp *_
             }
             if (step == 38 && active && e < 4) w.h_limbs[4 * (size_t)t + e] = fp_to_u64(v); // build_sig_info h_bytes
         }
-        const int r = (step + 1) & 63;
+        const int r = (step + 1) & (TR - 1);
         if (active) tile[r][e] = v;
-        if (r == 63) {
+        if (r == TR - 1) {
             __syncthreads();
-            flush_tile<14, 15>(tile, trace, n, gbase + (step + 1 - 63), 42, lane);
+            flush_rows<14, 15, TR>(tile, trace, n, gbase + (step + 1 - (TR - 1)), 42, lane);
             __syncthreads();
         }
     }
@@ -506,9 +516,9 @@ hipError_t launch_trace_gen(const TxWitnessDev &w, fp *d_trace, hipStream_t stre
     hipError_t e;
     if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace_merkle<false>, dim3(w.n_tx), dim3(64), 0, side, w, d_trace, n);
+    hipLaunchKernelGGL((k_trace_merkle<false, 64>), dim3(w.n_tx), dim3(64), 0, side, w, d_trace, n);
     if ((e = hipEventRecord(join, side)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace_schnorr_hash<false>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL((k_trace_schnorr_hash<false, 64>), dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL((k_trace_schnorr_ec<false, 64>), dim3(2 * w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_final<false>, dim3(w.n_tx), dim3(64), 0, stream, d_trace, n);
     hipLaunchKernelGGL(k_trace_aux<0>, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
@@ -523,10 +533,10 @@ hipError_t launch_trace_gen_split(const TxWitnessDev &w, fp *d_trace, hipStream_
     if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side_a, fork, 0)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side_b, fork, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace_merkle<false>, dim3(w.n_tx), dim3(64), 0, side_a, w, d_trace, n);
+    hipLaunchKernelGGL((k_trace_merkle<false, CS_RECUR_TILE_ROWS>), dim3(w.n_tx), dim3(64), 0, side_a, w, d_trace, n);
     if ((e = hipEventRecord(join_a, side_a)) != hipSuccess) return e;
     // the message hash produces the scalar h of the second ladder (w.h_limbs): the ladders run behind it
-    hipLaunchKernelGGL(k_trace_schnorr_hash<false>, dim3(w.n_tx), dim3(64), 0, side_b, w, d_trace, n);
+    hipLaunchKernelGGL((k_trace_schnorr_hash<false, CS_RECUR_TILE_ROWS>), dim3(w.n_tx), dim3(64), 0, side_b, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_aux<2>, dim3(w.n_tx, 4), dim3(256), 0, side_b, w, d_trace, n);
     if ((e = hipEventRecord(mid_b, side_b)) != hipSuccess) return e;
     hipLaunchKernelGGL((k_trace_schnorr_ec<false, 16>), dim3(2 * w.n_tx), dim3(64), ladder_lds_pad(), side_b, w, d_trace, n);
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(256) void k_schnorr_aux_columns(TxWitnessDev w, fp 
 }
 hipError_t launch_schnorr_trace(const TxWitnessDev &w, fp *d_trace, hipStream_t stream) {
     const size_t n = (size_t)w.n_tx * MERKLE_LEN;
-    hipLaunchKernelGGL(k_trace_schnorr_hash<true>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL((k_trace_schnorr_hash<true, 64>), dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL((k_trace_schnorr_ec<true, 64>), dim3(2 * w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_final<true>, dim3(w.n_tx), dim3(64), 0, stream, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_bits, dim3(w.n_tx, 2), dim3(256), 0, stream, w, d_trace, n);
@@ -595,7 +605,7 @@ hipError_t launch_schnorr_aux_columns(const TxWitnessDev &w, fp *d_out, hipStrea
 
 hipError_t launch_merkle_trace(const TxWitnessDev &w, fp *d_trace, hipStream_t stream) {
     const size_t n = (size_t)w.n_tx * MERKLE_LEN;
-    hipLaunchKernelGGL(k_trace_merkle<true>, dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
+    hipLaunchKernelGGL((k_trace_merkle<true, 64>), dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);
     return hipGetLastError();
 }
 
