@@ -58,6 +58,21 @@ def load():
     return _lib
 
 
+_dbg = None
+
+
+def load_debug():
+    """The test-only companion library (include/cstark_debug.h): element-wise field / tower operations and micro-benchmarks."""
+    global _dbg
+    if _dbg is None:
+        load()
+        path = os.path.join(HERE, "libcstark_debug.so")
+        if not os.path.exists(path):
+            raise CstarkError(-2, "libcstark_debug.so is missing at %s: build it with __graft_entry__.build()" % path)
+        _dbg = C.CDLL(path)
+    return _dbg
+
+
 def check(rc):
     if rc != 0:
         raise CstarkError(rc, load().cstark_last_error().decode())

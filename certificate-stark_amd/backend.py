@@ -189,6 +189,26 @@ class Backend:
         check(self.lib.cstark_range_build_trace(self.ctx, C.c_uint64(int(number_mont)), self._ptr(out)))
         return out
 
+    def range_build_trace_bits(self, words, log_n):
+        """cstark_range_build_trace_bits: the synthetic long accumulator (2 x 2^log_n); returns (trace, V mod p in memory form)."""
+        w = _np_u64(words)
+        out = self.empty_u64(2, 1 << log_n)
+        num = C.c_uint64()
+        check(self.lib.cstark_range_build_trace_bits(self.ctx, w.ctypes.data_as(u64p), C.c_uint32(log_n), self._ptr(out), C.byref(num)))
+        return out, num.value
+
+    def range_prove_bits(self, options, words, log_n):
+        """cstark_range_prove_bits: complete RangeProofAir proof over 2^log_n rows."""
+        w = _np_u64(words)
+        o = _lib.OptionsStruct(options.num_queries, options.blowup_factor, options.grinding_factor, options.hash_fn,
+                               options.field_extension, options.fri_folding_factor, options.fri_max_remainder)
+        self.lib.cstark_tx_proof_size_bound.restype = C.c_size_t
+        cap = 2 * self.lib.cstark_tx_proof_size_bound(C.c_uint32(max(1, (1 << log_n) // 1024)), C.byref(o))
+        buf = (C.c_uint8 * cap)()
+        n = C.c_size_t(0)
+        check(self.lib.cstark_range_prove_bits(self.ctx, C.byref(o), w.ctypes.data_as(u64p), C.c_uint32(log_n), buf, C.c_size_t(cap), C.byref(n)))
+        return bytes(memoryview(buf)[:n.value])
+
     def air_shape(self, air, n_items=2):
         w, nc, na, lce = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
         check(self.lib.cstark_air_shape(C.c_int(air), C.c_uint32(n_items), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)))

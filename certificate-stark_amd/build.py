@@ -12,6 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libcstark_hip.so")
+# Test-only companion: element-wise entry points for the device field arithmetic (csrc/debug/, declared in
+# include/cstark_debug.h).  Not part of the product library; the GPU parity tests and tools/modmul_bench.py load it.
+DEBUG_LIB = os.path.join(HERE, "libcstark_debug.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-const-variable", "-Wno-unused-variable",
@@ -59,11 +62,20 @@ def build(force=False, verbose=False):
     failed = [s for s, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    dbg_srcs = [os.path.join(CSRC, "debug", f) for f in sorted(os.listdir(os.path.join(CSRC, "debug"))) if f.endswith(".hip")]
+    dbg = None
+    if force or _stale(DEBUG_LIB, dbg_srcs + headers):
+        cmd = [hipcc()] + FLAGS + ["-shared", "-o", DEBUG_LIB] + dbg_srcs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        dbg = subprocess.Popen(cmd)
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    if dbg is not None and dbg.wait() != 0:
+        raise RuntimeError("hipcc failed for the debug library")
     return LIB
 
 

@@ -28,18 +28,33 @@ using cs::g_err;
 
 namespace {
 
+// frees the device allocations registered with it unless release() is reached: error paths of the table builders leak nothing
+struct DevGuard {
+    std::vector<void *> ptrs;
+    bool armed = true;
+    template <class T> hipError_t alloc(T **p, size_t bytes) {
+        const hipError_t e = hipMalloc((void **)p, bytes);
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+    void release() { armed = false; }
+    ~DevGuard() { if (armed) for (void *q : ptrs) (void)hipFree(q); }
+};
+
 int get_plan(cstark_ctx *c, unsigned log_n, const NttPlan **out) {
     for (const NttPlan &p : c->plans)
         if (p.log_n == log_n) { *out = &p; return CSTARK_OK; }
     const size_t n = (size_t)1 << log_n;
     NttPlan p{log_n, nullptr, nullptr, 0};
-    HIP_TRY(hipMalloc((void **)&p.w, n * 8));
-    HIP_TRY(hipMalloc((void **)&p.winv, n * 8));
+    DevGuard g;
+    HIP_TRY(g.alloc(&p.w, n * 8));
+    HIP_TRY(g.alloc(&p.winv, n * 8));
     const uint64_t w = cs::host::root_of_unity(log_n);
     HIP_TRY(cs::ntt_power_table(p.w, n, w, c->stream));
     HIP_TRY(cs::ntt_power_table(p.winv, n, cs::host::inv(w), c->stream));
     p.n_inv = cs::host::inv(cs::host::from_u64(n));
     c->plans.push_back(p);
+    g.release();
     *out = &c->plans.back();
     return CSTARK_OK;
 }
@@ -49,7 +64,8 @@ int get_coset_table(cstark_ctx *c, unsigned log_n, unsigned log_b, uint64_t offs
         if (t.log_n == log_n && t.log_b == log_b && t.offset == offset) { *out = &t; return CSTARK_OK; }
     const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b;
     CosetTable t{log_n, log_b, offset, nullptr};
-    HIP_TRY(hipMalloc((void **)&t.s, b * n * 8));
+    DevGuard g;
+    HIP_TRY(g.alloc(&t.s, b * n * 8));
     const uint64_t wbn = cs::host::root_of_unity(log_n + log_b);
     uint64_t shift = offset;
     for (size_t k = 0; k < b; k++) {
@@ -57,6 +73,7 @@ int get_coset_table(cstark_ctx *c, unsigned log_n, unsigned log_b, uint64_t offs
         shift = cs::host::mul(shift, wbn);
     }
     c->cosets.push_back(t);
+    g.release();
     *out = &c->cosets.back();
     return CSTARK_OK;
 }
@@ -141,10 +158,11 @@ int get_periodic(cstark_ctx *c, unsigned depth, unsigned log_n, unsigned log_b, 
     const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b, C = cs::host::TX_CYCLE, NP = cs::host::TX_NUM_PERIODIC;
     PeriodicTable t{depth, log_n, log_b, nullptr, nullptr, nullptr};
     uint64_t *d_cols = nullptr, *d_poly = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_cols, NP * C * 8));
-    HIP_TRY(hipMalloc((void **)&d_poly, NP * C * 8));
-    HIP_TRY(hipMalloc((void **)&t.tab, b * NP * C * 8));
-    HIP_TRY(hipMalloc((void **)&t.coset, b * cs::CE_COSET_CONSTS * 8));
+    DevGuard keep, tmp; // g: the table (kept on success); tmp: scratch (always freed)
+    HIP_TRY(tmp.alloc(&d_cols, NP * C * 8));
+    HIP_TRY(tmp.alloc(&d_poly, NP * C * 8));
+    HIP_TRY(keep.alloc(&t.tab, b * NP * C * 8));
+    HIP_TRY(keep.alloc(&t.coset, b * cs::CE_COSET_CONSTS * 8));
     HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), NP * C * 8, hipMemcpyHostToDevice, c->stream));
     RC_TRY(interpolate_impl(c, d_cols, d_poly, (uint32_t)NP, 10));
     // a column of period 1024 is a polynomial in x^(n/1024): evaluate it over offset' * <w_{b*1024}>, offset' = g^(n/1024)
@@ -165,11 +183,10 @@ int get_periodic(cstark_ctx *c, unsigned depth, unsigned log_n, unsigned log_b, 
     HIP_TRY(hipMemcpyAsync(t.coset, cc.data(), cc.size() * 8, hipMemcpyHostToDevice, c->stream));
     const NttPlan *plan;
     RC_TRY(get_plan(c, log_n, &plan));
-    HIP_TRY(hipMalloc((void **)&t.binv, b * 2 * n * 8));
+    HIP_TRY(keep.alloc(&t.binv, b * 2 * n * 8));
     HIP_TRY(cs::build_boundary_inverses(t.binv, plan->w, t.coset, cs::host::inv(cs::host::root_of_unity(log_n)), log_n, log_b, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream)); // cc / cols go out of scope
-    HIP_TRY(hipFree(d_cols));
-    HIP_TRY(hipFree(d_poly));
+    HIP_TRY(hipStreamSynchronize(c->stream)); // cc / cols go out of scope; tmp frees the scratch
+    keep.release();
     c->periodic.push_back(t);
     *out = &c->periodic.back();
     return CSTARK_OK;
@@ -426,7 +443,7 @@ int cstark_deep_composition(cstark_ctx *c, const uint64_t *d_trace_lde, const ui
     for (size_t k = 0; k < b; k++) { blk[2 * nco + k] = shift; shift = cs::host::mul(shift, wbn); }
     const size_t bytes = blk.size() * 8;
     if (bytes > c->desc_bytes) {
-        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); }
+        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); c->desc_buf = nullptr; c->desc_bytes = 0; }
         HIP_TRY(hipMalloc(&c->desc_buf, bytes));
         c->desc_bytes = bytes;
     }
@@ -731,6 +748,27 @@ int cstark_range_build_trace(cstark_ctx *c, uint64_t number, uint64_t *d_trace) 
     HIP_TRY(cs::launch_range_trace(canonical, d_trace, c->stream));
     return CSTARK_OK;
 }
+// Synthetic long form of the range accumulator (BASELINE.json "range-proof AIR, 2^16 steps"; the reference's trace is fixed at 64
+// rows): words = the n/64 little-endian words of an (n-1)-bit integer V, host memory.  *number_out (optional) = V mod p, memory form.
+int cstark_range_build_trace_bits(cstark_ctx *c, const uint64_t *words, uint32_t log_n, uint64_t *d_trace, uint64_t *number_out) {
+    if (!c || !words || !d_trace) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_build_trace_bits: null argument");
+    if (log_n < 6 || log_n > 21) return fail(CSTARK_ERR_INVALID_ARG, "trace length must be 2^6 .. 2^21");
+    const size_t nw = (size_t)1 << (log_n - 6);
+    if (words[nw - 1] >> 63) return fail(CSTARK_ERR_INVALID_ARG, "the value must have at most n - 1 bits (top bit of the last word clear)");
+    HIP_TRY(hipSetDevice(c->device));
+    RC_TRY(ensure_ws(c, 2 * nw * 8));
+    uint64_t *d_words = (uint64_t *)c->ws, *d_prefix = d_words + nw;
+    HIP_TRY(hipMemcpyAsync(d_words, words, nw * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(cs::launch_range_trace_bits(d_words, d_prefix, d_trace, log_n, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream)); // the caller's words may be transient
+    if (number_out) { // Horner in base 2^64, most significant word first
+        uint64_t v = 0;
+        const uint64_t B = cs::host::R2; // 2^64 in memory form
+        for (size_t i = nw; i-- > 0;) v = cs::host::add(cs::host::mul(v, B), cs::host::from_u64(words[i] % cs::host::P));
+        *number_out = v;
+    }
+    return CSTARK_OK;
+}
 
 // SchnorrAir (src/schnorr): messages [n][28], signatures (R.x [n][6], s bytes [n][32]); host arrays are copied
 int cstark_schnorr_witness_upload(cstark_ctx *c, uint32_t n_sig, const uint64_t *messages, const uint64_t *sig_rx, const uint8_t *sig_s) {
@@ -754,7 +792,7 @@ int cstark_schnorr_witness_upload(cstark_ctx *c, uint32_t n_sig, const uint64_t 
     w.deltas = deltas.data(); w.sig_rx = sig_rx; w.sig_s = sig_s;
     RC_TRY(cstark_tx_witness_upload(c, &w));
     if (c->tail_bytes < tail.size() * 8) {
-        if (c->tail_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->tail_buf)); }
+        if (c->tail_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->tail_buf)); c->tail_buf = nullptr; c->tail_bytes = 0; }
         HIP_TRY(hipMalloc((void **)&c->tail_buf, tail.size() * 8));
         c->tail_bytes = tail.size() * 8;
     }

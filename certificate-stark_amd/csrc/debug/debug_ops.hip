@@ -2,8 +2,8 @@
 // cstark_debug_* so the GPU parity tests can pin every primitive against the oracle, and so the modular
 // multiplication rate of the chip can be measured in isolation.
 #include <hip/hip_runtime.h>
-#include "../../include/cstark.h"
-#include "tower.cuh"
+#include "../../../include/cstark.h"
+#include "../tower.cuh"
 
 namespace cs {
 namespace {
@@ -91,8 +91,8 @@ int cstark_debug_modmul_bench(void *stream, uint64_t *d_out, int blocks, int ite
 }
 
 // ---- experiment: INV_MDS * d on the matrix cores vs the limb dot products -------------------------------------------------------
-#include "mds_mfma.cuh"
-#include "rescue.cuh"
+#include "../mds_mfma.cuh"
+#include "../rescue.cuh"
 namespace cs {
 namespace {
 __global__ void k_mds_table(uint8_t *tab) { mdsmfma::build_table_entry(tab, c_inv_mds, 14, blockIdx.x, threadIdx.x); }

@@ -33,6 +33,7 @@ struct ProveArena {
     unsigned log_n = 0, log_b = 0;
     uint64_t *trace = nullptr, *coeffs = nullptr, *lde = nullptr, *combined = nullptr, *cegather = nullptr, *ccoef = nullptr, *clde = nullptr, *deep = nullptr;
     std::vector<void *> extra; // per-AIR buffers (materialised transition evaluations, SchnorrAir's public columns)
+    std::vector<size_t> extra_bytes; // allocated size of every slot of `extra`
     uint8_t *tnodes = nullptr, *cnodes = nullptr;
     std::vector<uint64_t *> layer;   // FRI layer evaluations (layer[0] = DEEP composition in natural order), last = remainder
     std::vector<uint8_t *> lnodes;   // FRI layer trees
@@ -146,10 +147,24 @@ int dev_alloc(ProveArena *a, T **p, size_t bytes) {
     return CSTARK_OK;
 }
 
+// Slot `slot` of the arena's per-AIR buffers with at least `bytes` bytes.  A slot outlives the proof that created it (the arena is
+// reused across proofs with other query counts, field extensions or AIR options), so its size is recorded and a larger request
+// replaces the allocation once the stream has drained.
 template <class T>
-int arena_extra(ProveArena *a, size_t slot, T **p, size_t bytes) {
-    if (a->extra.size() <= slot) a->extra.resize(slot + 1, nullptr);
-    if (!a->extra[slot]) { void *q; HIP_TRY(hipMalloc(&q, bytes)); a->owned.push_back(q); a->extra[slot] = q; }
+int arena_extra(cstark_ctx *c, ProveArena *a, size_t slot, T **p, size_t bytes) {
+    if (a->extra.size() <= slot) { a->extra.resize(slot + 1, nullptr); a->extra_bytes.resize(slot + 1, 0); }
+    if (a->extra[slot] && a->extra_bytes[slot] < bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        void *old = a->extra[slot];
+        a->extra[slot] = nullptr; a->extra_bytes[slot] = 0;
+        a->owned.erase(std::find(a->owned.begin(), a->owned.end(), old));
+        HIP_TRY(hipFree(old));
+    }
+    if (!a->extra[slot]) {
+        void *q;
+        HIP_TRY(hipMalloc(&q, bytes));
+        a->owned.push_back(q); a->extra[slot] = q; a->extra_bytes[slot] = bytes;
+    }
     *p = (T *)a->extra[slot];
     return CSTARK_OK;
 }
@@ -181,6 +196,7 @@ struct AirJob {
     const uint64_t *pub_staging = nullptr; // pinned host copy of the public inputs, valid once every batch has been waited for
     bool evals_ready = false;       // sub-AIRs: the materialised transition evaluations of this proof are already in the arena
     uint64_t number = 0;            // RangeProofAir
+    const uint64_t *bits = nullptr; // RangeProofAir, long form: the n/64 words of the value (host)
 };
 
 int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned n_layers, size_t nq, ProveArena **out) {
@@ -355,7 +371,7 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     // coefficients of P(g y)) and extend to all cosets with offset 1 -- the same values as evaluating the sums at every point.
     {
         uint64_t *dcoef;
-        RC_TRY(arena_extra(a, 40, &dcoef, n * 8));
+        RC_TRY(arena_extra(c, a, 40, &dcoef, n * 8));
         RC_TRY(cstark_deep_composition(c, a->lde, a->clde, (uint32_t)W, (uint32_t)ce, z, ood_trace.data(), ood_comp.data(), d_alpha.data(),
                                        d_beta.data(), d_delta.data(), deg_a, deg_b, a->deep, log_n, log_b, 0, 1));
         RC_TRY(cstark_interpolate_columns(c, a->deep, dcoef, 1, log_n));
@@ -540,17 +556,20 @@ int merkle_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
 int merkle_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals;
-    RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
+    RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
     if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_MERKLE_UPDATE, a->lde, evals, job.item, job.log_n, 3, 0, 8));
     job.evals_ready = true;
     return cstark_air_combine(c, CSTARK_AIR_MERKLE_UPDATE, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, out, job.log_n, 3, 0, 8);
 }
 // ---- RangeProofAir (src/range) -------------------------------------------------------------------------------------------------------
-int range_build(cstark_ctx *c, ProveArena *a, AirJob &job) { return cstark_range_build_trace(c, job.number, a->trace); }
+int range_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
+    if (job.bits) return cstark_range_build_trace_bits(c, job.bits, job.log_n, a->trace, nullptr);
+    return cstark_range_build_trace(c, job.number, a->trace);
+}
 int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals;
-    RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
+    RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
     if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RANGE, a->lde, evals, 0, job.log_n, 3, 0, 8));
     job.evals_ready = true;
     const uint64_t vals[2] = {0, job.number}; // get_assertions, src/range/air.rs:79-86
@@ -561,12 +580,12 @@ int schnorr_build(cstark_ctx *c, ProveArena *a, AirJob &) { return cstark_schnor
 int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals, *aux, *aux_co, *aux_lde, *av_co, *av_lde;
-    RC_TRY(arena_extra(a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
-    RC_TRY(arena_extra(a, 1, &aux, 19 * n * 8));
-    RC_TRY(arena_extra(a, 2, &aux_co, 19 * n * 8));
-    RC_TRY(arena_extra(a, 3, &aux_lde, 8 * 19 * n * 8));
-    RC_TRY(arena_extra(a, 4, &av_co, 12 * n * 8));
-    RC_TRY(arena_extra(a, 5, &av_lde, 8 * 12 * n * 8));
+    RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
+    RC_TRY(arena_extra(c, a, 1, &aux, 19 * n * 8));
+    RC_TRY(arena_extra(c, a, 2, &aux_co, 19 * n * 8));
+    RC_TRY(arena_extra(c, a, 3, &aux_lde, 8 * 19 * n * 8));
+    RC_TRY(arena_extra(c, a, 4, &av_co, 12 * n * 8));
+    RC_TRY(arena_extra(c, a, 5, &av_lde, 8 * 12 * n * 8));
     if (!job.evals_ready) { // once per proof (extension proofs merge the same evaluations with m coefficient sets)
         // the public-input columns (src/schnorr/air.rs:228-290) are not committed: both sides derive them from the messages
         RC_TRY(cstark_schnorr_aux_columns(c, aux));
@@ -603,16 +622,16 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     RC_TRY(get_arena(c, job, log_b, n_layers, nq, &a));
     uint64_t *combined_x, *ccoef_x, *ccoefs, *cldes, *deepx;
     uint8_t *d_open;
-    RC_TRY(arena_extra(a, 16, &combined_x, 2 * N * 8));   // components 1, 2 of the merged evaluations
-    RC_TRY(arena_extra(a, 17, &ccoef_x, 2 * N * 8));      // their column coefficients
-    RC_TRY(arena_extra(a, 18, &ccoefs, 3 * N * 8));       // interleaved: column m i + k
-    RC_TRY(arena_extra(a, 19, &cldes, 3 * b * N * 8));
-    RC_TRY(arena_extra(a, 20, &deepx, 3 * N * 8));
-    RC_TRY(arena_extra(a, 21, &d_open, nq * (W * 8 + 192 + 2 * log_N * 32 + (size_t)n_layers * (96 + log_N * 32)) + 256));
+    RC_TRY(arena_extra(c, a, 16, &combined_x, 2 * N * 8));   // components 1, 2 of the merged evaluations
+    RC_TRY(arena_extra(c, a, 17, &ccoef_x, 2 * N * 8));      // their column coefficients
+    RC_TRY(arena_extra(c, a, 18, &ccoefs, 3 * N * 8));       // interleaved: column m i + k
+    RC_TRY(arena_extra(c, a, 19, &cldes, 3 * b * N * 8));
+    RC_TRY(arena_extra(c, a, 20, &deepx, 3 * N * 8));
+    RC_TRY(arena_extra(c, a, 21, &d_open, nq * (W * 8 + 192 + 2 * log_N * 32 + (size_t)n_layers * (96 + log_N * 32)) + 256));
     std::vector<uint64_t *> layer(n_layers + 1);
     {
         size_t sz = N;
-        for (unsigned l = 0; l <= n_layers; l++) { RC_TRY(arena_extra(a, 22 + l, &layer[l], 3 * sz * 8)); sz /= 4; }
+        for (unsigned l = 0; l <= n_layers; l++) { RC_TRY(arena_extra(c, a, 22 + l, &layer[l], 3 * sz * 8)); sz /= 4; }
     }
     hipStream_t st = c->stream;
     int evi = 0;
@@ -719,8 +738,8 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     const EX dga = draw_e(), dgb = draw_e();
     {   // degree < n in every component: coset 0 only, then interpolation and extension per component (see prove_core)
         uint64_t *dev0, *dcoef;
-        RC_TRY(arena_extra(a, 40, &dev0, 3 * n * 8));
-        RC_TRY(arena_extra(a, 41, &dcoef, 3 * n * 8));
+        RC_TRY(arena_extra(c, a, 40, &dev0, 3 * n * 8));
+        RC_TRY(arena_extra(c, a, 41, &dcoef, 3 * n * 8));
         RC_TRY(deep_composition_ext_cosets(c, a->lde, cldes, (uint32_t)W, (uint32_t)ce, m, z.c, ood_trace.data(), ood_comp.data(), d_alpha.data(),
                                            d_beta.data(), d_delta.data(), dga.c, dgb.c, dev0, log_n, log_b, 1));
         RC_TRY(cstark_interpolate_columns(c, dev0, dcoef, m, log_n));
@@ -883,6 +902,27 @@ int cstark_air_prove(cstark_ctx *c, int air, const cstark_options *opt, uint64_t
     } else {
         return fail(CSTARK_ERR_UNSUPPORTED, "no prover for this AIR");
     }
+    job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
+    if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
+    return prove_core(c, opt, job, proof, capacity, proof_len);
+}
+
+// RangeProofAir over 2^log_n rows (synthetic long form; log_n = 6 with a one-word value is cstark_air_prove(CSTARK_AIR_RANGE))
+int cstark_range_prove_bits(cstark_ctx *c, const cstark_options *opt, const uint64_t *words, uint32_t log_n, uint8_t *proof, size_t capacity,
+                            size_t *proof_len) {
+    if (!c || !opt || !words || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_prove_bits: null argument");
+    if (log_n < 6 || log_n > 21) return fail(CSTARK_ERR_INVALID_ARG, "trace length must be 2^6 .. 2^21");
+    const size_t nw = (size_t)1 << (log_n - 6);
+    if (words[nw - 1] >> 63) return fail(CSTARK_ERR_INVALID_ARG, "the value must have at most n - 1 bits");
+    uint64_t number = 0; // V mod p, memory form: Horner in base 2^64
+    for (size_t i = nw; i-- > 0;) number = host::add(host::mul(number, host::R2), host::from_u64(words[i] % host::P));
+    AirJob job;
+    job.air = CSTARK_AIR_RANGE;
+    host::AirShape s;
+    host::air_shape(CSTARK_AIR_RANGE, s, 0);
+    job.log_n = log_n; job.item = 0; job.number = number; job.bits = words;
+    job.pub = {number};
+    job.build = range_build; job.combine = range_combine;
     job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
     if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);

@@ -622,4 +622,45 @@ hipError_t launch_range_trace(uint64_t number_canonical, fp *d_trace, hipStream_
     return hipGetLastError();
 }
 
+// The same accumulator over n = 2^log_n rows (synthetic long form of BASELINE.json's "range, 2^16 steps"): V is an (n-1)-bit integer,
+// words[] its n/64 little-endian words; row q >= 1 holds bit (n-1-q) of V and acc_q = (V >> (n-1-q)) mod p.  With the MSB-first
+// 64-bit chunks U_c = words[n/64 - 1 - c] the accumulator at the end of chunk c is E_c = sum_{c' <= c} U_c' (2^64)^(c-c') and inside
+// the chunk acc_(64c+r) = E_(c-1) 2^(r+1) + (U_c >> (63-r)).
+// Pass 1 (one workgroup): E_c for every chunk -- per-thread Horner over a segment, a scan of the 256 segment values, a second
+// Horner pass.  Pass 2: one thread per row, coalesced stores.
+__global__ __launch_bounds__(256) void k_range_chunk_prefix(const uint64_t *__restrict__ words, fp *__restrict__ prefix, unsigned n_chunks) {
+    __shared__ fp seg[256], lead[256];
+    const unsigned t = threadIdx.x, per = (n_chunks + 255) / 256, c0 = t * per, c1 = min(c0 + per, n_chunks);
+    const fp B = FP_R2; // 2^64 in memory form is 2^128 mod p
+    fp v = 0;
+    for (unsigned c = c0; c < c1; c++) v = fp_add(fp_mul(v, B), fp_from_u64(words[n_chunks - 1 - c]));
+    seg[t] = v;
+    __syncthreads();
+    if (t == 0) { // value carried into every segment: 256 dependent products, negligible
+        const fp Bper = fp_pow(B, per);
+        fp carry = 0;
+        for (unsigned i = 0; i < 256; i++) { lead[i] = carry; carry = fp_add(fp_mul(carry, Bper), seg[i]); }
+    }
+    __syncthreads();
+    v = lead[t];
+    for (unsigned c = c0; c < c1; c++) { v = fp_add(fp_mul(v, B), fp_from_u64(words[n_chunks - 1 - c])); prefix[c] = v; }
+}
+__global__ __launch_bounds__(256) void k_trace_range_bits(const uint64_t *__restrict__ words, const fp *__restrict__ prefix, fp *__restrict__ trace,
+                                                          unsigned log_n) {
+    const size_t n = (size_t)1 << log_n, q = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (q >= n) return;
+    const unsigned c = (unsigned)(q >> 6), r = (unsigned)(q & 63), n_chunks = (unsigned)(n >> 6);
+    const uint64_t u = words[n_chunks - 1 - c];
+    const fp before = c ? prefix[c - 1] : 0;
+    const fp two_r1 = fp_pow(fp_from_u64(2), r + 1);
+    trace[q] = ((u >> (63 - r)) & 1) ? FP_ONE : 0;
+    trace[n + q] = fp_add(fp_mul(before, two_r1), fp_from_u64(u >> (63 - r)));
+}
+hipError_t launch_range_trace_bits(const uint64_t *d_words, fp *d_prefix, fp *d_trace, unsigned log_n, hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_range_chunk_prefix, dim3(1), dim3(256), 0, stream, d_words, d_prefix, (unsigned)(n >> 6));
+    hipLaunchKernelGGL(k_trace_range_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_words, (const fp *)d_prefix, d_trace, log_n);
+    return hipGetLastError();
+}
+
 } // namespace cs

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 #include "../../include/cstark.h"
 #include "ctx.h"
@@ -30,30 +31,43 @@ uint64_t splitmix64(uint64_t *s) {
     return z ^ (z >> 31);
 }
 
-struct Tree { // nodes[1] root, nodes[size + i] leaf i; 7 elements per node
+// Sparse account tree: node ids in heap order (1 = root, 2^depth + i = leaf i); only touched nodes are stored, an absent node of
+// level l has the digest of an empty subtree (empty leaves are the all-zero digest).  Depth 31 -- the largest the 512-row Merkle
+// cycle admits (src/merkle/constants.rs:27-29) and the nearest legal value to BASELINE.json's "depth 32" -- costs memory for
+// the touched paths only.
+struct Digest { fp v[7]; };
+struct Tree {
     unsigned depth;
-    size_t size;
-    std::vector<fp> nodes;
-    explicit Tree(unsigned d) : depth(d), size((size_t)1 << d), nodes(2 * ((size_t)1 << d) * 7, 0) {
-        fp h[7] = {0};
-        for (int lvl = (int)d - 1; lvl >= 0; lvl--) {
-            fp nh[7];
-            merge(h, h, nh);
-            memcpy(h, nh, sizeof h);
-            for (size_t i = (size_t)1 << lvl; i < ((size_t)2 << lvl); i++) memcpy(&nodes[7 * i], h, sizeof h);
+    uint64_t size;
+    std::unordered_map<uint64_t, Digest> nodes;
+    Digest empty[33]; // empty[l]: digest of an empty subtree rooted at level l
+    explicit Tree(unsigned d) : depth(d), size((uint64_t)1 << d) {
+        memset(empty, 0, sizeof empty);
+        for (int lvl = (int)d - 1; lvl >= 0; lvl--) merge(empty[lvl + 1].v, empty[lvl + 1].v, empty[lvl].v);
+    }
+    const fp *node(uint64_t id, unsigned lvl) const {
+        const auto it = nodes.find(id);
+        return it == nodes.end() ? empty[lvl].v : it->second.v;
+    }
+    const fp *root() const { return node(1, 0); }
+    void update_leaf(uint64_t index, const fp *leaf) {
+        uint64_t i = size + index;
+        unsigned lvl = depth;
+        memcpy(nodes[i].v, leaf, 56);
+        for (i >>= 1; i >= 1; i >>= 1) {
+            Digest h;
+            merge(node(2 * i, lvl), node(2 * i + 1, lvl), h.v);
+            lvl--;
+            nodes[i] = h;
         }
     }
-    void update_leaf(size_t index, const fp *leaf) {
-        size_t i = size + index;
-        memcpy(&nodes[7 * i], leaf, 56);
-        for (i >>= 1; i >= 1; i >>= 1) merge(&nodes[7 * (2 * i)], &nodes[7 * (2 * i + 1)], &nodes[7 * i]);
-    }
-    void prove(size_t index, fp *path) const { // [leaf, sibling_0 .. sibling_{d-1}] (src/merkle/update/trace.rs:113 reads [k+1])
-        size_t i = size + index;
-        memcpy(path, &nodes[7 * i], 56);
-        for (unsigned k = 0; k < depth; k++, i >>= 1) memcpy(path + 7 * (k + 1), &nodes[7 * (i ^ 1)], 56);
+    void prove(uint64_t index, fp *path) const { // [leaf, sibling_0 .. sibling_{d-1}] (src/merkle/update/trace.rs:113 reads [k+1])
+        uint64_t i = size + index;
+        memcpy(path, node(i, depth), 56);
+        for (unsigned k = 0; k < depth; k++, i >>= 1) memcpy(path + 7 * (k + 1), node(i ^ 1, depth - k), 56);
     }
 };
+struct Account { fp val[14]; uint64_t sk; }; // sk = 0: no account yet
 void leaf_hash(const fp *val, fp *out) { merge(val, val + 7, out); } // src/lib.rs:287-290
 
 void make_account(uint64_t *rng, fp *val, uint64_t *sk_out) {
@@ -107,42 +121,45 @@ extern "C" {
 int cstark_tx_witness_generate(cstark_tx_witness *w, uint64_t seed) {
     if (!w) return cs::fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_witness_generate: null argument");
     const uint32_t n = w->n_tx, depth = w->merkle_depth;
-    if (n == 0 || depth == 0 || depth > 24) return cs::fail(CSTARK_ERR_INVALID_ARG, "bad transaction count / tree depth");
+    if (n == 0 || depth == 0 || depth > 31) return cs::fail(CSTARK_ERR_INVALID_ARG, "bad transaction count / tree depth");
     if (!w->initial_roots || !w->final_root || !w->s_old_values || !w->r_old_values || !w->s_indices || !w->r_indices || !w->s_paths || !w->r_paths ||
         !w->deltas || !w->sig_rx || !w->sig_s)
         return cs::fail(CSTARK_ERR_INVALID_ARG, "witness array pointer is null (the caller allocates every array)");
     uint64_t rng = seed;
     Tree tree(depth);
-    const size_t tree_size = tree.size;
-    std::vector<fp> values(tree_size * 14, 0);
-    std::vector<uint64_t> sks(tree_size, 0), tx_sk(n, 0); // 0 = no account yet
+    const uint64_t tree_size = tree.size;
+    std::unordered_map<uint64_t, Account> accounts; // by leaf index
+    std::vector<uint64_t> tx_sk(n, 0);
     uint64_t *s_idx = (uint64_t *)w->s_indices, *r_idx = (uint64_t *)w->r_indices;
     fp leaf[7];
     for (uint32_t t = 0; t < n; t++) { // senders, src/lib.rs:273-296
-        const size_t i = splitmix64(&rng) % tree_size;
+        const uint64_t i = splitmix64(&rng) % tree_size;
         s_idx[t] = i;
-        make_account(&rng, &values[14 * i], &sks[i]);
-        leaf_hash(&values[14 * i], leaf);
+        Account &a = accounts[i];
+        make_account(&rng, a.val, &a.sk);
+        leaf_hash(a.val, leaf);
         tree.update_leaf(i, leaf);
     }
     for (uint32_t t = 0; t < n; t++) { // receivers, src/lib.rs:305-333
-        size_t i = splitmix64(&rng) % tree_size;
+        uint64_t i = splitmix64(&rng) % tree_size;
         while (i == s_idx[t]) i = splitmix64(&rng) % tree_size;
         r_idx[t] = i;
-        if (sks[i] == 0) {
-            make_account(&rng, &values[14 * i], &sks[i]);
-            leaf_hash(&values[14 * i], leaf);
+        Account &a = accounts[i]; // value-initialised (sk = 0) when new
+        if (a.sk == 0) {
+            make_account(&rng, a.val, &a.sk);
+            leaf_hash(a.val, leaf);
             tree.update_leaf(i, leaf);
         }
     }
     for (uint32_t t = 0; t < n; t++) { // transfers, src/lib.rs:347-422
-        const size_t si = s_idx[t], ri = r_idx[t];
-        fp *sv = &values[14 * si], *rv = &values[14 * ri];
+        const uint64_t si = s_idx[t], ri = r_idx[t];
+        Account &sa = accounts.at(si), &ra = accounts.at(ri);
+        fp *sv = sa.val, *rv = ra.val;
         const uint64_t sb = to_u64(sv[12]), rb = to_u64(rv[12]);
         const uint64_t bound = sb < UINT64_MAX - rb ? sb : UINT64_MAX - rb;
         const fp delta = from_u64(bound ? splitmix64(&rng) % bound : 0);
-        memcpy((fp *)w->initial_roots + 7 * t, &tree.nodes[7], 56);
-        tx_sk[t] = sks[si];
+        memcpy((fp *)w->initial_roots + 7 * t, tree.root(), 56);
+        tx_sk[t] = sa.sk;
         memcpy((fp *)w->s_old_values + 14 * t, sv, 112);
         memcpy((fp *)w->r_old_values + 14 * t, rv, 112);
         ((fp *)w->deltas)[t] = delta;
@@ -156,7 +173,7 @@ int cstark_tx_witness_generate(cstark_tx_witness *w, uint64_t seed) {
         tree.update_leaf(ri, leaf);
         tree.prove(ri, (fp *)w->r_paths + 7 * (depth + 1) * (size_t)t);
     }
-    memcpy((fp *)w->final_root, &tree.nodes[7], 56);
+    memcpy((fp *)w->final_root, tree.root(), 56);
     // signatures, src/lib.rs:435-447: independent per transaction -> per-transaction random streams, all host threads
     const uint64_t sig_seed = splitmix64(&rng);
     parallel_for(n, [&](uint32_t t) {

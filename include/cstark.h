@@ -181,7 +181,7 @@ int cstark_tx_evaluate_constraints_ext(cstark_ctx *ctx, const uint64_t *d_lde, c
  * (Rescue windows; doubling / mixed addition of s*G; of h*P; final addition; three linear groups) on the context's
  * stream; cstark_tx_constraint_part_ms waits for the last one and returns the 9 durations in milliseconds. */
 /* Inside cstark_tx_prove (base field) the parts run as the degree-split evaluation: every part except the final
- * addition on the even cosets only; the last figure (third linear group) then also holds the extension of the 18 merged
+ * addition on the even cosets only; the last figure (third linear group) then also holds the extension of the 14 merged
  * polynomials to the odd cosets and the recombination over all cosets. */
 int cstark_ctx_set_part_timing(cstark_ctx *ctx, int enable);
 int cstark_tx_constraint_part_ms(cstark_ctx *ctx, float *ms /* [9] */);
@@ -221,7 +221,7 @@ int cstark_fri_fold4(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, 
  * (host, `capacity` bytes; cstark_tx_proof_size_bound gives a sufficient capacity).  *proof_len receives the length; if the
  * buffer is too small the call fails with CSTARK_ERR_INVALID_ARG and *proof_len still holds the required size.
  * The public inputs are read from the trace as TransactionProver::get_pub_inputs does (src/prover.rs:106-129).
- * Supported options: blowup 8, Blake3_256 or Sha3_256, FieldExtension::None, FRI folding 4, remainder 128..1024 (the reference's
+ * Supported options: blowup 8, Blake3_256 or Sha3_256, FieldExtension::None / Quadratic / Cubic, FRI folding 4, remainder 128..1024 (the reference's
  * get_example options, src/lib.rs:78-86, qualify).
  *
  * Proof layout (little-endian; field elements as 8-byte memory form; this library's own format, the engine's
@@ -258,6 +258,15 @@ int cstark_merkle_build_trace(cstark_ctx *ctx, uint64_t *d_trace);
 /* RangeProver::build_trace (src/range/prover.rs:24-43): 2 x 64; `number` is a field element in memory form
  * whose canonical value must be below 2^63. */
 int cstark_range_build_trace(cstark_ctx *ctx, uint64_t number, uint64_t *d_trace);
+/* SYNTHETIC long form of the same accumulator for BASELINE.json's config "range-proof AIR, 2^16 steps" (the reference's range trace
+ * is fixed at 64 rows, src/range/mod.rs:34, so this size has no reference counterpart): 2 x 2^log_n rows of the (n-1)-bit integer V
+ * whose n/64 little-endian words are `words` (host; top bit of the last word clear).  Row q >= 1 holds bit (n-1-q) of V and
+ * acc_q = 2 acc_(q-1) + bit (src/range/prover.rs:74-84), the AIR is RangeProofAir unchanged (src/range/air.rs:60-105) with the
+ * assertion acc[n-1] = V mod p.  log_n = 6 with words[0] = number reproduces cstark_range_build_trace / cstark_air_prove exactly.
+ * *number_out (optional): V mod p in memory form. */
+int cstark_range_build_trace_bits(cstark_ctx *ctx, const uint64_t *words, uint32_t log_n, uint64_t *d_trace, uint64_t *number_out);
+int cstark_range_prove_bits(cstark_ctx *ctx, const cstark_options *opt, const uint64_t *words, uint32_t log_n, uint8_t *proof, size_t capacity,
+                            size_t *proof_len);
 /* SchnorrAir (src/schnorr/air.rs:41-300, src/schnorr/prover.rs:21-67): n signatures over 28-element messages
  * (message[0..12] = public key).  Trace 56 x (512*n); the 19 public-input columns (pkey x12, message chunks x7;
  * src/schnorr/air.rs:228-290) as a 19 x (512*n) table that the caller extends like trace columns; the 8 mask + 28

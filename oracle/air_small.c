@@ -142,6 +142,24 @@ int cso_range_build_trace(uint64_t number_canonical, uint64_t *trace /*[2][64]*/
     }
     return 0;
 }
+/* The same accumulator over a longer trace (BASELINE.json config "range-proof AIR, 2^16 steps": SYNTHETIC, the reference's trace
+ * is fixed at 64 rows, src/range/mod.rs:34).  n = 2^log_n rows; the value is the (n-1)-bit integer V given as n/64 little-endian
+ * 64-bit words (top bit clear); row q >= 1 holds bit (n-1-q) of V and acc_q = 2 acc_(q-1) + bit = (V >> (n-1-q)) mod p, exactly the
+ * update rule of src/range/prover.rs:74-84.  For log_n = 6 this is cso_range_build_trace.  Returns V mod p (memory form), the
+ * value asserted at the last row (src/range/air.rs:79-86). */
+uint64_t cso_range_build_trace_bits(const uint64_t *words, uint32_t log_n, uint64_t *trace /*[2][n]*/) {
+    const size_t n = (size_t)1 << log_n;
+    fp acc = 0;
+    trace[0] = 0; trace[n] = 0;
+    for (size_t q = 1; q < n; q++) {
+        const size_t pos = n - 1 - q;
+        const fp bit = ((words[pos / 64] >> (pos % 64)) & 1) ? FP_ONE : 0;
+        acc = fp_add(fp_dbl(acc), bit);
+        trace[q] = bit;
+        trace[n + q] = acc;
+    }
+    return acc;
+}
 /* src/range/air.rs:91-98: enforce_double_and_add_step(result, cur, next, 1, 0, ONE) */
 void cso_range_evaluate_transition(const uint64_t *cur, const uint64_t *next, const uint64_t *pv, uint64_t *res) {
     (void)pv;

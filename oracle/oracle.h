@@ -112,6 +112,7 @@ int cso_merkle_periodic_columns(unsigned depth, uint64_t *out);
 void cso_merkle_evaluate_transition(const uint64_t *cur, const uint64_t *next, const uint64_t *pv, uint64_t *res);
 void cso_merkle_constraint_degrees(uint32_t *base, uint32_t *cycles);
 int cso_range_build_trace(uint64_t number_canonical, uint64_t *trace);
+uint64_t cso_range_build_trace_bits(const uint64_t *words, uint32_t log_n, uint64_t *trace);
 void cso_range_evaluate_transition(const uint64_t *cur, const uint64_t *next, const uint64_t *pv, uint64_t *res);
 int cso_rescue_chain_build_trace(const uint64_t *seed7, uint32_t iterations, uint64_t *trace);
 void cso_rescue_compute_hash_chain(const uint64_t *seed7, uint32_t length, uint64_t *out7);

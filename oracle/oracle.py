@@ -392,6 +392,18 @@ def range_build_trace(number):
     return trace
 
 
+def range_build_trace_bits(words, log_n):
+    """Synthetic long accumulator (BASELINE 'range, 2^16 steps'): words = n/64 little-endian uint64 of an (n-1)-bit integer.
+    Returns (trace [2][n], V mod p in memory form)."""
+    words = _u64(words)
+    n = 1 << log_n
+    assert words.size == n // 64 and not (int(words[-1]) >> 63)
+    trace = np.zeros((2, n), np.uint64)
+    lib().cso_range_build_trace_bits.restype = C.c_uint64
+    v = lib().cso_range_build_trace_bits(_p(words), C.c_uint32(log_n), _p(trace))
+    return trace, int(v)
+
+
 def range_desc(number):
     return AirDesc(2, [2, 1], [0, 0], 0, [1, 1], [0, 1], [0, int(to_mont([number])[0])])
 

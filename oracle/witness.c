@@ -52,32 +52,73 @@ int cso_ecc_on_curve_affine(const uint64_t *q) {
     return memcmp(lhs.c, rhs.c, sizeof lhs.c) == 0;
 }
 
-/* ---- Rescue account tree: nodes[1] root, nodes[size + i] leaf i ------------------------------- */
-typedef struct { unsigned depth; size_t size; fp *nodes; } tree_t;
+/* ---- Rescue account tree, sparse: node ids in heap order (1 = root, 2^depth + i = leaf i) ------ */
+/* Only touched nodes are stored; an absent node of level l has the digest of an empty subtree (empty leaves are the all-zero
+ * digest).  Depth 31 -- the largest the 512-row Merkle cycle admits (src/merkle/constants.rs:27-29: 8 * 31 + 7 = 255 rows)
+ * and the nearest legal value to BASELINE.json's "depth 32" -- therefore costs memory for the touched paths only. */
+typedef struct { uint64_t *keys; size_t *slot; size_t cap, used; fp *vals; size_t stride, nvals, vcap; } u64map_t;
+static void map_init(u64map_t *m, size_t stride) {
+    m->cap = 1024; m->used = 0; m->stride = stride; m->nvals = 0; m->vcap = 256;
+    m->keys = calloc(m->cap, sizeof(uint64_t)); m->slot = calloc(m->cap, sizeof(size_t));
+    m->vals = calloc(m->vcap * stride, sizeof(fp));
+}
+static void map_free(u64map_t *m) { free(m->keys); free(m->slot); free(m->vals); }
+static size_t map_probe(const u64map_t *m, uint64_t key) { /* keys are nonzero (node ids >= 1, account ids stored + 1) */
+    size_t i = (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 20) & (m->cap - 1);
+    while (m->keys[i] && m->keys[i] != key) i = (i + 1) & (m->cap - 1);
+    return i;
+}
+static fp *map_get(const u64map_t *m, uint64_t key) {
+    size_t i = map_probe(m, key);
+    return m->keys[i] ? m->vals + m->slot[i] * m->stride : NULL;
+}
+static fp *map_insert(u64map_t *m, uint64_t key) { /* existing entry or a new zeroed one */
+    if (2 * (m->used + 1) > m->cap) {
+        uint64_t *ok = m->keys; size_t *os = m->slot; size_t oc = m->cap;
+        m->cap *= 2; m->keys = calloc(m->cap, sizeof(uint64_t)); m->slot = calloc(m->cap, sizeof(size_t));
+        for (size_t j = 0; j < oc; j++) if (ok[j]) { size_t i = map_probe(m, ok[j]); m->keys[i] = ok[j]; m->slot[i] = os[j]; }
+        free(ok); free(os);
+    }
+    size_t i = map_probe(m, key);
+    if (!m->keys[i]) {
+        if (m->nvals == m->vcap) { m->vcap *= 2; m->vals = realloc(m->vals, m->vcap * m->stride * sizeof(fp)); }
+        memset(m->vals + m->nvals * m->stride, 0, m->stride * sizeof(fp));
+        m->keys[i] = key; m->slot[i] = m->nvals++; m->used++;
+    }
+    return m->vals + m->slot[i] * m->stride;
+}
+
+typedef struct { unsigned depth; uint64_t size; u64map_t nodes; fp empty[33][7]; } tree_t; /* empty[l]: digest of an empty subtree rooted at level l */
 
 static void tree_init_empty(tree_t *t, unsigned depth) {
     t->depth = depth;
-    t->size = (size_t)1 << depth;
-    t->nodes = calloc(2 * t->size * 7, sizeof(fp));
-    fp h[7] = {0};
-    for (int lvl = (int)depth - 1; lvl >= 0; lvl--) {
-        fp nh[7];
-        rescue_merge(h, h, nh);
-        memcpy(h, nh, sizeof h);
-        for (size_t i = (size_t)1 << lvl; i < ((size_t)2 << lvl); i++) memcpy(t->nodes + 7 * i, h, sizeof h);
+    t->size = (uint64_t)1 << depth;
+    map_init(&t->nodes, 7);
+    memset(t->empty, 0, sizeof t->empty);
+    for (int lvl = (int)depth - 1; lvl >= 0; lvl--) rescue_merge(t->empty[lvl + 1], t->empty[lvl + 1], t->empty[lvl]);
+}
+static const fp *tree_node(const tree_t *t, uint64_t id, unsigned lvl) {
+    const fp *v = map_get(&t->nodes, id);
+    return v ? v : t->empty[lvl];
+}
+static void tree_update_leaf(tree_t *t, uint64_t index, const fp *leaf) {
+    uint64_t i = t->size + index;
+    unsigned lvl = t->depth;
+    memcpy(map_insert(&t->nodes, i), leaf, 7 * sizeof(fp));
+    for (i >>= 1; i >= 1; i >>= 1) {
+        fp h[7];
+        rescue_merge(tree_node(t, 2 * i, lvl), tree_node(t, 2 * i + 1, lvl), h);
+        lvl--;
+        memcpy(map_insert(&t->nodes, i), h, sizeof h);
     }
 }
-static void tree_update_leaf(tree_t *t, size_t index, const fp *leaf) {
-    size_t i = t->size + index;
-    memcpy(t->nodes + 7 * i, leaf, 7 * sizeof(fp));
-    for (i >>= 1; i >= 1; i >>= 1) rescue_merge(t->nodes + 7 * (2 * i), t->nodes + 7 * (2 * i + 1), t->nodes + 7 * i);
-}
 /* [leaf, sibling_0 .. sibling_{d-1}] as MerkleTree::prove returns it (src/merkle/update/trace.rs:113 uses [k+1]) */
-static void tree_prove(const tree_t *t, size_t index, fp *path) {
-    size_t i = t->size + index;
-    memcpy(path, t->nodes + 7 * i, 7 * sizeof(fp));
-    for (unsigned k = 0; k < t->depth; k++, i >>= 1) memcpy(path + 7 * (k + 1), t->nodes + 7 * (i ^ 1), 7 * sizeof(fp));
+static void tree_prove(const tree_t *t, uint64_t index, fp *path) {
+    uint64_t i = t->size + index;
+    memcpy(path, tree_node(t, i, t->depth), 7 * sizeof(fp));
+    for (unsigned k = 0; k < t->depth; k++, i >>= 1) memcpy(path + 7 * (k + 1), tree_node(t, i ^ 1, t->depth - k), 7 * sizeof(fp));
 }
+static const fp *tree_root(const tree_t *t) { return tree_node(t, 1, 0); }
 static void leaf_hash(const fp *val, fp *out) { rescue_merge(val, val + 7, out); } /* src/lib.rs:287-290 */
 
 static void make_account(uint64_t *rng, fp *val, uint64_t *sk_out) {
@@ -136,47 +177,49 @@ void cso_sign_message(uint64_t *rng_state, const uint64_t *msg28, uint64_t sk, u
 
 int cso_tx_witness_generate(cstark_tx_witness *w, uint64_t seed) {
     const uint32_t n = w->n_tx, depth = w->merkle_depth;
-    if (n == 0 || depth == 0 || depth > 24) return -1;
+    if (n == 0 || depth == 0 || depth > 31) return -1;
     uint64_t rng = seed;
     tree_t tree;
     tree_init_empty(&tree, depth);
-    const size_t tree_size = tree.size;
-    fp *values = calloc(tree_size * 14, sizeof(fp));
-    uint64_t *sks = calloc(tree_size, sizeof(uint64_t)); /* 0 = no account yet */
+    const uint64_t tree_size = tree.size;
+    u64map_t accounts; /* leaf index + 1 -> 14 leaf values | secret key (0 = no account yet) */
+    map_init(&accounts, 15);
     uint64_t *s_idx = (uint64_t *)w->s_indices, *r_idx = (uint64_t *)w->r_indices;
     fp leaf[7];
 
     for (uint32_t t = 0; t < n; t++) { /* senders, src/lib.rs:273-296 */
-        size_t i = splitmix64(&rng) % tree_size;
+        uint64_t i = splitmix64(&rng) % tree_size;
         s_idx[t] = i;
-        make_account(&rng, values + 14 * i, &sks[i]);
-        leaf_hash(values + 14 * i, leaf);
+        fp *acc = map_insert(&accounts, i + 1);
+        make_account(&rng, acc, &acc[14]);
+        leaf_hash(acc, leaf);
         tree_update_leaf(&tree, i, leaf);
     }
     for (uint32_t t = 0; t < n; t++) { /* receivers, src/lib.rs:305-333 */
-        size_t i = splitmix64(&rng) % tree_size;
+        uint64_t i = splitmix64(&rng) % tree_size;
         while (i == s_idx[t]) i = splitmix64(&rng) % tree_size;
         r_idx[t] = i;
-        if (sks[i] == 0) {
-            make_account(&rng, values + 14 * i, &sks[i]);
-            leaf_hash(values + 14 * i, leaf);
+        fp *acc = map_insert(&accounts, i + 1);
+        if (acc[14] == 0) {
+            make_account(&rng, acc, &acc[14]);
+            leaf_hash(acc, leaf);
             tree_update_leaf(&tree, i, leaf);
         }
     }
     uint64_t *tx_sk = calloc(n, sizeof(uint64_t));
     for (uint32_t t = 0; t < n; t++) { /* transfers, src/lib.rs:347-422 */
-        size_t si = s_idx[t], ri = r_idx[t];
-        fp *sv = values + 14 * si, *rv = values + 14 * ri;
+        uint64_t si = s_idx[t], ri = r_idx[t];
+        fp *sv = map_get(&accounts, si + 1), *rv = map_get(&accounts, ri + 1);
         uint64_t sb = fp_to_u64(sv[12]), rb = fp_to_u64(rv[12]);
         uint64_t bound = sb < UINT64_MAX - rb ? sb : UINT64_MAX - rb;
         uint64_t dv = bound ? splitmix64(&rng) % bound : 0;
         fp delta = fp_from_u64(dv);
-        memcpy((fp *)w->initial_roots + 7 * t, tree.nodes + 7, 7 * sizeof(fp));
-        tx_sk[t] = sks[si];
+        memcpy((fp *)w->initial_roots + 7 * t, tree_root(&tree), 7 * sizeof(fp));
+        tx_sk[t] = sv[14];
         memcpy((fp *)w->s_old_values + 14 * t, sv, 14 * sizeof(fp));
         memcpy((fp *)w->r_old_values + 14 * t, rv, 14 * sizeof(fp));
         ((fp *)w->deltas)[t] = delta;
-        tree_prove(&tree, si, (fp *)w->s_paths + 7 * (depth + 1) * t);
+        tree_prove(&tree, si, (fp *)w->s_paths + 7 * (size_t)(depth + 1) * t);
         sv[12] = fp_sub(sv[12], delta);
         sv[13] = fp_add(sv[13], FP_ONE);
         rv[12] = fp_add(rv[12], delta);
@@ -184,9 +227,9 @@ int cso_tx_witness_generate(cstark_tx_witness *w, uint64_t seed) {
         tree_update_leaf(&tree, si, leaf);
         leaf_hash(rv, leaf);
         tree_update_leaf(&tree, ri, leaf);
-        tree_prove(&tree, ri, (fp *)w->r_paths + 7 * (depth + 1) * t);
+        tree_prove(&tree, ri, (fp *)w->r_paths + 7 * (size_t)(depth + 1) * t);
     }
-    memcpy((fp *)w->final_root, tree.nodes + 7, 7 * sizeof(fp));
+    memcpy((fp *)w->final_root, tree_root(&tree), 7 * sizeof(fp));
 
     /* signatures, src/lib.rs:435-447; independent per transaction -> per-tx RNG streams */
     uint64_t sig_seed = splitmix64(&rng);
@@ -201,6 +244,6 @@ int cso_tx_witness_generate(cstark_tx_witness *w, uint64_t seed) {
         msg[25] = w->s_old_values[14 * t + 13];
         sign_tx(&r2, msg, tx_sk[t], msg, (fp *)w->sig_rx + 6 * t, (uint8_t *)w->sig_s + 32 * t);
     }
-    free(tx_sk); free(values); free(sks); free(tree.nodes);
+    free(tx_sk); map_free(&accounts); map_free(&tree.nodes);
     return 0;
 }

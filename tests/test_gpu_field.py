@@ -22,7 +22,8 @@ def _run(backend, name, a, b, n, op, out_len):
     da = backend.from_numpy_u64(a)
     db = backend.from_numpy_u64(b) if b is not None else None
     out = backend.empty_u64(out_len)
-    fn = getattr(backend.lib, name)
+    from certificate_stark_amd import _lib
+    fn = getattr(_lib.load_debug(), name)
     rc = fn(C.c_void_p(backend.stream.cuda_stream), backend._ptr(da), backend._ptr(db) if db is not None else None,
             backend._ptr(out), C.c_size_t(n), C.c_int(op))
     assert rc == 0
@@ -69,6 +70,7 @@ def test_fp6_ops(oracle, backend):
 
 
 def test_matrix_core_mds_product_is_exact(backend):
+    from certificate_stark_amd import _lib
     """mds_mfma.cuh: INV_MDS times a vector through the int8 matrix cores (byte-diagonal GEMM with signed digits and offsets)
     equals the 128-bit carry-propagating scalar code bit for bit, including the extreme operand patterns."""
     import ctypes as C
@@ -87,7 +89,7 @@ def test_matrix_core_mds_product_is_exact(backend):
     for use_mfma in (0, 1):
         d_out = backend.empty_u64(14, npts)
         ms = C.c_float()
-        assert backend.lib.cstark_debug_mds(C.c_void_p(backend.stream.cuda_stream), backend._ptr(d_in), backend._ptr(d_out), C.c_size_t(npts),
+        assert _lib.load_debug().cstark_debug_mds(C.c_void_p(backend.stream.cuda_stream), backend._ptr(d_in), backend._ptr(d_out), C.c_size_t(npts),
                                             use_mfma, 1, C.byref(ms)) == 0
         outs.append(to_numpy_u64(d_out))
     assert (outs[0] == outs[1]).all()

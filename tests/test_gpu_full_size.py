@@ -73,6 +73,11 @@ def test_state_transition_2_20_end_to_end(oracle, backend):
     cf = oracle.make_coeffs(2024)
     pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
     comb = backend.evaluate_constraints(lde, cf, pub, w.depth)                       # [8][n], coset-major
+    # the degree-split evaluation the prover and the benchmark use (k_rounds_split / k_ec_split / k_lin_split / k_split_finish):
+    # on this table -- a genuine extension -- it must give the direct evaluator's values bit for bit, at all 2^23 points
+    comb_split = backend.evaluate_constraints(lde, cf, pub, w.depth, input_is_lde=True)
+    assert torch.equal(comb, comb_split)
+    del comb_split
     nat = comb.t().contiguous().reshape(1, 8 * n)                                     # natural order i = 8 j + k
     h_poly = to_numpy_u64(backend.interpolate_columns(nat))[0]                        # H(g y) as a polynomial in y (2^23 coefficients)
     z = int(oracle.to_mont([0x0BADC0FFEE123457 % P])[0])
@@ -122,6 +127,17 @@ def test_state_transition_2_20_complete_proof_verifies(oracle):
     proof = tx.prove()
     d = V.parse(proof)
     assert d["log_n"] == 20 and len(d["layer_roots"]) == 8 and len(d["remainder"]) == 128  # layers 2^23 .. 2^9, SURVEY 8(f)
+    # bit-exact against the CPU restatement of the prover at the full size: digests of the proof oracle/prover.py wrote for this
+    # witness and these options (tools/make_proof_digest.py, generated in the build container), whole proof and per section
+    import hashlib
+    import json
+    from tools.make_proof_digest import section_digests
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proof_1024tx_d15_q96.json")))
+    assert gold["options"] == [96, 8, 0, 0, 0, 4, 256] and len(proof) == gold["proof_bytes"]
+    got = section_digests(proof, 96)
+    for name, digest in gold["sections"].items():
+        assert got[name] == digest, "proof section differs from the CPU prover's: " + name
+    assert hashlib.sha256(proof).hexdigest() == gold["sha256"]
     assert V.verify(proof, *tx.pub_inputs(), options=[96, 8, 0, 0, 0, 4, 256])
     with pytest.raises(V.VerifierError):
         V.verify(proof, meta.initial_roots[0], np.full(7, meta.final_root[0], np.uint64))

