@@ -10,8 +10,14 @@ Merkle depth 15) is already resident in HBM; the timed region is one cstark_tx_p
 i.e. exactly the region the reference times (TransactionExample::prove = build_trace + Prover::prove, src/lib.rs:116-141,
 benches/state_transition.rs:21-24).  --mode hotpath times only K1..K6 (the SURVEY 8(a) rows) stage by stage.
 
-Launch:  python bench.py --gpus N --steps K --warmup W      (N > 1: one rank per GPU via torch.distributed.run)
-Multi-GPU = independent proofs per GPU (replicas, no data-path collective): weak scaling.
+Launch:  python bench.py --gpus N --steps K --warmup W
+  N > 1 without a torch.distributed environment (RANK / WORLD_SIZE unset): this process starts the N ranks itself as a child
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` BEFORE it
+  imports torch or touches the GPU, relays rank 0's JSON line and exits with the child's code.  Launched by torch.distributed.run
+  (the driver's form) it is one rank; --gpus must then equal WORLD_SIZE.
+Multi-GPU, default (--mode prove): independent proofs per GPU (replicas, no data-path collective; the only RCCL traffic is the
+  barrier / max-over-ranks timing): weak scaling.  --mode shard: ONE proof across the GPUs by LDE coset with RCCL all-gathers of
+  leaf digests, merged evaluations and query rows: strong scaling.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -85,6 +91,33 @@ def cpu_baseline(meta, sample_tx, full_options=None):
     }
 
 
+def spawn_ranks(n):
+    """--gpus N without a torch.distributed environment: start the N ranks as a fresh child process tree (this process has not
+    imported torch and never touches the GPU), pass the child's output through, and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:  # rank 0 prints the one JSON line; anything else the ranks write to stdout is passed through to stderr
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,16 +141,28 @@ def main():
     ap.add_argument("--queries", type=int, default=96, help="FRI queries (BASELINE.json: 96; the reference's get_example: 42)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; pass --gpus equal to the number of ranks torch.distributed.run started "
+                         "(or run `python bench.py --gpus N` alone: it starts the ranks itself)" % (args.gpus, world))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local)
+    rccl_ranks = None
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        ones = torch.ones(1, device="cuda", dtype=torch.int64)
+        dist.all_reduce(ones)  # one real RCCL collective over every rank's device buffer: the sum is the number of ranks that took part
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != world or dist.get_world_size() != world:
+            raise SystemExit("bench.py: RCCL all-reduce saw %d ranks, expected %d" % (rccl_ranks, world))
 
     from certificate_stark_amd import _lib
     from certificate_stark_amd.backend import Backend
@@ -312,7 +357,7 @@ def main():
                       ("proofs/sec, state_transition AIR @ 2^%d steps (hot path only: trace gen + LDE + Blake3 commitment + constraint evaluation)" % log_n),
             "value": round((1 if coset_mode else world) / (ms_per_step * 1e-3), 4),
             "unit": "proofs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong" if coset_mode else "weak", "vs_baseline": None,
             "dtype": "u64 (63-bit prime field, Montgomery) + u32 (Blake3)", "data": "synthetic",
