@@ -65,8 +65,9 @@ def cpu_baseline(meta, sample_tx, full_options=None):
         total = time.perf_counter() - t0
         return {
             "value": round(sample_tx / meta.n_tx / total, 5), "unit": "proofs/s", "cores": O.num_threads(), "kind": "port",
-            "sample": "complete proof of %d of %d transactions (2^%d of 2^20 rows, %d proof bytes) by the OpenMP oracle prover in %.2f s, "
-                      "linearly extrapolated" % (sample_tx, meta.n_tx, (sample_tx * 1024).bit_length() - 1, len(proof), total),
+            "sample": "complete proof of %d of %d transactions (2^%d of 2^20 rows, %d proof bytes) by the OpenMP oracle prover in %.2f s%s" % (
+                sample_tx, meta.n_tx, (sample_tx * 1024).bit_length() - 1, len(proof), total,
+                "" if sample_tx == meta.n_tx else ", linearly extrapolated"),
         }
     cf = O.make_coeffs(17)
     pub = np.concatenate([w.initial_roots[0][:2], w.final_root[:2]])
@@ -89,6 +90,32 @@ def cpu_baseline(meta, sample_tx, full_options=None):
                   "OpenMP oracle: trace %.2fs, lde %.2fs, commit %.2fs, constraints %.2fs" % (
                       sample_tx, meta.n_tx, (sample_tx * 1024).bit_length() - 1, t1 - t0, t2 - t1, t3 - t2, t4 - t3),
     }
+
+
+class PmcTraffic:
+    """HBM bytes per proof and kernel from the newest PMC summary under profiles/ (tools/profile.sh + tools/pmc_summary.py run on the
+    GPU box for this build; separate FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE as MI355X_MICROARCH.md prescribes for gfx950).
+    No file, or a kernel that is not in it: None -- never a literal."""
+
+    def __init__(self):
+        import csv
+        import glob
+        import re
+        self.gb, self.source = {}, None
+        files = glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.csv"))
+        key = lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))]
+        for f in sorted(files, key=key, reverse=True):
+            rows = list(csv.DictReader(open(f)))
+            if rows and "fetch_x2_plus_write_GB_per_proof" in rows[0]:
+                self.gb = {r["kernel"]: float(r["fetch_x2_plus_write_GB_per_proof"]) for r in rows}
+                self.source = "profiles/" + os.path.basename(f)
+                break
+
+    def per_proof(self, names):
+        if not names or not self.gb:
+            return None
+        hit = [self.gb[k] for k in names if k in self.gb]
+        return sum(hit) if hit else None
 
 
 def spawn_ranks(n):
@@ -124,14 +151,17 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-tx", type=int, default=1024, help="transactions per proof (1024 = BASELINE's 2^20 rows)")
-    ap.add_argument("--cpu-sample-tx", type=int, default=256)
+    ap.add_argument("--cpu-sample-tx", type=int, default=1024,
+                    help="transactions the CPU baseline proves (default: the whole 1024-transaction witness, no extrapolation; about 25 s on the GPU "
+                         "box's host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-composition", action="store_true",
                     help="also time the next stage of prove(): composition polynomial columns + their LDE + Blake3 commitment "
                          "(reported as extra_stage_ms, not part of the hot-path metric)")
-    ap.add_argument("--mode", choices=["prove", "hotpath", "coset"], default="prove",
+    ap.add_argument("--mode", choices=["prove", "hotpath", "shard"], default="prove",
                     help="prove: complete proofs, independent per GPU (weak scaling, no collective); hotpath: K1..K6 only, "
-                         "independent per GPU; coset: the K1..K6 of ONE proof sharded by LDE coset with RCCL all-gathers (strong scaling)")
+                         "independent per GPU; shard: ONE complete proof sharded by LDE coset over the GPUs with RCCL all-gathers of "
+                         "digests and merged evaluations (strong scaling; needs --gpus 2, 4 or 8)")
     ap.add_argument("--hash-fn", choices=["blake3", "sha3"], default="blake3", help="ProofOptions hash (the headline metric uses Blake3_256, src/lib.rs:82)")
     ap.add_argument("--field-extension", choices=["none", "quadratic", "cubic"], default="none",
                     help="ProofOptions field extension (the headline metric uses None; the reference's CLI defaults to cubic)")
@@ -181,7 +211,7 @@ def main():
     field_ext = {"none": 0, "quadratic": 1, "cubic": 2}[args.field_extension]
     prover = TransactionProver(ProofOptions(num_queries=args.queries, hash_fn=hash_fn, field_extension=field_ext), Backend(local))
     prover.load_witness(meta)  # witness resident in HBM before the timed region
-    rng = np.random.default_rng(1234 + (rank if args.mode != "coset" else 0))  # one proof = one set of coefficients
+    rng = np.random.default_rng(1234 + rank)  # one proof = one set of coefficients
     cf = _lib.TxCoeffsStruct()
     for name, k in (("t_alpha", 115), ("t_beta", 115), ("b_alpha", 4), ("b_beta", 4)):
         v = rng.integers(1, P, size=k, dtype=np.uint64)
@@ -191,38 +221,23 @@ def main():
 
     stages = ["trace_gen", "interpolate", "lde", "hash_rows", "merkle", "constraints"]
     acc_ms = {s: 0.0 for s in stages}
-    coset_mode = args.mode == "coset" and world > 1
+    coset_mode = args.mode == "shard"
+    if coset_mode and world not in (2, 4, 8):
+        raise SystemExit("bench.py --mode shard splits one proof over 2, 4 or 8 GPUs (--gpus)")
     if coset_mode:
         from certificate_stark_amd import sharding
-        k0, nk = sharding.coset_range(rank, world, 1 << LOG_B)
 
     def step_coset(timed):
-        """one proof over all ranks: K1/K2 replicated, K3/K4/K6 on this rank's cosets, two all-gathers"""
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if timed else None
-        b = prover.backend
-        if timed: ev[0].record()
-        trace = prover.build_trace()
-        if timed: ev[1].record()
-        coeffs = b.interpolate_columns(trace, out=prover._buf("coeffs", (WIDTH, n)))
-        if timed: ev[2].record()
-        lde = b.lde_columns(coeffs, LOG_B, k0=k0, nk=nk, out=prover._buf("lde", (nk, WIDTH, n)))
-        if timed: ev[3].record()
-        local = prover._buf("leaves_local", (nk, n, 32), torch.uint8)
-        for i in range(nk):  # compact per-coset digests: hash each coset as a blowup-1 domain
-            b.hash_rows(lde[i:i + 1], 0, leaves=local[i])
-        all_leaves = sharding.all_gather_cosets(local)
-        L = n << LOG_B
-        nodes = prover._buf("nodes", (2 * L, 32), torch.uint8)
-        nodes[L:] = sharding.leaves_to_natural_order(all_leaves)
-        if timed: ev[4].record()
-        b.merkle_build(nodes)
-        if timed: ev[5].record()
-        comb = prover.evaluate_constraints(lde, cf, pub, k0=k0)
-        sharding.all_gather_cosets(comb)
-        if timed: ev[6].record()
-        return ev
+        """one complete proof over all ranks (cstark_tx_shard_* phases, RCCL all-gathers in between); bytes on rank 0"""
+        proof = sharding.prove_sharded(prover.backend, prover.options)
+        if proof is not None:
+            proof_len[0] = len(proof)
+            if timed:
+                for k, v in prover.backend.prove_stage_ms().items():
+                    pacc[k] += v
+        return None
 
-    prove_mode = args.mode == "prove"
+    prove_mode = args.mode in ("prove", "shard")
     pstages = list(Backend.PROVE_STAGES)
     pacc = {k: 0.0 for k in pstages}
     proof_len = [0]
@@ -236,10 +251,10 @@ def main():
         return None
 
     def step(timed):
-        if prove_mode:
-            return step_prove(timed)
         if coset_mode:
             return step_coset(timed)
+        if prove_mode:
+            return step_prove(timed)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if timed else None
         b = prover.backend
         if timed: ev[0].record()
@@ -337,20 +352,48 @@ def main():
         extra = {"composition_columns": round(e[0].elapsed_time(e[1]), 3), "composition_lde": round(e[1].elapsed_time(e[2]), 3),
                  "composition_commit": round(e[2].elapsed_time(e[3]), 3)}
 
+    lde_ms, lde_elements = prover.backend.lde_timing_ms()  # every low-degree extension of the timed steps (HIP events on the context's stream)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
+        per = args.steps // inflight
         ab = algorithmic_bytes(n, WIDTH, 1 << LOG_B)
-        part_avg = {k: v / (args.steps // inflight) for k, v in part_ms.items()}
-        # dominant single KERNEL: the Rescue-window launch of the constraint stage (k_eval_fused<0>).  Its algorithmic bytes:
-        # the 58 hash-state registers of every LDE row read once (current and next row share cache lines), the 28 round-
-        # constant values per point from the 3 MB periodic table (cache resident, not counted), one 8-byte result.
-        nb = (nk if coset_mode else (1 << LOG_B))
-        # In prove mode the windows run as k_rounds_split: the even cosets only (their merged polynomials have degree < 4n and are
-        # extended to the odd cosets afterwards), six 8-byte polynomial values per point out.
-        split = (prove_mode and field_ext == 0) or (not prove_mode and not coset_mode)
+        part_avg = {k: v / per for k, v in part_ms.items()}
+        split = (args.mode == "prove" and field_ext == 0) or args.mode == "hotpath"
+        traffic = PmcTraffic()
+        # ---- roofline entries: ALGORITHMIC bytes (input read once, output written once) / HIP-event duration measured
+        # in the timed region above; `traffic` = HBM bytes per launch set from the PMC passes of tools/profile.sh on this build
+        # (profiles/<tag>_hbm_traffic_pmc.csv: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md) ----
+        def entry(kernel, alg_bytes, ms, pmc_names, note=None, launches=1):
+            ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+            t = traffic.per_proof(pmc_names) if n_tx == 1024 and args.mode == "prove" and field_ext == 0 and hash_fn == 0 else None
+            e = {"bound": "hbm", "kernel": kernel, "achieved": None if ach is None else round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 4), "traffic": None if t is None else round(t * 1e9 / launches),
+                 "algorithmic_bytes": int(alg_bytes / launches), "kernel_ms": round(ms / launches, 4), "launches_per_proof": launches,
+                 "traffic_source": traffic.source if t is not None else None}
+            if note:
+                e["note"] = note
+            return e
+        # the transform pair of the low-degree extensions: per evaluation written 8 bytes out + 1/8 coefficient read (blowup 8)
+        lde_alg = lde_elements / per * 8 * (1 + 1.0 / (1 << LOG_B))
+        lde_pairs = max(1, round(lde_elements / per / (WIDTH * n)))  # in units of "94 columns of one coset"
+        ntt_names = ["k_ntt_cols_v2<5, 5, false>", "k_ntt_rows_v2<5, 5, false>", "k_lde_cols", "k_lde_rows"]
+        roofline_lde = entry("forward transform pair of the low-degree extension (k_ntt_cols_v2 + k_ntt_rows_v2, all LDE calls of a proof: trace 94 "
+                             "columns x 8 cosets, composition 8 x 8, DEEP 1 x 8)", lde_alg, lde_ms / per, ntt_names,
+                             "the dominant kernel family by GPU time; integer-VALU bound (about 350 VALU instructions per element and coset, "
+                             "profiles/*_valu_pmc.csv), priced against the HBM roofline as BASELINE.json asks; kernel_ms = per 94 columns x 1 coset; "
+                             "inside cstark_tx_prove the first two column batches are extended beside the trace recurrences (DESIGN.md 5a)",
+                             launches=lde_pairs)
+        nb = (8 // world) if coset_mode else 8
         rounds_bytes = (nb // 2) * n * (58 * 8 + 6 * 8) if split else nb * n * (58 * 8 + 8)
-        dom_ms = part_avg["rounds"]
-        achieved = rounds_bytes / (dom_ms * 1e-3) / 1e9
+        roofline_rounds = entry("k_rounds_split (Rescue windows of the constraint evaluation, even cosets)" if split else
+                                "k_eval_fused<0> (Rescue windows of the constraint evaluation)", rounds_bytes, part_avg["rounds"],
+                                ["k_rounds_split<1>"] if split else ["k_eval_fused<0, 1>"],
+                                "longest single launch; integer-multiplier bound (profiles/*_valu_pmc.csv, *_modmul.txt)")
+        roofline_stages = [roofline_lde, roofline_rounds]
+        if args.mode == "prove":
+            roofline_stages.append(entry("row hashes + Merkle tree of the trace commitment (k_hash_rows + k_merkle_level/top)", ab["hash_rows"] + ab["merkle"],
+                                         stage_ms["commit"], None, "the one HBM-shaped stage; k_hash_rows moves exactly its algorithmic bytes"))
+            roofline_stages.append(entry("constraint evaluation stage (all launches)", ab["constraints"], stage_ms["constraints"], None))
         out = {
             "metric": ("proofs/sec, state_transition AIR @ 2^%d steps (complete prove(): trace gen, LDE, Blake3 commitments, constraint "
                        "evaluation, composition, DEEP, FRI, %d queries)" % (log_n, args.queries)) if prove_mode else
@@ -365,8 +408,9 @@ def main():
                                    "Merkle depth %d, %s, %s" % (n_tx, log_n, meta.depth, "Sha3_256" if hash_fn else "Blake3_256",
                                                                       ["no field extension", "quadratic extension", "cubic extension"][field_ext]),
                        "queries": args.queries, "proof_bytes": proof_len[0] or None,
-                       "parallelism": ("one proof sharded by LDE coset over %d GPUs, RCCL all-gather of digests and evaluations" % world)
-                       if coset_mode else ("replica x%d (independent proofs per GPU, no collective)%s" % (
+                       "parallelism": ("one proof sharded by LDE coset over %d GPUs: RCCL all-gather of leaf digests and merged evaluations, "
+                                       "broadcast of query positions, reduction of opened rows" % world)
+                       if coset_mode else ("replica x%d (independent proofs per GPU, no data-path collective)%s" % (
                            world, ", %d proofs in flight per GPU" % inflight if inflight > 1 else "")),
                        "trace": "%d x 2^%d" % (WIDTH, log_n)},
             "stage_ms": {s: round(v, 3) for s, v in stage_ms.items()},
@@ -380,17 +424,8 @@ def main():
             "constraint_part_ms": {k: round(v, 3) for k, v in part_avg.items()},
             "constraint_part_note": ("all parts except final_add run on the even cosets only (split evaluation); lin_c includes the extension of their "
                                      "14 polynomials to the odd cosets and the recombination over all cosets") if split else None,
-            "roofline": {"bound": "hbm", "kernel": ("k_rounds_split (Rescue windows of the constraint evaluation, on the even cosets)" if split else
-                                                    "k_eval_fused<0> (Rescue windows of the constraint evaluation)"),
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (2.598e9 if split else 5.705e9) if (n_tx == 1024 and not coset_mode) else None,
-                         "algorithmic_bytes": rounds_bytes, "kernel_ms": round(dom_ms, 3),
-                         "traffic_source": "profiles/r01_v12_hbm_traffic_pmc.csv (k_rounds_split) / r01_v10_hbm_traffic_pmc.csv (k_eval_fused<0>): 2*FETCH_SIZE + WRITE_SIZE per launch (gfx950 FETCH_SIZE correction, calibrated on k_hash_rows). "
-                                           "Each window's 14 columns arrive once by LDS-DMA (66 rows per 64 points); the five windows overlap in 12 columns, which are "
-                                           "fetched once per window (70 column reads for 58 distinct columns = 1.21x), the rest is the periodic table and tables of w",
-                         "note": "integer-multiplier bound kernel (~1.1e4 v_mad_u64_u32 per point; the chip sustains 1.39e13/s = 2.3e12 field products/s) priced against the "
-                                 "HBM roofline as BASELINE.json asks; whole-stage figures are in stage_gbs"},
+            "roofline": roofline_lde,
+            "roofline_stages": roofline_stages,
         }
         if extra:
             out["extra_stage_ms"] = extra

@@ -270,6 +270,12 @@ class Backend:
         check(self.lib.cstark_tx_constraint_part_ms(self.ctx, ms))
         return dict(zip(self.CE_PARTS, [float(v) for v in ms]))
 
+    def lde_timing_ms(self):
+        """(milliseconds, evaluations written) of all low-degree extensions since the last call (part timing on)"""
+        ms, el = C.c_float(), C.c_uint64()
+        check(self.lib.cstark_lde_timing_ms(self.ctx, C.byref(ms), C.byref(el)))
+        return float(ms.value), int(el.value)
+
     def schnorr_assertion_polys(self, log_n):
         out = self.empty_u64(12, 1 << log_n)
         check(self.lib.cstark_schnorr_assertion_polys(self.ctx, self._ptr(out), C.c_uint32(log_n)))
@@ -339,6 +345,53 @@ class Backend:
         buf = (C.c_uint8 * cap)()
         n = C.c_size_t(0)
         check(self.lib.cstark_tx_prove(self.ctx, C.byref(o), buf, C.c_size_t(cap), C.byref(n)))
+        return bytes(memoryview(buf)[:n.value])
+
+    # ---- one proof across several GPUs by LDE coset: the phases of cstark_tx_shard_* (driver: sharding.prove_sharded) -------------
+    def _options_struct(self, options):
+        return _lib.OptionsStruct(options.num_queries, options.blowup_factor, options.grinding_factor, options.hash_fn,
+                                  options.field_extension, options.fri_folding_factor, options.fri_max_remainder)
+
+    def shard_commit(self, options, k0, nk):
+        """phase 1 -> digests of this rank's rows, uint8 [nk][n][32]"""
+        self._shard_options = options
+        n = self.n_tx * _lib.TX_CYCLE_LENGTH
+        leaves = self.empty_u8(nk, n, 32)
+        o = self._options_struct(options)
+        check(self.lib.cstark_tx_shard_commit(self.ctx, C.byref(o), C.c_uint32(k0), C.c_uint32(nk), self._ptr(leaves, u8p)))
+        self._shard_nk = nk
+        return leaves
+
+    def shard_evaluate(self, leaves_all):
+        """phase 2: all-gathered digests [8][n][32] -> merged constraint evaluations of this rank's cosets, int64 [nk][n]"""
+        n = self.n_tx * _lib.TX_CYCLE_LENGTH
+        assert tuple(leaves_all.shape) == (8, n, 32) and leaves_all.dtype == torch.uint8
+        out = self.empty_u64(self._shard_nk, n)
+        check(self.lib.cstark_tx_shard_evaluate(self.ctx, self._ptr(leaves_all.contiguous(), u8p), self._ptr(out)))
+        return out
+
+    def shard_compose(self, combined_all):
+        """phase 3 (the rank that owns coset 0): merged evaluations of all cosets [8][n] -> query positions, int32 [num_queries]"""
+        nq = self._shard_options.num_queries
+        pos = np.zeros(nq, np.uint32)
+        check(self.lib.cstark_tx_shard_compose(self.ctx, self._ptr(combined_all.contiguous()), pos.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return torch.from_numpy(pos.view(np.int32)).to(self.device)
+
+    def shard_open_rows(self, positions):
+        """phase 4: rows of the extended trace at `positions` that lie in this rank's cosets (zeros elsewhere), int64 [nq][94]"""
+        pos = np.ascontiguousarray(positions.detach().cpu().numpy().view(np.uint32))
+        rows = self.empty_u64(pos.size, _lib.TX_TRACE_WIDTH)
+        check(self.lib.cstark_tx_shard_open_rows(self.ctx, pos.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(pos.size), self._ptr(rows)))
+        return rows
+
+    def shard_finish(self, rows):
+        """phase 5 (the rank that ran phase 3): complete opened rows -> proof bytes"""
+        o = self._options_struct(self._shard_options)
+        self.lib.cstark_tx_proof_size_bound.restype = C.c_size_t
+        cap = self.lib.cstark_tx_proof_size_bound(C.c_uint32(self.n_tx), C.byref(o))
+        buf = (C.c_uint8 * cap)()
+        n = C.c_size_t(0)
+        check(self.lib.cstark_tx_shard_finish(self.ctx, self._ptr(rows.contiguous()), buf, C.c_size_t(cap), C.byref(n)))
         return bytes(memoryview(buf)[:n.value])
 
     PROVE_STAGES = ("trace", "interpolate", "lde", "commit", "constraints", "composition", "ood", "deep", "fri", "queries")

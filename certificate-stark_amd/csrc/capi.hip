@@ -101,10 +101,32 @@ int interpolate_impl(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint3
     return CSTARK_OK;
 }
 
+// part timing: an event on the stream, from a pool that grows on demand
+int lde_mark(cstark_ctx *c) {
+    if (c->lde_ev_used == c->lde_ev.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->lde_ev.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(c->lde_ev[c->lde_ev_used++], c->stream));
+    return CSTARK_OK;
+}
+
 constexpr size_t LDE_BATCH_WS_BYTES = (size_t)1 << 30; // batched-coset launches when their intermediate is at most this large
 constexpr uint32_t LDE_COLUMN_GROUP = 1u << 30; // columns per group of the LDE (see lde_impl); 2^30 = all columns at once
+int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n,
+                   uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);
 int lde_impl(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n, uint32_t log_blowup,
              uint64_t domain_offset, uint32_t k0, uint32_t nk) {
+    const bool timed = c && c->part_timing;
+    if (timed) RC_TRY(lde_mark(c));
+    const int rc = lde_impl_inner(c, d_coeffs, d_lde, width, col0, ncols, log_n, log_blowup, domain_offset, k0, nk);
+    if (timed && rc == CSTARK_OK) { RC_TRY(lde_mark(c)); c->lde_units += (uint64_t)ncols * nk << log_n; }
+    else if (timed) c->lde_ev_used--;
+    return rc;
+}
+int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n,
+                   uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk) {
     if (!c || !d_coeffs || !d_lde || width == 0 || ncols == 0 || (uint64_t)col0 + ncols > width) return fail(CSTARK_ERR_INVALID_ARG, "cstark_lde_columns: bad argument");
     if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6) return fail(CSTARK_ERR_UNSUPPORTED, "unsupported domain size");
     if (domain_offset == 0 || domain_offset >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "domain offset must be a nonzero field element");
@@ -269,6 +291,7 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     if (c->tail_buf) (void)hipFree(c->tail_buf);
     if (c->arena) cs::prove_arena_free(c->arena);
     for (hipEvent_t e : c->part_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->lde_ev) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -1028,6 +1051,21 @@ int cstark_ctx_set_part_timing(cstark_ctx *c, int enable) {
         for (hipEvent_t &e : c->part_ev) HIP_TRY(hipEventCreate(&e));
     c->part_timing = enable != 0;
     c->part_valid = false;
+    return CSTARK_OK;
+}
+int cstark_lde_timing_ms(cstark_ctx *c, float *total_ms, uint64_t *elements) {
+    if (!c || !total_ms || !elements) return fail(CSTARK_ERR_INVALID_ARG, "null argument");
+    float sum = 0;
+    if (c->lde_ev_used) HIP_TRY(hipEventSynchronize(c->lde_ev[c->lde_ev_used - 1]));
+    for (size_t i = 0; i + 1 < c->lde_ev_used; i += 2) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->lde_ev[i], c->lde_ev[i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *elements = c->lde_units;
+    c->lde_ev_used = 0;
+    c->lde_units = 0;
     return CSTARK_OK;
 }
 int cstark_tx_constraint_part_ms(cstark_ctx *c, float *ms /* [9] */) {

@@ -68,6 +68,11 @@ struct cstark_ctx {
     void *desc_buf = nullptr;     // device copy of a generic AIR description (cstark_air_combine)
     hipEvent_t part_ev[cs::CE_NUM_PARTS + 1] = {}; // optional per-launch timing of the fused constraint evaluation
     bool part_timing = false, part_valid = false;
+    // with part_timing: one event pair around every low-degree extension (cstark_lde_columns and the prover's own calls) since the
+    // last cstark_lde_timing_ms; lde_units = column x coset transforms inside the pairs
+    std::vector<hipEvent_t> lde_ev;
+    size_t lde_ev_used = 0;
+    uint64_t lde_units = 0;
     uint64_t *tail_buf = nullptr; // standalone SchnorrAir: message[26..28] per signature
     std::vector<uint64_t> schnorr_rx; // host copy of the signatures' R.x ([n][6]) for the sequence assertions
     std::vector<uint64_t> schnorr_pub; // messages [n][28] then R.x [n][6]: SchnorrAir's public inputs, for the channel seed

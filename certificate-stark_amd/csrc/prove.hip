@@ -44,10 +44,13 @@ struct ProveArena {
     hipEvent_t ev[PROVE_EVENTS] = {};
     bool timed = false;
     std::vector<void *> owned;
+    struct ProofRun *run = nullptr; // a proof in progress between the phases of the sharded entry points (cstark_tx_shard_*)
 };
+void proof_run_free(struct ProofRun *r);
 
 void prove_arena_free(ProveArena *a) {
     if (!a) return;
+    proof_run_free(a->run);
     for (void *p : a->owned) (void)hipFree(p);
     if (a->h_pub) (void)hipHostFree(a->h_pub);
     for (hipEvent_t e : a->ev) if (e) (void)hipEventDestroy(e);
@@ -126,6 +129,21 @@ __global__ void k_gather_rows(const uint64_t *__restrict__ lde, uint32_t width, 
     const uint32_t q = blockIdx.x, i = pos[q], k = i & ((1u << log_b) - 1), j = i >> log_b;
     for (uint32_t c = threadIdx.x; c < width; c += blockDim.x) out[(size_t)q * width + c] = lde[(((size_t)k * width + c) << log_n) + j];
 }
+// the same for a table that holds cosets [k0, k0 + nk) only: rows of other cosets are written as zeros (the owners' rows are summed in)
+__global__ void k_gather_rows_window(const uint64_t *__restrict__ lde, uint32_t width, uint32_t log_n, uint32_t log_b, uint32_t k0, uint32_t nk,
+                                     const uint32_t *__restrict__ pos, uint64_t *__restrict__ out) {
+    const uint32_t q = blockIdx.x, i = pos[q], k = i & ((1u << log_b) - 1), j = i >> log_b;
+    const bool mine = k >= k0 && k < k0 + nk;
+    for (uint32_t c = threadIdx.x; c < width; c += blockDim.x)
+        out[(size_t)q * width + c] = mine ? lde[(((size_t)(k - k0) * width + c) << log_n) + j] : 0;
+}
+// leaf digests [b][n] (coset-major, as the ranks' all-gather delivers them) -> natural order: leaf b*j + k = digest (k, j)
+__global__ void k_interleave_leaves(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n, uint32_t log_b) {
+    const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; // one 16-byte half of a digest
+    if (t >= (n << (log_b + 1))) return;
+    const size_t i = t >> 1, half = t & 1, k = i & ((1u << log_b) - 1), j = i >> log_b;
+    out[t] = in[2 * (k * n + j) + half];
+}
 // authentication path of leaf pos[q]: siblings from the leaf level upwards
 __global__ void k_gather_paths(const uint4 *__restrict__ nodes, uint32_t log_leaves, const uint32_t *__restrict__ pos, uint4 *__restrict__ out) {
     const uint32_t q = blockIdx.x;
@@ -195,6 +213,7 @@ struct AirJob {
     std::vector<ColumnBatch> batches;
     const uint64_t *pub_staging = nullptr; // pinned host copy of the public inputs, valid once every batch has been waited for
     bool evals_ready = false;       // sub-AIRs: the materialised transition evaluations of this proof are already in the arena
+    uint32_t k0 = 0, nk = 8;        // LDE cosets this GPU owns (all of them unless the proof is sharded)
     uint64_t number = 0;            // RangeProofAir
     const uint64_t *bits = nullptr; // RangeProofAir, long form: the n/64 words of the value (host)
 };
@@ -251,17 +270,17 @@ int check_options(const cstark_options *opt, unsigned *log_rem_out) {
     return CSTARK_OK;
 }
 
-// Prover::prove for any of the AIRs.
-// Interpolation and extension of the trace columns; records the two stage events (after the interpolation, after the extension).
-// With column batches (AirJob::batches) the complete columns go first -- interpolated AND extended while the internal streams still
-// write the later ones -- so the "interpolate" stage time then also holds the extension of the earlier batches.
+// Interpolation and extension of the trace columns (cosets [job.k0, job.k0 + job.nk)); records the two stage events (after the
+// interpolation, after the extension).  With column batches (AirJob::batches) the complete columns go first -- interpolated AND
+// extended while the internal streams still write the later ones -- so the "interpolate" stage time then also holds the extension
+// of the earlier batches.
 int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hipStream_t st, int &evi) {
-    const uint32_t W = job.width, log_n = job.log_n, b = 1u << log_b;
+    const uint32_t W = job.width, log_n = job.log_n;
     const size_t n = (size_t)1 << log_n;
     if (job.batches.empty()) {
         RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, W, log_n));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
-        RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, W, log_n, log_b, host::generator(), 0, b));
+        RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, W, log_n, log_b, host::generator(), job.k0, job.nk));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
         return CSTARK_OK;
     }
@@ -271,68 +290,115 @@ int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hi
             if (e) HIP_TRY(hipStreamWaitEvent(st, e, 0));
         RC_TRY(cstark_interpolate_columns(c, a->trace + (size_t)cb.col0 * n, a->coeffs + (size_t)cb.col0 * n, cb.ncols, log_n));
         if (i + 1 == job.batches.size()) HIP_TRY(hipEventRecord(a->ev[evi++], st));
-        RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, cb.col0, cb.ncols, log_n, log_b, host::generator(), 0, b));
+        RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, cb.col0, cb.ncols, log_n, log_b, host::generator(), job.k0, job.nk));
     }
     HIP_TRY(hipEventRecord(a->ev[evi++], st));
     return CSTARK_OK;
 }
 
-int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *proof, size_t capacity, size_t *proof_len) {
-    unsigned log_rem = 0;
-    RC_TRY(check_options(opt, &log_rem));
-    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b, log_ce = job.log_ce;
-    if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "at most 2^21 trace rows");
-    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = job.width, ce = (size_t)1 << log_ce;
-    const unsigned n_layers = num_fri_layers(log_N, log_rem);
-    const size_t nq = opt->num_queries;
-    if (nq > N / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
-    HIP_TRY(hipSetDevice(c->device));
-    ProveArena *a;
-    RC_TRY(get_arena(c, job, log_b, n_layers, nq, &a));
-    hipStream_t st = c->stream;
-    int evi = 0;
-#define STAGE() HIP_TRY(hipEventRecord(a->ev[evi++], st))
-    a->timed = false;
+} // namespace
 
-    // ---- trace, public inputs ---------------------------------------------------------------------------------------
+// Prover::prove for any of the AIRs over the base field, as a sequence of phases.  On one GPU (prove_core) they run back to back;
+// the sharded entry points (cstark_tx_shard_*: one proof across several GPUs by LDE coset) run them with the ranks' all-gathers in
+// between -- leaf digests after `commit`, merged evaluations after `evaluate`, the opened trace rows after `compose`.
+struct ProofRun {
+    cstark_options opt{};
+    AirJob job;
+    unsigned log_rem = 0, n_layers = 0;
+    Coin coin;
+    uint8_t trace_root[32] = {}, cons_root[32] = {}, rem_commit[32] = {};
+    std::vector<uint64_t> ta, tb, ba, bb, ood_trace, ood_comp, remainder;
+    std::vector<uint8_t> layer_roots;
+    uint64_t nonce = 0;
+    std::vector<uint32_t> positions;
+    std::vector<std::vector<uint32_t>> lpos;
+    int evi = 0, phase = 0; // phase: 1 commit, 2 evaluate, 3 compose done
+    bool sharded() const { return job.nk != 8; }
+};
+void proof_run_free(ProofRun *r) { delete r; }
+
+namespace {
+
+#define STAGE() HIP_TRY(hipEventRecord(a->ev[R.evi++], st))
+
+// ---- phase 1: trace, its interpolation and extension, row hashes of the owned cosets ---------------------------------------------
+// d_leaves_local (sharded only): compact digests [nk][n][32] of this rank's rows; otherwise the leaves go straight into the tree.
+int phase_commit(cstark_ctx *c, ProveArena *a, ProofRun &R, uint8_t *d_leaves_local) {
+    AirJob &job = R.job;
+    const unsigned log_n = job.log_n, log_b = 3;
+    const size_t n = (size_t)1 << log_n, N = n * 8, W = job.width;
+    hipStream_t st = c->stream;
+    a->timed = false;
+    R.evi = 0;
     STAGE();
     RC_TRY(job.build(c, a, job));
     STAGE();
-    // ---- trace commitment -----------------------------------------------------------------------------------------------
-    RC_TRY(commit_columns(c, a, job, log_b, st, evi));
-    const uint32_t hf = opt->hash_fn;
-    RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, (uint32_t)b));
+    RC_TRY(commit_columns(c, a, job, log_b, st, R.evi));
+    const uint32_t hf = R.opt.hash_fn;
+    if (!R.sharded()) {
+        RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, 8));
+    } else {
+        for (uint32_t i = 0; i < job.nk; i++) // a coset alone is a blowup-1 domain: leaf j of the call = row j of the coset
+            RC_TRY(cstark_hash_rows_fn(c, hf, a->lde + (size_t)i * W * n, d_leaves_local + (size_t)i * n * 32, (uint32_t)W, log_n, 0, 0, 1));
+    }
+    R.phase = 1;
+    return CSTARK_OK;
+}
+
+// ---- phase 2: trace tree, channel, coefficients, merged constraint evaluations of the owned cosets -----------------------------------
+// d_leaves_all (sharded only): the all-gathered digests [8][n][32], coset-major.  d_out: [nk][n].
+int phase_evaluate(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint8_t *d_leaves_all, uint64_t *d_out) {
+    AirJob &job = R.job;
+    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b;
+    const size_t n = (size_t)1 << log_n, N = n * 8, W = job.width;
+    hipStream_t st = c->stream;
+    const uint32_t hf = R.opt.hash_fn;
+    if (R.sharded()) {
+        k_interleave_leaves<<<(unsigned)((2 * N + 255) / 256), 256, 0, st>>>((const uint4 *)d_leaves_all, (uint4 *)(a->tnodes + 32 * N), n, log_b);
+        HIP_TRY(hipGetLastError());
+    }
     RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
-    uint8_t trace_root[32], cons_root[32];
-    HIP_TRY(hipMemcpyAsync(trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(R.trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(hipStreamSynchronize(st)); // also completes the public-input copy of job.build
     if (job.pub_staging) job.pub.assign(job.pub_staging, job.pub_staging + 14);
 
-    // ---- channel ------------------------------------------------------------------------------------------------------------
-    Coin coin;
+    Coin &coin = R.coin;
     coin.hash_fn = hf;
     {
         Writer s;
         const uint8_t ctxb[2] = {(uint8_t)W, (uint8_t)log_n};
         s.raw(ctxb, 2);
         s.u64(host::P);
-        const uint8_t ob[7] = {(uint8_t)opt->num_queries, (uint8_t)log_b, (uint8_t)opt->grinding_factor, (uint8_t)opt->hash_fn,
-                               (uint8_t)opt->field_extension, (uint8_t)opt->fri_folding_factor, (uint8_t)log_rem};
+        const uint8_t ob[7] = {(uint8_t)R.opt.num_queries, (uint8_t)log_b, (uint8_t)R.opt.grinding_factor, (uint8_t)R.opt.hash_fn,
+                               (uint8_t)R.opt.field_extension, (uint8_t)R.opt.fri_folding_factor, (uint8_t)R.log_rem};
         s.raw(ob, 7);
         for (uint64_t v : job.pub) s.u64(host::to_u64(v)); // PublicInputs::write_into (src/air.rs:57-62 and the sub-AIRs' equivalents)
         s.raw(job.pub_bytes.data(), job.pub_bytes.size());
         coin.init(s.b.data(), s.b.size());
     }
-    coin.reseed(trace_root);
+    coin.reseed(R.trace_root);
     const size_t nc = job.n_constraints, na = job.n_assertions;
-    std::vector<uint64_t> ta(nc), tb(nc), ba(na), bb(na);
-    for (size_t i = 0; i < nc; i++) { ta[i] = coin.draw(); tb[i] = coin.draw(); }
-    for (size_t i = 0; i < na; i++) { ba[i] = coin.draw(); bb[i] = coin.draw(); }
-
-    // ---- constraint evaluation, composition polynomial, its commitment ----------------------------------------------
-    RC_TRY(job.combine(c, a, job, ta.data(), tb.data(), ba.data(), bb.data(), a->combined));
+    R.ta.resize(nc); R.tb.resize(nc); R.ba.resize(na); R.bb.resize(na);
+    for (size_t i = 0; i < nc; i++) { R.ta[i] = coin.draw(); R.tb[i] = coin.draw(); }
+    for (size_t i = 0; i < na; i++) { R.ba[i] = coin.draw(); R.bb[i] = coin.draw(); }
+    RC_TRY(job.combine(c, a, job, R.ta.data(), R.tb.data(), R.ba.data(), R.bb.data(), d_out));
     STAGE();
+    R.phase = 2;
+    return CSTARK_OK;
+}
+
+// ---- phase 3: composition polynomial and its commitment, out-of-domain frame, DEEP composition, FRI, query positions -----------------
+// Needs the merged evaluations of ALL cosets in a->combined and coset 0 of the extended trace at a->lde (the owner of coset 0).
+int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
+    AirJob &job = R.job;
+    const cstark_options *opt = &R.opt;
+    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b, log_ce = job.log_ce, n_layers = R.n_layers;
+    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = job.width, ce = (size_t)1 << log_ce, nq = opt->num_queries;
+    hipStream_t st = c->stream;
+    const uint32_t hf = opt->hash_fn;
+    Coin &coin = R.coin;
+    if (job.k0 != 0) return fail(CSTARK_ERR_INVALID_ARG, "the composition phase runs on the rank that owns coset 0");
     const uint64_t *ce_evals = a->combined;
     if (log_ce < log_b) { // the constraint-evaluation domain is the sub-domain of every (b / ce)-th LDE coset
         const size_t stride = b >> log_ce;
@@ -344,16 +410,17 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     RC_TRY(cstark_lde_columns(c, a->ccoef, a->clde, (uint32_t)ce, log_n, log_b, host::generator(), 0, (uint32_t)b));
     RC_TRY(cstark_hash_rows_fn(c, hf, a->clde, a->cnodes + 32 * N, (uint32_t)ce, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
-    HIP_TRY(hipMemcpyAsync(cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(R.cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(hipStreamSynchronize(st));
-    coin.reseed(cons_root);
+    coin.reseed(R.cons_root);
 
     // ---- out-of-domain frame ----------------------------------------------------------------------------------------------
     const uint64_t z = coin.draw();
     const uint64_t zpts[2] = {z, host::mul(z, host::root_of_unity(log_n))};
     const uint64_t zb = host::pow(z, ce);
-    std::vector<uint64_t> ood_trace(2 * W), ood_comp(ce);
+    std::vector<uint64_t> &ood_trace = R.ood_trace, &ood_comp = R.ood_comp;
+    ood_trace.assign(2 * W, 0); ood_comp.assign(ce, 0);
     RC_TRY(cstark_evaluate_polys_at(c, a->coeffs, (uint32_t)W, log_n, zpts, 2, ood_trace.data()));
     RC_TRY(cstark_evaluate_polys_at(c, a->ccoef, (uint32_t)ce, log_n, &zb, 1, ood_comp.data()));
     uint8_t dg[32];
@@ -381,27 +448,26 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     STAGE();
 
     // ---- FRI commit phase -----------------------------------------------------------------------------------------------------
-    std::vector<uint8_t> layer_roots(32 * (size_t)n_layers);
+    R.layer_roots.assign(32 * (size_t)n_layers, 0);
     uint64_t offset = host::generator();
     unsigned lg = log_N;
     for (unsigned l = 0; l < n_layers; l++) {
         const size_t rows = (size_t)1 << (lg - 2);
         RC_TRY(cstark_hash_rows_fn(c, hf, a->layer[l], a->lnodes[l] + 32 * rows, 4, lg - 2, 0, 0, 1));
         RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - 2));
-        HIP_TRY(hipMemcpyAsync(&layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&R.layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        coin.reseed(&layer_roots[32 * l]);
+        coin.reseed(&R.layer_roots[32 * l]);
         const uint64_t alpha = coin.draw();
         RC_TRY(cstark_fri_fold4(c, a->layer[l], a->layer[l + 1], lg, offset, alpha));
         offset = host::pow(offset, 4);
         lg -= 2;
     }
-    std::vector<uint64_t> remainder((size_t)1 << lg);
-    HIP_TRY(hipMemcpyAsync(remainder.data(), a->layer[n_layers], remainder.size() * 8, hipMemcpyDeviceToHost, st));
+    R.remainder.assign((size_t)1 << lg, 0);
+    HIP_TRY(hipMemcpyAsync(R.remainder.data(), a->layer[n_layers], R.remainder.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    uint8_t rem_commit[32];
-    hash_elements(hf, remainder.data(), remainder.size(), rem_commit);
-    coin.reseed(rem_commit);
+    hash_elements(hf, R.remainder.data(), R.remainder.size(), R.rem_commit);
+    coin.reseed(R.rem_commit);
     STAGE();
 
     // ---- proof of work, query positions -------------------------------------------------------------------------------------
@@ -413,17 +479,29 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
         for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
         if (opt->grinding_factor == 0 || (v & ((1ull << opt->grinding_factor) - 1)) == 0) break;
     }
+    R.nonce = nonce;
     coin.reseed_int(nonce);
-    std::vector<uint32_t> positions;
-    coin.draw_integers(nq, N, positions);
-
-    // ---- openings: gather on the device, one copy back ----------------------------------------------------------------------
-    std::vector<std::vector<uint32_t>> lpos(n_layers);
+    coin.draw_integers(nq, N, R.positions);
+    R.lpos.assign(n_layers, {});
     {
-        std::vector<uint32_t> cur = positions;
+        std::vector<uint32_t> cur = R.positions;
         unsigned g2 = log_N;
-        for (unsigned l = 0; l < n_layers; l++) { lpos[l] = fold_positions(cur, 1u << (g2 - 2)); cur = lpos[l]; g2 -= 2; }
+        for (unsigned l = 0; l < n_layers; l++) { R.lpos[l] = fold_positions(cur, 1u << (g2 - 2)); cur = R.lpos[l]; g2 -= 2; }
     }
+    R.phase = 3;
+    return CSTARK_OK;
+}
+
+// ---- phase 4: openings (gathered on the device, one copy back) and the proof bytes ---------------------------------------------------
+// d_trace_rows (sharded only): the opened rows of the extended trace [nq][W], complete (summed over the ranks).
+int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trace_rows, uint8_t *proof, size_t capacity, size_t *proof_len) {
+    AirJob &job = R.job;
+    const cstark_options *opt = &R.opt;
+    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b, log_ce = job.log_ce, n_layers = R.n_layers;
+    const size_t W = job.width, ce = (size_t)1 << log_ce, nq = opt->num_queries;
+    hipStream_t st = c->stream;
+    const std::vector<uint32_t> &positions = R.positions;
+    const std::vector<std::vector<uint32_t>> &lpos = R.lpos;
     std::vector<uint32_t> hpos(256 * (n_layers + 1), 0);
     memcpy(hpos.data(), positions.data(), nq * 4);
     for (unsigned l = 0; l < n_layers; l++) memcpy(hpos.data() + 256 * (l + 1), lpos[l].data(), lpos[l].size() * 4);
@@ -434,7 +512,8 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     const size_t o_tpath = off; off += nq * log_N * 32;
     const size_t o_crows = off; off += nq * ce * 8;
     const size_t o_cpath = off; off += nq * log_N * 32;
-    k_gather_rows<<<(unsigned)nq, 128, 0, st>>>(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, (uint64_t *)(o + o_trows));
+    if (d_trace_rows) HIP_TRY(hipMemcpyAsync(o + o_trows, d_trace_rows, nq * W * 8, hipMemcpyDeviceToDevice, st));
+    else k_gather_rows<<<(unsigned)nq, 128, 0, st>>>(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, (uint64_t *)(o + o_trows));
     k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->tnodes, log_N, a->d_pos, (uint4 *)(o + o_tpath));
     k_gather_rows<<<(unsigned)nq, 64, 0, st>>>(a->clde, (uint32_t)ce, log_n, log_b, a->d_pos, (uint64_t *)(o + o_crows));
     k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->cnodes, log_N, a->d_pos, (uint4 *)(o + o_cpath));
@@ -456,7 +535,6 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     STAGE();
     HIP_TRY(hipStreamSynchronize(st));
     a->timed = true;
-#undef STAGE
 
     // ---- serialise ----------------------------------------------------------------------------------------------------------------
     Writer wr;
@@ -464,10 +542,10 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     wr.u32((uint32_t)job.air); wr.u32((uint32_t)W); wr.u32(log_n); wr.u32(job.item);
     wr.u32(opt->num_queries); wr.u32(opt->blowup_factor); wr.u32(opt->grinding_factor); wr.u32(opt->hash_fn); wr.u32(opt->field_extension);
     wr.u32(opt->fri_folding_factor); wr.u32(opt->fri_max_remainder);
-    wr.raw(trace_root, 32); wr.raw(cons_root, 32);
-    wr.u32(n_layers); wr.raw(layer_roots.data(), layer_roots.size()); wr.raw(rem_commit, 32);
-    wr.raw(ood_trace.data(), ood_trace.size() * 8); wr.raw(ood_comp.data(), ood_comp.size() * 8);
-    wr.u64(nonce);
+    wr.raw(R.trace_root, 32); wr.raw(R.cons_root, 32);
+    wr.u32(n_layers); wr.raw(R.layer_roots.data(), R.layer_roots.size()); wr.raw(R.rem_commit, 32);
+    wr.raw(R.ood_trace.data(), R.ood_trace.size() * 8); wr.raw(R.ood_comp.data(), R.ood_comp.size() * 8);
+    wr.u64(R.nonce);
     wr.raw(open.data() + o_trows, nq * W * 8); wr.raw(open.data() + o_tpath, nq * log_N * 32);
     wr.raw(open.data() + o_crows, nq * ce * 8); wr.raw(open.data() + o_cpath, nq * log_N * 32);
     {
@@ -480,11 +558,34 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
             g2 -= 2;
         }
     }
-    wr.u32((uint32_t)remainder.size()); wr.raw(remainder.data(), remainder.size() * 8);
+    wr.u32((uint32_t)R.remainder.size()); wr.raw(R.remainder.data(), R.remainder.size() * 8);
     *proof_len = wr.b.size();
     if (!proof || capacity < wr.b.size()) return fail(CSTARK_ERR_INVALID_ARG, "proof buffer too small (required size returned in *proof_len)");
     memcpy(proof, wr.b.data(), wr.b.size());
     return CSTARK_OK;
+}
+#undef STAGE
+
+// options / sizes of a run, its arena
+int run_setup(cstark_ctx *c, const cstark_options *opt, const AirJob &job, ProofRun &R, ProveArena **a) {
+    RC_TRY(check_options(opt, &R.log_rem));
+    const unsigned log_N = job.log_n + 3;
+    if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "at most 2^21 trace rows");
+    R.opt = *opt; R.job = job;
+    R.n_layers = num_fri_layers(log_N, R.log_rem);
+    if (opt->num_queries > ((size_t)1 << log_N) / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
+    HIP_TRY(hipSetDevice(c->device));
+    return get_arena(c, job, 3, R.n_layers, opt->num_queries, a);
+}
+
+int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *proof, size_t capacity, size_t *proof_len) {
+    ProofRun R;
+    ProveArena *a;
+    RC_TRY(run_setup(c, opt, job, R, &a));
+    RC_TRY(phase_commit(c, a, R, nullptr));
+    RC_TRY(phase_evaluate(c, a, R, nullptr, a->combined));
+    RC_TRY(phase_compose(c, a, R));
+    return phase_open(c, a, R, nullptr, proof, capacity, proof_len);
 }
 
 // first / last row of registers 58..64 -> job.pub (TransactionProver::get_pub_inputs src/prover.rs:106-129; MerkleProver alike)
@@ -536,7 +637,9 @@ int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, co
     memcpy(cf.b_alpha, ba, sizeof cf.b_alpha); memcpy(cf.b_beta, bb, sizeof cf.b_beta);
     const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]}; // get_assertions, src/air.rs:175-184
     uint64_t *outs[1] = {out};
-    return tx_evaluate_constraints_sets(c, a->lde, &cf, 1, pub4, outs, job.item, job.log_n, 3, 0, 8, true);
+    // all cosets on this GPU: the degree-split evaluation (the table is this prover's own extension); a coset window of a sharded
+    // proof: every point directly
+    return tx_evaluate_constraints_sets(c, a->lde, &cf, 1, pub4, outs, job.item, job.log_n, 3, job.k0, job.nk, job.nk == 8);
 }
 int tx_combine_sets(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned m, const uint64_t *const *ta, const uint64_t *const *tb, const uint64_t *const *ba,
                     const uint64_t *const *bb, uint64_t *const *outs) {
@@ -905,6 +1008,73 @@ int cstark_air_prove(cstark_ctx *c, int air, const cstark_options *opt, uint64_t
     job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
     if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);
+}
+
+// ---- one proof across several GPUs by LDE coset -------------------------------------------------------------------------
+// Every rank holds the witness and calls the phases in the same order; the caller moves the three exchanged buffers between the
+// ranks (RCCL all-gather / all-reduce through torch.distributed in sharding.py).  Trace generation and interpolation are replicated
+// (every rank needs all coefficient columns for its cosets), extension / row hashing / constraint evaluation run on the rank's cosets,
+// everything after the merged evaluations on the rank that owns coset 0.
+static int shard_run(cstark_ctx *c, int min_phase, ProofRun **out) {
+    if (!c || !c->arena || !c->arena->run || c->arena->run->phase < min_phase) return fail(CSTARK_ERR_INVALID_ARG, "sharded proof: phase called out of order");
+    *out = c->arena->run;
+    return CSTARK_OK;
+}
+int cstark_tx_shard_commit(cstark_ctx *c, const cstark_options *opt, uint32_t k0, uint32_t nk, uint8_t *d_leaves_local) {
+    if (!c || !opt || !d_leaves_local) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_commit: null argument");
+    if (!c->wit_buf || c->wit.n_tx == 0 || c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no transaction witness uploaded");
+    if (c->wit.n_tx & (c->wit.n_tx - 1)) return fail(CSTARK_ERR_INVALID_ARG, "the number of transactions must be a power of two");
+    if (nk == 0 || nk >= 8 || (nk & (nk - 1)) || k0 % nk || k0 + nk > 8) return fail(CSTARK_ERR_INVALID_ARG, "a rank owns 1, 2 or 4 consecutive cosets of the 8 (world size 8, 4 or 2)");
+    if (opt->field_extension != 0) return fail(CSTARK_ERR_UNSUPPORTED, "sharded proofs use FieldExtension::None");
+    AirJob job;
+    job.air = CSTARK_AIR_STATE_TRANSITION; job.width = CSTARK_TX_TRACE_WIDTH; job.log_n = 10 + ceil_log2(c->wit.n_tx); job.log_ce = 3;
+    job.n_constraints = CSTARK_TX_NUM_CONSTRAINTS; job.n_assertions = 4; job.item = c->wit.depth;
+    job.build = tx_build; job.combine = tx_combine;
+    job.k0 = k0; job.nk = nk;
+    ProofRun *R = new (std::nothrow) ProofRun();
+    if (!R) return fail(CSTARK_ERR_OOM, "host allocation failed");
+    ProveArena *a = nullptr;
+    int rc = run_setup(c, opt, job, *R, &a);
+    if (rc) { delete R; return rc; }
+    proof_run_free(a->run);
+    a->run = R;
+    return phase_commit(c, a, *R, d_leaves_local);
+}
+int cstark_tx_shard_evaluate(cstark_ctx *c, const uint8_t *d_leaves_all, uint64_t *d_combined_local) {
+    ProofRun *R;
+    RC_TRY(shard_run(c, 1, &R));
+    if (!d_leaves_all || !d_combined_local) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_evaluate: null argument");
+    return phase_evaluate(c, c->arena, *R, d_leaves_all, d_combined_local);
+}
+int cstark_tx_shard_compose(cstark_ctx *c, const uint64_t *d_combined_all, uint32_t *positions /* host [num_queries] */) {
+    ProofRun *R;
+    RC_TRY(shard_run(c, 2, &R));
+    if (!d_combined_all || !positions) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_compose: null argument");
+    ProveArena *a = c->arena;
+    const size_t N = (size_t)8 << R->job.log_n;
+    if (d_combined_all != a->combined) HIP_TRY(hipMemcpyAsync(a->combined, d_combined_all, N * 8, hipMemcpyDeviceToDevice, c->stream));
+    RC_TRY(phase_compose(c, a, *R));
+    memcpy(positions, R->positions.data(), R->positions.size() * 4);
+    return CSTARK_OK;
+}
+int cstark_tx_shard_open_rows(cstark_ctx *c, const uint32_t *positions, uint32_t nq, uint64_t *d_rows) {
+    ProofRun *R;
+    RC_TRY(shard_run(c, 2, &R));
+    if (!positions || !d_rows || nq == 0 || nq > 128) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_open_rows: bad argument");
+    ProveArena *a = c->arena;
+    HIP_TRY(hipMemcpyAsync(a->d_pos, positions, nq * 4, hipMemcpyHostToDevice, c->stream));
+    k_gather_rows_window<<<nq, 128, 0, c->stream>>>(a->lde, R->job.width, R->job.log_n, 3, R->job.k0, R->job.nk, a->d_pos, d_rows);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream)); // the caller's positions may be transient
+    return CSTARK_OK;
+}
+int cstark_tx_shard_finish(cstark_ctx *c, const uint64_t *d_rows, uint8_t *proof, size_t capacity, size_t *proof_len) {
+    ProofRun *R;
+    RC_TRY(shard_run(c, 3, &R));
+    if (!d_rows || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_finish: null argument");
+    const int rc = phase_open(c, c->arena, *R, d_rows, proof, capacity, proof_len);
+    if (rc == CSTARK_OK) { proof_run_free(c->arena->run); c->arena->run = nullptr; }
+    return rc;
 }
 
 // RangeProofAir over 2^log_n rows (synthetic long form; log_n = 6 with a one-word value is cstark_air_prove(CSTARK_AIR_RANGE))

@@ -6,6 +6,10 @@ need no halo.  Rank r owns cosets [k0, k0 + nk).  Two real exchange steps remain
   * leaf digests  (n * nk * 32 bytes per rank)  -> every rank (or rank 0) builds the Merkle tree
   * combined constraint evaluations (n * nk * 8 bytes per rank) -> composition polynomial
 The functions work on any torch.distributed backend/device (RCCL on GPUs; gloo on CPU tensors in the tests).
+
+prove_sharded() is the whole proof: the phases of cstark_tx_shard_* (include/cstark.h) with the collectives between them.  Besides the
+two all-gathers, the query positions are broadcast from the rank that owns coset 0 (it alone runs composition / DEEP / FRI), and the
+opened trace rows -- each lies in exactly one rank's cosets -- are summed onto that rank.
 """
 import torch
 import torch.distributed as dist
@@ -31,3 +35,23 @@ def leaves_to_natural_order(coset_major):
     """[b, n, 32] digests per (coset k, row j) -> [n * b, 32] in LDE order i = b*j + k."""
     b, n = coset_major.shape[0], coset_major.shape[1]
     return coset_major.permute(1, 0, 2).reshape(n * b, 32).contiguous()
+
+
+def prove_sharded(backend, options, group=None):
+    """One complete proof of the witness uploaded on every rank's `backend`, sharded by LDE coset over the ranks of `group`.
+    Returns the proof bytes on rank 0 (bit-identical to the single-GPU proof) and None elsewhere.  `backend` provides the phases
+    shard_commit / shard_evaluate / shard_compose / shard_open_rows / shard_finish on its own device's tensors
+    (certificate_stark_amd.backend.Backend over the C ABI; the CPU tests pass a stand-in built on the oracle)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    k0, nk = coset_range(rank, world, 8)
+    leaves = all_gather_cosets(backend.shard_commit(options, k0, nk), group)       # C2: [8][n][32] digests, coset-major
+    combined = all_gather_cosets(backend.shard_evaluate(leaves), group)            # C3: [8][n] merged evaluations
+    if rank == 0:
+        positions = backend.shard_compose(combined)
+    else:
+        positions = torch.zeros(options.num_queries, dtype=torch.int32, device=combined.device)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(positions, src=src, group=group)
+    rows = backend.shard_open_rows(positions)
+    dist.reduce(rows, dst=src, op=dist.ReduceOp.SUM, group=group)                   # every row is nonzero on exactly one rank
+    return backend.shard_finish(rows) if rank == 0 else None

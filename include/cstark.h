@@ -185,6 +185,10 @@ int cstark_tx_evaluate_constraints_ext(cstark_ctx *ctx, const uint64_t *d_lde, c
  * polynomials to the odd cosets and the recombination over all cosets. */
 int cstark_ctx_set_part_timing(cstark_ctx *ctx, int enable);
 int cstark_tx_constraint_part_ms(cstark_ctx *ctx, float *ms /* [9] */);
+/* With part timing enabled every low-degree extension on this context (cstark_lde_columns and the prover's own extensions: trace,
+ * composition columns, split polynomials, DEEP) is bracketed by a HIP event pair on the context's stream.  Returns the summed
+ * duration and the number of evaluations written (columns x cosets x n) since the previous call, and resets both. */
+int cstark_lde_timing_ms(cstark_ctx *ctx, float *total_ms, uint64_t *elements);
 /* Host-side AIR description (no GPU needed): degree (base; number of 1024-row cycles) of transition constraint i
  * (TransactionAir::new, src/air.rs:76-108) and the 48 periodic columns (src/air.rs:194-380), [48][1024]. */
 int cstark_tx_constraint_degree(uint32_t i, uint32_t *base, uint32_t *cycles);  /* CSTARK_AIR_STATE_TRANSITION */
@@ -243,6 +247,26 @@ int cstark_tx_prove(cstark_ctx *ctx, const cstark_options *opt, uint8_t *proof, 
  * holds the Merkle depth / the number of signatures / 0.  Use cstark_tx_proof_size_bound(rows / 1024 rounded up, opt) * 2 as capacity. */
 int cstark_air_prove(cstark_ctx *ctx, int air, const cstark_options *opt, uint64_t number, uint8_t *proof, size_t capacity, size_t *proof_len);
 size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt);
+
+/* ---- one proof across several GPUs, sharded by LDE coset (the reference's only parallel axis is the rayon loop
+ * over trace fragments, src/prover.rs:50-52) -------------------------------------------------------------------------------------
+ * Every rank (one process per GPU, one cstark_ctx each) uploads the same witness and calls the phases in this order; the caller
+ * moves three device buffers between the ranks -- RCCL collectives, see certificate-stark_amd/sharding.py.  Rank r of W in {2, 4, 8}
+ * owns the nk = 8 / W cosets [k0, k0 + nk), k0 = r nk.  The proof bytes equal cstark_tx_prove's bit for bit.
+ *   1 cstark_tx_shard_commit     trace + interpolation (replicated), extension and row hashes of the rank's cosets;
+ *                                d_leaves_local [nk][n][32]               -> all-gather -> d_leaves_all [8][n][32] (coset-major)
+ *   2 cstark_tx_shard_evaluate   trace tree + root (every rank: the channel is replayed everywhere), coefficients, merged constraint
+ *                                evaluations of the rank's cosets: d_combined_local [nk][n] -> all-gather -> d_combined_all [8][n]
+ *   3 cstark_tx_shard_compose    rank 0 only (it owns coset 0, which the DEEP composition reads): composition polynomial and its
+ *                                commitment, out-of-domain frame, DEEP, FRI; positions[num_queries] (host) -> broadcast
+ *   4 cstark_tx_shard_open_rows  every rank: the opened rows of the extended trace that lie in its cosets, zeros elsewhere;
+ *                                d_rows [nq][94] -> all-reduce (sum) -> complete rows
+ *   5 cstark_tx_shard_finish     rank 0: paths, remaining openings, proof bytes. */
+int cstark_tx_shard_commit(cstark_ctx *ctx, const cstark_options *opt, uint32_t k0, uint32_t nk, uint8_t *d_leaves_local);
+int cstark_tx_shard_evaluate(cstark_ctx *ctx, const uint8_t *d_leaves_all, uint64_t *d_combined_local);
+int cstark_tx_shard_compose(cstark_ctx *ctx, const uint64_t *d_combined_all, uint32_t *positions);
+int cstark_tx_shard_open_rows(cstark_ctx *ctx, const uint32_t *positions, uint32_t nq, uint64_t *d_rows);
+int cstark_tx_shard_finish(cstark_ctx *ctx, const uint64_t *d_rows, uint8_t *proof, size_t capacity, size_t *proof_len);
 /* Wall-clock of the stages of the last cstark_tx_prove on this context (HIP events on its stream), milliseconds:
  * trace, interpolate, LDE, row hashes + tree, constraint evaluation, composition polynomial + commitment,
  * out-of-domain frame, DEEP composition, FRI layers, query openings.
