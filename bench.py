@@ -282,6 +282,7 @@ def main():
     part_ms = {k: 0.0 for k in prover.backend.CE_PARTS}
     for _ in range(args.warmup):
         step(False)
+    prover.backend.lde_timing_ms()  # reset: only the timed steps count
     inflight = args.inflight if prove_mode else 1
     if inflight > 1 and args.steps % inflight:
         raise SystemExit("--steps must be a multiple of --inflight")

@@ -14,6 +14,12 @@
 // coset-scaling tables (8 MB each at n = 2^20) are shared by all columns and stay in L2 / Infinity Cache.
 #include "ntt.h"
 #include "fp.cuh"
+#include <stdlib.h>
+#ifdef CS_NTT_NOMATH // measurement build (tools/build_variant_fast.py): the kernels' memory / LDS traffic without their field arithmetic
+#define fp_mul(a, b) ((a) ^ (b))
+#define fp_add(a, b) ((a) + (b))
+#define fp_sub(a, b) ((a) - (b))
+#endif
 
 namespace cs {
 namespace {
@@ -296,6 +302,251 @@ __global__ __launch_bounds__(L2 << (LA > LB ? LA : LB)) void k_ntt_rows_v2(const
     }
 }
 
+// =====================================================================================================
+// v4 kernels: the same two passes with every 2^LOGM-point sub-transform in THREE register steps (2^LA, 2^LB, 2^LC points,
+// LA >= LB >= LC) instead of two.  A thread then holds 2^LA = 16 elements instead of 32, a workgroup of the same tile
+// (L2 columns x 2^LOGM points, 64 KB of LDS) has twice the threads, and a CU holds four waves per SIMD instead of two:
+// the v2 kernels spent half of their wave cycles waiting (rocprofv3: SQ_WAIT_ANY 22-39 %, SQ_WAIT_INST_ANY 16-30 % of
+// SQ_WAVE_CYCLES) because two waves per SIMD cannot cover global-load latency, LDS round trips and the issue gaps of
+// dependent v_mad_u64_u32 chains.
+//
+// Index algebra (w = w_M, M = 2^LOGM, T = 2^(LB+LC)):  r = r1 T + r2 2^LC + r3,  k = k1 + 2^LA k2 + 2^(LA+LB) k3
+//   step 1  (r2, r3) fixed: Y[k1]  = sum_r1 x[r] w_{2^LA}^(r1 k1),  then  * w^((r2 2^LC + r3) k1)
+//   step 2  (k1, r3) fixed: Z[k2]  = sum_r2 Y[k1; r2, r3] w_{2^LB}^(r2 k2),  then  * w^(2^LA r3 k2)
+//   step 3  (k1, k2) fixed: X[k3]  = sum_r3 Z[k1, k2; r3] w_{2^LC}^(r3 k3)
+// LDS tile: element (k1, q, l) at (k1 T + q) L2 + l (columns kernel) resp. ((k1 L2 + l)(T + 4) + q) (rows kernel), q = r2 2^LC + r3
+// after step 1; step 2 works in place and stores Z[k2] of task (k1, r3) at q = k2 2^LC + (r3 ^ (k2 mod 2^LC)) so that step 3's
+// reads (fixed r3, lanes over k2) fall into distinct banks.
+// -----------------------------------------------------------------------------------------------------
+template <int LA, int LB, int LC>
+struct V4 {
+    static constexpr int A = 1 << LA, Bn = 1 << LB, Cn = 1 << LC, T = Bn * Cn, M = A * T, LOGM = LA + LB + LC;
+    static constexpr int NT = L2 * T;       // threads per workgroup: one step-1 task each
+    static constexpr int J2 = A / Bn;       // step-2 tasks (k1, r3) per thread
+    static constexpr int J3 = A / Cn;       // step-3 tasks (k1, k2) per thread
+    static_assert(LA >= LB && LB >= LC && LC >= 1, "step sizes must not increase");
+};
+
+#ifndef CS_NTT_TILES
+#define CS_NTT_TILES 1
+#endif
+// Tiles per workgroup; with more than one the next tile's global loads are issued before the current tile's arithmetic.  Measured on
+// MI355X (2^20 x 94 x 8): the register prefetch pushes hipcc past the 128 VGPRs that four waves per SIMD allow (15-34 spilled
+// registers even behind scheduling barriers) and the extension takes 11.2 instead of 8.6 ms; the default stays 1.  Also measured and
+// dropped: steps 2 and 3 task by task inside one wave (the 64 lanes of a wave are the L2 columns x the 8 tasks of one k1, so no
+// workgroup barrier is needed after step 1) -- 9.2 ms: the per-task LDS round trips serialise; all cosets of a tile in one
+// workgroup with the coefficients kept in registers -- 83 spilled registers.
+constexpr int V4_TILES = CS_NTT_TILES;
+
+// Steps 2 and 3 of the column pass on the tile in LDS (after step 1 stored Y * twiddle), including the output factor and the
+// stores.  t, l: this thread's position; kb-dependent factors from w / ps as in the v2 kernel.
+template <int LA, int LB, int LC, bool INV>
+__device__ __forceinline__ void cols_v4_finish(fp *tile, const fp *tw, const fp *__restrict__ w, const fp *__restrict__ ps, fp *__restrict__ dst,
+                                               unsigned log_c, unsigned c, unsigned t, unsigned l) {
+    using G = V4<LA, LB, LC>;
+    constexpr int A = G::A, Bn = G::Bn, Cn = G::Cn, T = G::T;
+    fp z[G::J2][Bn];
+#pragma unroll
+    for (int j = 0; j < G::J2; j++) { // step 2: task u = t + T j = k1 Cn + r3
+        const unsigned u = t + T * j, k1 = u / Cn, r3 = u % Cn;
+#pragma unroll
+        for (int r2 = 0; r2 < Bn; r2++) z[j][r2] = tile[((size_t)k1 * T + r2 * Cn + r3) * L2 + l];
+    }
+    __syncthreads(); // every input of step 2 is in registers: the tile can be overwritten
+#pragma unroll
+    for (int j = 0; j < G::J2; j++) {
+        const unsigned u = t + T * j, k1 = u / Cn, r3 = u % Cn;
+        reg_ntt_dif<LB, INV>(z[j]);
+#pragma unroll
+        for (int p = 0; p < Bn; p++) {
+            const unsigned k2 = cx_brev(p, LB);
+            const fp v = (k2 == 0) ? z[j][p] : fp_mul(z[j][p], tw[(A * k2) * r3]);
+            tile[((size_t)k1 * T + k2 * Cn + (r3 ^ (k2 % Cn))) * L2 + l] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < G::J3; j++) { // step 3: task v = t + T j = k1 Bn + k2; output rows k = k1 + A k2 + A Bn k3
+        const unsigned v = t + T * j, k1 = v / Bn, k2 = v % Bn;
+        fp x[Cn];
+#pragma unroll
+        for (int r3 = 0; r3 < Cn; r3++) x[r3] = tile[((size_t)k1 * T + k2 * Cn + (r3 ^ (k2 % Cn))) * L2 + l];
+        reg_ntt_dif<LC, INV>(x);
+        // output factor shift^c w_n^(k c), k = (k1 + A k2) + A Bn k3: a geometric sequence in k3 with ratio w_n^(A Bn c)
+        const unsigned kb = k1 + A * k2;
+        fp g = w[(size_t)kb * c];
+        if (ps) g = fp_mul(g, ps[c]);
+        const fp ratio = w[(size_t)(A * Bn) * c];
+        const unsigned lane_off = (kb << log_c) + c; // uniform row base + 32-bit lane offset: one address register for all stores
+#pragma unroll
+        for (int k3 = 0; k3 < Cn; k3++) {
+            fp *row = dst + ((size_t)(A * Bn * k3) << log_c);
+            row[lane_off] = fp_mul(x[cx_brev(k3, LC)], g);
+            if (k3 + 1 < Cn) g = fp_mul(g, ratio);
+        }
+    }
+}
+
+// grid = (batch, C / L2 / V4_TILES, width)
+template <int LA, int LB, int LC, bool INV>
+__global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n,
+                                                                        const fp *__restrict__ w, const fp *__restrict__ prescale,
+                                                                        size_t in_batch_stride, size_t out_batch_stride, size_t prescale_batch_stride) {
+    using G = V4<LA, LB, LC>;
+    constexpr int A = G::A, T = G::T, M = G::M, LOGM = G::LOGM;
+    extern __shared__ __attribute__((aligned(16))) fp smem[];
+    fp *tile = smem;                      // [A][T][L2]
+    fp *tw = smem + (size_t)M * L2;       // [M] powers of w_M
+    const unsigned log_c = log_n - LOGM;
+    const size_t n = (size_t)1 << log_n;
+    const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
+    fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
+    const fp *ps = prescale ? prescale + blockIdx.x * prescale_batch_stride : nullptr;
+    const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2;
+
+    for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
+    fp nxt[A];
+    {
+        const unsigned lane_off = (t << log_c) + xcd_pair_tile(blockIdx.y * V4_TILES) * L2 + l;
+#pragma unroll
+        for (int r1 = 0; r1 < A; r1++) nxt[r1] = (src + ((size_t)(r1 * T) << log_c))[lane_off];
+    }
+    __syncthreads(); // tw[] ready
+#pragma unroll 1
+    for (int it = 0; it < V4_TILES; it++) {
+        const unsigned c = xcd_pair_tile(blockIdx.y * V4_TILES + it) * L2 + l;
+        {   // step 1: rows r = r1 T + t
+            fp a[A];
+#pragma unroll
+            for (int r1 = 0; r1 < A; r1++) a[r1] = nxt[r1];
+            if (it + 1 < V4_TILES) {
+                const unsigned lane_off = (t << log_c) + xcd_pair_tile(blockIdx.y * V4_TILES + it + 1) * L2 + l;
+#pragma unroll
+                for (int r1 = 0; r1 < A; r1++) nxt[r1] = (src + ((size_t)(r1 * T) << log_c))[lane_off];
+            }
+            __builtin_amdgcn_sched_barrier(0); // the prefetch is issued here, ahead of this tile's arithmetic
+            if (ps) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
+                const unsigned ps_off = t << log_c;
+#pragma unroll
+                for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], (ps + ((size_t)(r1 * T) << log_c))[ps_off]);
+            }
+            reg_ntt_dif<LA, INV>(a);
+#pragma unroll
+            for (int p = 0; p < A; p++) {
+                const unsigned k1 = cx_brev(p, LA);
+                tile[((size_t)k1 * T + t) * L2 + l] = (k1 == 0) ? a[p] : fp_mul(a[p], tw[k1 * t]);
+            }
+        }
+        __syncthreads();
+        cols_v4_finish<LA, LB, LC, INV>(tile, tw, w, ps, dst, log_c, c, t, l);
+        __syncthreads(); // the tile is rewritten by the next iteration
+    }
+}
+
+// grid = (batch, R / L2 / V4_TILES, width).  in: rows [k1][c] (each row M contiguous); out: natural order k = k1 + R * k2.
+template <int LA, int LB, int LC, bool INV>
+__global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n,
+                                                                        const fp *__restrict__ w, fp post_scale, int do_scale,
+                                                                        size_t in_batch_stride, size_t out_batch_stride) {
+    using G = V4<LA, LB, LC>;
+    constexpr int A = G::A, Bn = G::Bn, Cn = G::Cn, T = G::T, M = G::M, LOGM = G::LOGM;
+    constexpr int TP = T + 4; // padded run of q per (j1, l): lanes over l then hit distinct banks (T + 4 = 4 mod 32 for T = 32, 64)
+    extern __shared__ __attribute__((aligned(16))) fp smem[];
+    fp *tile = smem;                              // [A][L2][TP]
+    fp *tw = smem + (size_t)A * L2 * TP;          // [M]
+    const unsigned log_r = log_n - LOGM;
+    const size_t n = (size_t)1 << log_n;
+    const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
+    fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
+    const unsigned s1 = threadIdx.x % T, l1 = threadIdx.x / T; // step 1: s = c2 Cn + c3 fastest across lanes (coalesced row reads)
+    const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2; // steps 2 and 3: l fastest across lanes (64-byte transposed stores)
+
+    for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_r];
+    fp nxt[A];
+    const unsigned in_lane = (l1 << LOGM) + s1; // uniform row base + 32-bit lane offset: one address register for all loads
+    {
+        const unsigned k10 = xcd_pair_tile(blockIdx.y * V4_TILES) * L2;
+#pragma unroll
+        for (int c1 = 0; c1 < A; c1++) nxt[c1] = (src + ((size_t)k10 << LOGM) + c1 * T)[in_lane];
+    }
+    __syncthreads(); // tw[] ready
+#pragma unroll 1
+    for (int it = 0; it < V4_TILES; it++) {
+        const unsigned k10 = xcd_pair_tile(blockIdx.y * V4_TILES + it) * L2;
+        {   // step 1: columns c = c1 T + s
+            fp a[A];
+#pragma unroll
+            for (int c1 = 0; c1 < A; c1++) a[c1] = nxt[c1];
+            if (it + 1 < V4_TILES) {
+                const unsigned k11 = xcd_pair_tile(blockIdx.y * V4_TILES + it + 1) * L2;
+#pragma unroll
+                for (int c1 = 0; c1 < A; c1++) nxt[c1] = (src + ((size_t)k11 << LOGM) + c1 * T)[in_lane];
+            }
+            __builtin_amdgcn_sched_barrier(0); // the prefetch is issued here, ahead of this tile's arithmetic
+            reg_ntt_dif<LA, INV>(a);
+#pragma unroll
+            for (int p = 0; p < A; p++) {
+                const unsigned j1 = cx_brev(p, LA);
+                tile[((size_t)j1 * L2 + l1) * TP + s1] = (j1 == 0) ? a[p] : fp_mul(a[p], tw[j1 * s1]);
+            }
+        }
+        __syncthreads();
+        fp z[G::J2][Bn];
+#pragma unroll
+        for (int j = 0; j < G::J2; j++) { // step 2: task u = t + T j = j1 Cn + c3
+            const unsigned u = t + T * j, j1 = u / Cn, c3 = u % Cn;
+#pragma unroll
+            for (int c2 = 0; c2 < Bn; c2++) z[j][c2] = tile[((size_t)j1 * L2 + l) * TP + c2 * Cn + c3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < G::J2; j++) {
+            const unsigned u = t + T * j, j1 = u / Cn, c3 = u % Cn;
+            reg_ntt_dif<LB, INV>(z[j]);
+#pragma unroll
+            for (int p = 0; p < Bn; p++) {
+                const unsigned j2 = cx_brev(p, LB);
+                const fp v = (j2 == 0) ? z[j][p] : fp_mul(z[j][p], tw[(A * j2) * c3]);
+                tile[((size_t)j1 * L2 + l) * TP + j2 * Cn + (c3 ^ (j2 % Cn))] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < G::J3; j++) { // step 3: task v = t + T j = j1 Bn + j2; output frequency k2 = j1 + A j2 + A Bn j3
+            const unsigned v = t + T * j, j1 = v / Bn, j2 = v % Bn;
+            fp x[Cn];
+#pragma unroll
+            for (int c3 = 0; c3 < Cn; c3++) x[c3] = tile[((size_t)j1 * L2 + l) * TP + j2 * Cn + (c3 ^ (j2 % Cn))];
+            reg_ntt_dif<LC, INV>(x);
+            const unsigned out_lane = ((j1 + A * j2) << log_r) + l;
+#pragma unroll
+            for (int p = 0; p < Cn; p++) {
+                fp val = x[p];
+                if (do_scale) val = fp_mul(val, post_scale);
+                (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
+            }
+        }
+        __syncthreads(); // the tile is rewritten by the next iteration
+    }
+}
+
+template <int RA, int RB, int RC, int CA, int CB, int CC, bool INV>
+hipError_t launch_v4(const NttArgs &a, hipStream_t stream) {
+    using GR = V4<RA, RB, RC>;
+    using GC = V4<CA, CB, CC>;
+    const size_t lds_a = ((size_t)GR::M * L2 + GR::M) * sizeof(fp);
+    const size_t lds_b = ((size_t)GC::A * L2 * (GC::T + 4) + GC::M) * sizeof(fp);
+    static_assert((GC::M / L2) % V4_TILES == 0 && (GR::M / L2) % V4_TILES == 0, "tiles per workgroup");
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void *)k_ntt_rows_v4<CA, CB, CC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_ntt_cols_v4<RA, RB, RC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
+    hipLaunchKernelGGL((k_ntt_cols_v4<RA, RB, RC, INV>), dim3(a.batch, (unsigned)GC::M / L2 / V4_TILES, a.width), dim3(GR::NT), lds_a, stream, a.in,
+                       a.scratch, a.log_n, a.w, a.prescale, a.in_batch_stride, a.scratch_batch_stride, a.prescale_batch_stride);
+    hipLaunchKernelGGL((k_ntt_rows_v4<CA, CB, CC, INV>), dim3(a.batch, (unsigned)GR::M / L2 / V4_TILES, a.width), dim3(GC::NT), lds_b, stream,
+                       (const fp *)a.scratch, a.out, a.log_n, a.w, a.post_scale, a.do_scale ? 1 : 0, a.scratch_batch_stride, a.out_batch_stride);
+    return hipGetLastError();
+}
+
 template <int LRA, int LRB, int LCA, int LCB, bool INV>
 hipError_t launch_v2(const NttArgs &a, hipStream_t stream) {
     constexpr int LOG_R = LRA + LRB, LOG_C = LCA + LCB;
@@ -453,7 +704,11 @@ hipError_t ntt_power_table(fp *d_table, size_t n, fp base, hipStream_t stream) {
 hipError_t ntt_columns(const NttArgs &a, hipStream_t stream) {
     if (a.log_n < NTT_MIN_LOG_N || a.log_n > NTT_MAX_LOG_N) return hipErrorInvalidValue;
     // register-tiled kernels for the production sizes; `inverse` selects the compile-time small twiddles
+    static const bool v2_env = [] { const char *e = getenv("CSTARK_NTT_V2"); return e && atoi(e) != 0; }(); // tuning / debugging: two-step kernels
+    if (a.log_n == 20 && !v2_env) return a.inverse ? launch_v4<4, 3, 3, 4, 3, 3, true>(a, stream) : launch_v4<4, 3, 3, 4, 3, 3, false>(a, stream);
     if (a.log_n == 20) return a.inverse ? launch_v2<5, 5, 5, 5, true>(a, stream) : launch_v2<5, 5, 5, 5, false>(a, stream);
+    if (a.log_n == 18 && !v2_env) return a.inverse ? launch_v4<3, 3, 3, 3, 3, 3, true>(a, stream) : launch_v4<3, 3, 3, 3, 3, 3, false>(a, stream);
+    if (a.log_n == 16 && !v2_env) return a.inverse ? launch_v4<3, 3, 2, 3, 3, 2, true>(a, stream) : launch_v4<3, 3, 2, 3, 3, 2, false>(a, stream);
     if (a.log_n == 18) return a.inverse ? launch_v2<5, 4, 5, 4, true>(a, stream) : launch_v2<5, 4, 5, 4, false>(a, stream);
     if (a.log_n == 16) return a.inverse ? launch_v2<4, 4, 4, 4, true>(a, stream) : launch_v2<4, 4, 4, 4, false>(a, stream);
     // L = 8 keeps global segments at 64 bytes; sub-transforms above 2^11 points need the narrower tile to fit LDS
