@@ -7,6 +7,7 @@
 //   TransactionAir::new degrees src/air.rs:76-108
 // It runs once per (depth, trace length); the resulting table is kernel input (K7).
 #pragma once
+#include "../../include/cstark_conventions.h"
 #include <stdint.h>
 #include <vector>
 #include "constants_gen.h"
@@ -54,8 +55,9 @@ inline bool tx_periodic_columns(unsigned depth, std::vector<uint64_t> &out) {
 // evaluation degree of degree group g for trace length n (TransitionConstraintDegree [UPSTREAM-RECALL])
 inline uint64_t tx_group_eval_degree(int g, uint64_t n) { return TX_GROUP_BASE[g] * (n - 1) + TX_GROUP_CYCLES[g] * (n / TX_CYCLE) * (TX_CYCLE - 1); }
 // adjustment so that every merged constraint reaches degree (ce_size - 1) + (n - 1) before division
-inline uint64_t tx_group_adjustment(int g, uint64_t n, uint64_t ce_size) { return (ce_size - 1 + n - 1) - tx_group_eval_degree(g, n); }
-inline uint64_t tx_boundary_adjustment(uint64_t n, uint64_t ce_size) { return ce_size - n + 1; }
+inline uint64_t tx_group_adjustment(int g, uint64_t n, uint64_t ce_size) { return CSTARK_CONV_TRANSITION_ADJUSTMENT(ce_size, n, tx_group_eval_degree(g, n)); }
+inline uint64_t tx_boundary_adjustment(uint64_t n, uint64_t ce_size) { return CSTARK_CONV_BOUNDARY_ADJUSTMENT(ce_size, n, 1); }
+static_assert(CSTARK_CONV_TRANSITION_EXEMPTIONS == 1, "the evaluators divide by (x^n - 1) / (x - w^(n-1)): one exempted step");
 
 // ---- standalone sub-AIRs ------------------------------------------------------------
 // MerkleAir periodic columns (src/merkle/update/air.rs:182-212): setup, hash, hash_input (period 8), finish,

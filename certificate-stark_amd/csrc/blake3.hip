@@ -6,6 +6,8 @@
 // chained compressions.  One lane hashes one row; with the coset-major column layout the 64 lanes of a wave
 // read 64 consecutive rows of the same column, i.e. one contiguous 512-byte line per load.
 #include "blake3.h"
+#include "fp.cuh"
+#include "../../include/cstark_conventions.h"
 #include <hip/hip_runtime.h>
 
 namespace cs {
@@ -62,6 +64,9 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             uint64_t v = (unsigned)i < cnt ? col[(size_t)(c0 + i) * n] : 0;
+#if !CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY
+            if ((unsigned)i < cnt) v = fp_to_u64(v); // canonical little-endian bytes
+#endif
             m[2 * i] = (uint32_t)v;
             m[2 * i + 1] = (uint32_t)(v >> 32);
         }

@@ -188,7 +188,7 @@ int get_periodic(cstark_ctx *c, unsigned depth, unsigned log_n, unsigned log_b, 
     HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), NP * C * 8, hipMemcpyHostToDevice, c->stream));
     RC_TRY(interpolate_impl(c, d_cols, d_poly, (uint32_t)NP, 10));
     // a column of period 1024 is a polynomial in x^(n/1024): evaluate it over offset' * <w_{b*1024}>, offset' = g^(n/1024)
-    const uint64_t g = cs::host::generator();
+    const uint64_t g = cs::host::lde_offset();
     RC_TRY(lde_impl(c, d_poly, t.tab, (uint32_t)NP, 0, (uint32_t)NP, 10, log_b, cs::host::pow(g, n / C), 0, (uint32_t)b));
     // per-coset scalars: shift_k = g w_{bn}^k, 1/(shift^n - 1), shift^adj_g, shift^badj
     std::vector<uint64_t> cc(b * cs::CE_COSET_CONSTS);
@@ -379,7 +379,7 @@ int cstark_tx_build_trace(cstark_ctx *c, uint64_t *d_trace) {
 }
 
 // ---- K2 / K3 ---------------------------------------------------------------------------------------
-uint64_t cstark_field_generator(void) { return cs::host::generator(); }
+uint64_t cstark_field_generator(void) { return cs::host::lde_offset(); }
 uint64_t cstark_field_root_of_unity(uint32_t log_n) { return log_n <= 55 ? cs::host::root_of_unity(log_n) : 0; }
 
 int cstark_interpolate_columns(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint32_t width, uint32_t log_n) {
@@ -412,7 +412,7 @@ int cstark_composition_columns(cstark_ctx *c, const uint64_t *d_combined, uint64
         HIP_TRY(cs::ntt_columns(a, c->stream));
         const uint64_t b_inv = cs::host::inv(cs::host::from_u64(1ull << log_blowup));
         HIP_TRY(cs::coset_combine(nat, h, log_n, log_blowup, pN->winv, b_inv, c->stream));
-        HIP_TRY(cs::split_columns(h, d_cols, log_n, log_blowup, cs::host::inv(cs::host::generator()), c->stream));
+        HIP_TRY(cs::split_columns(h, d_cols, log_n, log_blowup, cs::host::inv(cs::host::lde_offset()), c->stream));
         return CSTARK_OK;
     }
     HIP_TRY(cs::interleave_cosets(d_combined, nat, log_n, log_blowup, c->stream));
@@ -423,7 +423,7 @@ int cstark_composition_columns(cstark_ctx *c, const uint64_t *d_combined, uint64
     a.in = nat; a.scratch = nat; a.out = h; a.width = 1; a.batch = 1; a.log_n = log_n + log_blowup;
     a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true; a.inverse = true;
     HIP_TRY(cs::ntt_columns(a, c->stream));
-    HIP_TRY(cs::split_columns(h, d_cols, log_n, log_blowup, cs::host::inv(cs::host::generator()), c->stream));
+    HIP_TRY(cs::split_columns(h, d_cols, log_n, log_blowup, cs::host::inv(cs::host::lde_offset()), c->stream));
     return CSTARK_OK;
 }
 
@@ -462,7 +462,7 @@ int cstark_deep_composition(cstark_ctx *c, const uint64_t *d_trace_lde, const ui
     memcpy(blk.data(), alpha, width * 8); memcpy(blk.data() + width, beta, width * 8); memcpy(blk.data() + 2 * width, delta, n_comp * 8);
     memcpy(blk.data() + nco, ood_trace, 2 * (size_t)width * 8); memcpy(blk.data() + nco + 2 * width, ood_comp, n_comp * 8);
     const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
-    uint64_t shift = cs::host::generator();
+    uint64_t shift = cs::host::lde_offset();
     for (size_t k = 0; k < b; k++) { blk[2 * nco + k] = shift; shift = cs::host::mul(shift, wbn); }
     const size_t bytes = blk.size() * 8;
     if (bytes > c->desc_bytes) {
@@ -538,7 +538,7 @@ int deep_composition_ext_cosets(cstark_ctx *c, const uint64_t *d_trace_lde, cons
     memcpy(blk.data() + (size_t)m * width, beta, (size_t)m * width * 8);
     memcpy(blk.data() + (size_t)2 * m * width, delta, (size_t)m * n_comp * 8);
     const uint64_t wbn = root_of_unity(log_n + log_blowup);
-    uint64_t shift = generator();
+    uint64_t shift = lde_offset();
     for (size_t k = 0; k < b; k++) { blk[nco + k] = shift; shift = mul(shift, wbn); }
     const size_t bytes = blk.size() * 8;
     if (bytes > c->desc_bytes) {
@@ -868,7 +868,7 @@ int cstark_schnorr_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, co
         HIP_TRY(hipMalloc((void **)&t.tab, b * cols.size() * 8));
         HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), cols.size() * 8, hipMemcpyHostToDevice, c->stream));
         RC_TRY(interpolate_impl(c, d_cols, d_poly, 36, 9));
-        RC_TRY(lde_impl(c, d_poly, t.tab, 36, 0, 36, 9, log_blowup, cs::host::pow(cs::host::generator(), n / 512), 0, (uint32_t)b));
+        RC_TRY(lde_impl(c, d_poly, t.tab, 36, 0, 36, 9, log_blowup, cs::host::pow(cs::host::lde_offset(), n / 512), 0, (uint32_t)b));
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipFree(d_cols));
         HIP_TRY(hipFree(d_poly));
@@ -924,7 +924,7 @@ int cstark_air_evaluate_transitions(cstark_ctx *c, int air, const uint64_t *d_ld
         HIP_TRY(hipMalloc((void **)&t.tab, b * cols.size() * 8));
         HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), cols.size() * 8, hipMemcpyHostToDevice, c->stream));
         RC_TRY(interpolate_impl(c, d_cols, d_poly, 33, 9));
-        RC_TRY(lde_impl(c, d_poly, t.tab, 33, 0, 33, 9, log_blowup, cs::host::pow(cs::host::generator(), n / 512), 0, (uint32_t)b));
+        RC_TRY(lde_impl(c, d_poly, t.tab, 33, 0, 33, 9, log_blowup, cs::host::pow(cs::host::lde_offset(), n / 512), 0, (uint32_t)b));
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipFree(d_cols));
         HIP_TRY(hipFree(d_poly));
@@ -984,7 +984,7 @@ int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t 
     cs::AirCombineParams p{};
     std::vector<uint32_t> t_grp(nc), a_grp(na);
     for (size_t i = 0; i < nc; i++) { // distinct degree adjustments
-        const uint64_t adj = (ce - 1 + n - 1) - s.eval_degree(i, n);
+        const uint64_t adj = CSTARK_CONV_TRANSITION_ADJUSTMENT(ce, n, s.eval_degree(i, n));
         uint32_t g = 0;
         while (g < p.n_tgrp && p.tgrp_adj[g] != adj) g++;
         if (g == p.n_tgrp) {
@@ -1001,7 +1001,7 @@ int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t 
         while (g < p.n_agrp && !(p.agrp_m[g] == m && p.agrp_zc[g] == zc)) g++;
         if (g == p.n_agrp) {
             if (g == cs::AIR_MAX_GROUPS) return fail(CSTARK_ERR_UNSUPPORTED, "too many distinct assertion divisors");
-            p.agrp_m[g] = m; p.agrp_zc[g] = zc; p.agrp_badj[g] = ce - 1 + m - (n - 1);
+            p.agrp_m[g] = m; p.agrp_zc[g] = zc; p.agrp_badj[g] = CSTARK_CONV_BOUNDARY_ADJUSTMENT(ce, n, m);
             p.n_agrp++;
         }
         a_grp[a] = g;
@@ -1014,7 +1014,7 @@ int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t 
     memcpy(q, b_beta, na * 8); q += na;
     for (size_t a = 0; a < na; a++) *q++ = s.a_const.empty() ? assertion_values[a] : s.a_const[a];
     const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
-    uint64_t shift = cs::host::generator();
+    uint64_t shift = cs::host::lde_offset();
     for (uint64_t k = 0; k < b; k++) { *q++ = shift; shift = cs::host::mul(shift, wbn); }
     uint32_t *q32 = (uint32_t *)q;
     for (size_t a = 0; a < na; a++) q32[a] = s.a_reg[a];

@@ -1,10 +1,11 @@
 // FieldExtension::Quadratic / Cubic: the stages after the constraint evaluation over an extension of f63.
 // [UPSTREAM-RECALL winterfell v0.3; the extensions the fork defines for f63 are not in the reference tree -- parity unpinned.
-// Assumed: the two polynomials of the reference's own curve tower (src/utils/ecc.rs:407-648): E2 = F_p[u]/(u^2 - 2u - 2) (= Fp2 of
-// tower.cuh) and E3 = F_p[v]/(v^3 + v + 1).]  The trace is base-field; coefficients, the out-of-domain point, the DEEP composition
-// and FRI are in the extension.
+// Assumed: the two polynomials of the reference's own curve tower (src/utils/ecc.rs:407-648): E2 = F_p[u]/(u^2 - 2u - 2) and
+// E3 = F_p[v]/(v^3 + v + 1) -- CSTARK_CONV_E2_* / E3_* of include/cstark_conventions.h; the arithmetic below is generic in those
+// coefficients.]  The trace is base-field; coefficients, the out-of-domain point, the DEEP composition and FRI are in the extension.
 #include "ext.h"
-#include "tower.cuh"
+#include "fp.cuh"
+#include "../../include/cstark_conventions.h"
 
 namespace cs {
 namespace {
@@ -16,17 +17,26 @@ template <int M> __device__ __forceinline__ Ext<M> x_load(const uint64_t *p) { E
 template <int M> __device__ __forceinline__ Ext<M> x_add(Ext<M> x, Ext<M> y) { Ext<M> r; for (int i = 0; i < M; i++) r.c[i] = fp_add(x.c[i], y.c[i]); return r; }
 template <int M> __device__ __forceinline__ Ext<M> x_sub(Ext<M> x, Ext<M> y) { Ext<M> r; for (int i = 0; i < M; i++) r.c[i] = fp_sub(x.c[i], y.c[i]); return r; }
 template <int M> __device__ __forceinline__ Ext<M> x_scale(Ext<M> x, fp s) { Ext<M> r; for (int i = 0; i < M; i++) r.c[i] = fp_mul(x.c[i], s); return r; }
-__device__ __forceinline__ Ext<2> x_mul(Ext<2> x, Ext<2> y) {
-    const Fp2 r = fp2_mul({x.c[0], x.c[1]}, {y.c[0], y.c[1]});
-    return {{r.a, r.b}};
+// x times a small signed integer constant (reduction coefficients of the extension polynomials)
+template <int C> __device__ __forceinline__ fp x_small(fp x) {
+    static_assert(C >= -4 && C <= 4, "extension polynomial coefficients are small integers");
+    return fp_mul_small(x, C);
 }
-__device__ __forceinline__ Ext<3> x_mul(Ext<3> x, Ext<3> y) { // v^3 = -v - 1, v^4 = -v^2 - v
+__device__ __forceinline__ Ext<2> x_mul(Ext<2> x, Ext<2> y) { // u^2 = C1 u + C0
+    const fp bd = fp_mul(x.c[1], y.c[1]);
+    return {{fp_add(fp_mul(x.c[0], y.c[0]), x_small<CSTARK_CONV_E2_C0>(bd)),
+             fp_add(fp_add(fp_mul(x.c[0], y.c[1]), fp_mul(x.c[1], y.c[0])), x_small<CSTARK_CONV_E2_C1>(bd))}};
+}
+__device__ __forceinline__ Ext<3> x_mul(Ext<3> x, Ext<3> y) { // v^3 = C2 v^2 + C1 v + C0, v^4 = (C2^2 + C1) v^2 + (C2 C1 + C0) v + C2 C0
+    constexpr int C0 = CSTARK_CONV_E3_C0, C1 = CSTARK_CONV_E3_C1, C2 = CSTARK_CONV_E3_C2;
     const fp d0 = fp_mul(x.c[0], y.c[0]);
     const fp d1 = fp_add(fp_mul(x.c[0], y.c[1]), fp_mul(x.c[1], y.c[0]));
     const fp d2 = fp_add(fp_add(fp_mul(x.c[0], y.c[2]), fp_mul(x.c[1], y.c[1])), fp_mul(x.c[2], y.c[0]));
     const fp d3 = fp_add(fp_mul(x.c[1], y.c[2]), fp_mul(x.c[2], y.c[1]));
     const fp d4 = fp_mul(x.c[2], y.c[2]);
-    return {{fp_sub(d0, d3), fp_sub(fp_sub(d1, d3), d4), fp_sub(d2, d4)}};
+    return {{fp_add(fp_add(d0, x_small<C0>(d3)), x_small<C2 * C0>(d4)),
+             fp_add(fp_add(d1, x_small<C1>(d3)), x_small<C2 * C1 + C0>(d4)),
+             fp_add(fp_add(d2, x_small<C2>(d3)), x_small<C2 * C2 + C1>(d4))}};
 }
 template <int M> __device__ inline Ext<M> x_pow(Ext<M> x, uint64_t e) {
     Ext<M> r = x_one<M>();
@@ -40,16 +50,22 @@ template <int M> __device__ inline Ext<M> x_pow(Ext<M> x, uint64_t e) {
 // 1 / (x - z) for base x as adjugate / norm (the norm is a base-field element, so several inverses share one inversion)
 template <int M> struct XInv { Ext<M> adj; fp norm; };
 __device__ __forceinline__ XInv<2> x_inv_parts(fp x, const uint64_t *zc, Ext<2> *) {
-    const fp a = fp_sub(x, zc[0]), b = fp_neg(zc[1]); // (a + b u)^-1 = (a + 2b - b u) / (a^2 + 2ab - 2b^2)
-    return {{{fp_add(a, fp_dbl(b)), fp_neg(b)}}, fp_sub(fp_add(fp_sqr(a), fp_mul(fp_dbl(a), b)), fp_dbl(fp_sqr(b)))};
+    // (a + b u)^-1 = (a + C1 b - b u) / (a (a + C1 b) - C0 b^2)   for u^2 = C1 u + C0
+    const fp a = fp_sub(x, zc[0]), b = fp_neg(zc[1]);
+    const fp t = fp_add(a, x_small<CSTARK_CONV_E2_C1>(b));
+    return {{{t, fp_neg(b)}}, fp_sub(fp_mul(a, t), x_small<CSTARK_CONV_E2_C0>(fp_sqr(b)))};
 }
 __device__ __forceinline__ XInv<3> x_inv_parts(fp x, const uint64_t *zc, Ext<3> *) {
-    const fp a = fp_sub(x, zc[0]), b = fp_neg(zc[1]), c = fp_neg(zc[2]); // adjugate modulo v^3 + v + 1 (cubic layer of ecc.rs:551-591)
-    const fp s0 = fp_sqr(a), s1 = fp_sqr(b), s2 = fp_sqr(c);
-    const fp r0 = fp_sub(fp_add(fp_add(s0, s1), s2), fp_mul(fp_sub(fp_dbl(a), b), c));
-    const fp r1 = fp_neg(fp_add(fp_mul(a, b), s2));
-    const fp r2 = fp_add(fp_sub(s1, fp_mul(a, c)), s2);
-    return {{{r0, r1, r2}}, fp_sub(fp_mul(a, r0), fp_add(fp_mul(b, r2), fp_mul(c, r1)))};
+    // Multiplication by e = a + b v + c v^2 in the basis (1, v, v^2) is the matrix with columns e, e v, e v^2; e^-1 is the first
+    // column of its adjugate over its determinant: the cofactors of the first row (for v^3 + v + 1: the cubic layer of ecc.rs:551-591).
+    constexpr int C0 = CSTARK_CONV_E3_C0, C1 = CSTARK_CONV_E3_C1, C2 = CSTARK_CONV_E3_C2;
+    const fp a = fp_sub(x, zc[0]), b = fp_neg(zc[1]), c = fp_neg(zc[2]);
+    const fp y0 = x_small<C0>(c), y1 = fp_add(a, x_small<C1>(c)), y2 = fp_add(b, x_small<C2>(c));          // e v
+    const fp w0 = x_small<C0>(y2), w1 = fp_add(y0, x_small<C1>(y2)), w2 = fp_add(y1, x_small<C2>(y2));     // e v^2
+    const fp r0 = fp_sub(fp_mul(y1, w2), fp_mul(y2, w1));
+    const fp r1 = fp_sub(fp_mul(c, w1), fp_mul(b, w2));
+    const fp r2 = fp_sub(fp_mul(b, y2), fp_mul(c, y1));
+    return {{{r0, r1, r2}}, fp_add(fp_add(fp_mul(a, r0), fp_mul(y0, r1)), fp_mul(w0, r2))};
 }
 
 constexpr int PE_SEG = 16384;

@@ -2,6 +2,7 @@
 // coset offsets, table parameters).  Same representation as the device code: Montgomery form, R = 2^64.
 #pragma once
 #include <stdint.h>
+#include "../../include/cstark_conventions.h"
 
 namespace cs {
 namespace host {
@@ -28,16 +29,24 @@ inline uint64_t pow(uint64_t b, uint64_t e) {
     return r;
 }
 inline uint64_t inv(uint64_t a) { return pow(a, P - 2); }
-// multiplicative generator 3 and the 2^55-th root of unity 3^131 (engine conventions [UPSTREAM-RECALL])
-inline uint64_t generator() { return from_u64(3); }
+// multiplicative generator, the 2^55-th root of unity and the offset of the evaluation domains: engine conventions
+// [UPSTREAM-RECALL], include/cstark_conventions.h
+inline uint64_t generator() { return from_u64(CSTARK_CONV_FIELD_GENERATOR); }
+inline uint64_t lde_offset() { return from_u64(CSTARK_CONV_LDE_OFFSET); }
 inline uint64_t root_of_unity(unsigned log_n) {
-    uint64_t g = pow(from_u64(3), 131);
+    uint64_t g = pow(generator(), CSTARK_CONV_TWO_ADIC_ROOT_EXP);
     for (unsigned i = log_n; i < 55; i++) g = mul(g, g);
     return g;
 }
+// x times a small signed integer (the reduction coefficients of the extension polynomials)
+inline uint64_t mul_small(uint64_t x, int c) {
+    uint64_t r = 0;
+    for (int i = 0; i < (c < 0 ? -c : c); i++) r = add(r, x);
+    return c < 0 ? sub(0, r) : r;
+}
 
-// Extension fields on the host (FieldExtension::Quadratic / Cubic; ext.hip has the assumed polynomials):
-// m = 2: F_p[u]/(u^2 - 2u - 2), m = 3: F_p[v]/(v^3 + v + 1); unused high coefficients stay zero
+// Extension fields on the host (FieldExtension::Quadratic / Cubic); the assumed polynomials are CSTARK_CONV_E2_* / E3_* of
+// include/cstark_conventions.h: u^2 = C1 u + C0, v^3 = C2 v^2 + C1 v + C0; unused high coefficients stay zero
 struct EX { uint64_t c[3]; };
 inline EX ex_zero() { return {{0, 0, 0}}; }
 inline EX ex_one() { return {{ONE, 0, 0}}; }
@@ -46,13 +55,18 @@ inline EX ex_add(EX x, EX y) { return {{add(x.c[0], y.c[0]), add(x.c[1], y.c[1])
 inline EX ex_scale(EX x, uint64_t s) { return {{mul(x.c[0], s), mul(x.c[1], s), mul(x.c[2], s)}}; }
 inline EX ex_mul(EX x, EX y, unsigned m) {
     if (m == 2) {
-        const uint64_t bd = mul(x.c[1], y.c[1]), bd2 = add(bd, bd);
-        return {{add(mul(x.c[0], y.c[0]), bd2), add(add(mul(x.c[0], y.c[1]), mul(x.c[1], y.c[0])), bd2), 0}};
+        const uint64_t bd = mul(x.c[1], y.c[1]);
+        return {{add(mul(x.c[0], y.c[0]), mul_small(bd, CSTARK_CONV_E2_C0)),
+                 add(add(mul(x.c[0], y.c[1]), mul(x.c[1], y.c[0])), mul_small(bd, CSTARK_CONV_E2_C1)), 0}};
     }
     const uint64_t d0 = mul(x.c[0], y.c[0]), d1 = add(mul(x.c[0], y.c[1]), mul(x.c[1], y.c[0]));
     const uint64_t d2 = add(add(mul(x.c[0], y.c[2]), mul(x.c[1], y.c[1])), mul(x.c[2], y.c[0]));
     const uint64_t d3 = add(mul(x.c[1], y.c[2]), mul(x.c[2], y.c[1])), d4 = mul(x.c[2], y.c[2]);
-    return {{sub(d0, d3), sub(sub(d1, d3), d4), sub(d2, d4)}};
+    // v^3 = C2 v^2 + C1 v + C0;  v^4 = v v^3 = (C2^2 + C1) v^2 + (C2 C1 + C0) v + C2 C0
+    constexpr int C0 = CSTARK_CONV_E3_C0, C1 = CSTARK_CONV_E3_C1, C2 = CSTARK_CONV_E3_C2;
+    return {{add(add(d0, mul_small(d3, C0)), mul_small(d4, C2 * C0)),
+             add(add(d1, mul_small(d3, C1)), mul_small(d4, C2 * C1 + C0)),
+             add(add(d2, mul_small(d3, C2)), mul_small(d4, C2 * C2 + C1))}};
 }
 inline EX ex_pow(EX x, uint64_t e, unsigned m) {
     EX r = ex_one();

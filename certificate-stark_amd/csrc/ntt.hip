@@ -14,6 +14,7 @@
 // coset-scaling tables (8 MB each at n = 2^20) are shared by all columns and stay in L2 / Infinity Cache.
 #include "ntt.h"
 #include "fp.cuh"
+#include "../../include/cstark_conventions.h"
 #include <stdlib.h>
 #ifdef CS_NTT_NOMATH // measurement build (tools/build_variant_fast.py): the kernels' memory / LDS traffic without their field arithmetic
 #define fp_mul(a, b) ((a) ^ (b))
@@ -128,9 +129,9 @@ __host__ __device__ constexpr uint64_t cx_pow(uint64_t b, uint64_t e) {
     while (e) { if (e & 1) r = cx_mul(r, b); b = cx_mul(b, b); e >>= 1; }
     return r;
 }
-// w_{2^log}^k (INV: its inverse); 2^55-th root of unity = 3^131 [UPSTREAM-RECALL, same as hostfield.h]
+// w_{2^log}^k (INV: its inverse); 2^55-th root of unity = generator^131 [UPSTREAM-RECALL, include/cstark_conventions.h, same as hostfield.h]
 __host__ __device__ constexpr uint64_t cx_root(int log, bool inv) {
-    uint64_t g = cx_pow(cx_mul(3, FP_R2), 131);
+    uint64_t g = cx_pow(cx_mul(CSTARK_CONV_FIELD_GENERATOR, FP_R2), CSTARK_CONV_TWO_ADIC_ROOT_EXP);
     for (int i = log; i < 55; i++) g = cx_mul(g, g);
     return inv ? cx_pow(g, FP_P - 2) : g;
 }

@@ -67,14 +67,14 @@ void digest(uint32_t hash_fn, const uint8_t *p, size_t n, uint8_t out[32]) {
 
 struct Coin {
     uint8_t seed[32];
-    uint64_t counter = 0;
+    uint64_t counter = CSTARK_CONV_COIN_FIRST_COUNTER - 1; // pre-incremented by every draw
     uint32_t hash_fn = 0;
-    void init(const uint8_t *p, size_t n) { digest(hash_fn, p, n, seed); counter = 0; }
+    void init(const uint8_t *p, size_t n) { digest(hash_fn, p, n, seed); counter = CSTARK_CONV_COIN_FIRST_COUNTER - 1; }
     void reseed(const uint8_t d[32]) {
         uint8_t buf[64];
         memcpy(buf, seed, 32); memcpy(buf + 32, d, 32);
         digest(hash_fn, buf, 64, seed);
-        counter = 0;
+        counter = CSTARK_CONV_COIN_FIRST_COUNTER - 1;
     }
     void with_int(const uint8_t s[32], uint64_t v, uint8_t out[32]) const {
         uint8_t buf[40];
@@ -82,7 +82,7 @@ struct Coin {
         for (int i = 0; i < 8; i++) buf[32 + i] = (uint8_t)(v >> (8 * i));
         digest(hash_fn, buf, 40, out);
     }
-    void reseed_int(uint64_t v) { with_int(seed, v, seed); counter = 0; }
+    void reseed_int(uint64_t v) { with_int(seed, v, seed); counter = CSTARK_CONV_COIN_FIRST_COUNTER - 1; }
     uint64_t next_u64() {
         uint8_t out[32];
         with_int(seed, ++counter, out);
@@ -93,19 +93,28 @@ struct Coin {
     uint64_t draw() { // a field element, memory form
         for (;;) {
             const uint64_t v = next_u64();
-            if (v < host::P) return host::from_u64(v);
+            if (!CSTARK_CONV_COIN_REJECT_ABOVE_P || v < host::P) return host::from_u64(v); // from_u64 reduces
         }
     }
     void draw_integers(size_t count, uint64_t domain, std::vector<uint32_t> &out) {
         out.clear();
         while (out.size() < count) {
             const uint32_t v = (uint32_t)(next_u64() & (domain - 1));
-            if (std::find(out.begin(), out.end(), v) == out.end()) out.push_back(v);
+            if (!CSTARK_CONV_QUERY_DEDUP || std::find(out.begin(), out.end(), v) == out.end()) out.push_back(v);
         }
     }
 };
 
-void hash_elements(uint32_t hash_fn, const uint64_t *e, size_t n, uint8_t out[32]) { digest(hash_fn, (const uint8_t *)e, 8 * n, out); } // little-endian host
+// digest of field elements: their little-endian bytes in memory form, or canonical (CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY)
+void hash_elements(uint32_t hash_fn, const uint64_t *e, size_t n, uint8_t out[32]) {
+#if CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY
+    digest(hash_fn, (const uint8_t *)e, 8 * n, out); // little-endian host
+#else
+    std::vector<uint64_t> can(n);
+    for (size_t i = 0; i < n; i++) can[i] = host::to_u64(e[i]);
+    digest(hash_fn, (const uint8_t *)can.data(), 8 * n, out);
+#endif
+}
 
 struct Writer {
     std::vector<uint8_t> b;
@@ -280,7 +289,7 @@ int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hi
     if (job.batches.empty()) {
         RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, W, log_n));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
-        RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, W, log_n, log_b, host::generator(), job.k0, job.nk));
+        RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, W, log_n, log_b, host::lde_offset(), job.k0, job.nk));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
         return CSTARK_OK;
     }
@@ -290,7 +299,7 @@ int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hi
             if (e) HIP_TRY(hipStreamWaitEvent(st, e, 0));
         RC_TRY(cstark_interpolate_columns(c, a->trace + (size_t)cb.col0 * n, a->coeffs + (size_t)cb.col0 * n, cb.ncols, log_n));
         if (i + 1 == job.batches.size()) HIP_TRY(hipEventRecord(a->ev[evi++], st));
-        RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, cb.col0, cb.ncols, log_n, log_b, host::generator(), job.k0, job.nk));
+        RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, cb.col0, cb.ncols, log_n, log_b, host::lde_offset(), job.k0, job.nk));
     }
     HIP_TRY(hipEventRecord(a->ev[evi++], st));
     return CSTARK_OK;
@@ -407,7 +416,7 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
         ce_evals = a->cegather;
     }
     RC_TRY(cstark_composition_columns(c, ce_evals, a->ccoef, log_n, log_ce));
-    RC_TRY(cstark_lde_columns(c, a->ccoef, a->clde, (uint32_t)ce, log_n, log_b, host::generator(), 0, (uint32_t)b));
+    RC_TRY(cstark_lde_columns(c, a->ccoef, a->clde, (uint32_t)ce, log_n, log_b, host::lde_offset(), 0, (uint32_t)b));
     RC_TRY(cstark_hash_rows_fn(c, hf, a->clde, a->cnodes + 32 * N, (uint32_t)ce, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
     HIP_TRY(hipMemcpyAsync(R.cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
@@ -430,7 +439,10 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
 
     // ---- DEEP composition -------------------------------------------------------------------------------------------------
     std::vector<uint64_t> d_alpha(W), d_beta(W), d_delta(ce);
-    for (size_t i = 0; i < W; i++) { d_alpha[i] = coin.draw(); d_beta[i] = coin.draw(); (void)coin.draw(); /* conjugate term, extension fields only */ }
+    for (size_t i = 0; i < W; i++) { // alpha (point z), beta (point z w), then the draws only extension fields use (conjugate term)
+        d_alpha[i] = coin.draw(); d_beta[i] = coin.draw();
+        for (int k = 2; k < CSTARK_CONV_DEEP_DRAWS_PER_REGISTER; k++) (void)coin.draw();
+    }
     for (size_t i = 0; i < ce; i++) d_delta[i] = coin.draw();
     const uint64_t deg_a = coin.draw(), deg_b = coin.draw();
     // The DEEP composition polynomial has degree < n (quotients of degree n - 2 times the linear degree adjustment): its values on
@@ -449,7 +461,7 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
 
     // ---- FRI commit phase -----------------------------------------------------------------------------------------------------
     R.layer_roots.assign(32 * (size_t)n_layers, 0);
-    uint64_t offset = host::generator();
+    uint64_t offset = host::lde_offset();
     unsigned lg = log_N;
     for (unsigned l = 0; l < n_layers; l++) {
         const size_t rows = (size_t)1 << (lg - 2);
@@ -693,10 +705,10 @@ int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *t
         // the public-input columns (src/schnorr/air.rs:228-290) are not committed: both sides derive them from the messages
         RC_TRY(cstark_schnorr_aux_columns(c, aux));
         RC_TRY(cstark_interpolate_columns(c, aux, aux_co, 19, job.log_n));
-        RC_TRY(cstark_lde_columns(c, aux_co, aux_lde, 19, job.log_n, 3, host::generator(), 0, 8));
+        RC_TRY(cstark_lde_columns(c, aux_co, aux_lde, 19, job.log_n, 3, host::lde_offset(), 0, 8));
         RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
         RC_TRY(cstark_schnorr_assertion_polys(c, av_co, job.log_n));
-        RC_TRY(cstark_lde_columns(c, av_co, av_lde, 12, job.log_n, 3, host::generator(), 0, 8));
+        RC_TRY(cstark_lde_columns(c, av_co, av_lde, 12, job.log_n, 3, host::lde_offset(), 0, 8));
         job.evals_ready = true;
     }
     return cstark_air_combine(c, CSTARK_AIR_SCHNORR, job.item, a->lde, evals, ta, tb, ba, bb, nullptr, av_lde, 12, out, job.log_n, 3, 0, 8);
@@ -801,7 +813,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     }
     for (size_t i = 0; i < ce; i++) // column m i + q = component q of composition column i
         for (unsigned q = 0; q < m; q++) HIP_TRY(hipMemcpyAsync(ccoefs + (m * i + q) * n, cco[q] + i * n, n * 8, hipMemcpyDeviceToDevice, st));
-    RC_TRY(cstark_lde_columns(c, ccoefs, cldes, (uint32_t)CW, log_n, log_b, generator(), 0, (uint32_t)b));
+    RC_TRY(cstark_lde_columns(c, ccoefs, cldes, (uint32_t)CW, log_n, log_b, lde_offset(), 0, (uint32_t)b));
     RC_TRY(cstark_hash_rows_fn(c, hf, cldes, a->cnodes + 32 * N, (uint32_t)CW, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
     HIP_TRY(hipMemcpyAsync(cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
@@ -834,7 +846,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     std::vector<uint64_t> d_alpha(m * W), d_beta(m * W), d_delta(m * ce);
     for (size_t i = 0; i < W; i++) {
         const EX al = draw_e(), be = draw_e();
-        (void)draw_e(); // conjugate-term coefficient of the engine, unused here
+        for (int k = 2; k < CSTARK_CONV_DEEP_DRAWS_PER_REGISTER; k++) (void)draw_e(); // conjugate-term coefficient of the engine, unused here
         for (unsigned q = 0; q < m; q++) { d_alpha[m * i + q] = al.c[q]; d_beta[m * i + q] = be.c[q]; }
     }
     for (size_t i = 0; i < ce; i++) { const EX dl = draw_e(); for (unsigned q = 0; q < m; q++) d_delta[m * i + q] = dl.c[q]; }
@@ -854,7 +866,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     STAGE();
 
     std::vector<uint8_t> layer_roots(32 * (size_t)n_layers);
-    uint64_t offset = generator();
+    uint64_t offset = lde_offset();
     unsigned lg = log_N;
     for (unsigned l = 0; l < n_layers; l++) {
         const size_t rows = (size_t)1 << (lg - 2);

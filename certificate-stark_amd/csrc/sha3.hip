@@ -3,6 +3,8 @@
 // Keccak state in registers; a row of `width` elements is width 8-byte little-endian words absorbed 17 per block.
 #include "blake3.h"
 #include "keccak.cuh"
+#include "fp.cuh"
+#include "../../include/cstark_conventions.h"
 
 namespace cs {
 namespace {
@@ -24,6 +26,9 @@ __global__ __launch_bounds__(256) void k_hash_rows_sha3(const uint64_t *__restri
 #pragma unroll
         for (int i = 0; i < 17; i++) {
             uint64_t w = (unsigned)i < cnt ? col[(size_t)(c0 + i) * n] : 0;
+#if !CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY
+            if ((unsigned)i < cnt) w = fp_to_u64(w); // canonical little-endian bytes
+#endif
             if (b + 1 == nblocks) { // pad10*1 with the SHA-3 domain bits: 0x06 after the message, 0x80 at the end of the rate
                 if ((unsigned)i == cnt) w ^= 0x06;
                 if (i == 16) w ^= 0x8000000000000000ULL;

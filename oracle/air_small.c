@@ -316,7 +316,7 @@ void cso_air_combine(const cso_air_desc *d, const uint64_t *lde, const uint64_t 
     const size_t n = (size_t)1 << log_n;
     const unsigned log_ce = d->log_ce_blowup, stride = 1u << (log_b - log_ce);
     const uint64_t ce = (uint64_t)n << log_ce;
-    fp g = fp_from_u64(FP_GENERATOR_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
+    fp g = fp_from_u64(FP_LDE_OFFSET_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
 #pragma omp parallel for schedule(static) collapse(2)
     for (uint32_t k = k0; k < k0 + nk; k++)
         for (size_t j = 0; j < n; j++) {
@@ -325,7 +325,7 @@ void cso_air_combine(const cso_air_desc *d, const uint64_t *lde, const uint64_t 
             fp x = fp_mul(fp_mul(g, fp_pow(wbn, k)), fp_pow(wn, j)), acc = 0;
             for (uint32_t i = 0; i < d->n_constraints; i++) {
                 uint64_t ev_deg = d->base[i] * (n - 1) + (d->cycle_len ? d->cycles[i] * (n / d->cycle_len) * (d->cycle_len - 1) : 0);
-                uint64_t adj = (ce - 1 + n - 1) - ev_deg;
+                uint64_t adj = CSTARK_CONV_TRANSITION_ADJUSTMENT(ce, n, ev_deg);
                 fp c = evals[((size_t)(k - k0) * d->n_constraints + i) * n + j];
                 acc = fp_add(acc, fp_mul(c, fp_add(t_alpha[i], fp_mul(t_beta[i], fp_pow(x, adj)))));
             }
@@ -337,7 +337,7 @@ void cso_air_combine(const cso_air_desc *d, const uint64_t *lde, const uint64_t 
                 uint64_t m = (d->a_stride && d->a_stride[a]) ? n / d->a_stride[a] : 1;
                 fp tv = lde[((size_t)(k - k0) * d->width + d->a_reg[a]) * n + j];
                 fp cv = (d->a_seq && d->a_seq[a] >= 0) ? avals[((size_t)(k - k0) * n_avals + d->a_seq[a]) * n + j] : d->a_value[a];
-                fp xb = fp_pow(x, ce - 1 + m - (n - 1));
+                fp xb = fp_pow(x, CSTARK_CONV_BOUNDARY_ADJUSTMENT(ce, n, m));
                 fp z = fp_sub(fp_pow(x, m), fp_pow(wn, (first * m) % n));
                 acc = fp_add(acc, fp_mul(fp_mul(fp_sub(tv, cv), fp_add(b_alpha[a], fp_mul(b_beta[a], xb))), fp_inv(z)));
             }
@@ -388,7 +388,7 @@ void cso_periodic_table(const uint64_t *cols, uint32_t np, unsigned log_cycle, u
     fp *co = malloc(np * C * sizeof(fp));
     memcpy(co, cols, np * C * sizeof(fp));
     cso_interpolate_columns(co, np, log_cycle);
-    fp g = fp_from_u64(FP_GENERATOR_CAN), wbn = fp_root_of_unity(log_n + log_b);
+    fp g = fp_from_u64(FP_LDE_OFFSET_CAN), wbn = fp_root_of_unity(log_n + log_b);
     for (size_t k = 0; k < b; k++) {
         fp off = fp_pow(fp_mul(g, fp_pow(wbn, k)), n / C);
         for (uint32_t c = 0; c < np; c++) {

@@ -88,7 +88,19 @@ void cso_lde_columns(const uint64_t *coeffs, uint64_t *lde, uint32_t width, unsi
             cso_ntt(out, log_n);
         }
 }
-uint64_t cso_fp_generator(void) { return fp_from_u64(FP_GENERATOR_CAN); }
+uint64_t cso_fp_generator(void) { return fp_from_u64(FP_LDE_OFFSET_CAN); } /* used as the offset of the evaluation domains */
+/* the engine conventions of include/cstark_conventions.h for the Python half of the oracle (verifier.py, prover.py) */
+void cso_conventions(int64_t *out /*[16]*/) {
+    out[0] = CSTARK_CONV_FIELD_GENERATOR; out[1] = CSTARK_CONV_TWO_ADIC_ROOT_EXP; out[2] = CSTARK_CONV_LDE_OFFSET;
+    out[3] = CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY; out[4] = CSTARK_CONV_TRANSITION_EXEMPTIONS;
+    out[5] = CSTARK_CONV_COIN_FIRST_COUNTER; out[6] = CSTARK_CONV_COIN_REJECT_ABOVE_P; out[7] = CSTARK_CONV_QUERY_DEDUP;
+    out[8] = CSTARK_CONV_DEEP_DRAWS_PER_REGISTER;
+    out[9] = CSTARK_CONV_E2_C0; out[10] = CSTARK_CONV_E2_C1; out[11] = CSTARK_CONV_E3_C0; out[12] = CSTARK_CONV_E3_C1; out[13] = CSTARK_CONV_E3_C2;
+    out[14] = 0; out[15] = 0;
+}
+/* degree adjustments (CSTARK_CONV_*_ADJUSTMENT) for the Python half */
+uint64_t cso_transition_adjustment(uint64_t ce_size, uint64_t n, uint64_t eval_degree) { return CSTARK_CONV_TRANSITION_ADJUSTMENT(ce_size, n, eval_degree); }
+uint64_t cso_boundary_adjustment(uint64_t ce_size, uint64_t n, uint64_t m) { return CSTARK_CONV_BOUNDARY_ADJUSTMENT(ce_size, n, m); }
 
 /* ---- BLAKE3 (public specification) -------------------------------------------------------------- */
 static const uint32_t B3_IV[8] = {0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19};
@@ -165,6 +177,9 @@ void cso_hash_rows(const uint64_t *lde, uint8_t *leaves, uint32_t width, unsigne
             uint8_t buf[8 * 256];
             for (uint32_t c = 0; c < width; c++) {
                 uint64_t v = lde[((size_t)(k - k0) * width + c) * n + j];
+#if !CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY
+                v = fp_to_u64(v); /* canonical little-endian bytes */
+#endif
                 for (int t = 0; t < 8; t++) buf[8 * c + t] = v >> (8 * t);
             }
             cso_blake3(buf, 8 * (size_t)width, leaves + 32 * (b * j + k));
@@ -188,7 +203,7 @@ void cso_tx_periodic_table(unsigned depth, unsigned log_n, unsigned log_b, uint6
     fp *cols = malloc(48 * C * sizeof(fp));
     cso_tx_periodic_columns(depth, cols);
     cso_interpolate_columns(cols, 48, LOGC);
-    fp g = fp_from_u64(FP_GENERATOR_CAN), wbn = fp_root_of_unity(log_n + log_b);
+    fp g = fp_from_u64(FP_LDE_OFFSET_CAN), wbn = fp_root_of_unity(log_n + log_b);
     for (size_t k = 0; k < b; k++) {
         fp off = fp_pow(fp_mul(g, fp_pow(wbn, k)), n / C), s;
         for (int c = 0; c < 48; c++) {
@@ -208,7 +223,7 @@ void cso_tx_degree_adjustments(unsigned log_n, unsigned log_b, uint64_t *adj /*1
     uint64_t n = (uint64_t)1 << log_n, ce = n << log_b;
     for (int i = 0; i < 115; i++) {
         uint64_t ev = base[i] * (n - 1) + cyc[i] * (n / 1024) * 1023;
-        adj[i] = (ce - 1 + n - 1) - ev;
+        adj[i] = CSTARK_CONV_TRANSITION_ADJUSTMENT(ce, n, ev);
     }
 }
 
@@ -238,8 +253,8 @@ void cso_tx_evaluate_constraints(const uint64_t *lde, const cstark_tx_coeffs *cf
     cso_tx_periodic_table(depth, log_n, log_b, ptab);
     uint64_t adj[115];
     cso_tx_degree_adjustments(log_n, log_b, adj);
-    const uint64_t badj = (n << log_b) - n + 1;
-    fp g = fp_from_u64(FP_GENERATOR_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
+    const uint64_t badj = CSTARK_CONV_BOUNDARY_ADJUSTMENT(n << log_b, n, 1);
+    fp g = fp_from_u64(FP_LDE_OFFSET_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
     fp w_last = fp_inv(wn); /* w^(n-1) */
 #pragma omp parallel for schedule(static) collapse(2)
     for (uint32_t k = k0; k < k0 + nk; k++)
@@ -294,7 +309,7 @@ uint64_t cso_tx_combined_from_frame(const uint64_t *cur, const uint64_t *next, c
     fp acc = 0;
     for (int i = 0; i < 115; i++) acc = fp_add(acc, fp_mul(res[i], fp_add(cf->t_alpha[i], fp_mul(cf->t_beta[i], fp_pow(z, adj[i])))));
     acc = fp_mul(acc, fp_inv(fp_mul(fp_sub(fp_pow(z, n), FP_ONE), fp_inv(fp_sub(z, w_last)))));
-    fp xb = fp_pow(z, (n << log_b) - n + 1), first = 0, last = 0;
+    fp xb = fp_pow(z, CSTARK_CONV_BOUNDARY_ADJUSTMENT(n << log_b, n, 1)), first = 0, last = 0;
     for (int a = 0; a < 2; a++) {
         first = fp_add(first, fp_mul(fp_sub(cur[58 + a], pub_inputs[a]), fp_add(cf->b_alpha[a], fp_mul(cf->b_beta[a], xb))));
         last = fp_add(last, fp_mul(fp_sub(cur[58 + a], pub_inputs[2 + a]), fp_add(cf->b_alpha[2 + a], fp_mul(cf->b_beta[2 + a], xb))));
@@ -326,7 +341,7 @@ void cso_composition_columns(const uint64_t *combined, uint64_t *out_cols, unsig
     fp *h = malloc(N * sizeof(fp));
     for (size_t k = 0; k < b; k++) for (size_t j = 0; j < n; j++) h[b * j + k] = combined[k * n + j]; /* natural order */
     cso_intt(h, log_n + log_b);
-    fp ginv = fp_inv(fp_from_u64(FP_GENERATOR_CAN)), s = FP_ONE;
+    fp ginv = fp_inv(fp_from_u64(FP_LDE_OFFSET_CAN)), s = FP_ONE;
     for (size_t m = 0; m < N; m++) { h[m] = fp_mul(h[m], s); s = fp_mul(s, ginv); }
     for (size_t m = 0; m < N; m++) out_cols[(m % b) * n + m / b] = h[m];
     free(h);
@@ -343,7 +358,7 @@ void cso_deep_composition(const uint64_t *trace_lde, const uint64_t *comp_lde, u
                           const uint64_t *delta, uint64_t deg_a, uint64_t deg_b, uint64_t *out, unsigned log_n, unsigned log_b,
                           uint32_t k0, uint32_t nk) {
     const size_t n = (size_t)1 << log_n;
-    fp g = fp_from_u64(FP_GENERATOR_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
+    fp g = fp_from_u64(FP_LDE_OFFSET_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
     fp zw = fp_mul(z, wn), zb = fp_pow(z, nb);
 #pragma omp parallel for schedule(static) collapse(2)
     for (uint32_t k = k0; k < k0 + nk; k++)
@@ -444,6 +459,9 @@ void cso_hash_rows_fn(int hash_fn, const uint64_t *lde, uint8_t *leaves, uint32_
             uint8_t buf[8 * 256];
             for (uint32_t c = 0; c < width; c++) {
                 uint64_t v = lde[((size_t)(k - k0) * width + c) * n + j];
+#if !CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY
+                v = fp_to_u64(v); /* canonical little-endian bytes */
+#endif
                 for (int t = 0; t < 8; t++) buf[8 * c + t] = v >> (8 * t);
             }
             cso_digest(hash_fn, buf, 8 * (size_t)width, leaves + 32 * (b * j + k));

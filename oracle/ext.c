@@ -25,39 +25,44 @@ static inline E e_scale(E x, fp s) { E r; for (int i = 0; i < 3; i++) r.c[i] = f
 static inline E e_sub_base(fp x, E z) { E r = {{fp_sub(x, z.c[0]), fp_neg(z.c[1]), fp_neg(z.c[2])}}; return r; } /* x - z */
 static E e_mul(E x, E y, int m) {
     E r = e_zero();
-    if (m == 2) { /* u^2 = 2u + 2 */
-        fp bd = fp_mul(x.c[1], y.c[1]), bd2 = fp_dbl(bd);
-        r.c[0] = fp_add(fp_mul(x.c[0], y.c[0]), bd2);
-        r.c[1] = fp_add(fp_add(fp_mul(x.c[0], y.c[1]), fp_mul(x.c[1], y.c[0])), bd2);
+    if (m == 2) { /* u^2 = C1 u + C0 (include/cstark_conventions.h; assumed 2u + 2) */
+        fp bd = fp_mul(x.c[1], y.c[1]);
+        r.c[0] = fp_add(fp_mul(x.c[0], y.c[0]), fp_mul_small(bd, CSTARK_CONV_E2_C0));
+        r.c[1] = fp_add(fp_add(fp_mul(x.c[0], y.c[1]), fp_mul(x.c[1], y.c[0])), fp_mul_small(bd, CSTARK_CONV_E2_C1));
         return r;
     }
-    /* v^3 = -v - 1, v^4 = -v^2 - v */
+    /* v^3 = C2 v^2 + C1 v + C0 (assumed -v - 1), v^4 = (C2^2 + C1) v^2 + (C2 C1 + C0) v + C2 C0 */
+    const int C0 = CSTARK_CONV_E3_C0, C1 = CSTARK_CONV_E3_C1, C2 = CSTARK_CONV_E3_C2;
     fp d0 = fp_mul(x.c[0], y.c[0]);
     fp d1 = fp_add(fp_mul(x.c[0], y.c[1]), fp_mul(x.c[1], y.c[0]));
     fp d2 = fp_add(fp_add(fp_mul(x.c[0], y.c[2]), fp_mul(x.c[1], y.c[1])), fp_mul(x.c[2], y.c[0]));
     fp d3 = fp_add(fp_mul(x.c[1], y.c[2]), fp_mul(x.c[2], y.c[1]));
     fp d4 = fp_mul(x.c[2], y.c[2]);
-    r.c[0] = fp_sub(d0, d3);
-    r.c[1] = fp_sub(fp_sub(d1, d3), d4);
-    r.c[2] = fp_sub(d2, d4);
+    r.c[0] = fp_add(fp_add(d0, fp_mul_small(d3, C0)), fp_mul_small(d4, C2 * C0));
+    r.c[1] = fp_add(fp_add(d1, fp_mul_small(d3, C1)), fp_mul_small(d4, C2 * C1 + C0));
+    r.c[2] = fp_add(fp_add(d2, fp_mul_small(d3, C2)), fp_mul_small(d4, C2 * C2 + C1));
     return r;
 }
 static E e_inv(E x, int m) {
     E r = e_zero();
-    if (m == 2) { /* 1/(a + b u) = (a + 2b - b u) / (a^2 + 2ab - 2b^2) */
+    if (m == 2) { /* 1/(a + b u) = (a + C1 b - b u) / (a (a + C1 b) - C0 b^2) */
         fp a = x.c[0], b = x.c[1];
-        fp t = fp_inv(fp_sub(fp_add(fp_sqr(a), fp_mul(fp_dbl(a), b)), fp_dbl(fp_sqr(b))));
-        r.c[0] = fp_mul(fp_add(a, fp_dbl(b)), t);
+        fp s = fp_add(a, fp_mul_small(b, CSTARK_CONV_E2_C1));
+        fp t = fp_inv(fp_sub(fp_mul(a, s), fp_mul_small(fp_sqr(b), CSTARK_CONV_E2_C0)));
+        r.c[0] = fp_mul(s, t);
         r.c[1] = fp_mul(fp_neg(b), t);
         return r;
     }
-    /* adjugate of the multiplication matrix of a + b v + c v^2 modulo v^3 + v + 1 (the cubic layer of ecc.rs:551-591) */
+    /* first column of the adjugate of the matrix of "multiply by a + b v + c v^2" (columns e, e v, e v^2) over its determinant; for
+     * v^3 + v + 1 this is the cubic layer of ecc.rs:551-591 */
+    const int C0 = CSTARK_CONV_E3_C0, C1 = CSTARK_CONV_E3_C1, C2 = CSTARK_CONV_E3_C2;
     fp a = x.c[0], b = x.c[1], c = x.c[2];
-    fp s0 = fp_sqr(a), s1 = fp_sqr(b), s2 = fp_sqr(c);
-    fp r0 = fp_sub(fp_add(fp_add(s0, s1), s2), fp_mul(fp_sub(fp_dbl(a), b), c));
-    fp r1 = fp_neg(fp_add(fp_mul(a, b), s2));
-    fp r2 = fp_add(fp_sub(s1, fp_mul(a, c)), s2);
-    fp nrm = fp_sub(fp_mul(a, r0), fp_add(fp_mul(b, r2), fp_mul(c, r1)));
+    fp y0 = fp_mul_small(c, C0), y1 = fp_add(a, fp_mul_small(c, C1)), y2 = fp_add(b, fp_mul_small(c, C2));
+    fp w0 = fp_mul_small(y2, C0), w1 = fp_add(y0, fp_mul_small(y2, C1)), w2 = fp_add(y1, fp_mul_small(y2, C2));
+    fp r0 = fp_sub(fp_mul(y1, w2), fp_mul(y2, w1));
+    fp r1 = fp_sub(fp_mul(c, w1), fp_mul(b, w2));
+    fp r2 = fp_sub(fp_mul(b, y2), fp_mul(c, y1));
+    fp nrm = fp_add(fp_add(fp_mul(a, r0), fp_mul(y0, r1)), fp_mul(w0, r2));
     fp t = fp_inv(nrm);
     r.c[0] = fp_mul(r0, t); r.c[1] = fp_mul(r1, t); r.c[2] = fp_mul(r2, t);
     return r;
@@ -86,7 +91,7 @@ void cso_deep_composition_ext(const uint64_t *trace_lde, const uint64_t *comp_ld
                               const uint64_t *delta, const uint64_t *deg_ap, const uint64_t *deg_bp, uint64_t *out, unsigned log_n, unsigned log_b,
                               int m) {
     const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b;
-    const fp g = fp_from_u64(FP_GENERATOR_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
+    const fp g = fp_from_u64(FP_LDE_OFFSET_CAN), wbn = fp_root_of_unity(log_n + log_b), wn = fp_root_of_unity(log_n);
     const E z = e_load(zp, m), zw = e_scale(z, wn);
     E zb = e_one();
     for (uint32_t i = 0; i < nb; i++) zb = e_mul(zb, z, m);

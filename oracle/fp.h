@@ -25,8 +25,9 @@ typedef unsigned __int128 u128;
 #define FP_R2    0x32734c36b7b1d512ULL /* 2^128 mod p */
 #define FP_ZERO  0ULL
 #define FP_TWO_ADICITY 55
-#define FP_GENERATOR_CAN 3ULL               /* smallest primitive root of p   [UPSTREAM-RECALL] */
-#define FP_TWO_ADIC_ROOT_CAN 90479342105353296ULL /* 3^131 mod p, order 2^55 [UPSTREAM-RECALL] */
+#include "../include/cstark_conventions.h"   /* the engine conventions [UPSTREAM-RECALL], shared with the product */
+#define FP_GENERATOR_CAN ((uint64_t)CSTARK_CONV_FIELD_GENERATOR)   /* multiplicative generator = offset of the evaluation domains */
+#define FP_LDE_OFFSET_CAN ((uint64_t)CSTARK_CONV_LDE_OFFSET)
 
 static inline fp fp_add(fp a, fp b) { uint64_t s = a + b; return s >= FP_P ? s - FP_P : s; }
 static inline fp fp_sub(fp a, fp b) { return a >= b ? a - b : a + (FP_P - b); }
@@ -54,10 +55,16 @@ static inline fp fp_pow(fp base, uint64_t e) {
     return r;
 }
 static inline fp fp_inv(fp a) { return fp_pow(a, FP_P - 2); } /* inv(0) = 0 */
+/* x times a small signed integer (reduction coefficients of the extension polynomials) */
+static inline fp fp_mul_small(fp x, int c) {
+    fp r = 0;
+    for (int i = 0; i < (c < 0 ? -c : c); i++) r = fp_add(r, x);
+    return c < 0 ? fp_neg(r) : r;
+}
 
-/* primitive 2^k-th root of unity: G^(2^(55-k)), G = 3^131   [UPSTREAM-RECALL get_root_of_unity] */
+/* primitive 2^k-th root of unity: G^(2^(55-k)), G = generator^131   [UPSTREAM-RECALL get_root_of_unity] */
 static inline fp fp_root_of_unity(unsigned log_n) {
-    fp g = fp_from_u64(FP_TWO_ADIC_ROOT_CAN);
+    fp g = fp_pow(fp_from_u64(FP_GENERATOR_CAN), CSTARK_CONV_TWO_ADIC_ROOT_EXP);
     for (unsigned i = log_n; i < FP_TWO_ADICITY; i++) g = fp_sqr(g);
     return g;
 }

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libcs_oracle.so")
+_SO = os.environ.get("CS_ORACLE_LIB") or os.path.join(_HERE, "_build", "libcs_oracle.so")  # CS_ORACLE_LIB: tools/flip_conventions.sh
 
 P = 2**62 + 2**56 + 2**55 + 1
 R = 2**64
@@ -36,9 +36,12 @@ class TxCoeffsStruct(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("CS_ORACLE_LIB"):
+        return _SO
     if force or not os.path.exists(_SO) or any(
-            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
-            for f in os.listdir(_HERE) if f.endswith((".c", ".h"))):
+            os.path.getmtime(f) > os.path.getmtime(_SO)
+            for f in [os.path.join(_HERE, g) for g in os.listdir(_HERE) if g.endswith((".c", ".h"))] +
+            [os.path.join(_HERE, "..", "include", "cstark_conventions.h")]):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 

@@ -76,11 +76,11 @@ class ShardedProver:
         zb = _mont(pow(z, b, V.P))
         self.ood_trace = ood_trace = O.evaluate_polys_at(self.coeffs, [zm, zw])          # [2][94]
         self.ood_comp = ood_comp = O.evaluate_polys_at(ccoef, [zb])[0]                   # [8]
-        coin.reseed(H(ood_trace.tobytes()))
-        coin.reseed(H(ood_comp.tobytes()))
+        coin.reseed(H(V.elem_bytes(ood_trace)))
+        coin.reseed(H(V.elem_bytes(ood_comp)))
         d_alpha, d_beta = [], []
         for _ in range(W):
-            d_alpha.append(_mont(coin.draw())); d_beta.append(_mont(coin.draw())); coin.draw()
+            d_alpha.append(_mont(coin.draw())); d_beta.append(_mont(coin.draw())); [coin.draw() for _ in range(2, V.CONV["deep_draws_per_register"])]
         d_delta = [_mont(coin.draw()) for _ in range(b)]
         deg_a, deg_b = _mont(coin.draw()), _mont(coin.draw())
         # the DEEP composition polynomial has degree < n: coset 0 of the extended trace determines it (as the product computes it)
@@ -91,7 +91,7 @@ class ShardedProver:
             deep = O.lde_columns(O.interpolate_columns(d0.reshape(1, n).copy()), log_b, offset=int(O.to_mont([1])[0]))[:, 0, :]
         layer = np.ascontiguousarray(deep.T).reshape(-1)            # natural order i = 8 j + k
         self.layers, self.trees, self.roots = [], [], []
-        offset, lg = 3, log_N
+        offset, lg = V.GEN, log_N
         while lg > self.log_rem:
             rows = 1 << (lg - 2)
             nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 4, rows), 0, hash_fn=hash_fn), hash_fn)
@@ -102,7 +102,7 @@ class ShardedProver:
             offset = pow(offset, 4, V.P)
             lg -= 2
         self.remainder = layer
-        self.rem_commit = H(layer.tobytes())
+        self.rem_commit = H(V.elem_bytes(layer))
         coin.reseed(self.rem_commit)
         nonce = 1
         while grinding and struct.unpack("<Q", H(coin.seed + struct.pack("<Q", nonce))[:8])[0] & ((1 << grinding) - 1):
@@ -219,19 +219,20 @@ def prove_ext(w, options):
             gk = V.e_mul(gk, V.e_gen(m))
         ood_comp[i] = V.e_mont(h)
     ood_trace = np.concatenate([ood_cur, ood_next])
-    coin.reseed(H(ood_trace.tobytes()))
-    coin.reseed(H(ood_comp.tobytes()))
+    coin.reseed(H(V.elem_bytes(ood_trace)))
+    coin.reseed(H(V.elem_bytes(ood_comp)))
     d_alpha, d_beta = np.zeros((W, m), np.uint64), np.zeros((W, m), np.uint64)
     for c in range(W):
         d_alpha[c], d_beta[c] = V.e_mont(coin.draw_e(m)), V.e_mont(coin.draw_e(m))
-        coin.draw_e(m)
+        for _ in range(2, V.CONV["deep_draws_per_register"]):
+            coin.draw_e(m)
     d_delta = np.array([V.e_mont(coin.draw_e(m)) for _ in range(b)], np.uint64)
     deg_a, deg_b = V.e_mont(coin.draw_e(m)), V.e_mont(coin.draw_e(m))
     deep = O.deep_composition_ext(lde, clde, V.e_mont(z), ood_trace, ood_comp, d_alpha, d_beta, d_delta, deg_a, deg_b, log_b)
     layer = np.ascontiguousarray(np.stack([np.ascontiguousarray(deep[k].T).reshape(-1) for k in range(m)]))  # [m][N] natural order
 
     layers, trees, roots = [], [], []
-    offset, lg = 3, log_N
+    offset, lg = V.GEN, log_N
     while lg > log_rem:
         rows = 1 << (lg - 2)
         nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 4 * m, rows), 0, hash_fn=hash_fn), hash_fn)
@@ -242,7 +243,7 @@ def prove_ext(w, options):
         offset = pow(offset, 4, V.P)
         lg -= 2
     remainder = layer
-    rem_commit = H(remainder.tobytes())
+    rem_commit = H(V.elem_bytes(remainder))
     coin.reseed(rem_commit)
     nonce = 1
     while grinding and struct.unpack("<Q", H(coin.seed + struct.pack("<Q", nonce))[:8])[0] & ((1 << grinding) - 1):

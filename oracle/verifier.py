@@ -19,8 +19,42 @@ from . import oracle as O
 
 P = (1 << 62) + (1 << 56) + (1 << 55) + 1
 R_INV = pow(1 << 64, -1, P)
-GEN = 3
-TWO_ADIC_ROOT = pow(3, 131, P)  # order 2^55
+
+
+def _conventions():
+    """the engine conventions of include/cstark_conventions.h, as compiled into the oracle library (shared with the product)"""
+    import ctypes as C
+    out = (C.c_int64 * 16)()
+    O.lib().cso_conventions(out)
+    keys = ("generator", "two_adic_root_exp", "lde_offset", "hashed_bytes_montgomery", "transition_exemptions", "coin_first_counter",
+            "coin_reject_above_p", "query_dedup", "deep_draws_per_register", "e2_c0", "e2_c1", "e3_c0", "e3_c1", "e3_c2")
+    return dict(zip(keys, [int(v) for v in out]))
+
+
+CONV = _conventions()
+GEN = CONV["lde_offset"]                                                     # offset of the evaluation domains
+TWO_ADIC_ROOT = pow(CONV["generator"], CONV["two_adic_root_exp"], P)         # order 2^55
+assert CONV["transition_exemptions"] == 1
+
+
+def elem_bytes(a):
+    """bytes of field elements (numpy uint64, memory form) as they enter a hash: memory form or canonical, little-endian"""
+    a = np.ascontiguousarray(a, np.uint64)
+    if CONV["hashed_bytes_montgomery"]:
+        return a.tobytes()
+    return np.ascontiguousarray(O.from_mont(a.reshape(-1))).tobytes()
+
+
+def transition_adjustment(ce_size, n, eval_degree):
+    O.lib().cso_transition_adjustment.restype = __import__("ctypes").c_uint64
+    c = __import__("ctypes").c_uint64
+    return int(O.lib().cso_transition_adjustment(c(ce_size), c(n), c(eval_degree)))
+
+
+def boundary_adjustment(ce_size, n, m):
+    O.lib().cso_boundary_adjustment.restype = __import__("ctypes").c_uint64
+    c = __import__("ctypes").c_uint64
+    return int(O.lib().cso_boundary_adjustment(c(ce_size), c(n), c(m)))
 
 
 class VerifierError(Exception):
@@ -50,15 +84,16 @@ def e_sub(x, y):
 
 
 def e_mul(x, y):
-    if len(x) == 2:
+    if len(x) == 2:  # u^2 = C1 u + C0
         bd = x[1] * y[1]
-        return ((x[0] * y[0] + 2 * bd) % P, (x[0] * y[1] + x[1] * y[0] + 2 * bd) % P)
+        return ((x[0] * y[0] + CONV["e2_c0"] * bd) % P, (x[0] * y[1] + x[1] * y[0] + CONV["e2_c1"] * bd) % P)
+    c0, c1, c2 = CONV["e3_c0"], CONV["e3_c1"], CONV["e3_c2"]  # v^3 = C2 v^2 + C1 v + C0
     d0 = x[0] * y[0]
     d1 = x[0] * y[1] + x[1] * y[0]
     d2 = x[0] * y[2] + x[1] * y[1] + x[2] * y[0]
     d3 = x[1] * y[2] + x[2] * y[1]
     d4 = x[2] * y[2]
-    return ((d0 - d3) % P, (d1 - d3 - d4) % P, (d2 - d4) % P)  # v^3 = -v - 1, v^4 = -v^2 - v
+    return ((d0 + c0 * d3 + c2 * c0 * d4) % P, (d1 + c1 * d3 + (c2 * c1 + c0) * d4) % P, (d2 + c2 * d3 + (c2 * c2 + c1) * d4) % P)
 
 
 def e_scale(x, s):
@@ -87,15 +122,19 @@ def e_pow(x, e):
 def e_inv(x):
     # Fermat would need p^m - 2; use the adjugate: x^-1 = adj(x) / norm(x) with the norm in the base field
     m = len(x)
-    if m == 2:  # 1/(a + b u) = (a + 2b - b u) / (a^2 + 2ab - 2b^2)
+    if m == 2:  # 1/(a + b u) = (a + C1 b - b u) / (a (a + C1 b) - C0 b^2)
         a, b = x
-        t = pow((a * a + 2 * a * b - 2 * b * b) % P, -1, P)
-        return ((a + 2 * b) * t % P, (-b) * t % P)
+        s_ = (a + CONV["e2_c1"] * b) % P
+        t = pow((a * s_ - CONV["e2_c0"] * b * b) % P, -1, P)
+        return (s_ * t % P, (-b) * t % P)
+    c0, c1, c2 = CONV["e3_c0"], CONV["e3_c1"], CONV["e3_c2"]
     a, b, c = x
-    r0 = (a * a + b * b + c * c - (2 * a - b) * c) % P
-    r1 = (-(a * b + c * c)) % P
-    r2 = (b * b - a * c + c * c) % P
-    t = pow((a * r0 - b * r2 - c * r1) % P, -1, P)
+    y0, y1, y2 = c0 * c % P, (a + c1 * c) % P, (b + c2 * c) % P            # x v
+    w0, w1, w2 = c0 * y2 % P, (y0 + c1 * y2) % P, (y1 + c2 * y2) % P       # x v^2
+    r0 = (y1 * w2 - y2 * w1) % P
+    r1 = (c * w1 - b * w2) % P
+    r2 = (b * y2 - c * y1) % P
+    t = pow((a * r0 + y0 * r1 + w0 * r2) % P, -1, P)
     return (r0 * t % P, r1 * t % P, r2 * t % P)
 
 
@@ -106,16 +145,16 @@ def e_mont(x):
 class Coin:
     def __init__(self, seed_bytes, hash_fn=0):
         self.hash_fn = hash_fn
-        self.seed, self.counter = self.h(seed_bytes), 0
+        self.seed, self.counter = self.h(seed_bytes), CONV["coin_first_counter"] - 1
 
     def h(self, data):
         return O.digest(data, self.hash_fn)
 
     def reseed(self, digest):
-        self.seed, self.counter = self.h(self.seed + bytes(digest)), 0
+        self.seed, self.counter = self.h(self.seed + bytes(digest)), CONV["coin_first_counter"] - 1
 
     def reseed_int(self, v):
-        self.seed, self.counter = self.h(self.seed + struct.pack("<Q", v)), 0
+        self.seed, self.counter = self.h(self.seed + struct.pack("<Q", v)), CONV["coin_first_counter"] - 1
 
     def _next(self):
         self.counter += 1
@@ -125,6 +164,8 @@ class Coin:
         """a field element (canonical integer)"""
         while True:
             v = self._next()
+            if not CONV["coin_reject_above_p"]:
+                return v % P
             if v < P:
                 return v
 
@@ -136,7 +177,7 @@ class Coin:
         out = []
         while len(out) < count:
             v = self._next() & (domain - 1)
-            if v not in out:
+            if not CONV["query_dedup"] or v not in out:
                 out.append(v)
         return out
 
@@ -279,7 +320,7 @@ def _tx_ood_combined_ext(self, d, log_n, z, ta, tb, ba, bb, m):
         acc = e_add(acc, e_mul(cvals[i], e_add(ta[i], e_mul(tb[i], zpow[adj[i]]))))
     w_last = pow(wn, n - 1, P)
     acc = e_mul(acc, e_mul(e_sub(z, B(w_last)), e_inv(e_sub(e_pow(z, n), B(1)))))
-    xb = e_pow(z, (n << log_b) - n + 1)
+    xb = e_pow(z, boundary_adjustment(n << log_b, n, 1))
     first = last = B(0)
     for a in range(2):
         first = e_add(first, e_mul(e_sub(cur[58 + a], B(self.pub[a])), e_add(ba[a], e_mul(bb[a], xb))))
@@ -300,12 +341,12 @@ class _GenericAir:
         acc = 0
         for i in range(self.nc):
             ev = int(self.base[i]) * (n - 1) + (int(self.cycles[i]) * (n // self.cycle_len) * (self.cycle_len - 1) if self.cycle_len else 0)
-            acc += res[i] * ((ta[i] + tb[i] * pow(z, (ce_size - 1 + n - 1) - ev, P)) % P)
+            acc += res[i] * ((ta[i] + tb[i] * pow(z, transition_adjustment(ce_size, n, ev), P)) % P)
         acc = acc % P * ((z - pow(wn, n - 1, P)) % P) % P * pow(pow(z, n, P) - 1, -1, P) % P
         for a, (reg, first, stride, value) in enumerate(assertions):
             m = n // stride if stride else 1
             div = (pow(z, m, P) - pow(wn, (first * m) % n, P)) % P
-            term = (cur[reg] - value) % P * ((ba[a] + bb[a] * pow(z, ce_size - 1 + m - (n - 1), P)) % P) % P
+            term = (cur[reg] - value) % P * ((ba[a] + bb[a] * pow(z, boundary_adjustment(ce_size, n, m), P)) % P) % P
             acc = (acc + term * pow(div, -1, P)) % P
         return acc
 
@@ -346,12 +387,12 @@ def _merge_e(air, log_n, z, res, ta, tb, ba, bb, cur, assertions, m):
     acc = B(0)
     for i in range(air.nc):
         ev = int(air.base[i]) * (n - 1) + (int(air.cycles[i]) * (n // air.cycle_len) * (air.cycle_len - 1) if air.cycle_len else 0)
-        acc = e_add(acc, e_mul(res[i], e_add(ta[i], e_mul(tb[i], e_pow(z, (ce_size - 1 + n - 1) - ev)))))
+        acc = e_add(acc, e_mul(res[i], e_add(ta[i], e_mul(tb[i], e_pow(z, transition_adjustment(ce_size, n, ev))))))
     acc = e_mul(acc, e_mul(e_sub(z, B(pow(wn, n - 1, P))), e_inv(e_sub(e_pow(z, n), B(1)))))
     for a, (reg, first, stride, value) in enumerate(assertions):
         mm = n // stride if stride else 1
         div = e_sub(e_pow(z, mm), B(pow(wn, (first * mm) % n, P)))
-        term = e_mul(e_sub(cur[reg], value), e_add(ba[a], e_mul(bb[a], e_pow(z, ce_size - 1 + mm - (n - 1)))))
+        term = e_mul(e_sub(cur[reg], value), e_add(ba[a], e_mul(bb[a], e_pow(z, boundary_adjustment(ce_size, n, mm)))))
         acc = e_add(acc, e_mul(term, e_inv(div)))
     return acc
 
@@ -561,18 +602,18 @@ def _verify(d, air, options):
     rhs = sum(h * pow(z, i, P) for i, h in enumerate(hz)) % P
     if lhs != rhs:
         raise VerifierError("out-of-domain constraint evaluations are inconsistent")
-    coin.reseed(H(cur.tobytes() + nxt.tobytes()))
-    coin.reseed(H(np.ascontiguousarray(d["ood_comp"]).tobytes()))
+    coin.reseed(H(elem_bytes(cur) + elem_bytes(nxt)))
+    coin.reseed(H(elem_bytes(d["ood_comp"])))
     d_alpha, d_beta = [], []
     for _ in range(W):
-        d_alpha.append(coin.draw()); d_beta.append(coin.draw()); coin.draw()
+        d_alpha.append(coin.draw()); d_beta.append(coin.draw()); [coin.draw() for _ in range(2, CONV["deep_draws_per_register"])]
     d_delta = [coin.draw() for _ in range(ce)]
     deg_a, deg_b = coin.draw(), coin.draw()
     alphas = []
     for root in d["layer_roots"]:
         coin.reseed(root)
         alphas.append(coin.draw())
-    if H(np.ascontiguousarray(d["remainder"]).tobytes()) != d["rem_commit"]:
+    if H(elem_bytes(d["remainder"])) != d["rem_commit"]:
         raise VerifierError("remainder does not match its commitment")
     coin.reseed(d["rem_commit"])
     if grinding:
@@ -584,9 +625,9 @@ def _verify(d, air, options):
 
     # 3. trace / composition openings
     for q, pos in enumerate(positions):
-        if merkle_root_from_path(H(d["trace_rows"][q].tobytes()), pos, d["trace_paths"][q], hash_fn) != d["trace_root"]:
+        if merkle_root_from_path(H(elem_bytes(d["trace_rows"][q])), pos, d["trace_paths"][q], hash_fn) != d["trace_root"]:
             raise VerifierError("trace opening %d does not match the trace commitment" % q)
-        if merkle_root_from_path(H(d["cons_rows"][q].tobytes()), pos, d["cons_paths"][q], hash_fn) != d["cons_root"]:
+        if merkle_root_from_path(H(elem_bytes(d["cons_rows"][q])), pos, d["cons_paths"][q], hash_fn) != d["cons_root"]:
             raise VerifierError("composition opening %d does not match the constraint commitment" % q)
 
     # 4. DEEP composition at the queried points
@@ -618,7 +659,7 @@ def _verify(d, air, options):
         if len(fpos) != len(rows):
             raise VerifierError("layer %d: wrong number of openings" % l)
         for t, rp in enumerate(fpos):
-            if merkle_root_from_path(H(rows[t].tobytes()), rp, paths[t], hash_fn) != d["layer_roots"][l]:
+            if merkle_root_from_path(H(elem_bytes(rows[t])), rp, paths[t], hash_fn) != d["layer_roots"][l]:
                 raise VerifierError("layer %d opening does not match its commitment" % l)
         for p, v in zip(cur_pos, cur_val):
             if from_mont(rows[fpos.index(p & (rows_n - 1))][p >> (lgl - 2)]) != v:
@@ -732,18 +773,18 @@ def _verify_ext(d, air, options):
         zi = e_mul(zi, z)
     if lhs != rhs:
         raise VerifierError("out-of-domain constraint evaluations are inconsistent")
-    coin.reseed(H(np.ascontiguousarray(d["ood_cur"]).tobytes() + np.ascontiguousarray(d["ood_next"]).tobytes()))
-    coin.reseed(H(np.ascontiguousarray(d["ood_comp"]).tobytes()))
+    coin.reseed(H(elem_bytes(d["ood_cur"]) + elem_bytes(d["ood_next"])))
+    coin.reseed(H(elem_bytes(d["ood_comp"])))
     d_alpha, d_beta = [], []
     for _ in range(W):
-        d_alpha.append(coin.draw_e(m)); d_beta.append(coin.draw_e(m)); coin.draw_e(m)
+        d_alpha.append(coin.draw_e(m)); d_beta.append(coin.draw_e(m)); [coin.draw_e(m) for _ in range(2, CONV["deep_draws_per_register"])]
     d_delta = [coin.draw_e(m) for _ in range(ce)]
     deg_a, deg_b = coin.draw_e(m), coin.draw_e(m)
     alphas = []
     for root in d["layer_roots"]:
         coin.reseed(root)
         alphas.append(coin.draw_e(m))
-    if H(np.ascontiguousarray(d["remainder"]).tobytes()) != d["rem_commit"]:
+    if H(elem_bytes(d["remainder"])) != d["rem_commit"]:
         raise VerifierError("remainder does not match its commitment")
     coin.reseed(d["rem_commit"])
     if grinding:
@@ -753,9 +794,9 @@ def _verify_ext(d, air, options):
     coin.reseed_int(d["nonce"])
     positions = coin.draw_integers(nq, N)
     for q, pos in enumerate(positions):
-        if merkle_root_from_path(H(d["trace_rows"][q].tobytes()), pos, d["trace_paths"][q], hash_fn) != d["trace_root"]:
+        if merkle_root_from_path(H(elem_bytes(d["trace_rows"][q])), pos, d["trace_paths"][q], hash_fn) != d["trace_root"]:
             raise VerifierError("trace opening %d does not match the trace commitment" % q)
-        if merkle_root_from_path(H(d["cons_rows"][q].tobytes()), pos, d["cons_paths"][q], hash_fn) != d["cons_root"]:
+        if merkle_root_from_path(H(elem_bytes(d["cons_rows"][q])), pos, d["cons_paths"][q], hash_fn) != d["cons_root"]:
             raise VerifierError("composition opening %d does not match the constraint commitment" % q)
     # DEEP composition over the extension at the queried points
     wN = root_of_unity(log_N)
@@ -786,7 +827,7 @@ def _verify_ext(d, air, options):
             raise VerifierError("layer %d: wrong number of openings" % l)
         vals = []
         for t, rp in enumerate(fpos):
-            if merkle_root_from_path(H(rows[t].tobytes()), rp, paths[t], hash_fn) != d["layer_roots"][l]:
+            if merkle_root_from_path(H(elem_bytes(rows[t])), rp, paths[t], hash_fn) != d["layer_roots"][l]:
                 raise VerifierError("layer %d opening does not match its commitment" % l)
             r = [from_mont(e) for e in rows[t]]
             vals.append([tuple(r[4 * q + k] for q in range(m)) for k in range(4)])

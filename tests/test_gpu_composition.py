@@ -38,7 +38,7 @@ def test_composition_columns_and_commitment(oracle, backend, log_n):
     assert (nodes.cpu().numpy() == oracle.merkle_build(oracle.hash_rows(ref_lde, 3))).all()
     # consistency: the column polynomials reproduce the combined evaluations on the LDE domain,
     # H(x_i) = sum_c x_i^c H_c(x_i^8) -- checked on a few points with the oracle
-    g, w8n, wn = 3, oracle.from_mont([oracle.root_of_unity(log_n + 3)])[0], oracle.from_mont([oracle.root_of_unity(log_n)])[0]
+    g, w8n, wn = int(oracle.from_mont([oracle.generator()])[0]), oracle.from_mont([oracle.root_of_unity(log_n + 3)])[0], oracle.from_mont([oracle.root_of_unity(log_n)])[0]
     for (k, j) in [(0, 0), (5, 17), (7, n - 1)]:
         x = g * pow(int(w8n), k, P) * pow(int(wn), j, P) % P
         x8 = int(oracle.to_mont([pow(x, 8, P)])[0])
