@@ -1039,6 +1039,19 @@ int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t 
     p.w_last = cs::host::inv(wn);
     p.width = s.width; p.n_constraints = (uint32_t)nc; p.n_assertions = (uint32_t)na;
     p.stride = 1u << (log_blowup - log_ce); p.log_n = log_n; p.k0 = k0;
+    if (b > 8) return fail(CSTARK_ERR_UNSUPPORTED, "cstark_air_combine: blowup factor at most 8");
+    {   // per-coset powers of the coset shift (the kernel completes them with a twiddle-table product per point)
+        uint64_t sh = cs::host::lde_offset();
+        for (uint64_t k = 0; k < b; k++) {
+            for (uint32_t g = 0; g < p.n_tgrp; g++) p.tgrp_shift[k][g] = cs::host::pow(sh, p.tgrp_adj[g]);
+            for (uint32_t g = 0; g < p.n_agrp; g++) {
+                p.agrp_bshift[k][g] = cs::host::pow(sh, p.agrp_badj[g]);
+                p.agrp_mshift[k][g] = cs::host::pow(sh, p.agrp_m[g]);
+            }
+            p.zinv_coset[k] = cs::host::inv(cs::host::sub(cs::host::pow(sh, n), cs::host::ONE));
+            sh = cs::host::mul(sh, wbn);
+        }
+    }
     HIP_TRY(cs::launch_air_combine(p, nk, c->stream));
     return CSTARK_OK;
 }

@@ -54,6 +54,9 @@ struct AirCombineParams {
     const uint32_t *t_grp, *a_grp; // device
     uint32_t n_tgrp, n_agrp;
     uint64_t tgrp_adj[AIR_MAX_GROUPS], agrp_m[AIR_MAX_GROUPS], agrp_zc[AIR_MAX_GROUPS], agrp_badj[AIR_MAX_GROUPS];
+    // powers of a point x = shift_k w_n^j without a square-and-multiply per point: x^e = shift_k^e * w_n^((j e) mod n).  Per LDE coset
+    // k (host-built): shift_k^adj of every transition group, shift_k^badj and shift_k^m of every assertion group, 1 / (shift_k^n - 1)
+    uint64_t tgrp_shift[8][AIR_MAX_GROUPS], agrp_bshift[8][AIR_MAX_GROUPS], agrp_mshift[8][AIR_MAX_GROUPS], zinv_coset[8];
 };
 hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_t stream);
 hipError_t launch_eval_transitions_merkle(const uint64_t *lde, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0, unsigned nk,

@@ -1594,21 +1594,31 @@ __global__ void k_air_combine(AirCombineParams p) {
     const unsigned kk = blockIdx.y, k = p.k0 + kk;
     fp *o = p.out + (size_t)kk * n + j;
     if (k % p.stride) { *o = 0; return; }
-    const fp shift = p.shifts[k];
-    const fp x = fp_mul(shift, p.w[j]);
-    // the degree adjustments take a handful of distinct values, and the assertions share a few divisors: one power /
-    // inversion per group and point, not per constraint
+    const fp x = fp_mul(p.shifts[k], p.w[j]);
+    // The degree adjustments take a handful of distinct values and the assertions share a few divisors: one power per group and
+    // point -- x^e = shift_k^e w_n^((j e) mod n), a table product instead of a square-and-multiply chain -- and ONE inversion per
+    // point for all assertion divisors (Montgomery's trick); 1 / (x^n - 1) is constant over a coset.
+    const size_t mask = n - 1;
     fp xp[AIR_MAX_GROUPS], zi[AIR_MAX_GROUPS], xb[AIR_MAX_GROUPS];
-    for (unsigned g = 0; g < p.n_tgrp; g++) xp[g] = fp_pow(x, p.tgrp_adj[g]);
-    for (unsigned g = 0; g < p.n_agrp; g++) {
-        zi[g] = fp_inv(fp_sub(fp_pow(x, p.agrp_m[g]), p.agrp_zc[g]));
-        xb[g] = fp_pow(x, p.agrp_badj[g]);
+    for (unsigned g = 0; g < p.n_tgrp; g++) xp[g] = fp_mul(p.tgrp_shift[k][g], p.w[(j * p.tgrp_adj[g]) & mask]);
+    {
+        fp den[AIR_MAX_GROUPS], pre[AIR_MAX_GROUPS], run = FP_ONE;
+        for (unsigned g = 0; g < p.n_agrp; g++) {
+            den[g] = fp_sub(fp_mul(p.agrp_mshift[k][g], p.w[(j * p.agrp_m[g]) & mask]), p.agrp_zc[g]);
+            xb[g] = fp_mul(p.agrp_bshift[k][g], p.w[(j * p.agrp_badj[g]) & mask]);
+            pre[g] = run;              // product of the denominators before g
+            run = fp_mul(run, den[g]);
+        }
+        fp inv = fp_inv(run);
+        for (unsigned g = p.n_agrp; g-- > 0;) {
+            zi[g] = fp_mul(inv, pre[g]);
+            inv = fp_mul(inv, den[g]);
+        }
     }
     fp acc = 0;
     for (unsigned i = 0; i < p.n_constraints; i++)
         acc = fp_add(acc, fp_mul(p.evals[((size_t)kk * p.n_constraints + i) * n + j], fp_add(p.t_alpha[i], fp_mul(p.t_beta[i], xp[p.t_grp[i]]))));
-    const fp zinv = fp_mul(fp_sub(x, p.w_last), fp_inv(fp_sub(fp_pow(x, n), FP_ONE)));
-    acc = fp_mul(acc, zinv);
+    acc = fp_mul(acc, fp_mul(fp_sub(x, p.w_last), p.zinv_coset[k]));
     // boundary constraints (single, periodic and sequence assertions): divisor x^m - w^(first*m)
     for (unsigned a = 0; a < p.n_assertions; a++) {
         const unsigned g = p.a_grp[a];

@@ -663,6 +663,17 @@ int tx_combine_sets(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned m, const
     const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]};
     return tx_evaluate_constraints_sets(c, a->lde, cf, m, pub4, outs, job.item, job.log_n, 3, 0, 8, true);
 }
+// Transition evaluations of a sub-AIR on the cosets of its constraint-evaluation domain only: an AIR whose constraints need a blowup
+// 2^log_ce below the LDE blowup 8 (MerkleAir 4, RangeProofAir 2) is evaluated on every (8 >> log_ce)-th coset; the merge
+// (cstark_air_combine) reads nothing else.  evals keeps the [8][n_constraints][n] layout.
+int evaluate_on_ce_cosets(cstark_ctx *c, ProveArena *a, AirJob &job, int air, uint64_t *evals) {
+    const size_t n = (size_t)1 << job.log_n;
+    const uint32_t stride = 8u >> job.log_ce;
+    for (uint32_t k = 0; k < 8; k += stride)
+        RC_TRY(cstark_air_evaluate_transitions(c, air, a->lde + (size_t)k * job.width * n, evals + (size_t)k * job.n_constraints * n, job.item, job.log_n,
+                                               3, k, 1));
+    return CSTARK_OK;
+}
 // ---- MerkleAir (src/merkle/update) ---------------------------------------------------------------------------------------------
 int merkle_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
     RC_TRY(cstark_merkle_build_trace(c, a->trace));
@@ -672,7 +683,7 @@ int merkle_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals;
     RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
-    if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_MERKLE_UPDATE, a->lde, evals, job.item, job.log_n, 3, 0, 8));
+    if (!job.evals_ready) RC_TRY(evaluate_on_ce_cosets(c, a, job, CSTARK_AIR_MERKLE_UPDATE, evals));
     job.evals_ready = true;
     return cstark_air_combine(c, CSTARK_AIR_MERKLE_UPDATE, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, out, job.log_n, 3, 0, 8);
 }
@@ -685,7 +696,7 @@ int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta,
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *evals;
     RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
-    if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RANGE, a->lde, evals, 0, job.log_n, 3, 0, 8));
+    if (!job.evals_ready) RC_TRY(evaluate_on_ce_cosets(c, a, job, CSTARK_AIR_RANGE, evals));
     job.evals_ready = true;
     const uint64_t vals[2] = {0, job.number}; // get_assertions, src/range/air.rs:79-86
     return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, out, job.log_n, 3, 0, 8);

@@ -1,5 +1,6 @@
-"""Times complete proofs of the standalone AIRs at BASELINE.json's sizes (configs 1-3): range (64 rows), merkle 512 transfers
-= 2^18 rows (depth 15 and 31), schnorr 512 signatures = 2^18 rows.  Run on a GPU box."""
+"""Times complete proofs of the standalone AIRs at BASELINE.json's sizes (configs 1-3): range (the reference's 64-row proof, the
+synthetic 2^16-row accumulator, and 1024 64-row proofs back to back), merkle 512 transfers = 2^18 rows (depth 15 and depth 31, the
+nearest legal value to BASELINE's "depth 32"), schnorr 512 signatures = 2^18 rows.  Run on a GPU box."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -21,12 +22,20 @@ def timeit(name, f, reps=5):
 
 
 timeit("range (64 rows)", RangeProofExample(opt, 12345 << 3, b).prove, reps=20)
+words = np.random.default_rng(16).integers(0, 2**64, size=(1 << 16) // 64, dtype=np.uint64)
+words[-1] &= np.uint64(2**63 - 1)
+timeit("range, synthetic 2^16-row accumulator", lambda: b.range_prove_bits(opt, words, 16), reps=10)
+t0 = time.perf_counter()
+for i in range(1024):
+    p = RangeProofExample(opt, (12345 + i) << 3, b).prove()
+dt = time.perf_counter() - t0
+print("%-34s %8.3f ms for 1024 proofs of 64 rows (2^16 rows in total)  %7.1f proofs/s" % ("range, 1024 x 64 rows", dt * 1e3, 1024 / dt))
 full = TransactionMetadata.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "witness_1024_d15.npz"))
 m512 = TransactionMetadata(*[getattr(full, f) if f == "final_root" else getattr(full, f)[:512] for f in TransactionMetadata.FIELDS])
 m512.final_root = full.initial_roots[512].copy()
 timeit("merkle 512 tx, depth 15 (2^18 rows)", MerkleExample(opt, m512, b).prove)
-# depth 31 (the nearest legal value to BASELINE's "depth 32") is supported by the kernels (8*31+7 = 255 <= 511 rows) but the
-# dense host witness generator stops at depth 24; its trace / constraint parity is covered at depths 3, 7, 15.
+m31 = TransactionMetadata.build_random(512, 31, seed=31)  # sparse account tree
+timeit("merkle 512 tx, depth 31 (2^18 rows)", MerkleExample(opt, m31, b).prove)
 t0 = time.perf_counter()
 ex = SchnorrExample.build_random(opt, 512, seed=1, backend=b)
 print("schnorr witness synthesis 512 sigs: %.1f s (host, serial)" % (time.perf_counter() - t0))
