@@ -377,19 +377,22 @@ def main():
         # the transform pair of the low-degree extensions: per evaluation written 8 bytes out + 1/8 coefficient read (blowup 8)
         lde_alg = lde_elements / per * 8 * (1 + 1.0 / (1 << LOG_B))
         lde_pairs = max(1, round(lde_elements / per / (WIDTH * n)))  # in units of "94 columns of one coset"
-        ntt_names = ["k_ntt_cols_v2<5, 5, false>", "k_ntt_rows_v2<5, 5, false>", "k_lde_cols", "k_lde_rows"]
-        roofline_lde = entry("forward transform pair of the low-degree extension (k_ntt_cols_v2 + k_ntt_rows_v2, all LDE calls of a proof: trace 94 "
-                             "columns x 8 cosets, composition 8 x 8, DEEP 1 x 8)", lde_alg, lde_ms / per, ntt_names,
-                             "the dominant kernel family by GPU time; integer-VALU bound (about 350 VALU instructions per element and coset, "
-                             "profiles/*_valu_pmc.csv), priced against the HBM roofline as BASELINE.json asks; kernel_ms = per 94 columns x 1 coset; "
-                             "inside cstark_tx_prove the first two column batches are extended beside the trace recurrences (DESIGN.md 5a)",
+        ntt_names = ["k_ntt_cols_v4<4, 3, 3, false>", "k_ntt_rows_v4<4, 3, 3, false>", "k_ntt_cols_v2<5, 5, false>", "k_ntt_rows_v2<5, 5, false>"]
+        roofline_lde = entry("forward transform pair of the low-degree extension (k_ntt_cols_v4 + k_ntt_rows_v4; all LDE calls of a proof: trace 94 "
+                             "columns x 8 cosets, composition 8 x 8, DEEP 1 x 8; traffic also covers the 56 split-polynomial transforms, same kernels)",
+                             lde_alg, lde_ms / per, ntt_names,
+                             "the dominant kernel family by GPU time: about 350 vector instructions per element and coset at 2-4 issue cycles each "
+                             "(profiles/*_valu_issue_bench.txt) on top of a latency-bound memory skeleton (the same kernels without arithmetic take 72 % of "
+                             "the time, DESIGN.md 5b), priced against the HBM roofline as BASELINE.json asks; kernel_ms = per 94 columns x 1 coset; inside "
+                             "cstark_tx_prove the first two column batches are extended beside the trace recurrences (DESIGN.md 5a)",
                              launches=lde_pairs)
         nb = (8 // world) if coset_mode else 8
         rounds_bytes = (nb // 2) * n * (58 * 8 + 6 * 8) if split else nb * n * (58 * 8 + 8)
         roofline_rounds = entry("k_rounds_split (Rescue windows of the constraint evaluation, even cosets)" if split else
                                 "k_eval_fused<0> (Rescue windows of the constraint evaluation)", rounds_bytes, part_avg["rounds"],
                                 ["k_rounds_split<1>"] if split else ["k_eval_fused<0, 1>"],
-                                "longest single launch; integer-multiplier bound (profiles/*_valu_pmc.csv, *_modmul.txt)")
+                                "longest single launch; bound by vector-instruction issue: 25.9 k instructions per point at 4.1 cycles each "
+                                "(profiles/*_valu_pmc.csv, *_valu_issue_bench.txt)")
         roofline_stages = [roofline_lde, roofline_rounds]
         if args.mode == "prove":
             roofline_stages.append(entry("row hashes + Merkle tree of the trace commitment (k_hash_rows + k_merkle_level/top)", ab["hash_rows"] + ab["merkle"],
