@@ -7,6 +7,13 @@
  *     TransactionExample::prove                    /root/reference/src/lib.rs:116-141
  * would call (the binding a maintainer adds is shown in INTEGRATION.md).
  *
+ * NOT winterfell-compatible: the reference's engine (winterfell fork, Cargo.toml:20) is absent from its tree.  Field conventions, the
+ * Fiat-Shamir coin and the extension polynomials are recalled / assumed (every one a macro in cstark_conventions.h), the channel
+ * order and the proof byte layout are this library's own (documented at cstark_tx_prove).  "Bit-exact" in this header always means:
+ * against the CPU restatement under oracle/, which is pinned by algebraic known answers and hash test vectors, not by a Rust run.
+ * The stage entry points (K1..K6) hand an engine its own objects (LDE values, digests, merged evaluations) and depend on two
+ * conventions only (domain offset / root of unity, byte form of hashed elements).
+ *
  * Conventions
  *  - Field elements cross the ABI as uint64_t holding the in-memory representation of the
  *    reference's `f63::BaseElement`: Montgomery form, R = 2^64, p = 2^62+2^56+2^55+1, reduced to

@@ -28,3 +28,4 @@ void cso_ecc_add(uint64_t *p, const uint64_t *q) { ecc_add(p, q); }
 void cso_ecc_add_mixed(uint64_t *p, const uint64_t *q) { ecc_add_mixed(p, q); }
 
 int cso_num_threads(void) { return omp_get_max_threads(); }
+void cso_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }

@@ -60,6 +60,7 @@ void cso_ntt(uint64_t *a, unsigned log_n);
 void cso_intt(uint64_t *a, unsigned log_n);
 void cso_dft_naive(const uint64_t *a, uint64_t *out, unsigned log_n);
 uint64_t cso_fp_generator(void);
+void cso_set_num_threads(int n);
 void cso_interpolate_columns(uint64_t *cols, uint32_t width, unsigned log_n);
 void cso_lde_columns(const uint64_t *coeffs, uint64_t *lde, uint32_t width, unsigned log_n, unsigned log_b, uint64_t offset,
                      uint32_t k0, uint32_t nk);

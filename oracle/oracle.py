@@ -55,6 +55,11 @@ def lib():
         if not os.path.exists(_SO):
             build()
         _lib = C.CDLL(_SO)
+        # The test-sized calls are tiny parallel regions: on a many-core host (the GPU boxes expose 128-256 hardware threads, shared)
+        # OpenMP's default team turns every one of them into a long spin.  Default to a modest team; OMP_NUM_THREADS or
+        # set_num_threads() (bench.py's cpu_baseline leg: all cores for the one big proof) override it.
+        if "OMP_NUM_THREADS" not in os.environ:
+            _lib.cso_set_num_threads(C.c_int(min(16, os.cpu_count() or 1)))
         _lib.cso_fp_root_of_unity.restype = C.c_uint64
         _lib.cso_fp_generator.restype = C.c_uint64
         _lib.cso_poly_eval.restype = C.c_uint64
@@ -323,6 +328,10 @@ def tx_combined_at(trace_coeffs, coeffs, pub_inputs, depth, log_b, z):
     pub = _u64(pub_inputs)
     return int(lib().cso_tx_combined_at(_p(trace_coeffs), C.byref(coeffs), _p(pub), C.c_uint(depth),
                                         C.c_uint(n.bit_length() - 1), C.c_uint(log_b), C.c_uint64(z)))
+
+
+def set_num_threads(n):
+    lib().cso_set_num_threads(C.c_int(int(n)))
 
 
 def num_threads():
