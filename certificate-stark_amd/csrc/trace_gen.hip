@@ -30,6 +30,9 @@ constexpr unsigned LADDER_LDS_PAD = 0;
 #ifndef CS_RECUR_TILE_ROWS
 #define CS_RECUR_TILE_ROWS 16 // staging rows of the Merkle / message-hash recurrences in the overlapped path
 #endif
+#ifndef CS_RECUR_PRIO
+#define CS_RECUR_PRIO 3 // wave priority of the latency-bound recurrences (0..3)
+#endif
 constexpr int SCALAR_MUL_LEN = 510; // src/schnorr/constants.rs:30
 
 // One Rescue round on a 14-element state held one element per lane (rescue.rs:246-263).
@@ -80,7 +83,7 @@ __device__ __forceinline__ void flush_rows(const fp (*tile)[LD], fp *__restrict_
 // LDS (a 64-row tile is 33 KB: four resident recurrences per CU leave no room for a 75 KB transform workgroup)
 template <bool STANDALONE, int TR>
 __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
-    __builtin_amdgcn_s_setprio(3); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
+    __builtin_amdgcn_s_setprio(CS_RECUR_PRIO); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
     __shared__ fp tile[TR][65];
     __shared__ fp st[4][14];
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(64) void k_trace_merkle(TxWitnessDev w, fp *__restr
 // ---------------------------------------------------------------------------------------------------
 template <bool STANDALONE, int TR>
 __global__ __launch_bounds__(64) void k_trace_schnorr_hash(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
-    __builtin_amdgcn_s_setprio(3); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
+    __builtin_amdgcn_s_setprio(CS_RECUR_PRIO); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
     __shared__ fp tile[TR][15];
     __shared__ fp st[14];
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -365,7 +368,7 @@ __device__ __forceinline__ int bit_le(const uint8_t *bytes, int i) { return (byt
 // ladders run beside the interpolation / extension of the other registers (prove.hip commit_columns: 43.1 vs 43.8 ms per proof).
 template <bool STANDALONE, int TR>
 __global__ __launch_bounds__(64) void k_trace_schnorr_ec(TxWitnessDev w, fp *__restrict__ trace, size_t n) {
-    __builtin_amdgcn_s_setprio(3); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
+    __builtin_amdgcn_s_setprio(CS_RECUR_PRIO); // latency-bound recurrence: issue ahead of the chip-filling kernels it runs beside
     constexpr int TG = 64 / TR; // column groups of a flush
     __shared__ fp tile[TR][19];
     __shared__ fp slots[NSLOT][6];
