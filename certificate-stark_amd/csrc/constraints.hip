@@ -1518,6 +1518,10 @@ __global__ __launch_bounds__(NT) void k_eval_transitions_merkle(const fp *lde, c
 }
 // SchnorrAir::evaluate_transition  src/schnorr/air.rs:68-109 -> evaluate_constraints :394-531.
 // lde: [nk][56][n]; aux: [nk][19][n] (LDE of pkey x12 and message-chunk x7 columns); ptab: [b][36][512] (8 masks, 28 ark)
+// PART: 0 = double-and-add step of s*G (slots 0..18), 1 = of h*P (19..37), 2 = limb accumulators, Rescue round, hash copies, 3 = final
+// addition.  One kernel for everything needs 450 VGPRs (one wave per SIMD); the parts accumulate into the zero-filled output one after
+// the other on the stream.
+template <int PART>
 __global__ __launch_bounds__(NT) void k_eval_transitions_schnorr(const fp *lde, const fp *aux, const fp *ptab, fp *out, unsigned log_n, unsigned k0) {
     const size_t n = (size_t)1 << log_n;
     const size_t j = blockIdx.x * (size_t)NT + threadIdx.x;
@@ -1537,28 +1541,32 @@ __global__ __launch_bounds__(NT) void k_eval_transitions_schnorr(const fp *lde, 
     const fp copy_hash = fp_mul(c_not(hash_flag), global_mask);
     const fp final_add = fp_mul(c_not(scalar_mult), global_mask);
     const fp addition = fp_mul(c_not(doubling), scalar_mult);
-    {
+    if constexpr (PART == 0) {
         const Fp6 gx = const6(c_generator), gy = const6(c_generator + 6);
         enforce_scalar_mult_step(acc, f, 0, gx, gy, doubling, addition);
+    }
+    if constexpr (PART == 1) {
         const Fp6 px = fp6_load_strided(ax, n), py = fp6_load_strided(ax + 6 * n, n); // periodic pkey columns
         enforce_scalar_mult_step(acc, f, 19, px, py, doubling, addition);
     }
+    if constexpr (PART == 2) {
 #pragma unroll 1
-    for (int i = 0; i < 4; i++) {
-        const fp dflag = f.pv(3 + i);
-        const fp c = f.cur(41 - i), nx = f.next(41 - i);
-        acc.add(41 - i, fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37))));
-        acc.add(41 - i, fp_mul(c_not(dflag), doubling), fp_sub(c, nx));
-        acc.add(38 + i, addition, fp_sub(f.cur(38 + i), f.next(38 + i)));
-        acc.add(38 + i, final_add, fp_sub(f.cur(38 + i), f.cur(42 + i)));
-    }
-    enforce_round(acc, fr, 42, 42, hash_flag, 0, 0, false);
+        for (int i = 0; i < 4; i++) {
+            const fp dflag = f.pv(3 + i);
+            const fp c = f.cur(41 - i), nx = f.next(41 - i);
+            acc.add(41 - i, fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37))));
+            acc.add(41 - i, fp_mul(c_not(dflag), doubling), fp_sub(c, nx));
+            acc.add(38 + i, addition, fp_sub(f.cur(38 + i), f.next(38 + i)));
+            acc.add(38 + i, final_add, fp_sub(f.cur(38 + i), f.cur(42 + i)));
+        }
+        enforce_round(acc, fr, 42, 42, hash_flag, 0, 0, false);
 #pragma unroll 1
-    for (int i = 0; i < 7; i++) {
-        acc.add(42 + i, copy_hash, fp_sub(f.cur(42 + i), f.next(42 + i)));
-        acc.add(49 + i, copy_hash, fp_sub(f.next(49 + i), ax[(size_t)(12 + i) * n]));
+        for (int i = 0; i < 7; i++) {
+            acc.add(42 + i, copy_hash, fp_sub(f.cur(42 + i), f.next(42 + i)));
+            acc.add(49 + i, copy_hash, fp_sub(f.next(49 + i), ax[(size_t)(12 + i) * n]));
+        }
     }
-    {
+    if constexpr (PART == 3) {
         const Point s = {load6(f, 0, false), load6(f, 6, false), load6(f, 12, false)};
         const Point hp = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
         const Point r = ec_add<true>(s, hp);
@@ -1652,7 +1660,10 @@ hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *
     const size_t n = (size_t)1 << log_n;
     hipError_t e = hipMemsetAsync(out, 0, (size_t)nk * 56 * n * sizeof(fp), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_eval_transitions_schnorr, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, aux, ptab, out, log_n, k0);
+    hipLaunchKernelGGL(k_eval_transitions_schnorr<0>, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, aux, ptab, out, log_n, k0);
+    hipLaunchKernelGGL(k_eval_transitions_schnorr<1>, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, aux, ptab, out, log_n, k0);
+    hipLaunchKernelGGL(k_eval_transitions_schnorr<2>, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, aux, ptab, out, log_n, k0);
+    hipLaunchKernelGGL(k_eval_transitions_schnorr<3>, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, aux, ptab, out, log_n, k0);
     return hipGetLastError();
 }
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream) {

@@ -19,7 +19,6 @@
 #include <vector>
 #include "../../include/cstark.h"
 #include "ctx.h"
-#include "blake3.h"
 #include "hostblake3.h"
 #include "keccak.cuh"
 #include "air_tx_host.h"
@@ -43,7 +42,6 @@ struct ProveArena {
     uint64_t *h_pub = nullptr; // pinned
     size_t open_bytes = 0;
     hipEvent_t ev[PROVE_EVENTS] = {};
-    hipEvent_t ev_coset[9] = {}; // extension of coset k complete (main stream) / all row hashes complete (side stream)
     bool timed = false;
     std::vector<void *> owned;
     struct ProofRun *run = nullptr; // a proof in progress between the phases of the sharded entry points (cstark_tx_shard_*)
@@ -56,7 +54,6 @@ void prove_arena_free(ProveArena *a) {
     for (void *p : a->owned) (void)hipFree(p);
     if (a->h_pub) (void)hipHostFree(a->h_pub);
     for (hipEvent_t e : a->ev) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : a->ev_coset) if (e) (void)hipEventDestroy(e);
     delete a;
 }
 
@@ -264,7 +261,6 @@ int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned n_layer
     const size_t per_q = W * 8 + ce * 8 + 2 * log_N * 32 + (size_t)n_layers * (32 + log_N * 32);
     RC_TRY(dev_alloc(a, &a->d_open, per_q * nq + 256));
     for (hipEvent_t &e : a->ev) HIP_TRY(hipEventCreate(&e));
-    for (hipEvent_t &e : a->ev_coset) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     *out = a;
     return CSTARK_OK;
 }
@@ -287,36 +283,13 @@ int check_options(const cstark_options *opt, unsigned *log_rem_out) {
 // interpolation, after the extension).  With column batches (AirJob::batches) the complete columns go first -- interpolated AND
 // extended while the internal streams still write the later ones -- so the "interpolate" stage time then also holds the extension
 // of the earlier batches.
-// hash_leaves: the row hashes of the trace commitment (leaves of a->tnodes) are part of this stage -- the extension of the last column
-// batch goes coset by coset on the caller's stream and each coset's rows are hashed on an internal stream as soon as they are
-// complete.  The transforms leave about half of the vector-issue slots idle (latency-bound) and the row hashes are pure
-// 32-bit ARX work without LDS: side by side the hashes of cosets 0..6 disappear behind the transforms of cosets 1..7.
-int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hipStream_t st, int &evi, bool hash_leaves, uint32_t hash_fn) {
+int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hipStream_t st, int &evi) {
     const uint32_t W = job.width, log_n = job.log_n;
-    const size_t n = (size_t)1 << log_n, N = n << log_b;
-    static const bool overlap_env = [] { const char *e = getenv("CSTARK_HASH_OVERLAP"); return !e || atoi(e) != 0; }(); // tuning / debugging
-    auto extend = [&](uint32_t col0, uint32_t ncols, bool last) -> int {
-        const bool overlap = hash_leaves && last && overlap_env && job.nk == 8 && (size_t)8 * ncols * n * 8 > ((size_t)1 << 30); // (wide tables: one launch pair per coset anyway)
-        if (!overlap) {
-            RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, col0, ncols, log_n, log_b, host::lde_offset(), job.k0, job.nk));
-            if (hash_leaves && last) RC_TRY(cstark_hash_rows_fn(c, hash_fn, a->lde, a->tnodes + 32 * N, W, log_n, log_b, 0, 8));
-            return CSTARK_OK;
-        }
-        for (uint32_t k = 0; k < 8; k++) {
-            RC_TRY(lde_column_range(c, a->coeffs, a->lde + (size_t)k * W * n, W, col0, ncols, log_n, log_b, host::lde_offset(), k, 1));
-            HIP_TRY(hipEventRecord(a->ev_coset[k], st));
-            HIP_TRY(hipStreamWaitEvent(c->side, a->ev_coset[k], 0));
-            if (hash_fn == 1) HIP_TRY(hash_rows_sha3(a->lde + (size_t)k * W * n, a->tnodes + 32 * N, W, log_n, log_b, k, 1, c->side));
-            else HIP_TRY(hash_rows(a->lde + (size_t)k * W * n, a->tnodes + 32 * N, W, log_n, log_b, k, 1, c->side));
-        }
-        HIP_TRY(hipEventRecord(a->ev_coset[8], c->side));
-        HIP_TRY(hipStreamWaitEvent(st, a->ev_coset[8], 0));
-        return CSTARK_OK;
-    };
+    const size_t n = (size_t)1 << log_n;
     if (job.batches.empty()) {
         RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, W, log_n));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
-        RC_TRY(extend(0, W, true));
+        RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, W, log_n, log_b, host::lde_offset(), job.k0, job.nk));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
         return CSTARK_OK;
     }
@@ -326,7 +299,7 @@ int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hi
             if (e) HIP_TRY(hipStreamWaitEvent(st, e, 0));
         RC_TRY(cstark_interpolate_columns(c, a->trace + (size_t)cb.col0 * n, a->coeffs + (size_t)cb.col0 * n, cb.ncols, log_n));
         if (i + 1 == job.batches.size()) HIP_TRY(hipEventRecord(a->ev[evi++], st));
-        RC_TRY(extend(cb.col0, cb.ncols, i + 1 == job.batches.size()));
+        RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, cb.col0, cb.ncols, log_n, log_b, host::lde_offset(), job.k0, job.nk));
     }
     HIP_TRY(hipEventRecord(a->ev[evi++], st));
     return CSTARK_OK;
@@ -369,9 +342,11 @@ int phase_commit(cstark_ctx *c, ProveArena *a, ProofRun &R, uint8_t *d_leaves_lo
     STAGE();
     RC_TRY(job.build(c, a, job));
     STAGE();
+    RC_TRY(commit_columns(c, a, job, log_b, st, R.evi));
     const uint32_t hf = R.opt.hash_fn;
-    RC_TRY(commit_columns(c, a, job, log_b, st, R.evi, !R.sharded(), hf)); // unsharded: the leaves of the trace tree are written here
-    if (R.sharded()) {
+    if (!R.sharded()) {
+        RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, 8));
+    } else {
         for (uint32_t i = 0; i < job.nk; i++) // a coset alone is a blowup-1 domain: leaf j of the call = row j of the coset
             RC_TRY(cstark_hash_rows_fn(c, hf, a->lde + (size_t)i * W * n, d_leaves_local + (size_t)i * n * 32, (uint32_t)W, log_n, 0, 0, 1));
     }
@@ -793,7 +768,8 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     STAGE();
     RC_TRY(job.build(c, a, job));
     STAGE();
-    RC_TRY(commit_columns(c, a, job, log_b, st, evi, true, hf));
+    RC_TRY(commit_columns(c, a, job, log_b, st, evi));
+    RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
     uint8_t trace_root[32], cons_root[32];
     HIP_TRY(hipMemcpyAsync(trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
