@@ -964,7 +964,10 @@ struct SplitAcc {
 // out = [3 (2 for the quartic half above)][4 even cosets][n] of this flag's family; ACCUMULATE: add to what an earlier part of the same
 // family wrote.  grid = (n / FNT, 4)
 template <int PART, bool ACCUMULATE, int M>
-__global__ __launch_bounds__(FNT, 2) void k_ec_split(CeParams p, fp *__restrict__ out, fp *__restrict__ out_linear) {
+#ifndef CS_EC_WAVES
+#define CS_EC_WAVES 2
+#endif
+__global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_ec_split(CeParams p, fp *__restrict__ out, fp *__restrict__ out_linear) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kc = blockIdx.y;
