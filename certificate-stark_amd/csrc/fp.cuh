@@ -31,21 +31,44 @@ __device__ __forceinline__ fp fp_reduce_once(uint64_t r) { return r >= FP_P ? r 
 __device__ __forceinline__ fp fp_add(fp a, fp b) { return fp_reduce_once(a + b); } // a + b < 2^64
 __device__ __forceinline__ fp fp_sub(fp a, fp b) { return a >= b ? a - b : a + (FP_P - b); }
 __device__ __forceinline__ fp fp_neg(fp a) { return a ? FP_P - a : 0; }
+// a - b + p in (0, 2p): admissible as the FIRST factor of fp_mul / fp_mul_lazy (12 instead of 20 issue cycles)
+__device__ __forceinline__ uint64_t fp_sub_lazy(fp a, fp b) { return a + FP_P - b; }
 __device__ __forceinline__ fp fp_dbl(fp a) { return fp_reduce_once(a << 1); }
+
+// A register holding 1 that the compiler cannot see through: x * one + c stays ONE v_mad_u64_u32 (4 issue cycles) where the
+// compiler's own form of "64-bit value + zero-extended 32-bit word" is two moves and a v_lshl_add_u64 (8 cycles).  The barrier
+// macro stops the reassociation pass from pulling such a chain apart again; neither emits an instruction in the loop.
+__device__ __forceinline__ uint32_t fp_opaque_one() {
+    uint32_t v;
+    asm("v_mov_b32 %0, 1" : "=v"(v));
+    return v;
+}
+#define CS_KEEP(x) asm("" : "+v"(x))
 
 // Montgomery product without the final conditional subtraction: result in (0, 2p) for a < 2p, b < p.
 // Word-serial REDC with q = 2^32 - t0 (never 0): (T + q p) / 2^32 = (T >> 32) + q P1 + 1 exactly, and
 // q P1 + 1 = ~t0 * P1 + (P1 + 1), so a reduction step is one NOT folded into one v_mad_u64_u32 whose addend
-// carries the constant -- no carry bit to materialise.  (q = 2^32 when t0 = 0 merely adds p.)
+// carries the constant K = P1 + 1 -- no carry bit to materialise.  (q = 2^32 when t0 = 0 merely adds p.)
+// Eight v_mad_u64_u32, two NOTs, one move and one 32-bit add: K joins the first step through (t >> 32) * 1 + K, the second
+// as the 32-bit sum (w >> 32) + K (w < 2^32 b1 + 2^32 with b1 < 2^30.1, so the sum stays below 2^32), and v >> 32 enters
+// through a multiply by one.  52 issue cycles with the conditional subtraction instead of 60 (tools/isa_mix.py).
 __device__ __forceinline__ uint64_t fp_mul_lazy(uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
     const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     constexpr uint64_t K = (uint64_t)FP_P1 + 1;
+    const uint32_t one = fp_opaque_one();
     const uint64_t t = (uint64_t)a0 * b0;
-    const uint64_t u = mad_u64_u32(a1, b0, (t >> 32) + K);
-    const uint64_t v = mad_u64_u32(~(uint32_t)t, FP_P1, u);        // (a * b0 + q p) / 2^32  < 2^63.6
+    uint64_t s = mad_u64_u32((uint32_t)(t >> 32), one, K);
+    CS_KEEP(s);
+    uint64_t u = mad_u64_u32(a1, b0, s);
+    CS_KEEP(u);
+    const uint64_t v = mad_u64_u32(~(uint32_t)t, FP_P1, u);        // (a * b0 + q p) / 2^32  < 2^63.7
     const uint64_t w = mad_u64_u32(a0, b1, (uint32_t)v);
-    const uint64_t x = mad_u64_u32(a1, b1, (w >> 32) + (v >> 32) + K);
+    const uint32_t c = (uint32_t)(w >> 32) + (uint32_t)K;
+    uint64_t x = mad_u64_u32(a1, b1, c);
+    CS_KEEP(x);
+    x = mad_u64_u32((uint32_t)(v >> 32), one, x);
+    CS_KEEP(x);
     return mad_u64_u32(~(uint32_t)w, FP_P1, x);                     // < a1 b1 + 2^33 + p < 2p
 }
 __device__ __forceinline__ fp fp_mul(fp a, fp b) { return fp_reduce_once(fp_mul_lazy(a, b)); }
@@ -114,17 +137,21 @@ struct Acc128 {
 
 __device__ __forceinline__ Acc128 acc_zero() { return {0, 0}; }
 
-// acc += a * b  (full 128-bit product, no reduction)
+// acc += a * b for REDUCED a, b (full 128-bit product, no reduction).  The two middle carries t1 >> 32 and t2 >> 32 are below
+// 2^30.1 each for reduced operands, so they are added in 32 bits; the accumulation is one four-word carry chain.
 __device__ __forceinline__ void acc_mad(Acc128 &acc, uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     const uint64_t t0 = (uint64_t)a0 * b0;
     const uint64_t t1 = mad_u64_u32(a1, b0, t0 >> 32);
     const uint64_t t2 = mad_u64_u32(a0, b1, (uint32_t)t1);
-    const uint64_t t3 = mad_u64_u32(a1, b1, (t1 >> 32) + (t2 >> 32));
-    const uint64_t plo = (t2 << 32) | (uint32_t)t0;
-    const uint64_t lo = acc.lo + plo;
-    acc.hi += t3 + (lo < plo);
-    acc.lo = lo;
+    const uint64_t t3 = mad_u64_u32(a1, b1, (uint32_t)((uint32_t)(t1 >> 32) + (uint32_t)(t2 >> 32)));
+    unsigned cy;
+    const uint32_t l0 = __builtin_addc((uint32_t)acc.lo, (uint32_t)t0, 0u, &cy);
+    const uint32_t l1 = __builtin_addc((uint32_t)(acc.lo >> 32), (uint32_t)t2, cy, &cy);
+    const uint32_t h0 = __builtin_addc((uint32_t)acc.hi, (uint32_t)t3, cy, &cy);
+    const uint32_t h1 = __builtin_addc((uint32_t)(acc.hi >> 32), (uint32_t)(t3 >> 32), cy, &cy);
+    acc.lo = ((uint64_t)l1 << 32) | l0;
+    acc.hi = ((uint64_t)h1 << 32) | h0;
 }
 // keep the value (mod p * 2^64 multiples are free: they vanish after reduction) below 2p * 2^64
 __device__ __forceinline__ void acc_fold(Acc128 &acc) {

@@ -43,7 +43,7 @@ __device__ __forceinline__ void lds_ntt_dif(fp *tile, unsigned log_m, const fp *
             const unsigned i0 = ((q >> hbits) << (hbits + 1)) + j, i1 = i0 + half;
             const fp u = tile[i0 * L + l], v = tile[i1 * L + l];
             tile[i0 * L + l] = fp_add(u, v);
-            tile[i1 * L + l] = fp_mul(fp_sub(u, v), tw[j << s]);
+            tile[i1 * L + l] = fp_mul(fp_sub_lazy(u, v), tw[j << s]);
         }
         __syncthreads();
     }
@@ -160,8 +160,7 @@ __device__ __forceinline__ void reg_ntt_dif(fp (&x)[1 << LOG]) {
                 const int i0 = blk * 2 * half + j, i1 = i0 + half;
                 const fp u = x[i0], v = x[i1];
                 x[i0] = fp_add(u, v);
-                const fp t = fp_sub(u, v);
-                x[i1] = (j == 0) ? t : fp_mul(t, tw.v[j << s]);
+                x[i1] = (j == 0) ? fp_sub(u, v) : fp_mul(fp_sub_lazy(u, v), tw.v[j << s]); // the product takes a first factor < 2p
             }
         }
     }

@@ -21,21 +21,32 @@ __device__ __forceinline__ Fp2 fp2_neg(Fp2 x) { return {fp_neg(x.a), fp_neg(x.b)
 // and the linear steps are plain 128-bit additions.  Same field values as the reference's form (ecc.rs:424-439).
 #ifndef CS_FP2_EAGER
 typedef unsigned __int128 u128_t;
-__device__ __forceinline__ u128_t mul_wide(uint64_t a, uint64_t b) { // full 128-bit product, four v_mad_u64_u32
+// full 128-bit product, four v_mad_u64_u32.  REDUCED: both operands < p, so the two middle carries fit a 32-bit sum; otherwise
+// (operand sums < 2p) the second one enters through a multiply by one (fp.cuh).
+template <bool REDUCED>
+__device__ __forceinline__ u128_t mul_wide(uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     const uint64_t t0 = (uint64_t)a0 * b0;
     const uint64_t t1 = mad_u64_u32(a1, b0, t0 >> 32);
     const uint64_t t2 = mad_u64_u32(a0, b1, (uint32_t)t1);
-    const uint64_t t3 = mad_u64_u32(a1, b1, (t1 >> 32) + (t2 >> 32));
+    uint64_t t3;
+    if (REDUCED) {
+        t3 = mad_u64_u32(a1, b1, (uint32_t)((uint32_t)(t1 >> 32) + (uint32_t)(t2 >> 32)));
+    } else {
+        t3 = mad_u64_u32(a1, b1, t1 >> 32);
+        CS_KEEP(t3);
+        t3 = mad_u64_u32((uint32_t)(t2 >> 32), fp_opaque_one(), t3);
+        CS_KEEP(t3);
+    }
     return ((u128_t)t3 << 64) | ((t2 << 32) | (uint32_t)t0);
 }
 __device__ __forceinline__ fp reduce_wide(u128_t v) { return acc_reduce(Acc128{(uint64_t)v, (uint64_t)(v >> 64)}); } // v < 2p 2^64
 __device__ __forceinline__ Fp2 fp2_mul(Fp2 x, Fp2 y) {
-    const u128_t v0 = mul_wide(x.a, y.a), v1 = mul_wide(x.b, y.b), v2 = mul_wide(x.a + x.b, y.a + y.b);
+    const u128_t v0 = mul_wide<true>(x.a, y.a), v1 = mul_wide<true>(x.b, y.b), v2 = mul_wide<false>(x.a + x.b, y.a + y.b);
     return {reduce_wide(v0 + (v1 << 1)), reduce_wide(v2 - v0 + v1)};
 }
 __device__ __forceinline__ Fp2 fp2_sqr(Fp2 x) {
-    const u128_t v0 = mul_wide(x.a, x.a), v1 = mul_wide(x.b, x.b), v2 = mul_wide(x.a + x.b, x.a + x.b);
+    const u128_t v0 = mul_wide<true>(x.a, x.a), v1 = mul_wide<true>(x.b, x.b), v2 = mul_wide<false>(x.a + x.b, x.a + x.b);
     return {reduce_wide(v0 + (v1 << 1)), reduce_wide(v2 - v0 + v1)};
 }
 #else
