@@ -53,6 +53,14 @@ int get_plan(cstark_ctx *c, unsigned log_n, const NttPlan **out) {
     HIP_TRY(cs::ntt_power_table(p.w, n, w, c->stream));
     HIP_TRY(cs::ntt_power_table(p.winv, n, cs::host::inv(w), c->stream));
     p.n_inv = cs::host::inv(cs::host::from_u64(n));
+    cs::NttV4Shape shape;
+    if (cs::ntt_v4_shape(log_n, &shape)) {
+        const size_t words = cs::ntt_aux_plan_words(shape);
+        HIP_TRY(g.alloc(&p.aux_w, words * 8));
+        HIP_TRY(g.alloc(&p.aux_winv, words * 8));
+        HIP_TRY(cs::ntt_build_aux_plan(p.aux_w, p.w, shape, c->stream));
+        HIP_TRY(cs::ntt_build_aux_plan(p.aux_winv, p.winv, shape, c->stream));
+    }
     c->plans.push_back(p);
     g.release();
     *out = &c->plans.back();
@@ -71,6 +79,14 @@ int get_coset_table(cstark_ctx *c, unsigned log_n, unsigned log_b, uint64_t offs
     for (size_t k = 0; k < b; k++) {
         HIP_TRY(cs::ntt_power_table(t.s + k * n, n, shift, c->stream));
         shift = cs::host::mul(shift, wbn);
+    }
+    cs::NttV4Shape shape;
+    if (cs::ntt_v4_shape(log_n, &shape)) {
+        const NttPlan *p;
+        RC_TRY(get_plan(c, log_n, &p));
+        t.aux_words = cs::ntt_aux_coset_words(shape);
+        HIP_TRY(g.alloc(&t.aux, b * t.aux_words * 8));
+        for (size_t k = 0; k < b; k++) HIP_TRY(cs::ntt_build_aux_coset(t.aux + k * t.aux_words, p->w, t.s + k * n, shape, c->stream));
     }
     c->cosets.push_back(t);
     g.release();
@@ -96,7 +112,7 @@ int interpolate_impl(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint3
     cs::NttArgs a{};
     a.in = d_evals; a.scratch = d_evals; a.out = d_coeffs;
     a.width = width; a.batch = 1; a.log_n = log_n;
-    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true; a.inverse = true;
+    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true; a.inverse = true; a.aux = p->aux_winv;
     HIP_TRY(cs::ntt_columns(a, c->stream));
     return CSTARK_OK;
 }
@@ -152,6 +168,7 @@ int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uin
         a.in = d_coeffs + (size_t)col0 * n; a.scratch = (uint64_t *)c->ws; a.out = d_lde + (size_t)col0 * n;
         a.width = ncols; a.batch = nk; a.log_n = log_n;
         a.w = p->w; a.prescale = t->s + (size_t)k0 * n; a.prescale_batch_stride = n; a.do_scale = false;
+        a.aux = p->aux_w; a.aux_ps = t->aux ? t->aux + (size_t)k0 * t->aux_words : nullptr; a.aux_ps_batch_stride = t->aux_words;
         a.in_batch_stride = 0; a.scratch_batch_stride = (size_t)ncols * n; a.out_batch_stride = (size_t)width * n;
         HIP_TRY(cs::ntt_columns(a, c->stream));
         return CSTARK_OK;
@@ -163,6 +180,7 @@ int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uin
             a.in = d_coeffs + (size_t)g0 * n; a.scratch = (uint64_t *)c->ws; a.out = d_lde + ((size_t)(k - k0) * width + g0) * n;
             a.width = gw; a.batch = 1; a.log_n = log_n;
             a.w = p->w; a.prescale = t->s + (size_t)k * n; a.do_scale = false;
+            a.aux = p->aux_w; a.aux_ps = t->aux ? t->aux + (size_t)k * t->aux_words : nullptr;
             HIP_TRY(cs::ntt_columns(a, c->stream));
         }
     }
@@ -283,8 +301,8 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     if (c->wit_buf) (void)hipFree(c->wit_buf);
     if (c->ws) (void)hipFree(c->ws);
     if (c->coef_buf) (void)hipFree(c->coef_buf);
-    for (NttPlan &p : c->plans) { (void)hipFree(p.w); (void)hipFree(p.winv); }
-    for (CosetTable &t : c->cosets) (void)hipFree(t.s);
+    for (NttPlan &p : c->plans) { (void)hipFree(p.w); (void)hipFree(p.winv); (void)hipFree(p.aux_w); (void)hipFree(p.aux_winv); }
+    for (CosetTable &t : c->cosets) { (void)hipFree(t.s); (void)hipFree(t.aux); }
     for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); (void)hipFree(t.binv); }
     for (PeriodicTable &t : c->small_periodic) (void)hipFree(t.tab);
     if (c->desc_buf) (void)hipFree(c->desc_buf);
@@ -408,7 +426,7 @@ int cstark_composition_columns(cstark_ctx *c, const uint64_t *d_combined, uint64
         RC_TRY(get_plan(c, log_n + log_blowup, &pN));
         cs::NttArgs a{};
         a.in = d_combined; a.scratch = h; a.out = nat; a.width = 1u << log_blowup; a.batch = 1; a.log_n = log_n;
-        a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true;
+        a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true; a.aux = pn->aux_winv;
         HIP_TRY(cs::ntt_columns(a, c->stream));
         const uint64_t b_inv = cs::host::inv(cs::host::from_u64(1ull << log_blowup));
         HIP_TRY(cs::coset_combine(nat, h, log_n, log_blowup, pN->winv, b_inv, c->stream));
@@ -421,7 +439,7 @@ int cstark_composition_columns(cstark_ctx *c, const uint64_t *d_combined, uint64
     RC_TRY(get_plan(c, log_n + log_blowup, &p));
     cs::NttArgs a{};
     a.in = nat; a.scratch = nat; a.out = h; a.width = 1; a.batch = 1; a.log_n = log_n + log_blowup;
-    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true; a.inverse = true;
+    a.w = p->winv; a.post_scale = p->n_inv; a.do_scale = true; a.inverse = true; a.aux = p->aux_winv;
     HIP_TRY(cs::ntt_columns(a, c->stream));
     HIP_TRY(cs::split_columns(h, d_cols, log_n, log_blowup, cs::host::inv(cs::host::lde_offset()), c->stream));
     return CSTARK_OK;
@@ -715,13 +733,14 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         }
         cs::NttArgs a{};
         a.in = even; a.scratch = sa; a.out = sb; a.width = 4 * T; a.batch = 1; a.log_n = log_n; // every polynomial on every even coset
-        a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true;
+        a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true; a.aux = pn->aux_winv;
         HIP_TRY(cs::ntt_columns(a, c->stream));
         // interpolants of the even cosets -> inputs of the odd cosets' transforms (the 4n coefficients are never written)
         HIP_TRY(cs::coset_even_to_odd(sb, sa, log_n, T, p4->winv, p8->w, cs::host::inv(cs::host::from_u64(4)), c->stream)); // sa = [4 odd cosets][T][n]
         cs::NttArgs f{};
         f.in = sa; f.scratch = sc; f.out = odd; f.width = T; f.batch = 4; f.log_n = log_n;
         f.w = pn->w; f.prescale = t1->s + n; f.prescale_batch_stride = 2 * n; f.do_scale = false; f.inverse = false;
+        f.aux = pn->aux_w; f.aux_ps = t1->aux ? t1->aux + t1->aux_words : nullptr; f.aux_ps_batch_stride = 2 * t1->aux_words;
         f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
         HIP_TRY(cs::ntt_columns(f, c->stream));
         HIP_TRY(cs::launch_split_finish(p, even, odd, c->stream));

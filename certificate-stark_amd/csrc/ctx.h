@@ -32,11 +32,14 @@ struct NttPlan {
     unsigned log_n;
     uint64_t *w, *winv; // [n] each: powers of w_n and of its inverse
     uint64_t n_inv;
+    uint64_t *aux_w = nullptr, *aux_winv = nullptr; // compact tables of the three-step kernels (ntt.h), null for other sizes
 };
 struct CosetTable {
     unsigned log_n, log_b;
     uint64_t offset;
     uint64_t *s; // [b][n]: (offset * w_{bn}^k)^m
+    uint64_t *aux = nullptr; // [b][aux_words]: compact prescale / output-factor tables per coset (ntt.h), null for other sizes
+    size_t aux_words = 0;
 };
 struct PeriodicTable {
     unsigned depth, log_n, log_b;

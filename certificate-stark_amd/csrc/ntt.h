@@ -21,7 +21,20 @@ struct NttArgs {
     bool do_scale;
     bool inverse;              // w is the inverse table (selects the compile-time twiddles of the register kernels)
     size_t in_batch_stride, scratch_batch_stride, out_batch_stride; // in elements
+    // optional compact tables of the three-step kernels (ntt_build_aux_*): of `w`, and per batch of `prescale`
+    const uint64_t *aux = nullptr, *aux_ps = nullptr;
+    size_t aux_ps_batch_stride = 0;
 };
+
+// Shape of the three-step kernels for a size (false: the size runs on other kernels and takes no compact tables):
+// column pass over 2^log_r points, row pass over 2^log_c, output factors tabulated for 2^log_kb row classes.
+struct NttV4Shape { unsigned log_r, log_c, log_kb; };
+bool ntt_v4_shape(unsigned log_n, NttV4Shape *s);
+size_t ntt_aux_plan_words(const NttV4Shape &s);
+size_t ntt_aux_coset_words(const NttV4Shape &s);
+// d_w: the n-entry power table of the plan (forward or inverse); d_s: one coset's n-entry prescale table (powers of its shift)
+hipError_t ntt_build_aux_plan(uint64_t *d_aux, const uint64_t *d_w, const NttV4Shape &s, hipStream_t stream);
+hipError_t ntt_build_aux_coset(uint64_t *d_aux, const uint64_t *d_w, const uint64_t *d_s, const NttV4Shape &s, hipStream_t stream);
 
 hipError_t ntt_columns(const NttArgs &a, hipStream_t stream);
 // table[e] = base^e, e < n

@@ -342,7 +342,8 @@ constexpr int V4_TILES = CS_NTT_TILES;
 // stores.  t, l: this thread's position; kb-dependent factors from w / ps as in the v2 kernel.
 template <int LA, int LB, int LC, bool INV>
 __device__ __forceinline__ void cols_v4_finish(fp *tile, const fp *tw, const fp *__restrict__ w, const fp *__restrict__ ps, fp *__restrict__ dst,
-                                               unsigned log_c, unsigned c, unsigned t, unsigned l) {
+                                               unsigned log_c, unsigned c, unsigned t, unsigned l, const fp *__restrict__ outf,
+                                               const fp *__restrict__ ratio_tab) {
     using G = V4<LA, LB, LC>;
     constexpr int A = G::A, Bn = G::Bn, Cn = G::Cn, T = G::T;
     fp z[G::J2][Bn];
@@ -374,9 +375,15 @@ __device__ __forceinline__ void cols_v4_finish(fp *tile, const fp *tw, const fp 
         reg_ntt_dif<LC, INV>(x);
         // output factor shift^c w_n^(k c), k = (k1 + A k2) + A Bn k3: a geometric sequence in k3 with ratio w_n^(A Bn c)
         const unsigned kb = k1 + A * k2;
-        fp g = w[(size_t)kb * c];
-        if (ps) g = fp_mul(g, ps[c]);
-        const fp ratio = w[(size_t)(A * Bn) * c];
+        fp g, ratio;
+        if (outf) { // compact tables (ntt_build_aux_*): one 64-byte segment per (kb, tile) instead of 8 scattered sectors
+            g = outf[((size_t)kb << log_c) + c];
+            ratio = ratio_tab[c];
+        } else {
+            g = w[(size_t)kb * c];
+            if (ps) g = fp_mul(g, ps[c]);
+            ratio = w[(size_t)(A * Bn) * c];
+        }
         const unsigned lane_off = (kb << log_c) + c; // uniform row base + 32-bit lane offset: one address register for all stores
 #pragma unroll
         for (int k3 = 0; k3 < Cn; k3++) {
@@ -391,7 +398,9 @@ __device__ __forceinline__ void cols_v4_finish(fp *tile, const fp *tw, const fp 
 template <int LA, int LB, int LC, bool INV>
 __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n,
                                                                         const fp *__restrict__ w, const fp *__restrict__ prescale,
-                                                                        size_t in_batch_stride, size_t out_batch_stride, size_t prescale_batch_stride) {
+                                                                        size_t in_batch_stride, size_t out_batch_stride, size_t prescale_batch_stride,
+                                                                        const fp *__restrict__ aux, const fp *__restrict__ aux_ps,
+                                                                        size_t aux_ps_batch_stride) {
     using G = V4<LA, LB, LC>;
     constexpr int A = G::A, T = G::T, M = G::M, LOGM = G::LOGM;
     extern __shared__ __attribute__((aligned(16))) fp smem[];
@@ -403,8 +412,14 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
     fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
     const fp *ps = prescale ? prescale + blockIdx.x * prescale_batch_stride : nullptr;
     const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2;
+    // compact tables (NttAux): aux = [M] twiddles of this pass | [C] twiddles of the row pass | [C] ratios | [A Bn][C] output factors;
+    // aux_ps (per batch) = [M] row part of the prescale | [A Bn][C] output factors times the column part
+    const fp *ps_row = (ps && aux_ps) ? aux_ps + blockIdx.x * aux_ps_batch_stride : nullptr;
+    const fp *outf = !aux ? nullptr : ps ? (ps_row ? ps_row + M : nullptr) : aux + M + ((size_t)2 << log_c);
+    const fp *ratio_tab = aux ? aux + M + ((size_t)1 << log_c) : nullptr;
 
-    for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
+    if (aux) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux[e];
+    else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
     fp nxt[A];
     {
         const unsigned lane_off = (t << log_c) + xcd_pair_tile(blockIdx.y * V4_TILES) * L2 + l;
@@ -425,7 +440,10 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
                 for (int r1 = 0; r1 < A; r1++) nxt[r1] = (src + ((size_t)(r1 * T) << log_c))[lane_off];
             }
             __builtin_amdgcn_sched_barrier(0); // the prefetch is issued here, ahead of this tile's arithmetic
-            if (ps) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
+            if (ps_row) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
+#pragma unroll
+                for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], ps_row[r1 * T + t]);
+            } else if (ps) {
                 const unsigned ps_off = t << log_c;
 #pragma unroll
                 for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], (ps + ((size_t)(r1 * T) << log_c))[ps_off]);
@@ -438,7 +456,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
             }
         }
         __syncthreads();
-        cols_v4_finish<LA, LB, LC, INV>(tile, tw, w, ps, dst, log_c, c, t, l);
+        cols_v4_finish<LA, LB, LC, INV>(tile, tw, w, ps, dst, log_c, c, t, l, outf, ratio_tab);
         __syncthreads(); // the tile is rewritten by the next iteration
     }
 }
@@ -447,7 +465,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
 template <int LA, int LB, int LC, bool INV>
 __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n,
                                                                         const fp *__restrict__ w, fp post_scale, int do_scale,
-                                                                        size_t in_batch_stride, size_t out_batch_stride) {
+                                                                        size_t in_batch_stride, size_t out_batch_stride, const fp *__restrict__ aux_tw) {
     using G = V4<LA, LB, LC>;
     constexpr int A = G::A, Bn = G::Bn, Cn = G::Cn, T = G::T, M = G::M, LOGM = G::LOGM;
     constexpr int TP = T + 4; // padded run of q per (j1, l): lanes over l then hit distinct banks (T + 4 = 4 mod 32 for T = 32, 64)
@@ -461,7 +479,8 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const f
     const unsigned s1 = threadIdx.x % T, l1 = threadIdx.x / T; // step 1: s = c2 Cn + c3 fastest across lanes (coalesced row reads)
     const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2; // steps 2 and 3: l fastest across lanes (64-byte transposed stores)
 
-    for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_r];
+    if (aux_tw) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux_tw[e];
+    else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_r];
     fp nxt[A];
     const unsigned in_lane = (l1 << LOGM) + s1; // uniform row base + 32-bit lane offset: one address register for all loads
     {
@@ -541,9 +560,11 @@ hipError_t launch_v4(const NttArgs &a, hipStream_t stream) {
     if ((e = hipFuncSetAttribute((const void *)k_ntt_rows_v4<CA, CB, CC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void *)k_ntt_cols_v4<RA, RB, RC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
     hipLaunchKernelGGL((k_ntt_cols_v4<RA, RB, RC, INV>), dim3(a.batch, (unsigned)GC::M / L2 / V4_TILES, a.width), dim3(GR::NT), lds_a, stream, a.in,
-                       a.scratch, a.log_n, a.w, a.prescale, a.in_batch_stride, a.scratch_batch_stride, a.prescale_batch_stride);
+                       a.scratch, a.log_n, a.w, a.prescale, a.in_batch_stride, a.scratch_batch_stride, a.prescale_batch_stride, a.aux,
+                       a.prescale ? a.aux_ps : nullptr, a.aux_ps_batch_stride);
     hipLaunchKernelGGL((k_ntt_rows_v4<CA, CB, CC, INV>), dim3(a.batch, (unsigned)GR::M / L2 / V4_TILES, a.width), dim3(GC::NT), lds_b, stream,
-                       (const fp *)a.scratch, a.out, a.log_n, a.w, a.post_scale, a.do_scale ? 1 : 0, a.scratch_batch_stride, a.out_batch_stride);
+                       (const fp *)a.scratch, a.out, a.log_n, a.w, a.post_scale, a.do_scale ? 1 : 0, a.scratch_batch_stride, a.out_batch_stride,
+                       a.aux ? a.aux + GR::M : nullptr);
     return hipGetLastError();
 }
 
@@ -692,6 +713,54 @@ hipError_t coset_combine(const fp *d_b, fp *d_h, unsigned log_n, unsigned log_b,
     else if (log_b == 2) hipLaunchKernelGGL(k_coset_combine<2>, grid, block, 0, stream, d_b, d_h, n, d_winv_N, b_inv);
     else if (log_b == 3) hipLaunchKernelGGL(k_coset_combine<3>, grid, block, 0, stream, d_b, d_h, n, d_winv_N, b_inv);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---- compact tables of the v4 kernels --------------------------------------------------------------------------------
+// The twiddles of a sub-transform, the row part of a coset's prescale and the output factors of the column pass are strided or
+// scattered entries of the n-entry tables (w[e << log_c], s[r << log_c], w[kb c]): 8 useful bytes per 64-byte sector and, for the
+// output factors, one sector per lane.  Gathered once per table into dense arrays, a workgroup reads them as a handful of
+// contiguous lines: 2.3 k instead of 5 k sector requests per column-pass workgroup.
+bool ntt_v4_shape(unsigned log_n, NttV4Shape *s) {
+    static const bool v2_env = [] { const char *e = getenv("CSTARK_NTT_V2"); return e && atoi(e) != 0; }();
+    if (v2_env) return false;
+    if (log_n == 20) { *s = {10, 10, 7}; return true; }
+    if (log_n == 18) { *s = {9, 9, 6}; return true; }
+    if (log_n == 16) { *s = {8, 8, 6}; return true; }
+    return false;
+}
+namespace {
+// plan block: [R] w^(e C) | [C] w^(e R) | [C] w^(KB c) | [KB][C] w^(kb c)
+__global__ void k_aux_plan(fp *aux, const fp *__restrict__ w, unsigned log_r, unsigned log_c, unsigned log_kb) {
+    const size_t R = (size_t)1 << log_r, C = (size_t)1 << log_c, total = R + 2 * C + (C << log_kb);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        fp v;
+        if (i < R) v = w[i << log_c];
+        else if (i < R + C) v = w[(i - R) << log_r];
+        else if (i < R + 2 * C) v = w[(i - R - C) << log_kb];
+        else { const size_t q = i - R - 2 * C, kb = q >> log_c, c = q & (C - 1); v = w[kb * c]; }
+        aux[i] = v;
+    }
+}
+// coset block: [R] s^(r C) | [KB][C] w^(kb c) s^c
+__global__ void k_aux_coset(fp *aux, const fp *__restrict__ w, const fp *__restrict__ s, unsigned log_r, unsigned log_c, unsigned log_kb) {
+    const size_t R = (size_t)1 << log_r, C = (size_t)1 << log_c, total = R + (C << log_kb);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        fp v;
+        if (i < R) v = s[i << log_c];
+        else { const size_t q = i - R, kb = q >> log_c, c = q & (C - 1); v = fp_mul(w[kb * c], s[c]); }
+        aux[i] = v;
+    }
+}
+} // namespace
+size_t ntt_aux_plan_words(const NttV4Shape &s) { return ((size_t)1 << s.log_r) + ((size_t)2 << s.log_c) + ((size_t)1 << (s.log_c + s.log_kb)); }
+size_t ntt_aux_coset_words(const NttV4Shape &s) { return ((size_t)1 << s.log_r) + ((size_t)1 << (s.log_c + s.log_kb)); }
+hipError_t ntt_build_aux_plan(fp *d_aux, const fp *d_w, const NttV4Shape &s, hipStream_t stream) {
+    hipLaunchKernelGGL(k_aux_plan, dim3(256), dim3(256), 0, stream, d_aux, d_w, s.log_r, s.log_c, s.log_kb);
+    return hipGetLastError();
+}
+hipError_t ntt_build_aux_coset(fp *d_aux, const fp *d_w, const fp *d_s, const NttV4Shape &s, hipStream_t stream) {
+    hipLaunchKernelGGL(k_aux_coset, dim3(256), dim3(256), 0, stream, d_aux, d_w, d_s, s.log_r, s.log_c, s.log_kb);
     return hipGetLastError();
 }
 

@@ -34,6 +34,22 @@ __global__ __launch_bounds__(256) void k_chain(uint64_t *out, int iters, uint32_
                 if (OP == 11) asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(w[i]), "v"((uint64_t)c) : "vcc");
                 if (OP == 12) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b[i]));
                 if (OP == 13) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (OP == 14) asm volatile("v_cmp_gt_i32 vcc, 0, %0" : : "v"(a[i]) : "vcc");
+                if (OP == 15) asm volatile("v_cmp_gt_i32_e64 s[20:21], 0, %0" : : "v"(a[i]) : "s20", "s21");
+                if (OP == 16) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (OP == 17) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(c));
+                if (OP == 18) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(a[i]));
+                if (OP == 19) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));
+                if (OP == 20) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));
+                if (OP == 21) asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(w[i]));
+                if (OP == 22) asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[i]) : "v"(c) : "vcc");
+                if (OP == 23) asm volatile("v_mad_u64_u32 %0, vcc, %1, 1, %0" : "+v"(w[i]) : "v"(a[i]) : "vcc");
+                if (OP == 24) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));
+                if (OP == 25) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]));
+                if (OP == 26) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(a[i]) : "v"(c));
+                if (OP == 27) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (OP == 28) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(w[i]) : "v"((uint64_t)c));
+                if (OP == 29) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
             }
         }
     }
@@ -85,5 +101,21 @@ int main() {
     run<8>("v_mul_hi_u32", out, clk);
     run<4>("v_mad_u64_u32", out, clk);
     run<13>("v_pk_add_u16", out, clk);
+    run<14>("v_cmp_gt_i32 vcc", out, clk);
+    run<15>("v_cmp_gt_i32 sgpr", out, clk);
+    run<16>("v_min_u32", out, clk);
+    run<17>("v_cndmask e64", out, clk);
+    run<18>("v_ashrrev_i32", out, clk);
+    run<19>("v_and_or_b32", out, clk);
+    run<20>("v_bfi_b32", out, clk);
+    run<21>("v_lshlrev_b64", out, clk);
+    run<22>("v_addc_co_u32", out, clk);
+    run<23>("v_mad_u64 x*1+c", out, clk);
+    run<24>("v_mad_u32_u24", out, clk);
+    run<25>("v_mov_b32 dpp", out, clk);
+    run<26>("v_add_u32 sdwa", out, clk);
+    run<27>("v_pk_mul_lo_u16", out, clk);
+    run<28>("v_fma_f64", out, clk);
+    run<29>("v_sub_u32", out, clk);
     return 0;
 }
