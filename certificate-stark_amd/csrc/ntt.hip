@@ -20,6 +20,12 @@
 #define fp_mul(a, b) ((a) ^ (b))
 #define fp_add(a, b) ((a) + (b))
 #define fp_sub(a, b) ((a) - (b))
+#define fp_sub_lazy(a, b) ((a) - (b))
+#endif
+// measurement builds only: leave out one memory phase of the v4 kernels (results are then wrong, the timing shows what the phase costs)
+//   1 twiddle-table fill   2 prescale loads   4 output-factor loads   8 global stores (kept alive by an impossible condition)   16 tile loads
+#ifndef CS_NTT_SKIP
+#define CS_NTT_SKIP 0
 #endif
 
 namespace cs {
@@ -376,7 +382,8 @@ __device__ __forceinline__ void cols_v4_finish(fp *tile, const fp *tw, const fp 
         // output factor shift^c w_n^(k c), k = (k1 + A k2) + A Bn k3: a geometric sequence in k3 with ratio w_n^(A Bn c)
         const unsigned kb = k1 + A * k2;
         fp g, ratio;
-        if (outf) { // compact tables (ntt_build_aux_*): one 64-byte segment per (kb, tile) instead of 8 scattered sectors
+        if (CS_NTT_SKIP & 4) { g = kb + c; ratio = c; }
+        else if (outf) { // compact tables (ntt_build_aux_*): one 64-byte segment per (kb, tile) instead of 8 scattered sectors
             g = outf[((size_t)kb << log_c) + c];
             ratio = ratio_tab[c];
         } else {
@@ -388,7 +395,8 @@ __device__ __forceinline__ void cols_v4_finish(fp *tile, const fp *tw, const fp 
 #pragma unroll
         for (int k3 = 0; k3 < Cn; k3++) {
             fp *row = dst + ((size_t)(A * Bn * k3) << log_c);
-            row[lane_off] = fp_mul(x[cx_brev(k3, LC)], g);
+            const fp val = fp_mul(x[cx_brev(k3, LC)], g);
+            if (!(CS_NTT_SKIP & 8) || val == 0x123456789abcdefull) row[lane_off] = val;
             if (k3 + 1 < Cn) g = fp_mul(g, ratio);
         }
     }
@@ -418,13 +426,14 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
     const fp *outf = !aux ? nullptr : ps ? (ps_row ? ps_row + M : nullptr) : aux + M + ((size_t)2 << log_c);
     const fp *ratio_tab = aux ? aux + M + ((size_t)1 << log_c) : nullptr;
 
-    if (aux) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux[e];
+    if (CS_NTT_SKIP & 1) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
+    else if (aux) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
     fp nxt[A];
     {
         const unsigned lane_off = (t << log_c) + xcd_pair_tile(blockIdx.y * V4_TILES) * L2 + l;
 #pragma unroll
-        for (int r1 = 0; r1 < A; r1++) nxt[r1] = (src + ((size_t)(r1 * T) << log_c))[lane_off];
+        for (int r1 = 0; r1 < A; r1++) nxt[r1] = (CS_NTT_SKIP & 16) ? (fp)(lane_off + r1) : (src + ((size_t)(r1 * T) << log_c))[lane_off];
     }
     __syncthreads(); // tw[] ready
 #pragma unroll 1
@@ -440,7 +449,8 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
                 for (int r1 = 0; r1 < A; r1++) nxt[r1] = (src + ((size_t)(r1 * T) << log_c))[lane_off];
             }
             __builtin_amdgcn_sched_barrier(0); // the prefetch is issued here, ahead of this tile's arithmetic
-            if (ps_row) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
+            if (CS_NTT_SKIP & 2) {
+            } else if (ps_row) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
 #pragma unroll
                 for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], ps_row[r1 * T + t]);
             } else if (ps) {
@@ -479,14 +489,15 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const f
     const unsigned s1 = threadIdx.x % T, l1 = threadIdx.x / T; // step 1: s = c2 Cn + c3 fastest across lanes (coalesced row reads)
     const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2; // steps 2 and 3: l fastest across lanes (64-byte transposed stores)
 
-    if (aux_tw) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux_tw[e];
+    if (CS_NTT_SKIP & 1) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
+    else if (aux_tw) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux_tw[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_r];
     fp nxt[A];
     const unsigned in_lane = (l1 << LOGM) + s1; // uniform row base + 32-bit lane offset: one address register for all loads
     {
         const unsigned k10 = xcd_pair_tile(blockIdx.y * V4_TILES) * L2;
 #pragma unroll
-        for (int c1 = 0; c1 < A; c1++) nxt[c1] = (src + ((size_t)k10 << LOGM) + c1 * T)[in_lane];
+        for (int c1 = 0; c1 < A; c1++) nxt[c1] = (CS_NTT_SKIP & 16) ? (fp)(in_lane + c1) : (src + ((size_t)k10 << LOGM) + c1 * T)[in_lane];
     }
     __syncthreads(); // tw[] ready
 #pragma unroll 1
@@ -542,11 +553,205 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const f
             for (int p = 0; p < Cn; p++) {
                 fp val = x[p];
                 if (do_scale) val = fp_mul(val, post_scale);
-                (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
+                if (!(CS_NTT_SKIP & 8) || val == 0x123456789abcdefull) (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
             }
         }
         __syncthreads(); // the tile is rewritten by the next iteration
     }
+}
+
+// =====================================================================================================
+// v5 kernels: the v4 passes for shapes with two step-2 and two step-3 tasks per thread (2^LA = 2 * 2^LB = 2 * 2^LC: the
+// 16 * 8 * 8 split of 1024 points), with each of the two exchanges done in TWO HALVES through a tile of half the size.  The tasks
+// of a thread are task h = 0, 1 with k1 in [8 h, 8 h + 8): step 1 writes its eight outputs of half h, every thread reads the
+// inputs of its task h, then the same buffer takes the other half.  32 KB of tile + 8 KB of twiddles per workgroup instead of
+// 72: three (row pass: 34.8 + 8 KB) to four workgroups per CU instead of two, so that a CU always holds workgroups in
+// different phases -- the loads and stores of one run under the arithmetic of the others.  (v4 measured with its arithmetic
+// alone 5.55 ms, with its memory traffic alone 5.74 ms, together 8.0 ms for 94 columns x 8 cosets: two resident workgroups
+// overlap too little.)  Register need after the cheaper field product: 62 (rows) / 95 (columns) VGPRs.
+// -----------------------------------------------------------------------------------------------------
+#ifndef CS_NTT_V5_COLS_WAVES
+#define CS_NTT_V5_COLS_WAVES 6
+#endif
+#ifndef CS_NTT_V5_ROWS_WAVES
+#define CS_NTT_V5_ROWS_WAVES 6
+#endif
+template <int LA, int LB, int LC, bool INV>
+__global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_COLS_WAVES) void k_ntt_cols_v5(
+    const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n, const fp *__restrict__ w, const fp *__restrict__ prescale, size_t in_batch_stride,
+    size_t out_batch_stride, size_t prescale_batch_stride, const fp *__restrict__ aux, const fp *__restrict__ aux_ps, size_t aux_ps_batch_stride) {
+    using G = V4<LA, LB, LC>;
+    constexpr int A = G::A, Bn = G::Bn, Cn = G::Cn, T = G::T, M = G::M, LOGM = G::LOGM, AH = A / 2;
+    static_assert(G::J2 == 2 && G::J3 == 2 && Bn == AH && Cn == AH, "two tasks per thread and step, one per half");
+    extern __shared__ __attribute__((aligned(16))) fp smem[];
+    fp *tile = smem;                        // [A / 2][T][L2]
+    fp *tw = smem + (size_t)(M / 2) * L2;   // [M] powers of w_M
+    const unsigned log_c = log_n - LOGM;
+    const size_t n = (size_t)1 << log_n;
+    const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
+    fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
+    const fp *ps = prescale ? prescale + blockIdx.x * prescale_batch_stride : nullptr;
+    const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2;
+    const fp *ps_row = (ps && aux_ps) ? aux_ps + blockIdx.x * aux_ps_batch_stride : nullptr; // tables as in the v4 kernel
+    const fp *outf = !aux ? nullptr : ps ? (ps_row ? ps_row + M : nullptr) : aux + M + ((size_t)2 << log_c);
+    const fp *ratio_tab = aux ? aux + M + ((size_t)1 << log_c) : nullptr;
+    const unsigned c = xcd_pair_tile(blockIdx.y) * L2 + l;
+
+    if (aux) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux[e];
+    else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
+    fp a[A];
+    {
+        const unsigned lane_off = (t << log_c) + c;
+#pragma unroll
+        for (int r1 = 0; r1 < A; r1++) a[r1] = (src + ((size_t)(r1 * T) << log_c))[lane_off];
+    }
+    if (ps_row) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
+#pragma unroll
+        for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], ps_row[r1 * T + t]);
+    } else if (ps) {
+        const unsigned ps_off = t << log_c;
+#pragma unroll
+        for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], (ps + ((size_t)(r1 * T) << log_c))[ps_off]);
+    }
+    reg_ntt_dif<LA, INV>(a); // step 1: rows r = r1 T + t; a[p] = Y[k1 = brev(p)]
+    __syncthreads(); // tw[] ready
+    const unsigned kh = t / Cn, r3 = t % Cn; // task h of this thread in step 2: k1 = kh + AH h, r3
+    fp z[2][Bn];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int p = 0; p < A; p++) {
+            const unsigned k1 = cx_brev(p, LA);
+            if ((int)(k1 / AH) == h) tile[((size_t)(k1 % AH) * T + t) * L2 + l] = (k1 == 0) ? a[p] : fp_mul(a[p], tw[k1 * t]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r2 = 0; r2 < Bn; r2++) z[h][r2] = tile[((size_t)kh * T + r2 * Cn + r3) * L2 + l];
+        __syncthreads(); // the half is rewritten
+    }
+    const unsigned k1s = t / Bn, k2 = t % Bn; // task h in step 3: k1 = k1s + AH h, k2
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        reg_ntt_dif<LB, INV>(z[h]);
+#pragma unroll
+        for (int p = 0; p < Bn; p++) {
+            const unsigned j2 = cx_brev(p, LB);
+            const fp v = (j2 == 0) ? z[h][p] : fp_mul(z[h][p], tw[(A * j2) * r3]);
+            tile[((size_t)kh * T + j2 * Cn + (r3 ^ (j2 % Cn))) * L2 + l] = v;
+        }
+        __syncthreads();
+        fp x[Cn];
+#pragma unroll
+        for (int q = 0; q < Cn; q++) x[q] = tile[((size_t)k1s * T + k2 * Cn + (q ^ (k2 % Cn))) * L2 + l];
+        if (h == 0) __syncthreads(); // the half is rewritten by task 1
+        reg_ntt_dif<LC, INV>(x);
+        // output factor shift^c w_n^(k c), k = (k1 + A k2) + A Bn k3: a geometric sequence in k3 with ratio w_n^(A Bn c)
+        const unsigned kb = (k1s + AH * h) + A * k2;
+        fp g, ratio;
+        if (outf) {
+            g = outf[((size_t)kb << log_c) + c];
+            ratio = ratio_tab[c];
+        } else {
+            g = w[(size_t)kb * c];
+            if (ps) g = fp_mul(g, ps[c]);
+            ratio = w[(size_t)(A * Bn) * c];
+        }
+        const unsigned lane_off = (kb << log_c) + c;
+#pragma unroll
+        for (int k3 = 0; k3 < Cn; k3++) {
+            fp *row = dst + ((size_t)(A * Bn * k3) << log_c);
+            row[lane_off] = fp_mul(x[cx_brev(k3, LC)], g);
+            if (k3 + 1 < Cn) g = fp_mul(g, ratio);
+        }
+    }
+}
+
+template <int LA, int LB, int LC, bool INV>
+__global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_ROWS_WAVES) void k_ntt_rows_v5(const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n,
+                                                                                           const fp *__restrict__ w, fp post_scale, int do_scale,
+                                                                                           size_t in_batch_stride, size_t out_batch_stride,
+                                                                                           const fp *__restrict__ aux_tw) {
+    using G = V4<LA, LB, LC>;
+    constexpr int A = G::A, Bn = G::Bn, Cn = G::Cn, T = G::T, M = G::M, LOGM = G::LOGM, AH = A / 2;
+    static_assert(G::J2 == 2 && G::J3 == 2 && Bn == AH && Cn == AH, "two tasks per thread and step, one per half");
+    constexpr int TP = T + 4; // padded run of q per (j1, l), as in the v4 kernel
+    extern __shared__ __attribute__((aligned(16))) fp smem[];
+    fp *tile = smem;                              // [A / 2][L2][TP]
+    fp *tw = smem + (size_t)AH * L2 * TP;         // [M]
+    const unsigned log_r = log_n - LOGM;
+    const size_t n = (size_t)1 << log_n;
+    const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
+    fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
+    const unsigned s1 = threadIdx.x % T, l1 = threadIdx.x / T; // step 1: s = c2 Cn + c3 fastest across lanes (coalesced row reads)
+    const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2; // steps 2 and 3: l fastest across lanes (64-byte transposed stores)
+    const unsigned k10 = xcd_pair_tile(blockIdx.y) * L2;
+
+    if (aux_tw) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux_tw[e];
+    else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_r];
+    fp a[A];
+    {
+        const unsigned in_lane = (l1 << LOGM) + s1;
+#pragma unroll
+        for (int c1 = 0; c1 < A; c1++) a[c1] = (src + ((size_t)k10 << LOGM) + c1 * T)[in_lane];
+    }
+    reg_ntt_dif<LA, INV>(a); // step 1: columns c = c1 T + s
+    __syncthreads(); // tw[] ready
+    const unsigned jh = t / Cn, c3 = t % Cn;
+    fp z[2][Bn];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int p = 0; p < A; p++) {
+            const unsigned j1 = cx_brev(p, LA);
+            if ((int)(j1 / AH) == h) tile[((size_t)(j1 % AH) * L2 + l1) * TP + s1] = (j1 == 0) ? a[p] : fp_mul(a[p], tw[j1 * s1]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c2 = 0; c2 < Bn; c2++) z[h][c2] = tile[((size_t)jh * L2 + l) * TP + c2 * Cn + c3];
+        __syncthreads();
+    }
+    const unsigned j1s = t / Bn, j2s = t % Bn;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        reg_ntt_dif<LB, INV>(z[h]);
+#pragma unroll
+        for (int p = 0; p < Bn; p++) {
+            const unsigned j2 = cx_brev(p, LB);
+            const fp v = (j2 == 0) ? z[h][p] : fp_mul(z[h][p], tw[(A * j2) * c3]);
+            tile[((size_t)jh * L2 + l) * TP + j2 * Cn + (c3 ^ (j2 % Cn))] = v;
+        }
+        __syncthreads();
+        fp x[Cn];
+#pragma unroll
+        for (int q = 0; q < Cn; q++) x[q] = tile[((size_t)j1s * L2 + l) * TP + j2s * Cn + (q ^ (j2s % Cn))];
+        if (h == 0) __syncthreads();
+        reg_ntt_dif<LC, INV>(x);
+        const unsigned out_lane = (((j1s + AH * h) + A * j2s) << log_r) + l; // output frequency k2 = j1 + A j2 + A Bn j3
+#pragma unroll
+        for (int p = 0; p < Cn; p++) {
+            fp val = x[p];
+            if (do_scale) val = fp_mul(val, post_scale);
+            (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
+        }
+    }
+}
+
+template <int RA, int RB, int RC, int CA, int CB, int CC, bool INV>
+hipError_t launch_v5(const NttArgs &a, hipStream_t stream) {
+    using GR = V4<RA, RB, RC>;
+    using GC = V4<CA, CB, CC>;
+    const size_t lds_a = ((size_t)GR::M / 2 * L2 + GR::M) * sizeof(fp);
+    const size_t lds_b = ((size_t)GC::A / 2 * L2 * (GC::T + 4) + GC::M) * sizeof(fp);
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void *)k_ntt_rows_v5<CA, CB, CC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_ntt_cols_v5<RA, RB, RC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
+    hipLaunchKernelGGL((k_ntt_cols_v5<RA, RB, RC, INV>), dim3(a.batch, (unsigned)GC::M / L2, a.width), dim3(GR::NT), lds_a, stream, a.in, a.scratch, a.log_n,
+                       a.w, a.prescale, a.in_batch_stride, a.scratch_batch_stride, a.prescale_batch_stride, a.aux, a.prescale ? a.aux_ps : nullptr,
+                       a.aux_ps_batch_stride);
+    hipLaunchKernelGGL((k_ntt_rows_v5<CA, CB, CC, INV>), dim3(a.batch, (unsigned)GR::M / L2, a.width), dim3(GC::NT), lds_b, stream, (const fp *)a.scratch,
+                       a.out, a.log_n, a.w, a.post_scale, a.do_scale ? 1 : 0, a.scratch_batch_stride, a.out_batch_stride,
+                       a.aux ? a.aux + GR::M : nullptr);
+    return hipGetLastError();
 }
 
 template <int RA, int RB, int RC, int CA, int CB, int CC, bool INV>
@@ -774,6 +979,8 @@ hipError_t ntt_columns(const NttArgs &a, hipStream_t stream) {
     if (a.log_n < NTT_MIN_LOG_N || a.log_n > NTT_MAX_LOG_N) return hipErrorInvalidValue;
     // register-tiled kernels for the production sizes; `inverse` selects the compile-time small twiddles
     static const bool v2_env = [] { const char *e = getenv("CSTARK_NTT_V2"); return e && atoi(e) != 0; }(); // tuning / debugging: two-step kernels
+    static const bool v4_env = [] { const char *e = getenv("CSTARK_NTT_V4"); return e && atoi(e) != 0; }(); // tuning / debugging: whole-tile exchanges
+    if (a.log_n == 20 && !v2_env && !v4_env) return a.inverse ? launch_v5<4, 3, 3, 4, 3, 3, true>(a, stream) : launch_v5<4, 3, 3, 4, 3, 3, false>(a, stream);
     if (a.log_n == 20 && !v2_env) return a.inverse ? launch_v4<4, 3, 3, 4, 3, 3, true>(a, stream) : launch_v4<4, 3, 3, 4, 3, 3, false>(a, stream);
     if (a.log_n == 20) return a.inverse ? launch_v2<5, 5, 5, 5, true>(a, stream) : launch_v2<5, 5, 5, 5, false>(a, stream);
     if (a.log_n == 18 && !v2_env) return a.inverse ? launch_v4<3, 3, 3, 3, 3, 3, true>(a, stream) : launch_v4<3, 3, 3, 3, 3, 3, false>(a, stream);
