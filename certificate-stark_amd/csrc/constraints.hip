@@ -1360,7 +1360,13 @@ __device__ __forceinline__ void lin_c_split(const CS_CONST fp *coefs, const Fram
 // adds to the six polynomials of the first family (alpha, beta of groups 0..4): out = [6][4 even cosets][n].  grid = (n / FNT, 4)
 // (extension proofs: one launch per coefficient set `set`; these groups are cheap and bandwidth-bound, nothing is worth sharing)
 template <int PART>
-__global__ __launch_bounds__(FNT, PART == PART_LIN_C ? 2 : 4) void k_lin_split(CeParams p, fp *__restrict__ out, unsigned set) {
+#ifndef CS_LIN_B_SPLIT_WAVES
+#define CS_LIN_B_SPLIT_WAVES 3 // measured 1.05 (4, 77 spilled registers) / 0.90 (3) / 0.99 ms (2)
+#endif
+#ifndef CS_LIN_C_SPLIT_WAVES
+#define CS_LIN_C_SPLIT_WAVES 2 // 3 (32 spilled registers) and 4 measured: no gain
+#endif
+__global__ __launch_bounds__(FNT, PART == PART_LIN_C ? CS_LIN_C_SPLIT_WAVES : PART == PART_LIN_B ? CS_LIN_B_SPLIT_WAVES : 4) void k_lin_split(CeParams p, fp *__restrict__ out, unsigned set) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kc = blockIdx.y;

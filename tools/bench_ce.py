@@ -14,6 +14,7 @@ from certificate_stark_amd.backend import Backend
 P = 2**62 + 2**56 + 2**55 + 1
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+split = len(sys.argv) > 3 and sys.argv[3] == "split"  # the degree-split evaluator (timing only: the random table is no extension)
 b = Backend()
 n = 1 << log_n
 lde = torch.randint(0, P, (8, 94, n), dtype=torch.int64, device=b.device)
@@ -25,15 +26,15 @@ for name, k in (("t_alpha", 115), ("t_beta", 115), ("b_alpha", 4), ("b_beta", 4)
         getattr(cf, name)[i] = int(v[i])
 pub = [1, 2, 3, 4]
 out = b.empty_u64(8, n)
-b.evaluate_constraints(lde, cf, pub, 15, out=out)
+b.evaluate_constraints(lde, cf, pub, 15, out=out, input_is_lde=split)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    b.evaluate_constraints(lde, cf, pub, 15, out=out)
+    b.evaluate_constraints(lde, cf, pub, 15, out=out, input_is_lde=split)
 e1.record()
 torch.cuda.synchronize()
 print("constraints: %.3f ms per evaluation (2^%d x 8 points)" % (e0.elapsed_time(e1) / reps, log_n))
 b.set_part_timing(True)
-b.evaluate_constraints(lde, cf, pub, 15, out=out)
+b.evaluate_constraints(lde, cf, pub, 15, out=out, input_is_lde=split)
 print("parts:", {k: round(v, 3) for k, v in b.constraint_part_ms().items()})
