@@ -379,13 +379,15 @@ def main():
         # the transform pair of the low-degree extensions: per evaluation written 8 bytes out + 1/8 coefficient read (blowup 8)
         lde_alg = lde_elements / per * 8 * (1 + 1.0 / (1 << LOG_B))
         lde_pairs = max(1, round(lde_elements / per / (WIDTH * n)))  # in units of "94 columns of one coset"
-        ntt_names = ["k_ntt_cols_v4<4, 3, 3, false>", "k_ntt_rows_v4<4, 3, 3, false>", "k_ntt_cols_v2<5, 5, false>", "k_ntt_rows_v2<5, 5, false>"]
-        roofline_lde = entry("forward transform pair of the low-degree extension (k_ntt_cols_v4 + k_ntt_rows_v4; all LDE calls of a proof: trace 94 "
+        ntt_names = ["k_ntt_cols_v5<4, 3, 3, false>", "k_ntt_rows_v5<4, 3, 3, false>", "k_ntt_cols_v4<4, 3, 3, false>", "k_ntt_rows_v4<4, 3, 3, false>",
+                     "k_ntt_cols_v2<5, 5, false>", "k_ntt_rows_v2<5, 5, false>"]
+        roofline_lde = entry("forward transform pair of the low-degree extension (k_ntt_cols_v5 + k_ntt_rows_v5; all LDE calls of a proof: trace 94 "
                              "columns x 8 cosets, composition 8 x 8, DEEP 1 x 8; traffic also covers the 56 split-polynomial transforms, same kernels)",
                              lde_alg, lde_ms / per, ntt_names,
-                             "the dominant kernel family by GPU time: about 350 vector instructions per element and coset at 2-4 issue cycles each "
-                             "(profiles/*_valu_issue_bench.txt) on top of a latency-bound memory skeleton (the same kernels without arithmetic take 72 % of "
-                             "the time, DESIGN.md 5b), priced against the HBM roofline as BASELINE.json asks; kernel_ms = per 94 columns x 1 coset; inside "
+                             "the dominant kernel family by GPU time: about 330 vector instructions per element and coset at 2-4 issue cycles each "
+                             "(profiles/*_valu_issue_bench*.txt): the extension of 94 columns to 8 cosets takes 8.0 ms, its arithmetic alone 5.55 ms (= the "
+                             "issue time), its memory traffic alone 5.74 ms (profiles/r02_ntt_phase_skip.txt, DESIGN.md 5b); priced against the HBM roofline "
+                             "as BASELINE.json asks; kernel_ms = per 94 columns x 1 coset; inside "
                              "cstark_tx_prove the first two column batches are extended beside the trace recurrences (DESIGN.md 5a)",
                              launches=lde_pairs)
         nb = (8 // world) if coset_mode else 8

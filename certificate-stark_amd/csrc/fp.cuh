@@ -56,6 +56,14 @@ __device__ __forceinline__ uint64_t fp_mul_lazy(uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
     const uint32_t b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     constexpr uint64_t K = (uint64_t)FP_P1 + 1;
+#ifdef CS_FP_MUL_PLAIN // measurement builds: the form left to the compiler (6 multiply-adds, 4 64-bit adds, 4 moves)
+    const uint64_t t_ = (uint64_t)a0 * b0;
+    const uint64_t u_ = mad_u64_u32(a1, b0, (t_ >> 32) + K);
+    const uint64_t v_ = mad_u64_u32(~(uint32_t)t_, FP_P1, u_);
+    const uint64_t w_ = mad_u64_u32(a0, b1, (uint32_t)v_);
+    const uint64_t x_ = mad_u64_u32(a1, b1, (w_ >> 32) + (v_ >> 32) + K);
+    return mad_u64_u32(~(uint32_t)w_, FP_P1, x_);
+#endif
     const uint32_t one = fp_opaque_one();
     const uint64_t t = (uint64_t)a0 * b0;
     uint64_t s = mad_u64_u32((uint32_t)(t >> 32), one, K);
