@@ -233,6 +233,17 @@ class Backend:
                                           self._ptr(out), C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out
 
+    def schnorr_evaluate_constraints(self, lde, aux_lde, t_alpha, t_beta, b_alpha, b_beta, avals_lde, log_blowup, k0=0, n_sig=2):
+        """SchnorrAir's combined constraint evaluations through the fused evaluator (cstark_schnorr_evaluate_constraints)."""
+        nk, width, n = lde.shape
+        out = self.empty_u64(nk, n)
+        arrs = [_np_u64(a) for a in (t_alpha, t_beta, b_alpha, b_beta)]
+        check(self.lib.cstark_schnorr_evaluate_constraints(self.ctx, C.c_uint32(n_sig), self._ptr(lde), self._ptr(aux_lde),
+                                                           *[a.ctypes.data_as(u64p) for a in arrs], self._ptr(avals_lde),
+                                                           C.c_uint32(avals_lde.shape[1]), self._ptr(out), C.c_uint32(n.bit_length() - 1),
+                                                           C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
+        return out
+
     # ---- standalone SchnorrAir ----
     def upload_schnorr_witness(self, messages, sig_rx, sig_s):
         m, rx = _np_u64(messages), _np_u64(sig_rx)

@@ -868,11 +868,8 @@ int cstark_schnorr_mask_columns(uint64_t *out /* [36][512] host */) {
     memcpy(out, cols.data(), cols.size() * 8);
     return CSTARK_OK;
 }
-int cstark_schnorr_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, const uint64_t *d_aux_lde, uint64_t *d_out, uint32_t log_n,
-                                        uint32_t log_blowup, uint32_t k0, uint32_t nk) {
-    if (!c || !d_lde || !d_aux_lde || !d_out || nk == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_evaluate_transitions: bad argument");
-    if (log_n < 9 || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
-    HIP_TRY(hipSetDevice(c->device));
+// SchnorrAir's 36 periodic columns over the LDE domain, [b][36][512]; built once per (trace length, blowup)
+static int schnorr_periodic(cstark_ctx *c, uint32_t log_n, uint32_t log_blowup, const PeriodicTable **out) {
     const PeriodicTable *pt = nullptr;
     for (const PeriodicTable &t : c->small_periodic)
         if (t.air == CSTARK_AIR_SCHNORR && t.log_n == log_n && t.log_b == log_blowup) pt = &t;
@@ -894,6 +891,16 @@ int cstark_schnorr_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, co
         c->small_periodic.push_back(t);
         pt = &c->small_periodic.back();
     }
+    *out = pt;
+    return CSTARK_OK;
+}
+int cstark_schnorr_evaluate_transitions(cstark_ctx *c, const uint64_t *d_lde, const uint64_t *d_aux_lde, uint64_t *d_out, uint32_t log_n,
+                                        uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!c || !d_lde || !d_aux_lde || !d_out || nk == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_evaluate_transitions: bad argument");
+    if (log_n < 9 || log_n > cs::NTT_MAX_LOG_N || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "bad domain parameters");
+    HIP_TRY(hipSetDevice(c->device));
+    const PeriodicTable *pt;
+    RC_TRY(schnorr_periodic(c, log_n, log_blowup, &pt));
     HIP_TRY(cs::launch_eval_transitions_schnorr(d_lde, d_aux_lde, pt->tab, d_out, log_n, k0, nk, c->stream));
     return CSTARK_OK;
 }
@@ -979,11 +986,14 @@ int cstark_schnorr_assertion_polys(cstark_ctx *c, uint64_t *d_out, uint32_t log_
     return CSTARK_OK;
 }
 
-int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha,
-                       const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values,
-                       const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
-    if (!c || !d_lde || !d_evals || !t_alpha || !t_beta || !b_alpha || !b_beta || !d_out || nk == 0)
+// d_schnorr_aux_lde != null (SchnorrAir only): the transition sum comes from the fused evaluator instead of d_evals
+static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha,
+                            const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values,
+                            const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
+                            const uint64_t *d_schnorr_aux_lde) {
+    if (!c || !d_lde || (!d_evals && !d_schnorr_aux_lde) || !t_alpha || !t_beta || !b_alpha || !b_beta || !d_out || nk == 0)
         return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: null argument");
+    if (d_schnorr_aux_lde && (air != CSTARK_AIR_SCHNORR || log_n < 9)) return fail(CSTARK_ERR_INVALID_ARG, "the fused evaluator is SchnorrAir's");
     cs::host::AirShape s;
     if (!cs::host::air_shape(air, s, n_items)) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
     if (s.a_const.empty() && !assertion_values) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: assertion values required");
@@ -1071,8 +1081,28 @@ int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t 
             sh = cs::host::mul(sh, wbn);
         }
     }
+    if (d_schnorr_aux_lde) {
+        const PeriodicTable *pt;
+        RC_TRY(schnorr_periodic(c, log_n, log_blowup, &pt));
+        HIP_TRY(cs::launch_schnorr_fused(p, d_schnorr_aux_lde, pt->tab, nk, c->stream));
+        p.tsum = d_out;
+    }
     HIP_TRY(cs::launch_air_combine(p, nk, c->stream));
     return CSTARK_OK;
+}
+int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha,
+                       const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values,
+                       const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!d_evals) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: null argument");
+    return air_combine_impl(c, air, n_items, d_lde, d_evals, t_alpha, t_beta, b_alpha, b_beta, assertion_values, d_avals_lde, n_avals, d_out, log_n,
+                            log_blowup, k0, nk, nullptr);
+}
+int cstark_schnorr_evaluate_constraints(cstark_ctx *c, uint32_t n_sig, const uint64_t *d_lde, const uint64_t *d_aux_lde, const uint64_t *t_alpha,
+                                        const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *d_avals_lde,
+                                        uint32_t n_avals, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (!d_aux_lde) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_evaluate_constraints: null argument");
+    return air_combine_impl(c, CSTARK_AIR_SCHNORR, n_sig, d_lde, nullptr, t_alpha, t_beta, b_alpha, b_beta, nullptr, d_avals_lde, n_avals, d_out, log_n,
+                            log_blowup, k0, nk, d_aux_lde);
 }
 
 // per-launch timing of the fused constraint evaluation (HIP events on the context's stream)

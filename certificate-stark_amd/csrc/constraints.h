@@ -47,6 +47,7 @@ struct AirCombineParams {
     const uint32_t *a_reg;                    // [n_assertions]
     const int32_t *a_seq;                     // column of `avals` holding the asserted values, or -1 for the constant a_value
     const uint64_t *avals;                    // [nk][n_avals][n] LDE of the sequence-value polynomials (may be null)
+    const uint64_t *tsum;                     // [nk][n] merged transition sum of a fused evaluator (then `evals` is not read), or null
     uint64_t *out;
     uint64_t w_last;
     uint32_t width, n_constraints, n_assertions, n_avals, stride, log_n, k0;
@@ -63,6 +64,9 @@ hipError_t launch_eval_transitions_merkle(const uint64_t *lde, const uint64_t *p
                                           hipStream_t stream);
 hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *aux, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0,
                                            unsigned nk, hipStream_t stream);
+// SchnorrAir, fused: writes sum_i (alpha_i + beta_i x^adj_i) C_i(x) of the nk cosets into p.out (six launches); aux / ptab as for
+// launch_eval_transitions_schnorr.  Follow with launch_air_combine on the same parameters with p.tsum = p.out.
+hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, unsigned nk, hipStream_t stream);
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream);
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);

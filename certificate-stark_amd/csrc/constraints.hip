@@ -892,8 +892,8 @@ __device__ __forceinline__ void fused_addition(A &acc, const Frame &f, int reg, 
     acc.end(addition);
 }
 // final addition S + h*P with X reduced to affine (ecc.rs:146-172)
-template <int M>
-__device__ __forceinline__ void fused_final_addition(Fused<M> &acc, const Frame &f, fp final_add) {
+template <class A>
+__device__ __forceinline__ void fused_final_addition(A &acc, const Frame &f, fp final_add) {
     const Point sp = {load6(f, 0, false), load6(f, 6, false), load6(f, 12, false)};
     const Point hp = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
     const Point r = ec_add<CS_EC_CALL>(sp, hp);
@@ -1588,6 +1588,80 @@ __global__ __launch_bounds__(NT) void k_eval_transitions_schnorr(const fp *lde, 
         }
     }
 }
+// ---- SchnorrAir, fused: the merged transition sum  sum_i (alpha_i + beta_i x^adj_i) C_i(x)  without the 56 materialised values -------
+// The same gadget templates as the TransactionAir evaluator (lazy F_p6 arithmetic, one 128-bit accumulation per section) behind an
+// accumulator that looks the coefficient and the degree group of a slot up in the tables of the generic merge (AirCombineParams).
+// Six launches (doubling / addition of s*G, of h*P, final addition, the rest) that accumulate into one value per point; k_air_combine
+// then takes that value instead of walking the materialised evaluations (p.tsum).  Exact arithmetic: the merged evaluations -- and
+// the proof bytes -- equal those of the materialising path (tests/test_gpu_small_airs.py).
+struct AirSum {
+    const CS_CONST fp *alpha, *beta;
+    const CS_CONST uint32_t *grp;
+    const fp *xp; // LDS [AIR_MAX_GROUPS][FNT]: x^adj_g of this lane's point
+    Acc128 s;
+    int cnt;
+    fp total;
+    __device__ __forceinline__ fp coef(int i) const { return fp_add(alpha[i], fp_mul(beta[i], xp[grp[i] * FNT + threadIdx.x])); }
+    __device__ __forceinline__ void begin() { s = acc_zero(); cnt = 0; }
+    __device__ __forceinline__ void term(int i, fp v) {
+        acc_mad(s, coef(i), v);
+        if (++cnt == 7) { acc_fold(s); cnt = 0; }
+    }
+    __device__ __forceinline__ void end(fp flag) {
+        acc_fold(s);
+        total = fp_add(total, fp_mul(flag, acc_reduce(s)));
+    }
+    __device__ __forceinline__ void add(int i, fp flag, fp val) { total = fp_add(total, fp_mul(coef(i), fp_mul(flag, val))); } // AccAll's interface
+};
+enum { SF_DBL0 = 0, SF_ADD0, SF_DBL1, SF_ADD1, SF_FINAL, SF_REST, SF_PARTS };
+template <int PART>
+__global__ __launch_bounds__(FNT, PART == SF_REST ? 2 : CS_EC_WAVES) void k_schnorr_fused(AirCombineParams p, const fp *__restrict__ aux,
+                                                                                       const fp *__restrict__ ptab) {
+    __shared__ fp xp_lds[AIR_MAX_GROUPS * FNT];
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kk = blockIdx.y, k = p.k0 + kk;
+    const fp *base = p.lde + (size_t)kk * 56 * n;
+    Frame f;
+    f.n = n;
+    f.cur_p = base + j;
+    f.next_p = base + ((j + 1) & (n - 1));
+    f.per_p = ptab + (size_t)k * 36 * 512 + (j & 511);
+    f.pcycle = 512;
+    for (unsigned g = 0; g < p.n_tgrp; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(p.tgrp_shift[k][g], p.w[(j * p.tgrp_adj[g]) & (n - 1)]);
+    AirSum acc{as_const(p.t_alpha), as_const(p.t_beta), as_const(p.t_grp), xp_lds, acc_zero(), 0, 0};
+    const fp *ax = aux + (size_t)kk * 19 * n + j;
+    const fp global_mask = f.pv(0), scalar_mult = f.pv(1), doubling = f.pv(2), hash_flag = f.pv(7);
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
+    if constexpr (PART == SF_DBL0) fused_doubling(acc, f, 0, doubling);
+    if constexpr (PART == SF_DBL1) fused_doubling(acc, f, 19, doubling);
+    if constexpr (PART == SF_ADD0) fused_addition(acc, f, 0, const6(c_generator), const6(c_generator + 6), addition);
+    if constexpr (PART == SF_ADD1) fused_addition(acc, f, 19, fp6_load_strided(ax, n), fp6_load_strided(ax + 6 * n, n), addition); // periodic pkey columns
+    if constexpr (PART == SF_FINAL) fused_final_addition(acc, f, fp_mul(c_not(scalar_mult), global_mask));
+    if constexpr (PART == SF_REST) {
+        const fp copy_hash = fp_mul(c_not(hash_flag), global_mask), final_add = fp_mul(c_not(scalar_mult), global_mask);
+        Frame fr = f; // view whose column P_ARK is the first round-constant column (index 8 here)
+        fr.per_p = f.per_p - (size_t)(P_ARK - 8) * 512;
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {
+            const fp dflag = f.pv(3 + i);
+            const fp c = f.cur(41 - i), nx = f.next(41 - i);
+            acc.add(41 - i, fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37))));
+            acc.add(41 - i, fp_mul(c_not(dflag), doubling), fp_sub(c, nx));
+            acc.add(38 + i, addition, fp_sub(f.cur(38 + i), f.next(38 + i)));
+            acc.add(38 + i, final_add, fp_sub(f.cur(38 + i), f.cur(42 + i)));
+        }
+        enforce_round(acc, fr, 42, 42, hash_flag, 0, 0, false);
+#pragma unroll 1
+        for (int i = 0; i < 7; i++) {
+            acc.add(42 + i, copy_hash, fp_sub(f.cur(42 + i), f.next(42 + i)));
+            acc.add(49 + i, copy_hash, fp_sub(f.next(49 + i), ax[(size_t)(12 + i) * n]));
+        }
+    }
+    fp *o = p.out + (size_t)kk * n + j;
+    *o = PART == SF_DBL0 ? acc.total : fp_add(*o, acc.total); // the launches follow each other on the stream
+}
+
 // RangeProofAir::evaluate_transition  src/range/air.rs:60-98 (enforce_double_and_add_step with flag ONE)
 __global__ void k_eval_transitions_range(const fp *lde, fp *out, unsigned log_n) {
     const size_t n = (size_t)1 << log_n;
@@ -1633,8 +1707,10 @@ __global__ void k_air_combine(AirCombineParams p) {
         }
     }
     fp acc = 0;
-    for (unsigned i = 0; i < p.n_constraints; i++)
-        acc = fp_add(acc, fp_mul(p.evals[((size_t)kk * p.n_constraints + i) * n + j], fp_add(p.t_alpha[i], fp_mul(p.t_beta[i], xp[p.t_grp[i]]))));
+    if (p.tsum) acc = p.tsum[(size_t)kk * n + j]; // merged by a fused evaluator (may be the output table itself: read before the write below)
+    else
+        for (unsigned i = 0; i < p.n_constraints; i++)
+            acc = fp_add(acc, fp_mul(p.evals[((size_t)kk * p.n_constraints + i) * n + j], fp_add(p.t_alpha[i], fp_mul(p.t_beta[i], xp[p.t_grp[i]]))));
     acc = fp_mul(acc, fp_mul(fp_sub(x, p.w_last), p.zinv_coset[k]));
     // boundary constraints (single, periodic and sequence assertions): divisor x^m - w^(first*m)
     for (unsigned a = 0; a < p.n_assertions; a++) {
@@ -1673,6 +1749,18 @@ hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *
     hipLaunchKernelGGL(k_eval_transitions_schnorr<1>, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, aux, ptab, out, log_n, k0);
     hipLaunchKernelGGL(k_eval_transitions_schnorr<2>, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, aux, ptab, out, log_n, k0);
     hipLaunchKernelGGL(k_eval_transitions_schnorr<3>, dim3((unsigned)(n / NT), nk), dim3(NT), 0, stream, lde, aux, ptab, out, log_n, k0);
+    return hipGetLastError();
+}
+hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, unsigned nk, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    if (n % FNT) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(n / FNT), nk), block(FNT);
+    hipLaunchKernelGGL(k_schnorr_fused<SF_DBL0>, grid, block, 0, stream, p, aux, ptab);
+    hipLaunchKernelGGL(k_schnorr_fused<SF_ADD0>, grid, block, 0, stream, p, aux, ptab);
+    hipLaunchKernelGGL(k_schnorr_fused<SF_DBL1>, grid, block, 0, stream, p, aux, ptab);
+    hipLaunchKernelGGL(k_schnorr_fused<SF_ADD1>, grid, block, 0, stream, p, aux, ptab);
+    hipLaunchKernelGGL(k_schnorr_fused<SF_FINAL>, grid, block, 0, stream, p, aux, ptab);
+    hipLaunchKernelGGL(k_schnorr_fused<SF_REST>, grid, block, 0, stream, p, aux, ptab);
     return hipGetLastError();
 }
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream) {

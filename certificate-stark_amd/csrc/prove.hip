@@ -16,6 +16,7 @@
 #include <string.h>
 #include <algorithm>
 #include <new>
+#include <chrono>
 #include <vector>
 #include "../../include/cstark.h"
 #include "ctx.h"
@@ -370,6 +371,8 @@ int phase_evaluate(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint8_t *d_l
     HIP_TRY(hipMemcpyAsync(R.trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(hipStreamSynchronize(st)); // also completes the public-input copy of job.build
+    static const bool hostprof = getenv("CSTARK_HOSTPROF") != nullptr; // debugging: host time between the root and the evaluation launches
+    const auto hp0 = std::chrono::steady_clock::now();
     if (job.pub_staging) job.pub.assign(job.pub_staging, job.pub_staging + 14);
 
     Coin &coin = R.coin;
@@ -391,7 +394,13 @@ int phase_evaluate(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint8_t *d_l
     R.ta.resize(nc); R.tb.resize(nc); R.ba.resize(na); R.bb.resize(na);
     for (size_t i = 0; i < nc; i++) { R.ta[i] = coin.draw(); R.tb[i] = coin.draw(); }
     for (size_t i = 0; i < na; i++) { R.ba[i] = coin.draw(); R.bb[i] = coin.draw(); }
+    const auto hp1 = std::chrono::steady_clock::now();
     RC_TRY(job.combine(c, a, job, R.ta.data(), R.tb.data(), R.ba.data(), R.bb.data(), d_out));
+    if (hostprof) {
+        const auto hp2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[cstark hostprof] coefficients drawn in %.1f us, evaluation enqueued in %.1f us\n",
+                std::chrono::duration<double, std::micro>(hp1 - hp0).count(), std::chrono::duration<double, std::micro>(hp2 - hp1).count());
+    }
     STAGE();
     R.phase = 2;
     return CSTARK_OK;
@@ -705,23 +714,26 @@ int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta,
 int schnorr_build(cstark_ctx *c, ProveArena *a, AirJob &) { return cstark_schnorr_build_trace(c, a->trace); }
 int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
-    uint64_t *evals, *aux, *aux_co, *aux_lde, *av_co, *av_lde;
-    RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
+    // CSTARK_SCHNORR_FUSED=0 (tuning / debugging): materialise the 56 transition values and merge them generically
+    static const bool fused = [] { const char *e = getenv("CSTARK_SCHNORR_FUSED"); return !e || atoi(e) != 0; }();
+    uint64_t *evals = nullptr, *aux, *aux_co, *aux_lde, *av_co, *av_lde;
+    if (!fused) RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
     RC_TRY(arena_extra(c, a, 1, &aux, 19 * n * 8));
     RC_TRY(arena_extra(c, a, 2, &aux_co, 19 * n * 8));
     RC_TRY(arena_extra(c, a, 3, &aux_lde, 8 * 19 * n * 8));
     RC_TRY(arena_extra(c, a, 4, &av_co, 12 * n * 8));
     RC_TRY(arena_extra(c, a, 5, &av_lde, 8 * 12 * n * 8));
-    if (!job.evals_ready) { // once per proof (extension proofs merge the same evaluations with m coefficient sets)
+    if (!job.evals_ready) { // once per proof (extension proofs merge with m coefficient sets)
         // the public-input columns (src/schnorr/air.rs:228-290) are not committed: both sides derive them from the messages
         RC_TRY(cstark_schnorr_aux_columns(c, aux));
         RC_TRY(cstark_interpolate_columns(c, aux, aux_co, 19, job.log_n));
         RC_TRY(cstark_lde_columns(c, aux_co, aux_lde, 19, job.log_n, 3, host::lde_offset(), 0, 8));
-        RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
+        if (!fused) RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
         RC_TRY(cstark_schnorr_assertion_polys(c, av_co, job.log_n));
         RC_TRY(cstark_lde_columns(c, av_co, av_lde, 12, job.log_n, 3, host::lde_offset(), 0, 8));
         job.evals_ready = true;
     }
+    if (fused) return cstark_schnorr_evaluate_constraints(c, job.item, a->lde, aux_lde, ta, tb, ba, bb, av_lde, 12, out, job.log_n, 3, 0, 8);
     return cstark_air_combine(c, CSTARK_AIR_SCHNORR, job.item, a->lde, evals, ta, tb, ba, bb, nullptr, av_lde, 12, out, job.log_n, 3, 0, 8);
 }
 

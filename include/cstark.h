@@ -334,6 +334,17 @@ int cstark_air_combine(cstark_ctx *ctx, int air, uint32_t n_items, const uint64_
                        const uint64_t *assertion_values, const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out,
                        uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 
+/* SchnorrAir's combined constraint evaluations WITHOUT the 56 materialised transition values: the transition sum
+ * sum_i (alpha_i + beta_i x^adj_i) C_i(x) is accumulated per point by the fused gadget evaluators (the ones behind
+ * cstark_tx_evaluate_constraints) and merged with the 61 assertions like cstark_air_combine does.  Same values as
+ * cstark_schnorr_evaluate_transitions followed by cstark_air_combine (exact arithmetic); what cstark_air_prove uses for
+ * CSTARK_AIR_SCHNORR.  Replaces the evaluation loop of winterfell's ConstraintEvaluator for SchnorrAir
+ * (/root/reference/src/schnorr/air.rs:72-109, :394-531) [UPSTREAM-RECALL for the driver]. */
+int cstark_schnorr_evaluate_constraints(cstark_ctx *ctx, uint32_t n_sig, const uint64_t *d_lde, const uint64_t *d_aux_lde,
+                                        const uint64_t *t_alpha, const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta,
+                                        const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n,
+                                        uint32_t log_blowup, uint32_t k0, uint32_t nk);
+
 /* ---- witness synthesis (host; counterpart of TransactionMetadata::build_random, src/lib.rs:235-465, and of
  * SchnorrExample::new + schnorr::sign, src/schnorr/mod.rs:86-141, :197-217; seeded and deterministic) -----------------
  * cstark_tx_witness_generate fills the arrays of `w` (every pointer caller-allocated with the sizes documented on

@@ -128,3 +128,10 @@ def test_schnorr_air_merged_evaluations(oracle, backend, n_sig):
     out = backend.air_combine(backend.AIR_SCHNORR, backend.from_numpy_u64(lde), backend.from_numpy_u64(ev), ta, tb, ba, bb, None, log_b,
                               n_items=n_sig, avals_lde=d_avals)
     assert (to_numpy_u64(out) == ref).all()
+    # the fused evaluator (no materialised transition values): same merged evaluations, whole table and a coset window
+    d_lde, d_aux = backend.from_numpy_u64(lde), backend.from_numpy_u64(aux_lde)
+    fused = backend.schnorr_evaluate_constraints(d_lde, d_aux, ta, tb, ba, bb, d_avals, log_b, n_sig=n_sig)
+    assert (to_numpy_u64(fused) == ref).all()
+    part = backend.schnorr_evaluate_constraints(d_lde[2:5].contiguous(), d_aux[2:5].contiguous(), ta, tb, ba, bb, d_avals[2:5].contiguous(), log_b,
+                                                k0=2, n_sig=n_sig)
+    assert (to_numpy_u64(part) == ref[2:5]).all()
