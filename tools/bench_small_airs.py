@@ -30,6 +30,27 @@ for i in range(1024):
     p = RangeProofExample(opt, (12345 + i) << 3, b).prove()
 dt = time.perf_counter() - t0
 print("%-34s %8.3f ms for 1024 proofs of 64 rows (2^16 rows in total)  %7.1f proofs/s" % ("range, 1024 x 64 rows", dt * 1e3, 1024 / dt))
+# The same 1024 proofs from several host threads, each with its own context and stream (the calls release the interpreter lock).
+# Measured on MI355X: 503 ms with one prover, 525 / 542 ms with 4 / 8 in flight -- a 64-row proof is ~150 tiny launches and host
+# round trips, and the HIP runtime serialises them across threads: the small proofs are bound by host API time (0.49 ms each), not
+# by the GPU.  A batched prover (one launch per stage for all proofs) is the way past that; see DESIGN.md 7.
+from concurrent.futures import ThreadPoolExecutor
+for workers in (4,):
+    backs = [Backend() for _ in range(workers)]
+    for bk in backs:
+        RangeProofExample(opt, 12345 << 3, bk).prove()
+
+    def run(wid, backs=backs, workers=workers):
+        for i in range(wid, 1024, workers):
+            RangeProofExample(opt, (12345 + i) << 3, backs[wid]).prove()
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(workers) as ex_:
+        list(ex_.map(run, range(workers)))
+    dt = time.perf_counter() - t0
+    print("%-34s %8.3f ms for 1024 proofs of 64 rows, %d provers in flight on one GPU  %7.1f proofs/s" % (
+        "range, 1024 x 64 rows", dt * 1e3, workers, 1024 / dt))
+    del backs
 full = TransactionMetadata.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "witness_1024_d15.npz"))
 m512 = TransactionMetadata(*[getattr(full, f) if f == "final_root" else getattr(full, f)[:512] for f in TransactionMetadata.FIELDS])
 m512.final_root = full.initial_roots[512].copy()
