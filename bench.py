@@ -186,9 +186,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    # CSTARK_BENCH_REHEARSE=1 (never the driver's form): every rank on GPU 0 and the control collectives over gloo, to exercise the spawner,
+    # the rendezvous, the barriers and the max-over-ranks reduction on a one-GPU box; the line then carries "rehearsal" and no rccl_ranks
+    rehearse = world > 1 and os.environ.get("CSTARK_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     rccl_ranks = None
-    if world > 1:
+    if rehearse:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         ones = torch.ones(1, device="cuda", dtype=torch.int64)
         dist.all_reduce(ones)  # one real RCCL collective over every rank's device buffer: the sum is the number of ranks that took part
@@ -324,7 +331,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if prove_mode:
@@ -408,7 +415,8 @@ def main():
                       ("proofs/sec, state_transition AIR @ 2^%d steps (hot path only: trace gen + LDE + Blake3 commitment + constraint evaluation)" % log_n),
             "value": round((1 if coset_mode else world) / (ms_per_step * 1e-3), 4),
             "unit": "proofs/s",
-            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, **({"rehearsal": "%d ranks on ONE GPU, control collectives over gloo" % world} if rehearse else {}),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong" if coset_mode else "weak", "vs_baseline": None,
             "dtype": "u64 (63-bit prime field, Montgomery) + u32 (Blake3)", "data": "synthetic",
