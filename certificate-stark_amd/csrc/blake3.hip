@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ 
         const unsigned cnt = width - c0 < 8 ? width - c0 : 8;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
+#ifdef CS_HASH_NOLOAD // measurement build: the compression work without the table reads
+            uint64_t v = (unsigned)i < cnt ? (uint64_t)(j * 0x9E3779B97F4A7C15ull + c0 + i) : 0;
+#else
             uint64_t v = (unsigned)i < cnt ? col[(size_t)(c0 + i) * n] : 0;
+#endif
 #if !CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY
             if ((unsigned)i < cnt) v = fp_to_u64(v); // canonical little-endian bytes
 #endif
