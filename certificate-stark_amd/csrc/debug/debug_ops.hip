@@ -23,6 +23,7 @@ __global__ void k_fp_op(const fp *a, const fp *b, fp *out, size_t n, int op) {
         case 7: r = fp_neg(x); break;
         case 8: r = fp_dbl(x); break;
         case 9: r = wave_next(x, y); break; // lane l + 1's x, lane 63: its own y
+        case 10: r = fp_mul(fp_sub_lazy(x, y), y); break; // the product takes an unreduced first factor in (0, 2p): (x - y) * y
     }
     out[i] = r;
 }

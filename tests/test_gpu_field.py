@@ -48,6 +48,14 @@ def test_fp_ops(oracle, backend):
     assert (_run(backend, "cstark_debug_fp_op", a, None, n, 6, n) == xs).all()
     assert (_run(backend, "cstark_debug_fp_op", a, None, n, 7, n) == oracle.fp_sub(np.zeros_like(a), a)).all()
     assert (_run(backend, "cstark_debug_fp_op", a, None, n, 8, n) == oracle.fp_add(a, a)).all()
+    # unreduced first factor of a product (fp_sub_lazy, the transform butterflies): x - y + p up to 2p - 1, times every extreme y
+    ext = [0, 1, P - 1, P - 2, 2**32 - 1, 2**32, 2**62, P - 2**32, (P - 1) // 2]
+    lx = np.array([u for u in ext for _ in ext] + [rng.randrange(P) for _ in range(1000)], np.uint64)
+    ly = np.array([v for _ in ext for v in ext] + [rng.randrange(P) for _ in range(1000)], np.uint64)
+    for raw in (False, True):  # canonical values through the Montgomery map, and the same bit patterns taken as memory-form words
+        la, lb = (lx, ly) if raw else (oracle.to_mont(lx), oracle.to_mont(ly))
+        assert (_run(backend, "cstark_debug_fp_op", la, lb, len(la), 10, len(la)) == oracle.fp_mul(oracle.fp_sub(la, lb), lb)).all()
+        assert (_run(backend, "cstark_debug_fp_op", la, lb, len(la), 0, len(la)) == oracle.fp_mul(la, lb)).all()
 
 
 def test_fp6_ops(oracle, backend):
@@ -55,6 +63,13 @@ def test_fp6_ops(oracle, backend):
     n = 512
     a = oracle.to_mont(np.array([rng.randrange(P) for _ in range(6 * n)], np.uint64))
     b = oracle.to_mont(np.array([rng.randrange(P) for _ in range(6 * n)], np.uint64))
+    # memory-form words at the ends of the range in every coefficient (carry bounds of the wide products and their 32-bit carry sums)
+    hi = [P - 1, P - 2, P - 2**32, 2**62, 2**32 - 1, 0]
+    for k in range(16):
+        a[6 * k:6 * k + 6] = [hi[(k + i) % 3 if k < 8 else (k * i) % 6] for i in range(6)]
+        b[6 * k:6 * k + 6] = [hi[(k // 2 + 2 * i) % 3 if k < 8 else (k + i) % 6] for i in range(6)]
+    a[0:6] = P - 1
+    b[0:6] = P - 1
     L = oracle.lib()
     exp_mul = np.zeros(6 * n, np.uint64); exp_sqr = np.zeros(6 * n, np.uint64); exp_inv = np.zeros(6 * n, np.uint64)
     for i in range(n):
