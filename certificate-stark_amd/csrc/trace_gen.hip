@@ -222,38 +222,59 @@ enum { OP_DOUBLE = 0, OP_ADD_MIXED = 1, OP_ADD_FULL = 2, NPHASE = 6, NROLE = 6 }
 #define NOPS6 {NOP, NOP, NOP, NOP, NOP, NOP}
 // Product phases take single-slot operands (optionally scaled by a small integer); every other operand is
 // materialised by a preceding linear phase, so that no lane recomputes a combination another lane also needs.
-__constant__ Instr c_prog[3][NPHASE][NROLE] = {
-    // OP_DOUBLE: X3 = 2XY(Y^2-2XZ-3bZ^2) - 2YZ(X^2+6bXZ-Z^2), ... (complete doubling, ecc.rs:177-242)
-    {{{6, T1(0, 1), T1(0, 1)}, {7, T1(1, 1), T1(1, 1)}, {8, T1(2, 1), T1(2, 1)}, {9, T1(0, 1), T1(1, 1)}, {10, T1(0, 1), T1(2, 1)}, {11, T1(1, 1), T1(2, 1)}},
-     {{12, T1(3, 1), T1(8, 1)}, {13, T1(3, 1), T1(10, 2)}, NOP, NOP, NOP, NOP},
-     {{19, T3(7, 1, 10, -2, 12, -1), NONE}, {20, T3(7, 1, 10, 2, 12, 1), NONE}, {21, T3(6, 1, 8, -1, 13, 1), NONE}, {22, T2(6, 3, 8, 1), NONE}, NOP, NOP},
-     {{14, T1(19, 1), T1(20, 1)}, {15, T1(9, 2), T1(19, 1)}, {16, T1(22, 1), T1(21, 1)}, {17, T1(11, 2), T1(21, 1)}, {18, T1(11, 2), T1(7, 1)}, NOP},
-     {{0, T2(15, 1, 17, -1), NONE}, {1, T2(14, 1, 16, 1), NONE}, {2, T1(18, 4), NONE}, NOP, NOP, NOP},
-     NOPS6},
-    // OP_ADD_MIXED with the affine point in slots 4,5 (complete mixed addition, ecc.rs:330-404)
-    {{{6, T1(0, 1), T1(4, 1)}, {7, T1(1, 1), T1(5, 1)}, {8, T1(26, 1), T1(25, 1)}, {9, T1(4, 1), T1(2, 1)}, {10, T1(5, 1), T1(2, 1)}, {11, T1(2, 1), T1(3, 1)}},
-     {{19, T2(9, 1, 0, 1), NONE}, NOP, NOP, NOP, NOP, NOP},
-     {{12, T1(19, 1), T1(3, 1)}, NOP, NOP, NOP, NOP, NOP},
-     {{20, T3(7, 1, 11, -1, 19, -1), NONE}, {21, T3(7, 1, 11, 1, 19, 1), NONE}, {22, T2(6, 3, 2, 1), NONE}, {23, T3(12, 1, 6, 1, 2, -1), NONE},
-      {24, T2(10, 1, 1, 1), NONE}, {25, T3(8, 1, 6, -1, 7, -1), NONE}},
-     {{13, T1(20, 1), T1(21, 1)}, {14, T1(22, 1), T1(23, 1)}, {15, T1(24, 1), T1(23, 1)}, {16, T1(25, 1), T1(20, 1)}, {17, T1(25, 1), T1(22, 1)}, {18, T1(24, 1), T1(21, 1)}},
-     {{0, T2(16, 1, 15, -1), NONE}, {1, T2(13, 1, 14, 1), NONE}, {2, T2(18, 1, 17, 1), NONE}, NOP, NOP, NOP}},
-    // OP_ADD_FULL with the projective point in slots 27..29 (complete addition, ecc.rs:244-328)
-    {{{6, T1(0, 1), T1(27, 1)}, {7, T1(1, 1), T1(28, 1)}, {8, T1(2, 1), T1(29, 1)}, {9, T1(20, 1), T1(21, 1)}, {10, T1(22, 1), T1(23, 1)}, {11, T1(24, 1), T1(25, 1)}},
-     {{19, T3(10, 1, 6, -1, 8, -1), NONE}, NOP, NOP, NOP, NOP, NOP},
-     {{12, T1(3, 1), T1(8, 1)}, {13, T1(3, 1), T1(19, 1)}, NOP, NOP, NOP, NOP},
-     {{20, T3(7, 1, 12, -1, 19, -1), NONE}, {21, T3(7, 1, 12, 1, 19, 1), NONE}, {22, T2(6, 3, 8, 1), NONE}, {23, T3(13, 1, 6, 1, 8, -1), NONE},
-      {24, T3(9, 1, 6, -1, 7, -1), NONE}, {25, T3(11, 1, 7, -1, 8, -1), NONE}},
-     {{14, T1(20, 1), T1(21, 1)}, {15, T1(22, 1), T1(23, 1)}, {16, T1(25, 1), T1(23, 1)}, {17, T1(24, 1), T1(20, 1)}, {18, T1(24, 1), T1(22, 1)}, {26, T1(25, 1), T1(21, 1)}},
-     {{0, T2(17, 1, 16, -1), NONE}, {1, T2(14, 1, 15, 1), NONE}, {2, T2(26, 1, 18, 1), NONE}, NOP, NOP, NOP}},
-};
+// (the tables exist twice: in constant memory for the kernels, and as constexpr twins from which the linear phases take their
+// compile-time shape -- how many terms a phase uses and which of them only carry coefficients 0, +1, -1)
+#define CS_EC_PROG { \
+    /* OP_DOUBLE: X3 = 2XY(Y^2-2XZ-3bZ^2) - 2YZ(X^2+6bXZ-Z^2), ... (complete doubling, ecc.rs:177-242) */ \
+    {{{6, T1(0, 1), T1(0, 1)}, {7, T1(1, 1), T1(1, 1)}, {8, T1(2, 1), T1(2, 1)}, {9, T1(0, 1), T1(1, 1)}, {10, T1(0, 1), T1(2, 1)}, {11, T1(1, 1), T1(2, 1)}}, \
+     {{12, T1(3, 1), T1(8, 1)}, {13, T1(3, 1), T1(10, 2)}, NOP, NOP, NOP, NOP}, \
+     {{19, T3(7, 1, 10, -2, 12, -1), NONE}, {20, T3(7, 1, 10, 2, 12, 1), NONE}, {21, T3(6, 1, 8, -1, 13, 1), NONE}, {22, T2(6, 3, 8, 1), NONE}, NOP, NOP}, \
+     {{14, T1(19, 1), T1(20, 1)}, {15, T1(9, 2), T1(19, 1)}, {16, T1(22, 1), T1(21, 1)}, {17, T1(11, 2), T1(21, 1)}, {18, T1(11, 2), T1(7, 1)}, NOP}, \
+     {{0, T2(15, 1, 17, -1), NONE}, {1, T2(14, 1, 16, 1), NONE}, {2, T1(18, 4), NONE}, NOP, NOP, NOP}, \
+     NOPS6}, \
+    /* OP_ADD_MIXED with the affine point in slots 4,5 (complete mixed addition, ecc.rs:330-404) */ \
+    {{{6, T1(0, 1), T1(4, 1)}, {7, T1(1, 1), T1(5, 1)}, {8, T1(26, 1), T1(25, 1)}, {9, T1(4, 1), T1(2, 1)}, {10, T1(5, 1), T1(2, 1)}, {11, T1(2, 1), T1(3, 1)}}, \
+     {{19, T2(9, 1, 0, 1), NONE}, NOP, NOP, NOP, NOP, NOP}, \
+     {{12, T1(19, 1), T1(3, 1)}, NOP, NOP, NOP, NOP, NOP}, \
+     {{20, T3(7, 1, 11, -1, 19, -1), NONE}, {21, T3(7, 1, 11, 1, 19, 1), NONE}, {22, T2(6, 3, 2, 1), NONE}, {23, T3(12, 1, 6, 1, 2, -1), NONE}, \
+      {24, T2(10, 1, 1, 1), NONE}, {25, T3(8, 1, 6, -1, 7, -1), NONE}}, \
+     {{13, T1(20, 1), T1(21, 1)}, {14, T1(22, 1), T1(23, 1)}, {15, T1(24, 1), T1(23, 1)}, {16, T1(25, 1), T1(20, 1)}, {17, T1(25, 1), T1(22, 1)}, {18, T1(24, 1), T1(21, 1)}}, \
+     {{0, T2(16, 1, 15, -1), NONE}, {1, T2(13, 1, 14, 1), NONE}, {2, T2(18, 1, 17, 1), NONE}, NOP, NOP, NOP}}, \
+    /* OP_ADD_FULL with the projective point in slots 27..29 (complete addition, ecc.rs:244-328) */ \
+    {{{6, T1(0, 1), T1(27, 1)}, {7, T1(1, 1), T1(28, 1)}, {8, T1(2, 1), T1(29, 1)}, {9, T1(20, 1), T1(21, 1)}, {10, T1(22, 1), T1(23, 1)}, {11, T1(24, 1), T1(25, 1)}}, \
+     {{19, T3(10, 1, 6, -1, 8, -1), NONE}, NOP, NOP, NOP, NOP, NOP}, \
+     {{12, T1(3, 1), T1(8, 1)}, {13, T1(3, 1), T1(19, 1)}, NOP, NOP, NOP, NOP}, \
+     {{20, T3(7, 1, 12, -1, 19, -1), NONE}, {21, T3(7, 1, 12, 1, 19, 1), NONE}, {22, T2(6, 3, 8, 1), NONE}, {23, T3(13, 1, 6, 1, 8, -1), NONE}, \
+      {24, T3(9, 1, 6, -1, 7, -1), NONE}, {25, T3(11, 1, 7, -1, 8, -1), NONE}}, \
+     {{14, T1(20, 1), T1(21, 1)}, {15, T1(22, 1), T1(23, 1)}, {16, T1(25, 1), T1(23, 1)}, {17, T1(24, 1), T1(20, 1)}, {18, T1(24, 1), T1(22, 1)}, {26, T1(25, 1), T1(21, 1)}}, \
+     {{0, T2(17, 1, 16, -1), NONE}, {1, T2(14, 1, 15, 1), NONE}, {2, T2(26, 1, 18, 1), NONE}, NOP, NOP, NOP}}, \
+}
 // operand sums that feed the first product phase of the additions (a "phase -1" run before the program):
 //   mixed: 26 = x2 + y2 (constant per ladder, set once), 25 = X + Y;  full: 20..25 = X1+Y1, X2+Y2, X1+Z1, X2+Z2, Y1+Z1, Y2+Z2
-__constant__ Instr c_pre[3][NROLE] = {
-    NOPS6,
-    {{25, T2(0, 1, 1, 1), NONE}, NOP, NOP, NOP, NOP, NOP},
-    {{20, T2(0, 1, 1, 1), NONE}, {21, T2(27, 1, 28, 1), NONE}, {22, T2(0, 1, 2, 1), NONE}, {23, T2(27, 1, 29, 1), NONE}, {24, T2(1, 1, 2, 1), NONE}, {25, T2(28, 1, 29, 1), NONE}},
-};
+#define CS_EC_PRE { \
+    NOPS6, \
+    {{25, T2(0, 1, 1, 1), NONE}, NOP, NOP, NOP, NOP, NOP}, \
+    {{20, T2(0, 1, 1, 1), NONE}, {21, T2(27, 1, 28, 1), NONE}, {22, T2(0, 1, 2, 1), NONE}, {23, T2(27, 1, 29, 1), NONE}, {24, T2(1, 1, 2, 1), NONE}, {25, T2(28, 1, 29, 1), NONE}}, \
+}
+__constant__ Instr c_prog[3][NPHASE][NROLE] = CS_EC_PROG;
+__constant__ Instr c_pre[3][NROLE] = CS_EC_PRE;
+constexpr Instr k_prog[3][NPHASE][NROLE] = CS_EC_PROG;
+constexpr Instr k_pre[3][NROLE] = CS_EC_PRE;
+#undef CS_EC_PROG
+#undef CS_EC_PRE
+// shape of a linear phase: (number of leading terms any instruction uses) | (bit 4 + k set: term k only has coefficients 0, 1, -1)
+constexpr int lin_shape(const Instr (&ph)[NROLE]) {
+    int nt = 0, unit = 7;
+    for (int m = 0; m < NROLE; m++) {
+        if (ph[m].out < 0) continue;
+        for (int k = 0; k < 3; k++) {
+            const int c = ph[m].a[k].coef;
+            if (c != 0 && k + 1 > nt) nt = k + 1;
+            if (c < -1 || c > 1) unit &= ~(1 << k);
+        }
+    }
+    return nt | (unit << 4);
+}
 #undef NOP
 #undef T1
 #undef T2
@@ -280,15 +301,27 @@ __device__ __forceinline__ void load_programs(ProgLds &p, int tid, int nthreads)
     }
 }
 
-// F_p2 component `comp` (0..2) of an integer combination of slots; comp2 >= 0 adds a second component
-// (the Karatsuba operand sums c_i + c_j)
+// F_p2 component `comp` (0..2) of an integer combination of slots.  SHAPE (lin_shape): only the terms the phase uses are walked, and a
+// term whose coefficients are all 0 / +1 / -1 is a conditional negation instead of a product (a product by a small constant costs 52
+// issue cycles per component, the negation and selects about 20); other coefficients are applied as one multiplication, the same
+// code for every lane.
+template <int SHAPE>
 __device__ __forceinline__ Fp2 lincomb2(const fp (*slot)[6], const Term (&t)[3], int comp, const fp *small) {
     Fp2 r = {0, 0};
 #pragma unroll
-    for (int k = 0; k < 3; k++) { // unused terms have coefficient 0 (and slot 0): they add 0
+    for (int k = 0; k < (SHAPE & 15); k++) { // unused terms have coefficient 0 (and slot 0): they add 0
         const fp *s = slot[t[k].slot];
-        const fp c = small[t[k].coef + 4];
-        r = fp2_add(r, {fp_mul(s[2 * comp], c), fp_mul(s[2 * comp + 1], c)});
+        const int cf = t[k].coef;
+        fp va, vb;
+        if ((SHAPE >> (4 + k)) & 1) {
+            va = s[2 * comp]; vb = s[2 * comp + 1];
+            if (cf < 0) { va = fp_neg(va); vb = fp_neg(vb); }
+            if (cf == 0) { va = 0; vb = 0; }
+        } else {
+            const fp c = small[cf + 4];
+            va = fp_mul(s[2 * comp], c); vb = fp_mul(s[2 * comp + 1], c);
+        }
+        r = fp2_add(r, {va, vb});
     }
     return r;
 }
@@ -307,6 +340,7 @@ __device__ __forceinline__ Fp2 operand2(const fp (*slot)[6], const Term t, int c
 //   recombination  lane (m, r), r < 3: F_p2 coefficient r of the F_p6 result of instruction m
 //   linear phase   lane (m, r): coefficient r of an integer combination of slots
 // Called by all lanes of the workgroup (barriers inside).  prod = this point's [6][6] F_p2 scratch.
+template <int SHAPE>
 __device__ __forceinline__ void run_linear_phase(const Instr (&prog)[NROLE], const fp *small, fp (*slot)[6], int lane, bool enabled) {
     const int m = lane / 3, r = lane % 3;
     Fp2 c = {0, 0};
@@ -314,47 +348,52 @@ __device__ __forceinline__ void run_linear_phase(const Instr (&prog)[NROLE], con
     if (enabled && m < NROLE) {
         const Instr ins = prog[m];
         out = ins.out;
-        if (out >= 0) c = lincomb2(slot, ins.a, r, small);
+        if (out >= 0) c = lincomb2<SHAPE>(slot, ins.a, r, small);
     }
     __syncthreads();
     if (out >= 0) { slot[out][2 * r] = c.a; slot[out][2 * r + 1] = c.b; }
     __syncthreads();
 }
 
-template <int OP>
-__device__ __forceinline__ void run_point_op(const ProgLds &pg, fp (*slot)[6], Fp2 (*prod)[6], int lane, bool enabled) {
-    if (OP != OP_DOUBLE) run_linear_phase(pg.pre[OP], pg.small, slot, lane, enabled);
-#pragma unroll
-    for (int ph = 0; ph < NPHASE; ph++) {
-        if (PHASE_KIND[OP][ph] < 0) break;
-        if (PHASE_KIND[OP][ph] == 1) {
-            const int m = lane / 6, q = lane % 6;
-            if (enabled && m < NROLE) {
-                const Instr ins = pg.prog[OP][ph][m];
-                if (ins.out >= 0) {
-                    const int c1 = q < 3 ? q : (q == 5 ? 1 : 0), c2 = q < 3 ? -1 : (q == 3 ? 1 : 2);
-                    prod[m][q] = fp2_mul(operand2(slot, ins.a[0], c1, c2), operand2(slot, ins.b[0], c1, c2));
+template <int OP, int PH>
+__device__ __forceinline__ void run_phases(const ProgLds &pg, fp (*slot)[6], Fp2 (*prod)[6], int lane, bool enabled) {
+    if constexpr (PH < NPHASE) {
+        if constexpr (PHASE_KIND[OP][PH] >= 0) {
+            if constexpr (PHASE_KIND[OP][PH] == 1) {
+                const int m = lane / 6, q = lane % 6;
+                if (enabled && m < NROLE) {
+                    const Instr ins = pg.prog[OP][PH][m];
+                    if (ins.out >= 0) {
+                        const int c1 = q < 3 ? q : (q == 5 ? 1 : 0), c2 = q < 3 ? -1 : (q == 3 ? 1 : 2);
+                        prod[m][q] = fp2_mul(operand2(slot, ins.a[0], c1, c2), operand2(slot, ins.b[0], c1, c2));
+                    }
                 }
-            }
-            __syncthreads();
-            const int m2 = lane / 3, r = lane % 3;
-            if (enabled && m2 < NROLE) {
-                const int out = pg.prog[OP][ph][m2].out;
-                if (out >= 0) {
-                    const Fp2 d0 = prod[m2][0], d1 = prod[m2][1], d2 = prod[m2][2];
-                    Fp2 c;
-                    if (r == 0) c = fp2_sub(fp2_add(fp2_add(d0, d1), d2), prod[m2][5]);       // d0 + d1 + d2 - e12
-                    else if (r == 1) c = fp2_sub(fp2_sub(prod[m2][3], prod[m2][5]), d0);       // e01 - e12 - d0
-                    else c = fp2_add(fp2_sub(fp2_sub(prod[m2][4], fp2_add(d0, d2)), d2), d1);  // e02 - d0 - 2 d2 + d1
-                    slot[out][2 * r] = c.a;
-                    slot[out][2 * r + 1] = c.b;
+                __syncthreads();
+                const int m2 = lane / 3, r = lane % 3;
+                if (enabled && m2 < NROLE) {
+                    const int out = pg.prog[OP][PH][m2].out;
+                    if (out >= 0) {
+                        const Fp2 d0 = prod[m2][0], d1 = prod[m2][1], d2 = prod[m2][2];
+                        Fp2 c;
+                        if (r == 0) c = fp2_sub(fp2_add(fp2_add(d0, d1), d2), prod[m2][5]);       // d0 + d1 + d2 - e12
+                        else if (r == 1) c = fp2_sub(fp2_sub(prod[m2][3], prod[m2][5]), d0);       // e01 - e12 - d0
+                        else c = fp2_add(fp2_sub(fp2_sub(prod[m2][4], fp2_add(d0, d2)), d2), d1);  // e02 - d0 - 2 d2 + d1
+                        slot[out][2 * r] = c.a;
+                        slot[out][2 * r + 1] = c.b;
+                    }
                 }
+                __syncthreads();
+            } else {
+                run_linear_phase<lin_shape(k_prog[OP][PH])>(pg.prog[OP][PH], pg.small, slot, lane, enabled);
             }
-            __syncthreads();
-        } else {
-            run_linear_phase(pg.prog[OP][ph], pg.small, slot, lane, enabled);
+            run_phases<OP, PH + 1>(pg, slot, prod, lane, enabled);
         }
     }
+}
+template <int OP>
+__device__ __forceinline__ void run_point_op(const ProgLds &pg, fp (*slot)[6], Fp2 (*prod)[6], int lane, bool enabled) {
+    if constexpr (OP != OP_DOUBLE) run_linear_phase<lin_shape(k_pre[OP])>(pg.pre[OP], pg.small, slot, lane, enabled);
+    run_phases<OP, 0>(pg, slot, prod, lane, enabled);
 }
 
 __device__ __forceinline__ int bit_le(const uint8_t *bytes, int i) { return (bytes[i >> 3] >> (i & 7)) & 1; }
