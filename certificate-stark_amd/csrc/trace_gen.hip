@@ -373,11 +373,17 @@ __device__ __forceinline__ void run_phases(const ProgLds &pg, fp (*slot)[6], Fp2
                 if (enabled && m2 < NROLE) {
                     const int out = pg.prog[OP][PH][m2].out;
                     if (out >= 0) {
+                        // r = 0: d0 + d1 + d2 - e12;  r = 1: e01 - e12 - d0;  r = 2: e02 + d1 - d0 - 2 d2.  One five-term form
+                        // t1 + t2 + t3 - t4 - t5 with the operands selected per lane: the three cases as branches would run one after
+                        // the other in the wave (nine F_p2 additions instead of six).
+                        const Fp2 zero = {0, 0};
                         const Fp2 d0 = prod[m2][0], d1 = prod[m2][1], d2 = prod[m2][2];
-                        Fp2 c;
-                        if (r == 0) c = fp2_sub(fp2_add(fp2_add(d0, d1), d2), prod[m2][5]);       // d0 + d1 + d2 - e12
-                        else if (r == 1) c = fp2_sub(fp2_sub(prod[m2][3], prod[m2][5]), d0);       // e01 - e12 - d0
-                        else c = fp2_add(fp2_sub(fp2_sub(prod[m2][4], fp2_add(d0, d2)), d2), d1);  // e02 - d0 - 2 d2 + d1
+                        const Fp2 t1 = r == 0 ? d0 : prod[m2][r + 2];        // d0 | e01 | e02
+                        const Fp2 t2 = r == 1 ? zero : d1;
+                        const Fp2 t3 = r == 0 ? d2 : zero;
+                        const Fp2 t4 = r == 2 ? d0 : prod[m2][5];            // e12 | e12 | d0
+                        const Fp2 t5 = r == 0 ? zero : (r == 1 ? d0 : fp2_dbl(d2));
+                        const Fp2 c = fp2_sub(fp2_sub(fp2_add(fp2_add(t1, t2), t3), t4), t5);
                         slot[out][2 * r] = c.a;
                         slot[out][2 * r + 1] = c.b;
                     }
