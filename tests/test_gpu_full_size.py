@@ -116,6 +116,25 @@ def test_schnorr_air_2_18(oracle, backend):
         assert (got[0:6, 512 * t + 511] == w.sig_rx[t]).all()
 
 
+@pytest.mark.parametrize("switch", ["CSTARK_NTT_V4", "CSTARK_NTT_V2"])
+def test_state_transition_2_20_proof_is_the_same_through_the_other_transform_kernels(switch):
+    """The 2^20-point transforms have three kernel generations (half-tile exchanges by default; CSTARK_NTT_V4=1: whole-tile three-step;
+    CSTARK_NTT_V2=1: two-step, without the dense side tables).  The switches are read once per process, so a child process proves the
+    golden witness through each of the other two: the proof must be the golden one, byte for byte."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, os, hashlib; sys.path.insert(0, %r)\n"
+            "from certificate_stark_amd.prover import ProofOptions, TransactionExample, TransactionMetadata\n"
+            "meta = TransactionMetadata.load(os.path.join(%r, 'tests', 'golden', 'witness_1024_d15.npz'))\n"
+            "print(hashlib.sha256(TransactionExample(ProofOptions(96, 8, 0, 0, 0, 4, 256), meta).prove()).hexdigest())\n") % (ROOT, ROOT)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proof_1024tx_d15_q96.json")))
+    got = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{switch: "1"}), capture_output=True, text=True, timeout=600)
+    assert got.returncode == 0, got.stderr[-2000:]
+    assert got.stdout.strip().splitlines()[-1] == gold["sha256"]
+
+
 def test_state_transition_2_20_complete_proof_verifies(oracle):
     """BASELINE.json's headline configuration end to end: 1024 transfers, 2^20 steps, blowup 8, 96 queries -> proof bytes ->
     restated verifier (and the reference's negative case, src/lib.rs:152-161)."""
