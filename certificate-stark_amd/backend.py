@@ -233,6 +233,16 @@ class Backend:
                                           self._ptr(out), C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0), C.c_uint32(nk)))
         return out
 
+    def merkle_evaluate_constraints(self, lde, depth, t_alpha, t_beta, b_alpha, b_beta, assertion_values, log_blowup, k0=0):
+        """MerkleAir's combined constraint evaluations through the fused evaluator (cstark_merkle_evaluate_constraints)."""
+        nk, width, n = lde.shape
+        out = self.empty_u64(nk, n)
+        arrs = [_np_u64(a) for a in (t_alpha, t_beta, b_alpha, b_beta, assertion_values)]
+        check(self.lib.cstark_merkle_evaluate_constraints(self.ctx, C.c_uint32(depth), self._ptr(lde), *[a.ctypes.data_as(u64p) for a in arrs],
+                                                          self._ptr(out), C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint32(k0),
+                                                          C.c_uint32(nk)))
+        return out
+
     def schnorr_evaluate_constraints(self, lde, aux_lde, t_alpha, t_beta, b_alpha, b_beta, avals_lde, log_blowup, k0=0, n_sig=2):
         """SchnorrAir's combined constraint evaluations through the fused evaluator (cstark_schnorr_evaluate_constraints)."""
         nk, width, n = lde.shape

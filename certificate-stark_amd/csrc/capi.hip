@@ -924,6 +924,7 @@ int cstark_merkle_periodic_columns(uint32_t merkle_depth, uint64_t *out /* [33][
     return CSTARK_OK;
 }
 
+static int merkle_periodic(cstark_ctx *c, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, const PeriodicTable **out);
 int cstark_air_evaluate_transitions(cstark_ctx *c, int air, const uint64_t *d_lde, uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n,
                                     uint32_t log_blowup, uint32_t k0, uint32_t nk) {
     if (!c || !d_lde || !d_out || nk == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_evaluate_transitions: bad argument");
@@ -936,6 +937,14 @@ int cstark_air_evaluate_transitions(cstark_ctx *c, int air, const uint64_t *d_ld
     }
     if (air != CSTARK_AIR_MERKLE_UPDATE) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
     if (log_n < 9) return fail(CSTARK_ERR_INVALID_ARG, "the trace must hold at least one 512-row transaction");
+    const PeriodicTable *pt;
+    RC_TRY(merkle_periodic(c, merkle_depth, log_n, log_blowup, &pt));
+    HIP_TRY(cs::launch_eval_transitions_merkle(d_lde, pt->tab, d_out, log_n, k0, nk, c->stream));
+    return CSTARK_OK;
+}
+// MerkleAir's 33 periodic columns over the LDE domain, [b][33][512]; built once per (depth, trace length, blowup)
+static int merkle_periodic(cstark_ctx *c, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, const PeriodicTable **out) {
+    const int air = CSTARK_AIR_MERKLE_UPDATE;
     const PeriodicTable *pt = nullptr;
     for (const PeriodicTable &t : c->small_periodic)
         if (t.air == air && t.depth == merkle_depth && t.log_n == log_n && t.log_b == log_blowup) pt = &t;
@@ -957,7 +966,7 @@ int cstark_air_evaluate_transitions(cstark_ctx *c, int air, const uint64_t *d_ld
         c->small_periodic.push_back(t);
         pt = &c->small_periodic.back();
     }
-    HIP_TRY(cs::launch_eval_transitions_merkle(d_lde, pt->tab, d_out, log_n, k0, nk, c->stream));
+    *out = pt;
     return CSTARK_OK;
 }
 
@@ -990,10 +999,12 @@ int cstark_schnorr_assertion_polys(cstark_ctx *c, uint64_t *d_out, uint32_t log_
 static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha,
                             const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values,
                             const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
-                            const uint64_t *d_schnorr_aux_lde) {
-    if (!c || !d_lde || (!d_evals && !d_schnorr_aux_lde) || !t_alpha || !t_beta || !b_alpha || !b_beta || !d_out || nk == 0)
+                            const uint64_t *d_schnorr_aux_lde, int merkle_depth_fused = -1) {
+    const bool fused_merkle = merkle_depth_fused >= 0;
+    if (!c || !d_lde || (!d_evals && !d_schnorr_aux_lde && !fused_merkle) || !t_alpha || !t_beta || !b_alpha || !b_beta || !d_out || nk == 0)
         return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: null argument");
     if (d_schnorr_aux_lde && (air != CSTARK_AIR_SCHNORR || log_n < 9)) return fail(CSTARK_ERR_INVALID_ARG, "the fused evaluator is SchnorrAir's");
+    if (fused_merkle && (air != CSTARK_AIR_MERKLE_UPDATE || log_n < 9)) return fail(CSTARK_ERR_INVALID_ARG, "the fused evaluator is MerkleAir's");
     cs::host::AirShape s;
     if (!cs::host::air_shape(air, s, n_items)) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
     if (s.a_const.empty() && !assertion_values) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: assertion values required");
@@ -1087,6 +1098,12 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
         HIP_TRY(cs::launch_schnorr_fused(p, d_schnorr_aux_lde, pt->tab, nk, c->stream));
         p.tsum = d_out;
     }
+    if (fused_merkle) {
+        const PeriodicTable *pt;
+        RC_TRY(merkle_periodic(c, (uint32_t)merkle_depth_fused, log_n, log_blowup, &pt));
+        HIP_TRY(cs::launch_merkle_fused(p, pt->tab, nk, c->stream));
+        p.tsum = d_out;
+    }
     HIP_TRY(cs::launch_air_combine(p, nk, c->stream));
     return CSTARK_OK;
 }
@@ -1096,6 +1113,13 @@ int cstark_air_combine(cstark_ctx *c, int air, uint32_t n_items, const uint64_t 
     if (!d_evals) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: null argument");
     return air_combine_impl(c, air, n_items, d_lde, d_evals, t_alpha, t_beta, b_alpha, b_beta, assertion_values, d_avals_lde, n_avals, d_out, log_n,
                             log_blowup, k0, nk, nullptr);
+}
+int cstark_merkle_evaluate_constraints(cstark_ctx *c, uint32_t merkle_depth, const uint64_t *d_lde, const uint64_t *t_alpha, const uint64_t *t_beta,
+                                       const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values, uint64_t *d_out, uint32_t log_n,
+                                       uint32_t log_blowup, uint32_t k0, uint32_t nk) {
+    if (merkle_depth > 31) return fail(CSTARK_ERR_INVALID_ARG, "cstark_merkle_evaluate_constraints: unsupported Merkle depth");
+    return air_combine_impl(c, CSTARK_AIR_MERKLE_UPDATE, 0, d_lde, nullptr, t_alpha, t_beta, b_alpha, b_beta, assertion_values, nullptr, 0, d_out, log_n,
+                            log_blowup, k0, nk, nullptr, (int)merkle_depth);
 }
 int cstark_schnorr_evaluate_constraints(cstark_ctx *c, uint32_t n_sig, const uint64_t *d_lde, const uint64_t *d_aux_lde, const uint64_t *t_alpha,
                                         const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *d_avals_lde,

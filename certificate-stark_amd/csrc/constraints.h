@@ -66,6 +66,8 @@ hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *
                                            unsigned nk, hipStream_t stream);
 // SchnorrAir, fused: writes sum_i (alpha_i + beta_i x^adj_i) C_i(x) of the nk cosets into p.out (six launches); aux / ptab as for
 // launch_eval_transitions_schnorr.  Follow with launch_air_combine on the same parameters with p.tsum = p.out.
+// MerkleAir likewise (one launch; ptab as for launch_eval_transitions_merkle)
+hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream);
 hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, unsigned nk, hipStream_t stream);
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream);
 

@@ -1481,21 +1481,9 @@ __global__ __launch_bounds__(FNT, part_waves(PART, M)) void k_eval_fused(CeParam
     }
 }
 
-// =====================================================================================================
-// Standalone sub-AIRs (SURVEY.md 8(a) a16): parity-oriented kernels, every constraint materialised.
-// MerkleAir::evaluate_transition  /root/reference/src/merkle/update/air.rs:64-141, :215-289
-__global__ __launch_bounds__(NT) void k_eval_transitions_merkle(const fp *lde, const fp *ptab, fp *out, unsigned log_n, unsigned k0) {
-    const size_t n = (size_t)1 << log_n;
-    const size_t j = blockIdx.x * (size_t)NT + threadIdx.x;
-    const unsigned kk = blockIdx.y;
-    const fp *base = lde + (size_t)kk * 65 * n;
-    Frame f;
-    f.n = n;
-    f.cur_p = base + j;
-    f.next_p = base + ((j + 1) & (n - 1));
-    f.per_p = ptab + (size_t)(k0 + kk) * 33 * 512 + (j & 511);
-    f.pcycle = 512;
-    AccAll acc{out + (size_t)kk * 106 * n + j, n};
+// the transition constraints of MerkleAir at one point, through any accumulator with add(slot, flag, value)
+template <class Acc>
+__device__ __forceinline__ void merkle_transitions(Acc &acc, const Frame &f) {
     // periodic layout: setup, hash(tx), hash_input, finish, hash_mask, ark[28]; the gadget templates read the round
     // constants at P_ARK + i relative to per_p, so give them a view shifted by (5 - P_ARK) columns
     Frame fr = f;
@@ -1524,6 +1512,23 @@ __global__ __launch_bounds__(NT) void k_eval_transitions_merkle(const fp *lde, c
         acc.add(INT_ROOT_RES + i, finish, fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)));
         acc.add(PREV_MATCH_RES + i, finish, fp_sub(f.next(S_INIT + i), cr));
     }
+}
+// =====================================================================================================
+// Standalone sub-AIRs (SURVEY.md 8(a) a16): parity-oriented kernels, every constraint materialised.
+// MerkleAir::evaluate_transition  /root/reference/src/merkle/update/air.rs:64-141, :215-289
+__global__ __launch_bounds__(NT) void k_eval_transitions_merkle(const fp *lde, const fp *ptab, fp *out, unsigned log_n, unsigned k0) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)NT + threadIdx.x;
+    const unsigned kk = blockIdx.y;
+    const fp *base = lde + (size_t)kk * 65 * n;
+    Frame f;
+    f.n = n;
+    f.cur_p = base + j;
+    f.next_p = base + ((j + 1) & (n - 1));
+    f.per_p = ptab + (size_t)(k0 + kk) * 33 * 512 + (j & 511);
+    f.pcycle = 512;
+    AccAll acc{out + (size_t)kk * 106 * n + j, n};
+    merkle_transitions(acc, f);
 }
 // SchnorrAir::evaluate_transition  src/schnorr/air.rs:68-109 -> evaluate_constraints :394-531.
 // lde: [nk][56][n]; aux: [nk][19][n] (LDE of pkey x12 and message-chunk x7 columns); ptab: [b][36][512] (8 masks, 28 ark)
@@ -1662,6 +1667,27 @@ __global__ __launch_bounds__(FNT, PART == SF_REST ? 2 : CS_EC_WAVES) void k_schn
     *o = PART == SF_DBL0 ? acc.total : fp_add(*o, acc.total); // the launches follow each other on the stream
 }
 
+// MerkleAir, fused: the same body as k_eval_transitions_merkle behind the table-driven accumulator; one value per point of the
+// cosets of the constraint-evaluation domain (the others are left alone: k_air_combine writes their zeros).
+__global__ __launch_bounds__(FNT, 2) void k_merkle_fused(AirCombineParams p, const fp *__restrict__ ptab) {
+    __shared__ fp xp_lds[AIR_MAX_GROUPS * FNT];
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kk = blockIdx.y, k = p.k0 + kk;
+    if (k % p.stride) return; // uniform over the workgroup
+    const fp *base = p.lde + (size_t)kk * 65 * n;
+    Frame f;
+    f.n = n;
+    f.cur_p = base + j;
+    f.next_p = base + ((j + 1) & (n - 1));
+    f.per_p = ptab + (size_t)k * 33 * 512 + (j & 511);
+    f.pcycle = 512;
+    for (unsigned g = 0; g < p.n_tgrp; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(p.tgrp_shift[k][g], p.w[(j * p.tgrp_adj[g]) & (n - 1)]);
+    AirSum acc{as_const(p.t_alpha), as_const(p.t_beta), as_const(p.t_grp), xp_lds, acc_zero(), 0, 0};
+    merkle_transitions(acc, f);
+    p.out[(size_t)kk * n + j] = acc.total;
+}
+
 // RangeProofAir::evaluate_transition  src/range/air.rs:60-98 (enforce_double_and_add_step with flag ONE)
 __global__ void k_eval_transitions_range(const fp *lde, fp *out, unsigned log_n) {
     const size_t n = (size_t)1 << log_n;
@@ -1761,6 +1787,12 @@ hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, 
     hipLaunchKernelGGL(k_schnorr_fused<SF_ADD1>, grid, block, 0, stream, p, aux, ptab);
     hipLaunchKernelGGL(k_schnorr_fused<SF_FINAL>, grid, block, 0, stream, p, aux, ptab);
     hipLaunchKernelGGL(k_schnorr_fused<SF_REST>, grid, block, 0, stream, p, aux, ptab);
+    return hipGetLastError();
+}
+hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    if (n % FNT) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(n / FNT), nk), dim3(FNT), 0, stream, p, ptab);
     return hipGetLastError();
 }
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream) {

@@ -690,6 +690,9 @@ int merkle_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
 }
 int merkle_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
+    // CSTARK_MERKLE_FUSED=0 (tuning / debugging): materialise the 106 transition values and merge them generically
+    static const bool fused = [] { const char *e = getenv("CSTARK_MERKLE_FUSED"); return !e || atoi(e) != 0; }();
+    if (fused) return cstark_merkle_evaluate_constraints(c, job.item, a->lde, ta, tb, ba, bb, job.pub.data(), out, job.log_n, 3, 0, 8);
     uint64_t *evals;
     RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
     if (!job.evals_ready) RC_TRY(evaluate_on_ce_cosets(c, a, job, CSTARK_AIR_MERKLE_UPDATE, evals));

@@ -340,6 +340,13 @@ int cstark_air_combine(cstark_ctx *ctx, int air, uint32_t n_items, const uint64_
  * cstark_schnorr_evaluate_transitions followed by cstark_air_combine (exact arithmetic); what cstark_air_prove uses for
  * CSTARK_AIR_SCHNORR.  Replaces the evaluation loop of winterfell's ConstraintEvaluator for SchnorrAir
  * (/root/reference/src/schnorr/air.rs:72-109, :394-531) [UPSTREAM-RECALL for the driver]. */
+/* MerkleAir likewise (one launch over the cosets of its constraint-evaluation domain, blowup 4; src/merkle/update/air.rs:64-141,
+ * :215-369): same values as cstark_air_evaluate_transitions + cstark_air_combine; what cstark_air_prove uses for
+ * CSTARK_AIR_MERKLE_UPDATE.  assertion_values: the 7 + 7 root elements (host). */
+int cstark_merkle_evaluate_constraints(cstark_ctx *ctx, uint32_t merkle_depth, const uint64_t *d_lde, const uint64_t *t_alpha,
+                                       const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta,
+                                       const uint64_t *assertion_values, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup,
+                                       uint32_t k0, uint32_t nk);
 int cstark_schnorr_evaluate_constraints(cstark_ctx *ctx, uint32_t n_sig, const uint64_t *d_lde, const uint64_t *d_aux_lde,
                                         const uint64_t *t_alpha, const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta,
                                         const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n,

@@ -42,6 +42,11 @@ def test_merkle_air(oracle, backend, n_tx, depth):
     out = to_numpy_u64(backend.air_combine(backend.AIR_MERKLE, d_lde, d_ev, ta, tb, ba, bb, desc.a_value, log_b))
     assert (out == ref).all()
     assert not out[1::2].any() and out[0::2].any()      # odd cosets are outside the 4n-point evaluation domain
+    # the fused evaluator (no materialised transition values): same merged evaluations, whole table and a coset window
+    fused = backend.merkle_evaluate_constraints(d_lde, depth, ta, tb, ba, bb, desc.a_value, log_b)
+    assert (to_numpy_u64(fused) == ref).all()
+    part = backend.merkle_evaluate_constraints(d_lde[3:7].contiguous(), depth, ta, tb, ba, bb, desc.a_value, log_b, k0=3)
+    assert (to_numpy_u64(part) == ref[3:7]).all()
 
 
 @pytest.mark.parametrize("number", [0, 1, 2**63 - 1, 0x0123456789ABCDEF])
