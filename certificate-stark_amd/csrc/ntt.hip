@@ -576,6 +576,13 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const f
 #ifndef CS_NTT_V5_ROWS_WAVES
 #define CS_NTT_V5_ROWS_WAVES 6
 #endif
+#ifndef CS_NTT_V5_ROWS_TILES
+#define CS_NTT_V5_ROWS_TILES 1
+#endif
+// Tiles per workgroup of the row pass; > 1: the next tile's loads are issued once the first exchange has freed the data registers and
+// fly behind steps 2 and 3.  Measured (94 columns x 8 cosets): 1 tile, three workgroups per CU 7.85 ms; 4 tiles at four waves per
+// SIMD (128 VGPRs, 2 spilled) 8.27 ms; 2 tiles (16 spilled) 8.77 ms -- more resident workgroups beat the software prefetch again.
+constexpr int V5_ROWS_TILES = CS_NTT_V5_ROWS_TILES;
 template <int LA, int LB, int LC, bool INV>
 __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_COLS_WAVES) void k_ntt_cols_v5(
     const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n, const fp *__restrict__ w, const fp *__restrict__ prescale, size_t in_batch_stride,
@@ -684,54 +691,62 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_ROWS_WAVES) void k_
     fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
     const unsigned s1 = threadIdx.x % T, l1 = threadIdx.x / T; // step 1: s = c2 Cn + c3 fastest across lanes (coalesced row reads)
     const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2; // steps 2 and 3: l fastest across lanes (64-byte transposed stores)
-    const unsigned k10 = xcd_pair_tile(blockIdx.y) * L2;
-
     if (aux_tw) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux_tw[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_r];
     fp a[A];
+    const unsigned in_lane = (l1 << LOGM) + s1;
     {
-        const unsigned in_lane = (l1 << LOGM) + s1;
+        const unsigned k10 = xcd_pair_tile(blockIdx.y * V5_ROWS_TILES) * L2;
 #pragma unroll
         for (int c1 = 0; c1 < A; c1++) a[c1] = (src + ((size_t)k10 << LOGM) + c1 * T)[in_lane];
     }
-    reg_ntt_dif<LA, INV>(a); // step 1: columns c = c1 T + s
-    __syncthreads(); // tw[] ready
     const unsigned jh = t / Cn, c3 = t % Cn;
-    fp z[2][Bn];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-#pragma unroll
-        for (int p = 0; p < A; p++) {
-            const unsigned j1 = cx_brev(p, LA);
-            if ((int)(j1 / AH) == h) tile[((size_t)(j1 % AH) * L2 + l1) * TP + s1] = (j1 == 0) ? a[p] : fp_mul(a[p], tw[j1 * s1]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c2 = 0; c2 < Bn; c2++) z[h][c2] = tile[((size_t)jh * L2 + l) * TP + c2 * Cn + c3];
-        __syncthreads();
-    }
     const unsigned j1s = t / Bn, j2s = t % Bn;
+#pragma unroll 1
+    for (int it = 0; it < V5_ROWS_TILES; it++) {
+        const unsigned k10 = xcd_pair_tile(blockIdx.y * V5_ROWS_TILES + it) * L2;
+        reg_ntt_dif<LA, INV>(a); // step 1: columns c = c1 T + s
+        __syncthreads(); // tw[] ready / the previous tile's last reads are done
+        fp z[2][Bn];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        reg_ntt_dif<LB, INV>(z[h]);
+        for (int h = 0; h < 2; h++) {
 #pragma unroll
-        for (int p = 0; p < Bn; p++) {
-            const unsigned j2 = cx_brev(p, LB);
-            const fp v = (j2 == 0) ? z[h][p] : fp_mul(z[h][p], tw[(A * j2) * c3]);
-            tile[((size_t)jh * L2 + l) * TP + j2 * Cn + (c3 ^ (j2 % Cn))] = v;
+            for (int p = 0; p < A; p++) {
+                const unsigned j1 = cx_brev(p, LA);
+                if ((int)(j1 / AH) == h) tile[((size_t)(j1 % AH) * L2 + l1) * TP + s1] = (j1 == 0) ? a[p] : fp_mul(a[p], tw[j1 * s1]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c2 = 0; c2 < Bn; c2++) z[h][c2] = tile[((size_t)jh * L2 + l) * TP + c2 * Cn + c3];
+            __syncthreads();
         }
-        __syncthreads();
-        fp x[Cn];
+        if (it + 1 < V5_ROWS_TILES) { // a[] is dead: the next tile's loads fly behind steps 2 and 3 of this one
+            const unsigned k11 = xcd_pair_tile(blockIdx.y * V5_ROWS_TILES + it + 1) * L2;
 #pragma unroll
-        for (int q = 0; q < Cn; q++) x[q] = tile[((size_t)j1s * L2 + l) * TP + j2s * Cn + (q ^ (j2s % Cn))];
-        if (h == 0) __syncthreads();
-        reg_ntt_dif<LC, INV>(x);
-        const unsigned out_lane = (((j1s + AH * h) + A * j2s) << log_r) + l; // output frequency k2 = j1 + A j2 + A Bn j3
+            for (int c1 = 0; c1 < A; c1++) a[c1] = (src + ((size_t)k11 << LOGM) + c1 * T)[in_lane];
+        }
 #pragma unroll
-        for (int p = 0; p < Cn; p++) {
-            fp val = x[p];
-            if (do_scale) val = fp_mul(val, post_scale);
-            (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
+        for (int h = 0; h < 2; h++) {
+            reg_ntt_dif<LB, INV>(z[h]);
+#pragma unroll
+            for (int p = 0; p < Bn; p++) {
+                const unsigned j2 = cx_brev(p, LB);
+                const fp v = (j2 == 0) ? z[h][p] : fp_mul(z[h][p], tw[(A * j2) * c3]);
+                tile[((size_t)jh * L2 + l) * TP + j2 * Cn + (c3 ^ (j2 % Cn))] = v;
+            }
+            __syncthreads();
+            fp x[Cn];
+#pragma unroll
+            for (int q = 0; q < Cn; q++) x[q] = tile[((size_t)j1s * L2 + l) * TP + j2s * Cn + (q ^ (j2s % Cn))];
+            if (h == 0) __syncthreads();
+            reg_ntt_dif<LC, INV>(x);
+            const unsigned out_lane = (((j1s + AH * h) + A * j2s) << log_r) + l; // output frequency k2 = j1 + A j2 + A Bn j3
+#pragma unroll
+            for (int p = 0; p < Cn; p++) {
+                fp val = x[p];
+                if (do_scale) val = fp_mul(val, post_scale);
+                (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
+            }
         }
     }
 }
@@ -748,7 +763,8 @@ hipError_t launch_v5(const NttArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL((k_ntt_cols_v5<RA, RB, RC, INV>), dim3(a.batch, (unsigned)GC::M / L2, a.width), dim3(GR::NT), lds_a, stream, a.in, a.scratch, a.log_n,
                        a.w, a.prescale, a.in_batch_stride, a.scratch_batch_stride, a.prescale_batch_stride, a.aux, a.prescale ? a.aux_ps : nullptr,
                        a.aux_ps_batch_stride);
-    hipLaunchKernelGGL((k_ntt_rows_v5<CA, CB, CC, INV>), dim3(a.batch, (unsigned)GR::M / L2, a.width), dim3(GC::NT), lds_b, stream, (const fp *)a.scratch,
+    static_assert((GR::M / L2) % V5_ROWS_TILES == 0, "tiles per workgroup");
+    hipLaunchKernelGGL((k_ntt_rows_v5<CA, CB, CC, INV>), dim3(a.batch, (unsigned)GR::M / L2 / V5_ROWS_TILES, a.width), dim3(GC::NT), lds_b, stream, (const fp *)a.scratch,
                        a.out, a.log_n, a.w, a.post_scale, a.do_scale ? 1 : 0, a.scratch_batch_stride, a.out_batch_stride,
                        a.aux ? a.aux + GR::M : nullptr);
     return hipGetLastError();
