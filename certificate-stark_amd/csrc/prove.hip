@@ -163,6 +163,50 @@ __global__ void k_gather_paths(const uint4 *__restrict__ nodes, uint32_t log_lea
         out[((size_t)q * log_leaves + lvl) * 2 + half] = nodes[2 * node + half];
     }
 }
+// All opening gathers of a proof in ONE launch (they were twenty launches of a few microseconds each, 0.14 ms of launch latency):
+// job = blockIdx.y, query = blockIdx.x.  kind 0: row pos[q] of a coset-major table (as k_gather_rows); kind 1: authentication path
+// of leaf pos[q] (as k_gather_paths; a = log2 of the leaf count).
+struct GatherJob { const void *src; void *out; const uint32_t *pos; uint32_t kind, a, log_n, log_b, count; };
+constexpr int MAX_GATHER_JOBS = 32;
+struct GatherBatch { GatherJob job[MAX_GATHER_JOBS]; };
+__global__ void k_gather_batch(GatherBatch b) {
+    const GatherJob g = b.job[blockIdx.y];
+    const uint32_t q = blockIdx.x;
+    if (q >= g.count) return;
+    if (g.kind == 0) {
+        const uint64_t *lde = (const uint64_t *)g.src;
+        uint64_t *out = (uint64_t *)g.out;
+        const uint32_t width = g.a, i = g.pos[q], k = i & ((1u << g.log_b) - 1), j = i >> g.log_b;
+        for (uint32_t c = threadIdx.x; c < width; c += blockDim.x) out[(size_t)q * width + c] = lde[(((size_t)k * width + c) << g.log_n) + j];
+    } else {
+        const uint4 *nodes = (const uint4 *)g.src;
+        uint4 *out = (uint4 *)g.out;
+        const uint32_t log_leaves = g.a;
+        for (uint32_t t = threadIdx.x; t < 2 * log_leaves; t += blockDim.x) {
+            const uint32_t lvl = t >> 1, half = t & 1;
+            const size_t node = ((((size_t)1 << log_leaves) + g.pos[q]) >> lvl) ^ 1;
+            out[((size_t)q * log_leaves + lvl) * 2 + half] = nodes[2 * node + half];
+        }
+    }
+}
+struct GatherList {
+    GatherBatch b{};
+    int n = 0;
+    uint32_t max_count = 0;
+    void rows(const uint64_t *lde, uint32_t width, uint32_t log_n, uint32_t log_b, const uint32_t *pos, void *out, uint32_t count) {
+        b.job[n++] = GatherJob{lde, out, pos, 0u, width, log_n, log_b, count};
+        if (count > max_count) max_count = count;
+    }
+    void paths(const uint8_t *nodes, uint32_t log_leaves, const uint32_t *pos, void *out, uint32_t count) {
+        b.job[n++] = GatherJob{nodes, out, pos, 1u, log_leaves, 0u, 0u, count};
+        if (count > max_count) max_count = count;
+    }
+    hipError_t launch(hipStream_t st) {
+        if (n == 0 || max_count == 0) return hipSuccess;
+        k_gather_batch<<<dim3(max_count, (unsigned)n), 128, 0, st>>>(b);
+        return hipGetLastError();
+    }
+};
 __global__ void k_gather_pub(const uint64_t *__restrict__ trace, size_t n, uint64_t *__restrict__ out) {
     const uint32_t t = threadIdx.x;
     if (t < 14) out[t] = trace[(size_t)(58 + (t % 7)) * n + (t < 7 ? 0 : n - 1)]; // PREV_TREE_ROOT_POS, src/prover.rs:106-129
@@ -533,11 +577,13 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
     const size_t o_tpath = off; off += nq * log_N * 32;
     const size_t o_crows = off; off += nq * ce * 8;
     const size_t o_cpath = off; off += nq * log_N * 32;
+    if (2 * (size_t)n_layers + 4 > MAX_GATHER_JOBS) return fail(CSTARK_ERR_UNSUPPORTED, "too many FRI layers for one opening launch");
+    GatherList gl;
     if (d_trace_rows) HIP_TRY(hipMemcpyAsync(o + o_trows, d_trace_rows, nq * W * 8, hipMemcpyDeviceToDevice, st));
-    else k_gather_rows<<<(unsigned)nq, 128, 0, st>>>(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, (uint64_t *)(o + o_trows));
-    k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->tnodes, log_N, a->d_pos, (uint4 *)(o + o_tpath));
-    k_gather_rows<<<(unsigned)nq, 64, 0, st>>>(a->clde, (uint32_t)ce, log_n, log_b, a->d_pos, (uint64_t *)(o + o_crows));
-    k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->cnodes, log_N, a->d_pos, (uint4 *)(o + o_cpath));
+    else gl.rows(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, o + o_trows, (uint32_t)nq);
+    gl.paths(a->tnodes, log_N, a->d_pos, o + o_tpath, (uint32_t)nq);
+    gl.rows(a->clde, (uint32_t)ce, log_n, log_b, a->d_pos, o + o_crows, (uint32_t)nq);
+    gl.paths(a->cnodes, log_N, a->d_pos, o + o_cpath, (uint32_t)nq);
     std::vector<size_t> o_lrows(n_layers), o_lpath(n_layers);
     {
         unsigned g2 = log_N;
@@ -545,12 +591,12 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
             const unsigned np = (unsigned)lpos[l].size(), lr = g2 - 2;
             o_lrows[l] = off; off += (size_t)np * 32;
             o_lpath[l] = off; off += (size_t)np * lr * 32;
-            k_gather_rows<<<np, 64, 0, st>>>(a->layer[l], 4, lr, 0, a->d_pos + 256 * (l + 1), (uint64_t *)(o + o_lrows[l]));
-            k_gather_paths<<<np, 64, 0, st>>>((const uint4 *)a->lnodes[l], lr, a->d_pos + 256 * (l + 1), (uint4 *)(o + o_lpath[l]));
+            gl.rows(a->layer[l], 4, lr, 0, a->d_pos + 256 * (l + 1), o + o_lrows[l], np);
+            gl.paths(a->lnodes[l], lr, a->d_pos + 256 * (l + 1), o + o_lpath[l], np);
             g2 -= 2;
         }
     }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(gl.launch(st));
     std::vector<uint8_t> open(off);
     HIP_TRY(hipMemcpyAsync(open.data(), o, off, hipMemcpyDeviceToHost, st));
     STAGE();
@@ -942,10 +988,12 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     const size_t o_tpath = off; off += nq * log_N * 32;
     const size_t o_crows = off; off += nq * CW * 8;
     const size_t o_cpath = off; off += nq * log_N * 32;
-    k_gather_rows<<<(unsigned)nq, 128, 0, st>>>(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, (uint64_t *)(o + o_trows));
-    k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->tnodes, log_N, a->d_pos, (uint4 *)(o + o_tpath));
-    k_gather_rows<<<(unsigned)nq, 64, 0, st>>>(cldes, (uint32_t)CW, log_n, log_b, a->d_pos, (uint64_t *)(o + o_crows));
-    k_gather_paths<<<(unsigned)nq, 64, 0, st>>>((const uint4 *)a->cnodes, log_N, a->d_pos, (uint4 *)(o + o_cpath));
+    if (2 * (size_t)n_layers + 4 > MAX_GATHER_JOBS) return fail(CSTARK_ERR_UNSUPPORTED, "too many FRI layers for one opening launch");
+    GatherList gl;
+    gl.rows(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, o + o_trows, (uint32_t)nq);
+    gl.paths(a->tnodes, log_N, a->d_pos, o + o_tpath, (uint32_t)nq);
+    gl.rows(cldes, (uint32_t)CW, log_n, log_b, a->d_pos, o + o_crows, (uint32_t)nq);
+    gl.paths(a->cnodes, log_N, a->d_pos, o + o_cpath, (uint32_t)nq);
     std::vector<size_t> o_lrows(n_layers), o_lpath(n_layers);
     {
         unsigned g2 = log_N;
@@ -953,12 +1001,12 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
             const unsigned np = (unsigned)lpos[l].size(), lr = g2 - 2;
             o_lrows[l] = off; off += (size_t)np * 32 * m;
             o_lpath[l] = off; off += (size_t)np * lr * 32;
-            k_gather_rows<<<np, 64, 0, st>>>(layer[l], 4 * m, lr, 0, a->d_pos + 256 * (l + 1), (uint64_t *)(o + o_lrows[l]));
-            k_gather_paths<<<np, 64, 0, st>>>((const uint4 *)a->lnodes[l], lr, a->d_pos + 256 * (l + 1), (uint4 *)(o + o_lpath[l]));
+            gl.rows(layer[l], 4 * m, lr, 0, a->d_pos + 256 * (l + 1), o + o_lrows[l], np);
+            gl.paths(a->lnodes[l], lr, a->d_pos + 256 * (l + 1), o + o_lpath[l], np);
             g2 -= 2;
         }
     }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(gl.launch(st));
     std::vector<uint8_t> open(off);
     HIP_TRY(hipMemcpyAsync(open.data(), o, off, hipMemcpyDeviceToHost, st));
     STAGE();
