@@ -101,6 +101,33 @@ __global__ __launch_bounds__(256) void k_merkle_level(uint8_t *__restrict__ node
     const size_t i = cnt + t;
     merge_node(nodes + 64 * i, nodes + 32 * i);
 }
+// Two tree levels per launch: thread t merges the parents cnt + 2t and cnt + 2t + 1 from their four children and then their own
+// parent cnt / 2 + t from the two digests it still holds.  Same number of compressions, half the launches -- the levels below a few
+// thousand nodes are bound by launch latency (4.6 us each), and a proof builds eleven trees.
+__global__ __launch_bounds__(256) void k_merkle_level2(uint8_t *__restrict__ nodes, size_t cnt) {
+    const size_t t = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (t >= cnt / 2) return;
+    const size_t i0 = cnt + 2 * t;
+    const uint4 *src = reinterpret_cast<const uint4 *>(nodes + 64 * i0); // children 2 i0 .. 2 i0 + 3: 128 contiguous bytes
+    uint32_t m[16];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint4 a = src[4 * h], b = src[4 * h + 1], c = src[4 * h + 2], d = src[4 * h + 3];
+        const uint32_t mm[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+        uint32_t cv[8] = {IV0, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+        compress(cv, mm, 64, CHUNK_START | CHUNK_END | ROOT);
+        uint4 *dst = reinterpret_cast<uint4 *>(nodes + 32 * (i0 + h));
+        dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+        dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+#pragma unroll
+        for (int q = 0; q < 8; q++) m[8 * h + q] = cv[q];
+    }
+    uint32_t cv[8] = {IV0, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+    compress(cv, m, 64, CHUNK_START | CHUNK_END | ROOT);
+    uint4 *dst = reinterpret_cast<uint4 *>(nodes + 32 * (cnt / 2 + t));
+    dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
 // the last levels (<= 1024 parents) in one workgroup
 __global__ __launch_bounds__(1024) void k_merkle_top(uint8_t *__restrict__ nodes, size_t cnt) {
     for (; cnt >= 1; cnt >>= 1) {
@@ -126,8 +153,15 @@ hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, u
 
 hipError_t merkle_build(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream) {
     size_t cnt = ((size_t)1 << log_leaves) >> 1;
-    for (; cnt > 1024; cnt >>= 1)
-        hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d_nodes, cnt);
+    while (cnt > 1024) {
+        if (cnt >= 4096) { // two levels: parents [cnt, 2 cnt) and [cnt / 2, cnt)
+            hipLaunchKernelGGL(k_merkle_level2, dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, stream, d_nodes, cnt);
+            cnt >>= 2;
+        } else {
+            hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, d_nodes, cnt);
+            cnt >>= 1;
+        }
+    }
     if (cnt >= 1) hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(1024), 0, stream, d_nodes, cnt);
     return hipGetLastError();
 }
