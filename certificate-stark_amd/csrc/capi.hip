@@ -461,7 +461,7 @@ int cstark_evaluate_polys_at(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t w
     HIP_TRY(hipMemcpyAsync(d_pts, points, (size_t)npts * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(cs::poly_eval(d_coeffs, width, log_n, d_pts, npts, d_out, d_scr, c->stream));
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)npts * width * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(cs::stream_wait(c->stream));
     return CSTARK_OK;
 }
 
@@ -489,7 +489,7 @@ int cstark_deep_composition(cstark_ctx *c, const uint64_t *d_trace_lde, const ui
         c->desc_bytes = bytes;
     }
     HIP_TRY(hipMemcpyAsync(c->desc_buf, blk.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(cs::stream_wait(c->stream));
     const uint64_t *d = (const uint64_t *)c->desc_buf;
     cs::DeepParams p{};
     p.trace_lde = d_trace_lde; p.comp_lde = d_comp_lde; p.w = plan->w; p.coef = d; p.ood = d + nco; p.shifts = d + 2 * nco; p.out = d_out;
@@ -533,7 +533,7 @@ int cstark_evaluate_polys_at_ext(cstark_ctx *c, const uint64_t *d_coeffs, uint32
     uint64_t *d_out = (uint64_t *)c->desc_buf, *d_scr = d_out + (size_t)m * width;
     HIP_TRY(cs::poly_eval_ext(d_coeffs, width, log_n, z, m, d_out, d_scr, c->stream));
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)m * width * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(cs::stream_wait(c->stream));
     return CSTARK_OK;
 }
 } // extern "C"
@@ -565,7 +565,7 @@ int deep_composition_ext_cosets(cstark_ctx *c, const uint64_t *d_trace_lde, cons
         c->desc_bytes = bytes;
     }
     HIP_TRY(hipMemcpyAsync(c->desc_buf, blk.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(cs::stream_wait(c->stream));
     cs::DeepExtParams p{};
     p.trace_lde = d_trace_lde; p.comp_lde = d_comp_lde; p.w = plan->w; p.coef = (const uint64_t *)c->desc_buf; p.shifts = p.coef + nco; p.out = d_out;
     const EX zz = ex_load(z, m), zw = ex_scale(zz, root_of_unity(log_n)), zb = ex_pow(zz, n_comp, m), da = ex_load(deg_a, m), db = ex_load(deg_b, m);
@@ -685,7 +685,7 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
     constexpr size_t COEF_WORDS = (size_t)cs::CE_MAX_SETS * cs::CE_COEF_WORDS;
     if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, (COEF_WORDS + (size_t)cs::CE_MAX_SETS * cs::CE_RTAB_WORDS) * 8));
     HIP_TRY(hipMemcpyAsync(c->coef_buf, coeffs, (size_t)m * sizeof(cstark_tx_coeffs), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream)); // the caller's struct may be transient
+    HIP_TRY(cs::stream_wait(c->stream)); // the caller's struct may be transient
     p.coef = c->coef_buf;
     p.rtab = c->coef_buf + COEF_WORDS;
     p.m = m;

@@ -241,16 +241,6 @@ int arena_extra(cstark_ctx *c, ProveArena *a, size_t slot, T **p, size_t bytes) 
     return CSTARK_OK;
 }
 
-// The channel waits for a root or a frame a dozen times per proof with the GPU idle until the host answers: poll the stream instead of
-// blocking in hipStreamSynchronize (whose wake-up costs tens of microseconds).  CSTARK_SYNC_BLOCK=1 restores the blocking wait.
-static hipError_t channel_sync(hipStream_t st) {
-    static const bool block = [] { const char *e = getenv("CSTARK_SYNC_BLOCK"); return e && atoi(e) != 0; }();
-    if (block) return hipStreamSynchronize(st);
-    hipError_t e;
-    while ((e = hipStreamQuery(st)) == hipErrorNotReady) {}
-    return e;
-}
-
 unsigned num_fri_layers(unsigned log_domain, unsigned log_max_remainder) {
     unsigned l = 0;
     while (log_domain > log_max_remainder) { log_domain -= 2; l++; }
@@ -424,7 +414,7 @@ int phase_evaluate(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint8_t *d_l
     RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
     HIP_TRY(hipMemcpyAsync(R.trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
-    HIP_TRY(channel_sync(st)); // also completes the public-input copy of job.build
+    HIP_TRY(cs::stream_wait(st)); // also completes the public-input copy of job.build
     static const bool hostprof = getenv("CSTARK_HOSTPROF") != nullptr; // debugging: host time between the root and the evaluation launches
     const auto hp0 = std::chrono::steady_clock::now();
     if (job.pub_staging) job.pub.assign(job.pub_staging, job.pub_staging + 14);
@@ -484,7 +474,7 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
     RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
     HIP_TRY(hipMemcpyAsync(R.cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
-    HIP_TRY(channel_sync(st));
+    HIP_TRY(cs::stream_wait(st));
     coin.reseed(R.cons_root);
 
     // ---- out-of-domain frame ----------------------------------------------------------------------------------------------
@@ -531,7 +521,7 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
         RC_TRY(cstark_hash_rows_fn(c, hf, a->layer[l], a->lnodes[l] + 32 * rows, 4, lg - 2, 0, 0, 1));
         RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - 2));
         HIP_TRY(hipMemcpyAsync(&R.layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
-        HIP_TRY(channel_sync(st));
+        HIP_TRY(cs::stream_wait(st));
         coin.reseed(&R.layer_roots[32 * l]);
         const uint64_t alpha = coin.draw();
         RC_TRY(cstark_fri_fold4(c, a->layer[l], a->layer[l + 1], lg, offset, alpha));
@@ -540,7 +530,7 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
     }
     R.remainder.assign((size_t)1 << lg, 0);
     HIP_TRY(hipMemcpyAsync(R.remainder.data(), a->layer[n_layers], R.remainder.size() * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(channel_sync(st));
+    HIP_TRY(cs::stream_wait(st));
     hash_elements(hf, R.remainder.data(), R.remainder.size(), R.rem_commit);
     coin.reseed(R.rem_commit);
     STAGE();
@@ -610,7 +600,7 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
     std::vector<uint8_t> open(off);
     HIP_TRY(hipMemcpyAsync(open.data(), o, off, hipMemcpyDeviceToHost, st));
     STAGE();
-    HIP_TRY(channel_sync(st));
+    HIP_TRY(cs::stream_wait(st));
     a->timed = true;
 
     // ---- serialise ----------------------------------------------------------------------------------------------------------------
@@ -845,7 +835,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     uint8_t trace_root[32], cons_root[32];
     HIP_TRY(hipMemcpyAsync(trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
-    HIP_TRY(channel_sync(st));
+    HIP_TRY(cs::stream_wait(st));
     if (job.pub_staging) job.pub.assign(job.pub_staging, job.pub_staging + 14);
 
     Coin coin;
@@ -900,7 +890,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
     HIP_TRY(hipMemcpyAsync(cons_root, a->cnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
-    HIP_TRY(channel_sync(st));
+    HIP_TRY(cs::stream_wait(st));
     coin.reseed(cons_root);
 
     const EX z = draw_e(), zw = ex_scale(z, root_of_unity(log_n)), zb = ex_pow(z, ce, m);
@@ -955,7 +945,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
         RC_TRY(cstark_hash_rows_fn(c, hf, layer[l], a->lnodes[l] + 32 * rows, 4 * m, lg - 2, 0, 0, 1)); // [m][4][rows]: component-major rows
         RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - 2));
         HIP_TRY(hipMemcpyAsync(&layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
-        HIP_TRY(channel_sync(st));
+        HIP_TRY(cs::stream_wait(st));
         coin.reseed(&layer_roots[32 * l]);
         const EX alpha = draw_e();
         RC_TRY(cstark_fri_fold4_ext(c, layer[l], layer[l + 1], lg, offset, m, alpha.c));
@@ -965,7 +955,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     const size_t R = (size_t)1 << lg;
     std::vector<uint64_t> remainder(m * R);
     HIP_TRY(hipMemcpyAsync(remainder.data(), layer[n_layers], remainder.size() * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(channel_sync(st));
+    HIP_TRY(cs::stream_wait(st));
     uint8_t rem_commit[32];
     hash_elements(hf, remainder.data(), remainder.size(), rem_commit);
     coin.reseed(rem_commit);
@@ -1020,7 +1010,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     std::vector<uint8_t> open(off);
     HIP_TRY(hipMemcpyAsync(open.data(), o, off, hipMemcpyDeviceToHost, st));
     STAGE();
-    HIP_TRY(channel_sync(st));
+    HIP_TRY(cs::stream_wait(st));
     a->timed = true;
 #undef STAGE
 
