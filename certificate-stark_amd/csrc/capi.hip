@@ -537,6 +537,33 @@ int cstark_evaluate_polys_at_ext(cstark_ctx *c, const uint64_t *d_coeffs, uint32
     return CSTARK_OK;
 }
 } // extern "C"
+// internal (ctx.h): both halves of the out-of-domain frame with ONE upload, one readback and one wait -- the trace polynomials at
+// (z, z w) and the composition columns at z^b; out_trace [2][width], out_comp [n_comp] (host)
+int evaluate_ood_frames(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, const uint64_t *d_ccoef, uint32_t n_comp, uint32_t log_n,
+                        const uint64_t zpts[2], uint64_t zb, uint64_t *out_trace, uint64_t *out_comp) {
+    if (!c || !d_coeffs || !d_ccoef || !out_trace || !out_comp || width == 0 || n_comp == 0) return fail(CSTARK_ERR_INVALID_ARG, "evaluate_ood_frames: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n_out = 2 * (size_t)width + n_comp;
+    const size_t scr_t = cs::poly_eval_scratch_words(width, log_n, 2), scr_c = cs::poly_eval_scratch_words(n_comp, log_n, 1);
+    const size_t need = (4 + n_out + scr_t + scr_c) * 8;
+    if (need > c->desc_bytes) {
+        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); c->desc_buf = nullptr; c->desc_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->desc_buf, need));
+        c->desc_bytes = need;
+    }
+    uint64_t *d_pts = (uint64_t *)c->desc_buf, *d_out = d_pts + 4, *d_scr = d_out + n_out;
+    const uint64_t pts[3] = {zpts[0], zpts[1], zb};
+    HIP_TRY(hipMemcpyAsync(d_pts, pts, sizeof pts, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(cs::poly_eval(d_coeffs, width, log_n, d_pts, 2, d_out, d_scr, c->stream));
+    HIP_TRY(cs::poly_eval(d_ccoef, n_comp, log_n, d_pts + 2, 1, d_out + 2 * (size_t)width, d_scr + scr_t, c->stream));
+    std::vector<uint64_t> host(n_out);
+    HIP_TRY(hipMemcpyAsync(host.data(), d_out, n_out * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(cs::stream_wait(c->stream));
+    memcpy(out_trace, host.data(), 2 * (size_t)width * 8);
+    memcpy(out_comp, host.data() + 2 * (size_t)width, (size_t)n_comp * 8);
+    return CSTARK_OK;
+}
+
 // internal (ctx.h): the first nk cosets only, d_out = [m][nk][n]
 int deep_composition_ext_cosets(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
                                 const uint64_t *z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,

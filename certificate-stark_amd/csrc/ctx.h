@@ -119,6 +119,8 @@ int tx_build_trace_split(cstark_ctx *c, uint64_t *d_trace);
 int lde_column_range(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n,
                      uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);
 // internal (capi.hip): cstark_deep_composition_ext restricted to the first nk cosets, d_out = [m][nk][n]
+int evaluate_ood_frames(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, const uint64_t *d_ccoef, uint32_t n_comp, uint32_t log_n,
+                        const uint64_t zpts[2], uint64_t zb, uint64_t *out_trace, uint64_t *out_comp);
 int deep_composition_ext_cosets(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
                                 const uint64_t *z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
                                 const uint64_t *delta, const uint64_t *deg_a, const uint64_t *deg_b, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup,

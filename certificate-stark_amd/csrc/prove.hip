@@ -483,8 +483,7 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
     const uint64_t zb = host::pow(z, ce);
     std::vector<uint64_t> &ood_trace = R.ood_trace, &ood_comp = R.ood_comp;
     ood_trace.assign(2 * W, 0); ood_comp.assign(ce, 0);
-    RC_TRY(cstark_evaluate_polys_at(c, a->coeffs, (uint32_t)W, log_n, zpts, 2, ood_trace.data()));
-    RC_TRY(cstark_evaluate_polys_at(c, a->ccoef, (uint32_t)ce, log_n, &zb, 1, ood_comp.data()));
+    RC_TRY(evaluate_ood_frames(c, a->coeffs, (uint32_t)W, a->ccoef, (uint32_t)ce, log_n, zpts, zb, ood_trace.data(), ood_comp.data()));
     uint8_t dg[32];
     hash_elements(hf, ood_trace.data(), 2 * W, dg); coin.reseed(dg);
     hash_elements(hf, ood_comp.data(), ce, dg); coin.reseed(dg);
