@@ -571,7 +571,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const f
 // overlap too little.)  Register need after the cheaper field product: 62 (rows) / 95 (columns) VGPRs.
 // -----------------------------------------------------------------------------------------------------
 #ifndef CS_NTT_V5_COLS_WAVES
-#define CS_NTT_V5_COLS_WAVES 6
+#define CS_NTT_V5_COLS_WAVES 5 // 95 VGPRs, no spills, two workgroups per CU; 6 (80 VGPRs, 8 spilled -> 30 % more HBM writes): LDE 7.80 vs 7.58 ms
 #endif
 #ifndef CS_NTT_V5_ROWS_WAVES
 #define CS_NTT_V5_ROWS_WAVES 6
