@@ -565,7 +565,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const f
 // 16 * 8 * 8 split of 1024 points), with each of the two exchanges done in TWO HALVES through a tile of half the size.  The tasks
 // of a thread are task h = 0, 1 with k1 in [8 h, 8 h + 8): step 1 writes its eight outputs of half h, every thread reads the
 // inputs of its task h, then the same buffer takes the other half.  32 KB of tile + 8 KB of twiddles per workgroup instead of
-// 72: three (row pass: 34.8 + 8 KB) to four workgroups per CU instead of two, so that a CU always holds workgroups in
+// 72: LDS no longer limits residency (registers do: three workgroups per CU in the row pass, two in the column pass), so a CU holds workgroups in
 // different phases -- the loads and stores of one run under the arithmetic of the others.  (v4 measured with its arithmetic
 // alone 5.55 ms, with its memory traffic alone 5.74 ms, together 8.0 ms for 94 columns x 8 cosets: two resident workgroups
 // overlap too little.)  Register need after the cheaper field product: 62 (rows) / 95 (columns) VGPRs.
