@@ -83,6 +83,41 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ 
     dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
 }
 
+// Narrow tables (one or two compressions per row: the composition columns): one lane per LEAF, the cosets of a row in neighbouring
+// lanes, so that the 32-byte digests of a wave are 2 KB of consecutive leaves (leaf = b j + k).  The lane-per-row kernel above writes
+// them 32 bytes at a stride of 32 b -- hidden behind twelve compressions for the trace, not behind one: 0.37 -> 0.2x ms for the
+// 8 x 2^23 composition table.  Reads become 64-byte segments (8 consecutive rows of one coset and column).  All b cosets present.
+__global__ __launch_bounds__(256) void k_hash_rows_narrow(const uint64_t *__restrict__ lde, uint8_t *__restrict__ leaves, unsigned width, unsigned log_n,
+                                                          unsigned log_b) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t leaf = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (leaf >= (n << log_b)) return;
+    const size_t j = leaf >> log_b;
+    const unsigned kk = (unsigned)(leaf & ((1u << log_b) - 1));
+    const uint64_t *col = lde + (size_t)kk * width * n + j;
+    uint32_t cv[8] = {IV0, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+    const unsigned nblocks = (width + 7) / 8;
+    for (unsigned b = 0; b < nblocks; b++) {
+        uint32_t m[16];
+        const unsigned c0 = b * 8;
+        const unsigned cnt = width - c0 < 8 ? width - c0 : 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t v = (unsigned)i < cnt ? col[(size_t)(c0 + i) * n] : 0;
+#if !CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY
+            if ((unsigned)i < cnt) v = fp_to_u64(v);
+#endif
+            m[2 * i] = (uint32_t)v;
+            m[2 * i + 1] = (uint32_t)(v >> 32);
+        }
+        const uint32_t flags = (b == 0 ? CHUNK_START : 0u) | (b + 1 == nblocks ? (CHUNK_END | ROOT) : 0u);
+        compress(cv, m, cnt * 8, flags);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(leaves + 32 * leaf);
+    dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
 __device__ __forceinline__ void merge_node(const uint8_t *__restrict__ children, uint8_t *__restrict__ parent) {
     const uint4 *src = reinterpret_cast<const uint4 *>(children);
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
@@ -147,6 +182,10 @@ hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, u
                      hipStream_t stream) {
     if (width == 0 || width > 128) return hipErrorInvalidValue; // single-chunk rows only
     const size_t n = (size_t)1 << log_n;
+    if (width <= 16 && log_b >= 1 && k0 == 0 && nk == (1u << log_b)) {
+        hipLaunchKernelGGL(k_hash_rows_narrow, dim3((unsigned)(((n << log_b) + 255) / 256)), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + 255) / 256), nk), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b, k0);
     return hipGetLastError();
 }
