@@ -61,6 +61,18 @@ struct AccAll {
 __device__ __forceinline__ fp c_not(fp a) { return fp_sub(FP_ONE, a); }
 __device__ __forceinline__ fp c_is_binary(fp a) { return fp_sub(fp_sqr(a), a); }
 
+// sum_j m[j] * x[j] for a row of 14 constants: seven products per fold of the 128-bit accumulator, one reduction
+__device__ __forceinline__ fp dot14_rows(const fp *__restrict__ m, const fp (&x)[14]) {
+    Acc128 a = acc_zero();
+#pragma unroll
+    for (int j = 0; j < 7; j++) acc_mad(a, m[j], x[j]);
+    acc_fold(a);
+#pragma unroll
+    for (int j = 7; j < 14; j++) acc_mad(a, m[j], x[j]);
+    acc_fold(a);
+    return acc_reduce(a);
+}
+
 // ---- Rescue round gadget (rescue.rs:269-300) on the 14-register window starting at `reg`; the same 14
 // differences feed up to two (result base, flag) pairs.
 template <class Acc>
@@ -73,12 +85,9 @@ __device__ __forceinline__ void enforce_round(Acc &acc, const Frame &f, int reg,
     }
 #pragma unroll 1
     for (int i = 0; i < 14; i++) {
-        fp s1 = f.pv(P_ARK + i), s2 = 0;
-#pragma unroll
-        for (int j = 0; j < 14; j++) {
-            s1 = fp_add(s1, fp_mul(c_mds[i * 14 + j], cube[j]));
-            s2 = fp_add(s2, fp_mul(c_inv_mds[i * 14 + j], d[j]));
-        }
+        // rows of the two matrices against the 14 cubes / differences: 128-bit accumulation, one reduction per row (dot14 below)
+        const fp s1 = fp_add(f.pv(P_ARK + i), dot14_rows(c_mds + i * 14, cube));
+        const fp s2 = dot14_rows(c_inv_mds + i * 14, d);
         const fp diff = fp_sub(fp_cube(s2), s1);
         acc.add(res_a + i, flag_a, diff);
         if (two) acc.add(res_b + i, flag_b, diff);
