@@ -218,6 +218,8 @@ int get_periodic(cstark_ctx *c, unsigned depth, unsigned log_n, unsigned log_b, 
         o[1] = cs::host::inv(cs::host::sub(cs::host::pow(shift, n), cs::host::ONE));
         for (int gi = 0; gi < 5; gi++) o[2 + gi] = cs::host::pow(shift, cs::host::tx_group_adjustment(gi, n, n * b));
         o[7] = cs::host::pow(shift, cs::host::tx_boundary_adjustment(n, n * b));
+        o[8] = cs::host::pow(shift, n - 1); // lift between neighbouring degree groups (merged split polynomials)
+        o[9] = 0;
         shift = cs::host::mul(shift, wbn);
     }
     HIP_TRY(hipMemcpyAsync(t.coset, cc.data(), cc.size() * 8, hipMemcpyHostToDevice, c->stream));
@@ -743,7 +745,7 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         HIP_TRY(cs::launch_rounds_setup(p, c->stream));
         HIP_TRY(cs::launch_rounds_split(p, even, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[1], c->stream));
-        uint64_t *fam_dbl = even + (size_t)cs::CE_SPLIT_FAM0 * 4 * n, *fam_add = fam_dbl + 12 * n, *fam_addbit = fam_add + 12 * n;
+        uint64_t *fam_dbl = even + (size_t)cs::CE_SPLIT_FAM0 * 4 * n, *fam_add = fam_dbl + 12 * n, *fam_addbit = fam_add + 8 * n; // 3 | 2 | 2 tables
         HIP_TRY(cs::launch_ec_split(p, 1, fam_dbl, nullptr, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[2], c->stream));
         HIP_TRY(cs::launch_ec_split(p, 2, fam_add, nullptr, c->stream));

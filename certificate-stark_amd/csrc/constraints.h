@@ -18,7 +18,7 @@ constexpr unsigned TX_GROUP_CYCLES[5] = {2, 2, 1, 1, 1};
 constexpr int CE_RTAB_WORDS = 12288;
 constexpr int CE_COEF_WORDS = 115 * 2 + 8; // one coefficient set: alpha[115] | beta[115] | b_alpha[4] | b_beta[4]
 constexpr int CE_MAX_SETS = 3;             // coefficient sets merged in one pass (the components of an extension proof)
-constexpr int CE_COSET_CONSTS = 8; // per coset: shift, 1/(shift^n - 1), shift^adj[0..5), shift^badj
+constexpr int CE_COSET_CONSTS = 10; // per coset: shift, 1/(shift^n - 1), shift^adj[0..5), shift^badj, shift^(n-1), unused
 
 struct CeParams {
     const uint64_t *lde;   // cosets [k0, k0+nk), coset-major [kk][94][n]
@@ -85,8 +85,8 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
 // part 4 = addition of the public key: its quartic half is a family of its own (d_even_family), its linear half is ADDED to the
 // addition family d_even_linear (after part 2 wrote it)
 hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, uint64_t *d_even_linear, hipStream_t stream);
-constexpr int CE_SPLIT_TABLES = 14, CE_SPLIT_FAM0 = 6; // first family (Rescue windows + linear groups): six polynomials; doubling 3 | addition 3 | addition x bit 2
-// split evaluation of a linear group (part 6, 7, 8): adds to the first family, d_even_family0 = [6][4][n]
+constexpr int CE_SPLIT_TABLES = 11, CE_SPLIT_FAM0 = 4; // first family (Rescue windows + linear groups): four polynomials; doubling 3 | addition 2 | addition x bit 2
+// split evaluation of a linear group (part 6, 7, 8): adds to the first family, d_even_family0 = [4][4][n]
 hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream);
 hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream);
 hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,

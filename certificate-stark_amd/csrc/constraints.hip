@@ -679,7 +679,17 @@ __device__ __forceinline__ void fused_rounds(Fused<M> &acc, const Frame &f, cons
 // the windows), interpolated there, extended to the odd cosets by transforms of four columns (capi.hip), and recombined with
 // x^adj_g and the transition divisor at every point (k_rounds_finish).  Exact arithmetic: the same merged evaluations.
 // out = [6 polynomials][4 even cosets][n] (alpha, beta of groups 0..4; this kernel initialises all six).  grid = (n / FNT, 4)
-constexpr int SPLIT_TABLES = 14, SPLIT_FAM0 = 6; // first family: alpha, beta of groups 0..4 (Rescue windows + linear groups, flags inside);
+// Polynomials that share their flag and differ only in the power x^adj_g they are multiplied with are MERGED when the sum still has
+// degree < 4n:  x^adj_g S_g + x^adj_h S_h = x^adj_g (S_g + x^(adj_h - adj_g) S_h), and adj_h - adj_g is the difference of the declared
+// evaluation degrees -- (n - 1) between neighbouring groups 2, 3, 4 and between groups 0, 1.  First family: beta of groups 2, 3, 4
+// in one table (degrees <= 4n - 3 - n/1024 after the lift; groups 0 and 1 hold Rescue terms of degree ~4n and stay apart); addition
+// family: beta of groups 0, 1 in one table (cubic terms: 4 (n - 1) after the lift).  11 tables instead of 14 to interpolate, extend
+// and read back.  x^(n-1) at a point = shift_k^(n-1) w_n^(-j).
+__device__ __forceinline__ fp split_lift(const CeParams &p, unsigned k, size_t j) { // x^(n-1) at point j of coset k
+    const size_t n = (size_t)1 << p.log_n;
+    return fp_mul(p.coset[(size_t)k * CE_COSET_CONSTS + 8], p.w[(n - j) & (n - 1)]);
+}
+constexpr int SPLIT_TABLES = 11, SPLIT_FAM0 = 4; // first family: alpha, beta of groups 0, 1, beta of groups 2..4 merged (Rescue windows + linear groups, flags inside);
                                                  // doubling: 3, addition: 3 (alpha, beta of groups 0, 1), addition x bit: 2 (alpha, beta of group 0)
 // M coefficient sets (the components of an extension proof): the windows' values are computed once, every set has its own tables
 // (rtab + c * CE_RTAB_WORDS) and its own block of SPLIT_TABLES output polynomials (out + c * SPLIT_TABLES * 4 n).
@@ -814,15 +824,16 @@ __global__ __launch_bounds__(FNT, M == 1 ? 3 : 2) void k_rounds_split(CeParams p
 #pragma unroll
     for (int c = 0; c < M; c++)
 #pragma unroll
-        for (int q = 0; q < 6; q++) // groups 3, 4: zero here, written by the linear groups
-            out[(((size_t)c * SPLIT_TABLES + q) * 4 + kc) * n + j] = q < 4 ? tot[c][q] : 0;
+        for (int q = 0; q < 4; q++) // table 3: group 2 here; the linear groups add groups 3, 4 lifted by x^(n-1), x^(2n-2)
+            out[(((size_t)c * SPLIT_TABLES + q) * 4 + kc) * n + j] = tot[c][q];
 }
 
 // grid = (n / 256, 8): out[k][j] = [ (R_a + sum_g x^adj_g R_b,g) + doubling(x) (D_a + sum_g x^adj_g D_b,g) + addition(x) (A_a + ...) ]
 //                                  * (x - w^(n-1)) / (x^n - 1).
-// (+ the fourth family with the "flag" -addition(x) * register 37, see k_ec_split; + the boundary terms).  The eighteen polynomials'
-// values come from the split evaluations (even cosets, [14][4][n]: the first family of six -- alpha, beta of groups 0..4 -- then
-// doubling (3), addition (3), addition x bit (2)) or from their extension (odd cosets, [4 cosets][14][n]).  ADDS to p.out.
+// (+ the fourth family with the "flag" -addition(x) * register 37, see k_ec_split; + the boundary terms).  The eleven polynomials'
+// values come from the split evaluations (even cosets, [11][4][n]: the first family of four -- alpha, beta of groups 0, 1, beta of
+// groups 2..4 merged -- then doubling (3), addition (2: beta of groups 0, 1 merged), addition x bit (2)) or from their extension
+// (odd cosets, [4 cosets][11][n]).  ADDS to p.out.
 template <int M>
 __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd) {
     const size_t n = (size_t)1 << p.log_n;
@@ -851,10 +862,10 @@ __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__re
         };
         fp total = value(0);
 #pragma unroll
-        for (int g = 0; g < 5; g++) total = fp_add(total, fp_mul(value(1 + g), xp[g]));
-        const fp dbl = fp_add(value(6), fp_add(fp_mul(value(7), xp[0]), fp_mul(value(8), xp[1])));
-        const fp add = fp_add(value(9), fp_add(fp_mul(value(10), xp[0]), fp_mul(value(11), xp[1])));
-        const fp addbit = fp_add(value(12), fp_mul(value(13), xp[0]));
+        for (int g = 0; g < 3; g++) total = fp_add(total, fp_mul(value(1 + g), xp[g])); // table 3 = groups 2, 3, 4 merged relative to x^adj_2
+        const fp dbl = fp_add(value(4), fp_add(fp_mul(value(5), xp[0]), fp_mul(value(6), xp[1])));
+        const fp add = fp_add(value(7), fp_mul(value(8), xp[0]));                      // table 8 = groups 0, 1 merged relative to x^adj_0
+        const fp addbit = fp_add(value(9), fp_mul(value(10), xp[0]));
         total = fp_add(total, fp_mul(doubling, dbl));
         total = fp_add(total, fp_mul(addition, fp_sub(add, fp_mul(bit37, addbit))));
         fp t = fp_mul(total, divisor);
@@ -1008,13 +1019,17 @@ __global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_ec_split(CeParams p, fp *_
             acc.term(31 + i, fp_sub(a.z.c[i], pt.z.c[i]));
         }
     }
-    constexpr int NQ = PART == PART_ADD1 ? 2 : 3; // the h*P registers 19..36 are all in group 0 (PART_DBL1 adds zero for group 1)
+    // the h*P registers 19..36 are all in group 0 (PART_DBL1 adds zero for group 1); the addition family keeps beta of groups 0, 1 in ONE
+    // table, group 1 lifted by x^(n-1) (cubic terms: the sum stays below degree 4n)
+    constexpr int NQ = (PART == PART_ADD1 || PART == PART_ADD0) ? 2 : 3;
+    const fp xd1 = PART == PART_ADD0 ? split_lift(p, 2 * kc, j) : 0;
 #pragma unroll
     for (int c = 0; c < M; c++)
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             fp *o = out + (c * SET + (size_t)q * 4 + kc) * n + j;
-            const fp v = acc.result(c, q);
+            fp v = acc.result(c, q);
+            if (PART == PART_ADD0 && q == 1) v = fp_add(v, fp_mul(xd1, acc.result(c, 2)));
             *o = ACCUMULATE ? fp_add(*o, v) : v;
         }
 }
@@ -1386,9 +1401,12 @@ __global__ __launch_bounds__(FNT, PART == PART_LIN_C ? CS_LIN_C_SPLIT_WAVES : PA
     if (PART == PART_LIN_A) lin_a_split(coefs, f, tot);
     if (PART == PART_LIN_B) lin_b_split(coefs, f, tot);
     if (PART == PART_LIN_C) lin_c_split(coefs, f, tot);
+    const fp xd1 = split_lift(p, 2 * kc, j);
+    // beta of groups 2, 3, 4 in one table: S_2 + x^(n-1) S_3 + x^(2n-2) S_4 (LIN_A only has alpha and group 4)
+    tot[3] = PART == PART_LIN_A ? fp_mul(fp_mul(xd1, xd1), tot[5]) : fp_add(tot[3], fp_mul(xd1, fp_add(tot[4], fp_mul(xd1, tot[5]))));
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-        const bool touched = PART == PART_LIN_A ? (q == 0 || q == 5) : true;
+    for (int q = 0; q < 4; q++) {
+        const bool touched = PART == PART_LIN_A ? (q == 0 || q == 3) : true;
         if (touched) {
             fp *o = out + ((size_t)q * 4 + kc) * n + j;
             *o = fp_add(*o, tot[q]);
