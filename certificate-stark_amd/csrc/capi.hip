@@ -739,8 +739,10 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         RC_TRY(get_plan(c, log_n + 3, &p8));
         RC_TRY(get_coset_table(c, log_n, 3, cs::host::from_u64(1), &t1));
         const size_t region = (size_t)T * 4 * n; // words per array of T x 4 columns
-        RC_TRY(ensure_ws(c, 5 * region * 8));
+        const size_t hcol = (size_t)2 * m * n;   // the final addition's two sums per set: one n-point table each
+        RC_TRY(ensure_ws(c, (5 * region + 9 * hcol) * 8));
         uint64_t *even = (uint64_t *)c->ws, *sa = even + region, *sb = sa + region, *sc = sb + region, *odd = sc + region;
+        uint64_t *fin_direct = odd + region, *fin_hi = fin_direct + hcol /* [4 odd cosets][2 m][n] */, *fin_co = fin_hi + 4 * hcol, *fin_scr = fin_co + hcol /* [3] */;
         if (pev) HIP_TRY(hipEventRecord(pev[0], c->stream));
         HIP_TRY(cs::launch_rounds_setup(p, c->stream));
         HIP_TRY(cs::launch_rounds_split(p, even, c->stream));
@@ -753,9 +755,11 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         HIP_TRY(cs::launch_ec_split(p, 3, fam_dbl, nullptr, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[4], c->stream));
         HIP_TRY(cs::launch_ec_split(p, 4, fam_addbit, fam_add, c->stream));
-        // the final addition reaches degree 5 (n - 1): all cosets, accumulated into the zero-filled output first
-        for (uint32_t q = 0; q < m; q++) HIP_TRY(hipMemsetAsync(d_outs[q], 0, 8 * n * 8, c->stream));
-        HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev, 0x1FFu & ~(1u << 5), false));
+        // the final addition reaches degree 5 (n - 1): its two sums on the four even cosets join the tables, ONE odd coset pins the
+        // n coefficients above 4n (below, after the extension); constraints.hip, k_final_split
+        if (pev) HIP_TRY(hipEventRecord(pev[5], c->stream));
+        uint64_t *fam_final = fam_addbit + 8 * n;
+        HIP_TRY(cs::launch_final_split(p, -1, fam_final, c->stream));
         for (int part = 6; part <= 8; part++) {
             if (pev) HIP_TRY(hipEventRecord(pev[part], c->stream));
             HIP_TRY(cs::launch_lin_split(p, part, even, c->stream));
@@ -772,7 +776,22 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         f.aux = pn->aux_w; f.aux_ps = t1->aux ? t1->aux + t1->aux_words : nullptr; f.aux_ps_batch_stride = 2 * t1->aux_words;
         f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
         HIP_TRY(cs::ntt_columns(f, c->stream));
-        HIP_TRY(cs::launch_split_finish(p, even, odd, c->stream));
+        {   // high parts of the final addition's sums: H = (T - Q) / 2 on LDE coset 1, interpolated there and extended to cosets 3, 5, 7
+            HIP_TRY(cs::launch_final_split(p, 1, fin_direct, c->stream));
+            HIP_TRY(cs::launch_final_hi(p, odd, fin_direct, fin_hi, cs::host::inv(cs::host::from_u64(2)), c->stream));
+            cs::NttArgs hi_inv{};
+            hi_inv.in = fin_hi; hi_inv.scratch = fin_scr; hi_inv.out = fin_co; hi_inv.width = 2 * m; hi_inv.batch = 1; hi_inv.log_n = log_n;
+            hi_inv.w = pn->winv; hi_inv.post_scale = pn->n_inv; hi_inv.do_scale = true; hi_inv.inverse = true; hi_inv.aux = pn->aux_winv;
+            HIP_TRY(cs::ntt_columns(hi_inv, c->stream));
+            // coefficients of H(w_8n z) in z -> values on coset k: prescale by (w_8n^(k-1))^s, k - 1 = 2, 4, 6: rows 2, 4, 6 of the offset-1 table
+            cs::NttArgs hi_fwd{};
+            hi_fwd.in = fin_co; hi_fwd.scratch = fin_scr; hi_fwd.out = fin_hi + hcol; hi_fwd.width = 2 * m; hi_fwd.batch = 3; hi_fwd.log_n = log_n;
+            hi_fwd.w = pn->w; hi_fwd.prescale = t1->s + 2 * n; hi_fwd.prescale_batch_stride = 2 * n; hi_fwd.do_scale = false; hi_fwd.inverse = false;
+            hi_fwd.aux = pn->aux_w; hi_fwd.aux_ps = t1->aux ? t1->aux + 2 * t1->aux_words : nullptr; hi_fwd.aux_ps_batch_stride = 2 * t1->aux_words;
+            hi_fwd.in_batch_stride = 0; hi_fwd.scratch_batch_stride = hcol; hi_fwd.out_batch_stride = hcol;
+            HIP_TRY(cs::ntt_columns(hi_fwd, c->stream));
+        }
+        HIP_TRY(cs::launch_split_finish(p, even, odd, fin_hi, c->stream));
         if (pev) HIP_TRY(hipEventRecord(pev[cs::CE_NUM_PARTS], c->stream));
     } else {
         HIP_TRY(cs::launch_eval_constraints(p, nk, c->stream, pev));

@@ -85,10 +85,19 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
 // part 4 = addition of the public key: its quartic half is a family of its own (d_even_family), its linear half is ADDED to the
 // addition family d_even_linear (after part 2 wrote it)
 hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, uint64_t *d_even_linear, hipStream_t stream);
-constexpr int CE_SPLIT_TABLES = 11, CE_SPLIT_FAM0 = 4; // first family (Rescue windows + linear groups): four polynomials; doubling 3 | addition 2 | addition x bit 2
+constexpr int CE_SPLIT_TABLES = 13, CE_SPLIT_FAM0 = 4; // first family (Rescue windows + linear groups): four polynomials; doubling 3 | addition 2 | addition x bit 2 | final addition 2
 // split evaluation of a linear group (part 6, 7, 8): adds to the first family, d_even_family0 = [4][4][n]
 hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream);
-hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream);
+// d_hi = [4 odd cosets][2 m][n]: the high parts of the final-addition polynomials on the odd cosets (launch_final_hi + their extension)
+hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, const uint64_t *d_hi, hipStream_t stream);
+// Final addition (degree 5 (n - 1): one n-coefficient block above the 4n the even cosets determine).  coset < 0: the two sums
+// (alpha; beta of groups 0, 1 merged) on the four even cosets into the family's tables d_out = [2][4][n] (per set: stride of the
+// table block); coset >= 0: on that one coset, d_out = [m][2][n].
+hipError_t launch_final_split(const CeParams &p, int coset, uint64_t *d_out, hipStream_t stream);
+// hi[c][q][j] = (T(coset 1)[c][q][j] - direct[c][q][j]) / 2: values of the high-part polynomials on LDE coset 1; d_odd as for
+// launch_split_finish, d_direct = launch_final_split(coset 1), d_hi = [m][2][n]
+hipError_t launch_final_hi(const CeParams &p, const uint64_t *d_odd, const uint64_t *d_direct, uint64_t *d_hi, uint64_t half /* 1/2, memory form */,
+                           hipStream_t stream);
 hipError_t build_boundary_inverses(uint64_t *d_table, const uint64_t *d_w, const uint64_t *d_coset, uint64_t w_last, unsigned log_n, unsigned log_b,
                                    hipStream_t stream);
 

@@ -689,7 +689,8 @@ __device__ __forceinline__ fp split_lift(const CeParams &p, unsigned k, size_t j
     const size_t n = (size_t)1 << p.log_n;
     return fp_mul(p.coset[(size_t)k * CE_COSET_CONSTS + 8], p.w[(n - j) & (n - 1)]);
 }
-constexpr int SPLIT_TABLES = 11, SPLIT_FAM0 = 4; // first family: alpha, beta of groups 0, 1, beta of groups 2..4 merged (Rescue windows + linear groups, flags inside);
+constexpr int SPLIT_TABLES = 13, SPLIT_FAM0 = 4, SPLIT_FINAL = 11; // (tables 11, 12: the final addition, below)
+constexpr int SPLIT_TABLES_DOC = 13, SPLIT_FAM0_DOC = 4; // first family: alpha, beta of groups 0, 1, beta of groups 2..4 merged (Rescue windows + linear groups, flags inside);
                                                  // doubling: 3, addition: 3 (alpha, beta of groups 0, 1), addition x bit: 2 (alpha, beta of group 0)
 // M coefficient sets (the components of an extension proof): the windows' values are computed once, every set has its own tables
 // (rtab + c * CE_RTAB_WORDS) and its own block of SPLIT_TABLES output polynomials (out + c * SPLIT_TABLES * 4 n).
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(FNT, M == 1 ? 3 : 2) void k_rounds_split(CeParams p
 // groups 2..4 merged -- then doubling (3), addition (2: beta of groups 0, 1 merged), addition x bit (2)) or from their extension
 // (odd cosets, [4 cosets][11][n]).  ADDS to p.out.
 template <int M>
-__global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd) {
+__global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd, const fp *__restrict__ hi) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
     const unsigned k = blockIdx.y;
@@ -868,6 +869,15 @@ __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__re
         const fp addbit = fp_add(value(9), fp_mul(value(10), xp[0]));
         total = fp_add(total, fp_mul(doubling, dbl));
         total = fp_add(total, fp_mul(addition, fp_sub(add, fp_mul(bit37, addbit))));
+        {   // final addition: Q = T on the even cosets, T - 2 H on the odd ones (k_final_split); flag = (1 - scalar_mult) schnorr
+            fp fa = value(SPLIT_FINAL), fb = value(SPLIT_FINAL + 1);
+            if (k & 1) {
+                const fp *h = hi + (((size_t)(k >> 1) * M + c) * 2) * n + j;
+                fa = fp_sub(fa, fp_dbl(h[0]));
+                fb = fp_sub(fb, fp_dbl(h[n]));
+            }
+            total = fp_add(total, fp_mul(fp_mul(c_not(scalar_mult), per[(size_t)P_SCHNORR * 1024]), fp_add(fa, fp_mul(fb, xp[0]))));
+        }
         fp t = fp_mul(total, divisor);
         // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184), as in the last linear group
         const fp *ba = p.coef + c * CE_COEF_WORDS + 230, *bb = ba + 4;
@@ -875,7 +885,7 @@ __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__re
         const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
         t = fp_add(t, fp_add(fp_mul(first, bi0), fp_mul(last, bi1)));
         fp *o = (c == 0 ? p.out : p.out_ext[c == 0 ? 0 : c - 1]) + (size_t)k * n + j;
-        *o = fp_add(*o, t); // the final addition (all cosets) was accumulated into the zero-filled table before
+        *o = t;
     }
 }
 
@@ -1032,6 +1042,45 @@ __global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_ec_split(CeParams p, fp *_
             if (PART == PART_ADD0 && q == 1) v = fp_add(v, fp_mul(xd1, acc.result(c, 2)));
             *o = ACCUMULATE ? fp_add(*o, v) : v;
         }
+}
+
+// ---- final addition on FIVE cosets instead of eight --------------------------------------------------------------------------
+// Its two sums Q (alpha; beta of groups 0, 1 merged with the lift) have degree <= 5 (n - 1): as polynomials in y = x / g,
+// Q = sum_{t < 5n} a_t y^t.  On the even cosets y^(4n) = 1, so the values there are those of T(y) = sum_{t < 4n} (a_t + [t < n] a_{4n+t}) y^t,
+// a polynomial of degree < 4n that the split machinery interpolates and extends like the others; on the odd cosets y^(4n) = -1 and
+// Q = T - 2 H with H(y) = sum_{s < n} a_{4n+s} y^s.  H is pinned by ONE odd coset: the sums are evaluated directly on LDE coset 1
+// (this kernel with coset = 1), H = (T - Q) / 2 there (k_final_hi), interpolated (n points) and extended to cosets 3, 5, 7.
+// Curve arithmetic on 5 n instead of 8 n points for 24 more n-point transforms.
+template <int M>
+__global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_final_split(CeParams p, fp *__restrict__ out, int coset) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kc = blockIdx.y, k = coset < 0 ? 2 * kc : (unsigned)coset;
+    const Frame f = make_frame(p, k, j); // the launcher guarantees k0 = 0 and all cosets present
+    SplitAcc<M> acc;
+    acc.coefs = as_const(p.coef);
+    fused_final_addition(acc, f, (fp)0);
+    const fp xd1 = split_lift(p, k, j);
+    constexpr size_t SET = (size_t)SPLIT_TABLES * 4;
+#pragma unroll
+    for (int c = 0; c < M; c++) {
+        const fp a = acc.result(c, 0), b = fp_add(acc.result(c, 1), fp_mul(xd1, acc.result(c, 2)));
+        if (coset < 0) {
+            out[(c * SET + kc) * n + j] = a;
+            out[(c * SET + 4 + kc) * n + j] = b;
+        } else {
+            out[((size_t)c * 2) * n + j] = a;
+            out[((size_t)c * 2 + 1) * n + j] = b;
+        }
+    }
+}
+template <int M>
+__global__ __launch_bounds__(256) void k_final_hi(CeParams p, const fp *__restrict__ odd, const fp *__restrict__ direct, fp *__restrict__ hi, fp half) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    const unsigned q = blockIdx.y % 2, c = blockIdx.y / 2;
+    const fp t = odd[((size_t)c * SPLIT_TABLES + SPLIT_FINAL + q) * n + j]; // LDE coset 1 = the first odd coset of `odd`
+    hi[((size_t)c * 2 + q) * n + j] = fp_mul(fp_sub(t, direct[((size_t)c * 2 + q) * n + j]), half);
 }
 
 template <int M>
@@ -1876,13 +1925,33 @@ hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family
     }
     return hipGetLastError();
 }
-hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, hipStream_t stream) {
+hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, const uint64_t *d_hi, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / 256), 8), block(256);
     const unsigned m = p.m ? p.m : 1;
-    if (m == 1) hipLaunchKernelGGL(k_split_finish<1>, grid, block, 0, stream, p, d_even, d_odd);
-    else if (m == 2) hipLaunchKernelGGL(k_split_finish<2>, grid, block, 0, stream, p, d_even, d_odd);
-    else if (m == 3) hipLaunchKernelGGL(k_split_finish<3>, grid, block, 0, stream, p, d_even, d_odd);
+    if (m == 1) hipLaunchKernelGGL(k_split_finish<1>, grid, block, 0, stream, p, d_even, d_odd, d_hi);
+    else if (m == 2) hipLaunchKernelGGL(k_split_finish<2>, grid, block, 0, stream, p, d_even, d_odd, d_hi);
+    else if (m == 3) hipLaunchKernelGGL(k_split_finish<3>, grid, block, 0, stream, p, d_even, d_odd, d_hi);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_final_split(const CeParams &p, int coset, uint64_t *d_out, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    const dim3 grid((unsigned)(n / FNT), coset < 0 ? 4 : 1), block(FNT);
+    const unsigned m = p.m ? p.m : 1;
+    if (m == 1) hipLaunchKernelGGL(k_final_split<1>, grid, block, 0, stream, p, d_out, coset);
+    else if (m == 2) hipLaunchKernelGGL(k_final_split<2>, grid, block, 0, stream, p, d_out, coset);
+    else if (m == 3) hipLaunchKernelGGL(k_final_split<3>, grid, block, 0, stream, p, d_out, coset);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_final_hi(const CeParams &p, const uint64_t *d_odd, const uint64_t *d_direct, uint64_t *d_hi, uint64_t half_m, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    const unsigned m = p.m ? p.m : 1;
+    const dim3 grid((unsigned)(n / 256), 2 * m), block(256);
+    if (m == 1) hipLaunchKernelGGL(k_final_hi<1>, grid, block, 0, stream, p, d_odd, d_direct, d_hi, half_m);
+    else if (m == 2) hipLaunchKernelGGL(k_final_hi<2>, grid, block, 0, stream, p, d_odd, d_direct, d_hi, half_m);
+    else if (m == 3) hipLaunchKernelGGL(k_final_hi<3>, grid, block, 0, stream, p, d_odd, d_direct, d_hi, half_m);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
