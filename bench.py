@@ -389,7 +389,7 @@ def main():
         ntt_names = ["k_ntt_cols_v5<4, 3, 3, false>", "k_ntt_rows_v5<4, 3, 3, false>", "k_ntt_cols_v4<4, 3, 3, false>", "k_ntt_rows_v4<4, 3, 3, false>",
                      "k_ntt_cols_v2<5, 5, false>", "k_ntt_rows_v2<5, 5, false>"]
         roofline_lde = entry("forward transform pair of the low-degree extension (k_ntt_cols_v5 + k_ntt_rows_v5; all LDE calls of a proof: trace 94 "
-                             "columns x 8 cosets, composition 8 x 8, DEEP 1 x 8; traffic also covers the 56 split-polynomial transforms, same kernels)",
+                             "columns x 8 cosets, composition 8 x 8, DEEP 1 x 8; traffic also covers the 58 forward transforms of the split polynomials, same kernels)",
                              lde_alg, lde_ms / per, ntt_names,
                              "the dominant kernel family by GPU time: about 330 vector instructions per element and coset at 2-4 issue cycles each "
                              "(profiles/*_valu_issue_bench*.txt): the extension of 94 columns to 8 cosets takes 8.0 ms, its arithmetic alone 5.55 ms (= the "

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ 
 
 // Narrow tables (one or two compressions per row: the composition columns): one lane per LEAF, the cosets of a row in neighbouring
 // lanes, so that the 32-byte digests of a wave are 2 KB of consecutive leaves (leaf = b j + k).  The lane-per-row kernel above writes
-// them 32 bytes at a stride of 32 b -- hidden behind twelve compressions for the trace, not behind one: 0.37 -> 0.2x ms for the
+// them 32 bytes at a stride of 32 b -- hidden behind twelve compressions for the trace, not behind one: the composition stage 1.55 -> 1.49 ms for the
 // 8 x 2^23 composition table.  Reads become 64-byte segments (8 consecutive rows of one coset and column).  All b cosets present.
 __global__ __launch_bounds__(256) void k_hash_rows_narrow(const uint64_t *__restrict__ lde, uint8_t *__restrict__ leaves, unsigned width, unsigned log_n,
                                                           unsigned log_b) {

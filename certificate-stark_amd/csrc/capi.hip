@@ -727,8 +727,8 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
     static const bool split_ext_env = [] { const char *e = getenv("CSTARK_ROUNDS_SPLIT_EXT"); return !e || atoi(e) != 0; }();
     if (split_env && input_is_lde && (m == 1 || split_ext_env) && k0 == 0 && nk == 8 && log_n + 3 <= cs::NTT_MAX_LOG_N) { // (twiddle tables of size 8n)
         // Parts whose merged polynomials have degree < 4n (constraints.hip: the Rescue windows with their flags; the doublings and the
-        // addition of the generator with the flag factored out) run on the even cosets only; their twelve polynomials are
-        // interpolated over that 4n-point sub-domain, extended to the odd cosets by transforms of twelve columns and recombined
+        // addition of the generator with the flag factored out) run on the even cosets only; their thirteen polynomials are
+        // interpolated over that 4n-point sub-domain, extended to the odd cosets by transforms of thirteen columns and recombined
         // at every point.  (Part timing: the extension and the recombination are counted with the last of these parts.)
         const size_t n = (size_t)1 << log_n;
         const unsigned T = cs::CE_SPLIT_TABLES * m; // every coefficient set has its own block of polynomials
