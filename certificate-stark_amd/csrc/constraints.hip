@@ -689,9 +689,10 @@ __device__ __forceinline__ fp split_lift(const CeParams &p, unsigned k, size_t j
     const size_t n = (size_t)1 << p.log_n;
     return fp_mul(p.coset[(size_t)k * CE_COSET_CONSTS + 8], p.w[(n - j) & (n - 1)]);
 }
-constexpr int SPLIT_TABLES = 13, SPLIT_FAM0 = 4, SPLIT_FINAL = 11; // (tables 11, 12: the final addition, below)
-constexpr int SPLIT_TABLES_DOC = 13, SPLIT_FAM0_DOC = 4; // first family: alpha, beta of groups 0, 1, beta of groups 2..4 merged (Rescue windows + linear groups, flags inside);
-                                                 // doubling: 3, addition: 3 (alpha, beta of groups 0, 1), addition x bit: 2 (alpha, beta of group 0)
+// tables per coefficient set: first family 4 (alpha, beta of groups 0, 1, beta of groups 2..4 merged; Rescue windows + linear groups,
+// flags inside) | doubling 3 (alpha, beta of groups 0, 1) | addition 2 (alpha, beta of groups 0, 1 merged) | addition x bit 2 (alpha,
+// beta of group 0) | final addition 2 (alpha, beta of groups 0, 1 merged; below)
+constexpr int SPLIT_TABLES = 13, SPLIT_FAM0 = 4, SPLIT_FINAL = 11;
 // M coefficient sets (the components of an extension proof): the windows' values are computed once, every set has its own tables
 // (rtab + c * CE_RTAB_WORDS) and its own block of SPLIT_TABLES output polynomials (out + c * SPLIT_TABLES * 4 n).
 template <int M>
