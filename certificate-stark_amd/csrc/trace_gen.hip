@@ -35,6 +35,19 @@ constexpr unsigned LADDER_LDS_PAD = 0;
 #endif
 constexpr int SCALAR_MUL_LEN = 510; // src/schnorr/constants.rs:30
 
+// this lane's row of the MDS matrix against the state in LDS: 128-bit accumulation of the 14 products, one reduction (572 instead of
+// 936 issue cycles for 14 reduced products and 13 modular additions)
+__device__ __forceinline__ fp mds_row_dot(const fp (&mrow)[14], const fp *xch) {
+    Acc128 a = acc_zero();
+#pragma unroll
+    for (int j = 0; j < 7; j++) acc_mad(a, mrow[j], xch[j]);
+    acc_fold(a);
+#pragma unroll
+    for (int j = 7; j < 14; j++) acc_mad(a, mrow[j], xch[j]);
+    acc_fold(a);
+    return acc_reduce(a);
+}
+
 // One Rescue round on a 14-element state held one element per lane (rescue.rs:246-263).
 // `xch` is the state's 14-word LDS exchange row.  Must be called by every lane of the block
 // (it synchronises); lanes with active == false only take part in the barriers.
@@ -42,21 +55,11 @@ __device__ __forceinline__ fp rescue_round_lane(fp v, fp *xch, const fp (&mrow)[
     fp x = 0;
     if (active) { x = fp_cube(v); xch[e] = x; }
     __syncthreads();
-    if (active) {
-        fp acc = 0;
-#pragma unroll
-        for (int j = 0; j < 14; j++) acc = fp_add(acc, fp_mul(mrow[j], xch[j]));
-        x = fp_inv_sbox(fp_add(acc, c_ark[cyc * 28 + e]));
-    }
+    if (active) x = fp_inv_sbox(fp_add(mds_row_dot(mrow, xch), c_ark[cyc * 28 + e]));
     __syncthreads();
     if (active) xch[e] = x;
     __syncthreads();
-    if (active) {
-        fp acc = 0;
-#pragma unroll
-        for (int j = 0; j < 14; j++) acc = fp_add(acc, fp_mul(mrow[j], xch[j]));
-        v = fp_add(acc, c_ark[cyc * 28 + 14 + e]);
-    }
+    if (active) v = fp_add(mds_row_dot(mrow, xch), c_ark[cyc * 28 + 14 + e]);
     __syncthreads();
     return v;
 }
