@@ -96,23 +96,36 @@ __device__ inline fp fp_pow(fp base, uint64_t e) {
 }
 __device__ inline fp fp_inv(fp a) { return fp_pow(a, FP_P - 2); }
 
-// x^INV_ALPHA for the fixed 62-bit exponent 0b101011 (10)^27 11: left-to-right sliding window of width 3 (tools/gen_invsbox_chain.py
-// emits and checks the chain): x^5, then (^16, * x^7), thirteen times (^16, * x^5), then (^8, * x^3) -- 59 squarings + 15 products +
-// 4 for the odd powers = 78 field products instead of the 93 of plain square-and-multiply.
+// x^INV_ALPHA for the fixed 62-bit exponent 0b 101011 (10)^27 11 (rescue.rs:383), as an addition chain on its pattern: x^42 = 0b101010
+// from x^2, x^3, x^5, x^10, x^20, x^21; the prefix 0b101011 = x^42 * x; nine times (six squarings, * x^42) append the 27 pairs "10";
+// two squarings and * x^3 append the final "11".  60 squarings + 14 products = 74 field products (plain square-and-multiply: 93; a
+// generic width-3 sliding window, tools/gen_invsbox_chain.py: 78).  Checked against the oracle's pow() in tests/test_gpu_field.py.
 __device__ inline fp fp_inv_sbox(fp x) {
-    const fp x2 = fp_sqr(x), x3 = fp_mul(x2, x), x5 = fp_mul(x3, x2), x7 = fp_mul(x5, x2);
-    fp r = x5;
+#ifdef CS_INVSBOX_W3 // measurement builds: the generic width-3 sliding window (78 products)
+    {
+        const fp y2 = fp_sqr(x), y3 = fp_mul(y2, x), y5 = fp_mul(y3, y2), y7 = fp_mul(y5, y2);
+        fp r = y5;
 #pragma unroll 1
-    for (int i = 0; i < 4; i++) r = fp_sqr(r);
-    r = fp_mul(r, x7);
-#pragma unroll 1
-    for (int k = 0; k < 13; k++) {
-#pragma unroll
         for (int i = 0; i < 4; i++) r = fp_sqr(r);
-        r = fp_mul(r, x5);
+        r = fp_mul(r, y7);
+#pragma unroll 1
+        for (int k = 0; k < 13; k++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) r = fp_sqr(r);
+            r = fp_mul(r, y5);
+        }
+        return fp_mul(fp_sqr(fp_sqr(fp_sqr(r))), y3);
     }
-    r = fp_sqr(fp_sqr(fp_sqr(r)));
-    return fp_mul(r, x3);
+#endif
+    const fp x2 = fp_sqr(x), x3 = fp_mul(x2, x), x5 = fp_mul(x3, x2), x10 = fp_sqr(x5), x21 = fp_mul(fp_sqr(x10), x), x42 = fp_sqr(x21);
+    fp r = fp_mul(x42, x);
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) r = fp_sqr(r);
+        r = fp_mul(r, x42);
+    }
+    return fp_mul(fp_sqr(fp_sqr(r)), x3);
 }
 
 // small-integer multiples by repeated addition (|c| <= 4), for the linear steps of the curve formulas
