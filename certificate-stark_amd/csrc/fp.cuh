@@ -94,7 +94,22 @@ __device__ inline fp fp_pow(fp base, uint64_t e) {
     }
     return r;
 }
-__device__ inline fp fp_inv(fp a) { return fp_pow(a, FP_P - 2); }
+// a^(p-2), p - 2 = 0b 1000001 0 1^55: x^65 by six squarings and a product, one squaring for the zero, then eleven windows of five
+// ones (five squarings, * x^31): 66 squarings + 16 products instead of the 117 of the generic square-and-multiply.  0 -> 0.
+__device__ inline fp fp_inv(fp a) {
+    const fp a3 = fp_mul(fp_sqr(a), a), a7 = fp_mul(fp_sqr(a3), a), a15 = fp_mul(fp_sqr(a7), a), a31 = fp_mul(fp_sqr(a15), a);
+    fp r = a;
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) r = fp_sqr(r);
+    r = fp_sqr(fp_mul(r, a));
+#pragma unroll 1
+    for (int k = 0; k < 11; k++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) r = fp_sqr(r);
+        r = fp_mul(r, a31);
+    }
+    return r;
+}
 
 // x^INV_ALPHA for the fixed 62-bit exponent 0b 101011 (10)^27 11 (rescue.rs:383), as an addition chain on its pattern: x^42 = 0b101010
 // from x^2, x^3, x^5, x^10, x^20, x^21; the prefix 0b101011 = x^42 * x; nine times (six squarings, * x^42) append the 27 pairs "10";
