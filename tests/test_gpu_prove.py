@@ -262,6 +262,16 @@ def test_extension_field_proofs(n_tx, depth, hash_fn, ext):
         V.verify(bytes(bad), r0, r1)
 
 
+def test_repeated_proofs_are_identical():
+    """The prover overlaps its trace recurrences with the transforms on side streams, polls its stream at the channel's wait points and
+    gathers every opening in one launch: forty proofs of one witness on one context (buffers reused each time) must be the same bytes."""
+    import hashlib
+    tx = example(16, 15, seed=4242)
+    want = hashlib.sha256(tx.prove()).hexdigest()
+    for _ in range(40):
+        assert hashlib.sha256(tx.prove()).hexdigest() == want
+
+
 def test_direct_and_split_prover_paths_give_the_same_bytes():
     """Inside cstark_tx_prove the constraints run as the degree-split evaluation and the trace is committed in overlapped column
     batches; CSTARK_ROUNDS_SPLIT=0 / CSTARK_TRACE_OVERLAP=0 select the direct forms (read once per process, hence the child
