@@ -303,6 +303,8 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     if (c->wit_buf) (void)hipFree(c->wit_buf);
     if (c->ws) (void)hipFree(c->ws);
     if (c->coef_buf) (void)hipFree(c->coef_buf);
+    if (c->coef_stage) (void)hipHostFree(c->coef_stage);
+    if (c->coef_ev) (void)hipEventDestroy(c->coef_ev);
     for (NttPlan &p : c->plans) { (void)hipFree(p.w); (void)hipFree(p.winv); (void)hipFree(p.aux_w); (void)hipFree(p.aux_winv); }
     for (CosetTable &t : c->cosets) { (void)hipFree(t.s); (void)hipFree(t.aux); }
     for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); (void)hipFree(t.binv); }
@@ -713,8 +715,16 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
     static_assert(sizeof(cstark_tx_coeffs) == cs::CE_COEF_WORDS * 8, "coefficient block layout");
     constexpr size_t COEF_WORDS = (size_t)cs::CE_MAX_SETS * cs::CE_COEF_WORDS;
     if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, (COEF_WORDS + (size_t)cs::CE_MAX_SETS * cs::CE_RTAB_WORDS) * 8));
-    HIP_TRY(hipMemcpyAsync(c->coef_buf, coeffs, (size_t)m * sizeof(cstark_tx_coeffs), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(cs::stream_wait(c->stream)); // the caller's struct may be transient
+    // the caller's struct may be transient: copy it into the context's pinned staging block and upload from there without waiting
+    if (!c->coef_stage) {
+        HIP_TRY(hipHostMalloc(&c->coef_stage, (size_t)cs::CE_MAX_SETS * sizeof(cstark_tx_coeffs), hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
+    } else {
+        HIP_TRY(hipEventSynchronize(c->coef_ev)); // the previous upload has left the staging block (long ago, normally)
+    }
+    memcpy(c->coef_stage, coeffs, (size_t)m * sizeof(cstark_tx_coeffs));
+    HIP_TRY(hipMemcpyAsync(c->coef_buf, c->coef_stage, (size_t)m * sizeof(cstark_tx_coeffs), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->coef_ev, c->stream));
     p.coef = c->coef_buf;
     p.rtab = c->coef_buf + COEF_WORDS;
     p.m = m;

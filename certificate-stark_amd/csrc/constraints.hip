@@ -1886,8 +1886,12 @@ hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_
 hipError_t launch_rounds_setup(const CeParams &p, hipStream_t stream) {
     const unsigned m = p.m ? p.m : 1;
     if (m > 3) return hipErrorInvalidValue;
+#ifdef CS_ROUNDS_MFMA // the matrix-core table of the inverse matrix: 14 more blocks and a zero-fill, only for the opt-in variant
     (void)hipMemsetAsync(p.rtab + RT_MT, 0, MT_BYTES, stream);
     hipLaunchKernelGGL(k_rounds_setup, dim3(RT_SECTIONS + 14, m), dim3(64), 0, stream, p.coef, p.ptab, p.rtab);
+#else
+    hipLaunchKernelGGL(k_rounds_setup, dim3(RT_SECTIONS, m), dim3(64), 0, stream, p.coef, p.ptab, p.rtab);
+#endif
     return hipGetLastError();
 }
 hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t stream) {

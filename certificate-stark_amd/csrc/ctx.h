@@ -81,6 +81,8 @@ struct cstark_ctx {
     std::deque<cs::CosetTable> cosets;
     std::deque<cs::PeriodicTable> periodic;
     uint64_t *coef_buf = nullptr; // device copy of the composition coefficients
+    void *coef_stage = nullptr;   // pinned host staging of the same block: the upload is asynchronous, no wait for the caller's struct
+    hipEvent_t coef_ev = nullptr; // recorded behind the upload; waited on before the staging block is rewritten
     std::deque<cs::PeriodicTable> small_periodic; // standalone sub-AIRs: keyed by (air, depth, log_n, log_b); coset/binv unused
     void *desc_buf = nullptr;     // device copy of a generic AIR description (cstark_air_combine)
     hipEvent_t part_ev[cs::CE_NUM_PARTS + 1] = {}; // optional per-launch timing of the fused constraint evaluation
