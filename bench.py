@@ -402,7 +402,7 @@ def main():
         roofline_rounds = entry("k_rounds_split (Rescue windows of the constraint evaluation, even cosets)" if split else
                                 "k_eval_fused<0> (Rescue windows of the constraint evaluation)", rounds_bytes, part_avg["rounds"],
                                 ["k_rounds_split<1>"] if split else ["k_eval_fused<0, 1>"],
-                                "longest single launch; bound by vector-instruction issue: 25.9 k instructions per point at 4.1 cycles each "
+                                "longest single launch; bound by vector-instruction issue: 22.9 k instructions per point at 4.5 cycles each "
                                 "(profiles/*_valu_pmc.csv, *_valu_issue_bench.txt)")
         roofline_stages = [roofline_lde, roofline_rounds]
         if args.mode == "prove":
