@@ -696,7 +696,10 @@ constexpr int SPLIT_TABLES = 13, SPLIT_FAM0 = 4, SPLIT_FINAL = 11;
 // M coefficient sets (the components of an extension proof): the windows' values are computed once, every set has its own tables
 // (rtab + c * CE_RTAB_WORDS) and its own block of SPLIT_TABLES output polynomials (out + c * SPLIT_TABLES * 4 n).
 template <int M>
-__global__ __launch_bounds__(FNT, M == 1 ? 3 : 2) void k_rounds_split(CeParams p, fp *__restrict__ out) {
+#ifndef CS_ROUNDS_SPLIT_WAVES
+#define CS_ROUNDS_SPLIT_WAVES 3 // measured: 2 waves 3.86 ms, 3 waves 3.15 ms, 4 waves (spills) 10.3 ms
+#endif
+__global__ __launch_bounds__(FNT, M == 1 ? CS_ROUNDS_SPLIT_WAVES : 2) void k_rounds_split(CeParams p, fp *__restrict__ out) {
     __shared__ fp ark2_lds[8 * 14];
     __shared__ __attribute__((aligned(16))) fp img_lds[(FNT / 64) * RW_IMG];
     __shared__ fp atab_lds[M * RT_SECTIONS * 8];
