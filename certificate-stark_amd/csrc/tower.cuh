@@ -41,13 +41,14 @@ __device__ __forceinline__ u128_t mul_wide(uint64_t a, uint64_t b) {
     return ((u128_t)t3 << 64) | ((t2 << 32) | (uint32_t)t0);
 }
 __device__ __forceinline__ fp reduce_wide(u128_t v) { return acc_reduce(Acc128{(uint64_t)v, (uint64_t)(v >> 64)}); } // v < 2p 2^64
+__device__ __forceinline__ fp reduce_wide_below_p(u128_t v) { return acc_reduce_below_p(Acc128{(uint64_t)v, (uint64_t)(v >> 64)}); } // v < p 2^64
 __device__ __forceinline__ Fp2 fp2_mul(Fp2 x, Fp2 y) {
     const u128_t v0 = mul_wide<true>(x.a, y.a), v1 = mul_wide<true>(x.b, y.b), v2 = mul_wide<false>(x.a + x.b, y.a + y.b);
-    return {reduce_wide(v0 + (v1 << 1)), reduce_wide(v2 - v0 + v1)};
+    return {reduce_wide_below_p(v0 + (v1 << 1)), reduce_wide(v2 - v0 + v1)}; // c0 < 3 p^2 < 0.77 p 2^64; c1 < 4 p^2 = 1.03 p 2^64
 }
 __device__ __forceinline__ Fp2 fp2_sqr(Fp2 x) {
     const u128_t v0 = mul_wide<true>(x.a, x.a), v1 = mul_wide<true>(x.b, x.b), v2 = mul_wide<false>(x.a + x.b, x.a + x.b);
-    return {reduce_wide(v0 + (v1 << 1)), reduce_wide(v2 - v0 + v1)};
+    return {reduce_wide_below_p(v0 + (v1 << 1)), reduce_wide(v2 - v0 + v1)}; // c0 < 3 p^2 < 0.77 p 2^64; c1 < 4 p^2 = 1.03 p 2^64
 }
 #else
 __device__ __forceinline__ Fp2 fp2_mul(Fp2 x, Fp2 y) {
