@@ -88,6 +88,10 @@ class Backend:
         self.lib.cstark_field_generator.restype = C.c_uint64
         return int(self.lib.cstark_field_generator())
 
+    def field_lde_offset(self):
+        self.lib.cstark_field_lde_offset.restype = C.c_uint64
+        return int(self.lib.cstark_field_lde_offset())
+
     def interpolate_columns(self, evals, out=None):
         """evals: int64 [width, n] tensor (destroyed). Returns the coefficient tensor."""
         width, n = evals.shape
@@ -102,7 +106,7 @@ class Backend:
         nk = (1 << log_blowup) - k0 if nk is None else nk
         if out is None:
             out = self.empty_u64(nk, width, n)
-        off = self.field_generator() if offset is None else int(offset)
+        off = self.field_lde_offset() if offset is None else int(offset)
         check(self.lib.cstark_lde_columns(self.ctx, self._ptr(coeffs), self._ptr(out), C.c_uint32(width),
                                           C.c_uint32(n.bit_length() - 1), C.c_uint32(log_blowup), C.c_uint64(off),
                                           C.c_uint32(k0), C.c_uint32(nk)))

@@ -117,9 +117,13 @@ int interpolate_impl(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint3
     return CSTARK_OK;
 }
 
-// part timing: an event on the stream, from a pool that grows on demand
+// part timing: an event on the stream, from a pool that grows on demand up to LDE_EVENT_CAP (reset by cstark_lde_timing_ms; a caller
+// that never collects stops being timed instead of growing the pool without bound)
+constexpr size_t LDE_EVENT_CAP = 4096;
 int lde_mark(cstark_ctx *c) {
     if (c->lde_ev_used == c->lde_ev.size()) {
+        if (c->lde_ev.size() >= LDE_EVENT_CAP) return CSTARK_ERR_UNSUPPORTED; // pool full: this extension is not timed
+
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         c->lde_ev.push_back(e);
@@ -134,11 +138,15 @@ int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uin
                    uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);
 int lde_impl(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n, uint32_t log_blowup,
              uint64_t domain_offset, uint32_t k0, uint32_t nk) {
-    const bool timed = c && c->part_timing;
-    if (timed) RC_TRY(lde_mark(c));
+    // events come in pairs: without room for both, or if the first cannot be recorded, the extension simply is not timed
+    bool timed = c && c->part_timing && c->lde_ev_used + 2 <= LDE_EVENT_CAP;
+    const size_t mark = timed ? c->lde_ev_used : 0;
+    if (timed && lde_mark(c) != CSTARK_OK) { c->lde_ev_used = mark; timed = false; }
     const int rc = lde_impl_inner(c, d_coeffs, d_lde, width, col0, ncols, log_n, log_blowup, domain_offset, k0, nk);
-    if (timed && rc == CSTARK_OK) { RC_TRY(lde_mark(c)); c->lde_units += (uint64_t)ncols * nk << log_n; }
-    else if (timed) c->lde_ev_used--;
+    if (timed) {
+        if (rc == CSTARK_OK && lde_mark(c) == CSTARK_OK) c->lde_units += (uint64_t)ncols * nk << log_n;
+        else c->lde_ev_used = mark; // never leave an unpaired event behind
+    }
     return rc;
 }
 int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n,
@@ -401,7 +409,8 @@ int cstark_tx_build_trace(cstark_ctx *c, uint64_t *d_trace) {
 }
 
 // ---- K2 / K3 ---------------------------------------------------------------------------------------
-uint64_t cstark_field_generator(void) { return cs::host::lde_offset(); }
+uint64_t cstark_field_generator(void) { return cs::host::generator(); }
+uint64_t cstark_field_lde_offset(void) { return cs::host::lde_offset(); }
 uint64_t cstark_field_root_of_unity(uint32_t log_n) { return log_n <= 55 ? cs::host::root_of_unity(log_n) : 0; }
 
 int cstark_interpolate_columns(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint32_t width, uint32_t log_n) {
@@ -716,9 +725,9 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
     constexpr size_t COEF_WORDS = (size_t)cs::CE_MAX_SETS * cs::CE_COEF_WORDS;
     if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, (COEF_WORDS + (size_t)cs::CE_MAX_SETS * cs::CE_RTAB_WORDS) * 8));
     // the caller's struct may be transient: copy it into the context's pinned staging block and upload from there without waiting
-    if (!c->coef_stage) {
+    if (!c->coef_stage) { // the event first: the staging block is only published once both exist
+        if (!c->coef_ev) HIP_TRY(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc(&c->coef_stage, (size_t)cs::CE_MAX_SETS * sizeof(cstark_tx_coeffs), hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
     } else {
         HIP_TRY(hipEventSynchronize(c->coef_ev)); // the previous upload has left the staging block (long ago, normally)
     }

@@ -11,14 +11,23 @@
 #include "trace_gen.h"
 
 // The prover waits for a root, a frame or an upload a dozen times per proof with the GPU idle until the host answers: poll the stream
-// instead of blocking in hipStreamSynchronize (whose wake-up costs tens of microseconds; FRI stage 0.69 -> 0.58 ms).  One host core is
-// busy while a proof runs.  CSTARK_SYNC_BLOCK=1 restores the blocking wait.
+// instead of blocking in hipStreamSynchronize (whose wake-up costs tens of microseconds; FRI stage 0.69 -> 0.58 ms).  The poll is
+// BOUNDED: the short waits (FRI layers, frames: tens of microseconds) end inside it; a long one (the 10 ms of the trace commitment, a
+// wedged stream) falls back to the blocking call after CSTARK_SPIN_US microseconds (default 200), so a context costs a host core only
+// in the latency-critical tail of a proof and never spins forever.  CSTARK_SYNC_BLOCK=1: always block.
+#include <chrono>
 namespace cs {
 inline hipError_t stream_wait(hipStream_t st) {
     static const bool block = [] { const char *e = getenv("CSTARK_SYNC_BLOCK"); return e && atoi(e) != 0; }();
-    if (block) return hipStreamSynchronize(st);
+    static const long spin_us = [] { const char *e = getenv("CSTARK_SPIN_US"); return e ? atol(e) : 200L; }();
+    if (block || spin_us <= 0) return hipStreamSynchronize(st);
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e;
-    while ((e = hipStreamQuery(st)) == hipErrorNotReady) {}
+    for (unsigned it = 0; (e = hipStreamQuery(st)) == hipErrorNotReady; it++) {
+        __builtin_ia32_pause();
+        if ((it & 15) == 15 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us)
+            return hipStreamSynchronize(st);
+    }
     return e;
 }
 } // namespace cs

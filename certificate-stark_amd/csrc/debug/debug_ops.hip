@@ -24,6 +24,8 @@ __global__ void k_fp_op(const fp *a, const fp *b, fp *out, size_t n, int op) {
         case 8: r = fp_dbl(x); break;
         case 9: r = wave_next(x, y); break; // lane l + 1's x, lane 63: its own y
         case 10: r = fp_mul(fp_sub_lazy(x, y), y); break; // the product takes an unreduced first factor in (0, 2p): (x - y) * y
+        case 11: { Acc128 acc; acc.lo = x; acc.hi = y; r = acc_reduce_below_p(acc); break; } // (y 2^64 + x) / 2^64 mod p, y <= p - 2^32
+        case 12: { Acc128 acc; acc.lo = x; acc.hi = y; r = acc_reduce(acc); break; }         // the same for y < 2p
     }
     out[i] = r;
 }

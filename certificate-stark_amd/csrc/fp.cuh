@@ -6,8 +6,10 @@
 //
 // CDNA4 notes: there is no 64x64 multiplier; a product is four v_mad_u64_u32.  Because
 // p = P1 * 2^32 + 1, -p^-1 mod 2^32 = 0xFFFFFFFF: each 32-bit REDC step is one negate plus one
-// v_mad_u64_u32 (the low word cancels by construction and only contributes a carry bit), for a
-// total of six v_mad_u64_u32 per modular multiplication.
+// v_mad_u64_u32 (the low word cancels by construction and only contributes a carry bit).  Two more
+// v_mad_u64_u32 (multiplies by an opaque 1) carry a word into a 64-bit sum where the compiler would
+// otherwise emit two moves and a 64-bit add: eight v_mad_u64_u32 per modular multiplication, 52 issue
+// cycles.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -201,8 +203,11 @@ __device__ __forceinline__ void acc_mad(Acc128 &acc, uint64_t a, uint64_t b) {
 __device__ __forceinline__ void acc_fold(Acc128 &acc) {
     if (acc.hi >= 2 * FP_P) acc.hi -= 2 * FP_P;
 }
-// The same for an accumulator below p * 2^64 (hi < p): the result of the two REDC steps is then below 2p -- r < (2^32 - 1) P1 + hi + 2^31
-// < p + hi -- and ONE conditional subtraction finishes it (12 issue cycles saved).  E.g. a0 b0 + 2 a1 b1 < 3 p^2 = 0.77 p * 2^64.
+// The same with ONE conditional subtraction (12 issue cycles saved) for an accumulator whose high word is at most p - 2^32.
+// PRECONDITION acc.hi <= p - 2^32 (NOT merely hi < p): the second REDC step gives r = (2^32 - 1 - v0) P1 + hi + (v >> 32) + P1 + 1 with
+// (v >> 32) + P1 + 1 <= 2 (P1 + 1), i.e. r <= 2^32 P1 + hi + 2 P1 + 2 = p + hi + 2 P1 + 1 < p + hi + 2^31.04, and r < 2p needs
+// hi < p - 2 P1 - 1, which hi <= p - 2^32 guarantees.  Both callers: the F_p2 component a0 b0 + 2 a1 b1 < 3 p^2 = 0.77 p * 2^64
+// (tower.cuh).  tests/test_gpu_field.py drives the boundary hi = p - 2^32 and the first failing hi = p - 2 P1 - 1.
 __device__ __forceinline__ fp acc_reduce_below_p(const Acc128 &acc) {
     constexpr uint64_t K = (uint64_t)FP_P1 + 1;
     const uint64_t v = mad_u64_u32(~(uint32_t)acc.lo, FP_P1, (acc.lo >> 32) + K);

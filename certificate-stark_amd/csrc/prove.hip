@@ -272,7 +272,15 @@ struct AirJob {
     const uint64_t *bits = nullptr; // RangeProofAir, long form: the n/64 words of the value (host)
 };
 
+// A sharded proof in progress (cstark_tx_shard_*) lives in the arena's buffers between its phases.  Anything else that takes the arena --
+// a whole proof on the same context, a new sharded proof, a replacement of the arena -- ends it: the later phases then fail with "phase
+// called out of order" instead of building a proof from foreign buffers.
+void drop_run(ProveArena *a) {
+    if (a && a->run) { proof_run_free(a->run); a->run = nullptr; }
+}
+
 int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned n_layers, size_t nq, ProveArena **out) {
+    drop_run(c->arena);
     if (c->arena && c->arena->air == job.air && c->arena->log_n == job.log_n && c->arena->log_b == log_b && c->arena->layer.size() == n_layers + 1 &&
         c->arena->open_bytes >= nq) { *out = c->arena; return CSTARK_OK; }
     if (c->arena) { HIP_TRY(hipStreamSynchronize(c->stream)); prove_arena_free(c->arena); c->arena = nullptr; }
@@ -1119,11 +1127,12 @@ int cstark_tx_shard_commit(cstark_ctx *c, const cstark_options *opt, uint32_t k0
     ProofRun *R = new (std::nothrow) ProofRun();
     if (!R) return fail(CSTARK_ERR_OOM, "host allocation failed");
     ProveArena *a = nullptr;
-    int rc = run_setup(c, opt, job, *R, &a);
+    int rc = run_setup(c, opt, job, *R, &a); // ends any earlier run on this context (get_arena)
     if (rc) { delete R; return rc; }
-    proof_run_free(a->run);
     a->run = R;
-    return phase_commit(c, a, *R, d_leaves_local);
+    rc = phase_commit(c, a, *R, d_leaves_local);
+    if (rc) { proof_run_free(a->run); a->run = nullptr; }
+    return rc;
 }
 int cstark_tx_shard_evaluate(cstark_ctx *c, const uint8_t *d_leaves_all, uint64_t *d_combined_local) {
     ProofRun *R;
@@ -1145,7 +1154,12 @@ int cstark_tx_shard_compose(cstark_ctx *c, const uint64_t *d_combined_all, uint3
 int cstark_tx_shard_open_rows(cstark_ctx *c, const uint32_t *positions, uint32_t nq, uint64_t *d_rows) {
     ProofRun *R;
     RC_TRY(shard_run(c, 2, &R));
-    if (!positions || !d_rows || nq == 0 || nq > 128) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_open_rows: bad argument");
+    if (!positions || !d_rows) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_open_rows: null argument");
+    // d_rows is sized by the caller's nq and read back as num_queries rows by cstark_tx_shard_finish: they must agree
+    if (nq != R->opt.num_queries) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_open_rows: nq differs from the proof's num_queries");
+    const uint32_t N = 8u << R->job.log_n;
+    for (uint32_t q = 0; q < nq; q++)
+        if (positions[q] >= N) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_open_rows: position outside the LDE domain");
     ProveArena *a = c->arena;
     HIP_TRY(hipMemcpyAsync(a->d_pos, positions, nq * 4, hipMemcpyHostToDevice, c->stream));
     k_gather_rows_window<<<nq, 128, 0, c->stream>>>(a->lde, R->job.width, R->job.log_n, 3, R->job.k0, R->job.nk, a->d_pos, d_rows);
@@ -1157,6 +1171,7 @@ int cstark_tx_shard_finish(cstark_ctx *c, const uint64_t *d_rows, uint8_t *proof
     ProofRun *R;
     RC_TRY(shard_run(c, 3, &R));
     if (!d_rows || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_finish: null argument");
+    if (R->job.k0 != 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_finish runs on the rank that owns coset 0");
     const int rc = phase_open(c, c->arena, *R, d_rows, proof, capacity, proof_len);
     if (rc == CSTARK_OK) { proof_run_free(c->arena->run); c->arena->run = nullptr; }
     return rc;

@@ -23,12 +23,43 @@ def coset_range(rank, world, blowup):
     return rank * nk, nk
 
 
+def _via_host(t, group):
+    """A gloo group moving device tensors (the one-GPU rehearsal: RCCL refuses two ranks on one device): stage through the host.
+    RCCL groups and CPU tensors go straight through."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def all_gather_cosets(local, group=None):
     """local: [nk, ...] tensor of this rank's cosets (same shape on every rank) -> [world * nk, ...] in coset order."""
     world = dist.get_world_size(group)
+    if _via_host(local, group):
+        host = local.contiguous().cpu()
+        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(local.device)
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     return out
+
+
+def broadcast_(t, src, group=None):
+    if _via_host(t, group):
+        host = t.cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def reduce_sum_(t, dst, group=None):
+    if _via_host(t, group):
+        host = t.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return t
 
 
 def leaves_to_natural_order(coset_major):
@@ -51,7 +82,7 @@ def prove_sharded(backend, options, group=None):
     else:
         positions = torch.zeros(options.num_queries, dtype=torch.int32, device=combined.device)
     src = dist.get_global_rank(group, 0) if group is not None else 0
-    dist.broadcast(positions, src=src, group=group)
+    broadcast_(positions, src, group)
     rows = backend.shard_open_rows(positions)
-    dist.reduce(rows, dst=src, op=dist.ReduceOp.SUM, group=group)                   # every row is nonzero on exactly one rank
+    reduce_sum_(rows, src, group)                                                   # every row is nonzero on exactly one rank
     return backend.shard_finish(rows) if rank == 0 else None

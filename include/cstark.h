@@ -116,14 +116,15 @@ int cstark_tx_build_trace(cstark_ctx *ctx, uint64_t *d_trace);
 /* ---- K2/K3: low-degree extension (engine: trace.extend) ------------------------------------- */
 /* Field conventions of the engine [UPSTREAM-RECALL]: multiplicative generator (domain offset) and
  * the primitive 2^log_n-th root of unity, in memory form. */
-uint64_t cstark_field_generator(void);
+uint64_t cstark_field_generator(void);   /* multiplicative generator of the field (CSTARK_CONV_GENERATOR) */
+uint64_t cstark_field_lde_offset(void);  /* domain offset of the STARK's LDE domain (CSTARK_CONV_LDE_OFFSET; the generator unless flipped) */
 uint64_t cstark_field_root_of_unity(uint32_t log_n);
 /* d_evals: width x n evaluations over the trace domain <w_n> (natural order); it is used as scratch
  * and destroyed.  d_coeffs (distinct buffer): width x n polynomial coefficients, natural order. */
 int cstark_interpolate_columns(cstark_ctx *ctx, uint64_t *d_evals, uint64_t *d_coeffs, uint32_t width, uint32_t log_n);
 /* d_coeffs: width x n coefficients.  d_lde: cosets [k0, k0+nk) of the blowup-times larger domain,
  * coset-major:  d_lde[((k - k0) * width + c) * n + j] = f_c(offset * w_{bn}^k * w_n^j),
- * i.e. natural LDE-domain index i = b*j + k.  offset = cstark_field_generator() for the STARK domain.
+ * i.e. natural LDE-domain index i = b*j + k.  offset = cstark_field_lde_offset() for the STARK domain.
  * Sharding by coset is what distributes one proof over several GPUs. */
 int cstark_lde_columns(cstark_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t log_n,
                        uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);

@@ -9,7 +9,7 @@
  * This header is plain C preprocessor: the product (certificate-stark_amd/csrc, C++/HIP) and the CPU oracle (oracle/, C; its Python
  * half reads the values back through cso_conventions()) include the SAME file, so flipping a line and rebuilding moves both sides
  * together and the parity suite stays meaningful.  Every value can also be overridden with -D for both builds at once:
- * tools/flip_conventions.sh does that and re-runs the GPU-against-oracle parity tests under the flipped conventions.
+ * tools/flip_conventions.py does that and re-runs the GPU-against-oracle parity tests under the flipped conventions.
  */
 #ifndef CSTARK_CONVENTIONS_H
 #define CSTARK_CONVENTIONS_H

@@ -13,7 +13,9 @@
 extern "C" {
 #endif
 /* out[i] = op(a[i], b[i]); op: 0 mul, 1 add, 2 sub, 3 inverse, 4 x^(1/alpha) (Rescue inverse S-box, src/utils/rescue.rs:337-341),
- * 5 from canonical, 6 to canonical, 7 negate, 8 double, 9 wave_next (lane l gets a of lane l + 1, lane 63 its own b). */
+ * 5 from canonical, 6 to canonical, 7 negate, 8 double, 9 wave_next (lane l gets a of lane l + 1, lane 63 its own b),
+ * 10 (a - b) * b with the unreduced difference, 11 / 12 Montgomery reduction of the 128-bit accumulator b 2^64 + a
+ * (acc_reduce_below_p: b <= p - 2^32; acc_reduce: b < 2p). */
 int cstark_debug_fp_op(void *stream, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n, int op);
 /* n independent F_p6 operations (src/utils/ecc.rs:506-591); op: 0 mul, 1 square, 2 inverse. */
 int cstark_debug_fp6_op(void *stream, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n, int op);

@@ -15,21 +15,129 @@ def _mont(v):
     return V.to_mont(v)
 
 
+# ---- what differs between the AIRs (the product's AirJob, csrc/prove.hip): how the trace is built, what seeds the channel, how the merged
+# ---- constraint evaluations are produced from the extended trace and ONE set of base-field coefficients --------------------------------
+class TxJob:
+    """TransactionAir (src/air.rs:64-189; TransactionProver src/prover.rs:20-134)"""
+    air, width, ce, nc, na = 0, 94, 8, 115, 4
+
+    def __init__(self, w):
+        self.w, self.item = w, w.depth
+
+    def build(self):
+        return O.tx_build_trace(self.w)
+
+    def public(self, trace):
+        n = trace.shape[1]
+        self.pub_m = [int(trace[58 + i, 0]) for i in range(7)] + [int(trace[58 + i, n - 1]) for i in range(7)]  # src/prover.rs:106-129
+        return self.pub_m, b""
+
+    def combine(self, trace, lde, ta, tb, ba, bb, k0=0):
+        cf = O.TxCoeffsStruct()
+        for i in range(115):
+            cf.t_alpha[i], cf.t_beta[i] = int(ta[i]), int(tb[i])
+        for i in range(4):
+            cf.b_alpha[i], cf.b_beta[i] = int(ba[i]), int(bb[i])
+        pub4 = np.array([self.pub_m[0], self.pub_m[1], self.pub_m[7], self.pub_m[8]], np.uint64)  # get_assertions, src/air.rs:175-184
+        return O.tx_evaluate_constraints(lde, cf, pub4, self.w.depth, 3, k0=k0)
+
+
+def _on_ce_cosets(evaluate, lde, nc, log_ce):
+    """transition values [8][nc][n] on the cosets of the constraint-evaluation domain only (every (8 >> log_ce)-th), zeros elsewhere"""
+    out = np.zeros((8, nc, lde.shape[2]), np.uint64)
+    for k in range(0, 8, 8 >> log_ce):
+        out[k] = evaluate(lde[k:k + 1], k)[0]
+    return out
+
+
+class MerkleJob:
+    """MerkleAir (src/merkle/update/air.rs:36-177; MerkleProver src/merkle/update/prover.rs:19-116; prove: src/merkle/update/mod.rs:81-106)"""
+    air, width, ce, nc, na = 1, 65, 4, 106, 14
+
+    def __init__(self, w):
+        self.w, self.item = w, w.depth
+
+    def build(self):
+        return O.merkle_build_trace(self.w)
+
+    def public(self, trace):
+        n = trace.shape[1]
+        return [int(trace[58 + i, 0]) for i in range(7)] + [int(trace[58 + i, n - 1]) for i in range(7)], b""
+
+    def combine(self, trace, lde, ta, tb, ba, bb, k0=0):
+        assert k0 == 0 and lde.shape[0] == 8
+        log_n = trace.shape[1].bit_length() - 1
+        if not hasattr(self, "ev"):  # once per proof (extension proofs merge m coefficient sets)
+            ptab = O.periodic_table(O.merkle_periodic_columns(self.w.depth), log_n, 3)
+            self.ev = _on_ce_cosets(lambda l, k: O.air_evaluate_transitions(O.AIR_MERKLE, l, ptab, 106, k0=k), lde, 106, 2)
+        return O.air_combine(O.merkle_desc(trace), lde, self.ev, ta, tb, ba, bb, 3)
+
+
+class RangeJob:
+    """RangeProofAir (src/range/air.rs:23-105; RangeProver src/range/prover.rs:15-59; prove: src/range/mod.rs:75-100).  words / log_n:
+    the synthetic long accumulator of cstark_range_prove_bits; number: a field element in memory form (the reference's 64-row proof)."""
+    air, width, ce, nc, na, item = 3, 2, 2, 2, 2, 0
+
+    def __init__(self, number=None, words=None, log_n=6):
+        self.number, self.words, self.log_n = number, words, log_n
+
+    def build(self):
+        if self.words is not None:
+            trace, self.number = O.range_build_trace_bits(self.words, self.log_n)
+            return trace
+        return O.range_build_trace(V.from_mont(self.number))
+
+    def public(self, trace):
+        return [int(self.number)], b""
+
+    def combine(self, trace, lde, ta, tb, ba, bb, k0=0):
+        assert k0 == 0 and lde.shape[0] == 8
+        if not hasattr(self, "ev"):
+            self.ev = _on_ce_cosets(lambda l, k: O.air_evaluate_transitions(O.AIR_RANGE, l, None, 2, k0=k), lde, 2, 1)
+        return O.air_combine(O.range_desc(V.from_mont(self.number)), lde, self.ev, ta, tb, ba, bb, 3)
+
+
+class SchnorrJob:
+    """SchnorrAir (src/schnorr/air.rs:41-300; SchnorrProver src/schnorr/prover.rs:21-90; prove: src/schnorr/mod.rs:143-172)"""
+    air, width, ce, nc, na = 2, 56, 8, 56, 61
+
+    def __init__(self, w):
+        self.w, self.item = w, w.n_sig
+
+    def build(self):
+        return O.schnorr_build_trace(self.w)
+
+    def public(self, trace):  # messages [n][28] then R.x [n][6] (src/schnorr/air.rs:29-38), then the s halves verbatim
+        w = self.w
+        return [int(v) for v in w.messages.reshape(-1)] + [int(v) for v in w.sig_rx.reshape(-1)], w.sig_s.tobytes()
+
+    def combine(self, trace, lde, ta, tb, ba, bb, k0=0):
+        assert k0 == 0 and lde.shape[0] == 8
+        w = self.w
+        log_n = trace.shape[1].bit_length() - 1
+        if not hasattr(self, "ev"):
+            aux_lde = O.lde_columns(O.interpolate_columns(O.schnorr_aux_columns(w)), 3)  # not committed: both sides derive them
+            self.ev = O.schnorr_evaluate_transitions(lde, aux_lde, O.periodic_table(O.schnorr_mask_columns(), log_n, 3))
+            self.avals = O.lde_columns(O.schnorr_assertion_polys(w, log_n), 3)
+        return O.air_combine(O.schnorr_desc(w), lde, self.ev, ta, tb, ba, bb, 3, avals=self.avals)
+
+
 class ShardedProver:
     """The base-field prover as the phases of the product's sharded entry points (cstark_tx_shard_*, include/cstark.h): one proof
     across `world` ranks by LDE coset.  Rank r owns cosets [k0, k0 + nk); prove() below is the one-rank case.  A phase's output that
     other ranks need is returned as a numpy array; the caller exchanges it (all-gather / broadcast / sum)."""
 
-    def __init__(self, w, options, k0=0, nk=8):
+    def __init__(self, w, options, k0=0, nk=8, job=None):
         nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
         assert blowup == 8 and hash_fn in (0, 1) and ext == 0 and folding == 4
+        self.job = job if job is not None else TxJob(w)
         self.w, self.options, self.k0, self.nk = w, tuple(options), k0, nk
         self.H = lambda data: O.digest(data, hash_fn)
 
     def commit(self):
         """trace + interpolation (replicated), extension and row hashes of the owned cosets -> digests [nk][n][32]"""
         hash_fn = self.options[3]
-        self.trace = O.tx_build_trace(self.w)
+        self.trace = self.job.build()
         self.n = self.trace.shape[1]
         self.log_n = self.n.bit_length() - 1
         self.coeffs = O.interpolate_columns(self.trace.copy())
@@ -44,28 +152,29 @@ class ShardedProver:
         self.tnodes = O.merkle_build(natural, hash_fn)
         self.trace_root = self.tnodes[1].tobytes()
         self.log_rem = max_rem.bit_length() - 1
-        pub_m = [int(trace[58 + i, 0]) for i in range(7)] + [int(trace[58 + i, n - 1]) for i in range(7)]  # src/prover.rs:106-129
+        job = self.job
+        pub_m, pub_bytes = job.public(trace)
         pub = [V.from_mont(v) for v in pub_m]
-        seed = bytes([94, log_n]) + struct.pack("<Q", V.P) + bytes([nq, 3, grinding, hash_fn, ext, folding, self.log_rem])
-        seed += b"".join(struct.pack("<Q", v) for v in pub)
+        seed = bytes([job.width, log_n]) + struct.pack("<Q", V.P) + bytes([nq, 3, grinding, hash_fn, ext, folding, self.log_rem])
+        seed += b"".join(struct.pack("<Q", v) for v in pub) + pub_bytes
         self.coin = coin = V.Coin(seed, hash_fn)
         coin.reseed(self.trace_root)
-        cf = O.TxCoeffsStruct()
-        for i in range(115):
-            cf.t_alpha[i], cf.t_beta[i] = _mont(coin.draw()), _mont(coin.draw())
-        for i in range(4):
-            cf.b_alpha[i], cf.b_beta[i] = _mont(coin.draw()), _mont(coin.draw())
-        pub4 = np.array([pub_m[0], pub_m[1], pub_m[7], pub_m[8]], np.uint64)
-        return O.tx_evaluate_constraints(self.lde, cf, pub4, self.w.depth, 3, k0=self.k0)
+        ta, tb, ba, bb = (np.zeros(k, np.uint64) for k in (job.nc, job.nc, job.na, job.na))
+        for i in range(job.nc):
+            ta[i], tb[i] = _mont(coin.draw()), _mont(coin.draw())
+        for i in range(job.na):
+            ba[i], bb[i] = _mont(coin.draw()), _mont(coin.draw())
+        return job.combine(trace, self.lde, ta, tb, ba, bb, k0=self.k0)
 
     def compose(self, combined):
         """combined [8][n] (all cosets); the owner of coset 0: composition .. FRI -> query positions"""
         assert self.k0 == 0
         nq, blowup, grinding, hash_fn, ext, folding, max_rem = self.options
         H, coin, log_n, n = self.H, self.coin, self.log_n, self.n
-        log_b, b, W = 3, 8, 94
+        log_b, b, W, ce = 3, 8, self.job.width, self.job.ce
         log_N, N = log_n + 3, n * 8
-        self.ccoef = ccoef = O.composition_columns(combined)
+        # a constraint-evaluation domain smaller than the LDE domain is the sub-domain of every (b / ce)-th LDE coset
+        self.ccoef = ccoef = O.composition_columns(np.ascontiguousarray(combined[::b // ce]))
         self.clde = clde = O.lde_columns(ccoef, log_b)
         self.cnodes = O.merkle_build(O.hash_rows(clde, log_b, hash_fn=hash_fn), hash_fn)
         self.cons_root = self.cnodes[1].tobytes()
@@ -73,15 +182,15 @@ class ShardedProver:
         z = coin.draw()
         zm = _mont(z)
         zw = _mont(z * V.root_of_unity(log_n) % V.P)
-        zb = _mont(pow(z, b, V.P))
-        self.ood_trace = ood_trace = O.evaluate_polys_at(self.coeffs, [zm, zw])          # [2][94]
-        self.ood_comp = ood_comp = O.evaluate_polys_at(ccoef, [zb])[0]                   # [8]
+        zb = _mont(pow(z, ce, V.P))
+        self.ood_trace = ood_trace = O.evaluate_polys_at(self.coeffs, [zm, zw])          # [2][W]
+        self.ood_comp = ood_comp = O.evaluate_polys_at(ccoef, [zb])[0]                   # [ce]
         coin.reseed(H(V.elem_bytes(ood_trace)))
         coin.reseed(H(V.elem_bytes(ood_comp)))
         d_alpha, d_beta = [], []
         for _ in range(W):
             d_alpha.append(_mont(coin.draw())); d_beta.append(_mont(coin.draw())); [coin.draw() for _ in range(2, V.CONV["deep_draws_per_register"])]
-        d_delta = [_mont(coin.draw()) for _ in range(b)]
+        d_delta = [_mont(coin.draw()) for _ in range(ce)]
         deg_a, deg_b = _mont(coin.draw()), _mont(coin.draw())
         # the DEEP composition polynomial has degree < n: coset 0 of the extended trace determines it (as the product computes it)
         if self.nk == 8:
@@ -114,7 +223,7 @@ class ShardedProver:
 
     def open_rows(self, positions):
         """rows of the extended trace at the positions that lie in the owned cosets, zeros elsewhere: [nq][94]"""
-        out = np.zeros((len(positions), 94), np.uint64)
+        out = np.zeros((len(positions), self.job.width), np.uint64)
         for q, p in enumerate(positions):
             k, j = int(p) & 7, int(p) >> 3
             if self.k0 <= k < self.k0 + self.nk:
@@ -134,7 +243,7 @@ class ShardedProver:
             return np.ascontiguousarray(tab[pos & 7, :, pos >> 3]).tobytes()
 
         roots = self.roots
-        out = [b"CSTK", struct.pack("<IIIII", 1, 0, 94, log_n, self.w.depth), struct.pack("<7I", *self.options),
+        out = [b"CSTK", struct.pack("<IIIII", 1, self.job.air, self.job.width, log_n, self.job.item), struct.pack("<7I", *self.options),
                self.trace_root, self.cons_root, struct.pack("<I", len(roots))] + roots + [self.rem_commit, self.ood_trace.tobytes(),
                                                                                          self.ood_comp.tobytes(), struct.pack("<Q", self.nonce)]
         out += [np.ascontiguousarray(rows[q]).tobytes() for q in range(len(positions))] + [path(self.tnodes, log_N, p) for p in positions]
@@ -153,53 +262,80 @@ class ShardedProver:
         return b"".join(out)
 
 
-def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
+def _prove_job(job, options):
     if options[4] in (1, 2):
-        return prove_ext(w, options)
-    p = ShardedProver(w, options)
+        return prove_ext(job, options)
+    p = ShardedProver(None, options, job=job)
     leaves = p.commit()
     combined = p.evaluate(leaves)
     positions = p.compose(combined)
     return p.finish(p.open_rows(positions))
 
 
-def prove_ext(w, options):
+def prove(w, options=(42, 8, 0, 0, 0, 4, 256)):
+    """TransactionExample::prove (src/lib.rs:116-141)"""
+    return _prove_job(TxJob(w), options)
+
+
+def prove_air(air, witness, options=(42, 8, 0, 0, 0, 4, 256), log_n=6):
+    """The standalone AIRs' prove() -- the CPU counterpart of cstark_air_prove / cstark_range_prove_bits, byte for byte:
+    O.AIR_MERKLE   witness = TxWitness          (src/merkle/update/mod.rs:81-106)
+    O.AIR_SCHNORR  witness = SchnorrWitness     (src/schnorr/mod.rs:143-172)
+    O.AIR_RANGE    witness = field element in memory form (src/range/mod.rs:75-100), or -- the synthetic long accumulator -- the
+                   n / 64 little-endian words of the value together with log_n."""
+    if air == O.AIR_STATE_TRANSITION:
+        return prove(witness, options)
+    if air == O.AIR_MERKLE:
+        return _prove_job(MerkleJob(witness), options)
+    if air == O.AIR_SCHNORR:
+        return _prove_job(SchnorrJob(witness), options)
+    if air == O.AIR_RANGE:
+        if isinstance(witness, (int, np.integer)):
+            return _prove_job(RangeJob(number=int(witness)), options)
+        return _prove_job(RangeJob(words=np.ascontiguousarray(witness, np.uint64), log_n=log_n), options)
+    raise ValueError("no prover for this AIR")
+
+
+def prove_ext(job, options):
     """FieldExtension::Quadratic / Cubic: base-field trace, everything drawn from the coin in the degree-m extension (oracle/ext.c).
-    Layout differences: out-of-domain values are m-tuples; composition rows hold 8 m-tuples; FRI rows and the remainder are
+    Layout differences: out-of-domain values are m-tuples; composition rows hold ce m-tuples; FRI rows and the remainder are
     component-major (component 0 of the four points, then component 1, ...)."""
+    if not hasattr(job, "combine"):
+        job = TxJob(job)  # a TxWitness
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
     assert blowup == 8 and hash_fn in (0, 1) and ext in (1, 2) and folding == 4
     m = ext + 1
     H = lambda data: O.digest(data, hash_fn)
-    log_b, b, W = 3, 8, 94
-    trace = O.tx_build_trace(w)
+    log_b, b, W, ce = 3, 8, job.width, job.ce
+    trace = job.build()
     n = trace.shape[1]
     log_n = n.bit_length() - 1
     log_N, N = log_n + 3, n * 8
     log_rem = max_rem.bit_length() - 1
-    pub_m = [int(trace[58 + i, 0]) for i in range(7)] + [int(trace[58 + i, n - 1]) for i in range(7)]
+    pub_m, pub_bytes = job.public(trace)
     pub = [V.from_mont(v) for v in pub_m]
     coeffs = O.interpolate_columns(trace.copy())
     lde = O.lde_columns(coeffs, log_b)
     tnodes = O.merkle_build(O.hash_rows(lde, log_b, hash_fn=hash_fn), hash_fn)
     trace_root = tnodes[1].tobytes()
     seed = bytes([W, log_n]) + struct.pack("<Q", V.P) + bytes([nq, log_b, grinding, hash_fn, ext, folding, log_rem])
-    seed += b"".join(struct.pack("<Q", v) for v in pub)
+    seed += b"".join(struct.pack("<Q", v) for v in pub) + pub_bytes
     coin = V.Coin(seed, hash_fn)
     coin.reseed(trace_root)
-    cfs = [O.TxCoeffsStruct() for _ in range(m)]
-    for i in range(115):
+    ta, tb = np.zeros((m, job.nc), np.uint64), np.zeros((m, job.nc), np.uint64)
+    ba, bb = np.zeros((m, job.na), np.uint64), np.zeros((m, job.na), np.uint64)
+    for i in range(job.nc):
         a, bt = coin.draw_e(m), coin.draw_e(m)
         for k in range(m):
-            cfs[k].t_alpha[i], cfs[k].t_beta[i] = _mont(a[k]), _mont(bt[k])
-    for i in range(4):
+            ta[k, i], tb[k, i] = _mont(a[k]), _mont(bt[k])
+    for i in range(job.na):
         a, bt = coin.draw_e(m), coin.draw_e(m)
         for k in range(m):
-            cfs[k].b_alpha[i], cfs[k].b_beta[i] = _mont(a[k]), _mont(bt[k])
-    pub4 = np.array([pub_m[0], pub_m[1], pub_m[7], pub_m[8]], np.uint64)
-    # coefficients multiply base-field values: the components of the merged evaluations are independent base-field merges
-    cc = [O.composition_columns(O.tx_evaluate_constraints(lde, cfs[k], pub4, w.depth, log_b)) for k in range(m)]
-    ccoef = np.ascontiguousarray(np.stack(cc, axis=1).reshape(m * b, n))  # column m i + k = component k of H_i
+            ba[k, i], bb[k, i] = _mont(a[k]), _mont(bt[k])
+    # coefficients multiply base-field values: the components of the merged evaluations are independent base-field merges (on the
+    # cosets of the constraint-evaluation domain: every (b / ce)-th LDE coset)
+    cc = [O.composition_columns(np.ascontiguousarray(job.combine(trace, lde, ta[k], tb[k], ba[k], bb[k])[::b // ce])) for k in range(m)]
+    ccoef = np.ascontiguousarray(np.stack(cc, axis=1).reshape(m * ce, n))  # column m i + k = component k of H_i
     clde = O.lde_columns(ccoef, log_b)
     cnodes = O.merkle_build(O.hash_rows(clde, log_b, hash_fn=hash_fn), hash_fn)
     cons_root = cnodes[1].tobytes()
@@ -207,12 +343,12 @@ def prove_ext(w, options):
 
     z = coin.draw_e(m)
     zw = V.e_scale(z, V.root_of_unity(log_n))
-    zb = V.e_pow(z, b)
+    zb = V.e_pow(z, ce)
     ood_cur = O.evaluate_polys_at_ext(coeffs, V.e_mont(z))
     ood_next = O.evaluate_polys_at_ext(coeffs, V.e_mont(zw))
     raw = O.evaluate_polys_at_ext(ccoef, V.e_mont(zb))                     # each component polynomial at z^8
-    ood_comp = np.zeros((b, m), np.uint64)
-    for i in range(b):
+    ood_comp = np.zeros((ce, m), np.uint64)
+    for i in range(ce):
         h, gk = V.e_base(0, m), V.e_base(1, m)
         for k in range(m):                                                  # H_i = sum_k root^k H_i,k
             h = V.e_add(h, V.e_mul(gk, tuple(V.from_mont(v) for v in raw[m * i + k])))
@@ -226,7 +362,7 @@ def prove_ext(w, options):
         d_alpha[c], d_beta[c] = V.e_mont(coin.draw_e(m)), V.e_mont(coin.draw_e(m))
         for _ in range(2, V.CONV["deep_draws_per_register"]):
             coin.draw_e(m)
-    d_delta = np.array([V.e_mont(coin.draw_e(m)) for _ in range(b)], np.uint64)
+    d_delta = np.array([V.e_mont(coin.draw_e(m)) for _ in range(ce)], np.uint64)
     deg_a, deg_b = V.e_mont(coin.draw_e(m)), V.e_mont(coin.draw_e(m))
     deep = O.deep_composition_ext(lde, clde, V.e_mont(z), ood_trace, ood_comp, d_alpha, d_beta, d_delta, deg_a, deg_b, log_b)
     layer = np.ascontiguousarray(np.stack([np.ascontiguousarray(deep[k].T).reshape(-1) for k in range(m)]))  # [m][N] natural order
@@ -258,7 +394,7 @@ def prove_ext(w, options):
     def row(tab, pos):
         return np.ascontiguousarray(tab[pos & 7, :, pos >> 3]).tobytes()
 
-    out = [b"CSTK", struct.pack("<IIIII", 1, 0, W, log_n, w.depth), struct.pack("<7I", *options),
+    out = [b"CSTK", struct.pack("<IIIII", 1, job.air, W, log_n, job.item), struct.pack("<7I", *options),
            trace_root, cons_root, struct.pack("<I", len(roots))] + roots + [rem_commit, ood_trace.tobytes(), ood_comp.tobytes(),
                                                                            struct.pack("<Q", nonce)]
     out += [row(lde, p) for p in positions] + [path(tnodes, log_N, p) for p in positions]

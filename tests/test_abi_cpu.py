@@ -82,7 +82,10 @@ def test_host_air_description_matches_oracle(oracle):
     assert lib.cstark_tx_periodic_columns(C.c_uint32(64), out.ctypes.data_as(C.POINTER(C.c_uint64))) == -1
     lib.cstark_field_generator.restype = C.c_uint64
     lib.cstark_field_root_of_unity.restype = C.c_uint64
-    assert lib.cstark_field_generator() == oracle.generator()
+    lib.cstark_field_lde_offset.restype = C.c_uint64
+    assert lib.cstark_field_lde_offset() == oracle.generator()   # the oracle's "generator" is its domain offset
+    from oracle import verifier as V
+    assert lib.cstark_field_generator() == int(oracle.to_mont([V.CONV["generator"]])[0])
     for k in (1, 10, 20, 23):
         assert lib.cstark_field_root_of_unity(C.c_uint32(k)) == oracle.root_of_unity(k)
 

@@ -58,6 +58,30 @@ def test_fp_ops(oracle, backend):
         assert (_run(backend, "cstark_debug_fp_op", la, lb, len(la), 0, len(la)) == oracle.fp_mul(la, lb)).all()
 
 
+def test_wide_accumulator_reductions_at_their_bounds(backend):
+    """acc_reduce_below_p (one conditional subtraction) is sound for a high word up to p - 2^32 -- not for every hi < p, as its
+    comment once said -- and acc_reduce for hi < 2p.  Drives the boundary with the low words that maximise the unreduced result
+    (low 32 bits of the first REDC step zero, its high part as large as it gets)."""
+    rng = random.Random(77)
+    P1, K, M32 = 0x41800000, 0x41800001, 2**32 - 1
+    lows = [0, 1, 2**64 - 1, 2**32 - 1, 2**32, 2**63]
+    for lo0 in (0, 1, 2, 0x80000000, M32, 12345):      # craft lo1 so that v = ~lo0 * P1 + lo1 + K has a zero low word
+        lo1 = (-(((~lo0) & M32) * P1 + K)) & M32
+        lows.append((lo1 << 32) | lo0)
+    lows += [rng.randrange(2**64) for _ in range(500)]
+    r_inv = pow(2**64, -1, P)
+
+    def check(op, his):
+        lo = np.array([l for l in lows for _ in his], np.uint64)
+        hi = np.array([h for _ in lows for h in his], np.uint64)
+        got = _run(backend, "cstark_debug_fp_op", lo, hi, len(lo), op, len(lo))
+        want = np.array([((int(h) << 64) + int(l)) * r_inv % P for l, h in zip(lo, hi)], np.uint64)
+        assert (got == want).all()
+    below = [0, 1, P - 2**32, P - 2**32 - 1, (3 * P * P) >> 64, 2**62, 2**32] + [rng.randrange(P - 2**32 + 1) for _ in range(50)]
+    check(11, below)
+    check(12, below + [P - 1, P, P + 1, 2 * P - 1, 2 * P - 2**32] + [rng.randrange(2 * P) for _ in range(50)])
+
+
 def test_fp6_ops(oracle, backend):
     rng = random.Random(10)
     n = 512

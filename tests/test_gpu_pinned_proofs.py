@@ -1,0 +1,209 @@
+"""GPU: every proof the MI355X is timed on is pinned to the CPU restatement of the prover byte for byte.
+
+* small sizes: cstark_air_prove / cstark_range_prove_bits == oracle/prover.py::prove_air for MerkleAir, SchnorrAir, RangeProofAir
+  (src/merkle/update/mod.rs:81-106, src/schnorr/mod.rs:143-172, src/range/mod.rs:75-100), base field, both extensions, both hashes;
+* BASELINE sizes (tools/proof_configs.py): SHA-256 of the whole proof and of every section against tests/golden/proof_<name>.json,
+  written in the build container by tools/make_proof_digest.py from the CPU prover: range 2^16 / 64 rows, merkle 2^18 at depth 15
+  and 31, schnorr 2^18, and the 2^20 TransactionAir proof under the quadratic / cubic extension and Sha3_256;
+* the fused sub-AIR evaluators at 2^18 rows (k_schnorr_fused / k_merkle_fused index far beyond the 2^12 rows of the stage tests):
+  == the materialising evaluator + the generic merge on one coset, and the whole proofs accepted by the restated verifier.
+"""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+OPTS = (42, 8, 0, 0, 0, 4, 256)
+
+
+@pytest.fixture(scope="module")
+def backend():
+    from certificate_stark_amd.backend import Backend
+    b = Backend()
+    yield b
+    b.close()
+
+
+def options(opts=OPTS):
+    from certificate_stark_amd.prover import ProofOptions
+    return ProofOptions(*opts)
+
+
+def gpu_prove(backend, oracle, cfg, witness):
+    from certificate_stark_amd.backend import Backend
+    air, opts = cfg["air"], options(cfg["options"])
+    if air == oracle.AIR_STATE_TRANSITION:
+        backend.upload_witness(witness)
+        return backend.prove(opts)
+    if air == oracle.AIR_MERKLE:
+        backend.upload_witness(witness)
+        return backend.air_prove(Backend.AIR_MERKLE, opts)
+    if air == oracle.AIR_SCHNORR:
+        backend.upload_schnorr_witness(witness.messages, witness.sig_rx, witness.sig_s)
+        return backend.air_prove(Backend.AIR_SCHNORR, opts)
+    if isinstance(witness, int):
+        return backend.air_prove(Backend.AIR_RANGE, opts, witness)
+    return backend.range_prove_bits(opts, witness, cfg["log_n"])
+
+
+# ---- byte parity at sizes the CPU prover finishes in seconds ------------------------------------------------------------------------
+@pytest.mark.parametrize("n_tx,depth,opts", [(2, 3, OPTS), (8, 15, OPTS), (4, 7, (28, 8, 4, 1, 0, 4, 128)), (2, 3, (42, 8, 0, 0, 1, 4, 256)),
+                                             (4, 7, (42, 8, 0, 1, 2, 4, 512))])
+def test_merkle_proof_bytes(oracle, backend, n_tx, depth, opts):
+    from oracle import prover as OP
+    w = oracle.TxWitness.generate(n_tx, depth, seed=40 + n_tx)
+    got = gpu_prove(backend, oracle, dict(air=oracle.AIR_MERKLE, options=opts), w)
+    assert got == OP.prove_air(oracle.AIR_MERKLE, w, opts)
+
+
+@pytest.mark.parametrize("n_sig,opts", [(1, OPTS), (2, OPTS), (8, OPTS), (2, (28, 8, 4, 1, 0, 4, 128)), (2, (42, 8, 0, 0, 1, 4, 256)),
+                                        (4, (42, 8, 0, 0, 2, 4, 256))])
+def test_schnorr_proof_bytes(oracle, backend, n_sig, opts):
+    from oracle import prover as OP
+    w = oracle.SchnorrWitness.generate(n_sig, seed=600 + n_sig)
+    got = gpu_prove(backend, oracle, dict(air=oracle.AIR_SCHNORR, options=opts), w)
+    assert got == OP.prove_air(oracle.AIR_SCHNORR, w, opts)
+
+
+@pytest.mark.parametrize("value,opts", [(17, OPTS), (2**63 - 1, OPTS), (0, OPTS), (42, (42, 8, 0, 1, 2, 4, 256)), (42, (30, 8, 3, 0, 1, 4, 128))])
+def test_range_proof_bytes(oracle, backend, value, opts):
+    from oracle import prover as OP
+    number = int(oracle.to_mont([value % oracle.P])[0])
+    got = gpu_prove(backend, oracle, dict(air=oracle.AIR_RANGE, options=opts), number)
+    assert got == OP.prove_air(oracle.AIR_RANGE, number, opts)
+
+
+@pytest.mark.parametrize("log_n,opts", [(7, OPTS), (12, OPTS), (10, (28, 8, 4, 1, 0, 4, 128)), (12, (42, 8, 0, 0, 2, 4, 256))])
+def test_long_range_proof_bytes(oracle, backend, log_n, opts):
+    from oracle import prover as OP
+    from tools.proof_configs import range_words
+    words = range_words(log_n, 100 + log_n)
+    got = gpu_prove(backend, oracle, dict(air=oracle.AIR_RANGE, options=opts, log_n=log_n), words)
+    assert got == OP.prove_air(oracle.AIR_RANGE, words, opts, log_n=log_n)
+
+
+# ---- BASELINE sizes: digests of the CPU prover's proofs -----------------------------------------------------------------------------
+def _check_digest(name, cfg, proof):
+    from tools.make_proof_digest import section_digests
+    from tools.proof_configs import golden_path
+    gold = json.load(open(golden_path(name)))
+    assert gold["options"] == list(cfg["options"])
+    assert len(proof) == gold["proof_bytes"]
+    got = section_digests(proof, cfg["options"][0], cfg["width"], cfg["n_comp"])
+    for sec, digest in gold["sections"].items():
+        assert got[sec] == digest, "%s: proof section differs from the CPU prover's: %s" % (name, sec)
+    assert hashlib.sha256(proof).hexdigest() == gold["sha256"]
+
+
+@pytest.mark.parametrize("name", ["range_64", "range_2_16", "merkle_2_18_d15", "merkle_2_18_d31", "schnorr_2_18"])
+def test_sub_air_proofs_at_baseline_size_equal_the_cpu_provers(oracle, backend, name):
+    from oracle import verifier as V
+    from tools.proof_configs import configs
+    cfg = configs(oracle)[name]
+    w = cfg["witness"]()
+    proof = gpu_prove(backend, oracle, cfg, w)
+    _check_digest(name, cfg, proof)
+    # ... and the restated verifier accepts them (the reference's acceptance tests at BASELINE's sizes)
+    opts = list(cfg["options"])
+    if cfg["air"] == oracle.AIR_MERKLE:
+        assert V.parse(proof)["log_n"] == 18
+        assert V.verify_merkle(proof, w.initial_roots[0], w.final_root, options=opts)
+        with pytest.raises(V.VerifierError):
+            V.verify_merkle(proof, w.initial_roots[0], np.full(7, w.final_root[0], np.uint64))
+    elif cfg["air"] == oracle.AIR_SCHNORR:
+        assert V.parse(proof)["log_n"] == 18 and V.parse(proof)["depth"] == 512
+        assert V.verify_schnorr(proof, w, options=opts)
+        w2 = oracle.SchnorrWitness(512)
+        w2.messages[...], w2.sig_rx[...], w2.sig_s[...] = w.messages, w.sig_rx, w.sig_s
+        w2.messages[300, 20] ^= np.uint64(1)
+        with pytest.raises(V.VerifierError):
+            V.verify_schnorr(proof, w2)
+    elif isinstance(w, int):
+        assert V.verify_range(proof, w, options=opts)
+    else:
+        assert V.verify_range(proof, oracle.range_build_trace_bits(w, cfg["log_n"])[1], options=opts)
+
+
+@pytest.mark.parametrize("name", ["tx_2_20_quadratic", "tx_2_20_cubic", "tx_2_20_sha3"])
+def test_state_transition_2_20_option_sets_equal_the_cpu_provers(oracle, backend, name):
+    """The headline witness under FieldExtension::Quadratic / Cubic and Sha3_256 (src/tests.rs:40-54, examples/state-transition.rs:62-71):
+    the proofs `profiles/*bench_{quadratic,cubic,sha3}.json` time."""
+    from tools.proof_configs import configs
+    cfg = configs(oracle)[name]
+    proof = gpu_prove(backend, oracle, cfg, cfg["witness"]())
+    _check_digest(name, cfg, proof)
+
+
+def test_product_witness_generators_give_the_pinned_witnesses(oracle):
+    """bench.py's other_configs build their witnesses with the product's generators and the seeds of tools/proof_configs.py."""
+    from certificate_stark_amd.prover import ProofOptions, SchnorrExample, TransactionMetadata
+    from tools.proof_configs import configs
+    cf = configs(oracle)
+    w = cf["schnorr_2_18"]["witness"]()
+    ex = SchnorrExample.build_random(ProofOptions(), 512, seed=1, backend=object())
+    assert (ex.messages == w.messages).all() and (ex.sig_rx == w.sig_rx).all() and (ex.sig_s == w.sig_s).all()
+    w = cf["merkle_2_18_d31"]["witness"]()
+    meta = TransactionMetadata.build_random(512, 31, seed=31)
+    for f in TransactionMetadata.FIELDS:
+        assert (getattr(meta, f) == getattr(w, f)).all(), f
+
+
+# ---- the fused sub-AIR evaluators at 2^18 rows ------------------------------------------------------------------------------------------
+def test_schnorr_fused_evaluator_at_2_18(oracle, backend):
+    """cstark_schnorr_evaluate_constraints (k_schnorr_fused) == cstark_schnorr_evaluate_transitions + cstark_air_combine at 512
+    signatures, on two cosets (a whole 8-coset table of materialised values would be 0.94 GB; two cosets exercise the same indexing)."""
+    import torch
+    from certificate_stark_amd.backend import to_numpy_u64
+    n_sig, log_n, log_b = 512, 18, 3
+    w = oracle.SchnorrWitness.generate(n_sig, seed=1)
+    backend.upload_schnorr_witness(w.messages, w.sig_rx, w.sig_s)
+    co = backend.interpolate_columns(backend.schnorr_build_trace())
+    aux_co = backend.interpolate_columns(backend.schnorr_aux_columns())
+    av_co = backend.schnorr_assertion_polys(log_n)
+    ta, tb = oracle.random_elements(56, 11), oracle.random_elements(56, 12)
+    ba, bb = oracle.random_elements(61, 13), oracle.random_elements(61, 14)
+    for k0 in (0, 5):
+        lde = backend.lde_columns(co, log_b, k0=k0, nk=1)
+        aux = backend.lde_columns(aux_co, log_b, k0=k0, nk=1)
+        av = backend.lde_columns(av_co, log_b, k0=k0, nk=1)
+        ev = backend.schnorr_evaluate_transitions(lde, aux, log_b, k0=k0)
+        ref = backend.air_combine(backend.AIR_SCHNORR, lde, ev, ta, tb, ba, bb, None, log_b, k0=k0, n_items=n_sig, avals_lde=av)
+        fused = backend.schnorr_evaluate_constraints(lde, aux, ta, tb, ba, bb, av, log_b, k0=k0, n_sig=n_sig)
+        assert torch.equal(ref, fused)
+        if k0 == 5:  # the materialising side itself against the oracle, on a window of one coset's values
+            ptab = oracle.periodic_table(oracle.schnorr_mask_columns(), log_n, log_b)
+            ref_ev = oracle.schnorr_evaluate_transitions(to_numpy_u64(lde), to_numpy_u64(aux), ptab, k0=k0)
+            assert (to_numpy_u64(ev) == ref_ev).all()
+            desc = oracle.schnorr_desc(w)
+            ref_comb = oracle.air_combine(desc, to_numpy_u64(lde), ref_ev, ta, tb, ba, bb, log_b, k0=k0, avals=to_numpy_u64(av))
+            assert (to_numpy_u64(fused) == ref_comb).all()
+
+
+def test_merkle_fused_evaluator_at_2_18_depth_15(oracle, backend):
+    """cstark_merkle_evaluate_constraints (k_merkle_fused) == the materialising evaluator + merge == the oracle, 512 transfers at the
+    reference's depth 15, on one coset of the constraint-evaluation domain and one outside it."""
+    import torch
+    from certificate_stark_amd.backend import to_numpy_u64
+    from tools.proof_configs import configs
+    w = configs(oracle)["merkle_2_18_d15"]["witness"]()
+    backend.upload_witness(w)
+    d_trace = backend.merkle_build_trace()
+    ref_trace = oracle.merkle_build_trace(w)
+    assert (to_numpy_u64(d_trace) == ref_trace).all()
+    desc = oracle.merkle_desc(ref_trace)
+    co = backend.interpolate_columns(d_trace)
+    ta, tb = oracle.random_elements(106, 21), oracle.random_elements(106, 22)
+    ba, bb = oracle.random_elements(14, 23), oracle.random_elements(14, 24)
+    ptab = oracle.periodic_table(oracle.merkle_periodic_columns(15), 18, 3)
+    for k0 in (4, 3):
+        lde = backend.lde_columns(co, 3, k0=k0, nk=1)
+        ev = backend.air_evaluate_transitions(backend.AIR_MERKLE, lde, 15, 3, k0=k0)
+        ref = backend.air_combine(backend.AIR_MERKLE, lde, ev, ta, tb, ba, bb, desc.a_value, 3, k0=k0)
+        fused = backend.merkle_evaluate_constraints(lde, 15, ta, tb, ba, bb, desc.a_value, 3, k0=k0)
+        assert torch.equal(ref, fused)
+        ref_ev = oracle.air_evaluate_transitions(oracle.AIR_MERKLE, to_numpy_u64(lde), ptab, 106, k0=k0)
+        assert (to_numpy_u64(ev) == ref_ev).all()
+        assert (to_numpy_u64(fused) == oracle.air_combine(desc, to_numpy_u64(lde), ref_ev, ta, tb, ba, bb, 3, k0=k0)).all()
+        assert bool(fused.any()) == (k0 % 2 == 0)   # odd cosets are outside the 4n-point evaluation domain

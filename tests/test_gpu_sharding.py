@@ -74,3 +74,102 @@ def test_phases_out_of_order_are_refused():
     with pytest.raises(CstarkError):
         b.shard_commit(ProofOptions(), 2, 4)      # misaligned coset window
     b.close()
+
+
+def test_a_sharded_run_does_not_survive_another_proof_on_its_context():
+    """cstark_tx_prove / cstark_air_prove between the phases of a sharded proof overwrite the arena; the later phases must
+    fail ("phase called out of order") instead of composing a proof from foreign buffers.  Also: open_rows insists on the proof's
+    query count, finish on the rank that owns coset 0."""
+    import torch
+    from certificate_stark_amd import CstarkError
+    from certificate_stark_amd.backend import Backend
+    from certificate_stark_amd.prover import ProofOptions, TransactionMetadata
+    meta = TransactionMetadata.build_random(2, 3, seed=6)
+    opts = ProofOptions(42, 8, 0, 0, 0, 4, 256)
+    b0, b1 = Backend(), Backend()
+    try:
+        for b in (b0, b1):
+            b.upload_witness(meta)
+        leaves = torch.cat([b0.shard_commit(opts, 0, 4), b1.shard_commit(opts, 4, 4)])
+        combined = torch.cat([b0.shard_evaluate(leaves), b1.shard_evaluate(leaves)])
+        positions = b0.shard_compose(combined)
+        with pytest.raises(CstarkError):           # a caller that sized its row buffer by another query count
+            b1.shard_open_rows(positions[:10])
+        bad = positions.clone()
+        bad[3] = 8 * 2048                          # outside the LDE domain
+        with pytest.raises(CstarkError):
+            b1.shard_open_rows(bad)
+        rows = b0.shard_open_rows(positions) + b1.shard_open_rows(positions)
+        with pytest.raises(CstarkError):           # rank 1 never composed: no phase-3 state, and it does not own coset 0
+            b1.shard_finish(rows)
+        reference = b0.shard_finish(rows)
+        single = Backend()
+        single.upload_witness(meta)
+        assert reference == single.prove(opts)
+        single.close()
+        # now the same again with a whole proof squeezed in between the phases
+        leaves = torch.cat([b0.shard_commit(opts, 0, 4), b1.shard_commit(opts, 4, 4)])
+        combined = torch.cat([b0.shard_evaluate(leaves), b1.shard_evaluate(leaves)])
+        assert b0.prove(opts) == reference         # takes the arena: the run on b0 is over
+        with pytest.raises(CstarkError):
+            b0.shard_compose(combined)
+        with pytest.raises(CstarkError):
+            b0.shard_open_rows(positions)
+        with pytest.raises(CstarkError):
+            b0.shard_finish(rows)
+        b1.upload_witness(meta)
+        assert b1.air_prove(Backend.AIR_MERKLE, opts)   # a sub-AIR proof replaces the arena altogether
+        with pytest.raises(CstarkError):
+            b1.shard_open_rows(positions)
+        # and a fresh run on the same contexts works
+        leaves = torch.cat([b0.shard_commit(opts, 0, 4), b1.shard_commit(opts, 4, 4)])
+        combined = torch.cat([b0.shard_evaluate(leaves), b1.shard_evaluate(leaves)])
+        positions = b0.shard_compose(combined)
+        rows = b0.shard_open_rows(positions) + b1.shard_open_rows(positions)
+        assert b0.shard_finish(rows) == reference
+    finally:
+        b0.close(); b1.close()
+
+
+_REHEARSAL = r"""
+import hashlib, os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                       # every rank on the one GPU of the box; RCCL refuses that, so the group is gloo and
+dist.init_process_group("gloo")                # sharding.py stages the exchanged DEVICE buffers through the host
+from certificate_stark_amd import sharding
+from certificate_stark_amd.backend import Backend
+from certificate_stark_amd.prover import ProofOptions, TransactionMetadata
+meta = TransactionMetadata.load(os.path.join(%(root)r, "tests", "golden", "witness_1024_d15.npz"))
+b = Backend(0)
+b.upload_witness(meta)
+for rep in range(2):                           # twice: the second run reuses the arena and the run bookkeeping
+    proof = sharding.prove_sharded(b, ProofOptions(96, 8, 0, 0, 0, 4, 256))
+    assert (proof is None) == (rank != 0)
+if rank == 0:
+    print("PROOF", len(proof), hashlib.sha256(proof).hexdigest(), flush=True)
+b.close()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_prove_sharded_with_real_backends_in_separate_processes(tmp_path, world):
+    """sharding.prove_sharded -- the driver the ranks run over RCCL -- with the real Backend in `world` separate processes
+    (one process per rank, as on a multi-GPU node) on the ONE GPU of this box: uint8 all-gather of the digests, int64 all-gather of
+    the merged evaluations, int32 broadcast of the positions, int64 reduce of the opened rows, rank-0-only compose, at the headline
+    size; the proof must be the golden one.  The collectives run over gloo with host staging because RCCL does not accept two ranks
+    on one device: what is NOT covered here is RCCL's own transport between GPUs."""
+    import subprocess
+    import sys
+    script = tmp_path / "rehearsal.py"
+    script.write_text(_REHEARSAL % {"root": ROOT})
+    port = 29500 + (os.getpid() * 13 + world) % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    got = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert got.returncode == 0, got.stdout[-2000:] + got.stderr[-4000:]
+    line = [l for l in got.stdout.splitlines() if l.startswith("PROOF")][-1].split()
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proof_1024tx_d15_q96.json")))
+    assert int(line[1]) == gold["proof_bytes"] and line[2] == gold["sha256"]
