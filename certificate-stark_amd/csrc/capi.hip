@@ -132,7 +132,10 @@ int lde_mark(cstark_ctx *c) {
     return CSTARK_OK;
 }
 
-constexpr size_t LDE_BATCH_WS_BYTES = (size_t)1 << 30; // batched-coset launches when their intermediate is at most this large
+// All cosets of an extension go into ONE launch pair (the grid's batch dimension) when their intermediate fits this budget: the eight
+// cosets of a coefficient tile then run together on one XCD and the coefficients are read from HBM once (ntt.hip, k_ntt_cols_v5).  7 GiB
+// covers the 94 x 2^20 x 8 trace (6.3 GB; HBM holds 288 GB); CSTARK_LDE_BATCH_MB overrides (tuning; 0 = coset by coset as in round 2).
+const size_t LDE_BATCH_WS_BYTES = [] { const char *e = getenv("CSTARK_LDE_BATCH_MB"); return e ? (size_t)atoll(e) << 20 : (size_t)7 << 30; }();
 constexpr uint32_t LDE_COLUMN_GROUP = 1u << 30; // columns per group of the LDE (see lde_impl); 2^30 = all columns at once
 int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n,
                    uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);
@@ -170,15 +173,20 @@ int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uin
     const uint32_t group = group_env ? group_env : LDE_COLUMN_GROUP;
     // narrow tables (composition columns, periodic columns): all cosets in one launch pair -- the grid's batch dimension -- when the
     // intermediate of every coset fits the workspace budget; 2 launches of nk x the workgroups instead of 2 nk small ones
-    if (!group_env && nk > 1 && (size_t)nk * ncols * n * 8 <= LDE_BATCH_WS_BYTES) {
-        RC_TRY(ensure_ws(c, (size_t)nk * ncols * n * 8));
-        cs::NttArgs a{};
-        a.in = d_coeffs + (size_t)col0 * n; a.scratch = (uint64_t *)c->ws; a.out = d_lde + (size_t)col0 * n;
-        a.width = ncols; a.batch = nk; a.log_n = log_n;
-        a.w = p->w; a.prescale = t->s + (size_t)k0 * n; a.prescale_batch_stride = n; a.do_scale = false;
-        a.aux = p->aux_w; a.aux_ps = t->aux ? t->aux + (size_t)k0 * t->aux_words : nullptr; a.aux_ps_batch_stride = t->aux_words;
-        a.in_batch_stride = 0; a.scratch_batch_stride = (size_t)ncols * n; a.out_batch_stride = (size_t)width * n;
-        HIP_TRY(cs::ntt_columns(a, c->stream));
+    if (nk > 1 && (size_t)nk * (group < ncols ? group : ncols) * n * 8 <= LDE_BATCH_WS_BYTES) {
+        // (with CSTARK_NTT_GROUP: column groups, all cosets of a group in one launch pair -- the group's intermediate, nk x group x n
+        // words, is then written and read back within a short window)
+        for (uint32_t g0 = col0; g0 < col0 + ncols; g0 += group) {
+            const uint32_t gw = col0 + ncols - g0 < group ? col0 + ncols - g0 : group;
+            RC_TRY(ensure_ws(c, (size_t)nk * gw * n * 8));
+            cs::NttArgs a{};
+            a.in = d_coeffs + (size_t)g0 * n; a.scratch = (uint64_t *)c->ws; a.out = d_lde + (size_t)g0 * n;
+            a.width = gw; a.batch = nk; a.log_n = log_n;
+            a.w = p->w; a.prescale = t->s + (size_t)k0 * n; a.prescale_batch_stride = n; a.do_scale = false;
+            a.aux = p->aux_w; a.aux_ps = t->aux ? t->aux + (size_t)k0 * t->aux_words : nullptr; a.aux_ps_batch_stride = t->aux_words;
+            a.in_batch_stride = 0; a.scratch_batch_stride = (size_t)gw * n; a.out_batch_stride = (size_t)width * n;
+            HIP_TRY(cs::ntt_columns(a, c->stream));
+        }
         return CSTARK_OK;
     }
     for (uint32_t g0 = col0; g0 < col0 + ncols; g0 += group) {

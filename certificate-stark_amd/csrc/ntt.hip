@@ -402,7 +402,7 @@ __device__ __forceinline__ void cols_v4_finish(fp *tile, const fp *tw, const fp 
     }
 }
 
-// grid = (batch, C / L2 / V4_TILES, width)
+// grid = (C / L2 / V4_TILES, batch, width)
 template <int LA, int LB, int LC, bool INV>
 __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const fp *__restrict__ in, fp *__restrict__ out, unsigned log_n,
                                                                         const fp *__restrict__ w, const fp *__restrict__ prescale,
@@ -416,13 +416,14 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
     fp *tw = smem + (size_t)M * L2;       // [M] powers of w_M
     const unsigned log_c = log_n - LOGM;
     const size_t n = (size_t)1 << log_n;
-    const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
-    fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
-    const fp *ps = prescale ? prescale + blockIdx.x * prescale_batch_stride : nullptr;
+    const unsigned bz = blockIdx.y, tile_id = blockIdx.x; // batch (coset), tile: see the grid note at k_ntt_cols_v5
+    const fp *src = in + bz * in_batch_stride + (size_t)blockIdx.z * n;
+    fp *dst = out + bz * out_batch_stride + (size_t)blockIdx.z * n;
+    const fp *ps = prescale ? prescale + bz * prescale_batch_stride : nullptr;
     const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2;
     // compact tables (NttAux): aux = [M] twiddles of this pass | [C] twiddles of the row pass | [C] ratios | [A Bn][C] output factors;
     // aux_ps (per batch) = [M] row part of the prescale | [A Bn][C] output factors times the column part
-    const fp *ps_row = (ps && aux_ps) ? aux_ps + blockIdx.x * aux_ps_batch_stride : nullptr;
+    const fp *ps_row = (ps && aux_ps) ? aux_ps + bz * aux_ps_batch_stride : nullptr;
     const fp *outf = !aux ? nullptr : ps ? (ps_row ? ps_row + M : nullptr) : aux + M + ((size_t)2 << log_c);
     const fp *ratio_tab = aux ? aux + M + ((size_t)1 << log_c) : nullptr;
 
@@ -431,20 +432,20 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
     fp nxt[A];
     {
-        const unsigned lane_off = (t << log_c) + xcd_pair_tile(blockIdx.y * V4_TILES) * L2 + l;
+        const unsigned lane_off = (t << log_c) + xcd_pair_tile(tile_id * V4_TILES) * L2 + l;
 #pragma unroll
         for (int r1 = 0; r1 < A; r1++) nxt[r1] = (CS_NTT_SKIP & 16) ? (fp)(lane_off + r1) : (src + ((size_t)(r1 * T) << log_c))[lane_off];
     }
     __syncthreads(); // tw[] ready
 #pragma unroll 1
     for (int it = 0; it < V4_TILES; it++) {
-        const unsigned c = xcd_pair_tile(blockIdx.y * V4_TILES + it) * L2 + l;
+        const unsigned c = xcd_pair_tile(tile_id * V4_TILES + it) * L2 + l;
         {   // step 1: rows r = r1 T + t
             fp a[A];
 #pragma unroll
             for (int r1 = 0; r1 < A; r1++) a[r1] = nxt[r1];
             if (it + 1 < V4_TILES) {
-                const unsigned lane_off = (t << log_c) + xcd_pair_tile(blockIdx.y * V4_TILES + it + 1) * L2 + l;
+                const unsigned lane_off = (t << log_c) + xcd_pair_tile(tile_id * V4_TILES + it + 1) * L2 + l;
 #pragma unroll
                 for (int r1 = 0; r1 < A; r1++) nxt[r1] = (src + ((size_t)(r1 * T) << log_c))[lane_off];
             }
@@ -595,14 +596,19 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_COLS_WAVES) void k_
     fp *tw = smem + (size_t)(M / 2) * L2;   // [M] powers of w_M
     const unsigned log_c = log_n - LOGM;
     const size_t n = (size_t)1 << log_n;
-    const fp *src = in + blockIdx.x * in_batch_stride + (size_t)blockIdx.z * n;
-    fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
-    const fp *ps = prescale ? prescale + blockIdx.x * prescale_batch_stride : nullptr;
+    // grid = (C / L2, batch, width): the TILE is the fastest grid dimension.  Workgroups go to the 8 XCDs round-robin by linear id, so
+    // the XCD of a workgroup is its tile index mod 8 whatever its coset: the eight cosets of a tile -- which read the SAME coefficients
+    // -- share one L2, and the coefficient table leaves HBM once per extension instead of once per coset (round 2: batch fastest put
+    // coset k on XCD k, and the wide tables were extended coset by coset, 3 GB of other traffic between two reads of a tile).
+    const unsigned bz = blockIdx.y;
+    const fp *src = in + bz * in_batch_stride + (size_t)blockIdx.z * n;
+    fp *dst = out + bz * out_batch_stride + (size_t)blockIdx.z * n;
+    const fp *ps = prescale ? prescale + bz * prescale_batch_stride : nullptr;
     const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2;
-    const fp *ps_row = (ps && aux_ps) ? aux_ps + blockIdx.x * aux_ps_batch_stride : nullptr; // tables as in the v4 kernel
+    const fp *ps_row = (ps && aux_ps) ? aux_ps + bz * aux_ps_batch_stride : nullptr; // tables as in the v4 kernel
     const fp *outf = !aux ? nullptr : ps ? (ps_row ? ps_row + M : nullptr) : aux + M + ((size_t)2 << log_c);
     const fp *ratio_tab = aux ? aux + M + ((size_t)1 << log_c) : nullptr;
-    const unsigned c = xcd_pair_tile(blockIdx.y) * L2 + l;
+    const unsigned c = xcd_pair_tile(blockIdx.x) * L2 + l;
 
     if (aux) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
@@ -760,7 +766,7 @@ hipError_t launch_v5(const NttArgs &a, hipStream_t stream) {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void *)k_ntt_rows_v5<CA, CB, CC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void *)k_ntt_cols_v5<RA, RB, RC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ntt_cols_v5<RA, RB, RC, INV>), dim3(a.batch, (unsigned)GC::M / L2, a.width), dim3(GR::NT), lds_a, stream, a.in, a.scratch, a.log_n,
+    hipLaunchKernelGGL((k_ntt_cols_v5<RA, RB, RC, INV>), dim3((unsigned)GC::M / L2, a.batch, a.width), dim3(GR::NT), lds_a, stream, a.in, a.scratch, a.log_n,
                        a.w, a.prescale, a.in_batch_stride, a.scratch_batch_stride, a.prescale_batch_stride, a.aux, a.prescale ? a.aux_ps : nullptr,
                        a.aux_ps_batch_stride);
     static_assert((GR::M / L2) % V5_ROWS_TILES == 0, "tiles per workgroup");
@@ -780,7 +786,7 @@ hipError_t launch_v4(const NttArgs &a, hipStream_t stream) {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void *)k_ntt_rows_v4<CA, CB, CC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void *)k_ntt_cols_v4<RA, RB, RC, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)) != hipSuccess) return e;
-    hipLaunchKernelGGL((k_ntt_cols_v4<RA, RB, RC, INV>), dim3(a.batch, (unsigned)GC::M / L2 / V4_TILES, a.width), dim3(GR::NT), lds_a, stream, a.in,
+    hipLaunchKernelGGL((k_ntt_cols_v4<RA, RB, RC, INV>), dim3((unsigned)GC::M / L2 / V4_TILES, a.batch, a.width), dim3(GR::NT), lds_a, stream, a.in,
                        a.scratch, a.log_n, a.w, a.prescale, a.in_batch_stride, a.scratch_batch_stride, a.prescale_batch_stride, a.aux,
                        a.prescale ? a.aux_ps : nullptr, a.aux_ps_batch_stride);
     hipLaunchKernelGGL((k_ntt_rows_v4<CA, CB, CC, INV>), dim3(a.batch, (unsigned)GR::M / L2 / V4_TILES, a.width), dim3(GC::NT), lds_b, stream,
