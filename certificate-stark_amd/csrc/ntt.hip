@@ -22,7 +22,7 @@
 #define fp_sub(a, b) ((a) - (b))
 #define fp_sub_lazy(a, b) ((a) - (b))
 #endif
-// measurement builds only: leave out one memory phase of the v4 kernels (results are then wrong, the timing shows what the phase costs)
+// measurement builds only: leave out one memory phase of the v4 / v5 kernels (results are then wrong, the timing shows what the phase costs)
 //   1 twiddle-table fill   2 prescale loads   4 output-factor loads   8 global stores (kept alive by an impossible condition)   16 tile loads
 #ifndef CS_NTT_SKIP
 #define CS_NTT_SKIP 0
@@ -610,15 +610,17 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_COLS_WAVES) void k_
     const fp *ratio_tab = aux ? aux + M + ((size_t)1 << log_c) : nullptr;
     const unsigned c = xcd_pair_tile(blockIdx.x) * L2 + l;
 
-    if (aux) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux[e];
+    if (CS_NTT_SKIP & 1) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
+    else if (aux) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
     fp a[A];
     {
         const unsigned lane_off = (t << log_c) + c;
 #pragma unroll
-        for (int r1 = 0; r1 < A; r1++) a[r1] = (src + ((size_t)(r1 * T) << log_c))[lane_off];
+        for (int r1 = 0; r1 < A; r1++) a[r1] = (CS_NTT_SKIP & 16) ? (fp)(lane_off + r1) : (src + ((size_t)(r1 * T) << log_c))[lane_off];
     }
-    if (ps_row) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
+    if (CS_NTT_SKIP & 2) {
+    } else if (ps_row) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
 #pragma unroll
         for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], ps_row[r1 * T + t]);
     } else if (ps) {
@@ -661,7 +663,8 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_COLS_WAVES) void k_
         // output factor shift^c w_n^(k c), k = (k1 + A k2) + A Bn k3: a geometric sequence in k3 with ratio w_n^(A Bn c)
         const unsigned kb = (k1s + AH * h) + A * k2;
         fp g, ratio;
-        if (outf) {
+        if (CS_NTT_SKIP & 4) { g = kb + c; ratio = c; }
+        else if (outf) {
             g = outf[((size_t)kb << log_c) + c];
             ratio = ratio_tab[c];
         } else {
@@ -673,7 +676,8 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_COLS_WAVES) void k_
 #pragma unroll
         for (int k3 = 0; k3 < Cn; k3++) {
             fp *row = dst + ((size_t)(A * Bn * k3) << log_c);
-            row[lane_off] = fp_mul(x[cx_brev(k3, LC)], g);
+            const fp val = fp_mul(x[cx_brev(k3, LC)], g);
+            if (!(CS_NTT_SKIP & 8) || val == 0x123456789abcdefull) row[lane_off] = val;
             if (k3 + 1 < Cn) g = fp_mul(g, ratio);
         }
     }
@@ -697,14 +701,15 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_ROWS_WAVES) void k_
     fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
     const unsigned s1 = threadIdx.x % T, l1 = threadIdx.x / T; // step 1: s = c2 Cn + c3 fastest across lanes (coalesced row reads)
     const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2; // steps 2 and 3: l fastest across lanes (64-byte transposed stores)
-    if (aux_tw) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux_tw[e];
+    if (CS_NTT_SKIP & 1) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
+    else if (aux_tw) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux_tw[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_r];
     fp a[A];
     const unsigned in_lane = (l1 << LOGM) + s1;
     {
         const unsigned k10 = xcd_pair_tile(blockIdx.y * V5_ROWS_TILES) * L2;
 #pragma unroll
-        for (int c1 = 0; c1 < A; c1++) a[c1] = (src + ((size_t)k10 << LOGM) + c1 * T)[in_lane];
+        for (int c1 = 0; c1 < A; c1++) a[c1] = (CS_NTT_SKIP & 16) ? (fp)(in_lane + c1) : (src + ((size_t)k10 << LOGM) + c1 * T)[in_lane];
     }
     const unsigned jh = t / Cn, c3 = t % Cn;
     const unsigned j1s = t / Bn, j2s = t % Bn;
@@ -751,7 +756,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_ROWS_WAVES) void k_
             for (int p = 0; p < Cn; p++) {
                 fp val = x[p];
                 if (do_scale) val = fp_mul(val, post_scale);
-                (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
+                if (!(CS_NTT_SKIP & 8) || val == 0x123456789abcdefull) (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
             }
         }
     }
