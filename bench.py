@@ -94,6 +94,76 @@ def cpu_baseline(meta, sample_tx, full_options=None):
     }
 
 
+def b_core(n, w, b=8):
+    """algorithmic bytes of the hot path (trace .. constraint evaluation) for an n x w trace at blowup b."""
+    return 8 * n * w * (4 + 3 * b) + 104 * b * n
+
+
+def other_configs(backend, queries=42):
+    """BASELINE.json configs 1-3 (range / merkle / schnorr) through the product path, after the timed headline region: complete proofs
+    (cstark_air_prove / cstark_range_prove_bits), milliseconds per proof from the host clock around `reps` back-to-back proofs, proof
+    bytes, the stage split of the last proof (HIP events inside the library), and a roofline entry per configuration: B_core of
+    SURVEY.md 8(d) over the hot-path stages (trace .. constraints).  Witnesses come from the product's own seeded generators with the
+    seeds of tools/proof_configs.py, so every proof timed here is one the GPU suite pins to the CPU prover byte for byte
+    (tests/test_gpu_pinned_proofs.py; range 1024 x 64: tests/test_gpu_baseline_configs.py)."""
+    from certificate_stark_amd.prover import MerkleExample, ProofOptions, RangeProofExample, SchnorrExample, TransactionMetadata
+    opt = ProofOptions(queries, 8, 0, 0, 0, 4, 256)
+    out = []
+
+    def timed(name, workload, prove, rows, width, reps, note=None):
+        proof = prove()
+        prove()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            proof = prove()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        st = backend.prove_stage_ms()
+        hot = sum(st[k] for k in ("trace", "interpolate", "lde", "commit", "constraints"))
+        alg = b_core(rows, width)
+        e = {"config": name, "workload": workload, "ms_per_proof": round(ms, 3), "proofs_per_s": round(1e3 / ms, 2), "proof_bytes": len(proof),
+             "stage_ms": {k: round(v, 3) for k, v in st.items()},
+             "roofline": {"bound": "hbm", "achieved": round(alg / (hot * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(alg / (hot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg, "hot_path_ms": round(hot, 3), "traffic": None}}
+        if note:
+            e["note"] = note
+        out.append(e)
+
+    rng_words = np.random.default_rng(16).integers(0, 2**64, size=(1 << 16) // 64, dtype=np.uint64)
+    rng_words[-1] &= np.uint64(2**63 - 1)
+    timed("range_2_16", "benches/range.rs range-proof AIR, 2^16 steps, blowup 8 (SYNTHETIC long accumulator: the reference's range trace is fixed at 64 rows)",
+          lambda: backend.range_prove_bits(opt, rng_words, 16), 1 << 16, 2, 10)
+    one = RangeProofExample(opt, 12345 << 3, backend)
+    timed("range_64", "benches/range.rs range-proof AIR, the reference's own shape: 64 rows x 2 registers", one.prove, 64, 2, 20)
+    numbers = [(12345 + i) << 3 for i in range(1024)]
+    if hasattr(backend, "range_prove_batch"):
+        backend.range_prove_batch(opt, numbers[:64])
+        t0 = time.perf_counter()
+        proofs = backend.range_prove_batch(opt, numbers)
+        ms = (time.perf_counter() - t0) * 1e3
+        out.append({"config": "range_1024x64", "workload": "1024 independent 64-row range proofs (2^16 rows in total) in ONE batched call (cstark_range_prove_batch)",
+                    "ms_per_proof": round(ms / 1024, 4), "ms_per_batch": round(ms, 3), "proofs_per_s": round(1024e3 / ms, 1),
+                    "proof_bytes": len(proofs[0])})
+    else:
+        t0 = time.perf_counter()
+        for v in numbers:
+            proof = RangeProofExample(opt, v, backend).prove()
+        ms = (time.perf_counter() - t0) * 1e3
+        out.append({"config": "range_1024x64", "workload": "1024 independent 64-row range proofs (2^16 rows in total), one cstark_air_prove call each",
+                    "ms_per_proof": round(ms / 1024, 4), "ms_per_batch": round(ms, 3), "proofs_per_s": round(1024e3 / ms, 1), "proof_bytes": len(proof),
+                    "note": "host-API bound: about 150 launches and round trips per 64-row proof"})
+    full = TransactionMetadata.load(FIXTURE)
+    m512 = TransactionMetadata(*[getattr(full, f) if f == "final_root" else getattr(full, f)[:512] for f in TransactionMetadata.FIELDS])
+    m512.final_root = full.initial_roots[512].copy()
+    timed("merkle_2_18_d15", "benches/merkle.rs Merkle AIR, 512 transfers = 2^18 steps, depth 15 (the reference's constant)",
+          MerkleExample(opt, m512, backend).prove, 1 << 18, 65, 5)
+    m31 = TransactionMetadata.build_random(512, 31, seed=31)
+    timed("merkle_2_18_d31", "benches/merkle.rs Merkle AIR, 512 transfers = 2^18 steps, depth 31 (nearest legal depth to BASELINE's 32: depth + 1 must be a power of two)",
+          MerkleExample(opt, m31, backend).prove, 1 << 18, 65, 5)
+    sch = SchnorrExample.build_random(opt, 512, seed=1, backend=backend)
+    timed("schnorr_2_18", "benches/schnorr.rs Schnorr AIR, 512 signatures = 2^18 steps", sch.prove, 1 << 18, 56, 5)
+    return out
+
+
 class PmcTraffic:
     """HBM bytes per proof and kernel from the newest PMC summary under profiles/ (tools/profile.sh + tools/pmc_summary.py run on the
     GPU box for this build; separate FETCH_SIZE / WRITE_SIZE passes, 2 x FETCH + WRITE as MI355X_MICROARCH.md prescribes for gfx950).
@@ -114,9 +184,10 @@ class PmcTraffic:
                 break
 
     def per_proof(self, names):
+        """names: exact kernel names; a name ending in '<' matches every instantiation of that template"""
         if not names or not self.gb:
             return None
-        hit = [self.gb[k] for k in names if k in self.gb]
+        hit = [v for k, v in self.gb.items() if any(k == nm or (nm.endswith("<") and k.startswith(nm)) for nm in names)]
         return sum(hit) if hit else None
 
 
@@ -157,6 +228,8 @@ def main():
                     help="transactions the CPU baseline proves (default: the whole 1024-transaction witness, no extrapolation; about 25 s on the GPU "
                          "box's host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip BASELINE.json's configs 1-3 (range / merkle / schnorr proofs, about 2 s after the timed region; N = 1, --mode prove only)")
     ap.add_argument("--with-composition", action="store_true",
                     help="also time the next stage of prove(): composition polynomial columns + their LDE + Blake3 commitment "
                          "(reported as extra_stage_ms, not part of the hot-path metric)")
@@ -391,11 +464,12 @@ def main():
         roofline_lde = entry("forward transform pair of the low-degree extension (k_ntt_cols_v5 + k_ntt_rows_v5; all LDE calls of a proof: trace 94 "
                              "columns x 8 cosets, composition 8 x 8, DEEP 1 x 8; traffic also covers the 58 forward transforms of the split polynomials, same kernels)",
                              lde_alg, lde_ms / per, ntt_names,
-                             "the dominant kernel family by GPU time: about 330 vector instructions per element and coset at 2-4 issue cycles each "
-                             "(profiles/*_valu_issue_bench*.txt): the extension of 94 columns to 8 cosets takes 8.0 ms, its arithmetic alone 5.55 ms (= the "
-                             "issue time), its memory traffic alone 5.74 ms (profiles/r02_ntt_phase_skip.txt, DESIGN.md 5b); priced against the HBM roofline "
-                             "as BASELINE.json asks; kernel_ms = per 94 columns x 1 coset; inside "
-                             "cstark_tx_prove the first two column batches are extended beside the trace recurrences (DESIGN.md 5a)",
+                             "the dominant kernel family by GPU time: about 300 vector instructions per element and coset at 2-4 issue cycles each "
+                             "(profiles/*_valu_issue_bench*.txt); bound by vector-instruction issue, not by HBM: the two kernels spend 87 / 96 % of their "
+                             "cycles issuing at the clock they reach beside their HBM traffic (1.8-1.9 GHz; 2.1-2.2 GHz with the traffic compiled out, "
+                             "2.4 GHz for pure arithmetic: profiles/r03_ntt_clock_and_phase_skip.txt, DESIGN.md 5); priced against the HBM roofline as "
+                             "BASELINE.json asks; kernel_ms = per 94 columns x 1 coset; inside cstark_tx_prove the first two column batches are extended "
+                             "beside the trace recurrences",
                              launches=lde_pairs)
         nb = (8 // world) if coset_mode else 8
         rounds_bytes = (nb // 2) * n * (58 * 8 + 6 * 8) if split else nb * n * (58 * 8 + 8)
@@ -407,8 +481,14 @@ def main():
         roofline_stages = [roofline_lde, roofline_rounds]
         if args.mode == "prove":
             roofline_stages.append(entry("row hashes + Merkle tree of the trace commitment (k_hash_rows + k_merkle_level/top)", ab["hash_rows"] + ab["merkle"],
-                                         stage_ms["commit"], None, "the one HBM-shaped stage; k_hash_rows moves exactly its algorithmic bytes"))
-            roofline_stages.append(entry("constraint evaluation stage (all launches)", ab["constraints"], stage_ms["constraints"], None))
+                                         stage_ms["commit"], ["k_hash_rows", "k_merkle_level2", "k_merkle_level", "k_merkle_top"],
+                                         "the one HBM-shaped stage; k_hash_rows moves exactly its algorithmic bytes; `traffic` is per kernel NAME and so also "
+                                         "holds the small FRI-layer hashes and the composition / layer trees of a proof (about +0.5 GB)"))
+            roofline_stages.append(entry("constraint evaluation stage (all launches)", ab["constraints"], stage_ms["constraints"],
+                                         ["k_rounds_split<", "k_rounds_setup", "k_ec_split<", "k_final_split<", "k_final_hi<", "k_lin_split<", "k_lin_all<",
+                                          "k_coset_even_to_odd", "k_split_finish<"] if split else ["k_eval_fused<", "k_rounds_setup"],
+                                         "`traffic` = the stage's own kernels; the interpolation and extension of its split polynomials run through the "
+                                         "transform kernels and are counted in the first entry (about 4 GB)" if split else None))
         out = {
             "metric": ("proofs/sec, state_transition AIR @ 2^%d steps (complete prove(): trace gen, LDE, Blake3 commitments, constraint "
                        "evaluation, composition, DEEP, FRI, %d queries)" % (log_n, args.queries)) if prove_mode else
@@ -438,13 +518,20 @@ def main():
                            "then registers 0..36 interpolated, 'lde' = their extension; the three add up to the time to the complete extended trace "
                            "(include/cstark.h, cstark_prove_stage_ms)") if prove_mode else None,
             "constraint_part_ms": {k: round(v, 3) for k, v in part_avg.items()},
-            "constraint_part_note": ("all parts except final_add run on the even cosets only (split evaluation); lin_c includes the extension of their "
-                                     "14 polynomials to the odd cosets and the recombination over all cosets") if split else None,
+            "constraint_part_note": ("all parts run on the even cosets only (split evaluation; final_add also on LDE coset 1); lin_c includes the "
+                                     "extension of the 11 + 2 split polynomials to the odd cosets and the recombination over all cosets") if split else None,
             "roofline": roofline_lde,
             "roofline_stages": roofline_stages,
         }
         if extra:
             out["extra_stage_ms"] = extra
+        if world == 1 and args.mode == "prove" and not args.no_other_configs:
+            try:  # after the timed region and on its own context; a report beside the headline, never a reason to lose it
+                ob = Backend(local)
+                out["other_configs"] = other_configs(ob)
+                ob.close()
+            except Exception as e:
+                out["other_configs"] = {"failed": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(meta_full, min(args.cpu_sample_tx, n_tx),

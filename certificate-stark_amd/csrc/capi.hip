@@ -787,9 +787,18 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
         if (pev) HIP_TRY(hipEventRecord(pev[5], c->stream));
         uint64_t *fam_final = fam_addbit + 8 * n;
         HIP_TRY(cs::launch_final_split(p, -1, fam_final, c->stream));
-        for (int part = 6; part <= 8; part++) {
-            if (pev) HIP_TRY(hipEventRecord(pev[part], c->stream));
-            HIP_TRY(cs::launch_lin_split(p, part, even, c->stream));
+        // the three linear groups: one pass over the frame (k_lin_all); CSTARK_LIN_MERGED=0 (tuning / debugging): the three launches
+        // of round 2.  Part timing: the merged pass is reported as lin_a, lin_b = 0, lin_c = the extension and recombination below.
+        static const bool lin_merged = [] { const char *e = getenv("CSTARK_LIN_MERGED"); return !e || atoi(e) != 0; }();
+        if (lin_merged) {
+            if (pev) HIP_TRY(hipEventRecord(pev[6], c->stream));
+            HIP_TRY(cs::launch_lin_all(p, even, c->stream));
+            if (pev) { HIP_TRY(hipEventRecord(pev[7], c->stream)); HIP_TRY(hipEventRecord(pev[8], c->stream)); }
+        } else {
+            for (int part = 6; part <= 8; part++) {
+                if (pev) HIP_TRY(hipEventRecord(pev[part], c->stream));
+                HIP_TRY(cs::launch_lin_split(p, part, even, c->stream));
+            }
         }
         cs::NttArgs a{};
         a.in = even; a.scratch = sa; a.out = sb; a.width = 4 * T; a.batch = 1; a.log_n = log_n; // every polynomial on every even coset

@@ -88,6 +88,8 @@ hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family,
 constexpr int CE_SPLIT_TABLES = 13, CE_SPLIT_FAM0 = 4; // first family (Rescue windows + linear groups): four polynomials; doubling 3 | addition 2 | addition x bit 2 | final addition 2
 // split evaluation of a linear group (part 6, 7, 8): adds to the first family, d_even_family0 = [4][4][n]
 hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream);
+// the three linear groups in one pass over the frame (k_lin_all); same four polynomials as the three launch_lin_split parts
+hipError_t launch_lin_all(const CeParams &p, uint64_t *d_even_family0, hipStream_t stream);
 // d_hi = [4 odd cosets][2 m][n]: the high parts of the final-addition polynomials on the odd cosets (launch_final_hi + their extension)
 hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, const uint64_t *d_hi, hipStream_t stream);
 // Final addition (degree 5 (n - 1): one n-coefficient block above the 4n the even cosets determine).  coset < 0: the two sums

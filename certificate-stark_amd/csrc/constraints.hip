@@ -1467,6 +1467,167 @@ __global__ __launch_bounds__(FNT, PART == PART_LIN_C ? CS_LIN_C_SPLIT_WAVES : PA
     }
 }
 
+// ---- the three linear groups in ONE pass over the frame (round 3) -------------------------------------------------------------------
+// k_lin_split<LIN_A>, <LIN_B>, <LIN_C> each walk the Merkle registers 0..57 (LIN_A their current rows for the setup constraints,
+// LIN_B current and next rows), LIN_A and LIN_C both read the next rows of the key / amount / nonce copies, and each launch does a
+// read-modify-write of the same four tables: 9.2 GB of counter traffic for 3.1 GB of distinct cells, at 3.4-5.4 TB/s (profiles/r02_v13).
+// Here every cell is loaded once where the groups overlap: the Merkle loop of LIN_B also feeds LIN_A's setup / copy sections (their
+// slots are all in degree group 4: two accumulators each) and the hash-input sums of LIN_C; the rest of LIN_B and LIN_C follows.  Same
+// terms, same coefficients, same flags -- the sums are exact, so the four polynomials are bit-identical (split == direct at 2^23 points,
+// proof bytes: tests/test_gpu_full_size.py).
+#ifndef CS_LIN_ALL_WAVES
+#define CS_LIN_ALL_WAVES 3
+#endif
+#ifndef CS_LIN_ALL_UNROLL
+#define CS_LIN_ALL_UNROLL 1 // rolled: 162 VGPRs, no spills; unrolled (7) the scheduler hoists every load: 256 VGPRs + 98 spilled
+#endif
+__device__ __forceinline__ void lin_all_split(const CS_CONST fp *coefs, const Frame &f, fp (&tot)[6]) {
+    const fp setup = f.pv(P_SETUP), copy_values = f.pv(P_VALUE_COPY);
+    const fp tx_hash = f.pv(P_MERKLE), hash_input = f.pv(P_HASH_INPUT), finish = f.pv(P_FINISH), hash_flag = f.pv(P_HASH);
+    const fp hash_copy = fp_mul(tx_hash, c_not(fp_add(hash_flag, hash_input)));
+    const fp hash_init = fp_mul(tx_hash, hash_input);
+    SectionAcc s_set, s_cp, sa, sb;
+    s_set.coefs = s_cp.coefs = sa.coefs = sb.coefs = coefs;
+    s_set.begin(); s_cp.begin();
+    fp inp[7] = {0, 0, 0, 0, 0, 0, 0};                 // hash-internal inputs of LIN_C: inp[i] = sum_k pv(P_HASH_INTERNAL + k) cell(7 k + i)
+    const fp hi0 = f.pv(P_HASH_INTERNAL), hi1 = f.pv(P_HASH_INTERNAL + 1), hi2 = f.pv(P_HASH_INTERNAL + 2), hi3 = f.pv(P_HASH_INTERNAL + 3);
+    fp s_spent = 0, su12 = 0, si13 = 0;
+#pragma unroll
+    for (int blk = 0; blk < 2; blk++) {
+        const int base = blk == 0 ? S_INIT : R_INIT, key = blk == 0 ? S_KEY : R_KEY, key_res = blk == 0 ? S_KEY_RES : R_KEY_RES;
+        const fp bit = f.next(base + 14), not_bit = c_not(bit);
+        sa.begin();
+        sa.term(base + 14, c_is_binary(bit));
+        sa.flush<G1 | G2>(tx_hash, tot); // slot 14: group 1, slot 43: group 2
+        sa.begin(); sb.begin();
+#pragma unroll CS_LIN_ALL_UNROLL
+        for (int i = 0; i < 7; i++) {
+            const fp ca = f.cur(base + i), na0 = f.next(base + i), cb = f.cur(base + 15 + i), nb0 = f.next(base + 15 + i);
+            const fp ca7 = f.cur(base + 7 + i), na7 = f.next(base + 7 + i), cb7 = f.cur(base + 22 + i), nb7 = f.next(base + 22 + i);
+            const fp da = fp_sub(ca, na0), db = fp_sub(cb, nb0);
+            // merkle::update, hash copy / hash input sections (LIN_B)
+            sa.term(base + i, da);
+            sa.term(base + 15 + i, db);
+            sb.term(base + i, fp_add(fp_mul(not_bit, da), fp_mul(bit, fp_sub(nb0, na0))));
+            sb.term(base + 7 + i, fp_add(fp_mul(bit, fp_sub(ca, na7)), fp_mul(not_bit, fp_sub(nb7, na7))));
+            sb.term(base + 15 + i, fp_mul(not_bit, db));
+            sb.term(base + 22 + i, fp_mul(bit, fp_sub(cb, nb7)));
+            // setup / value-copy sections (LIN_A): elements i and 7 + i of the leaf pair (init, updated) and of the key copy
+            const fp kn = f.next(key + i), kc = f.cur(key + i);
+            s_set.term(VALUE_RES + 12 * blk + i, fp_sub(ca, cb));
+            s_set.term(key_res + i, fp_sub(kn, ca));
+            s_cp.term(key_res + i, fp_sub(kn, kc));
+            {   // cell m = 12 blk + i of the hash-internal inputs
+                const int m = 12 * blk + i;
+                inp[m % 7] = fp_add(inp[m % 7], fp_mul(m / 7 == 0 ? hi0 : m / 7 == 1 ? hi1 : hi2, kn));
+            }
+            if (i < 5) {
+                const fp kn7 = f.next(key + 7 + i), kc7 = f.cur(key + 7 + i);
+                s_set.term(VALUE_RES + 12 * blk + 7 + i, fp_sub(ca7, cb7));
+                s_set.term(key_res + 7 + i, fp_sub(kn7, ca7));
+                s_cp.term(key_res + 7 + i, fp_sub(kn7, kc7));
+                const int m = 12 * blk + 7 + i;
+                inp[m % 7] = fp_add(inp[m % 7], fp_mul(m / 7 == 0 ? hi0 : m / 7 == 1 ? hi1 : m / 7 == 2 ? hi2 : hi3, kn7));
+            } else if (i == 5) { // element 12: balances
+                if (blk == 0) { s_spent = fp_sub(ca7, cb7); su12 = cb7; }
+                else s_set.term(BALANCE_RES, fp_sub(s_spent, fp_sub(cb7, ca7)));
+            } else {             // element 13: nonces
+                if (blk == 0) { si13 = ca7; s_set.term(NONCE_UPD_RES, fp_sub(cb7, fp_add(ca7, FP_ONE))); }
+                else s_set.term(VALUE_RES + 24, fp_sub(ca7, cb7));
+            }
+#ifdef CS_LIN_ALL_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0); // keep the next iteration's loads out of this one (the scheduler otherwise hoists them all)
+#endif
+        }
+        sa.flush<G0 | G1 | G2>(hash_copy, tot);
+        sb.flush<G0 | G1 | G2>(hash_init, tot);
+    }
+    {   // amount / balance / nonce copies (LIN_A) and the last two cells of the hash-internal inputs (LIN_C)
+        const fp nd = f.next(DELTA_COPY), ns = f.next(SIGMA_COPY), nn = f.next(NONCE_COPY);
+        s_set.term(DELTA_COPY_RES, fp_sub(nd, s_spent));
+        s_set.term(SIGMA_COPY_RES, fp_sub(ns, su12));
+        s_set.term(NONCE_COPY_RES, fp_sub(nn, si13));
+        s_cp.term(DELTA_COPY_RES, fp_sub(nd, f.cur(DELTA_COPY)));
+        s_cp.term(SIGMA_COPY_RES, fp_sub(ns, f.cur(SIGMA_COPY)));
+        s_cp.term(NONCE_COPY_RES, fp_sub(nn, f.cur(NONCE_COPY)));
+        inp[24 % 7] = fp_add(inp[24 % 7], fp_mul(hi3, nd));
+        inp[25 % 7] = fp_add(inp[25 % 7], fp_mul(hi3, nn));
+    }
+    s_set.flush<G4>(setup, tot);
+    s_cp.flush<G4>(copy_values, tot);
+    // root carry / finish of merkle::update (LIN_B)
+    sa.begin(); sb.begin();
+#pragma unroll CS_LIN_ALL_UNROLL
+    for (int i = 0; i < 7; i++) {
+        const fp nr = f.next(PREV_ROOT + i), cr = f.cur(PREV_ROOT + i);
+        sa.term(PREV_ROOT + i, fp_sub(nr, cr));
+        sb.term(PREV_ROOT + i, fp_sub(nr, f.next(R_UPD + i)));
+        sb.term(INT_ROOT_RES + i, fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)));
+        sb.term(PREV_MATCH_RES + i, fp_sub(f.next(S_INIT + i), cr));
+    }
+    sa.flush<G4>(c_not(finish), tot);
+    sb.flush<G3 | G4>(finish, tot);
+    // schnorr linear parts, hash copy, range proofs (LIN_C)
+    const fp schnorr_mask = f.pv(P_SCHNORR), scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING), schnorr_hash = f.pv(P_SCHNORR_HASH);
+    const fp range_flag = f.pv(P_RANGE_STEP), range_finish = f.pv(P_RANGE_FINISH);
+    const fp copy_hash = fp_mul(c_not(schnorr_hash), schnorr_mask);
+    const fp final_add = fp_mul(c_not(scalar_mult), schnorr_mask);
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
+    SectionAcc &s = sa;
+    s.begin(); // flags are part of the values here
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const fp dflag = f.pv(P_DIGEST + i);
+        const fp c = f.cur(41 - i), nx = f.next(41 - i);
+        s.term(41 - i, fp_add(fp_mul(fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37)))), fp_mul(fp_mul(c_not(dflag), doubling), fp_sub(c, nx))));
+        s.term(38 + i, fp_add(fp_mul(addition, fp_sub(f.cur(38 + i), f.next(38 + i))), fp_mul(final_add, fp_sub(f.cur(38 + i), f.cur(42 + i)))));
+    }
+    {
+        const fp b18 = f.cur(18), b37 = f.cur(37);
+        s.term(18, fp_add(fp_mul(doubling, c_is_binary(b18)), fp_mul(addition, fp_sub(b18, f.next(18)))));
+        s.term(37, fp_add(fp_mul(doubling, c_is_binary(b37)), fp_mul(addition, fp_sub(b37, f.next(37)))));
+    }
+    s.flush<G2>(FP_ONE, tot);
+    s.begin();
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        s.term(42 + i, fp_sub(f.cur(42 + i), f.next(42 + i)));
+        s.term(49 + i, fp_sub(f.next(49 + i), inp[i]));
+    }
+    s.flush<G2>(copy_hash, tot);
+    const fp dbit = f.next(DELTA_BIT), sbit = f.next(SIGMA_BIT);
+    s.begin();
+    s.term(DELTA_ACC, fp_sub(f.next(DELTA_ACC), fp_add(fp_dbl(f.cur(DELTA_ACC)), dbit)));
+    s.term(DELTA_BIT, c_is_binary(dbit));
+    s.term(SIGMA_ACC, fp_sub(f.next(SIGMA_ACC), fp_add(fp_dbl(f.cur(SIGMA_ACC)), sbit)));
+    s.term(SIGMA_BIT, c_is_binary(sbit));
+    s.flush<G2 | G3 | G4>(range_flag, tot);
+    const fp dr = fp_sub(f.next(DELTA_ACC), f.next(DELTA_COPY));
+    s.begin();
+    s.term(DELTA_RANGE_RES, dr);
+    s.term(SIGMA_RANGE_RES, dr);
+    s.flush<G4>(range_finish, tot);
+}
+// adds to the four polynomials of the first family: out = [4][4 even cosets][n].  grid = (n / FNT, 4); one launch per coefficient set
+__global__ __launch_bounds__(FNT, CS_LIN_ALL_WAVES) void k_lin_all(CeParams p, fp *__restrict__ out, unsigned set) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kc = blockIdx.y;
+    const Frame f = make_frame(p, 2 * kc, j);
+    out += (size_t)set * SPLIT_TABLES * 4 * n;
+    const CS_CONST fp *coefs = as_const(p.coef + (size_t)set * CE_COEF_WORDS);
+    fp tot[6] = {0, 0, 0, 0, 0, 0};
+    lin_all_split(coefs, f, tot);
+    const fp xd1 = split_lift(p, 2 * kc, j);
+    // beta of groups 2, 3, 4 in one table: S_2 + x^(n-1) S_3 + x^(2n-2) S_4
+    tot[3] = fp_add(tot[3], fp_mul(xd1, fp_add(tot[4], fp_mul(xd1, tot[5]))));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        fp *o = out + ((size_t)q * 4 + kc) * n + j;
+        *o = fp_add(*o, tot[q]);
+    }
+}
+
 // grid = (n / FNT, nk)
 #ifndef CS_ROUNDS_WAVES
 #define CS_ROUNDS_WAVES 3
@@ -1919,6 +2080,13 @@ hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family,
     else return hipErrorInvalidValue;
     if (m == 1) { CS_EC(1) } else if (m == 2) { CS_EC(2) } else if (m == 3) { CS_EC(3) } else return hipErrorInvalidValue;
 #undef CS_EC
+    return hipGetLastError();
+}
+hipError_t launch_lin_all(const CeParams &p, uint64_t *d_even_family0, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
+    const unsigned m = p.m ? p.m : 1;
+    for (unsigned set = 0; set < m; set++) hipLaunchKernelGGL(k_lin_all, grid, block, 0, stream, p, d_even_family0, set);
     return hipGetLastError();
 }
 hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream) {
