@@ -19,6 +19,31 @@ def to_numpy_u64(t):
     return t.detach().cpu().contiguous().numpy().view(np.uint64)
 
 
+class ProofBatch:
+    """The proofs of one batched call: a sequence of bytes objects, materialised on access."""
+
+    def __init__(self, buf, stride, lens):
+        self._buf, self._stride, self._lens = buf, stride, lens
+
+    def __len__(self):
+        return len(self._lens)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._buf[i * self._stride:i * self._stride + int(self._lens[i])].tobytes()
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+
 class Backend:
     """One cstark_ctx bound to a torch device and the current torch stream."""
 
@@ -212,6 +237,23 @@ class Backend:
         n = C.c_size_t(0)
         check(self.lib.cstark_range_prove_bits(self.ctx, C.byref(o), w.ctypes.data_as(u64p), C.c_uint32(log_n), buf, C.c_size_t(cap), C.byref(n)))
         return bytes(memoryview(buf)[:n.value])
+
+    def range_prove_batch(self, options, numbers):
+        """cstark_range_prove_batch: one reference-shaped (64-row) range proof per element of `numbers` (memory form).  Returns a
+        sequence of proofs (bytes on access: the call itself leaves them in one host buffer)."""
+        nums = _np_u64(numbers)
+        o = self._options_struct(options)
+        self.lib.cstark_tx_proof_size_bound.restype = C.c_size_t
+        stride = int(self.lib.cstark_tx_proof_size_bound(C.c_uint32(1), C.byref(o)))
+        buf = np.empty(nums.size * stride, np.uint8)
+        lens = np.zeros(nums.size, np.uint64)
+        check(self.lib.cstark_range_prove_batch(self.ctx, C.byref(o), self._hptr(nums), C.c_uint32(nums.size), buf.ctypes.data_as(u8p), C.c_size_t(stride),
+                                                lens.ctypes.data_as(C.POINTER(C.c_size_t))))
+        return ProofBatch(buf, stride, lens)
+
+    @staticmethod
+    def _hptr(a, typ=u64p):
+        return a.ctypes.data_as(typ)
 
     def air_shape(self, air, n_items=2):
         w, nc, na, lce = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

@@ -14,4 +14,12 @@ hipError_t merkle_build(uint8_t *d_nodes, unsigned log_leaves, hipStream_t strea
 hipError_t hash_rows_sha3(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, unsigned log_n, unsigned log_b, unsigned k0, unsigned nk,
                           hipStream_t stream);
 hipError_t merkle_build_sha3(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream);
+// `batch` small tables side by side (the batched range prover): table t = columns [t gw, (t + 1) gw) of a coset-major table of
+// width_total columns, gw <= 8; its leaves at d_leaves + t leaf_stride (bytes), its tree (<= 2048 leaves) at d_nodes + t node_stride
+hipError_t hash_rows_batch(const uint64_t *d_lde, uint8_t *d_leaves, unsigned gw, unsigned width_total, unsigned log_n, unsigned log_b, unsigned batch,
+                           size_t leaf_stride, hipStream_t stream);
+hipError_t merkle_build_batch(uint8_t *d_nodes, unsigned log_leaves, unsigned batch, size_t node_stride, hipStream_t stream);
+hipError_t hash_rows_batch_sha3(const uint64_t *d_lde, uint8_t *d_leaves, unsigned gw, unsigned width_total, unsigned log_n, unsigned log_b, unsigned batch,
+                                size_t leaf_stride, hipStream_t stream);
+hipError_t merkle_build_batch_sha3(uint8_t *d_nodes, unsigned log_leaves, unsigned batch, size_t node_stride, hipStream_t stream);
 } // namespace cs

@@ -176,7 +176,63 @@ __global__ __launch_bounds__(1024) void k_merkle_top(uint8_t *__restrict__ nodes
     if (threadIdx.x < 2) reinterpret_cast<uint4 *>(nodes)[threadIdx.x] = make_uint4(0, 0, 0, 0); // nodes[0] unused
 }
 
+// ---- batches of small tables (the batched range prover, prove.hip): `batch` independent tables side by side ---------------------------
+// Table t owns columns [t gw, (t + 1) gw) of a coset-major table of width_total columns; one lane per leaf (leaf = b j + k of table t),
+// digests to leaves + t leaf_stride.  A row holds at most 8 elements (one compression).
+__global__ __launch_bounds__(256) void k_hash_rows_batch(const uint64_t *__restrict__ lde, uint8_t *__restrict__ leaves, unsigned gw, unsigned width_total,
+                                                         unsigned log_n, unsigned log_b, size_t leaf_stride) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t leaf = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (leaf >= (n << log_b)) return;
+    const unsigned t = blockIdx.y;
+    const size_t j = leaf >> log_b;
+    const unsigned kk = (unsigned)(leaf & ((1u << log_b) - 1));
+    const uint64_t *col = lde + ((size_t)kk * width_total + (size_t)t * gw) * n + j;
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t v = (unsigned)i < gw ? col[(size_t)i * n] : 0;
+#if !CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY
+        if ((unsigned)i < gw) v = fp_to_u64(v);
+#endif
+        m[2 * i] = (uint32_t)v;
+        m[2 * i + 1] = (uint32_t)(v >> 32);
+    }
+    uint32_t cv[8] = {IV0, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+    compress(cv, m, gw * 8, CHUNK_START | CHUNK_END | ROOT);
+    uint4 *dst = reinterpret_cast<uint4 *>(leaves + (size_t)t * leaf_stride + 32 * leaf);
+    dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+// one workgroup per tree of at most 2048 leaves: every level in turn
+__global__ __launch_bounds__(1024) void k_merkle_batch(uint8_t *__restrict__ nodes_all, size_t cnt, size_t node_stride) {
+    uint8_t *nodes = nodes_all + (size_t)blockIdx.x * node_stride;
+    for (; cnt >= 1; cnt >>= 1) {
+        if (threadIdx.x < cnt) {
+            const size_t i = cnt + threadIdx.x;
+            merge_node(nodes + 64 * i, nodes + 32 * i);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) reinterpret_cast<uint4 *>(nodes)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+}
+
 } // namespace
+
+hipError_t hash_rows_batch(const uint64_t *d_lde, uint8_t *d_leaves, unsigned gw, unsigned width_total, unsigned log_n, unsigned log_b, unsigned batch,
+                           size_t leaf_stride, hipStream_t stream) {
+    if (gw == 0 || gw > 8 || batch == 0) return hipErrorInvalidValue;
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_hash_rows_batch, dim3((unsigned)(((n << log_b) + 255) / 256), batch), dim3(256), 0, stream, d_lde, d_leaves, gw, width_total, log_n,
+                       log_b, leaf_stride);
+    return hipGetLastError();
+}
+hipError_t merkle_build_batch(uint8_t *d_nodes, unsigned log_leaves, unsigned batch, size_t node_stride, hipStream_t stream) {
+    if (log_leaves < 1 || log_leaves > 11 || batch == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_merkle_batch, dim3(batch), dim3(1024), 0, stream, d_nodes, ((size_t)1 << log_leaves) >> 1, node_stride);
+    return hipGetLastError();
+}
 
 #ifndef CS_HASH_NARROW_MAX
 #define CS_HASH_NARROW_MAX 16 // widest table hashed leaf-per-lane (the 94-column trace table that way: 2.47 vs 2.29 ms)

@@ -102,6 +102,15 @@ int ensure_ws(cstark_ctx *c, size_t bytes) {
     return CSTARK_OK;
 }
 
+} // namespace
+int plan_tables(cstark_ctx *c, unsigned log_n, const uint64_t **w, const uint64_t **winv) {
+    const NttPlan *p;
+    RC_TRY(get_plan(c, log_n, &p));
+    *w = p->w; *winv = p->winv;
+    return CSTARK_OK;
+}
+namespace {
+
 int interpolate_impl(cstark_ctx *c, uint64_t *d_evals, uint64_t *d_coeffs, uint32_t width, uint32_t log_n) {
     if (!c || !d_evals || !d_coeffs || width == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_interpolate_columns: bad argument");
     if (d_evals == d_coeffs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_interpolate_columns: output must not alias input");
@@ -326,6 +335,8 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); (void)hipFree(t.binv); }
     for (PeriodicTable &t : c->small_periodic) (void)hipFree(t.tab);
     if (c->desc_buf) (void)hipFree(c->desc_buf);
+    if (c->rb_dev) (void)hipFree(c->rb_dev);
+    if (c->rb_host) (void)hipHostFree(c->rb_host);
     if (c->tail_buf) (void)hipFree(c->tail_buf);
     if (c->arena) cs::prove_arena_free(c->arena);
     for (hipEvent_t e : c->part_ev) if (e) (void)hipEventDestroy(e);

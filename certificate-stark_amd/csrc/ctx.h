@@ -110,7 +110,11 @@ struct cstark_ctx {
     cs::ProveArena *arena = nullptr; // device buffers of cstark_tx_prove (prove.hip)
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    void *rb_dev = nullptr, *rb_host = nullptr; // cstark_range_prove_batch: one device block and one pinned host block, carved per call
+    size_t rb_dev_bytes = 0, rb_host_bytes = 0;
 };
+// internal (capi.hip): the cached twiddle tables of a 2^log_n-point domain: powers of w and of its inverse (device, n entries each)
+int plan_tables(cstark_ctx *c, unsigned log_n, const uint64_t **w, const uint64_t **winv);
 
 // internal (capi.hip): merged TransactionAir constraint evaluations for m coefficient sets in one pass over the frame
 struct cstark_tx_coeffs;

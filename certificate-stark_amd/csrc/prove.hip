@@ -17,9 +17,12 @@
 #include <algorithm>
 #include <new>
 #include <chrono>
+#include <thread>
 #include <vector>
 #include "../../include/cstark.h"
 #include "ctx.h"
+#include "blake3.h"
+#include "range_batch.h"
 #include "hostblake3.h"
 #include "keccak.cuh"
 #include "air_tx_host.h"
@@ -1052,6 +1055,23 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
 } // namespace
 } // namespace cs
 
+namespace {
+template <class F>
+void parallel_for(size_t count, F f) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : nt > 8 ? 8 : nt;
+    if (count < 64 || nt == 1) { for (size_t i = 0; i < count; i++) f(i); return; }
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < nt; w++)
+        th.emplace_back([=] { for (size_t i = w; i < count; i += nt) f(i); });
+    for (std::thread &t : th) t.join();
+}
+struct Carver { // consecutive 256-byte aligned pieces of one block
+    uint8_t *base; size_t off = 0;
+    template <class T> T *take(size_t bytes) { T *q = (T *)(base + off); off += (bytes + 255) & ~(size_t)255; return q; }
+};
+} // namespace
+
 using namespace cs;
 
 extern "C" {
@@ -1196,6 +1216,246 @@ int cstark_range_prove_bits(cstark_ctx *c, const cstark_options *opt, const uint
     job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
     if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);
+}
+
+// ---- B reference-shaped range proofs in one call (RangeProofExample::prove, src/range/mod.rs:75-100, benches/range.rs:15-37) ---------
+// Every stage is one launch over the batch (range_batch.hip; interpolation and extension of the 2 B columns through the generic
+// transform kernels), the host walks the B Fiat-Shamir channels between the stages on a few threads.  Same protocol, same bytes as
+// prove_core for CSTARK_AIR_RANGE: the channel order, the proof layout and every formula are the ones documented there.
+int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uint64_t *numbers, uint32_t count, uint8_t *proofs, size_t stride, size_t *lens) {
+    using namespace cs::host;
+    if (!c || !opt || !numbers || !proofs || !lens || count == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_prove_batch: null argument");
+    if (count > 65535) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_prove_batch: at most 65535 proofs per call");
+    if (opt->field_extension != 0) return fail(CSTARK_ERR_UNSUPPORTED, "cstark_range_prove_batch: FieldExtension::None only (use cstark_air_prove)");
+    unsigned log_rem = 0;
+    RC_TRY(check_options(opt, &log_rem));
+    const unsigned log_n = RB_LOG_N, log_N = log_n + 3, n_layers = num_fri_layers(log_N, log_rem);
+    const size_t B = count, n = RB_N, N = RB_LDE, nq = opt->num_queries, W = 2, ce = RB_CE;
+    if (nq > N / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
+    std::vector<uint64_t> canon(B);
+    for (size_t t = 0; t < B; t++) {
+        if (numbers[t] >= P) return fail(CSTARK_ERR_INVALID_ARG, "number is not a field element");
+        canon[t] = to_u64(numbers[t]);
+        if (canon[t] >> 63) return fail(CSTARK_ERR_INVALID_ARG, "range proofs cover 63-bit field elements (src/range/tests.rs:54-62)");
+    }
+    const size_t rem_len = n_layers ? N / 4 : N, slot = nq * 864;
+    const size_t per_proof = 4096 + 32 * 3 + 8 * (2 * W + ce) + nq * (W * 8 + ce * 8 + 2 * log_N * 32) + n_layers * (4 + nq * (32 + 7 * 32)) + 4 + 8 * rem_len;
+    if (stride < per_proof) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_prove_batch: stride too small (cstark_tx_proof_size_bound(1, opt) is sufficient)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const uint32_t hf = opt->hash_fn;
+
+    // ---- buffers: one device block, one pinned host block ----------------------------------------------------------------------------
+    const size_t dev_need = B * (16 + 1024 * 2 + 8192 + 32768 + 64 + 1024 + 1024 + 8192 + 32768 + 8 + 48 + 64 + 4096 + 8192 + 8 + 8 * rem_len + 8 * nq + 4 + slot) + 64 * 256;
+    const size_t host_need = B * (32 * 3 + 64 + 48 + 64 + 8 + 8 + 8 * rem_len + 8 * nq + 4 + slot) + 32 * 256;
+    if (c->rb_dev_bytes < dev_need) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c->rb_dev) { HIP_TRY(hipFree(c->rb_dev)); c->rb_dev = nullptr; c->rb_dev_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->rb_dev, dev_need));
+        c->rb_dev_bytes = dev_need;
+    }
+    if (c->rb_host_bytes < host_need) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c->rb_host) { HIP_TRY(hipHostFree(c->rb_host)); c->rb_host = nullptr; c->rb_host_bytes = 0; }
+        HIP_TRY(hipHostMalloc(&c->rb_host, host_need, hipHostMallocDefault));
+        c->rb_host_bytes = host_need;
+    }
+    Carver D{(uint8_t *)c->rb_dev}, H{(uint8_t *)c->rb_host};
+    uint64_t *d_canon = D.take<uint64_t>(B * 8), *d_num = D.take<uint64_t>(B * 8), *d_trace = D.take<uint64_t>(B * 1024), *d_coeffs = D.take<uint64_t>(B * 1024);
+    uint64_t *d_lde = D.take<uint64_t>(B * 8192), *d_coefs = D.take<uint64_t>(B * 64), *d_comb = D.take<uint64_t>(B * 1024), *d_ccoef = D.take<uint64_t>(B * 1024);
+    uint64_t *d_clde = D.take<uint64_t>(B * 8192), *d_z = D.take<uint64_t>(B * 8), *d_ood = D.take<uint64_t>(B * 48), *d_dcoef = D.take<uint64_t>(B * 64);
+    uint64_t *d_layer = D.take<uint64_t>(B * 4096), *d_alpha = D.take<uint64_t>(B * 8), *d_rem = D.take<uint64_t>(B * 8 * rem_len);
+    uint8_t *d_tnodes = D.take<uint8_t>(B * 32768), *d_cnodes = D.take<uint8_t>(B * 32768), *d_lnodes = D.take<uint8_t>(B * 8192);
+    uint32_t *d_pos = D.take<uint32_t>(B * nq * 4), *d_lpos = D.take<uint32_t>(B * nq * 4), *d_lcount = D.take<uint32_t>(B * 4);
+    uint8_t *d_open = D.take<uint8_t>(B * slot);
+    uint8_t *h_troot = H.take<uint8_t>(B * 32), *h_croot = H.take<uint8_t>(B * 32), *h_lroot = H.take<uint8_t>(B * 32);
+    uint64_t *h_coefs = H.take<uint64_t>(B * 64), *h_ood = H.take<uint64_t>(B * 48), *h_dcoef = H.take<uint64_t>(B * 64), *h_z = H.take<uint64_t>(B * 8);
+    uint64_t *h_alpha = H.take<uint64_t>(B * 8), *h_rem = H.take<uint64_t>(B * 8 * rem_len);
+    uint32_t *h_pos = H.take<uint32_t>(B * nq * 4), *h_lpos = H.take<uint32_t>(B * nq * 4), *h_lcount = H.take<uint32_t>(B * 4);
+    uint8_t *h_open = H.take<uint8_t>(B * slot);
+
+    RangeBatchConsts K{};
+    {
+        const uint64_t wN = root_of_unity(log_N), g = lde_offset();
+        uint64_t sh = g;
+        for (int k = 0; k < 8; k++) { K.shift[k] = sh; K.zinv[k] = inv(sub(pow(sh, n), ONE)); sh = mul(sh, wN); }
+        K.w_last = inv(root_of_unity(log_n));
+        const uint64_t cen = n * ce;
+        K.adj[0] = CSTARK_CONV_TRANSITION_ADJUSTMENT(cen, n, 2 * (n - 1)); // degrees (2), (1): src/range/air.rs:100-105
+        K.adj[1] = CSTARK_CONV_TRANSITION_ADJUSTMENT(cen, n, 1 * (n - 1));
+        K.badj = CSTARK_CONV_BOUNDARY_ADJUSTMENT(cen, n, 1);
+        K.inv128 = inv(from_u64(cen)); K.ginv = inv(g); K.offset_inv = inv(g); K.inv4 = inv(from_u64(4));
+        const uint64_t *unused;
+        RC_TRY(plan_tables(c, log_n, &K.w64, &unused));
+        RC_TRY(plan_tables(c, log_n + 1, &unused, &K.winv128));
+        RC_TRY(plan_tables(c, log_N, &unused, &K.winv512));
+    }
+    auto hash_rows_b = [&](const uint64_t *tab, uint8_t *leaves, unsigned gw, unsigned ln, unsigned lb, size_t leaf_stride) {
+        return hf == 1 ? hash_rows_batch_sha3(tab, leaves, gw, (unsigned)(gw * B), ln, lb, (unsigned)B, leaf_stride, st)
+                       : hash_rows_batch(tab, leaves, gw, (unsigned)(gw * B), ln, lb, (unsigned)B, leaf_stride, st);
+    };
+    auto merkle_b = [&](uint8_t *nodes, unsigned log_leaves, size_t node_stride) {
+        return hf == 1 ? merkle_build_batch_sha3(nodes, log_leaves, (unsigned)B, node_stride, st) : merkle_build_batch(nodes, log_leaves, (unsigned)B, node_stride, st);
+    };
+
+    static const bool rb_prof = getenv("CSTARK_RB_PROF") != nullptr; // debugging: host wall-clock of the phases on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!rb_prof) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[cstark range batch] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_prev).count());
+        t_prev = now;
+    };
+    mark("setup");
+    // ---- trace, extension, commitment ----------------------------------------------------------------------------------------------------
+    HIP_TRY(hipMemcpyAsync(d_canon, canon.data(), B * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_num, numbers, B * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(rb_trace(d_canon, d_trace, (unsigned)B, st));
+    RC_TRY(cstark_interpolate_columns(c, d_trace, d_coeffs, (uint32_t)(2 * B), log_n));
+    RC_TRY(cstark_lde_columns(c, d_coeffs, d_lde, (uint32_t)(2 * B), log_n, 3, lde_offset(), 0, 8));
+    HIP_TRY(hash_rows_b(d_lde, d_tnodes + 32 * N, 2, log_n, 3, 2 * N * 32));
+    HIP_TRY(merkle_b(d_tnodes, log_N, 2 * N * 32));
+    HIP_TRY(hipMemcpy2DAsync(h_troot, 32, d_tnodes + 32, 2 * N * 32, 32, B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(cs::stream_wait(st)); // (also: `canon` and the caller's numbers have been read)
+
+    mark("trace..trace roots (gpu)");
+    std::vector<Coin> coins(B);
+    parallel_for(B, [&](size_t t) {
+        Coin &coin = coins[t];
+        coin.hash_fn = hf;
+        Writer sd;
+        const uint8_t ctxb[2] = {(uint8_t)W, (uint8_t)log_n};
+        sd.raw(ctxb, 2);
+        sd.u64(P);
+        const uint8_t ob[7] = {(uint8_t)opt->num_queries, 3, (uint8_t)opt->grinding_factor, (uint8_t)opt->hash_fn, (uint8_t)opt->field_extension,
+                               (uint8_t)opt->fri_folding_factor, (uint8_t)log_rem};
+        sd.raw(ob, 7);
+        sd.u64(canon[t]); // PublicInputs: the number (src/range/air.rs:26-36)
+        coin.init(sd.b.data(), sd.b.size());
+        coin.reseed(h_troot + 32 * t);
+        uint64_t *cf = h_coefs + 8 * t; // t_alpha[2] t_beta[2] b_alpha[2] b_beta[2]
+        for (int i = 0; i < 2; i++) { cf[i] = coin.draw(); cf[2 + i] = coin.draw(); }
+        for (int i = 0; i < 2; i++) { cf[4 + i] = coin.draw(); cf[6 + i] = coin.draw(); }
+    });
+    mark("coefficients (host)");
+    HIP_TRY(hipMemcpyAsync(d_coefs, h_coefs, B * 64, hipMemcpyHostToDevice, st));
+
+    // ---- constraint evaluation, composition polynomial and its commitment -------------------------------------------------------------
+    HIP_TRY(rb_combine(K, d_lde, d_coefs, d_num, d_comb, (unsigned)B, st));
+    HIP_TRY(rb_composition(K, d_comb, d_ccoef, (unsigned)B, st));
+    RC_TRY(cstark_lde_columns(c, d_ccoef, d_clde, (uint32_t)(2 * B), log_n, 3, lde_offset(), 0, 8));
+    HIP_TRY(hash_rows_b(d_clde, d_cnodes + 32 * N, 2, log_n, 3, 2 * N * 32));
+    HIP_TRY(merkle_b(d_cnodes, log_N, 2 * N * 32));
+    HIP_TRY(hipMemcpy2DAsync(h_croot, 32, d_cnodes + 32, 2 * N * 32, 32, B, hipMemcpyDeviceToHost, st));
+    HIP_TRY(cs::stream_wait(st));
+    mark("constraints..comp roots (gpu)");
+    parallel_for(B, [&](size_t t) { coins[t].reseed(h_croot + 32 * t); h_z[t] = coins[t].draw(); });
+    HIP_TRY(hipMemcpyAsync(d_z, h_z, B * 8, hipMemcpyHostToDevice, st));
+
+    // ---- out-of-domain frame, DEEP composition -----------------------------------------------------------------------------------------
+    HIP_TRY(rb_ood(K, d_coeffs, d_ccoef, d_z, d_ood, (unsigned)B, st));
+    HIP_TRY(hipMemcpyAsync(h_ood, d_ood, B * 48, hipMemcpyDeviceToHost, st));
+    HIP_TRY(cs::stream_wait(st));
+    parallel_for(B, [&](size_t t) {
+        Coin &coin = coins[t];
+        uint8_t dg[32];
+        hash_elements(hf, h_ood + 6 * t, 4, dg); coin.reseed(dg);
+        hash_elements(hf, h_ood + 6 * t + 4, 2, dg); coin.reseed(dg);
+        uint64_t *cf = h_dcoef + 8 * t; // alpha[2] beta[2] delta[2] deg_a deg_b
+        for (int i = 0; i < 2; i++) {
+            cf[i] = coin.draw(); cf[2 + i] = coin.draw();
+            for (int k = 2; k < CSTARK_CONV_DEEP_DRAWS_PER_REGISTER; k++) (void)coin.draw();
+        }
+        for (int i = 0; i < 2; i++) cf[4 + i] = coin.draw();
+        cf[6] = coin.draw(); cf[7] = coin.draw();
+    });
+    mark("ood + deep coefficients");
+    HIP_TRY(hipMemcpyAsync(d_dcoef, h_dcoef, B * 64, hipMemcpyHostToDevice, st));
+    HIP_TRY(rb_deep(K, d_lde, d_clde, d_z, d_ood, d_dcoef, d_layer, (unsigned)B, st));
+
+    // ---- FRI: at most one layer for a 512-point domain (remainder 128 .. 1024) ----------------------------------------------------------
+    if (n_layers) {
+        HIP_TRY(hash_rows_b(d_layer, d_lnodes + 32 * 128, 4, 7, 0, 256 * 32)); // rows { e[i + t 128] }: table t = [4][128] inside its 512 words
+        HIP_TRY(merkle_b(d_lnodes, 7, 256 * 32));
+        HIP_TRY(hipMemcpy2DAsync(h_lroot, 32, d_lnodes + 32, 256 * 32, 32, B, hipMemcpyDeviceToHost, st));
+        HIP_TRY(cs::stream_wait(st));
+        parallel_for(B, [&](size_t t) { coins[t].reseed(h_lroot + 32 * t); h_alpha[t] = coins[t].draw(); });
+        HIP_TRY(hipMemcpyAsync(d_alpha, h_alpha, B * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(rb_fold(K, d_layer, d_alpha, d_rem, (unsigned)B, st));
+        HIP_TRY(hipMemcpyAsync(h_rem, d_rem, B * 8 * rem_len, hipMemcpyDeviceToHost, st));
+    } else {
+        HIP_TRY(hipMemcpyAsync(h_rem, d_layer, B * 8 * rem_len, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(cs::stream_wait(st));
+    mark("deep + fri (gpu + host)");
+    std::vector<uint64_t> nonces(B);
+    std::vector<uint8_t> rem_commit(32 * B);
+    parallel_for(B, [&](size_t t) {
+        Coin &coin = coins[t];
+        hash_elements(hf, h_rem + rem_len * t, rem_len, &rem_commit[32 * t]);
+        coin.reseed(&rem_commit[32 * t]);
+        uint64_t nonce = 1;
+        for (;; nonce++) {
+            uint8_t out[32];
+            coin.with_int(coin.seed, nonce, out);
+            uint64_t v = 0;
+            for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
+            if (opt->grinding_factor == 0 || (v & ((1ull << opt->grinding_factor) - 1)) == 0) break;
+        }
+        nonces[t] = nonce;
+        coin.reseed_int(nonce);
+        std::vector<uint32_t> pos;
+        coin.draw_integers(nq, N, pos);
+        memcpy(h_pos + nq * t, pos.data(), nq * 4);
+        if (n_layers) {
+            const std::vector<uint32_t> lp = fold_positions(pos, 128);
+            h_lcount[t] = (uint32_t)lp.size();
+            memcpy(h_lpos + nq * t, lp.data(), lp.size() * 4);
+            for (size_t q = lp.size(); q < nq; q++) h_lpos[nq * t + q] = 0;
+        } else h_lcount[t] = 0;
+    });
+
+    mark("remainder, positions (host)");
+    // ---- openings, proof bytes ----------------------------------------------------------------------------------------------------------------
+    HIP_TRY(hipMemcpyAsync(d_pos, h_pos, B * nq * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_lpos, h_lpos, B * nq * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_lcount, h_lcount, B * 4, hipMemcpyHostToDevice, st));
+    RangeBatchOpen o{d_lde, d_clde, d_layer, d_tnodes, d_cnodes, d_lnodes, d_pos, d_lpos, d_lcount, d_open, (uint32_t)nq, (uint32_t)B, n_layers, slot};
+    HIP_TRY(rb_open(o, st));
+    HIP_TRY(hipMemcpyAsync(h_open, d_open, B * slot, hipMemcpyDeviceToHost, st));
+    HIP_TRY(cs::stream_wait(st));
+    parallel_for(B, [&](size_t t) {
+        const uint8_t *op = h_open + slot * t;
+        const size_t o_trows = 0, o_tpath = o_trows + nq * 16, o_crows = o_tpath + nq * 288, o_cpath = o_crows + nq * 16, o_lrows = o_cpath + nq * 288,
+                     o_lpath = o_lrows + nq * 32;
+        Writer wr;
+        wr.b.reserve(per_proof);
+        wr.raw("CSTK", 4); wr.u32(CSTARK_PROOF_VERSION);
+        wr.u32((uint32_t)CSTARK_AIR_RANGE); wr.u32((uint32_t)W); wr.u32(log_n); wr.u32(0);
+        wr.u32(opt->num_queries); wr.u32(opt->blowup_factor); wr.u32(opt->grinding_factor); wr.u32(opt->hash_fn); wr.u32(opt->field_extension);
+        wr.u32(opt->fri_folding_factor); wr.u32(opt->fri_max_remainder);
+        wr.raw(h_troot + 32 * t, 32); wr.raw(h_croot + 32 * t, 32);
+        wr.u32(n_layers);
+        if (n_layers) wr.raw(h_lroot + 32 * t, 32);
+        wr.raw(&rem_commit[32 * t], 32);
+        wr.raw(h_ood + 6 * t, 6 * 8);
+        wr.u64(nonces[t]);
+        wr.raw(op + o_trows, nq * 16); wr.raw(op + o_tpath, nq * log_N * 32);
+        wr.raw(op + o_crows, nq * 16); wr.raw(op + o_cpath, nq * log_N * 32);
+        if (n_layers) {
+            const size_t np = h_lcount[t];
+            wr.u32((uint32_t)np);
+            wr.raw(op + o_lrows, np * 32);
+            wr.raw(op + o_lpath, np * 7 * 32);
+        }
+        wr.u32((uint32_t)rem_len); wr.raw(h_rem + rem_len * t, rem_len * 8);
+        lens[t] = wr.b.size();
+        if (wr.b.size() <= stride) memcpy(proofs + stride * t, wr.b.data(), wr.b.size());
+    });
+    mark("openings + serialise");
+    for (size_t t = 0; t < B; t++)
+        if (lens[t] > stride) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_prove_batch: stride too small");
+    return CSTARK_OK;
 }
 
 size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt) {

@@ -79,7 +79,62 @@ __global__ __launch_bounds__(1024) void k_merkle_top_sha3(uint8_t *__restrict__ 
     if (threadIdx.x < 2) reinterpret_cast<uint4 *>(nodes)[threadIdx.x] = make_uint4(0, 0, 0, 0);
 }
 
+// batches of small tables (see blake3.hip: k_hash_rows_batch / k_merkle_batch); a row holds at most 8 elements
+__global__ __launch_bounds__(256) void k_hash_rows_batch_sha3(const uint64_t *__restrict__ lde, uint8_t *__restrict__ leaves, unsigned gw, unsigned width_total,
+                                                              unsigned log_n, unsigned log_b, size_t leaf_stride) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t leaf = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (leaf >= (n << log_b)) return;
+    const unsigned t = blockIdx.y;
+    const size_t j = leaf >> log_b;
+    const unsigned kk = (unsigned)(leaf & ((1u << log_b) - 1));
+    const uint64_t *col = lde + ((size_t)kk * width_total + (size_t)t * gw) * n + j;
+    uint64_t s[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) s[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 17; i++) {
+        uint64_t w = (unsigned)i < gw ? col[(size_t)i * n] : 0;
+#if !CSTARK_CONV_HASHED_ELEMENT_BYTES_MONTGOMERY
+        if ((unsigned)i < gw) w = fp_to_u64(w);
+#endif
+        if ((unsigned)i == gw) w ^= 0x06;
+        if (i == 16) w ^= 0x8000000000000000ULL;
+        s[i] ^= w;
+    }
+    keccak::permute(s);
+    uint4 *dst = reinterpret_cast<uint4 *>(leaves + (size_t)t * leaf_stride + 32 * leaf);
+    dst[0] = make_uint4((uint32_t)s[0], (uint32_t)(s[0] >> 32), (uint32_t)s[1], (uint32_t)(s[1] >> 32));
+    dst[1] = make_uint4((uint32_t)s[2], (uint32_t)(s[2] >> 32), (uint32_t)s[3], (uint32_t)(s[3] >> 32));
+}
+__global__ __launch_bounds__(1024) void k_merkle_batch_sha3(uint8_t *__restrict__ nodes_all, size_t cnt, size_t node_stride) {
+    uint8_t *nodes = nodes_all + (size_t)blockIdx.x * node_stride;
+    for (; cnt >= 1; cnt >>= 1) {
+        if (threadIdx.x < cnt) {
+            const size_t i = cnt + threadIdx.x;
+            merge_node_sha3(nodes + 64 * i, nodes + 32 * i);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) reinterpret_cast<uint4 *>(nodes)[threadIdx.x] = make_uint4(0, 0, 0, 0);
+}
+
 } // namespace
+
+hipError_t hash_rows_batch_sha3(const uint64_t *d_lde, uint8_t *d_leaves, unsigned gw, unsigned width_total, unsigned log_n, unsigned log_b, unsigned batch,
+                                size_t leaf_stride, hipStream_t stream) {
+    if (gw == 0 || gw > 8 || batch == 0) return hipErrorInvalidValue;
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_hash_rows_batch_sha3, dim3((unsigned)(((n << log_b) + 255) / 256), batch), dim3(256), 0, stream, d_lde, d_leaves, gw, width_total,
+                       log_n, log_b, leaf_stride);
+    return hipGetLastError();
+}
+hipError_t merkle_build_batch_sha3(uint8_t *d_nodes, unsigned log_leaves, unsigned batch, size_t node_stride, hipStream_t stream) {
+    if (log_leaves < 1 || log_leaves > 11 || batch == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_merkle_batch_sha3, dim3(batch), dim3(1024), 0, stream, d_nodes, ((size_t)1 << log_leaves) >> 1, node_stride);
+    return hipGetLastError();
+}
 
 hipError_t hash_rows_sha3(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, unsigned log_n, unsigned log_b, unsigned k0, unsigned nk,
                           hipStream_t stream) {

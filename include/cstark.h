@@ -299,6 +299,13 @@ int cstark_range_build_trace(cstark_ctx *ctx, uint64_t number, uint64_t *d_trace
 int cstark_range_build_trace_bits(cstark_ctx *ctx, const uint64_t *words, uint32_t log_n, uint64_t *d_trace, uint64_t *number_out);
 int cstark_range_prove_bits(cstark_ctx *ctx, const cstark_options *opt, const uint64_t *words, uint32_t log_n, uint8_t *proof, size_t capacity,
                             size_t *proof_len);
+/* `count` reference-shaped range proofs (RangeProofExample::prove, src/range/mod.rs:75-100; the loop of benches/range.rs:15-37) in ONE
+ * call: every stage is one launch over the batch, the host walks the `count` Fiat-Shamir channels between the stages.  numbers[count]:
+ * field elements in memory form, canonical value below 2^63.  Proof t is written to proofs + t * stride (host memory;
+ * cstark_tx_proof_size_bound(1, opt) is a sufficient stride), its length to lens[t]; it equals
+ * cstark_air_prove(ctx, CSTARK_AIR_RANGE, opt, numbers[t], ...) byte for byte.  FieldExtension::None; both hash functions. */
+int cstark_range_prove_batch(cstark_ctx *ctx, const cstark_options *opt, const uint64_t *numbers, uint32_t count, uint8_t *proofs, size_t stride,
+                             size_t *lens);
 /* SchnorrAir (src/schnorr/air.rs:41-300, src/schnorr/prover.rs:21-67): n signatures over 28-element messages
  * (message[0..12] = public key).  Trace 56 x (512*n); the 19 public-input columns (pkey x12, message chunks x7;
  * src/schnorr/air.rs:228-290) as a 19 x (512*n) table that the caller extends like trace columns; the 8 mask + 28

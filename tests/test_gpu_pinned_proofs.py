@@ -207,3 +207,46 @@ def test_merkle_fused_evaluator_at_2_18_depth_15(oracle, backend):
         assert (to_numpy_u64(ev) == ref_ev).all()
         assert (to_numpy_u64(fused) == oracle.air_combine(desc, to_numpy_u64(lde), ref_ev, ta, tb, ba, bb, 3, k0=k0)).all()
         assert bool(fused.any()) == (k0 % 2 == 0)   # odd cosets are outside the 4n-point evaluation domain
+
+
+# ---- the batched range prover ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opts", [OPTS, (30, 8, 3, 1, 0, 4, 128), (42, 8, 0, 0, 0, 4, 512), (96, 8, 0, 0, 0, 4, 1024)])
+def test_batched_range_proofs_equal_single_proofs(oracle, backend, opts):
+    """cstark_range_prove_batch: B reference-shaped proofs in one call (benches/range.rs:15-37 proves them one by one); every proof
+    must equal cstark_air_prove's bytes -- and, for a sample, the CPU prover's -- and verify."""
+    from oracle import prover as OP
+    from oracle import verifier as V
+    from certificate_stark_amd.backend import Backend
+    rng = np.random.default_rng(5)
+    values = [0, 1, 17, 2**63 - 1, 2**62, oracle.P - 1] + [int(v) for v in rng.integers(0, 2**63, size=94, dtype=np.uint64)]
+    numbers = oracle.to_mont(np.array([v % oracle.P for v in values], np.uint64))
+    proofs = backend.range_prove_batch(options(opts), numbers)
+    assert len(proofs) == len(values)
+    for i, proof in enumerate(proofs):
+        assert proof == backend.air_prove(Backend.AIR_RANGE, options(opts), int(numbers[i])), i
+        if i < 8:
+            assert proof == OP.prove_air(oracle.AIR_RANGE, int(numbers[i]), opts)
+            assert V.verify_range(proof, int(numbers[i]), options=list(opts))
+    assert backend.range_prove_batch(options(opts), numbers[:3]) == proofs[:3]   # a smaller batch on the same context
+
+
+def test_batched_range_prover_at_baseline_size_and_its_errors(oracle, backend):
+    """BASELINE 'range, 2^16 steps' in the reference's own shape: 1024 proofs of 64 rows in ONE call; every proof parsed, a sample
+    compared with the single-proof path and verified.  Non-elements and values of 64 bits are refused as by the single prover."""
+    from oracle import verifier as V
+    from certificate_stark_amd import CstarkError
+    from certificate_stark_amd.backend import Backend
+    from certificate_stark_amd.prover import ProofOptions
+    values = np.random.default_rng(64).integers(0, 2**63, size=1024, dtype=np.uint64)
+    numbers = oracle.to_mont(values % np.uint64(oracle.P))
+    proofs = backend.range_prove_batch(options(), numbers)
+    assert len(proofs) == 1024
+    for i in range(0, 1024, 97):
+        assert proofs[i] == backend.air_prove(Backend.AIR_RANGE, options(), int(numbers[i]))
+        assert V.verify_range(proofs[i], int(numbers[i]), options=list(OPTS))
+    for p in proofs:
+        assert V.parse(p)["log_n"] == 6
+    with pytest.raises(CstarkError):
+        backend.range_prove_batch(options(), np.array([1, oracle.P], np.uint64))            # raw M is not an element (src/range/tests.rs:54-62)
+    with pytest.raises(CstarkError):
+        backend.range_prove_batch(ProofOptions(42, 8, 0, 0, 1, 4, 256), numbers[:2])        # extension fields: cstark_air_prove
