@@ -430,15 +430,17 @@ class Backend:
         return leaves
 
     def shard_evaluate(self, leaves_all):
-        """phase 2: all-gathered digests [8][n][32] -> merged constraint evaluations of this rank's cosets, int64 [nk][n]"""
+        """phase 2: all-gathered digests [8][n][32] -> this rank's share of the merged constraint evaluations, int64 [R][n]
+        (R = cstark_tx_shard_rows(nk): its cosets, or its even cosets + its share of the four odd ones; include/cstark.h)"""
         n = self.n_tx * _lib.TX_CYCLE_LENGTH
         assert tuple(leaves_all.shape) == (8, n, 32) and leaves_all.dtype == torch.uint8
-        out = self.empty_u64(self._shard_nk, n)
+        self.lib.cstark_tx_shard_rows.restype = C.c_uint32
+        out = self.empty_u64(int(self.lib.cstark_tx_shard_rows(C.c_uint32(self._shard_nk))), n)
         check(self.lib.cstark_tx_shard_evaluate(self.ctx, self._ptr(leaves_all.contiguous(), u8p), self._ptr(out)))
         return out
 
     def shard_compose(self, combined_all):
-        """phase 3 (the rank that owns coset 0): merged evaluations of all cosets [8][n] -> query positions, int32 [num_queries]"""
+        """phase 3 (the rank that owns coset 0): the ranks' shares [W * R][n] -> query positions, int32 [num_queries]"""
         nq = self._shard_options.num_queries
         pos = np.zeros(nq, np.uint32)
         check(self.lib.cstark_tx_shard_compose(self.ctx, self._ptr(combined_all.contiguous()), pos.ctypes.data_as(C.POINTER(C.c_uint32))))

@@ -336,6 +336,7 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     for (PeriodicTable &t : c->small_periodic) (void)hipFree(t.tab);
     if (c->desc_buf) (void)hipFree(c->desc_buf);
     if (c->rb_dev) (void)hipFree(c->rb_dev);
+    if (c->shard_bit37) (void)hipFree(c->shard_bit37);
     if (c->rb_host) (void)hipHostFree(c->rb_host);
     if (c->tail_buf) (void)hipFree(c->tail_buf);
     if (c->arena) cs::prove_arena_free(c->arena);
@@ -846,6 +847,102 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
     c->part_valid = c->part_timing;
     return CSTARK_OK;
 }
+// One rank of a proof sharded by LDE coset: the split evaluation on the rank's even cosets, the extension of its (partial) tables to the
+// odd cosets and the recombination of its share (constraints.hip: k_split_finish_shard).  Everything between the even-coset values
+// and the merged evaluations of an odd coset is linear in those values, so the ranks' shares add up to what the single-GPU path
+// writes; exact field arithmetic, hence bit-identical proofs.
+int tx_evaluate_constraints_shard(cstark_ctx *c, const uint64_t *d_lde, const uint64_t *d_coeffs, const cstark_tx_coeffs *coeffs, const uint64_t pub_inputs[4],
+                                  uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t k0, uint32_t nk) {
+    if (!coeffs || !pub_inputs || !d_out || !d_coeffs) return fail(CSTARK_ERR_INVALID_ARG, "sharded constraint evaluation: null argument");
+    if ((nk != 2 && nk != 4) || (k0 % nk) || k0 + nk > 8) return fail(CSTARK_ERR_INVALID_ARG, "sharded split evaluation: a rank holds 2 or 4 consecutive cosets");
+    if (log_n + 3 > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "trace too long for the split evaluation");
+    cs::CeParams p;
+    RC_TRY(ce_params(c, d_lde, d_out, merkle_depth, log_n, 3, k0, nk, &p));
+    constexpr size_t COEF_WORDS = (size_t)cs::CE_MAX_SETS * cs::CE_COEF_WORDS;
+    if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, (COEF_WORDS + (size_t)cs::CE_MAX_SETS * cs::CE_RTAB_WORDS) * 8));
+    if (!c->coef_stage) {
+        if (!c->coef_ev) HIP_TRY(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc(&c->coef_stage, (size_t)cs::CE_MAX_SETS * sizeof(cstark_tx_coeffs), hipHostMallocDefault));
+    } else {
+        HIP_TRY(hipEventSynchronize(c->coef_ev));
+    }
+    memcpy(c->coef_stage, coeffs, sizeof(cstark_tx_coeffs));
+    HIP_TRY(hipMemcpyAsync(c->coef_buf, c->coef_stage, sizeof(cstark_tx_coeffs), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->coef_ev, c->stream));
+    p.coef = c->coef_buf; p.rtab = c->coef_buf + COEF_WORDS; p.m = 1;
+    for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
+    p.nkc = nk / 2;
+    const unsigned kc0 = k0 / 2, nkc = nk / 2;
+    const size_t n = (size_t)1 << log_n;
+    const unsigned T = cs::CE_SPLIT_TABLES;
+    const NttPlan *pn, *p4, *p8;
+    const CosetTable *t1;
+    RC_TRY(get_plan(c, log_n, &pn));
+    RC_TRY(get_plan(c, log_n + 2, &p4));
+    RC_TRY(get_plan(c, log_n + 3, &p8));
+    RC_TRY(get_coset_table(c, log_n, 3, cs::host::from_u64(1), &t1));
+    const size_t region = (size_t)T * 4 * n, hcol = (size_t)2 * n;
+    // register 37 on all eight cosets first: the extension uses the workspace itself
+    uint64_t *bit37 = nullptr;
+    {
+        cs::ProveArena *unused = nullptr; (void)unused;
+        if (!c->shard_bit37 || c->shard_bit37_words < 8 * n) {
+            if (c->shard_bit37) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->shard_bit37)); c->shard_bit37 = nullptr; }
+            HIP_TRY(hipMalloc((void **)&c->shard_bit37, 8 * n * 8));
+            c->shard_bit37_words = 8 * n;
+        }
+        bit37 = c->shard_bit37;
+        RC_TRY(lde_impl(c, d_coeffs + (size_t)37 * n, bit37, 1, 0, 1, log_n, 3, cs::host::lde_offset(), 0, 8));
+    }
+    RC_TRY(ensure_ws(c, (5 * region + 9 * hcol) * 8));
+    uint64_t *even = (uint64_t *)c->ws, *sa = even + region, *sb = sa + region, *sc = sb + region, *odd = sc + region;
+    uint64_t *fin_direct = odd + region, *fin_hi = fin_direct + hcol, *fin_co = fin_hi + 4 * hcol, *fin_scr = fin_co + hcol;
+    HIP_TRY(cs::launch_rounds_setup(p, c->stream));
+    HIP_TRY(cs::launch_rounds_split(p, even, c->stream));
+    uint64_t *fam_dbl = even + (size_t)cs::CE_SPLIT_FAM0 * 4 * n, *fam_add = fam_dbl + 12 * n, *fam_addbit = fam_add + 8 * n, *fam_final = fam_addbit + 8 * n;
+    HIP_TRY(cs::launch_ec_split(p, 1, fam_dbl, nullptr, c->stream));
+    HIP_TRY(cs::launch_ec_split(p, 2, fam_add, nullptr, c->stream));
+    HIP_TRY(cs::launch_ec_split(p, 3, fam_dbl, nullptr, c->stream));
+    HIP_TRY(cs::launch_ec_split(p, 4, fam_addbit, fam_add, c->stream));
+    HIP_TRY(cs::launch_final_split(p, -1, fam_final, c->stream));
+    HIP_TRY(cs::launch_lin_all(p, even, c->stream));
+    // interpolation of every table on the rank's even cosets: columns [kc0, kc0 + nkc) of each table's four (batch = table)
+    cs::NttArgs a{};
+    a.in = even + (size_t)kc0 * n; a.scratch = sa + (size_t)kc0 * n; a.out = sb + (size_t)kc0 * n; a.width = nkc; a.batch = T; a.log_n = log_n;
+    a.in_batch_stride = 4 * n; a.scratch_batch_stride = 4 * n; a.out_batch_stride = 4 * n;
+    a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true; a.aux = pn->aux_winv;
+    HIP_TRY(cs::ntt_columns(a, c->stream));
+    HIP_TRY(cs::coset_even_to_odd(sb, sa, log_n, T, p4->winv, p8->w, cs::host::inv(cs::host::from_u64(4)), c->stream, kc0, nkc));
+    cs::NttArgs f{};
+    f.in = sa; f.scratch = sc; f.out = odd; f.width = T; f.batch = 4; f.log_n = log_n;
+    f.w = pn->w; f.prescale = t1->s + n; f.prescale_batch_stride = 2 * n; f.do_scale = false; f.inverse = false;
+    f.aux = pn->aux_w; f.aux_ps = t1->aux ? t1->aux + t1->aux_words : nullptr; f.aux_ps_batch_stride = 2 * t1->aux_words;
+    f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
+    HIP_TRY(cs::ntt_columns(f, c->stream));
+    {   // high parts of the final addition: H = (T - Q) / 2 on LDE coset 1 -- Q (the direct evaluation there) only on the rank that holds coset 1
+        if (k0 == 0) HIP_TRY(cs::launch_final_split(p, 1, fin_direct, c->stream));
+        else HIP_TRY(hipMemsetAsync(fin_direct, 0, hcol * 8, c->stream));
+        HIP_TRY(cs::launch_final_hi(p, odd, fin_direct, fin_hi, cs::host::inv(cs::host::from_u64(2)), c->stream));
+        cs::NttArgs hi_inv{};
+        hi_inv.in = fin_hi; hi_inv.scratch = fin_scr; hi_inv.out = fin_co; hi_inv.width = 2; hi_inv.batch = 1; hi_inv.log_n = log_n;
+        hi_inv.w = pn->winv; hi_inv.post_scale = pn->n_inv; hi_inv.do_scale = true; hi_inv.inverse = true; hi_inv.aux = pn->aux_winv;
+        HIP_TRY(cs::ntt_columns(hi_inv, c->stream));
+        cs::NttArgs hi_fwd{};
+        hi_fwd.in = fin_co; hi_fwd.scratch = fin_scr; hi_fwd.out = fin_hi + hcol; hi_fwd.width = 2; hi_fwd.batch = 3; hi_fwd.log_n = log_n;
+        hi_fwd.w = pn->w; hi_fwd.prescale = t1->s + 2 * n; hi_fwd.prescale_batch_stride = 2 * n; hi_fwd.do_scale = false; hi_fwd.inverse = false;
+        hi_fwd.aux = pn->aux_w; hi_fwd.aux_ps = t1->aux ? t1->aux + 2 * t1->aux_words : nullptr; hi_fwd.aux_ps_batch_stride = 2 * t1->aux_words;
+        hi_fwd.in_batch_stride = 0; hi_fwd.scratch_batch_stride = hcol; hi_fwd.out_batch_stride = hcol;
+        HIP_TRY(cs::ntt_columns(hi_fwd, c->stream));
+    }
+    HIP_TRY(cs::launch_split_finish_shard(p, even, odd, fin_hi, bit37, d_out, c->stream));
+    return CSTARK_OK;
+}
+int tx_shard_combine(cstark_ctx *c, const uint64_t *d_parts, uint64_t *d_out, uint32_t log_n, uint32_t nk) {
+    if (!c || !d_parts || !d_out || (nk != 2 && nk != 4)) return fail(CSTARK_ERR_INVALID_ARG, "tx_shard_combine: bad argument");
+    HIP_TRY(cs::launch_shard_combine(d_parts, d_out, log_n, nk / 2, c->stream));
+    return CSTARK_OK;
+}
+
 extern "C" {
 
 int cstark_tx_evaluate_constraints(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, const uint64_t pub_inputs[4],

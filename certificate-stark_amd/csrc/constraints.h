@@ -36,6 +36,7 @@ struct CeParams {
     uint32_t adj_mod_n[5]; // degree adjustments reduced mod n (x^adj = shift^adj * w^(j*adj mod n))
     uint32_t badj_mod_n;
     uint32_t log_n, log_b, k0;
+    uint32_t nkc;          // split evaluation of a coset window (one rank of a sharded proof): even cosets in p.lde, 1 or 2; 0 = all four
 };
 
 constexpr int AIR_MAX_GROUPS = 8;
@@ -90,6 +91,12 @@ constexpr int CE_SPLIT_TABLES = 13, CE_SPLIT_FAM0 = 4; // first family (Rescue w
 hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream);
 // the three linear groups in one pass over the frame (k_lin_all); same four polynomials as the three launch_lin_split parts
 hipError_t launch_lin_all(const CeParams &p, uint64_t *d_even_family0, hipStream_t stream);
+// one rank of a proof sharded by LDE coset (p.k0 even, p.nkc = 1 or 2 even cosets, m = 1): rows [p.nkc + 4][n] = its even cosets'
+// complete values, then its share of the four odd cosets (constraints.hip, k_split_finish_shard); d_bit37_all = register 37 on all cosets
+hipError_t launch_split_finish_shard(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, const uint64_t *d_hi, const uint64_t *d_bit37_all,
+                                     uint64_t *d_out, hipStream_t stream);
+// the ranks' rows [4 / nkc][nkc + 4][n] -> merged evaluations of all cosets [8][n]
+hipError_t launch_shard_combine(const uint64_t *d_parts, uint64_t *d_out, unsigned log_n, unsigned nkc, hipStream_t stream);
 // d_hi = [4 odd cosets][2 m][n]: the high parts of the final-addition polynomials on the odd cosets (launch_final_hi + their extension)
 hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, const uint64_t *d_hi, hipStream_t stream);
 // Final addition (degree 5 (n - 1): one n-coefficient block above the 4n the even cosets determine).  coset < 0: the two sums

@@ -706,15 +706,17 @@ __global__ __launch_bounds__(FNT, M == 1 ? CS_ROUNDS_SPLIT_WAVES : 2) void k_rou
     __shared__ fp s2_lds[M == 1 ? 1 : (FNT / 64) * 14 * 64]; // several sets: the window's cubes, one column per lane
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
-    const unsigned kc = blockIdx.y, kk = 2 * kc; // the launcher guarantees k0 = 0 and all cosets present
+    // Even cosets of this table: blockIdx.y-th even coset of the window p.lde holds (cosets [p.k0, ...), p.k0 even; all eight on one
+    // GPU).  kk = its index in p.lde, kc = its index among the four even cosets of the domain (table row), ka = 2 kc = its LDE coset.
+    const unsigned kk = 2 * blockIdx.y, kc = (p.k0 >> 1) + blockIdx.y, ka = 2 * kc;
     const Frame f = make_frame(p, kk, j);
     if (threadIdx.x < 8 * 14) {
         const unsigned r = threadIdx.x / 14, c = threadIdx.x % 14;
-        ark2_lds[threadIdx.x] = p.ptab[((size_t)kk * 48 + P_ARK + 14 + c) * 1024 + ((blockIdx.x * (size_t)FNT + r) & 1023)];
+        ark2_lds[threadIdx.x] = p.ptab[((size_t)ka * 48 + P_ARK + 14 + c) * 1024 + ((blockIdx.x * (size_t)FNT + r) & 1023)];
     }
     for (unsigned e = threadIdx.x; e < M * RT_SECTIONS * 8; e += FNT) {
         const unsigned c = e / (RT_SECTIONS * 8), r = e % (RT_SECTIONS * 8);
-        atab_lds[e] = p.rtab[(size_t)c * CE_RTAB_WORDS + RT_A + (r >> 3) * 64 + kk * 8 + (r & 7)];
+        atab_lds[e] = p.rtab[(size_t)c * CE_RTAB_WORDS + RT_A + (r >> 3) * 64 + ka * 8 + (r & 7)];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -893,6 +895,80 @@ __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__re
     }
 }
 
+// The recombination for ONE RANK of a proof sharded by LDE coset (cstark_tx_shard_evaluate): the rank holds cosets [p.k0, p.k0 + nk),
+// nk = 2 p.nkc, and evaluated the split polynomials on ITS even cosets only; `odd` / `hi` are the extensions of those PARTIAL tables
+// (the other ranks' even cosets taken as zero).  Interpolation, extension and this recombination are linear in the even-coset values,
+// so the sum of the ranks' rows for an odd coset is the value the single-GPU k_split_finish writes.  Rows of out[p.nkc + 4][n]:
+//   y < p.nkc   own even coset p.k0 + 2 y: complete value (its tables are complete here)
+//   y >= p.nkc  odd coset 2 (y - p.nkc) + 1: this rank's share; the boundary terms (registers 58, 59 of the extended trace) only on
+//               the rank that holds the coset.  bit37 = register 37 extended to ALL cosets, [8][n]: the one trace column the
+//               recombination itself reads (the "flag" of the public-key addition), every rank extends it from its coefficients.
+__global__ __launch_bounds__(256) void k_split_finish_shard(CeParams p, const fp *__restrict__ even, const fp *__restrict__ odd, const fp *__restrict__ hi,
+                                                            const fp *__restrict__ bit37_all, fp *__restrict__ out) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    const unsigned y = blockIdx.y;
+    const bool is_odd = y >= p.nkc;
+    const unsigned k = is_odd ? 2 * (y - p.nkc) + 1 : p.k0 + 2 * y;
+    const bool mine = k >= p.k0 && k < p.k0 + 2 * p.nkc;
+    const fp *cc = p.coset + (size_t)k * CE_COSET_CONSTS;
+    const fp x = fp_mul(cc[0], p.w[j]);
+    fp xp[3];
+#pragma unroll
+    for (int g = 0; g < 3; g++) xp[g] = fp_mul(cc[2 + g], p.w[(j * p.adj_mod_n[g]) & (n - 1)]);
+    const fp *per = p.ptab + (size_t)k * 48 * 1024 + (j & 1023);
+    const fp doubling = per[(size_t)P_DOUBLING * 1024], scalar_mult = per[(size_t)P_SCALAR_MULT * 1024];
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
+    const fp bit37 = bit37_all[(size_t)k * n + j];
+    const fp divisor = fp_mul(fp_sub(x, p.w_last), cc[1]);
+    constexpr int T = SPLIT_TABLES;
+    auto value = [&](int t) { return is_odd ? odd[((size_t)(k >> 1) * T + t) * n + j] : even[((size_t)t * 4 + (k >> 1)) * n + j]; };
+    fp total = value(0);
+#pragma unroll
+    for (int g = 0; g < 3; g++) total = fp_add(total, fp_mul(value(1 + g), xp[g]));
+    const fp dbl = fp_add(value(4), fp_add(fp_mul(value(5), xp[0]), fp_mul(value(6), xp[1])));
+    const fp add = fp_add(value(7), fp_mul(value(8), xp[0]));
+    const fp addbit = fp_add(value(9), fp_mul(value(10), xp[0]));
+    total = fp_add(total, fp_mul(doubling, dbl));
+    total = fp_add(total, fp_mul(addition, fp_sub(add, fp_mul(bit37, addbit))));
+    {
+        fp fa = value(SPLIT_FINAL), fb = value(SPLIT_FINAL + 1);
+        if (is_odd) {
+            const fp *h = hi + ((size_t)(k >> 1) * 2) * n + j;
+            fa = fp_sub(fa, fp_dbl(h[0]));
+            fb = fp_sub(fb, fp_dbl(h[n]));
+        }
+        total = fp_add(total, fp_mul(fp_mul(c_not(scalar_mult), per[(size_t)P_SCHNORR * 1024]), fp_add(fa, fp_mul(fb, xp[0]))));
+    }
+    fp t = fp_mul(total, divisor);
+    if (mine) { // boundary constraints on registers 58, 59 (src/air.rs:175-184): the rank that holds the coset adds them
+        const fp *col = p.lde + (size_t)(k - p.k0) * 94 * n + j;
+        const fp r58 = col[(size_t)58 * n], r59 = col[(size_t)59 * n];
+        const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
+        const fp *bi = p.binv + (size_t)k * 2 * n + j;
+        const fp *ba = p.coef + 230, *bb = ba + 4;
+        const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
+        const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
+        t = fp_add(t, fp_add(fp_mul(first, bi[0]), fp_mul(last, bi[n])));
+    }
+    out[(size_t)y * n + j] = t;
+}
+// parts = the ranks' rows side by side, [world][nkc + 4][n] (world = 4 / nkc): merged evaluations of all eight cosets, out[8][n]
+__global__ __launch_bounds__(256) void k_shard_combine(const fp *__restrict__ parts, fp *__restrict__ out, unsigned log_n, unsigned nkc) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    const unsigned k = blockIdx.y, rows = nkc + 4, world = 4 / nkc;
+    fp v;
+    if (!(k & 1)) {
+        const unsigned kc = k >> 1, r = kc / nkc;
+        v = parts[((size_t)r * rows + kc % nkc) * n + j];
+    } else {
+        v = 0;
+        for (unsigned r = 0; r < world; r++) v = fp_add(v, parts[((size_t)r * rows + nkc + (k >> 1)) * n + j]);
+    }
+    out[(size_t)k * n + j] = v;
+}
+
 // doubling gadget for the point at registers [reg, reg + 19)  (ecc.rs:73-98)
 template <class A>
 __device__ __forceinline__ void fused_doubling(A &acc, const Frame &f, int reg, fp doubling) {
@@ -1004,8 +1080,8 @@ template <int PART, bool ACCUMULATE, int M>
 __global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_ec_split(CeParams p, fp *__restrict__ out, fp *__restrict__ out_linear) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
-    const unsigned kc = blockIdx.y;
-    const Frame f = make_frame(p, 2 * kc, j); // the launcher guarantees k0 = 0 and all cosets present
+    const unsigned kc = (p.k0 >> 1) + blockIdx.y; // own even coset blockIdx.y of the window = even coset kc of the domain (k_rounds_split)
+    const Frame f = make_frame(p, 2 * blockIdx.y, j);
     SplitAcc<M> acc;
     acc.coefs = as_const(p.coef);
     constexpr size_t SET = (size_t)SPLIT_TABLES * 4; // tables (x n words) between the blocks of two coefficient sets
@@ -1059,8 +1135,8 @@ template <int M>
 __global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_final_split(CeParams p, fp *__restrict__ out, int coset) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
-    const unsigned kc = blockIdx.y, k = coset < 0 ? 2 * kc : (unsigned)coset;
-    const Frame f = make_frame(p, k, j); // the launcher guarantees k0 = 0 and all cosets present
+    const unsigned kc = (p.k0 >> 1) + blockIdx.y, k = coset < 0 ? 2 * kc : (unsigned)coset; // k: LDE coset; p.lde holds it at k - p.k0
+    const Frame f = make_frame(p, k - p.k0, j);
     SplitAcc<M> acc;
     acc.coefs = as_const(p.coef);
     fused_final_addition(acc, f, (fp)0);
@@ -1446,8 +1522,8 @@ template <int PART>
 __global__ __launch_bounds__(FNT, PART == PART_LIN_C ? CS_LIN_C_SPLIT_WAVES : PART == PART_LIN_B ? CS_LIN_B_SPLIT_WAVES : 4) void k_lin_split(CeParams p, fp *__restrict__ out, unsigned set) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
-    const unsigned kc = blockIdx.y;
-    const Frame f = make_frame(p, 2 * kc, j);
+    const unsigned kc = (p.k0 >> 1) + blockIdx.y; // (k_rounds_split)
+    const Frame f = make_frame(p, 2 * blockIdx.y, j);
     out += (size_t)set * SPLIT_TABLES * 4 * n;
     const CS_CONST fp *coefs = as_const(p.coef + (size_t)set * CE_COEF_WORDS);
     fp tot[6] = {0, 0, 0, 0, 0, 0};
@@ -1612,8 +1688,8 @@ __device__ __forceinline__ void lin_all_split(const CS_CONST fp *coefs, const Fr
 __global__ __launch_bounds__(FNT, CS_LIN_ALL_WAVES) void k_lin_all(CeParams p, fp *__restrict__ out, unsigned set) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
-    const unsigned kc = blockIdx.y;
-    const Frame f = make_frame(p, 2 * kc, j);
+    const unsigned kc = (p.k0 >> 1) + blockIdx.y; // (k_rounds_split)
+    const Frame f = make_frame(p, 2 * blockIdx.y, j);
     out += (size_t)set * SPLIT_TABLES * 4 * n;
     const CS_CONST fp *coefs = as_const(p.coef + (size_t)set * CE_COEF_WORDS);
     fp tot[6] = {0, 0, 0, 0, 0, 0};
@@ -2060,7 +2136,7 @@ hipError_t launch_rounds_setup(const CeParams &p, hipStream_t stream) {
 }
 hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
+    const dim3 grid((unsigned)(n / FNT), p.nkc ? p.nkc : 4), block(FNT);
     const unsigned m = p.m ? p.m : 1;
     if (m == 1) hipLaunchKernelGGL(k_rounds_split<1>, grid, block, 0, stream, p, d_even);
     else if (m == 2) hipLaunchKernelGGL(k_rounds_split<2>, grid, block, 0, stream, p, d_even);
@@ -2070,7 +2146,7 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
 }
 hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family, uint64_t *d_even_linear, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
+    const dim3 grid((unsigned)(n / FNT), p.nkc ? p.nkc : 4), block(FNT);
     const unsigned m = p.m ? p.m : 1;
 #define CS_EC(M)                                                                                                                                      \
     if (part == PART_DBL0) hipLaunchKernelGGL((k_ec_split<PART_DBL0, false, M>), grid, block, 0, stream, p, d_even_family, d_even_linear);           \
@@ -2084,14 +2160,14 @@ hipError_t launch_ec_split(const CeParams &p, int part, uint64_t *d_even_family,
 }
 hipError_t launch_lin_all(const CeParams &p, uint64_t *d_even_family0, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
+    const dim3 grid((unsigned)(n / FNT), p.nkc ? p.nkc : 4), block(FNT);
     const unsigned m = p.m ? p.m : 1;
     for (unsigned set = 0; set < m; set++) hipLaunchKernelGGL(k_lin_all, grid, block, 0, stream, p, d_even_family0, set);
     return hipGetLastError();
 }
 hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
+    const dim3 grid((unsigned)(n / FNT), p.nkc ? p.nkc : 4), block(FNT);
     const unsigned m = p.m ? p.m : 1;
     for (unsigned set = 0; set < m; set++) {
         if (part == PART_LIN_A) hipLaunchKernelGGL(k_lin_split<PART_LIN_A>, grid, block, 0, stream, p, d_even_family0, set);
@@ -2111,9 +2187,23 @@ hipError_t launch_split_finish(const CeParams &p, const uint64_t *d_even, const 
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+hipError_t launch_split_finish_shard(const CeParams &p, const uint64_t *d_even, const uint64_t *d_odd, const uint64_t *d_hi, const uint64_t *d_bit37_all,
+                                     uint64_t *d_out, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    if (p.nkc != 1 && p.nkc != 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_split_finish_shard, dim3((unsigned)(n / 256), p.nkc + 4), dim3(256), 0, stream, p, d_even, d_odd, d_hi, d_bit37_all, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_shard_combine(const uint64_t *d_parts, uint64_t *d_out, unsigned log_n, unsigned nkc, hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    if (nkc != 1 && nkc != 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_shard_combine, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, d_parts, d_out, log_n, nkc);
+    return hipGetLastError();
+}
 hipError_t launch_final_split(const CeParams &p, int coset, uint64_t *d_out, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    const dim3 grid((unsigned)(n / FNT), coset < 0 ? 4 : 1), block(FNT);
+    const unsigned even_rows = p.nkc ? p.nkc : 4;
+    const dim3 grid((unsigned)(n / FNT), coset < 0 ? even_rows : 1), block(FNT);
     const unsigned m = p.m ? p.m : 1;
     if (m == 1) hipLaunchKernelGGL(k_final_split<1>, grid, block, 0, stream, p, d_out, coset);
     else if (m == 2) hipLaunchKernelGGL(k_final_split<2>, grid, block, 0, stream, p, d_out, coset);

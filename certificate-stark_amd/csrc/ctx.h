@@ -110,6 +110,8 @@ struct cstark_ctx {
     cs::ProveArena *arena = nullptr; // device buffers of cstark_tx_prove (prove.hip)
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    uint64_t *shard_bit37 = nullptr; // sharded split evaluation: register 37 on all eight cosets
+    size_t shard_bit37_words = 0;
     void *rb_dev = nullptr, *rb_host = nullptr; // cstark_range_prove_batch: one device block and one pinned host block, carved per call
     size_t rb_dev_bytes = 0, rb_host_bytes = 0;
 };
@@ -123,6 +125,13 @@ struct cstark_tx_coeffs;
 int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
                                  uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
                                  bool input_is_lde);
+// internal (capi.hip): one rank's share of the degree-split evaluation of a proof sharded by LDE coset.  d_lde: the rank's cosets
+// [k0, k0 + nk) (k0 even, nk = 2 or 4) of its own extension; d_coeffs: the 94 coefficient columns (register 37 is extended to all
+// cosets here: the recombination reads it on cosets the rank does not hold).  d_out [nk / 2 + 4][n]: merged evaluations of the rank's
+// even cosets, then its share of the four odd cosets (summed over the ranks by tx_shard_combine: d_parts [8 / nk][nk / 2 + 4][n] -> [8][n]).
+int tx_evaluate_constraints_shard(cstark_ctx *c, const uint64_t *d_lde, const uint64_t *d_coeffs, const cstark_tx_coeffs *coeffs, const uint64_t pub_inputs[4],
+                                  uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n, uint32_t k0, uint32_t nk);
+int tx_shard_combine(cstark_ctx *c, const uint64_t *d_parts, uint64_t *d_out, uint32_t log_n, uint32_t nk);
 // internal (capi.hip): TransactionAir trace spread over the context's streams, nothing joined.  In stream order `stream` holds
 // registers >= TX_COPY_COLS (closed forms); c->side: the Merkle recurrence, c->ev_join recorded behind it; c->side2: message hash
 // (c->ev_mid behind it), then the curve ladders (c->ev_join2 behind them).  Registers [TX_LATE_COLS, TX_COPY_COLS) are complete

@@ -52,7 +52,7 @@ hipError_t coset_combine(const uint64_t *d_b, uint64_t *d_h, unsigned log_n, uns
 // inputs of the n-point transforms over the odd cosets (whose prescale table supplies the twist w_8n^((2k'+1) q)), in one pass: the
 // 4n coefficients are never written.  d_out [4 odd cosets][tables][n]; d_winv_4n = powers of w_4n^-1, d_w_8n = powers of w_8n, quarter = 1/4.
 hipError_t coset_even_to_odd(const uint64_t *d_b, uint64_t *d_out, unsigned log_n, unsigned tables, const uint64_t *d_winv_4n, const uint64_t *d_w_8n,
-                             uint64_t quarter, hipStream_t stream);
+                             uint64_t quarter, hipStream_t stream, unsigned kc0 = 0, unsigned nkc = 4); // (only even cosets [kc0, kc0 + nkc) present)
 hipError_t split_columns(const uint64_t *d_h, uint64_t *d_out, unsigned log_n, unsigned log_b, uint64_t ginv, hipStream_t stream);
 
 } // namespace cs

@@ -902,8 +902,10 @@ __global__ __launch_bounds__(256) void k_coset_combine(const fp *__restrict__ in
         out[(size_t)i * n + q] = acc_reduce(a);
     }
 }
+// (kc0, nkc): only even cosets [kc0, kc0 + nkc) of `in` are present, the others count as zero (one rank's share of a sharded proof:
+// the map is linear, the ranks' outputs add up)
 __global__ __launch_bounds__(256) void k_coset_even_to_odd(const fp *__restrict__ in, fp *__restrict__ out, size_t n, unsigned tables,
-                                                           const fp *__restrict__ winv4n, const fp *__restrict__ w8n, fp quarter) {
+                                                           const fp *__restrict__ winv4n, const fp *__restrict__ w8n, fp quarter, unsigned kc0, unsigned nkc) {
     const size_t q = blockIdx.x * (size_t)256 + threadIdx.x;
     if (q >= n) return;
     const unsigned tb = blockIdx.y;
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(256) void k_coset_even_to_odd(const fp *__restrict_
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         w4[k] = winv4n[(size_t)k * n]; // w_4^-k
-        const fp x = fp_mul(in[((size_t)tb * 4 + k) * n + q], quarter);
+        const fp x = ((unsigned)k - kc0 < nkc) ? fp_mul(in[((size_t)tb * 4 + k) * n + q], quarter) : 0;
         v[k] = k == 0 ? x : fp_mul(x, winv4n[(size_t)k * q]);
     }
 #pragma unroll
@@ -933,9 +935,10 @@ __global__ __launch_bounds__(256) void k_coset_even_to_odd(const fp *__restrict_
     }
 }
 hipError_t coset_even_to_odd(const fp *d_b, fp *d_out, unsigned log_n, unsigned tables, const fp *d_winv_4n, const fp *d_w_8n, fp quarter,
-                             hipStream_t stream) {
+                             hipStream_t stream, unsigned kc0, unsigned nkc) {
     const size_t n = (size_t)1 << log_n;
-    hipLaunchKernelGGL(k_coset_even_to_odd, dim3((unsigned)((n + 255) / 256), tables), dim3(256), 0, stream, d_b, d_out, n, tables, d_winv_4n, d_w_8n, quarter);
+    hipLaunchKernelGGL(k_coset_even_to_odd, dim3((unsigned)((n + 255) / 256), tables), dim3(256), 0, stream, d_b, d_out, n, tables, d_winv_4n, d_w_8n, quarter,
+                       kc0, nkc);
     return hipGetLastError();
 }
 hipError_t coset_combine(const fp *d_b, fp *d_h, unsigned log_n, unsigned log_b, const fp *d_winv_N, fp b_inv, hipStream_t stream, unsigned tables) {

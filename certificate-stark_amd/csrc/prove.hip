@@ -665,6 +665,15 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     return phase_open(c, a, R, nullptr, proof, capacity, proof_len);
 }
 
+// Sharded proofs: a rank that holds 2 or 4 cosets evaluates its share of the degree-split form (CSTARK_SHARD_SPLIT=0, tuning /
+// debugging: every point of its cosets directly, as a rank with a single coset always does).  shard_rows = rows of n merged
+// evaluations the rank hands to the all-gather: its nk cosets, or its nk / 2 even cosets + its share of the four odd ones.
+bool shard_split(uint32_t nk) {
+    static const bool on = [] { const char *e = getenv("CSTARK_SHARD_SPLIT"); return !e || atoi(e) != 0; }();
+    return on && (nk == 2 || nk == 4);
+}
+uint32_t shard_rows(uint32_t nk) { return shard_split(nk) ? nk / 2 + 4 : nk; }
+
 // first / last row of registers 58..64 -> job.pub (TransactionProver::get_pub_inputs src/prover.rs:106-129; MerkleProver alike)
 int gather_roots(cstark_ctx *c, ProveArena *a, AirJob &job) {
     const size_t n = (size_t)1 << job.log_n;
@@ -714,8 +723,9 @@ int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, co
     memcpy(cf.b_alpha, ba, sizeof cf.b_alpha); memcpy(cf.b_beta, bb, sizeof cf.b_beta);
     const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]}; // get_assertions, src/air.rs:175-184
     uint64_t *outs[1] = {out};
-    // all cosets on this GPU: the degree-split evaluation (the table is this prover's own extension); a coset window of a sharded
-    // proof: every point directly
+    // all cosets on this GPU: the degree-split evaluation (the table is this prover's own extension); a window of 2 or 4 cosets of a
+    // sharded proof: the rank's share of the split evaluation (rows: shard_rows); a single coset (8 ranks): every point directly
+    if (shard_split(job.nk)) return tx_evaluate_constraints_shard(c, a->lde, a->coeffs, &cf, pub4, out, job.item, job.log_n, job.k0, job.nk);
     return tx_evaluate_constraints_sets(c, a->lde, &cf, 1, pub4, outs, job.item, job.log_n, 3, job.k0, job.nk, job.nk == 8);
 }
 int tx_combine_sets(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned m, const uint64_t *const *ta, const uint64_t *const *tb, const uint64_t *const *ba,
@@ -1154,6 +1164,7 @@ int cstark_tx_shard_commit(cstark_ctx *c, const cstark_options *opt, uint32_t k0
     if (rc) { proof_run_free(a->run); a->run = nullptr; }
     return rc;
 }
+uint32_t cstark_tx_shard_rows(uint32_t nk) { return (nk == 1 || nk == 2 || nk == 4) ? shard_rows(nk) : 0; }
 int cstark_tx_shard_evaluate(cstark_ctx *c, const uint8_t *d_leaves_all, uint64_t *d_combined_local) {
     ProofRun *R;
     RC_TRY(shard_run(c, 1, &R));
@@ -1166,7 +1177,8 @@ int cstark_tx_shard_compose(cstark_ctx *c, const uint64_t *d_combined_all, uint3
     if (!d_combined_all || !positions) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_compose: null argument");
     ProveArena *a = c->arena;
     const size_t N = (size_t)8 << R->job.log_n;
-    if (d_combined_all != a->combined) HIP_TRY(hipMemcpyAsync(a->combined, d_combined_all, N * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (shard_split(R->job.nk)) RC_TRY(tx_shard_combine(c, d_combined_all, a->combined, R->job.log_n, R->job.nk)); // the ranks' shares -> [8][n]
+    else if (d_combined_all != a->combined) HIP_TRY(hipMemcpyAsync(a->combined, d_combined_all, N * 8, hipMemcpyDeviceToDevice, c->stream));
     RC_TRY(phase_compose(c, a, *R));
     memcpy(positions, R->positions.data(), R->positions.size() * 4);
     return CSTARK_OK;

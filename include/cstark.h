@@ -263,13 +263,19 @@ size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt);
  * owns the nk = 8 / W cosets [k0, k0 + nk), k0 = r nk.  The proof bytes equal cstark_tx_prove's bit for bit.
  *   1 cstark_tx_shard_commit     trace + interpolation (replicated), extension and row hashes of the rank's cosets;
  *                                d_leaves_local [nk][n][32]               -> all-gather -> d_leaves_all [8][n][32] (coset-major)
- *   2 cstark_tx_shard_evaluate   trace tree + root (every rank: the channel is replayed everywhere), coefficients, merged constraint
- *                                evaluations of the rank's cosets: d_combined_local [nk][n] -> all-gather -> d_combined_all [8][n]
- *   3 cstark_tx_shard_compose    rank 0 only (it owns coset 0, which the DEEP composition reads): composition polynomial and its
- *                                commitment, out-of-domain frame, DEEP, FRI; positions[num_queries] (host) -> broadcast
+ *   2 cstark_tx_shard_evaluate   trace tree + root (every rank: the channel is replayed everywhere), coefficients, the rank's share of the
+ *                                merged constraint evaluations: d_combined_local [R][n], R = cstark_tx_shard_rows(nk)
+ *                                -> all-gather -> d_combined_all [W][R][n].  W = 8: R = 1, the rank's coset evaluated point by point.
+ *                                W = 2, 4: the degree-split evaluation, sharded -- R = nk / 2 + 4: the rank's nk / 2 even cosets
+ *                                (complete), then ITS SHARE of each of the four odd cosets (the split polynomials are evaluated on the
+ *                                rank's even cosets only; their extension to the odd cosets is linear, so the ranks' shares add up)
+ *   3 cstark_tx_shard_compose    rank 0 only (it owns coset 0, which the DEEP composition reads): sums the shares into the merged
+ *                                evaluations of all cosets, composition polynomial and its commitment, out-of-domain frame, DEEP, FRI;
+ *                                positions[num_queries] (host) -> broadcast
  *   4 cstark_tx_shard_open_rows  every rank: the opened rows of the extended trace that lie in its cosets, zeros elsewhere;
  *                                d_rows [nq][94] -> all-reduce (sum) -> complete rows
  *   5 cstark_tx_shard_finish     rank 0: paths, remaining openings, proof bytes. */
+uint32_t cstark_tx_shard_rows(uint32_t nk); /* rows of n evaluations a rank with nk cosets contributes in phase 2 (0: invalid nk) */
 int cstark_tx_shard_commit(cstark_ctx *ctx, const cstark_options *opt, uint32_t k0, uint32_t nk, uint8_t *d_leaves_local);
 int cstark_tx_shard_evaluate(cstark_ctx *ctx, const uint8_t *d_leaves_all, uint64_t *d_combined_local);
 int cstark_tx_shard_compose(cstark_ctx *ctx, const uint64_t *d_combined_all, uint32_t *positions);

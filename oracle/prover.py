@@ -164,11 +164,35 @@ class ShardedProver:
             ta[i], tb[i] = _mont(coin.draw()), _mont(coin.draw())
         for i in range(job.na):
             ba[i], bb[i] = _mont(coin.draw()), _mont(coin.draw())
-        return job.combine(trace, self.lde, ta, tb, ba, bb, k0=self.k0)
+        own = job.combine(trace, self.lde, ta, tb, ba, bb, k0=self.k0)
+        if self.nk not in (2, 4):
+            return own
+        # A rank with 2 or 4 cosets hands over ROWS as the product does (cstark_tx_shard_rows): its even cosets, then a share of each
+        # of the four odd cosets whose sum over the ranks is that coset's evaluations.  The product's shares come out of the
+        # degree-split evaluation (its own even cosets' part of every split polynomial, extended); here the share is simply the
+        # direct evaluation on the rank that holds the coset and zero elsewhere -- the same sums, which is all the driver relies on.
+        rows = np.zeros((self.nk // 2 + 4, self.n), np.uint64)
+        rows[:self.nk // 2] = own[0::2]
+        for i in range(1, self.nk, 2):
+            rows[self.nk // 2 + (self.k0 + i) // 2] = own[i]
+        return rows
 
     def compose(self, combined):
-        """combined [8][n] (all cosets); the owner of coset 0: composition .. FRI -> query positions"""
+        """combined: the ranks' rows of evaluate() side by side ([8][n] when every rank hands over whole cosets); the owner of coset 0:
+        composition .. FRI -> query positions"""
         assert self.k0 == 0
+        if self.nk in (2, 4) and combined.shape[0] != 8:
+            world, nkc, rows = 8 // self.nk, self.nk // 2, self.nk // 2 + 4
+            parts = combined.reshape(world, rows, self.n)
+            full = np.zeros((8, self.n), np.uint64)
+            for k in range(0, 8, 2):
+                full[k] = parts[(k // 2) // nkc, (k // 2) % nkc]
+            for k in range(1, 8, 2):
+                acc = np.zeros(self.n, np.uint64)
+                for r in range(world):
+                    acc = O.fp_add(acc, parts[r, nkc + k // 2])
+                full[k] = acc
+            combined = full
         nq, blowup, grinding, hash_fn, ext, folding, max_rem = self.options
         H, coin, log_n, n = self.H, self.coin, self.log_n, self.n
         log_b, b, W, ce = 3, 8, self.job.width, self.job.ce
