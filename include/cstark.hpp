@@ -210,6 +210,18 @@ class RangeProofExample {
     BaseElement number_;
     Context &ctx_;
 };
+// The loop of benches/range.rs:15-37 in one call: one 64-row range proof per number (cstark_range_prove_batch), each byte-identical to
+// RangeProofExample(options, number, ctx).prove()
+inline std::vector<std::vector<uint8_t>> prove_range_batch(const ProofOptions &options, const std::vector<BaseElement> &numbers, Context &ctx) {
+    const cstark_options o = options.raw();
+    const size_t stride = cstark_tx_proof_size_bound(1, &o);
+    std::vector<uint8_t> buf(stride * numbers.size());
+    std::vector<size_t> lens(numbers.size());
+    check(cstark_range_prove_batch(ctx.raw(), &o, numbers.data(), (uint32_t)numbers.size(), buf.data(), stride, lens.data()));
+    std::vector<std::vector<uint8_t>> out(numbers.size());
+    for (size_t t = 0; t < numbers.size(); t++) out[t].assign(buf.begin() + t * stride, buf.begin() + t * stride + lens[t]);
+    return out;
+}
 // schnorr::SchnorrExample (src/schnorr/mod.rs:52-186)
 class SchnorrExample {
   public:
