@@ -154,8 +154,8 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_prove_sharded_with_real_backends_in_separate_processes(tmp_path, world):
+@pytest.mark.parametrize("world,split", [(2, "1"), (4, "1"), (2, "0")])
+def test_prove_sharded_with_real_backends_in_separate_processes(tmp_path, world, split):
     """sharding.prove_sharded -- the driver the ranks run over RCCL -- with the real Backend in `world` separate processes
     (one process per rank, as on a multi-GPU node) on the ONE GPU of this box: uint8 all-gather of the digests, int64 all-gather of
     the merged evaluations, int32 broadcast of the positions, int64 reduce of the opened rows, rank-0-only compose, at the headline
@@ -168,7 +168,9 @@ def test_prove_sharded_with_real_backends_in_separate_processes(tmp_path, world)
     port = 29500 + (os.getpid() * 13 + world) % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
-    got = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    # split = "0": the ranks evaluate every point of their cosets directly (CSTARK_SHARD_SPLIT=0, round 2's form) instead of their share of
+    # the degree-split evaluation
+    got = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="2", CSTARK_SHARD_SPLIT=split))
     assert got.returncode == 0, got.stdout[-2000:] + got.stderr[-4000:]
     line = [l for l in got.stdout.splitlines() if l.startswith("PROOF")][-1].split()
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proof_1024tx_d15_q96.json")))
