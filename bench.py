@@ -357,6 +357,9 @@ def main():
         return ev
 
     def collect_parts():
+        if coset_mode:  # the ranks' shares of the split evaluation are not timed part by part
+            prover.backend.synchronize()
+            return
         for k, v in prover.backend.constraint_part_ms().items():
             part_ms[k] += v
 
@@ -478,14 +481,14 @@ def main():
                                 ["k_rounds_split<1>"] if split else ["k_eval_fused<0, 1>"],
                                 "longest single launch; bound by vector-instruction issue: 22.9 k instructions per point at 4.5 cycles each "
                                 "(profiles/*_valu_pmc.csv, *_valu_issue_bench.txt)")
-        roofline_stages = [roofline_lde, roofline_rounds]
+        roofline_stages = [roofline_lde] + ([] if coset_mode else [roofline_rounds])
         if args.mode == "prove":
             roofline_stages.append(entry("row hashes + Merkle tree of the trace commitment (k_hash_rows + k_merkle_level/top)", ab["hash_rows"] + ab["merkle"],
                                          stage_ms["commit"], ["k_hash_rows", "k_merkle_level2", "k_merkle_level", "k_merkle_top"],
                                          "the one HBM-shaped stage; k_hash_rows moves exactly its algorithmic bytes; `traffic` is per kernel NAME and so also "
                                          "holds the small FRI-layer hashes and the composition / layer trees of a proof (about +0.5 GB)"))
             roofline_stages.append(entry("constraint evaluation stage (all launches)", ab["constraints"], stage_ms["constraints"],
-                                         ["k_rounds_split<", "k_rounds_setup", "k_ec_split<", "k_final_split<", "k_final_hi<", "k_lin_split<", "k_lin_all<",
+                                         ["k_rounds_split<", "k_rounds_setup", "k_ec_split<", "k_final_split<", "k_final_hi<", "k_lin_split<", "k_lin_all",
                                           "k_coset_even_to_odd", "k_split_finish<"] if split else ["k_eval_fused<", "k_rounds_setup"],
                                          "`traffic` = the stage's own kernels; the interpolation and extension of its split polynomials run through the "
                                          "transform kernels and are counted in the first entry (about 4 GB)" if split else None))
@@ -517,7 +520,7 @@ def main():
                            "'interpolate' = registers 65..93 and 37..64 interpolated AND extended while the recurrences / curve ladders still run, "
                            "then registers 0..36 interpolated, 'lde' = their extension; the three add up to the time to the complete extended trace "
                            "(include/cstark.h, cstark_prove_stage_ms)") if prove_mode else None,
-            "constraint_part_ms": {k: round(v, 3) for k, v in part_avg.items()},
+            "constraint_part_ms": None if coset_mode else {k: round(v, 3) for k, v in part_avg.items()},
             "constraint_part_note": ("all parts run on the even cosets only (split evaluation; final_add also on LDE coset 1); lin_c includes the "
                                      "extension of the 11 + 2 split polynomials to the odd cosets and the recombination over all cosets") if split else None,
             "roofline": roofline_lde,

@@ -885,7 +885,6 @@ int tx_evaluate_constraints_shard(cstark_ctx *c, const uint64_t *d_lde, const ui
     // register 37 on all eight cosets first: the extension uses the workspace itself
     uint64_t *bit37 = nullptr;
     {
-        cs::ProveArena *unused = nullptr; (void)unused;
         if (!c->shard_bit37 || c->shard_bit37_words < 8 * n) {
             if (c->shard_bit37) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->shard_bit37)); c->shard_bit37 = nullptr; }
             HIP_TRY(hipMalloc((void **)&c->shard_bit37, 8 * n * 8));
