@@ -409,10 +409,16 @@ class Backend:
                                options.field_extension, options.fri_folding_factor, options.fri_max_remainder)
         self.lib.cstark_tx_proof_size_bound.restype = C.c_size_t
         cap = self.lib.cstark_tx_proof_size_bound(C.c_uint32(self.n_tx), C.byref(o))
-        buf = (C.c_uint8 * cap)()
+        buf = self._proof_buffer(cap)
         n = C.c_size_t(0)
         check(self.lib.cstark_tx_prove(self.ctx, C.byref(o), buf, C.c_size_t(cap), C.byref(n)))
         return bytes(memoryview(buf)[:n.value])
+
+    def _proof_buffer(self, cap):
+        """host buffer the library writes a proof into, kept across calls (a fresh ctypes array is zero-filled: 1 MB per proof)"""
+        if getattr(self, "_pbuf_cap", 0) < cap:
+            self._pbuf, self._pbuf_cap = (C.c_uint8 * cap)(), cap
+        return self._pbuf
 
     # ---- one proof across several GPUs by LDE coset: the phases of cstark_tx_shard_* (driver: sharding.prove_sharded) -------------
     def _options_struct(self, options):

@@ -69,4 +69,68 @@ static inline void hash(const uint8_t *p, size_t len, uint8_t out[32]) {
     for (int i = 0; i < 8; i++) for (int b = 0; b < 4; b++) out[4 * i + b] = (uint8_t)(cv[i] >> (8 * b));
 }
 
+
+// Eight public-coin candidates at once: the first 8 bytes (little-endian) of BLAKE3(seed || counter_le64) for counter = c0 .. c0 + 7.
+// A draw of the coin rejects values >= p, i.e. three out of four candidates (p / 2^64 = 0.256), so the 238 composition coefficients
+// of a TransactionAir proof are ~930 hashes on the critical path between two launches; the candidates of consecutive counters are
+// independent, so eight of them go through one pass of the compression function on 8-lane vectors (AVX2 when the CPU has it, checked
+// at run time; plain loop otherwise).
+typedef uint32_t v8u __attribute__((vector_size(32)));
+#if defined(__x86_64__)
+#define CS_B3X8_TARGET __attribute__((target("avx2")))
+#else
+#define CS_B3X8_TARGET
+#endif
+CS_B3X8_TARGET static inline v8u rotr8(v8u x, int r) { return (x >> r) | (x << (32 - r)); }
+#define CS_B3X8_G(a, b, c, d, mx, my)            \
+    a = a + b + (mx); d = rotr8(d ^ a, 16);       \
+    c = c + d;        b = rotr8(b ^ c, 12);       \
+    a = a + b + (my); d = rotr8(d ^ a, 8);        \
+    c = c + d;        b = rotr8(b ^ c, 7);
+#define CS_B3X8_ROUND(i0, i1, i2, i3, i4, i5, i6, i7, i8, i9, i10, i11, i12, i13, i14, i15)            \
+    CS_B3X8_G(s0, s4, s8, s12, m[i0], m[i1]) CS_B3X8_G(s1, s5, s9, s13, m[i2], m[i3])                  \
+    CS_B3X8_G(s2, s6, s10, s14, m[i4], m[i5]) CS_B3X8_G(s3, s7, s11, s15, m[i6], m[i7])                \
+    CS_B3X8_G(s0, s5, s10, s15, m[i8], m[i9]) CS_B3X8_G(s1, s6, s11, s12, m[i10], m[i11])              \
+    CS_B3X8_G(s2, s7, s8, s13, m[i12], m[i13]) CS_B3X8_G(s3, s4, s9, s14, m[i14], m[i15])
+CS_B3X8_TARGET static inline void coin_candidates_x8_simd(const uint8_t seed[32], uint64_t c0, uint64_t out[8]) {
+    v8u m[16];
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = (uint32_t)seed[4 * i] | (uint32_t)seed[4 * i + 1] << 8 | (uint32_t)seed[4 * i + 2] << 16 | (uint32_t)seed[4 * i + 3] << 24;
+        m[i] = (v8u){w, w, w, w, w, w, w, w};
+    }
+    for (int l = 0; l < 8; l++) { m[8][l] = (uint32_t)(c0 + l); m[9][l] = (uint32_t)((c0 + l) >> 32); }
+    for (int i = 10; i < 16; i++) m[i] = (v8u){0, 0, 0, 0, 0, 0, 0, 0};
+#define CS_SPLAT(x) ((v8u){x, x, x, x, x, x, x, x})
+    v8u s0 = CS_SPLAT(IV[0]), s1 = CS_SPLAT(IV[1]), s2 = CS_SPLAT(IV[2]), s3 = CS_SPLAT(IV[3]), s4 = CS_SPLAT(IV[4]), s5 = CS_SPLAT(IV[5]),
+        s6 = CS_SPLAT(IV[6]), s7 = CS_SPLAT(IV[7]), s8 = CS_SPLAT(IV[0]), s9 = CS_SPLAT(IV[1]), s10 = CS_SPLAT(IV[2]), s11 = CS_SPLAT(IV[3]),
+        s12 = CS_SPLAT(0u), s13 = CS_SPLAT(0u), s14 = CS_SPLAT(40u), s15 = CS_SPLAT((uint32_t)(CHUNK_START | CHUNK_END | ROOT));
+#undef CS_SPLAT
+    CS_B3X8_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    CS_B3X8_ROUND(2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8)
+    CS_B3X8_ROUND(3, 4, 10, 12, 13, 2, 7, 14, 6, 5, 9, 0, 11, 15, 8, 1)
+    CS_B3X8_ROUND(10, 7, 12, 9, 14, 3, 13, 15, 4, 0, 11, 2, 5, 8, 1, 6)
+    CS_B3X8_ROUND(12, 13, 9, 11, 15, 10, 14, 8, 7, 2, 5, 3, 0, 1, 6, 4)
+    CS_B3X8_ROUND(9, 14, 11, 5, 8, 12, 15, 1, 13, 3, 0, 10, 2, 6, 4, 7)
+    CS_B3X8_ROUND(11, 15, 5, 0, 1, 9, 8, 6, 14, 10, 2, 12, 3, 4, 7, 13)
+    const v8u o0 = s0 ^ s8, o1 = s1 ^ s9;
+    for (int l = 0; l < 8; l++) out[l] = (uint64_t)o0[l] | (uint64_t)o1[l] << 32;
+}
+#undef CS_B3X8_ROUND
+#undef CS_B3X8_G
+static inline void coin_candidates_x8(const uint8_t seed[32], uint64_t c0, uint64_t out[8]) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { coin_candidates_x8_simd(seed, c0, out); return; }
+#endif
+    for (int l = 0; l < 8; l++) {
+        uint8_t buf[40], dg[32];
+        memcpy(buf, seed, 32);
+        for (int i = 0; i < 8; i++) buf[32 + i] = (uint8_t)((c0 + l) >> (8 * i));
+        hash(buf, 40, dg);
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)dg[i] << (8 * i);
+        out[l] = v;
+    }
+}
+
 }} // namespace cs::hostb3

@@ -100,6 +100,22 @@ struct Coin {
             if (!CSTARK_CONV_COIN_REJECT_ABOVE_P || v < host::P) return host::from_u64(v); // from_u64 reduces
         }
     }
+    // the next `count` draws, in order -- the same values and the same final counter as `count` calls of draw().  Blake3 coin: the
+    // candidates of eight consecutive counters per pass of the vectorised compression (hostblake3.h); candidates computed beyond the
+    // last accepted one are simply not consumed.
+    void draw_many(size_t count, uint64_t *out) {
+        static const bool scalar = [] { const char *e = getenv("CSTARK_COIN_SCALAR"); return e && atoi(e) != 0; }(); // tuning / debugging
+        if (hash_fn != 0 || scalar) { for (size_t i = 0; i < count; i++) out[i] = draw(); return; }
+        size_t got = 0;
+        while (got < count) {
+            uint64_t cand[8];
+            hostb3::coin_candidates_x8(seed, counter + 1, cand);
+            for (int l = 0; l < 8 && got < count; l++) {
+                counter++;
+                if (!CSTARK_CONV_COIN_REJECT_ABOVE_P || cand[l] < host::P) out[got++] = host::from_u64(cand[l]);
+            }
+        }
+    }
     void draw_integers(size_t count, uint64_t domain, std::vector<uint32_t> &out) {
         out.clear();
         while (out.size() < count) {
@@ -447,8 +463,12 @@ int phase_evaluate(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint8_t *d_l
     coin.reseed(R.trace_root);
     const size_t nc = job.n_constraints, na = job.n_assertions;
     R.ta.resize(nc); R.tb.resize(nc); R.ba.resize(na); R.bb.resize(na);
-    for (size_t i = 0; i < nc; i++) { R.ta[i] = coin.draw(); R.tb[i] = coin.draw(); }
-    for (size_t i = 0; i < na; i++) { R.ba[i] = coin.draw(); R.bb[i] = coin.draw(); }
+    {   // (alpha, beta) per transition constraint, then per assertion: 2 (nc + na) draws in the coin's order
+        std::vector<uint64_t> dr(2 * (nc + na));
+        coin.draw_many(dr.size(), dr.data());
+        for (size_t i = 0; i < nc; i++) { R.ta[i] = dr[2 * i]; R.tb[i] = dr[2 * i + 1]; }
+        for (size_t i = 0; i < na; i++) { R.ba[i] = dr[2 * nc + 2 * i]; R.bb[i] = dr[2 * nc + 2 * i + 1]; }
+    }
     const auto hp1 = std::chrono::steady_clock::now();
     RC_TRY(job.combine(c, a, job, R.ta.data(), R.tb.data(), R.ba.data(), R.bb.data(), d_out));
     if (hostprof) {
@@ -502,12 +522,16 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
 
     // ---- DEEP composition -------------------------------------------------------------------------------------------------
     std::vector<uint64_t> d_alpha(W), d_beta(W), d_delta(ce);
-    for (size_t i = 0; i < W; i++) { // alpha (point z), beta (point z w), then the draws only extension fields use (conjugate term)
-        d_alpha[i] = coin.draw(); d_beta[i] = coin.draw();
-        for (int k = 2; k < CSTARK_CONV_DEEP_DRAWS_PER_REGISTER; k++) (void)coin.draw();
+    uint64_t deg_a, deg_b;
+    {   // per register: alpha (point z), beta (point z w), then the draws only extension fields use (conjugate term); one per composition
+        // column; two for the degree adjustment -- drawn in this order
+        constexpr size_t PER = CSTARK_CONV_DEEP_DRAWS_PER_REGISTER;
+        std::vector<uint64_t> dr(PER * W + ce + 2);
+        coin.draw_many(dr.size(), dr.data());
+        for (size_t i = 0; i < W; i++) { d_alpha[i] = dr[PER * i]; d_beta[i] = dr[PER * i + 1]; }
+        for (size_t i = 0; i < ce; i++) d_delta[i] = dr[PER * W + i];
+        deg_a = dr[PER * W + ce]; deg_b = dr[PER * W + ce + 1];
     }
-    for (size_t i = 0; i < ce; i++) d_delta[i] = coin.draw();
-    const uint64_t deg_a = coin.draw(), deg_b = coin.draw();
     // The DEEP composition polynomial has degree < n (quotients of degree n - 2 times the linear degree adjustment): its values on
     // ONE coset determine it.  Evaluate the quotient sums on coset 0 only (1/8 of the extended trace read), interpolate there (the
     // coefficients of P(g y)) and extend to all cosets with offset 1 -- the same values as evaluating the sums at every point.

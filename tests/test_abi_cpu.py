@@ -140,3 +140,13 @@ def test_host_schnorr_witness_generator_matches_oracle(oracle):
                                                s.ctypes.data_as(u8p)) == 0
     w = oracle.SchnorrWitness.generate(n, seed=99)
     assert np.array_equal(msg, w.messages) and np.array_equal(rx, w.sig_rx) and np.array_equal(s, w.sig_s)
+
+
+def test_vectorised_coin_candidates_equal_the_scalar_hash(tmp_path):
+    """hostblake3.h::coin_candidates_x8 (eight BLAKE3(seed || counter) per pass on 8-lane vectors; the prover draws its coefficients
+    through it) against the scalar implementation: compiled with g++ from the product's header, host code only."""
+    import subprocess
+    exe = str(tmp_path / "host_coin_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_coin_check.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
