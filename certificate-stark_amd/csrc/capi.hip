@@ -731,20 +731,12 @@ int tx_build_trace_split(cstark_ctx *c, uint64_t *d_trace) {
     return CSTARK_OK;
 }
 // m coefficient sets over the same frame (the components of an extension-field proof): the constraint values are computed once.
-// (internal: declared in ctx.h for the prover)
-int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
-                                 uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
-                                 bool input_is_lde) {
-    if (!coeffs || !pub_inputs || !d_outs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null argument");
-    if (m < 1 || m > (uint32_t)cs::CE_MAX_SETS) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: 1..3 coefficient sets");
-    for (uint32_t q = 1; q < m; q++)
-        if (!d_outs[q]) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null output");
-    cs::CeParams p;
-    RC_TRY(ce_params(c, d_lde, d_outs[0], merkle_depth, log_n, log_blowup, k0, nk, &p));
+// The m coefficient sets of a proof into the context's device block (coefficients, then the per-proof tables of the Rescue windows):
+// the caller's struct may be transient, so it is copied into a pinned staging block and uploaded from there without waiting.
+static int upload_coeffs(cstark_ctx *c, const cstark_tx_coeffs *coeffs, uint32_t m, cs::CeParams &p) {
     static_assert(sizeof(cstark_tx_coeffs) == cs::CE_COEF_WORDS * 8, "coefficient block layout");
     constexpr size_t COEF_WORDS = (size_t)cs::CE_MAX_SETS * cs::CE_COEF_WORDS;
     if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, (COEF_WORDS + (size_t)cs::CE_MAX_SETS * cs::CE_RTAB_WORDS) * 8));
-    // the caller's struct may be transient: copy it into the context's pinned staging block and upload from there without waiting
     if (!c->coef_stage) { // the event first: the staging block is only published once both exist
         if (!c->coef_ev) HIP_TRY(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc(&c->coef_stage, (size_t)cs::CE_MAX_SETS * sizeof(cstark_tx_coeffs), hipHostMallocDefault));
@@ -757,6 +749,20 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
     p.coef = c->coef_buf;
     p.rtab = c->coef_buf + COEF_WORDS;
     p.m = m;
+    return CSTARK_OK;
+}
+
+// (internal: declared in ctx.h for the prover)
+int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
+                                 uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
+                                 bool input_is_lde) {
+    if (!coeffs || !pub_inputs || !d_outs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null argument");
+    if (m < 1 || m > (uint32_t)cs::CE_MAX_SETS) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: 1..3 coefficient sets");
+    for (uint32_t q = 1; q < m; q++)
+        if (!d_outs[q]) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null output");
+    cs::CeParams p;
+    RC_TRY(ce_params(c, d_lde, d_outs[0], merkle_depth, log_n, log_blowup, k0, nk, &p));
+    RC_TRY(upload_coeffs(c, coeffs, m, p));
     for (uint32_t q = 1; q < m; q++) p.out_ext[q - 1] = d_outs[q];
     for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
     static const bool split_env = [] { const char *e = getenv("CSTARK_ROUNDS_SPLIT"); return !e || atoi(e) != 0; }(); // tuning / debugging
@@ -858,18 +864,7 @@ int tx_evaluate_constraints_shard(cstark_ctx *c, const uint64_t *d_lde, const ui
     if (log_n + 3 > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "trace too long for the split evaluation");
     cs::CeParams p;
     RC_TRY(ce_params(c, d_lde, d_out, merkle_depth, log_n, 3, k0, nk, &p));
-    constexpr size_t COEF_WORDS = (size_t)cs::CE_MAX_SETS * cs::CE_COEF_WORDS;
-    if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, (COEF_WORDS + (size_t)cs::CE_MAX_SETS * cs::CE_RTAB_WORDS) * 8));
-    if (!c->coef_stage) {
-        if (!c->coef_ev) HIP_TRY(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
-        HIP_TRY(hipHostMalloc(&c->coef_stage, (size_t)cs::CE_MAX_SETS * sizeof(cstark_tx_coeffs), hipHostMallocDefault));
-    } else {
-        HIP_TRY(hipEventSynchronize(c->coef_ev));
-    }
-    memcpy(c->coef_stage, coeffs, sizeof(cstark_tx_coeffs));
-    HIP_TRY(hipMemcpyAsync(c->coef_buf, c->coef_stage, sizeof(cstark_tx_coeffs), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->coef_ev, c->stream));
-    p.coef = c->coef_buf; p.rtab = c->coef_buf + COEF_WORDS; p.m = 1;
+    RC_TRY(upload_coeffs(c, coeffs, 1, p));
     for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
     p.nkc = nk / 2;
     const unsigned kc0 = k0 / 2, nkc = nk / 2;
