@@ -250,3 +250,14 @@ def test_batched_range_prover_at_baseline_size_and_its_errors(oracle, backend):
         backend.range_prove_batch(options(), np.array([1, oracle.P], np.uint64))            # raw M is not an element (src/range/tests.rs:54-62)
     with pytest.raises(CstarkError):
         backend.range_prove_batch(ProofOptions(42, 8, 0, 0, 1, 4, 256), numbers[:2])        # extension fields: cstark_air_prove
+    # a slot too small for a proof is refused (the required size is what cstark_tx_proof_size_bound(1, opt) returns)
+    import ctypes as C
+    from certificate_stark_amd import _lib
+    o = backend._options_struct(options())
+    nums = np.ascontiguousarray(numbers[:2])
+    buf, lens = np.zeros(2 * 1000, np.uint8), np.zeros(2, np.uint64)
+    rc = backend.lib.cstark_range_prove_batch(backend.ctx, C.byref(o), nums.ctypes.data_as(_lib.u64p), C.c_uint32(2), buf.ctypes.data_as(_lib.u8p),
+                                              C.c_size_t(1000), lens.ctypes.data_as(C.POINTER(C.c_size_t)))
+    assert rc == -1 and not buf.any()
+    assert backend.lib.cstark_range_prove_batch(backend.ctx, C.byref(o), nums.ctypes.data_as(_lib.u64p), C.c_uint32(0), buf.ctypes.data_as(_lib.u8p),
+                                                C.c_size_t(1000), lens.ctypes.data_as(C.POINTER(C.c_size_t))) == -1
