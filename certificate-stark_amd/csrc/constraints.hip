@@ -1614,6 +1614,9 @@ __device__ __forceinline__ void lin_all_split(const CS_CONST fp *coefs, const Fr
 #ifdef CS_LIN_ALL_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0); // keep the next iteration's loads out of this one (the scheduler otherwise hoists them all)
 #endif
+#ifdef CS_LIN_ALL_MEM_BARRIER
+            asm volatile("" ::: "memory"); // compiler-level: no load of a later iteration is moved above this point
+#endif
         }
         sa.flush<G0 | G1 | G2>(hash_copy, tot);
         sb.flush<G0 | G1 | G2>(hash_init, tot);

@@ -35,6 +35,16 @@ int main(int argc, char **argv) {
             cstark::TransactionProver(options, ctx).prove(m);
         } catch (const cstark::Error &) { length_checked = true; }
         const auto ms = ctx.prove_stage_ms(); // of the last successful proof on this context
+        // the range-proof loop of benches/range.rs in one call: every proof equals the single-proof path's bytes
+        bool batch_ok = true;
+        {
+            cstark::Context rctx;
+            const std::vector<cstark::BaseElement> numbers = {cstark_field_root_of_unity(1), cstark_field_generator(), cstark_field_root_of_unity(5)};
+            const auto proofs = cstark::prove_range_batch(options, numbers, rctx);
+            for (size_t t = 0; t < numbers.size(); t++) batch_ok = batch_ok && proofs[t] == cstark::RangeProofExample(options, numbers[t], rctx).prove();
+            dump(prefix + ".range", proofs[1].data(), proofs[1].size());
+        }
+        if (!batch_ok) { std::fprintf(stderr, "batched range proofs differ from the single proofs\n"); return 4; }
         std::printf("proof_bytes=%zu refused=%d length_checked=%d trace_ms=%.3f\n", proof.size(), (int)refused, (int)length_checked, ms[0]);
         return refused && length_checked ? 0 : 1;
     } catch (const std::exception &e) {
