@@ -258,8 +258,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-tx", type=int, default=1024, help="transactions per proof (1024 = BASELINE's 2^20 rows)")
     ap.add_argument("--cpu-sample-tx", type=int, default=1024,
                     help="transactions the CPU baseline proves (default: the whole 1024-transaction witness, no extrapolation; about 25 s on the GPU "
