@@ -301,6 +301,16 @@ class Backend:
         return out
 
     # ---- standalone SchnorrAir ----
+    def schnorr_evaluate_constraints_lde(self, lde, aux_lde, t_alpha, t_beta, b_alpha, b_beta, avals_lde, n_sig=2):
+        """cstark_schnorr_evaluate_constraints_lde: all 8 cosets of genuine extensions -> the degree-split evaluation of the curve gadgets"""
+        nk, width, n = lde.shape
+        assert nk == 8 and width == 56
+        out = self.empty_u64(8, n)
+        arrs = [_np_u64(a) for a in (t_alpha, t_beta, b_alpha, b_beta)]
+        check(self.lib.cstark_schnorr_evaluate_constraints_lde(self.ctx, C.c_uint32(n_sig), self._ptr(lde), self._ptr(aux_lde), *[a.ctypes.data_as(u64p) for a in arrs],
+                                                               self._ptr(avals_lde), C.c_uint32(avals_lde.shape[1]), self._ptr(out), C.c_uint32(n.bit_length() - 1)))
+        return out
+
     def upload_schnorr_witness(self, messages, sig_rx, sig_s):
         m, rx = _np_u64(messages), _np_u64(sig_rx)
         s = np.ascontiguousarray(sig_s, np.uint8)

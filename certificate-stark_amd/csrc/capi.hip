@@ -1185,7 +1185,7 @@ int cstark_schnorr_assertion_polys(cstark_ctx *c, uint64_t *d_out, uint32_t log_
 static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha,
                             const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values,
                             const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
-                            const uint64_t *d_schnorr_aux_lde, int merkle_depth_fused = -1) {
+                            const uint64_t *d_schnorr_aux_lde, int merkle_depth_fused = -1, bool schnorr_input_is_lde = false) {
     const bool fused_merkle = merkle_depth_fused >= 0;
     if (!c || !d_lde || (!d_evals && !d_schnorr_aux_lde && !fused_merkle) || !t_alpha || !t_beta || !b_alpha || !b_beta || !d_out || nk == 0)
         return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: null argument");
@@ -1232,7 +1232,13 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
         }
         a_grp[a] = g;
     }
-    std::vector<uint64_t> blk(2 * nc + 3 * na + b + 2 * na + (nc + 1) / 2 + 1);
+    constexpr size_t TXL = 230; // SchnorrAir split evaluation: the transition coefficients once more, laid out alpha[i] | beta[115 + i]
+    std::vector<uint64_t> blk(2 * nc + 3 * na + b + 2 * na + (nc + 1) / 2 + 1 + TXL);
+    const size_t txl_off = blk.size() - TXL;
+    if (nc <= 115) {
+        memcpy(blk.data() + txl_off, t_alpha, nc * 8);
+        memcpy(blk.data() + txl_off + 115, t_beta, nc * 8);
+    }
     uint64_t *q = blk.data();
     memcpy(q, t_alpha, nc * 8); q += nc;
     memcpy(q, t_beta, nc * 8); q += nc;
@@ -1281,7 +1287,39 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
     if (d_schnorr_aux_lde) {
         const PeriodicTable *pt;
         RC_TRY(schnorr_periodic(c, log_n, log_blowup, &pt));
-        HIP_TRY(cs::launch_schnorr_fused(p, d_schnorr_aux_lde, pt->tab, nk, c->stream));
+        // The doubling / addition gadgets in the degree-split form of the TransactionAir evaluator when the whole extension is at hand
+        // (every coset, blowup 8, at least eight signatures): their sums have degree < 4n without the periodic flags, so they are
+        // evaluated on the four even cosets, interpolated, extended to the odd cosets and recombined (constraints.hip,
+        // k_schnorr_ec_split).  The table must be a genuine extension -- it is the prover's own; the stage entry point passes any table,
+        // so it takes this path only under CSTARK_SCHNORR_SPLIT_STAGE=1 (tests).  CSTARK_SCHNORR_SPLIT=0: every point directly.
+        static const bool split_env = [] { const char *e = getenv("CSTARK_SCHNORR_SPLIT"); return !e || atoi(e) != 0; }();
+        if (split_env && schnorr_input_is_lde && k0 == 0 && nk == 8 && log_blowup == 3 && log_n >= 12 && log_n + 3 <= cs::NTT_MAX_LOG_N && n_items > 1) {
+            constexpr unsigned T = cs::SCHNORR_SPLIT_TABLES;
+            const NttPlan *pn, *p4, *p8;
+            const CosetTable *t1;
+            RC_TRY(get_plan(c, log_n, &pn));
+            RC_TRY(get_plan(c, log_n + 2, &p4));
+            RC_TRY(get_plan(c, log_n + 3, &p8));
+            RC_TRY(get_coset_table(c, log_n, 3, cs::host::from_u64(1), &t1));
+            const size_t region = (size_t)T * 4 * n;
+            RC_TRY(ensure_ws(c, 5 * region * 8));
+            uint64_t *even = (uint64_t *)c->ws, *sa = even + region, *sb = sa + region, *sc = sb + region, *odd = sc + region;
+            HIP_TRY(cs::launch_schnorr_ec_split(p, d_schnorr_aux_lde, d + txl_off, even, c->stream));
+            cs::NttArgs a{};
+            a.in = even; a.scratch = sa; a.out = sb; a.width = 4 * T; a.batch = 1; a.log_n = log_n;
+            a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true; a.aux = pn->aux_winv;
+            HIP_TRY(cs::ntt_columns(a, c->stream));
+            HIP_TRY(cs::coset_even_to_odd(sb, sa, log_n, T, p4->winv, p8->w, cs::host::inv(cs::host::from_u64(4)), c->stream));
+            cs::NttArgs f{};
+            f.in = sa; f.scratch = sc; f.out = odd; f.width = T; f.batch = 4; f.log_n = log_n;
+            f.w = pn->w; f.prescale = t1->s + n; f.prescale_batch_stride = 2 * n; f.do_scale = false; f.inverse = false;
+            f.aux = pn->aux_w; f.aux_ps = t1->aux ? t1->aux + t1->aux_words : nullptr; f.aux_ps_batch_stride = 2 * t1->aux_words;
+            f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
+            HIP_TRY(cs::ntt_columns(f, c->stream));
+            HIP_TRY(cs::launch_schnorr_split_finish(p, d_schnorr_aux_lde, pt->tab, even, odd, t_grp[0], t_grp[6], c->stream));
+        } else {
+            HIP_TRY(cs::launch_schnorr_fused(p, d_schnorr_aux_lde, pt->tab, nk, c->stream));
+        }
         p.tsum = d_out;
     }
     if (fused_merkle) {
@@ -1313,6 +1351,14 @@ int cstark_schnorr_evaluate_constraints(cstark_ctx *c, uint32_t n_sig, const uin
     if (!d_aux_lde) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_evaluate_constraints: null argument");
     return air_combine_impl(c, CSTARK_AIR_SCHNORR, n_sig, d_lde, nullptr, t_alpha, t_beta, b_alpha, b_beta, nullptr, d_avals_lde, n_avals, d_out, log_n,
                             log_blowup, k0, nk, d_aux_lde);
+}
+
+int cstark_schnorr_evaluate_constraints_lde(cstark_ctx *c, uint32_t n_sig, const uint64_t *d_lde, const uint64_t *d_aux_lde, const uint64_t *t_alpha,
+                                            const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *d_avals_lde,
+                                            uint32_t n_avals, uint64_t *d_out, uint32_t log_n) {
+    if (!d_aux_lde) return fail(CSTARK_ERR_INVALID_ARG, "cstark_schnorr_evaluate_constraints_lde: null argument");
+    return air_combine_impl(c, CSTARK_AIR_SCHNORR, n_sig, d_lde, nullptr, t_alpha, t_beta, b_alpha, b_beta, nullptr, d_avals_lde, n_avals, d_out, log_n, 3, 0,
+                            8, d_aux_lde, -1, true);
 }
 
 // per-launch timing of the fused constraint evaluation (HIP events on the context's stream)

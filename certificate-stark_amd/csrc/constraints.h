@@ -70,6 +70,13 @@ hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *
 // MerkleAir likewise (one launch; ptab as for launch_eval_transitions_merkle)
 hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream);
 hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, unsigned nk, hipStream_t stream);
+// SchnorrAir's doubling / addition gadgets in the degree-split form (all cosets, k0 = 0; constraints.hip): eight polynomials on the even
+// cosets, d_even = [8][4][n] (d_coefs_tx_layout: alpha[i] at word i, beta[i] at word 115 + i, device); after their extension to the odd
+// cosets (d_odd = [4][8][n]) the recombination into p.out, to which the final addition and the remaining constraints are then added
+constexpr int SCHNORR_SPLIT_TABLES = 8;
+hipError_t launch_schnorr_ec_split(const AirCombineParams &p, const uint64_t *aux, const uint64_t *d_coefs_tx_layout, uint64_t *d_even, hipStream_t stream);
+hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, const uint64_t *d_even, const uint64_t *d_odd,
+                                       unsigned g0, unsigned g1, hipStream_t stream);
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream);
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);

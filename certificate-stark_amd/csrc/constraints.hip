@@ -1939,7 +1939,10 @@ struct AirSum {
     __device__ __forceinline__ void add(int i, fp flag, fp val) { total = fp_add(total, fp_mul(coef(i), fp_mul(flag, val))); } // AccAll's interface
 };
 enum { SF_DBL0 = 0, SF_ADD0, SF_DBL1, SF_ADD1, SF_FINAL, SF_REST, SF_PARTS };
-template <int PART>
+// AFTER_SPLIT: the four doubling / addition parts came from the degree-split form (k_schnorr_ec_split + k_schnorr_split_finish wrote the
+// output first): every part here adds to it, and SF_REST also carries the terms of the two bit registers (slots 18, 37) that the split
+// curve families leave out
+template <int PART, bool AFTER_SPLIT = false>
 __global__ __launch_bounds__(FNT, PART == SF_REST ? 2 : CS_EC_WAVES) void k_schnorr_fused(AirCombineParams p, const fp *__restrict__ aux,
                                                                                        const fp *__restrict__ ptab) {
     __shared__ fp xp_lds[AIR_MAX_GROUPS * FNT];
@@ -1982,9 +1985,95 @@ __global__ __launch_bounds__(FNT, PART == SF_REST ? 2 : CS_EC_WAVES) void k_schn
             acc.add(42 + i, copy_hash, fp_sub(f.cur(42 + i), f.next(42 + i)));
             acc.add(49 + i, copy_hash, fp_sub(f.next(49 + i), ax[(size_t)(12 + i) * n]));
         }
+        if (AFTER_SPLIT) { // the bit registers of the two ladders: binary under `doubling` (ecc.rs:96), copied under `addition` (ecc.rs:136)
+            const fp b18 = f.cur(18), b37 = f.cur(37);
+            acc.add(18, doubling, c_is_binary(b18));
+            acc.add(18, addition, fp_sub(b18, f.next(18)));
+            acc.add(37, doubling, c_is_binary(b37));
+            acc.add(37, addition, fp_sub(b37, f.next(37)));
+        }
     }
     fp *o = p.out + (size_t)kk * n + j;
-    *o = PART == SF_DBL0 ? acc.total : fp_add(*o, acc.total); // the launches follow each other on the stream
+    *o = (PART == SF_DBL0 && !AFTER_SPLIT) ? acc.total : fp_add(*o, acc.total); // the launches follow each other on the stream
+}
+
+// ---- SchnorrAir: the doubling / addition gadgets in the degree-split form of the TransactionAir evaluator ------------------------------
+// Same algebra as k_ec_split (the sums S of coefficient x term WITHOUT their periodic flag have degree < 4n: doubling quartic, addition of
+// the constant generator cubic, addition of the public key L - bit Q with Q quartic), on SchnorrAir's 56-register frame: the public key
+// is the periodic / public-input column pair of `aux` at the CURRENT row (src/schnorr/air.rs:228-290), the coefficients and degree
+// groups those of SchnorrAir (slots 0..5 and 19..36: first group, 6..17: second -- the same partition of the curve slots as in
+// TransactionAir, so SplitAcc applies with the coefficients laid out alpha[i] | beta[115 + i]).
+// Eight polynomials per proof on the even cosets, out = [8][4][n]: doubling alpha, beta_0, beta_1 | addition alpha, beta_0, beta_1 |
+// addition x bit alpha, beta_0.  PART: 1 = doubling of s*G (writes the doubling family), 3 = doubling of h*P (adds to it), 2 = addition of
+// G (writes the addition family), 4 = addition of P (adds its linear half to the addition family, writes the third family).
+constexpr int SCH_SPLIT_TABLES = 8;
+template <int PART>
+__global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_schnorr_ec_split(const fp *__restrict__ lde, const fp *__restrict__ aux, const fp *__restrict__ coefs_tx_layout,
+                                                                      fp *__restrict__ out, unsigned log_n) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kc = blockIdx.y, kk = 2 * kc;
+    const fp *base = lde + (size_t)kk * 56 * n;
+    Frame f;
+    f.n = n;
+    f.cur_p = base + j;
+    f.next_p = base + ((j + 1) & (n - 1));
+    f.per_p = nullptr; // no periodic value is read: the flags are applied by k_schnorr_split_finish
+    f.pcycle = 512;
+    SplitAcc<1> acc;
+    acc.coefs = as_const(coefs_tx_layout);
+    fp *fam = out + (size_t)(PART == PART_DBL0 || PART == PART_DBL1 ? 0 : 3) * 4 * n;
+    if (PART == PART_DBL0) fused_doubling(acc, f, 0, (fp)0);
+    if (PART == PART_DBL1) fused_doubling(acc, f, 19, (fp)0);
+    if (PART == PART_ADD0) fused_addition(acc, f, 0, const6(c_generator), const6(c_generator + 6), (fp)0);
+    if (PART == PART_ADD1) {
+        acc.begin(); // the linear half: next - cur of registers 19..36 (all in the first group)
+#pragma unroll
+        for (int i = 0; i < 18; i++) acc.term(19 + i, fp_sub(f.next(19 + i), f.cur(19 + i)));
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            fp *o = fam + ((size_t)q * 4 + kc) * n + j;
+            *o = fp_add(*o, acc.result(0, q));
+        }
+        const fp *ax = aux + (size_t)kk * 19 * n + j;
+        const Point pt = {load6(f, 19, false), load6(f, 25, false), load6(f, 31, false)};
+        const Point a = ec_add_mixed<CS_EC_CALL>(pt, fp6_load_strided(ax, n), fp6_load_strided(ax + 6 * n, n));
+        acc.begin();
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            acc.term(19 + i, fp_sub(a.x.c[i], pt.x.c[i]));
+            acc.term(25 + i, fp_sub(a.y.c[i], pt.y.c[i]));
+            acc.term(31 + i, fp_sub(a.z.c[i], pt.z.c[i]));
+        }
+        fam = out + (size_t)6 * 4 * n; // third family: alpha, beta_0
+    }
+    constexpr int NQ = PART == PART_ADD1 ? 2 : 3;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        fp *o = fam + ((size_t)q * 4 + kc) * n + j;
+        const fp v = acc.result(0, q);
+        *o = PART == PART_DBL1 ? fp_add(*o, v) : v;
+    }
+}
+// recombination over all cosets: out[k][j] = doubling(x) (D_a + x^adj_0 D_b0 + x^adj_1 D_b1) + addition(x) [(A_a + x^adj_0 A_b0 + x^adj_1 A_b1)
+// - bit37 (Q_a + x^adj_0 Q_b0)]; the remaining parts (final addition, hash / limb constraints, bit registers) ADD to it afterwards.
+// even = [8][4][n] (even cosets), odd = [4 odd cosets][8][n] (their extension); g0, g1 = degree groups of slots 0 and 6.
+__global__ __launch_bounds__(256) void k_schnorr_split_finish(AirCombineParams p, const fp *__restrict__ even, const fp *__restrict__ odd,
+                                                              const fp *__restrict__ ptab, unsigned g0, unsigned g1) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    const unsigned k = blockIdx.y; // all eight cosets present, k0 = 0
+    const fp x0 = fp_mul(p.tgrp_shift[k][g0], p.w[(j * p.tgrp_adj[g0]) & (n - 1)]), x1 = fp_mul(p.tgrp_shift[k][g1], p.w[(j * p.tgrp_adj[g1]) & (n - 1)]);
+    const fp *per = ptab + (size_t)k * 36 * 512 + (j & 511);
+    const fp scalar_mult = per[(size_t)1 * 512], doubling = per[(size_t)2 * 512];
+    const fp addition = fp_mul(c_not(doubling), scalar_mult);
+    const fp bit37 = p.lde[((size_t)k * 56 + 37) * n + j];
+    constexpr int T = SCH_SPLIT_TABLES;
+    auto value = [&](int t) { return (k & 1) ? odd[((size_t)(k >> 1) * T + t) * n + j] : even[((size_t)t * 4 + (k >> 1)) * n + j]; };
+    const fp dbl = fp_add(value(0), fp_add(fp_mul(value(1), x0), fp_mul(value(2), x1)));
+    const fp add = fp_add(value(3), fp_add(fp_mul(value(4), x0), fp_mul(value(5), x1)));
+    const fp addbit = fp_add(value(6), fp_mul(value(7), x0));
+    p.out[(size_t)k * n + j] = fp_add(fp_mul(doubling, dbl), fp_mul(addition, fp_sub(add, fp_mul(bit37, addbit))));
 }
 
 // MerkleAir, fused: the same body as k_eval_transitions_merkle behind the table-driven accumulator; one value per point of the
@@ -2107,6 +2196,29 @@ hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, 
     hipLaunchKernelGGL(k_schnorr_fused<SF_ADD1>, grid, block, 0, stream, p, aux, ptab);
     hipLaunchKernelGGL(k_schnorr_fused<SF_FINAL>, grid, block, 0, stream, p, aux, ptab);
     hipLaunchKernelGGL(k_schnorr_fused<SF_REST>, grid, block, 0, stream, p, aux, ptab);
+    return hipGetLastError();
+}
+// SchnorrAir's curve gadgets in the degree-split form (all eight cosets, k0 = 0).  1: launch_schnorr_ec_split -- the eight polynomials on
+// the even cosets, d_even = [8][4][n]; the caller interpolates them per coset, carries them to the odd cosets (ntt.h: coset_even_to_odd)
+// and extends them, d_odd = [4][8][n]; 2: launch_schnorr_split_finish -- recombination into p.out, then the remaining parts add to it.
+hipError_t launch_schnorr_ec_split(const AirCombineParams &p, const uint64_t *aux, const uint64_t *d_coefs_tx_layout, uint64_t *d_even, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    if (n % FNT) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(n / FNT), 4), block(FNT);
+    hipLaunchKernelGGL(k_schnorr_ec_split<PART_DBL0>, grid, block, 0, stream, p.lde, aux, d_coefs_tx_layout, d_even, p.log_n);
+    hipLaunchKernelGGL(k_schnorr_ec_split<PART_DBL1>, grid, block, 0, stream, p.lde, aux, d_coefs_tx_layout, d_even, p.log_n);
+    hipLaunchKernelGGL(k_schnorr_ec_split<PART_ADD0>, grid, block, 0, stream, p.lde, aux, d_coefs_tx_layout, d_even, p.log_n);
+    hipLaunchKernelGGL(k_schnorr_ec_split<PART_ADD1>, grid, block, 0, stream, p.lde, aux, d_coefs_tx_layout, d_even, p.log_n);
+    return hipGetLastError();
+}
+hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, const uint64_t *d_even, const uint64_t *d_odd,
+                                       unsigned g0, unsigned g1, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    if (n % FNT) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_schnorr_split_finish, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd, ptab, g0, g1);
+    const dim3 grid((unsigned)(n / FNT), 8), block(FNT);
+    hipLaunchKernelGGL((k_schnorr_fused<SF_FINAL, true>), grid, block, 0, stream, p, aux, ptab);
+    hipLaunchKernelGGL((k_schnorr_fused<SF_REST, true>), grid, block, 0, stream, p, aux, ptab);
     return hipGetLastError();
 }
 hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream) {

@@ -826,7 +826,7 @@ int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *t
         RC_TRY(cstark_lde_columns(c, av_co, av_lde, 12, job.log_n, 3, host::lde_offset(), 0, 8));
         job.evals_ready = true;
     }
-    if (fused) return cstark_schnorr_evaluate_constraints(c, job.item, a->lde, aux_lde, ta, tb, ba, bb, av_lde, 12, out, job.log_n, 3, 0, 8);
+    if (fused) return cstark_schnorr_evaluate_constraints_lde(c, job.item, a->lde, aux_lde, ta, tb, ba, bb, av_lde, 12, out, job.log_n); // own extensions: split form
     return cstark_air_combine(c, CSTARK_AIR_SCHNORR, job.item, a->lde, evals, ta, tb, ba, bb, nullptr, av_lde, 12, out, job.log_n, 3, 0, 8);
 }
 

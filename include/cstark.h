@@ -365,6 +365,13 @@ int cstark_schnorr_evaluate_constraints(cstark_ctx *ctx, uint32_t n_sig, const u
                                         const uint64_t *t_alpha, const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta,
                                         const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n,
                                         uint32_t log_blowup, uint32_t k0, uint32_t nk);
+/* The same result for tables that ARE low-degree extensions over all 8 cosets (d_lde: 56 columns of degree < n, d_aux_lde: the 19
+ * public-input columns; e.g. outputs of cstark_lde_columns): allows the degree-split evaluation of the doubling / addition gadgets that
+ * cstark_air_prove uses (on the even cosets only, their eight merged polynomials extended to the odd cosets).  On such tables
+ * the output equals cstark_schnorr_evaluate_constraints bit for bit; on any other table it is undefined. */
+int cstark_schnorr_evaluate_constraints_lde(cstark_ctx *ctx, uint32_t n_sig, const uint64_t *d_lde, const uint64_t *d_aux_lde,
+                                            const uint64_t *t_alpha, const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta,
+                                            const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n);
 
 /* ---- witness synthesis (host; counterpart of TransactionMetadata::build_random, src/lib.rs:235-465, and of
  * SchnorrExample::new + schnorr::sign, src/schnorr/mod.rs:86-141, :197-217; seeded and deterministic) -----------------

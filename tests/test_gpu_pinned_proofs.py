@@ -261,3 +261,29 @@ def test_batched_range_prover_at_baseline_size_and_its_errors(oracle, backend):
     assert rc == -1 and not buf.any()
     assert backend.lib.cstark_range_prove_batch(backend.ctx, C.byref(o), nums.ctypes.data_as(_lib.u64p), C.c_uint32(0), buf.ctypes.data_as(_lib.u8p),
                                                 C.c_size_t(1000), lens.ctypes.data_as(C.POINTER(C.c_size_t))) == -1
+
+
+@pytest.mark.parametrize("n_sig", [8, 64, 512])
+def test_schnorr_degree_split_equals_direct_evaluation(oracle, backend, n_sig):
+    """cstark_schnorr_evaluate_constraints_lde (the doubling / addition gadgets on the even cosets only, their eight merged polynomials
+    extended to the odd cosets: what cstark_air_prove uses) == cstark_schnorr_evaluate_constraints (every point directly) at every
+    point of the real extension; at 8 signatures also == the oracle's materialise-and-merge."""
+    import torch
+    from certificate_stark_amd.backend import to_numpy_u64
+    log_b = 3
+    w = oracle.SchnorrWitness.generate(n_sig, seed=900 + n_sig)
+    backend.upload_schnorr_witness(w.messages, w.sig_rx, w.sig_s)
+    log_n = 9 + n_sig.bit_length() - 1
+    lde = backend.lde_columns(backend.interpolate_columns(backend.schnorr_build_trace()), log_b)
+    aux = backend.lde_columns(backend.interpolate_columns(backend.schnorr_aux_columns()), log_b)
+    av = backend.lde_columns(backend.schnorr_assertion_polys(log_n), log_b)
+    ta, tb = oracle.random_elements(56, 31), oracle.random_elements(56, 32)
+    ba, bb = oracle.random_elements(61, 33), oracle.random_elements(61, 34)
+    direct = backend.schnorr_evaluate_constraints(lde, aux, ta, tb, ba, bb, av, log_b, n_sig=n_sig)
+    split = backend.schnorr_evaluate_constraints_lde(lde, aux, ta, tb, ba, bb, av, n_sig=n_sig)
+    assert torch.equal(direct, split)
+    if n_sig == 8:
+        ptab = oracle.periodic_table(oracle.schnorr_mask_columns(), log_n, log_b)
+        ev = oracle.schnorr_evaluate_transitions(to_numpy_u64(lde), to_numpy_u64(aux), ptab)
+        ref = oracle.air_combine(oracle.schnorr_desc(w), to_numpy_u64(lde), ev, ta, tb, ba, bb, log_b, avals=to_numpy_u64(av))
+        assert (to_numpy_u64(split) == ref).all()
