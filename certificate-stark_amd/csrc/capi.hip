@@ -1233,8 +1233,8 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
         a_grp[a] = g;
     }
     constexpr size_t TXL = 230; // SchnorrAir split evaluation: the transition coefficients once more, laid out alpha[i] | beta[115 + i]
-    std::vector<uint64_t> blk(2 * nc + 3 * na + b + 2 * na + (nc + 1) / 2 + 1 + TXL);
-    const size_t txl_off = blk.size() - TXL;
+    std::vector<uint64_t> blk(2 * nc + 3 * na + b + 2 * na + (nc + 1) / 2 + 1 + TXL + cs::MERKLE_RTAB_WORDS);
+    const size_t txl_off = blk.size() - TXL - cs::MERKLE_RTAB_WORDS, mrt_off = blk.size() - cs::MERKLE_RTAB_WORDS; // (device scratch of k_merkle_rounds)
     if (nc <= 115) {
         memcpy(blk.data() + txl_off, t_alpha, nc * 8);
         memcpy(blk.data() + txl_off + 115, t_beta, nc * 8);
@@ -1325,7 +1325,10 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
     if (fused_merkle) {
         const PeriodicTable *pt;
         RC_TRY(merkle_periodic(c, (uint32_t)merkle_depth_fused, log_n, log_blowup, &pt));
-        HIP_TRY(cs::launch_merkle_fused(p, pt->tab, nk, c->stream));
+        // the round gadgets in the folded form of the TransactionAir evaluator (CSTARK_MERKLE_ROUNDS=0: the generic frame evaluator)
+        static const bool rounds_env = [] { const char *e = getenv("CSTARK_MERKLE_ROUNDS"); return !e || atoi(e) != 0; }();
+        const bool folded = rounds_env && b <= 8 && log_n >= 9;
+        HIP_TRY(cs::launch_merkle_fused(p, pt->tab, nk, c->stream, folded ? (uint64_t *)c->desc_buf + mrt_off : nullptr, t_grp[0]));
         p.tsum = d_out;
     }
     HIP_TRY(cs::launch_air_combine(p, nk, c->stream));

@@ -68,7 +68,11 @@ hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *
 // SchnorrAir, fused: writes sum_i (alpha_i + beta_i x^adj_i) C_i(x) of the nk cosets into p.out (six launches); aux / ptab as for
 // launch_eval_transitions_schnorr.  Follow with launch_air_combine on the same parameters with p.tsum = p.out.
 // MerkleAir likewise (one launch; ptab as for launch_eval_transitions_merkle)
-hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream);
+// d_rtab != null (MERKLE_RTAB_WORDS device words, scratch): the four Rescue round gadgets through their folded form (k_merkle_rounds; blowup
+// at most 8), round_group = p.t_grp of the round slots; null: every constraint through the generic frame evaluator
+constexpr int MERKLE_RTAB_WORDS = 1280;
+hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream, uint64_t *d_rtab = nullptr,
+                               unsigned round_group = 0);
 hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, unsigned nk, hipStream_t stream);
 // SchnorrAir's doubling / addition gadgets in the degree-split form (all cosets, k0 = 0; constraints.hip): eight polynomials on the even
 // cosets, d_even = [8][4][n] (d_coefs_tx_layout: alpha[i] at word i, beta[i] at word 115 + i, device); after their extension to the odd

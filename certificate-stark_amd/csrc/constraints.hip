@@ -1802,7 +1802,8 @@ __global__ __launch_bounds__(FNT, part_waves(PART, M)) void k_eval_fused(CeParam
 }
 
 // the transition constraints of MerkleAir at one point, through any accumulator with add(slot, flag, value)
-template <class Acc>
+// ROUNDS = false: without the four Rescue round gadgets (k_merkle_rounds evaluates them in their folded form)
+template <bool ROUNDS = true, class Acc>
 __device__ __forceinline__ void merkle_transitions(Acc &acc, const Frame &f) {
     // periodic layout: setup, hash(tx), hash_input, finish, hash_mask, ark[28]; the gadget templates read the round
     // constants at P_ARK + i relative to per_p, so give them a view shifted by (5 - P_ARK) columns
@@ -1817,10 +1818,12 @@ __device__ __forceinline__ void merkle_transitions(Acc &acc, const Frame &f) {
     acc.add(VALUE_RES + 24, setup, fp_sub(f.cur(R_INIT + 13), f.cur(R_UPD + 13)));
     acc.add(BALANCE_RES, setup, fp_sub(fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12)), fp_sub(f.cur(R_UPD + 12), f.cur(R_INIT + 12))));
     acc.add(NONCE_UPD_RES, setup, fp_sub(f.cur(S_UPD + 13), fp_add(f.cur(S_INIT + 13), FP_ONE)));
-    enforce_round(acc, fr, S_INIT, S_INIT, hash_flag, 0, 0, false);
-    enforce_round(acc, fr, S_UPD, S_UPD, hash_flag, 0, 0, false);
-    enforce_round(acc, fr, R_INIT, R_INIT, hash_flag, 0, 0, false);
-    enforce_round(acc, fr, R_UPD, R_UPD, hash_flag, 0, 0, false);
+    if (ROUNDS) {
+        enforce_round(acc, fr, S_INIT, S_INIT, hash_flag, 0, 0, false);
+        enforce_round(acc, fr, S_UPD, S_UPD, hash_flag, 0, 0, false);
+        enforce_round(acc, fr, R_INIT, R_INIT, hash_flag, 0, 0, false);
+        enforce_round(acc, fr, R_UPD, R_UPD, hash_flag, 0, 0, false);
+    }
     merkle_auth_rest(acc, f, S_INIT, tx_hash, hash_input, hash_flag);
     merkle_auth_rest(acc, f, R_INIT, tx_hash, hash_input, hash_flag);
     const fp not_finish = c_not(finish);
@@ -2078,6 +2081,8 @@ __global__ __launch_bounds__(256) void k_schnorr_split_finish(AirCombineParams p
 
 // MerkleAir, fused: the same body as k_eval_transitions_merkle behind the table-driven accumulator; one value per point of the
 // cosets of the constraint-evaluation domain (the others are left alone: k_air_combine writes their zeros).
+// AFTER_ROUNDS: k_merkle_rounds wrote the four round gadgets' sum first; this kernel adds every other constraint to it.
+template <bool AFTER_ROUNDS>
 __global__ __launch_bounds__(FNT, 2) void k_merkle_fused(AirCombineParams p, const fp *__restrict__ ptab) {
     __shared__ fp xp_lds[AIR_MAX_GROUPS * FNT];
     const size_t n = (size_t)1 << p.log_n;
@@ -2093,8 +2098,98 @@ __global__ __launch_bounds__(FNT, 2) void k_merkle_fused(AirCombineParams p, con
     f.pcycle = 512;
     for (unsigned g = 0; g < p.n_tgrp; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(p.tgrp_shift[k][g], p.w[(j * p.tgrp_adj[g]) & (n - 1)]);
     AirSum acc{as_const(p.t_alpha), as_const(p.t_beta), as_const(p.t_grp), xp_lds, acc_zero(), 0, 0};
-    merkle_transitions(acc, f);
-    p.out[(size_t)kk * n + j] = acc.total;
+    merkle_transitions<!AFTER_ROUNDS>(acc, f);
+    fp *o = p.out + (size_t)kk * n + j;
+    *o = AFTER_ROUNDS ? fp_add(*o, acc.total) : acc.total;
+}
+
+// MerkleAir's four Rescue round gadgets (registers S_INIT, S_UPD, R_INIT, R_UPD under the hash mask; result slots = the registers;
+// src/merkle/update/air.rs:215-289) in the folded form of the TransactionAir evaluator (k_rounds_setup / k_rounds_split above): the
+// forward half is linear in the cubes, so sum_i c_i (MDS cube + ark1)_i = (MDS^T c) . cube + c . ark1 -- two 14-term dot products per
+// window (alpha, beta: the 56 round slots share ONE declared degree, i.e. one power x^adj) instead of a 14 x 14 product; the window's
+// cells come by LDS-DMA, every LDE cell fetched once.  Exact arithmetic: the merged value is unchanged.
+// rtab (u64 words; sections = (window, {alpha, beta})): A[8][8 cosets][8] | limbs of U[8][14] | limbs of INV_MDS[196] | G[8][14]
+constexpr int MR_SECTIONS = 8, MR_A = 0, MR_UL = MR_SECTIONS * 64, MR_ML = MR_UL + MR_SECTIONS * 14 * 2, MR_G = MR_ML + 196 * 2, MR_SIZE = MR_G + MR_SECTIONS * 14;
+static_assert(MR_SIZE <= MERKLE_RTAB_WORDS, "MerkleAir rounds table");
+__global__ void k_merkle_rounds_setup(const fp *__restrict__ t_alpha, const fp *__restrict__ t_beta, const fp *__restrict__ ptab, fp *__restrict__ rtab,
+                                      unsigned n_cosets) {
+    const int sec = blockIdx.x, reg = c_windows[sec >> 1].reg, t = threadIdx.x;
+    __shared__ fp gam[14];
+    if (t < 14) gam[t] = ((sec & 1) ? t_beta : t_alpha)[reg + t];
+    __syncthreads();
+    if (t < 14) {
+        rtab[MR_G + sec * 14 + t] = gam[t];
+        fp u = 0;
+        for (int i = 0; i < 14; i++) u = fp_add(u, fp_mul(gam[i], c_mds[i * 14 + t]));
+        split_limbs(u, (uint32_t *)(rtab + MR_UL) + (sec * 14 + t) * 4);
+    }
+    if (sec == 0)
+        for (int e = t; e < 196; e += blockDim.x) split_limbs(c_inv_mds[e], (uint32_t *)(rtab + MR_ML) + e * 4);
+    if (t < 64) { // sum_i c_i ark1_i on coset k at rows = r mod 8 (the round constants' extension has period 8 in the row index)
+        const unsigned k = t >> 3, r = t & 7;
+        fp a = 0;
+        if (k < n_cosets)
+            for (int i = 0; i < 14; i++) a = fp_add(a, fp_mul(gam[i], ptab[((size_t)k * 33 + 5 + i) * 512 + r]));
+        rtab[MR_A + sec * 64 + t] = a;
+    }
+}
+// grid = (n / FNT, nk); xg = the degree group of the round slots (p.t_grp[S_INIT])
+__global__ __launch_bounds__(FNT, 3) void k_merkle_rounds(AirCombineParams p, const fp *__restrict__ ptab, const fp *__restrict__ rtab, unsigned xg) {
+    __shared__ fp ark2_lds[8 * 14];
+    __shared__ __attribute__((aligned(16))) fp img_lds[(FNT / 64) * RW_IMG];
+    __shared__ fp atab_lds[MR_SECTIONS * 8];
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kk = blockIdx.y, k = p.k0 + kk;
+    if (k % p.stride) return; // uniform over the workgroup
+    const fp *base = p.lde + (size_t)kk * 65 * n;
+    if (threadIdx.x < 8 * 14) {
+        const unsigned r = threadIdx.x / 14, c = threadIdx.x % 14;
+        ark2_lds[threadIdx.x] = ptab[((size_t)k * 33 + 5 + 14 + c) * 512 + ((blockIdx.x * (size_t)FNT + r) & 511)];
+    }
+    if (threadIdx.x < MR_SECTIONS * 8) atab_lds[threadIdx.x] = rtab[MR_A + (threadIdx.x >> 3) * 64 + k * 8 + (threadIdx.x & 7)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const unsigned jr = (unsigned)(j & 7);
+    fp *img = img_lds + (threadIdx.x >> 6) * RW_IMG;
+    const fp *ark2 = ark2_lds + jr * 14, *atab = atab_lds + jr;
+    const fp flag = ptab[((size_t)k * 33 + 4) * 512 + (j & 511)];
+    const fp xp = fp_mul(p.tgrp_shift[k][xg], p.w[(j * p.tgrp_adj[xg]) & (n - 1)]);
+    const CS_CONST uint32_t *ul = as_const((const uint32_t *)(rtab + MR_UL)), *ml = as_const((const uint32_t *)(rtab + MR_ML));
+    const CS_CONST fp *gt = as_const(rtab + MR_G);
+    const fp *rows = base + j + lane; // rows j0 + 2 lane, + 1 of the wave's window (j0 = j - lane); rows n, n + 1 wrap to 0, 1
+    if (lane == 32 && ((j - lane + 64) & (n - 1)) == 0) rows -= n;
+    rounds_fetch_window(rows, n, c_windows[0].reg, lane, img);
+    fp ta = 0, tb = 0;
+#pragma unroll 1
+    for (int wdx = 0; wdx < 4; wdx++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fp d[14];
+#pragma unroll
+        for (int jj = 0; jj < 14; jj++) d[jj] = fp_sub(img[jj * RW_ROWS + lane + 1], ark2[jj]);
+        Acc128 sa = acc_zero(), sb = acc_zero();
+        const CS_CONST fp *ga = gt + (wdx * 2) * 14;
+#pragma unroll 1
+        for (int i = 0; i < 14; i++) {
+            const fp s2 = fp_cube(dot14l(ml + i * 56, d));
+            acc_mad(sa, ga[i], s2);
+            acc_mad(sb, ga[14 + i], s2);
+            if (i == 6) { acc_fold(sa); acc_fold(sb); }
+        }
+        fp cube[14];
+#pragma unroll
+        for (int jj = 0; jj < 14; jj++) cube[jj] = fp_cube(img[jj * RW_ROWS + lane]);
+        if (wdx < 3) { // the image is free again: the next window arrives behind the forward half
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            rounds_fetch_window(rows, n, c_windows[wdx + 1].reg, lane, img);
+        }
+        acc_fold(sa); acc_fold(sb);
+        const fp fa = fp_add(dot14l(ul + (wdx * 2) * 56, cube), atab[(wdx * 2) * 8]);
+        const fp fb = fp_add(dot14l(ul + (wdx * 2 + 1) * 56, cube), atab[(wdx * 2 + 1) * 8]);
+        ta = fp_add(ta, fp_sub(acc_reduce(sa), fa));
+        tb = fp_add(tb, fp_sub(acc_reduce(sb), fb));
+    }
+    p.out[(size_t)kk * n + j] = fp_mul(flag, fp_add(ta, fp_mul(xp, tb)));
 }
 
 // RangeProofAir::evaluate_transition  src/range/air.rs:60-98 (enforce_double_and_add_step with flag ONE)
@@ -2221,10 +2316,18 @@ hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t
     hipLaunchKernelGGL((k_schnorr_fused<SF_REST, true>), grid, block, 0, stream, p, aux, ptab);
     return hipGetLastError();
 }
-hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream) {
+hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream, uint64_t *d_rtab, unsigned round_group) {
     const size_t n = (size_t)1 << p.log_n;
     if (n % FNT) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(n / FNT), nk), dim3(FNT), 0, stream, p, ptab);
+    const dim3 grid((unsigned)(n / FNT), nk);
+    if (!d_rtab) {
+        hipLaunchKernelGGL(k_merkle_fused<false>, grid, dim3(FNT), 0, stream, p, ptab);
+        return hipGetLastError();
+    }
+    if (p.k0 + nk > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_merkle_rounds_setup, dim3(MR_SECTIONS), dim3(64), 0, stream, p.t_alpha, p.t_beta, ptab, d_rtab, p.k0 + nk);
+    hipLaunchKernelGGL(k_merkle_rounds, grid, dim3(FNT), 0, stream, p, ptab, (const fp *)d_rtab, round_group);
+    hipLaunchKernelGGL(k_merkle_fused<true>, grid, dim3(FNT), 0, stream, p, ptab);
     return hipGetLastError();
 }
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream) {

@@ -1136,6 +1136,12 @@ int cstark_air_prove(cstark_ctx *c, int air, const cstark_options *opt, uint64_t
         job.build = merkle_build; job.combine = merkle_combine;
     } else if (air == CSTARK_AIR_RANGE) {
         if (number >= host::P || (host::to_u64(number) >> 63)) return fail(CSTARK_ERR_INVALID_ARG, "range proofs cover 63-bit field elements (src/range/tests.rs:54-62)");
+        // One 64-row proof is host-API bound on the generic path (~150 launches and round trips: 0.35 ms); the batch prover with a
+        // batch of one makes the same bytes from ~25 launches.  CSTARK_RANGE_GENERIC=1 keeps the generic path (cstark_range_prove_bits
+        // with log_n = 6 always takes it: the tests compare the two).
+        static const bool generic = getenv("CSTARK_RANGE_GENERIC") != nullptr;
+        if (!generic && opt->field_extension == 0 && proof && capacity >= cstark_tx_proof_size_bound(1, opt))
+            return cstark_range_prove_batch(c, opt, &number, 1, proof, capacity, proof_len);
         host::air_shape(air, s, 0);
         job.log_n = 6; job.item = 0; job.number = number; // RANGE_LOG = 64 rows, src/range/mod.rs:34
         job.pub = {number};
@@ -1280,6 +1286,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const uint32_t hf = opt->hash_fn;
+    if (c->arena) c->arena->timed = false; // cstark_prove_stage_ms describes the generic prover's last proof: none after a batch
 
     // ---- buffers: one device block, one pinned host block ----------------------------------------------------------------------------
     const size_t dev_need = B * (16 + 1024 * 2 + 8192 + 32768 + 64 + 1024 + 1024 + 8192 + 32768 + 8 + 48 + 64 + 4096 + 8192 + 8 + 8 * rem_len + 8 * nq + 4 + slot) + 64 * 256;

@@ -223,7 +223,9 @@ def test_batched_range_proofs_equal_single_proofs(oracle, backend, opts):
     proofs = backend.range_prove_batch(options(opts), numbers)
     assert len(proofs) == len(values)
     for i, proof in enumerate(proofs):
-        assert proof == backend.air_prove(Backend.AIR_RANGE, options(opts), int(numbers[i])), i
+        assert proof == backend.air_prove(Backend.AIR_RANGE, options(opts), int(numbers[i])), i     # a batch of one
+        if i < 24:   # the generic prover (cstark_range_prove_bits at 64 rows never takes the batch path)
+            assert proof == backend.range_prove_bits(options(opts), np.array([values[i] % oracle.P], np.uint64), 6), i
         if i < 8:
             assert proof == OP.prove_air(oracle.AIR_RANGE, int(numbers[i]), opts)
             assert V.verify_range(proof, int(numbers[i]), options=list(opts))
@@ -243,6 +245,7 @@ def test_batched_range_prover_at_baseline_size_and_its_errors(oracle, backend):
     assert len(proofs) == 1024
     for i in range(0, 1024, 97):
         assert proofs[i] == backend.air_prove(Backend.AIR_RANGE, options(), int(numbers[i]))
+        assert proofs[i] == backend.range_prove_bits(options(), np.array([int(values[i]) % oracle.P], np.uint64), 6)   # generic path
         assert V.verify_range(proofs[i], int(numbers[i]), options=list(OPTS))
     for p in proofs:
         assert V.parse(p)["log_n"] == 6
