@@ -285,6 +285,7 @@ struct AirJob {
     struct ColumnBatch { uint32_t col0, ncols; hipEvent_t wait[2]; };
     std::vector<ColumnBatch> batches;
     const uint64_t *pub_staging = nullptr; // pinned host copy of the public inputs, valid once every batch has been waited for
+    bool public_ready = false;      // SchnorrAir: the extended public-input columns of this proof are in the arena
     bool evals_ready = false;       // sub-AIRs: the materialised transition evaluations of this proof are already in the arena
     uint32_t k0 = 0, nk = 8;        // LDE cosets this GPU owns (all of them unless the proof is sharded)
     uint64_t number = 0;            // RangeProofAir
@@ -804,26 +805,51 @@ int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta,
     return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, out, job.log_n, 3, 0, 8);
 }
 // ---- SchnorrAir (src/schnorr) ---------------------------------------------------------------------------------------------------------
-int schnorr_build(cstark_ctx *c, ProveArena *a, AirJob &) { return cstark_schnorr_build_trace(c, a->trace); }
-int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
+// the public-input columns (src/schnorr/air.rs:228-290; not committed: both sides derive them from the messages) and the sequence
+// polynomials of the assertions, extended: they depend on the public inputs only
+int schnorr_public_columns(cstark_ctx *c, ProveArena *a, AirJob &job, uint64_t **aux_lde_out, uint64_t **av_lde_out, bool compute) {
     const size_t n = (size_t)1 << job.log_n;
-    // CSTARK_SCHNORR_FUSED=0 (tuning / debugging): materialise the 56 transition values and merge them generically
-    static const bool fused = [] { const char *e = getenv("CSTARK_SCHNORR_FUSED"); return !e || atoi(e) != 0; }();
-    uint64_t *evals = nullptr, *aux, *aux_co, *aux_lde, *av_co, *av_lde;
-    if (!fused) RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
+    uint64_t *aux, *aux_co, *aux_lde, *av_co, *av_lde;
     RC_TRY(arena_extra(c, a, 1, &aux, 19 * n * 8));
     RC_TRY(arena_extra(c, a, 2, &aux_co, 19 * n * 8));
     RC_TRY(arena_extra(c, a, 3, &aux_lde, 8 * 19 * n * 8));
     RC_TRY(arena_extra(c, a, 4, &av_co, 12 * n * 8));
     RC_TRY(arena_extra(c, a, 5, &av_lde, 8 * 12 * n * 8));
-    if (!job.evals_ready) { // once per proof (extension proofs merge with m coefficient sets)
-        // the public-input columns (src/schnorr/air.rs:228-290) are not committed: both sides derive them from the messages
+    if (compute) {
         RC_TRY(cstark_schnorr_aux_columns(c, aux));
         RC_TRY(cstark_interpolate_columns(c, aux, aux_co, 19, job.log_n));
         RC_TRY(cstark_lde_columns(c, aux_co, aux_lde, 19, job.log_n, 3, host::lde_offset(), 0, 8));
-        if (!fused) RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
         RC_TRY(cstark_schnorr_assertion_polys(c, av_co, job.log_n));
         RC_TRY(cstark_lde_columns(c, av_co, av_lde, 12, job.log_n, 3, host::lde_offset(), 0, 8));
+    }
+    *aux_lde_out = aux_lde; *av_lde_out = av_lde;
+    return CSTARK_OK;
+}
+// The ladders are latency-bound (two waves per signature, one per SIMD at 512 signatures): they run on an internal stream beside the
+// work that does not need them -- the public-input columns above, then the interpolation and extension of registers 37..55 (message
+// hash, bit registers, limb accumulators).  CSTARK_SCHNORR_OVERLAP=0 (tuning / debugging): one stream, one thing after the other.
+int schnorr_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
+    static const bool overlap = [] { const char *e = getenv("CSTARK_SCHNORR_OVERLAP"); return !e || atoi(e) != 0; }();
+    if (!overlap) return cstark_schnorr_build_trace(c, a->trace);
+    if (!c->wit_buf || c->wit.n_tx == 0 || !c->wit.msg_tail) return fail(CSTARK_ERR_INVALID_ARG, "no Schnorr witness uploaded");
+    uint64_t *aux_lde, *av_lde;
+    RC_TRY(schnorr_public_columns(c, a, job, &aux_lde, &av_lde, false)); // allocations (they may synchronise) before the fork
+    HIP_TRY(cs::launch_schnorr_trace_split(c->wit, a->trace, c->stream, c->side, c->ev_fork, c->ev_join, c->ev_join2));
+    RC_TRY(schnorr_public_columns(c, a, job, &aux_lde, &av_lde, true));
+    job.public_ready = true;
+    job.batches = {{37, job.width - 37, {c->ev_join, nullptr}}, {0, 37, {c->ev_join2, nullptr}}};
+    return CSTARK_OK;
+}
+int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
+    const size_t n = (size_t)1 << job.log_n;
+    // CSTARK_SCHNORR_FUSED=0 (tuning / debugging): materialise the 56 transition values and merge them generically
+    static const bool fused = [] { const char *e = getenv("CSTARK_SCHNORR_FUSED"); return !e || atoi(e) != 0; }();
+    uint64_t *evals = nullptr, *aux_lde, *av_lde;
+    if (!fused) RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
+    RC_TRY(schnorr_public_columns(c, a, job, &aux_lde, &av_lde, !job.public_ready)); // once per proof, in schnorr_build when it overlaps
+    job.public_ready = true;
+    if (!job.evals_ready) { // once per proof (extension proofs merge with m coefficient sets)
+        if (!fused) RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
         job.evals_ready = true;
     }
     if (fused) return cstark_schnorr_evaluate_constraints_lde(c, job.item, a->lde, aux_lde, ta, tb, ba, bb, av_lde, 12, out, job.log_n); // own extensions: split form

@@ -31,6 +31,9 @@ hipError_t launch_range_trace_bits(const uint64_t *d_words, uint64_t *d_prefix, 
 // SchnorrProver::build_trace (src/schnorr/prover.rs:40-67): 56 x 512*n; the witness view holds message[0..12] in s_old,
 // [12..24] in r_old, [24] in deltas, [25] in s_old[13], [26..28] in msg_tail
 hipError_t launch_schnorr_trace(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream);
+// the same on the internal stream `side` (forked from `stream`): join_a = registers 37..55 complete, join_b = all registers complete
+hipError_t launch_schnorr_trace_split(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t join_a,
+                                      hipEvent_t join_b);
 // the 19 public-input columns of SchnorrAir (pkey x12, message chunks x7; src/schnorr/air.rs:228-290): 19 x 512*n
 hipError_t launch_schnorr_aux_columns(const TxWitnessDev &w, uint64_t *d_out, hipStream_t stream);
 

@@ -648,6 +648,25 @@ hipError_t launch_schnorr_trace(const TxWitnessDev &w, fp *d_trace, hipStream_t 
     hipLaunchKernelGGL(k_trace_schnorr_bits, dim3(w.n_tx, 2), dim3(256), 0, stream, w, d_trace, n);
     return hipGetLastError();
 }
+// The same kernels on an internal stream, so that the caller's stream can do work that does not depend on the trace (the public-input
+// columns of SchnorrAir, then the interpolation and extension of registers 37..55) beside the latency-bound ladders (one wave per SIMD
+// at 512 signatures).  join_a: registers 37..55 are complete (message hash, bit registers, limb accumulators); join_b: all of them.
+// The ladders' staging tile: 64 rows while four ladders per CU leave room in LDS for a transform workgroup (13.5 KB each), else 16.
+hipError_t launch_schnorr_trace_split(const TxWitnessDev &w, fp *d_trace, hipStream_t stream, hipStream_t side, hipEvent_t fork, hipEvent_t join_a,
+                                      hipEvent_t join_b) {
+    const size_t n = (size_t)w.n_tx * MERKLE_LEN;
+    hipError_t e;
+    if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(side, fork, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL((k_trace_schnorr_hash<true, 64>), dim3(w.n_tx), dim3(64), 0, side, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_bits, dim3(w.n_tx, 2), dim3(256), 0, side, w, d_trace, n);
+    if ((e = hipEventRecord(join_a, side)) != hipSuccess) return e;
+    if (w.n_tx <= 512) hipLaunchKernelGGL((k_trace_schnorr_ec<true, 64>), dim3(2 * w.n_tx), dim3(64), 0, side, w, d_trace, n);
+    else hipLaunchKernelGGL((k_trace_schnorr_ec<true, 16>), dim3(2 * w.n_tx), dim3(64), 0, side, w, d_trace, n);
+    hipLaunchKernelGGL(k_trace_schnorr_final<true>, dim3(w.n_tx), dim3(64), 0, side, d_trace, n);
+    if ((e = hipEventRecord(join_b, side)) != hipSuccess) return e;
+    return hipGetLastError();
+}
 hipError_t launch_schnorr_aux_columns(const TxWitnessDev &w, fp *d_out, hipStream_t stream) {
     const size_t n = (size_t)w.n_tx * MERKLE_LEN;
     hipLaunchKernelGGL(k_schnorr_aux_columns, dim3(w.n_tx, 2), dim3(256), 0, stream, w, d_out, n);
