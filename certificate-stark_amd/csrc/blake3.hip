@@ -176,6 +176,76 @@ __global__ __launch_bounds__(1024) void k_merkle_top(uint8_t *__restrict__ nodes
     if (threadIdx.x < 2) reinterpret_cast<uint4 *>(nodes)[threadIdx.x] = make_uint4(0, 0, 0, 0); // nodes[0] unused
 }
 
+// ---- the upper levels, bound by latency ------------------------------------------------------------------------------------------------
+// Below ~2^17 parents a level no longer fills the GPU: what a launch costs is its dependent chain -- one compression is ~670 dependent
+// instructions (3 us) for a single lane, the lane-per-node kernels above chain two or three of them, and k_merkle_top walks eleven levels
+// (24 us).  A proof builds about ten trees one after the other, each ending in such a tail.  Here FOUR lanes share a compression, the
+// way SIMD implementations of BLAKE3 do: lane c of a quad holds column c of the 4 x 4 state, the column step is one G per lane, the
+// diagonal step another after rotating rows 1..3 by 1..3 lanes (DPP quad_perm, no LDS); 7 x (2 G + 6 moves) = ~210 dependent
+// instructions.  A workgroup of 256 quads takes 512 nodes and reduces them through nine levels in LDS (every level also goes to the
+// node array); a second launch of one workgroup finishes the tree.
+__constant__ uint32_t c_quad_sched[4][7] = { // lane c, round r: bytes = message word indices of (column mx, my, diagonal mx, my)
+#define QS(r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15, c) \
+    ((uint32_t)(c == 0 ? r0 : c == 1 ? r2 : c == 2 ? r4 : r6) | (uint32_t)(c == 0 ? r1 : c == 1 ? r3 : c == 2 ? r5 : r7) << 8 | \
+     (uint32_t)(c == 0 ? r8 : c == 1 ? r10 : c == 2 ? r12 : r14) << 16 | (uint32_t)(c == 0 ? r9 : c == 1 ? r11 : c == 2 ? r13 : r15) << 24)
+#define QROW(c)                                                                                                                       \
+    {QS(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, c), QS(2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8, c),         \
+     QS(3, 4, 10, 12, 13, 2, 7, 14, 6, 5, 9, 0, 11, 15, 8, 1, c), QS(10, 7, 12, 9, 14, 3, 13, 15, 4, 0, 11, 2, 5, 8, 1, 6, c),         \
+     QS(12, 13, 9, 11, 15, 10, 14, 8, 7, 2, 5, 3, 0, 1, 6, 4, c), QS(9, 14, 11, 5, 8, 12, 15, 1, 13, 3, 0, 10, 2, 6, 4, 7, c),         \
+     QS(11, 15, 5, 0, 1, 9, 8, 6, 14, 10, 2, 12, 3, 4, 7, 13, c)}
+    QROW(0), QROW(1), QROW(2), QROW(3)
+#undef QROW
+#undef QS
+};
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
+// Blake3 of the 64-byte message m[0..15] (LDS) by the four lanes of a quad: lane c returns words c and 4 + c of the digest
+__device__ __forceinline__ void quad_hash64(const uint32_t *m, const uint32_t (&sched)[7], unsigned c, uint32_t &lo, uint32_t &hi) {
+    uint32_t w[28];
+#pragma unroll
+    for (int r = 0; r < 7; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[4 * r + q] = m[(sched[r] >> (8 * q)) & 15];
+    const uint32_t iv_lo = c == 0 ? IV0 : c == 1 ? IV1 : c == 2 ? IV2 : IV3, iv_hi = c == 0 ? IV4 : c == 1 ? IV5 : c == 2 ? IV6 : IV7;
+    uint32_t a = iv_lo, b = iv_hi, cc = iv_lo, d = c == 2 ? 64u : c == 3 ? (uint32_t)(CHUNK_START | CHUNK_END | ROOT) : 0u;
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        B3_G(a, b, cc, d, w[4 * r], w[4 * r + 1])
+        b = quad_perm<0x39>(b); cc = quad_perm<0x4E>(cc); d = quad_perm<0x93>(d);  // lane c <- lanes c + 1, c + 2, c + 3: the diagonals
+        B3_G(a, b, cc, d, w[4 * r + 2], w[4 * r + 3])
+        b = quad_perm<0x93>(b); cc = quad_perm<0x4E>(cc); d = quad_perm<0x39>(d);  // and back to columns
+    }
+    lo = a ^ cc;
+    hi = b ^ d;
+}
+// Workgroup w reduces the parents [cnt + P0 w, cnt + P0 (w + 1)), P0 = min(cnt, 256), through `levels` levels (P0 >> (levels - 1) >= 1).
+// cnt: a power of two; grid = cnt / P0.
+__global__ __launch_bounds__(1024) void k_merkle_quad(uint8_t *__restrict__ nodes, size_t cnt, int levels) {
+    __shared__ __attribute__((aligned(16))) uint32_t buf[2][512 * 8];
+    const unsigned tid = threadIdx.x, quad = tid >> 2, c = tid & 3;
+    const unsigned p0 = cnt < 256 ? (unsigned)cnt : 256u;
+    const size_t base = (size_t)blockIdx.x * p0;
+    uint32_t sched[7];
+#pragma unroll
+    for (int r = 0; r < 7; r++) sched[r] = c_quad_sched[c][r];
+    if (tid < 4 * p0) reinterpret_cast<uint4 *>(buf[0])[tid] = reinterpret_cast<const uint4 *>(nodes + 64 * (cnt + base))[tid]; // 2 p0 children
+    __syncthreads();
+    for (int l = 0; l < levels; l++) {
+        const unsigned p = p0 >> l;
+        const uint32_t *cur = buf[l & 1];
+        uint32_t *nxt = buf[(l & 1) ^ 1];
+        if (quad < p) {
+            uint32_t lo, hi;
+            quad_hash64(cur + 16 * quad, sched, c, lo, hi);
+            uint32_t *g = reinterpret_cast<uint32_t *>(nodes + 32 * ((cnt >> l) + (base >> l) + quad));
+            g[c] = lo; g[4 + c] = hi;
+            nxt[8 * quad + c] = lo; nxt[8 * quad + 4 + c] = hi;
+        }
+        __syncthreads();
+    }
+    if (cnt >> (levels - 1) == 1 && tid < 8) reinterpret_cast<uint32_t *>(nodes)[tid] = 0; // the root was written: nodes[0] unused
+}
+
 // ---- batches of small tables (the batched range prover, prove.hip): `batch` independent tables side by side ---------------------------
 // Table t owns columns [t gw, (t + 1) gw) of a coset-major table of width_total columns; one lane per leaf (leaf = b j + k of table t),
 // digests to leaves + t leaf_stride.  A row holds at most 8 elements (one compression).
@@ -251,6 +321,23 @@ hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, u
 
 hipError_t merkle_build(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream) {
     size_t cnt = ((size_t)1 << log_leaves) >> 1;
+    static const bool quad = [] { const char *e = getenv("CSTARK_MERKLE_QUAD"); return !e || atoi(e) != 0; }(); // 0 (tuning / debugging): lane-per-node kernels throughout
+    if (quad) {
+        while (cnt > ((size_t)1 << 17)) { // wide levels: throughput, one lane per node, two levels per launch
+            hipLaunchKernelGGL(k_merkle_level2, dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, stream, d_nodes, cnt);
+            cnt >>= 2;
+        }
+        if (cnt > 256) { // 256 parents per workgroup, nine levels: 512 children -> 1
+            hipLaunchKernelGGL(k_merkle_quad, dim3((unsigned)(cnt / 256)), dim3(1024), 0, stream, d_nodes, cnt, 9);
+            cnt >>= 9;
+        }
+        if (cnt >= 1) {
+            int levels = 1;
+            while (((size_t)1 << (levels - 1)) < cnt) levels++;
+            hipLaunchKernelGGL(k_merkle_quad, dim3(1), dim3(1024), 0, stream, d_nodes, cnt, levels);
+        }
+        return hipGetLastError();
+    }
     while (cnt > 1024) {
         if (cnt >= 4096) { // two levels: parents [cnt, 2 cnt) and [cnt / 2, cnt)
             hipLaunchKernelGGL(k_merkle_level2, dim3((unsigned)((cnt / 2 + 255) / 256)), dim3(256), 0, stream, d_nodes, cnt);
