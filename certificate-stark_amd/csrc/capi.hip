@@ -334,6 +334,7 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     for (CosetTable &t : c->cosets) { (void)hipFree(t.s); (void)hipFree(t.aux); }
     for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); (void)hipFree(t.binv); }
     for (PeriodicTable &t : c->small_periodic) (void)hipFree(t.tab);
+    for (cs::AssertInverseTable &t : c->assert_inv) (void)hipFree(t.tab);
     if (c->desc_buf) (void)hipFree(c->desc_buf);
     if (c->rb_dev) (void)hipFree(c->rb_dev);
     if (c->shard_bit37) (void)hipFree(c->shard_bit37);
@@ -1282,6 +1283,26 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
             }
             p.zinv_coset[k] = cs::host::inv(cs::host::sub(cs::host::pow(sh, n), cs::host::ONE));
             sh = cs::host::mul(sh, wbn);
+        }
+    }
+    {   // 1 / (x^m - zc) of every assertion divisor over the domain: cached per (m, zc, trace length, blowup).
+        // CSTARK_AIR_INV_TABLES=0 (tuning / debugging): one inversion per point inside k_air_combine
+        static const bool inv_tables = [] { const char *e = getenv("CSTARK_AIR_INV_TABLES"); return !e || atoi(e) != 0; }();
+        for (uint32_t g = 0; inv_tables && g < p.n_agrp; g++) {
+            const cs::AssertInverseTable *t = nullptr;
+            for (const cs::AssertInverseTable &q : c->assert_inv)
+                if (q.log_n == log_n && q.log_b == log_blowup && q.m == p.agrp_m[g] && q.zc == p.agrp_zc[g]) t = &q;
+            if (!t) {
+                cs::AssertInverseTable q{log_n, log_blowup, p.agrp_m[g], p.agrp_zc[g], nullptr};
+                HIP_TRY(hipMalloc((void **)&q.tab, (size_t)b * (n / q.m) * 8));
+                uint64_t sm[8] = {};
+                for (uint64_t k = 0; k < b; k++) sm[k] = p.agrp_mshift[k][g];
+                const hipError_t e = cs::launch_assert_inverses(q.tab, plan->w, sm, (unsigned)b, q.m, q.zc, log_n, c->stream);
+                if (e != hipSuccess) { (void)hipFree(q.tab); HIP_TRY(e); }
+                c->assert_inv.push_back(q);
+                t = &c->assert_inv.back();
+            }
+            p.agrp_inv[g] = t->tab;
         }
     }
     if (d_schnorr_aux_lde) {

@@ -59,7 +59,13 @@ struct AirCombineParams {
     // powers of a point x = shift_k w_n^j without a square-and-multiply per point: x^e = shift_k^e * w_n^((j e) mod n).  Per LDE coset
     // k (host-built): shift_k^adj of every transition group, shift_k^badj and shift_k^m of every assertion group, 1 / (shift_k^n - 1)
     uint64_t tgrp_shift[8][AIR_MAX_GROUPS], agrp_bshift[8][AIR_MAX_GROUPS], agrp_mshift[8][AIR_MAX_GROUPS], zinv_coset[8];
+    // optional (all groups or none): cached 1 / (x^m - zc), agrp_inv[g][k (n / m_g) + (j mod n / m_g)] for LDE coset k; null = one
+    // inversion per point (Montgomery's trick over the groups)
+    const uint64_t *agrp_inv[AIR_MAX_GROUPS];
 };
+// tab[k][i] = 1 / (shift_m[k] w_n^(i m) - zc), i < n / m, for the b cosets (shift_m[k] = shift_k^m)
+hipError_t launch_assert_inverses(uint64_t *d_tab, const uint64_t *d_w, const uint64_t shift_m[8], unsigned b, uint64_t m, uint64_t zc, unsigned log_n,
+                                  hipStream_t stream);
 hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_t stream);
 hipError_t launch_eval_transitions_merkle(const uint64_t *lde, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0, unsigned nk,
                                           hipStream_t stream);

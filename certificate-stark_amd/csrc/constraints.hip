@@ -2205,6 +2205,7 @@ __global__ void k_eval_transitions_range(const fp *lde, fp *out, unsigned log_n)
     out[((size_t)kk * 2 + 0) * n + j] = c_is_binary(nb);                                         // result[0]: bit
 }
 
+struct AssertShifts { fp s[8]; };
 // Generic merge of materialised transition evaluations with single-step boundary constraints:
 //   out = sum_i (alpha_i + beta_i x^adj_i) C_i(x) / Z(x) + sum_a (T_reg(x) - v_a)(alpha_a + beta_a x^badj) / (x - w^step_a)
 // Cosets outside the constraint-evaluation domain (k % stride != 0) are written as 0.
@@ -2221,8 +2222,15 @@ __global__ void k_air_combine(AirCombineParams p) {
     // point for all assertion divisors (Montgomery's trick); 1 / (x^n - 1) is constant over a coset.
     const size_t mask = n - 1;
     fp xp[AIR_MAX_GROUPS], zi[AIR_MAX_GROUPS], xb[AIR_MAX_GROUPS];
-    for (unsigned g = 0; g < p.n_tgrp; g++) xp[g] = fp_mul(p.tgrp_shift[k][g], p.w[(j * p.tgrp_adj[g]) & mask]);
-    {
+    if (!p.tsum)
+        for (unsigned g = 0; g < p.n_tgrp; g++) xp[g] = fp_mul(p.tgrp_shift[k][g], p.w[(j * p.tgrp_adj[g]) & mask]);
+    if (p.agrp_inv[0]) { // the divisors depend on the domain only: cached inverses
+        for (unsigned g = 0; g < p.n_agrp; g++) {
+            const size_t period = n / p.agrp_m[g];
+            zi[g] = p.agrp_inv[g][(size_t)k * period + (j & (period - 1))];
+            xb[g] = fp_mul(p.agrp_bshift[k][g], p.w[(j * p.agrp_badj[g]) & mask]);
+        }
+    } else {
         fp den[AIR_MAX_GROUPS], pre[AIR_MAX_GROUPS], run = FP_ONE;
         for (unsigned g = 0; g < p.n_agrp; g++) {
             den[g] = fp_sub(fp_mul(p.agrp_mshift[k][g], p.w[(j * p.agrp_m[g]) & mask]), p.agrp_zc[g]);
@@ -2242,13 +2250,23 @@ __global__ void k_air_combine(AirCombineParams p) {
         for (unsigned i = 0; i < p.n_constraints; i++)
             acc = fp_add(acc, fp_mul(p.evals[((size_t)kk * p.n_constraints + i) * n + j], fp_add(p.t_alpha[i], fp_mul(p.t_beta[i], xp[p.t_grp[i]]))));
     acc = fp_mul(acc, fp_mul(fp_sub(x, p.w_last), p.zinv_coset[k]));
-    // boundary constraints (single, periodic and sequence assertions): divisor x^m - w^(first*m)
-    for (unsigned a = 0; a < p.n_assertions; a++) {
-        const unsigned g = p.a_grp[a];
-        const fp tv = p.lde[((size_t)kk * p.width + p.a_reg[a]) * n + j];
-        const fp cv = p.a_seq[a] >= 0 ? p.avals[((size_t)kk * p.n_avals + p.a_seq[a]) * n + j] : p.a_value[a];
-        const fp term = fp_mul(fp_sub(tv, cv), fp_add(p.b_alpha[a], fp_mul(p.b_beta[a], xb[g])));
-        acc = fp_add(acc, fp_mul(term, zi[g]));
+    // boundary constraints (single, periodic and sequence assertions): divisor x^m - w^(first*m).  Group by group (the assertion
+    // tables are uniform over the wave, so the skip is a scalar branch): sum_a (alpha_a + beta_a x^badj)(T_a - v_a) =
+    // sum_a alpha_a d_a + x^badj sum_a beta_a d_a, two 128-bit multiply-accumulates per assertion and one reduction pair per group.
+    for (unsigned g = 0; g < p.n_agrp; g++) {
+        Acc128 sa = acc_zero(), sb = acc_zero();
+        int cnt = 0;
+        for (unsigned a = 0; a < p.n_assertions; a++) {
+            if (p.a_grp[a] != g) continue;
+            const fp tv = p.lde[((size_t)kk * p.width + p.a_reg[a]) * n + j];
+            const fp cv = p.a_seq[a] >= 0 ? p.avals[((size_t)kk * p.n_avals + p.a_seq[a]) * n + j] : p.a_value[a];
+            const fp d = fp_sub(tv, cv);
+            acc_mad(sa, p.b_alpha[a], d);
+            acc_mad(sb, p.b_beta[a], d);
+            if (++cnt == 7) { acc_fold(sa); acc_fold(sb); cnt = 0; }
+        }
+        acc_fold(sa); acc_fold(sb);
+        acc = fp_add(acc, fp_mul(fp_add(acc_reduce(sa), fp_mul(xb[g], acc_reduce(sb))), zi[g]));
     }
     *o = acc;
 }
@@ -2333,6 +2351,21 @@ hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, 
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream) {
     const size_t n = (size_t)1 << log_n;
     hipLaunchKernelGGL(k_eval_transitions_range, dim3((unsigned)((n + 63) / 64), nk), dim3(64), 0, stream, lde, out, log_n);
+    return hipGetLastError();
+}
+__global__ void k_assert_inverses(fp *__restrict__ tab, const fp *__restrict__ w, AssertShifts sh, uint64_t m, fp zc, unsigned log_n) {
+    const size_t n = (size_t)1 << log_n, period = n / m;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= period) return;
+    const unsigned k = blockIdx.y;
+    tab[(size_t)k * period + i] = fp_inv(fp_sub(fp_mul(sh.s[k], w[(i * m) & (n - 1)]), zc));
+}
+hipError_t launch_assert_inverses(uint64_t *d_tab, const uint64_t *d_w, const uint64_t shift_m[8], unsigned b, uint64_t m, uint64_t zc, unsigned log_n,
+                                  hipStream_t stream) {
+    const size_t period = ((size_t)1 << log_n) / m;
+    AssertShifts sh;
+    for (unsigned k = 0; k < 8; k++) sh.s[k] = k < b ? shift_m[k] : 0;
+    hipLaunchKernelGGL(k_assert_inverses, dim3((unsigned)((period + 255) / 256), b), dim3(256), 0, stream, d_tab, d_w, sh, m, zc, log_n);
     return hipGetLastError();
 }
 hipError_t launch_air_combine(const AirCombineParams &p, unsigned nk, hipStream_t stream) {

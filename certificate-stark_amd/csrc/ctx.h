@@ -71,6 +71,12 @@ struct PeriodicTable {
     uint64_t *binv;  // [b][2][n] inverses of the boundary divisors
     int air = 0;     // cstark_air_id the table belongs to
 };
+// 1 / (x^m - zc) over the LDE domain for one assertion divisor: [b cosets][n / m] (x^m has period n / m in the row index of a coset)
+struct AssertInverseTable {
+    unsigned log_n, log_b;
+    uint64_t m, zc;
+    uint64_t *tab;
+};
 struct ProveArena; // prove.hip
 void prove_arena_free(ProveArena *a);
 
@@ -92,6 +98,7 @@ struct cstark_ctx {
     uint64_t *coef_buf = nullptr; // device copy of the composition coefficients
     void *coef_stage = nullptr;   // pinned host staging of the same block: the upload is asynchronous, no wait for the caller's struct
     hipEvent_t coef_ev = nullptr; // recorded behind the upload; waited on before the staging block is rewritten
+    std::deque<cs::AssertInverseTable> assert_inv;  // k_air_combine's divisor inverses, keyed by (m, zc, log_n, log_b)
     std::deque<cs::PeriodicTable> small_periodic; // standalone sub-AIRs: keyed by (air, depth, log_n, log_b); coset/binv unused
     void *desc_buf = nullptr;     // device copy of a generic AIR description (cstark_air_combine)
     hipEvent_t part_ev[cs::CE_NUM_PARTS + 1] = {}; // optional per-launch timing of the fused constraint evaluation
