@@ -44,6 +44,8 @@ struct ProveArena {
     uint32_t *d_pos = nullptr;
     uint8_t *d_open = nullptr;
     uint64_t *h_pub = nullptr; // pinned
+    uint8_t *h_open = nullptr; // pinned: the openings land here (a pageable destination is staged by the runtime: ~60 us for 0.5 MB)
+    size_t h_open_bytes = 0;
     size_t open_bytes = 0;
     hipEvent_t ev[PROVE_EVENTS] = {};
     bool timed = false;
@@ -57,6 +59,7 @@ void prove_arena_free(ProveArena *a) {
     proof_run_free(a->run);
     for (void *p : a->owned) (void)hipFree(p);
     if (a->h_pub) (void)hipHostFree(a->h_pub);
+    if (a->h_open) (void)hipHostFree(a->h_open);
     for (hipEvent_t e : a->ev) if (e) (void)hipEventDestroy(e);
     delete a;
 }
@@ -632,14 +635,20 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
         }
     }
     HIP_TRY(gl.launch(st));
-    std::vector<uint8_t> open(off);
-    HIP_TRY(hipMemcpyAsync(open.data(), o, off, hipMemcpyDeviceToHost, st));
+    if (a->h_open_bytes < off) {
+        if (a->h_open) { HIP_TRY(hipHostFree(a->h_open)); a->h_open = nullptr; a->h_open_bytes = 0; }
+        HIP_TRY(hipHostMalloc((void **)&a->h_open, off, hipHostMallocDefault));
+        a->h_open_bytes = off;
+    }
+    const struct { const uint8_t *p; const uint8_t *data() const { return p; } } open{a->h_open};
+    HIP_TRY(hipMemcpyAsync(a->h_open, o, off, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(cs::stream_wait(st));
     a->timed = true;
 
     // ---- serialise ----------------------------------------------------------------------------------------------------------------
     Writer wr;
+    wr.b.reserve(off + ((size_t)64 << 10) + 8 * ((size_t)opt->fri_max_remainder * (opt->field_extension + 1)));
     wr.raw("CSTK", 4); wr.u32(CSTARK_PROOF_VERSION);
     wr.u32((uint32_t)job.air); wr.u32((uint32_t)W); wr.u32(log_n); wr.u32(job.item);
     wr.u32(opt->num_queries); wr.u32(opt->blowup_factor); wr.u32(opt->grinding_factor); wr.u32(opt->hash_fn); wr.u32(opt->field_extension);
@@ -1077,14 +1086,20 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
         }
     }
     HIP_TRY(gl.launch(st));
-    std::vector<uint8_t> open(off);
-    HIP_TRY(hipMemcpyAsync(open.data(), o, off, hipMemcpyDeviceToHost, st));
+    if (a->h_open_bytes < off) {
+        if (a->h_open) { HIP_TRY(hipHostFree(a->h_open)); a->h_open = nullptr; a->h_open_bytes = 0; }
+        HIP_TRY(hipHostMalloc((void **)&a->h_open, off, hipHostMallocDefault));
+        a->h_open_bytes = off;
+    }
+    const struct { const uint8_t *p; const uint8_t *data() const { return p; } } open{a->h_open};
+    HIP_TRY(hipMemcpyAsync(a->h_open, o, off, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(cs::stream_wait(st));
     a->timed = true;
 #undef STAGE
 
     Writer wr;
+    wr.b.reserve(off + ((size_t)64 << 10) + 8 * ((size_t)opt->fri_max_remainder * (opt->field_extension + 1)));
     wr.raw("CSTK", 4); wr.u32(CSTARK_PROOF_VERSION);
     wr.u32((uint32_t)job.air); wr.u32((uint32_t)W); wr.u32(log_n); wr.u32(job.item);
     wr.u32(opt->num_queries); wr.u32(opt->blowup_factor); wr.u32(opt->grinding_factor); wr.u32(opt->hash_fn); wr.u32(opt->field_extension);
