@@ -577,9 +577,10 @@ def main():
                 out["two_proofs_in_flight"] = {"failed": repr(e)}
         if world == 1 and args.mode == "prove" and not args.no_other_configs:
             try:  # after the timed region and on its own context; a report beside the headline, never a reason to lose it
-                ob = Backend(local)
-                out["other_configs"] = other_configs(ob)
-                ob.close()
+                with torch.cuda.stream(torch.cuda.Stream()):  # a stream of its own, as a caller with several contexts would give it
+                    ob = Backend(local)
+                    out["other_configs"] = other_configs(ob)
+                    ob.close()
             except Exception as e:
                 out["other_configs"] = {"failed": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

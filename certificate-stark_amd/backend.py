@@ -59,6 +59,7 @@ class Backend:
         self.ctx = ctx
         self.n_tx = 0
         self.depth = 0
+        self.resident = None   # the example object whose witness is in device memory (prover.MerkleExample / SchnorrExample), if any
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -88,6 +89,7 @@ class Backend:
     # ---- K1 ----
     def upload_witness(self, w):
         """w: any object with the TransactionMetadata arrays as numpy attributes (see prover.TransactionMetadata)."""
+        self.resident = None
         s = _lib.TxWitnessStruct()
         s.n_tx, s.merkle_depth = int(w.n_tx), int(w.depth)
         keep = []
@@ -312,6 +314,7 @@ class Backend:
         return out
 
     def upload_schnorr_witness(self, messages, sig_rx, sig_s):
+        self.resident = None
         m, rx = _np_u64(messages), _np_u64(sig_rx)
         s = np.ascontiguousarray(sig_s, np.uint8)
         n_sig = m.shape[0]

@@ -1180,7 +1180,7 @@ int cstark_air_prove(cstark_ctx *c, int air, const cstark_options *opt, uint64_t
         // One 64-row proof is host-API bound on the generic path (~150 launches and round trips: 0.35 ms); the batch prover with a
         // batch of one makes the same bytes from ~25 launches.  CSTARK_RANGE_GENERIC=1 keeps the generic path (cstark_range_prove_bits
         // with log_n = 6 always takes it: the tests compare the two).
-        static const bool generic = getenv("CSTARK_RANGE_GENERIC") != nullptr;
+        static const bool generic = [] { const char *e = getenv("CSTARK_RANGE_GENERIC"); return e && atoi(e) != 0; }();
         if (!generic && opt->field_extension == 0 && proof && capacity >= cstark_tx_proof_size_bound(1, opt))
             return cstark_range_prove_batch(c, opt, &number, 1, proof, capacity, proof_len);
         host::air_shape(air, s, 0);

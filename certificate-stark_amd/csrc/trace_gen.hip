@@ -582,6 +582,9 @@ hipError_t launch_trace_gen_split(const TxWitnessDev &w, fp *d_trace, hipStream_
     const size_t n = (size_t)w.n_tx * TXC;
     hipError_t e;
     if ((e = hipEventRecord(fork, stream)) != hipSuccess) return e;
+    // the closed-form registers first: the caller's stream transforms them next, and that chain of transforms is what a proof waits for
+    // (launched after the recurrences it started ~45 us later)
+    hipLaunchKernelGGL(k_trace_aux<1>, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
     if ((e = hipStreamWaitEvent(side_a, fork, 0)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(side_b, fork, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL((k_trace_merkle<false, CS_RECUR_TILE_ROWS>), dim3(w.n_tx), dim3(64), 0, side_a, w, d_trace, n);
@@ -593,7 +596,6 @@ hipError_t launch_trace_gen_split(const TxWitnessDev &w, fp *d_trace, hipStream_
     hipLaunchKernelGGL((k_trace_schnorr_ec<false, 16>), dim3(2 * w.n_tx), dim3(64), ladder_lds_pad(), side_b, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_final<false>, dim3(w.n_tx), dim3(64), 0, side_b, d_trace, n);
     if ((e = hipEventRecord(join_b, side_b)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_trace_aux<1>, dim3(w.n_tx, 4), dim3(256), 0, stream, w, d_trace, n);
     return hipGetLastError();
 }
 

@@ -194,7 +194,10 @@ class MerkleExample:
         self.backend = backend or Backend()
 
     def prove(self):
-        self.backend.upload_witness(self.tx_metadata)
+        """The witness is uploaded by the first call and stays resident (any other upload on the same backend replaces it)."""
+        if getattr(self.backend, "resident", None) is not self:
+            self.backend.upload_witness(self.tx_metadata)
+            self.backend.resident = self
         return self.backend.air_prove(Backend.AIR_MERKLE, self.options)
 
     def pub_inputs(self):
@@ -218,7 +221,10 @@ class SchnorrExample:
         return cls(options, msg, rx, s, backend)
 
     def prove(self):
-        self.backend.upload_schnorr_witness(self.messages, self.sig_rx, self.sig_s)
+        """The witness is uploaded by the first call and stays resident (any other upload on the same backend replaces it)."""
+        if getattr(self.backend, "resident", None) is not self:
+            self.backend.upload_schnorr_witness(self.messages, self.sig_rx, self.sig_s)
+            self.backend.resident = self
         return self.backend.air_prove(Backend.AIR_SCHNORR, self.options)
 
 
