@@ -137,8 +137,8 @@ def other_configs(backend, queries=42):
     timed("range_2_16", "benches/range.rs range-proof AIR, 2^16 steps, blowup 8 (SYNTHETIC long accumulator: the reference's range trace is fixed at 64 rows)",
           lambda: backend.range_prove_bits(opt, rng_words, 16), 1 << 16, 2, 10)
     one = RangeProofExample(opt, 12345 << 3, backend)
-    timed("range_64", "benches/range.rs range-proof AIR, the reference's own shape: 64 rows x 2 registers", one.prove, 64, 2, 20, stages=False,
-          note="one call per proof: host-API bound (about 25 launches and 6 channel round trips); the batched call below is the throughput path")
+    timed("range_64", "benches/range.rs range-proof AIR, the reference's own shape: 64 rows x 2 registers", one.prove, 64, 2, 20,
+          note="one call per proof: host-API bound (about 150 launches and round trips); the batched call below is the throughput path")
     numbers = [(12345 + i) << 3 for i in range(1024)]
     if hasattr(backend, "range_prove_batch"):
         backend.range_prove_batch(opt, numbers[:64])

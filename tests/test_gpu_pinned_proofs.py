@@ -223,8 +223,8 @@ def test_batched_range_proofs_equal_single_proofs(oracle, backend, opts):
     proofs = backend.range_prove_batch(options(opts), numbers)
     assert len(proofs) == len(values)
     for i, proof in enumerate(proofs):
-        assert proof == backend.air_prove(Backend.AIR_RANGE, options(opts), int(numbers[i])), i     # a batch of one
-        if i < 24:   # the generic prover (cstark_range_prove_bits at 64 rows never takes the batch path)
+        assert proof == backend.air_prove(Backend.AIR_RANGE, options(opts), int(numbers[i])), i
+        if i < 24:   # cstark_range_prove_bits at 64 rows: the generic prover whatever CSTARK_RANGE_VIA_BATCH says
             assert proof == backend.range_prove_bits(options(opts), np.array([values[i] % oracle.P], np.uint64), 6), i
         if i < 8:
             assert proof == OP.prove_air(oracle.AIR_RANGE, int(numbers[i]), opts)
