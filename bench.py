@@ -525,8 +525,8 @@ def main():
                                 "(profiles/*_valu_pmc.csv, *_valu_issue_bench.txt)")
         roofline_stages = [roofline_lde] + ([] if coset_mode else [roofline_rounds])
         if args.mode == "prove":
-            roofline_stages.append(entry("row hashes + Merkle tree of the trace commitment (k_hash_rows + k_merkle_level/top)", ab["hash_rows"] + ab["merkle"],
-                                         stage_ms["commit"], ["k_hash_rows", "k_merkle_level2", "k_merkle_level", "k_merkle_top"],
+            roofline_stages.append(entry("row hashes + Merkle tree of the trace commitment (k_hash_rows + k_merkle_level2 / k_merkle_quad)", ab["hash_rows"] + ab["merkle"],
+                                         stage_ms["commit"], ["k_hash_rows", "k_merkle_level2", "k_merkle_level", "k_merkle_top", "k_merkle_quad"],
                                          "the one HBM-shaped stage; k_hash_rows moves exactly its algorithmic bytes; `traffic` is per kernel NAME and so also "
                                          "holds the small FRI-layer hashes and the composition / layer trees of a proof (about +0.5 GB)"))
             roofline_stages.append(entry("constraint evaluation stage (all launches)", ab["constraints"], stage_ms["constraints"],

@@ -16,7 +16,7 @@ R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs"
-python3 bench.py --steps 8 --warmup 2 > $O/${TAG}_bench_prove.json 2> $O/${TAG}_bench_prove.err || exit 1
+python3 bench.py > $O/${TAG}_bench_prove.json 2> $O/${TAG}_bench_prove.err || exit 1
 python3 tools/modmul_bench.py > $O/${TAG}_modmul.txt 2>&1 || exit 1
 rm -rf $O/prof_$TAG
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$TAG/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $O/${TAG}_bench_under_rocprof.json 2> $O/prof_$TAG.stats.err) || exit 1
