@@ -116,3 +116,39 @@ def test_sub_air_proofs_over_extension_fields(oracle, backend, ext):
     w.messages[1, 15] ^= np.uint64(2)
     with pytest.raises(V.VerifierError):
         V.verify_schnorr(proof, w)
+
+
+def _switch_digests():
+    """sha256 of one proof per sub-AIR (and one with an extension field), on a fresh backend: what the child process of the test below
+    prints and what the test itself computes with the default paths."""
+    import hashlib
+    from certificate_stark_amd.backend import Backend
+    from certificate_stark_amd.prover import MerkleExample, ProofOptions, RangeProofExample, SchnorrExample, TransactionMetadata
+    b = Backend()
+    try:
+        opt = ProofOptions(*OPTS)
+        out = [hashlib.sha256(MerkleExample(opt, TransactionMetadata.build_random(8, 15, seed=39), b).prove()).hexdigest(),
+               hashlib.sha256(SchnorrExample.build_random(opt, 8, seed=508, backend=b).prove()).hexdigest(),
+               hashlib.sha256(SchnorrExample.build_random(ProofOptions(42, 8, 0, 0, 1, 4, 256), 8, seed=509, backend=b).prove()).hexdigest(),
+               hashlib.sha256(RangeProofExample(opt, 12345 << 3, b).prove()).hexdigest()]
+    finally:
+        b.close()
+    return out
+
+
+def test_alternative_sub_air_paths_give_the_same_bytes():
+    """The sub-AIR provers choose their kernels by switches read once per process: SchnorrAir's degree split and overlapped ladders,
+    MerkleAir's folded round gadgets, the four-lane Merkle tails, the cached assertion divisors, the 8-lane host coin, a single range
+    proof as a batch of one.  A child process with every switch on its other setting must produce the same proofs, byte for byte."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_gpu_prove_small_airs import _switch_digests\n"
+            "print(' '.join(_switch_digests()))\n") % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, CSTARK_SCHNORR_SPLIT="0", CSTARK_SCHNORR_OVERLAP="0", CSTARK_MERKLE_ROUNDS="0", CSTARK_MERKLE_QUAD="0",
+               CSTARK_AIR_INV_TABLES="0", CSTARK_COIN_SCALAR="1", CSTARK_RANGE_VIA_BATCH="1")
+    got = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert got.returncode == 0, got.stderr[-2000:]
+    assert got.stdout.strip().splitlines()[-1].split() == _switch_digests()
