@@ -593,7 +593,10 @@ hipError_t launch_trace_gen_split(const TxWitnessDev &w, fp *d_trace, hipStream_
     hipLaunchKernelGGL((k_trace_schnorr_hash<false, CS_RECUR_TILE_ROWS>), dim3(w.n_tx), dim3(64), 0, side_b, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_aux<2>, dim3(w.n_tx, 4), dim3(256), 0, side_b, w, d_trace, n);
     if ((e = hipEventRecord(mid_b, side_b)) != hipSuccess) return e;
-    hipLaunchKernelGGL((k_trace_schnorr_ec<false, 16>), dim3(2 * w.n_tx), dim3(64), ladder_lds_pad(), side_b, w, d_trace, n);
+    static const int ec_rows = [] { const char *e = getenv("CSTARK_EC_TILE_ROWS"); return e ? atoi(e) : 16; }(); // tuning: rows per flush of the ladders
+    if (ec_rows == 64) hipLaunchKernelGGL((k_trace_schnorr_ec<false, 64>), dim3(2 * w.n_tx), dim3(64), ladder_lds_pad(), side_b, w, d_trace, n);
+    else if (ec_rows == 32) hipLaunchKernelGGL((k_trace_schnorr_ec<false, 32>), dim3(2 * w.n_tx), dim3(64), ladder_lds_pad(), side_b, w, d_trace, n);
+    else hipLaunchKernelGGL((k_trace_schnorr_ec<false, 16>), dim3(2 * w.n_tx), dim3(64), ladder_lds_pad(), side_b, w, d_trace, n);
     hipLaunchKernelGGL(k_trace_schnorr_final<false>, dim3(w.n_tx), dim3(64), 0, side_b, d_trace, n);
     if ((e = hipEventRecord(join_b, side_b)) != hipSuccess) return e;
     return hipGetLastError();
