@@ -1611,12 +1611,6 @@ __device__ __forceinline__ void lin_all_split(const CS_CONST fp *coefs, const Fr
                 if (blk == 0) { si13 = ca7; s_set.term(NONCE_UPD_RES, fp_sub(cb7, fp_add(ca7, FP_ONE))); }
                 else s_set.term(VALUE_RES + 24, fp_sub(ca7, cb7));
             }
-#ifdef CS_LIN_ALL_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0); // keep the next iteration's loads out of this one (the scheduler otherwise hoists them all)
-#endif
-#ifdef CS_LIN_ALL_MEM_BARRIER
-            asm volatile("" ::: "memory"); // compiler-level: no load of a later iteration is moved above this point
-#endif
         }
         sa.flush<G0 | G1 | G2>(hash_copy, tot);
         sb.flush<G0 | G1 | G2>(hash_init, tot);
