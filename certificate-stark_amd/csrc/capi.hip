@@ -314,6 +314,19 @@ int cstark_ctx_create(int device, void *stream, cstark_ctx **out) {
     *out = c;
     return CSTARK_OK;
 }
+int cstark_ctx_create_own_stream(int device, cstark_ctx **out) {
+    if (!out) return fail(CSTARK_ERR_INVALID_ARG, "cstark_ctx_create_own_stream: out is null");
+    RC_TRY(cstark_ctx_create(device, nullptr, out));
+    cstark_ctx *c = *out;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        c->stream = nullptr;
+        cstark_ctx_destroy(c);
+        *out = nullptr;
+        return fail(CSTARK_ERR_HIP, "could not create the context's stream");
+    }
+    c->owns_stream = true;
+    return CSTARK_OK;
+}
 
 void cstark_ctx_destroy(cstark_ctx *c) {
     if (!c) return;
@@ -343,6 +356,7 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     if (c->arena) cs::prove_arena_free(c->arena);
     for (hipEvent_t e : c->part_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->lde_ev) (void)hipEventDestroy(e);
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 

@@ -85,6 +85,7 @@ void prove_arena_free(ProveArena *a);
 struct cstark_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = false; // cstark_ctx_create_own_stream: destroyed with the context
     hipStream_t side = nullptr, side2 = nullptr; // internal streams (forked from / joined into `stream`)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_mid = nullptr;
     // uploaded witness

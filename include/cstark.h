@@ -102,6 +102,9 @@ typedef struct cstark_ctx cstark_ctx;
 /* device < 0: current HIP device.  stream: the hipStream_t every launch of this context goes to
  * (NULL = HIP's default stream).  Work is asynchronous; cstark_ctx_synchronize() waits for it. */
 int cstark_ctx_create(int device, void *stream, cstark_ctx **out);
+/* The same with a stream of the context's own (non-blocking, destroyed with the context): for callers that do not link HIP, and
+ * for several contexts working side by side -- contexts that share a stream (e.g. the default one) serialise their work on it. */
+int cstark_ctx_create_own_stream(int device, cstark_ctx **out);
 void cstark_ctx_destroy(cstark_ctx *ctx);
 const char *cstark_last_error(void);
 const char *cstark_version(void);

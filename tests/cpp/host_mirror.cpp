@@ -45,6 +45,23 @@ int main(int argc, char **argv) {
             dump(prefix + ".range", proofs[1].data(), proofs[1].size());
         }
         if (!batch_ok) { std::fprintf(stderr, "batched range proofs differ from the single proofs\n"); return 4; }
+        // several proofs in flight on one GPU: every proof equals the one proved alone; a bad witness fails its own future only
+        bool pool_ok = true;
+        {
+            cstark::ProverPool pool(options, 2);
+            std::vector<cstark::TransactionMetadata> metas;
+            std::vector<std::future<std::vector<uint8_t>>> futures;
+            for (int t = 0; t < 5; t++) metas.push_back(cstark::TransactionMetadata::build_random(4, 3, 100 + t));
+            for (const auto &m : metas) futures.push_back(pool.submit(m));
+            cstark::TransactionMetadata broken = metas[0];
+            broken.deltas.pop_back();
+            std::future<std::vector<uint8_t>> bad = pool.submit(broken);
+            for (size_t t = 0; t < metas.size(); t++) pool_ok = pool_ok && futures[t].get() == cstark::TransactionProver(options, ctx).prove(metas[t]);
+            bool threw = false;
+            try { bad.get(); } catch (const cstark::Error &) { threw = true; }
+            pool_ok = pool_ok && threw;
+        }
+        if (!pool_ok) { std::fprintf(stderr, "proofs of the pool differ from proofs proved alone\n"); return 5; }
         std::printf("proof_bytes=%zu refused=%d length_checked=%d trace_ms=%.3f\n", proof.size(), (int)refused, (int)length_checked, ms[0]);
         return refused && length_checked ? 0 : 1;
     } catch (const std::exception &e) {

@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "certificate-stark_amd")
 def build_program(tmp):
     exe = os.path.join(tmp, "host_mirror")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "host_mirror.cpp"),
-                           "-o", exe, "-L", PKG, "-lcstark_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-o", exe, "-pthread", "-L", PKG, "-lcstark_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
