@@ -9,6 +9,9 @@ namespace cs {
 hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, unsigned log_n, unsigned log_b, unsigned k0, unsigned nk,
                      hipStream_t stream);
 // d_nodes: 2 * 2^log_leaves digests, leaves in the upper half; fills nodes[1 .. 2^log_leaves)
+// The Blake3 coin of one FRI layer on the device: d_seed (8 words) <- Blake3(seed || root), *d_alpha = the drawn field element (memory
+// form), d_root_out <- the root (8 words).  Same bytes as the host coin of prove.hip.
+hipError_t fri_coin(uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, hipStream_t stream);
 hipError_t merkle_build(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream);
 // the same two stages with SHA3-256 (sha3.hip)
 hipError_t hash_rows_sha3(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, unsigned log_n, unsigned log_b, unsigned k0, unsigned nk,

@@ -199,15 +199,16 @@ __constant__ uint32_t c_quad_sched[4][7] = { // lane c, round r: bytes = message
 };
 template <int CTRL>
 __device__ __forceinline__ uint32_t quad_perm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
-// Blake3 of the 64-byte message m[0..15] (LDS) by the four lanes of a quad: lane c returns words c and 4 + c of the digest
-__device__ __forceinline__ void quad_hash64(const uint32_t *m, const uint32_t (&sched)[7], unsigned c, uint32_t &lo, uint32_t &hi) {
+// Blake3 of the single-block message m[0..15] (LDS; block_len bytes, zero-padded) by the four lanes of a quad: lane c returns words c
+// and 4 + c of the digest
+__device__ __forceinline__ void quad_hash_block(const uint32_t *m, const uint32_t (&sched)[7], unsigned c, uint32_t block_len, uint32_t &lo, uint32_t &hi) {
     uint32_t w[28];
 #pragma unroll
     for (int r = 0; r < 7; r++)
 #pragma unroll
         for (int q = 0; q < 4; q++) w[4 * r + q] = m[(sched[r] >> (8 * q)) & 15];
     const uint32_t iv_lo = c == 0 ? IV0 : c == 1 ? IV1 : c == 2 ? IV2 : IV3, iv_hi = c == 0 ? IV4 : c == 1 ? IV5 : c == 2 ? IV6 : IV7;
-    uint32_t a = iv_lo, b = iv_hi, cc = iv_lo, d = c == 2 ? 64u : c == 3 ? (uint32_t)(CHUNK_START | CHUNK_END | ROOT) : 0u;
+    uint32_t a = iv_lo, b = iv_hi, cc = iv_lo, d = c == 2 ? block_len : c == 3 ? (uint32_t)(CHUNK_START | CHUNK_END | ROOT) : 0u;
 #pragma unroll
     for (int r = 0; r < 7; r++) {
         B3_G(a, b, cc, d, w[4 * r], w[4 * r + 1])
@@ -217,6 +218,52 @@ __device__ __forceinline__ void quad_hash64(const uint32_t *m, const uint32_t (&
     }
     lo = a ^ cc;
     hi = b ^ d;
+}
+__device__ __forceinline__ void quad_hash64(const uint32_t *m, const uint32_t (&sched)[7], unsigned c, uint32_t &lo, uint32_t &hi) {
+    quad_hash_block(m, sched, c, 64u, lo, hi);
+}
+// The public coin of a FRI layer on the device (prove.hip's Coin::reseed + Coin::draw for the Blake3 coin, same bytes):
+//   seed <- Blake3(seed || root);  alpha = the first of Blake3(seed || le64(counter))[0..8), counter = FIRST_COUNTER, ..., that is a field
+//   element (CSTARK_CONV_COIN_REJECT_ABOVE_P; otherwise the first one, reduced), in memory form.
+// One wave: every quad recomputes the new seed, then the sixteen quads try sixteen consecutive counters at a time.  The root is also
+// copied to root_out, so that the host collects all layer roots with one transfer after the last layer.
+__global__ __launch_bounds__(64) void k_fri_coin(uint32_t *__restrict__ seed, const uint8_t *__restrict__ root, uint64_t *__restrict__ alpha_out,
+                                                 uint32_t *__restrict__ root_out) {
+    __shared__ uint32_t msg[16][16];
+    const unsigned tid = threadIdx.x, quad = tid >> 2, c = tid & 3;
+    uint32_t sched[7];
+#pragma unroll
+    for (int r = 0; r < 7; r++) sched[r] = c_quad_sched[c][r];
+    const uint32_t *rw = reinterpret_cast<const uint32_t *>(root);
+    const uint32_t r_lo = rw[c], r_hi = rw[4 + c];
+    if (quad == 0) { root_out[c] = r_lo; root_out[4 + c] = r_hi; }
+    uint32_t *m = msg[quad];
+    m[c] = seed[c]; m[4 + c] = seed[4 + c]; m[8 + c] = r_lo; m[12 + c] = r_hi;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t s_lo, s_hi;
+    quad_hash64(m, sched, c, s_lo, s_hi); // the reseeded coin: words c and 4 + c
+    __builtin_amdgcn_wave_barrier();
+    uint64_t counter = CSTARK_CONV_COIN_FIRST_COUNTER;
+    for (;;) {
+        const uint64_t ctr = counter + quad;
+        m[c] = s_lo; m[4 + c] = s_hi;
+        m[8 + c] = c == 0 ? (uint32_t)ctr : c == 1 ? (uint32_t)(ctr >> 32) : 0u;
+        m[12 + c] = 0;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t lo, hi;
+        quad_hash_block(m, sched, c, 40u, lo, hi);
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t v = (uint64_t)__shfl(lo, (int)(quad * 4)) | (uint64_t)__shfl(lo, (int)(quad * 4 + 1)) << 32; // digest words 0, 1
+        const bool ok = !CSTARK_CONV_COIN_REJECT_ABOVE_P || v < FP_P;
+        const uint64_t votes = __ballot(ok && c == 0);
+        if (votes) {
+            const unsigned first = (unsigned)__builtin_ctzll(votes) >> 2; // lowest counter that was accepted
+            if (quad == first && c == 0) *alpha_out = fp_from_u64(v);
+            break;
+        }
+        counter += 16;
+    }
+    if (quad == 0) { seed[c] = s_lo; seed[4 + c] = s_hi; }
 }
 // Workgroup w reduces the parents [cnt + P0 w, cnt + P0 (w + 1)), P0 = min(cnt, 256), through `levels` levels (P0 >> (levels - 1) >= 1).
 // cnt: a power of two; grid = cnt / P0.
@@ -319,6 +366,10 @@ hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, u
     return hipGetLastError();
 }
 
+hipError_t fri_coin(uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fri_coin, dim3(1), dim3(64), 0, stream, d_seed, d_root, d_alpha, d_root_out);
+    return hipGetLastError();
+}
 hipError_t merkle_build(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream) {
     size_t cnt = ((size_t)1 << log_leaves) >> 1;
     static const bool quad = [] { const char *e = getenv("CSTARK_MERKLE_QUAD"); return !e || atoi(e) != 0; }(); // 0 (tuning / debugging): lane-per-node kernels throughout

@@ -585,6 +585,18 @@ int cstark_evaluate_polys_at_ext(cstark_ctx *c, const uint64_t *d_coeffs, uint32
     return CSTARK_OK;
 }
 } // extern "C"
+
+// internal (ctx.h): one FRI layer's coin on the device (Blake3 coin: reseed with the layer root at d_root, draw the folding point) and the
+// fold with that point; d_state = [seed: 8 words][alpha: one element per layer][roots: 8 words per layer]
+int fri_coin_fold4_dev(cstark_ctx *c, uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, const uint64_t *d_evals,
+                       uint64_t *d_out, uint32_t log_n, uint64_t domain_offset) {
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "layer size must be 2^6 .. 2^24");
+    const NttPlan *p;
+    RC_TRY(get_plan(c, log_n, &p));
+    HIP_TRY(cs::fri_coin(d_seed, d_root, d_alpha, d_root_out, c->stream));
+    HIP_TRY(cs::fri_fold4(d_evals, d_out, log_n, p->winv, cs::host::inv(domain_offset), 0, cs::host::inv(cs::host::from_u64(4)), c->stream, d_alpha));
+    return CSTARK_OK;
+}
 // internal (ctx.h): both halves of the out-of-domain frame with ONE upload, one readback and one wait -- the trace polynomials at
 // (z, z w) and the composition columns at z^b; out_trace [2][width], out_comp [n_comp] (host)
 int evaluate_ood_frames(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, const uint64_t *d_ccoef, uint32_t n_comp, uint32_t log_n,

@@ -123,6 +123,9 @@ struct cstark_ctx {
     void *rb_dev = nullptr, *rb_host = nullptr; // cstark_range_prove_batch: one device block and one pinned host block, carved per call
     size_t rb_dev_bytes = 0, rb_host_bytes = 0;
 };
+// internal (capi.hip): the coin of one FRI layer on the device followed by the fold with the drawn point (prove.hip)
+int fri_coin_fold4_dev(cstark_ctx *c, uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, const uint64_t *d_evals,
+                       uint64_t *d_out, uint32_t log_n, uint64_t domain_offset);
 // internal (capi.hip): the cached twiddle tables of a 2^log_n-point domain: powers of w and of its inverse (device, n entries each)
 int plan_tables(cstark_ctx *c, unsigned log_n, const uint64_t **w, const uint64_t **winv);
 

@@ -23,7 +23,8 @@ hipError_t poly_eval(const uint64_t *d_coeffs, unsigned width, unsigned log_n, c
                      uint64_t *d_scratch, hipStream_t stream);
 hipError_t deep_composition(const DeepParams &p, unsigned nk, hipStream_t stream);
 // N = 2^log_n evaluations over offset*<w_N> (natural order) -> N/4 evaluations of the alpha-folding over offset^4*<w_{N/4}>
+// d_alpha != null: the folding point is read from device memory instead of `alpha`
 hipError_t fri_fold4(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, const uint64_t *d_winv, uint64_t offset_inv, uint64_t alpha,
-                     uint64_t inv4, hipStream_t stream);
+                     uint64_t inv4, hipStream_t stream, const uint64_t *d_alpha = nullptr);
 
 } // namespace cs

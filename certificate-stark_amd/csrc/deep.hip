@@ -84,10 +84,12 @@ __global__ __launch_bounds__(256) void k_deep(DeepParams p) {
 // FRI layer folding, factor 4 [UPSTREAM-RECALL winterfell-fri apply_drp]: row i = { f(x_i zeta^t) } = evals[i + t N/4];
 // the cubic through the four points evaluated at alpha:  (1/4) sum_k (alpha / x_i)^k sum_t v_t zeta^(-t k).
 // winv = powers of w_N^-1 (x_i^-1 = offset^-1 * winv[i]); zeta^-1 = winv[N/4] is a primitive 4th root: zeta^-2 = -1.
+// alpha_dev != null: the folding point is read from device memory (drawn there by the device-side coin, blake3.hip k_fri_coin)
 __global__ __launch_bounds__(256) void k_fri_fold4(const fp *__restrict__ evals, fp *__restrict__ out, size_t q, const fp *__restrict__ winv,
-                                                   fp offset_inv, fp alpha, fp inv4) {
+                                                   fp offset_inv, fp alpha, fp inv4, const fp *__restrict__ alpha_dev) {
     const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
     if (i >= q) return;
+    if (alpha_dev) alpha = *alpha_dev;
     const fp v0 = evals[i], v1 = evals[i + q], v2 = evals[i + 2 * q], v3 = evals[i + 3 * q];
     const fp zi = winv[q]; // zeta^-1
     // size-4 inverse DFT: s_k = sum_t v_t zeta^(-t k)
@@ -102,9 +104,9 @@ __global__ __launch_bounds__(256) void k_fri_fold4(const fp *__restrict__ evals,
 } // namespace
 
 hipError_t fri_fold4(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, const uint64_t *d_winv, uint64_t offset_inv, uint64_t alpha,
-                     uint64_t inv4, hipStream_t stream) {
+                     uint64_t inv4, hipStream_t stream, const uint64_t *d_alpha) {
     const size_t q = ((size_t)1 << log_n) / 4;
-    hipLaunchKernelGGL(k_fri_fold4, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, alpha, inv4);
+    hipLaunchKernelGGL(k_fri_fold4, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, alpha, inv4, d_alpha);
     return hipGetLastError();
 }
 

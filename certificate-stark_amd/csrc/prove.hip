@@ -554,21 +554,39 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
     R.layer_roots.assign(32 * (size_t)n_layers, 0);
     uint64_t offset = host::lde_offset();
     unsigned lg = log_N;
+    // Blake3 coin: the layers' coin lives on the device (k_fri_coin: reseed with the layer's root, draw the folding point), so the host
+    // enqueues all layers at once and collects the roots with the remainder -- one wait instead of one per layer (8 x ~20 us of GPU
+    // idle time at 2^20 steps); it then replays the reseeds on its own coin.  CSTARK_FRI_DEVICE_COIN=0, and the Sha3 coin: the host
+    // draws every folding point between two launches.
+    static const bool dev_coin_env = [] { const char *e = getenv("CSTARK_FRI_DEVICE_COIN"); return !e || atoi(e) != 0; }();
+    const bool dev_coin = dev_coin_env && hf == 0 && n_layers > 0;
+    uint32_t *d_fri = nullptr; // [seed 8 words][alpha: 2 words per layer][roots: 8 words per layer]
+    if (dev_coin) {
+        RC_TRY(arena_extra(c, a, 41, &d_fri, (size_t)(8 + 10 * 32) * 4));
+        HIP_TRY(hipMemcpyAsync(d_fri, coin.seed, 32, hipMemcpyHostToDevice, st));
+    }
     for (unsigned l = 0; l < n_layers; l++) {
         const size_t rows = (size_t)1 << (lg - 2);
         RC_TRY(cstark_hash_rows_fn(c, hf, a->layer[l], a->lnodes[l] + 32 * rows, 4, lg - 2, 0, 0, 1));
         RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - 2));
-        HIP_TRY(hipMemcpyAsync(&R.layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
-        HIP_TRY(cs::stream_wait(st));
-        coin.reseed(&R.layer_roots[32 * l]);
-        const uint64_t alpha = coin.draw();
-        RC_TRY(cstark_fri_fold4(c, a->layer[l], a->layer[l + 1], lg, offset, alpha));
+        if (dev_coin) {
+            RC_TRY(fri_coin_fold4_dev(c, d_fri, a->lnodes[l] + 32, (uint64_t *)(d_fri + 8) + l, d_fri + 8 + 2 * 32 + 8 * l, a->layer[l], a->layer[l + 1], lg, offset));
+        } else {
+            HIP_TRY(hipMemcpyAsync(&R.layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
+            HIP_TRY(cs::stream_wait(st));
+            coin.reseed(&R.layer_roots[32 * l]);
+            const uint64_t alpha = coin.draw();
+            RC_TRY(cstark_fri_fold4(c, a->layer[l], a->layer[l + 1], lg, offset, alpha));
+        }
         offset = host::pow(offset, 4);
         lg -= 2;
     }
     R.remainder.assign((size_t)1 << lg, 0);
+    if (dev_coin) HIP_TRY(hipMemcpyAsync(R.layer_roots.data(), d_fri + 8 + 2 * 32, 32 * (size_t)n_layers, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(R.remainder.data(), a->layer[n_layers], R.remainder.size() * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(cs::stream_wait(st));
+    if (dev_coin)
+        for (unsigned l = 0; l < n_layers; l++) coin.reseed(&R.layer_roots[32 * l]); // the draws in between left no trace: reseed resets the counter
     hash_elements(hf, R.remainder.data(), R.remainder.size(), R.rem_commit);
     coin.reseed(R.rem_commit);
     STAGE();

@@ -138,8 +138,8 @@ def _switch_digests():
 
 def test_alternative_sub_air_paths_give_the_same_bytes():
     """The sub-AIR provers choose their kernels by switches read once per process: SchnorrAir's degree split and overlapped ladders,
-    MerkleAir's folded round gadgets, the four-lane Merkle tails, the cached assertion divisors, the 8-lane host coin, a single range
-    proof as a batch of one.  A child process with every switch on its other setting must produce the same proofs, byte for byte."""
+    MerkleAir's folded round gadgets, the four-lane Merkle tails, the cached assertion divisors, the 8-lane host coin, the device-side coin of the FRI layers, a single
+    range proof as a batch of one.  A child process with every switch on its other setting must produce the same proofs, byte for byte."""
     import os
     import subprocess
     import sys
@@ -148,7 +148,7 @@ def test_alternative_sub_air_paths_give_the_same_bytes():
             "from test_gpu_prove_small_airs import _switch_digests\n"
             "print(' '.join(_switch_digests()))\n") % (root, os.path.join(root, "tests"))
     env = dict(os.environ, CSTARK_SCHNORR_SPLIT="0", CSTARK_SCHNORR_OVERLAP="0", CSTARK_MERKLE_ROUNDS="0", CSTARK_MERKLE_QUAD="0",
-               CSTARK_AIR_INV_TABLES="0", CSTARK_COIN_SCALAR="1", CSTARK_RANGE_VIA_BATCH="1")
+               CSTARK_AIR_INV_TABLES="0", CSTARK_COIN_SCALAR="1", CSTARK_RANGE_VIA_BATCH="1", CSTARK_FRI_DEVICE_COIN="0")
     got = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert got.returncode == 0, got.stderr[-2000:]
     assert got.stdout.strip().splitlines()[-1].split() == _switch_digests()
