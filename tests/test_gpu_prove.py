@@ -285,7 +285,8 @@ def test_direct_and_split_prover_paths_give_the_same_bytes():
             "from test_gpu_prove import example\n"
             "print(hashlib.sha256(example(4, 15, seed=77).prove()).hexdigest())\n") % (root, os.path.join(root, "tests"))
     want = hashlib.sha256(example(4, 15, seed=77).prove()).hexdigest()
-    env = dict(os.environ, CSTARK_ROUNDS_SPLIT="0", CSTARK_TRACE_OVERLAP="0", CSTARK_SYNC_BLOCK="1")  # also: blocking channel waits
+    env = dict(os.environ, CSTARK_ROUNDS_SPLIT="0", CSTARK_TRACE_OVERLAP="0", CSTARK_SYNC_BLOCK="1",  # also: blocking channel waits,
+               CSTARK_MERKLE_QUAD="0", CSTARK_FRI_DEVICE_COIN="0", CSTARK_COIN_SCALAR="1")  # lane-per-node tree tails, host-side FRI and scalar coin
     got = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert got.returncode == 0, got.stderr[-2000:]
     assert got.stdout.strip().splitlines()[-1] == want
