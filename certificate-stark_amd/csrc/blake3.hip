@@ -244,7 +244,9 @@ __global__ __launch_bounds__(64) void k_fri_coin(uint32_t *__restrict__ seed, co
     quad_hash64(m, sched, c, s_lo, s_hi); // the reseeded coin: words c and 4 + c
     __builtin_amdgcn_wave_barrier();
     uint64_t counter = CSTARK_CONV_COIN_FIRST_COUNTER;
-    for (;;) {
+    // a candidate is a field element with probability 0.256: sixteen at a time, the loop ends after 1.01 passes on average; the bound
+    // (2^-6900 to be reached) only guarantees that the wave terminates whatever the hash does
+    for (int pass = 0; pass < 1024; pass++) {
         const uint64_t ctr = counter + quad;
         m[c] = s_lo; m[4 + c] = s_hi;
         m[8 + c] = c == 0 ? (uint32_t)ctr : c == 1 ? (uint32_t)(ctr >> 32) : 0u;
