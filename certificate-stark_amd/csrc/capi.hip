@@ -1363,7 +1363,10 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
             f.aux = pn->aux_w; f.aux_ps = t1->aux ? t1->aux + t1->aux_words : nullptr; f.aux_ps_batch_stride = 2 * t1->aux_words;
             f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
             HIP_TRY(cs::ntt_columns(f, c->stream));
-            HIP_TRY(cs::launch_schnorr_split_finish(p, d_schnorr_aux_lde, pt->tab, even, odd, t_grp[0], t_grp[6], c->stream));
+            // the round gadget of the message hash in the folded form (CSTARK_SCHNORR_ROUNDS=0: inside the frame evaluator)
+            static const bool rounds_env = [] { const char *e = getenv("CSTARK_SCHNORR_ROUNDS"); return !e || atoi(e) != 0; }();
+            HIP_TRY(cs::launch_schnorr_split_finish(p, d_schnorr_aux_lde, pt->tab, even, odd, t_grp[0], t_grp[6], c->stream,
+                                                    rounds_env ? (uint64_t *)c->desc_buf + mrt_off : nullptr, t_grp[42]));
         } else {
             HIP_TRY(cs::launch_schnorr_fused(p, d_schnorr_aux_lde, pt->tab, nk, c->stream));
         }

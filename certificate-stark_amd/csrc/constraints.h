@@ -86,7 +86,7 @@ hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, 
 constexpr int SCHNORR_SPLIT_TABLES = 8;
 hipError_t launch_schnorr_ec_split(const AirCombineParams &p, const uint64_t *aux, const uint64_t *d_coefs_tx_layout, uint64_t *d_even, hipStream_t stream);
 hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, const uint64_t *d_even, const uint64_t *d_odd,
-                                       unsigned g0, unsigned g1, hipStream_t stream);
+                                       unsigned g0, unsigned g1, hipStream_t stream, uint64_t *d_rtab = nullptr, unsigned round_group = 0);
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream);
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);

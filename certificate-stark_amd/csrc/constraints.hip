@@ -1939,7 +1939,8 @@ enum { SF_DBL0 = 0, SF_ADD0, SF_DBL1, SF_ADD1, SF_FINAL, SF_REST, SF_PARTS };
 // AFTER_SPLIT: the four doubling / addition parts came from the degree-split form (k_schnorr_ec_split + k_schnorr_split_finish wrote the
 // output first): every part here adds to it, and SF_REST also carries the terms of the two bit registers (slots 18, 37) that the split
 // curve families leave out
-template <int PART, bool AFTER_SPLIT = false>
+// FOLDED_ROUND (SF_REST): the Rescue round of the message hash is left to k_merkle_rounds<4, 1, 56, ...> (its folded form)
+template <int PART, bool AFTER_SPLIT = false, bool FOLDED_ROUND = false>
 __global__ __launch_bounds__(FNT, PART == SF_REST ? 2 : CS_EC_WAVES) void k_schnorr_fused(AirCombineParams p, const fp *__restrict__ aux,
                                                                                        const fp *__restrict__ ptab) {
     __shared__ fp xp_lds[AIR_MAX_GROUPS * FNT];
@@ -1976,7 +1977,7 @@ __global__ __launch_bounds__(FNT, PART == SF_REST ? 2 : CS_EC_WAVES) void k_schn
             acc.add(38 + i, addition, fp_sub(f.cur(38 + i), f.next(38 + i)));
             acc.add(38 + i, final_add, fp_sub(f.cur(38 + i), f.cur(42 + i)));
         }
-        enforce_round(acc, fr, 42, 42, hash_flag, 0, 0, false);
+        if (!FOLDED_ROUND) enforce_round(acc, fr, 42, 42, hash_flag, 0, 0, false);
 #pragma unroll 1
         for (int i = 0; i < 7; i++) {
             acc.add(42 + i, copy_hash, fp_sub(f.cur(42 + i), f.next(42 + i)));
@@ -2105,9 +2106,12 @@ __global__ __launch_bounds__(FNT, 2) void k_merkle_fused(AirCombineParams p, con
 // rtab (u64 words; sections = (window, {alpha, beta})): A[8][8 cosets][8] | limbs of U[8][14] | limbs of INV_MDS[196] | G[8][14]
 constexpr int MR_SECTIONS = 8, MR_A = 0, MR_UL = MR_SECTIONS * 64, MR_ML = MR_UL + MR_SECTIONS * 14 * 2, MR_G = MR_ML + 196 * 2, MR_SIZE = MR_G + MR_SECTIONS * 14;
 static_assert(MR_SIZE <= MERKLE_RTAB_WORDS, "MerkleAir rounds table");
+// W0: first Rescue window of the AIR in c_windows (MerkleAir 0..3, SchnorrAir's message hash 4); PCOLS / ARKCOL: columns of the AIR's
+// periodic table and the first of its 28 round-constant columns
+template <int W0, int PCOLS, int ARKCOL>
 __global__ void k_merkle_rounds_setup(const fp *__restrict__ t_alpha, const fp *__restrict__ t_beta, const fp *__restrict__ ptab, fp *__restrict__ rtab,
                                       unsigned n_cosets) {
-    const int sec = blockIdx.x, reg = c_windows[sec >> 1].reg, t = threadIdx.x;
+    const int sec = blockIdx.x, reg = c_windows[W0 + (sec >> 1)].reg, t = threadIdx.x;
     __shared__ fp gam[14];
     if (t < 14) gam[t] = ((sec & 1) ? t_beta : t_alpha)[reg + t];
     __syncthreads();
@@ -2123,11 +2127,14 @@ __global__ void k_merkle_rounds_setup(const fp *__restrict__ t_alpha, const fp *
         const unsigned k = t >> 3, r = t & 7;
         fp a = 0;
         if (k < n_cosets)
-            for (int i = 0; i < 14; i++) a = fp_add(a, fp_mul(gam[i], ptab[((size_t)k * 33 + 5 + i) * 512 + r]));
+            for (int i = 0; i < 14; i++) a = fp_add(a, fp_mul(gam[i], ptab[((size_t)k * PCOLS + ARKCOL + i) * 512 + r]));
         rtab[MR_A + sec * 64 + t] = a;
     }
 }
-// grid = (n / FNT, nk); xg = the degree group of the round slots (p.t_grp[S_INIT])
+// grid = (n / FNT, nk); xg = the degree group of the round slots (p.t_grp[S_INIT]).  The same kernel serves SchnorrAir's message hash
+// (one window, registers 42..55 of a 56-register frame, hash mask in periodic column 7): NWIN windows from c_windows[W0], WIDTH
+// registers per coset, FLAGCOL the mask; ADD: the sum is added to the output instead of written.
+template <int W0, int NWIN, int WIDTH, int PCOLS, int FLAGCOL, int ARKCOL, bool ADD>
 __global__ __launch_bounds__(FNT, 3) void k_merkle_rounds(AirCombineParams p, const fp *__restrict__ ptab, const fp *__restrict__ rtab, unsigned xg) {
     __shared__ fp ark2_lds[8 * 14];
     __shared__ __attribute__((aligned(16))) fp img_lds[(FNT / 64) * RW_IMG];
@@ -2136,10 +2143,10 @@ __global__ __launch_bounds__(FNT, 3) void k_merkle_rounds(AirCombineParams p, co
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kk = blockIdx.y, k = p.k0 + kk;
     if (k % p.stride) return; // uniform over the workgroup
-    const fp *base = p.lde + (size_t)kk * 65 * n;
+    const fp *base = p.lde + (size_t)kk * WIDTH * n;
     if (threadIdx.x < 8 * 14) {
         const unsigned r = threadIdx.x / 14, c = threadIdx.x % 14;
-        ark2_lds[threadIdx.x] = ptab[((size_t)k * 33 + 5 + 14 + c) * 512 + ((blockIdx.x * (size_t)FNT + r) & 511)];
+        ark2_lds[threadIdx.x] = ptab[((size_t)k * PCOLS + ARKCOL + 14 + c) * 512 + ((blockIdx.x * (size_t)FNT + r) & 511)];
     }
     if (threadIdx.x < MR_SECTIONS * 8) atab_lds[threadIdx.x] = rtab[MR_A + (threadIdx.x >> 3) * 64 + k * 8 + (threadIdx.x & 7)];
     __syncthreads();
@@ -2147,16 +2154,16 @@ __global__ __launch_bounds__(FNT, 3) void k_merkle_rounds(AirCombineParams p, co
     const unsigned jr = (unsigned)(j & 7);
     fp *img = img_lds + (threadIdx.x >> 6) * RW_IMG;
     const fp *ark2 = ark2_lds + jr * 14, *atab = atab_lds + jr;
-    const fp flag = ptab[((size_t)k * 33 + 4) * 512 + (j & 511)];
+    const fp flag = ptab[((size_t)k * PCOLS + FLAGCOL) * 512 + (j & 511)];
     const fp xp = fp_mul(p.tgrp_shift[k][xg], p.w[(j * p.tgrp_adj[xg]) & (n - 1)]);
     const CS_CONST uint32_t *ul = as_const((const uint32_t *)(rtab + MR_UL)), *ml = as_const((const uint32_t *)(rtab + MR_ML));
     const CS_CONST fp *gt = as_const(rtab + MR_G);
     const fp *rows = base + j + lane; // rows j0 + 2 lane, + 1 of the wave's window (j0 = j - lane); rows n, n + 1 wrap to 0, 1
     if (lane == 32 && ((j - lane + 64) & (n - 1)) == 0) rows -= n;
-    rounds_fetch_window(rows, n, c_windows[0].reg, lane, img);
+    rounds_fetch_window(rows, n, c_windows[W0].reg, lane, img);
     fp ta = 0, tb = 0;
 #pragma unroll 1
-    for (int wdx = 0; wdx < 4; wdx++) {
+    for (int wdx = 0; wdx < NWIN; wdx++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         fp d[14];
 #pragma unroll
@@ -2173,9 +2180,9 @@ __global__ __launch_bounds__(FNT, 3) void k_merkle_rounds(AirCombineParams p, co
         fp cube[14];
 #pragma unroll
         for (int jj = 0; jj < 14; jj++) cube[jj] = fp_cube(img[jj * RW_ROWS + lane]);
-        if (wdx < 3) { // the image is free again: the next window arrives behind the forward half
+        if (wdx + 1 < NWIN) { // the image is free again: the next window arrives behind the forward half
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            rounds_fetch_window(rows, n, c_windows[wdx + 1].reg, lane, img);
+            rounds_fetch_window(rows, n, c_windows[W0 + wdx + 1].reg, lane, img);
         }
         acc_fold(sa); acc_fold(sb);
         const fp fa = fp_add(dot14l(ul + (wdx * 2) * 56, cube), atab[(wdx * 2) * 8]);
@@ -2183,7 +2190,9 @@ __global__ __launch_bounds__(FNT, 3) void k_merkle_rounds(AirCombineParams p, co
         ta = fp_add(ta, fp_sub(acc_reduce(sa), fa));
         tb = fp_add(tb, fp_sub(acc_reduce(sb), fb));
     }
-    p.out[(size_t)kk * n + j] = fp_mul(flag, fp_add(ta, fp_mul(xp, tb)));
+    const fp v = fp_mul(flag, fp_add(ta, fp_mul(xp, tb)));
+    fp *o = p.out + (size_t)kk * n + j;
+    *o = ADD ? fp_add(*o, v) : v;
 }
 
 // RangeProofAir::evaluate_transition  src/range/air.rs:60-98 (enforce_double_and_add_step with flag ONE)
@@ -2319,13 +2328,19 @@ hipError_t launch_schnorr_ec_split(const AirCombineParams &p, const uint64_t *au
     return hipGetLastError();
 }
 hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, const uint64_t *d_even, const uint64_t *d_odd,
-                                       unsigned g0, unsigned g1, hipStream_t stream) {
+                                       unsigned g0, unsigned g1, hipStream_t stream, uint64_t *d_rtab, unsigned round_group) {
     const size_t n = (size_t)1 << p.log_n;
     if (n % FNT) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_schnorr_split_finish, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd, ptab, g0, g1);
     const dim3 grid((unsigned)(n / FNT), 8), block(FNT);
     hipLaunchKernelGGL((k_schnorr_fused<SF_FINAL, true>), grid, block, 0, stream, p, aux, ptab);
-    hipLaunchKernelGGL((k_schnorr_fused<SF_REST, true>), grid, block, 0, stream, p, aux, ptab);
+    if (d_rtab) { // the message hash's round gadget in the folded form (as MerkleAir's four), added to the output
+        hipLaunchKernelGGL((k_merkle_rounds_setup<4, 36, 8>), dim3(2), dim3(64), 0, stream, p.t_alpha, p.t_beta, ptab, d_rtab, 8u);
+        hipLaunchKernelGGL((k_merkle_rounds<4, 1, 56, 36, 7, 8, true>), grid, block, 0, stream, p, ptab, (const fp *)d_rtab, round_group);
+        hipLaunchKernelGGL((k_schnorr_fused<SF_REST, true, true>), grid, block, 0, stream, p, aux, ptab);
+    } else {
+        hipLaunchKernelGGL((k_schnorr_fused<SF_REST, true>), grid, block, 0, stream, p, aux, ptab);
+    }
     return hipGetLastError();
 }
 hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream, uint64_t *d_rtab, unsigned round_group) {
@@ -2337,8 +2352,8 @@ hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, 
         return hipGetLastError();
     }
     if (p.k0 + nk > 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_merkle_rounds_setup, dim3(MR_SECTIONS), dim3(64), 0, stream, p.t_alpha, p.t_beta, ptab, d_rtab, p.k0 + nk);
-    hipLaunchKernelGGL(k_merkle_rounds, grid, dim3(FNT), 0, stream, p, ptab, (const fp *)d_rtab, round_group);
+    hipLaunchKernelGGL((k_merkle_rounds_setup<0, 33, 5>), dim3(MR_SECTIONS), dim3(64), 0, stream, p.t_alpha, p.t_beta, ptab, d_rtab, p.k0 + nk);
+    hipLaunchKernelGGL((k_merkle_rounds<0, 4, 65, 33, 4, 5, false>), grid, dim3(FNT), 0, stream, p, ptab, (const fp *)d_rtab, round_group);
     hipLaunchKernelGGL(k_merkle_fused<true>, grid, dim3(FNT), 0, stream, p, ptab);
     return hipGetLastError();
 }

@@ -147,8 +147,13 @@ def test_alternative_sub_air_paths_give_the_same_bytes():
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "from test_gpu_prove_small_airs import _switch_digests\n"
             "print(' '.join(_switch_digests()))\n") % (root, os.path.join(root, "tests"))
-    env = dict(os.environ, CSTARK_SCHNORR_SPLIT="0", CSTARK_SCHNORR_OVERLAP="0", CSTARK_MERKLE_ROUNDS="0", CSTARK_MERKLE_QUAD="0",
+    env = dict(os.environ, CSTARK_SCHNORR_SPLIT="0", CSTARK_SCHNORR_OVERLAP="0", CSTARK_MERKLE_ROUNDS="0", CSTARK_MERKLE_QUAD="0",  # (without the
+               # split the folded round of SchnorrAir's hash is not used either; CSTARK_SCHNORR_ROUNDS=0 alone: second child below)
                CSTARK_AIR_INV_TABLES="0", CSTARK_COIN_SCALAR="1", CSTARK_RANGE_VIA_BATCH="1", CSTARK_FRI_DEVICE_COIN="0")
     got = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert got.returncode == 0, got.stderr[-2000:]
-    assert got.stdout.strip().splitlines()[-1].split() == _switch_digests()
+    want = _switch_digests()
+    assert got.stdout.strip().splitlines()[-1].split() == want
+    got = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTARK_SCHNORR_ROUNDS="0"), capture_output=True, text=True, timeout=600)
+    assert got.returncode == 0, got.stderr[-2000:]
+    assert got.stdout.strip().splitlines()[-1].split() == want
