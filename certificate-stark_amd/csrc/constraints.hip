@@ -1163,8 +1163,9 @@ __global__ __launch_bounds__(256) void k_final_hi(CeParams p, const fp *__restri
     hi[((size_t)c * 2 + q) * n + j] = fp_mul(fp_sub(t, direct[((size_t)c * 2 + q) * n + j]), half);
 }
 
-template <int M>
-__device__ __forceinline__ void fused_merkle_auth_rest(Fused<M> &acc, const Frame &f, int base, fp tx_hash, fp hash_copy, fp hash_init) {
+// A: Fused<M>, or any accumulator with its interface for M sets (AirSumView below: the standalone MerkleAir)
+template <int M, class A>
+__device__ __forceinline__ void fused_merkle_auth_rest_sets(A &acc, const Frame &f, int base, fp tx_hash, fp hash_copy, fp hash_init) {
     const fp bit = f.next(base + 14), not_bit = c_not(bit);
     acc.begin();
     acc.term(base + 14, c_is_binary(bit));
@@ -1209,6 +1210,11 @@ __device__ __forceinline__ void fused_merkle_auth_rest(Fused<M> &acc, const Fram
         acc_fold(s_copy[c]);
         acc.add(c, fp_add(fp_mul(hash_copy, acc_reduce(s_copy[c])), fp_mul(hash_init, acc_reduce(s_init[c]))));
     }
+}
+
+template <int M>
+__device__ __forceinline__ void fused_merkle_auth_rest(Fused<M> &acc, const Frame &f, int base, fp tx_hash, fp hash_copy, fp hash_init) {
+    fused_merkle_auth_rest_sets<M>(acc, f, base, tx_hash, hash_copy, hash_init);
 }
 
 // setup + value-copy constraints (src/air.rs:406-529)
@@ -2076,6 +2082,48 @@ __global__ __launch_bounds__(256) void k_schnorr_split_finish(AirCombineParams p
 
 // MerkleAir, fused: the same body as k_eval_transitions_merkle behind the table-driven accumulator; one value per point of the
 // cosets of the constraint-evaluation domain (the others are left alone: k_air_combine writes their zeros).
+// MerkleAir without its round gadgets, for the table-driven accumulator: the same terms as merkle_transitions<false>, grouped by their
+// flag into sections (one multiply-accumulate per term and one reduction per section instead of three field products per term; the two
+// authentication-path blocks through the TransactionAir evaluator's fused_merkle_auth_rest).  Exact arithmetic: the same sum.
+struct AirSumView { // the interface of Fused<1> over an AirSum
+    AirSum &a;
+    __device__ __forceinline__ fp coef(int, int i) const { return a.coef(i); }
+    __device__ __forceinline__ void begin() { a.begin(); }
+    __device__ __forceinline__ void term(int i, fp v) { a.term(i, v); }
+    __device__ __forceinline__ void end(fp flag) { a.end(flag); }
+    __device__ __forceinline__ void add(int, fp v) { a.total = fp_add(a.total, v); }
+};
+__device__ __forceinline__ void merkle_linear_sections(AirSum &acc, const Frame &f) {
+    const fp setup = f.pv(0), tx_hash = f.pv(1), hash_input = f.pv(2), finish = f.pv(3), hash_flag = f.pv(4);
+    acc.begin();
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) {
+        acc.term(VALUE_RES + i, fp_sub(f.cur(S_INIT + i), f.cur(S_UPD + i)));
+        acc.term(VALUE_RES + 12 + i, fp_sub(f.cur(R_INIT + i), f.cur(R_UPD + i)));
+    }
+    acc.term(VALUE_RES + 24, fp_sub(f.cur(R_INIT + 13), f.cur(R_UPD + 13)));
+    acc.term(BALANCE_RES, fp_sub(fp_sub(f.cur(S_INIT + 12), f.cur(S_UPD + 12)), fp_sub(f.cur(R_UPD + 12), f.cur(R_INIT + 12))));
+    acc.term(NONCE_UPD_RES, fp_sub(f.cur(S_UPD + 13), fp_add(f.cur(S_INIT + 13), FP_ONE)));
+    acc.end(setup);
+    {
+        const fp hash_copy = fp_mul(tx_hash, c_not(fp_add(hash_flag, hash_input))), hash_init = fp_mul(tx_hash, hash_input);
+        AirSumView v{acc};
+        fused_merkle_auth_rest_sets<1>(v, f, S_INIT, tx_hash, hash_copy, hash_init);
+        fused_merkle_auth_rest_sets<1>(v, f, R_INIT, tx_hash, hash_copy, hash_init);
+    }
+    acc.begin();
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) acc.term(PREV_ROOT + i, fp_sub(f.next(PREV_ROOT + i), f.cur(PREV_ROOT + i)));
+    acc.end(c_not(finish));
+    acc.begin();
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) {
+        acc.term(PREV_ROOT + i, fp_sub(f.next(PREV_ROOT + i), f.next(R_UPD + i)));
+        acc.term(INT_ROOT_RES + i, fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)));
+        acc.term(PREV_MATCH_RES + i, fp_sub(f.next(S_INIT + i), f.cur(PREV_ROOT + i)));
+    }
+    acc.end(finish);
+}
 // AFTER_ROUNDS: k_merkle_rounds wrote the four round gadgets' sum first; this kernel adds every other constraint to it.
 template <bool AFTER_ROUNDS>
 __global__ __launch_bounds__(FNT, 2) void k_merkle_fused(AirCombineParams p, const fp *__restrict__ ptab) {
@@ -2093,7 +2141,8 @@ __global__ __launch_bounds__(FNT, 2) void k_merkle_fused(AirCombineParams p, con
     f.pcycle = 512;
     for (unsigned g = 0; g < p.n_tgrp; g++) xp_lds[g * FNT + threadIdx.x] = fp_mul(p.tgrp_shift[k][g], p.w[(j * p.tgrp_adj[g]) & (n - 1)]);
     AirSum acc{as_const(p.t_alpha), as_const(p.t_beta), as_const(p.t_grp), xp_lds, acc_zero(), 0, 0};
-    merkle_transitions<!AFTER_ROUNDS>(acc, f);
+    if (AFTER_ROUNDS) merkle_linear_sections(acc, f);
+    else merkle_transitions<true>(acc, f);
     fp *o = p.out + (size_t)kk * n + j;
     *o = AFTER_ROUNDS ? fp_add(*o, acc.total) : acc.total;
 }
