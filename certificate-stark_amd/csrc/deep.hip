@@ -14,7 +14,10 @@ namespace {
 // coefficients of one column, every lane reads them with stride 256 (coalesced 2 KB per wave-row) and runs one Horner chain
 // in z^256 per point; the column is read from HBM once for all points.  partial[(p * width + c) * segments + s] =
 // sum over the segment of c_m z_p^m.  Pass 2 adds the segments.
-constexpr int PE_SEG = 16384, PE_MAXPTS = 2;
+#ifndef CS_PE_SEG
+#define CS_PE_SEG 16384
+#endif
+constexpr int PE_SEG = CS_PE_SEG, PE_MAXPTS = 2;
 template <int NP>
 __global__ __launch_bounds__(256) void k_poly_eval_partial(const fp *__restrict__ coeffs, size_t n, const fp *__restrict__ points, fp *__restrict__ partial,
                                                            unsigned width, unsigned seg_len) {
