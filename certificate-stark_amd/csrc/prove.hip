@@ -145,6 +145,15 @@ struct Writer {
     void u32(uint32_t v) { raw(&v, 4); }
     void u64(uint64_t v) { raw(&v, 8); }
 };
+// The proof bytes go straight into the caller's buffer: a first pass only counts (dst = null), so that a buffer that is too small is left
+// untouched and the required size is known; a 0.6 MB temporary per proof would be fresh pages from the allocator every time.
+struct ProofWriter {
+    uint8_t *dst = nullptr;
+    size_t len = 0;
+    void raw(const void *p, size_t n) { if (dst) memcpy(dst + len, p, n); len += n; }
+    void u32(uint32_t v) { raw(&v, 4); }
+    void u64(uint64_t v) { raw(&v, 8); }
+};
 
 // positions folded into the next layer's row indices, first occurrence order
 std::vector<uint32_t> fold_positions(const std::vector<uint32_t> &pos, uint32_t rows) {
@@ -665,8 +674,7 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
     a->timed = true;
 
     // ---- serialise ----------------------------------------------------------------------------------------------------------------
-    Writer wr;
-    wr.b.reserve(off + ((size_t)64 << 10) + 8 * ((size_t)opt->fri_max_remainder * (opt->field_extension + 1)));
+    auto emit = [&](ProofWriter &wr) {
     wr.raw("CSTK", 4); wr.u32(CSTARK_PROOF_VERSION);
     wr.u32((uint32_t)job.air); wr.u32((uint32_t)W); wr.u32(log_n); wr.u32(job.item);
     wr.u32(opt->num_queries); wr.u32(opt->blowup_factor); wr.u32(opt->grinding_factor); wr.u32(opt->hash_fn); wr.u32(opt->field_extension);
@@ -688,9 +696,13 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
         }
     }
     wr.u32((uint32_t)R.remainder.size()); wr.raw(R.remainder.data(), R.remainder.size() * 8);
-    *proof_len = wr.b.size();
-    if (!proof || capacity < wr.b.size()) return fail(CSTARK_ERR_INVALID_ARG, "proof buffer too small (required size returned in *proof_len)");
-    memcpy(proof, wr.b.data(), wr.b.size());
+    };
+    ProofWriter count, out;
+    emit(count);
+    *proof_len = count.len;
+    if (!proof || capacity < count.len) return fail(CSTARK_ERR_INVALID_ARG, "proof buffer too small (required size returned in *proof_len)");
+    out.dst = proof;
+    emit(out);
     return CSTARK_OK;
 }
 #undef STAGE
