@@ -1341,17 +1341,22 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
         // so it takes this path only under CSTARK_SCHNORR_SPLIT_STAGE=1 (tests).  CSTARK_SCHNORR_SPLIT=0: every point directly.
         static const bool split_env = [] { const char *e = getenv("CSTARK_SCHNORR_SPLIT"); return !e || atoi(e) != 0; }();
         if (split_env && schnorr_input_is_lde && k0 == 0 && nk == 8 && log_blowup == 3 && log_n >= 12 && log_n + 3 <= cs::NTT_MAX_LOG_N && n_items > 1) {
-            constexpr unsigned T = cs::SCHNORR_SPLIT_TABLES;
+            // the final addition (degree 5 (n - 1) without its flag) on five cosets: three more tables on the even cosets, LDE coset 1
+            // directly (CSTARK_SCHNORR_FINAL5=0: on all eight cosets through the frame evaluator)
+            static const bool final5 = [] { const char *e = getenv("CSTARK_SCHNORR_FINAL5"); return !e || atoi(e) != 0; }();
+            const unsigned T = final5 ? cs::SCHNORR_SPLIT_TABLES : cs::SCHNORR_SPLIT_EC_TABLES;
             const NttPlan *pn, *p4, *p8;
             const CosetTable *t1;
             RC_TRY(get_plan(c, log_n, &pn));
             RC_TRY(get_plan(c, log_n + 2, &p4));
             RC_TRY(get_plan(c, log_n + 3, &p8));
             RC_TRY(get_coset_table(c, log_n, 3, cs::host::from_u64(1), &t1));
-            const size_t region = (size_t)T * 4 * n;
-            RC_TRY(ensure_ws(c, 5 * region * 8));
+            const size_t region = (size_t)T * 4 * n, hcol = (size_t)3 * n; // hcol: the final addition's three sums, one n-point table each
+            RC_TRY(ensure_ws(c, (5 * region + 9 * hcol) * 8));
             uint64_t *even = (uint64_t *)c->ws, *sa = even + region, *sb = sa + region, *sc = sb + region, *odd = sc + region;
+            uint64_t *fin_direct = odd + region, *fin_hi = fin_direct + hcol /* [4 odd cosets][3][n] */, *fin_co = fin_hi + 4 * hcol, *fin_scr = fin_co + hcol /* [3] */;
             HIP_TRY(cs::launch_schnorr_ec_split(p, d_schnorr_aux_lde, d + txl_off, even, c->stream));
+            if (final5) HIP_TRY(cs::launch_schnorr_final_split(p, d + txl_off, even + (size_t)cs::SCHNORR_SPLIT_EC_TABLES * 4 * n, -1, c->stream));
             cs::NttArgs a{};
             a.in = even; a.scratch = sa; a.out = sb; a.width = 4 * T; a.batch = 1; a.log_n = log_n;
             a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true; a.aux = pn->aux_winv;
@@ -1363,10 +1368,24 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
             f.aux = pn->aux_w; f.aux_ps = t1->aux ? t1->aux + t1->aux_words : nullptr; f.aux_ps_batch_stride = 2 * t1->aux_words;
             f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
             HIP_TRY(cs::ntt_columns(f, c->stream));
+            if (final5) { // H = (T - F) / 2 on LDE coset 1, interpolated there and extended to cosets 3, 5, 7 (as for TransactionAir)
+                HIP_TRY(cs::launch_schnorr_final_split(p, d + txl_off, fin_direct, 1, c->stream));
+                HIP_TRY(cs::launch_schnorr_final_hi(p, odd, fin_direct, fin_hi, cs::host::inv(cs::host::from_u64(2)), c->stream));
+                cs::NttArgs hi_inv{};
+                hi_inv.in = fin_hi; hi_inv.scratch = fin_scr; hi_inv.out = fin_co; hi_inv.width = 3; hi_inv.batch = 1; hi_inv.log_n = log_n;
+                hi_inv.w = pn->winv; hi_inv.post_scale = pn->n_inv; hi_inv.do_scale = true; hi_inv.inverse = true; hi_inv.aux = pn->aux_winv;
+                HIP_TRY(cs::ntt_columns(hi_inv, c->stream));
+                cs::NttArgs hi_fwd{}; // coefficients of H(w_8n z) in z -> coset k: prescale by (w_8n^(k-1))^s, k - 1 = 2, 4, 6: rows 2, 4, 6 of the offset-1 table
+                hi_fwd.in = fin_co; hi_fwd.scratch = fin_scr; hi_fwd.out = fin_hi + hcol; hi_fwd.width = 3; hi_fwd.batch = 3; hi_fwd.log_n = log_n;
+                hi_fwd.w = pn->w; hi_fwd.prescale = t1->s + 2 * n; hi_fwd.prescale_batch_stride = 2 * n; hi_fwd.do_scale = false; hi_fwd.inverse = false;
+                hi_fwd.aux = pn->aux_w; hi_fwd.aux_ps = t1->aux ? t1->aux + 2 * t1->aux_words : nullptr; hi_fwd.aux_ps_batch_stride = 2 * t1->aux_words;
+                hi_fwd.in_batch_stride = 0; hi_fwd.scratch_batch_stride = hcol; hi_fwd.out_batch_stride = hcol;
+                HIP_TRY(cs::ntt_columns(hi_fwd, c->stream));
+            }
             // the round gadget of the message hash in the folded form (CSTARK_SCHNORR_ROUNDS=0: inside the frame evaluator)
             static const bool rounds_env = [] { const char *e = getenv("CSTARK_SCHNORR_ROUNDS"); return !e || atoi(e) != 0; }();
             HIP_TRY(cs::launch_schnorr_split_finish(p, d_schnorr_aux_lde, pt->tab, even, odd, t_grp[0], t_grp[6], c->stream,
-                                                    rounds_env ? (uint64_t *)c->desc_buf + mrt_off : nullptr, t_grp[42]));
+                                                    rounds_env ? (uint64_t *)c->desc_buf + mrt_off : nullptr, t_grp[42], final5 ? fin_hi : nullptr));
         } else {
             HIP_TRY(cs::launch_schnorr_fused(p, d_schnorr_aux_lde, pt->tab, nk, c->stream));
         }

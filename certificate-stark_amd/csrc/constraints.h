@@ -83,10 +83,17 @@ hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, 
 // SchnorrAir's doubling / addition gadgets in the degree-split form (all cosets, k0 = 0; constraints.hip): eight polynomials on the even
 // cosets, d_even = [8][4][n] (d_coefs_tx_layout: alpha[i] at word i, beta[i] at word 115 + i, device); after their extension to the odd
 // cosets (d_odd = [4][8][n]) the recombination into p.out, to which the final addition and the remaining constraints are then added
-constexpr int SCHNORR_SPLIT_TABLES = 8;
+constexpr int SCHNORR_SPLIT_EC_TABLES = 8, SCHNORR_SPLIT_TABLES = 11; // without / with the final addition's three sums (tables 8..10)
 hipError_t launch_schnorr_ec_split(const AirCombineParams &p, const uint64_t *aux, const uint64_t *d_coefs_tx_layout, uint64_t *d_even, hipStream_t stream);
 hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, const uint64_t *d_even, const uint64_t *d_odd,
-                                       unsigned g0, unsigned g1, hipStream_t stream, uint64_t *d_rtab = nullptr, unsigned round_group = 0);
+                                       unsigned g0, unsigned g1, hipStream_t stream, uint64_t *d_rtab = nullptr, unsigned round_group = 0,
+                                       const uint64_t *d_hi = nullptr);
+// The final addition on five cosets: its three sums on the even cosets (coset < 0: d_out = tables 8..10 of d_even, [3][4][n]) or directly
+// on LDE coset 1 (coset = 1: d_out = [3][n]); launch_schnorr_final_hi: d_hi[q] = (d_odd's table 8 + q on coset 1 - d_direct[q]) / 2.
+// With d_hi = [4 odd cosets][3][n] (coset 1 from launch_schnorr_final_hi, cosets 3, 5, 7 its extension) launch_schnorr_split_finish
+// recombines the final addition too (tables of SCHNORR_SPLIT_TABLES); without it the tables are SCHNORR_SPLIT_EC_TABLES wide.
+hipError_t launch_schnorr_final_split(const AirCombineParams &p, const uint64_t *d_coefs_tx_layout, uint64_t *d_out, int coset, hipStream_t stream);
+hipError_t launch_schnorr_final_hi(const AirCombineParams &p, const uint64_t *d_odd, const uint64_t *d_direct, uint64_t *d_hi, uint64_t half_m, hipStream_t stream);
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream);
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);

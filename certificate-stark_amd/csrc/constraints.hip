@@ -2010,7 +2010,7 @@ __global__ __launch_bounds__(FNT, PART == SF_REST ? 2 : CS_EC_WAVES) void k_schn
 // Eight polynomials per proof on the even cosets, out = [8][4][n]: doubling alpha, beta_0, beta_1 | addition alpha, beta_0, beta_1 |
 // addition x bit alpha, beta_0.  PART: 1 = doubling of s*G (writes the doubling family), 3 = doubling of h*P (adds to it), 2 = addition of
 // G (writes the addition family), 4 = addition of P (adds its linear half to the addition family, writes the third family).
-constexpr int SCH_SPLIT_TABLES = 8;
+constexpr int SCH_SPLIT_EC_TABLES = 8, SCH_SPLIT_TABLES = 11; // the doubling / addition families | + the final addition's three sums
 template <int PART>
 __global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_schnorr_ec_split(const fp *__restrict__ lde, const fp *__restrict__ aux, const fp *__restrict__ coefs_tx_layout,
                                                                       fp *__restrict__ out, unsigned log_n) {
@@ -2059,11 +2059,47 @@ __global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_schnorr_ec_split(const fp 
         *o = PART == PART_DBL1 ? fp_add(*o, v) : v;
     }
 }
+// The final addition on FIVE cosets (the scheme of k_final_split / k_final_hi above, with the beta sums of the two degree groups kept
+// apart): its three sums F (alpha, beta_0, beta_1; degree <= 5 (n - 1) without the flag) are evaluated on the even cosets, where they
+// equal T = F mod (y^4n - 1), tables 8..10 of `even`, and directly on LDE coset 1, which pins H = (T - F) / 2 there; H has degree < n
+// and is interpolated from that one coset and extended to cosets 3, 5, 7 by the caller.  coset < 0: the even cosets (grid.y = 4, out =
+// tables [3][4][n]); coset = 1: out = [3][n].
+__global__ __launch_bounds__(FNT, CS_EC_WAVES) void k_schnorr_final_split(const fp *__restrict__ lde, const fp *__restrict__ coefs_tx_layout, fp *__restrict__ out,
+                                                                         unsigned log_n, int coset) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
+    const unsigned kc = blockIdx.y, kk = coset < 0 ? 2 * kc : (unsigned)coset;
+    const fp *base = lde + (size_t)kk * 56 * n;
+    Frame f;
+    f.n = n;
+    f.cur_p = base + j;
+    f.next_p = base + ((j + 1) & (n - 1));
+    f.per_p = nullptr; // no periodic value is read: the flag is applied by k_schnorr_split_finish
+    f.pcycle = 512;
+    SplitAcc<1> acc;
+    acc.coefs = as_const(coefs_tx_layout);
+    fused_final_addition(acc, f, (fp)0);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        if (coset < 0) out[((size_t)q * 4 + kc) * n + j] = acc.result(0, q);
+        else out[(size_t)q * n + j] = acc.result(0, q);
+    }
+}
+// hi[q][j] = (T_q - F_q) / 2 on LDE coset 1: odd = [4 odd cosets][T][n] (coset 1 first), direct = [3][n]
+__global__ __launch_bounds__(256) void k_schnorr_final_hi(const fp *__restrict__ odd, const fp *__restrict__ direct, fp *__restrict__ hi, fp half, unsigned log_n) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    const unsigned q = blockIdx.y;
+    hi[(size_t)q * n + j] = fp_mul(fp_sub(odd[((size_t)SCH_SPLIT_EC_TABLES + q) * n + j], direct[(size_t)q * n + j]), half);
+}
 // recombination over all cosets: out[k][j] = doubling(x) (D_a + x^adj_0 D_b0 + x^adj_1 D_b1) + addition(x) [(A_a + x^adj_0 A_b0 + x^adj_1 A_b1)
-// - bit37 (Q_a + x^adj_0 Q_b0)]; the remaining parts (final addition, hash / limb constraints, bit registers) ADD to it afterwards.
-// even = [8][4][n] (even cosets), odd = [4 odd cosets][8][n] (their extension); g0, g1 = degree groups of slots 0 and 6.
+// - bit37 (Q_a + x^adj_0 Q_b0)] + final(x) (F_a + x^adj_0 F_b0 + x^adj_1 F_b1), F = T on the even cosets and T - 2 H on the odd ones
+// (hi = [4 odd cosets][3][n]; null: the final addition is left to k_schnorr_fused<SF_FINAL>); the remaining parts (hash / limb
+// constraints, bit registers) ADD to it afterwards.
+// even = [T][4][n] (even cosets), odd = [4 odd cosets][T][n] (their extension), T = 8 or 11; g0, g1 = degree groups of slots 0 and 6.
+template <int T>
 __global__ __launch_bounds__(256) void k_schnorr_split_finish(AirCombineParams p, const fp *__restrict__ even, const fp *__restrict__ odd,
-                                                              const fp *__restrict__ ptab, unsigned g0, unsigned g1) {
+                                                              const fp *__restrict__ ptab, unsigned g0, unsigned g1, const fp *__restrict__ hi) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
     const unsigned k = blockIdx.y; // all eight cosets present, k0 = 0
@@ -2072,12 +2108,23 @@ __global__ __launch_bounds__(256) void k_schnorr_split_finish(AirCombineParams p
     const fp scalar_mult = per[(size_t)1 * 512], doubling = per[(size_t)2 * 512];
     const fp addition = fp_mul(c_not(doubling), scalar_mult);
     const fp bit37 = p.lde[((size_t)k * 56 + 37) * n + j];
-    constexpr int T = SCH_SPLIT_TABLES;
     auto value = [&](int t) { return (k & 1) ? odd[((size_t)(k >> 1) * T + t) * n + j] : even[((size_t)t * 4 + (k >> 1)) * n + j]; };
     const fp dbl = fp_add(value(0), fp_add(fp_mul(value(1), x0), fp_mul(value(2), x1)));
     const fp add = fp_add(value(3), fp_add(fp_mul(value(4), x0), fp_mul(value(5), x1)));
     const fp addbit = fp_add(value(6), fp_mul(value(7), x0));
-    p.out[(size_t)k * n + j] = fp_add(fp_mul(doubling, dbl), fp_mul(addition, fp_sub(add, fp_mul(bit37, addbit))));
+    fp total = fp_add(fp_mul(doubling, dbl), fp_mul(addition, fp_sub(add, fp_mul(bit37, addbit))));
+    if (T > SCH_SPLIT_EC_TABLES) {
+        fp fa = value(8), fb0 = value(9), fb1 = value(10);
+        if (k & 1) {
+            const fp *h = hi + (size_t)(k >> 1) * 3 * n + j;
+            fa = fp_sub(fa, fp_dbl(h[0]));
+            fb0 = fp_sub(fb0, fp_dbl(h[n]));
+            fb1 = fp_sub(fb1, fp_dbl(h[2 * n]));
+        }
+        const fp final_add = fp_mul(c_not(scalar_mult), per[0]); // (1 - scalar_mult) * global mask
+        total = fp_add(total, fp_mul(final_add, fp_add(fa, fp_add(fp_mul(fb0, x0), fp_mul(fb1, x1)))));
+    }
+    p.out[(size_t)k * n + j] = total;
 }
 
 // MerkleAir, fused: the same body as k_eval_transitions_merkle behind the table-driven accumulator; one value per point of the
@@ -2376,13 +2423,28 @@ hipError_t launch_schnorr_ec_split(const AirCombineParams &p, const uint64_t *au
     hipLaunchKernelGGL(k_schnorr_ec_split<PART_ADD1>, grid, block, 0, stream, p.lde, aux, d_coefs_tx_layout, d_even, p.log_n);
     return hipGetLastError();
 }
-hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, const uint64_t *d_even, const uint64_t *d_odd,
-                                       unsigned g0, unsigned g1, hipStream_t stream, uint64_t *d_rtab, unsigned round_group) {
+hipError_t launch_schnorr_final_split(const AirCombineParams &p, const uint64_t *d_coefs_tx_layout, uint64_t *d_out, int coset, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
     if (n % FNT) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_schnorr_split_finish, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd, ptab, g0, g1);
+    hipLaunchKernelGGL(k_schnorr_final_split, dim3((unsigned)(n / FNT), coset < 0 ? 4 : 1), dim3(FNT), 0, stream, p.lde, d_coefs_tx_layout, d_out, p.log_n, coset);
+    return hipGetLastError();
+}
+hipError_t launch_schnorr_final_hi(const AirCombineParams &p, const uint64_t *d_odd, const uint64_t *d_direct, uint64_t *d_hi, uint64_t half_m, hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    hipLaunchKernelGGL(k_schnorr_final_hi, dim3((unsigned)(n / 256), 3), dim3(256), 0, stream, d_odd, d_direct, d_hi, half_m, p.log_n);
+    return hipGetLastError();
+}
+hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, const uint64_t *d_even, const uint64_t *d_odd,
+                                       unsigned g0, unsigned g1, hipStream_t stream, uint64_t *d_rtab, unsigned round_group, const uint64_t *d_hi) {
+    const size_t n = (size_t)1 << p.log_n;
+    if (n % FNT) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(n / FNT), 8), block(FNT);
-    hipLaunchKernelGGL((k_schnorr_fused<SF_FINAL, true>), grid, block, 0, stream, p, aux, ptab);
+    if (d_hi) { // tables of SCH_SPLIT_TABLES: the final addition came with them
+        hipLaunchKernelGGL(k_schnorr_split_finish<SCH_SPLIT_TABLES>, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd, ptab, g0, g1, d_hi);
+    } else {    // tables of SCH_SPLIT_EC_TABLES
+        hipLaunchKernelGGL(k_schnorr_split_finish<SCH_SPLIT_EC_TABLES>, dim3((unsigned)(n / 256), 8), dim3(256), 0, stream, p, d_even, d_odd, ptab, g0, g1, d_hi);
+        hipLaunchKernelGGL((k_schnorr_fused<SF_FINAL, true>), grid, block, 0, stream, p, aux, ptab);
+    }
     if (d_rtab) { // the message hash's round gadget in the folded form (as MerkleAir's four), added to the output
         hipLaunchKernelGGL((k_merkle_rounds_setup<4, 36, 8>), dim3(2), dim3(64), 0, stream, p.t_alpha, p.t_beta, ptab, d_rtab, 8u);
         hipLaunchKernelGGL((k_merkle_rounds<4, 1, 56, 36, 7, 8, true>), grid, block, 0, stream, p, ptab, (const fp *)d_rtab, round_group);

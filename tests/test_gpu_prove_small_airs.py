@@ -154,6 +154,6 @@ def test_alternative_sub_air_paths_give_the_same_bytes():
     assert got.returncode == 0, got.stderr[-2000:]
     want = _switch_digests()
     assert got.stdout.strip().splitlines()[-1].split() == want
-    got = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTARK_SCHNORR_ROUNDS="0"), capture_output=True, text=True, timeout=600)
+    got = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTARK_SCHNORR_ROUNDS="0", CSTARK_SCHNORR_FINAL5="0"), capture_output=True, text=True, timeout=600)
     assert got.returncode == 0, got.stderr[-2000:]
     assert got.stdout.strip().splitlines()[-1].split() == want
