@@ -2127,8 +2127,6 @@ __global__ __launch_bounds__(256) void k_schnorr_split_finish(AirCombineParams p
     p.out[(size_t)k * n + j] = total;
 }
 
-// MerkleAir, fused: the same body as k_eval_transitions_merkle behind the table-driven accumulator; one value per point of the
-// cosets of the constraint-evaluation domain (the others are left alone: k_air_combine writes their zeros).
 // MerkleAir without its round gadgets, for the table-driven accumulator: the same terms as merkle_transitions<false>, grouped by their
 // flag into sections (one multiply-accumulate per term and one reduction per section instead of three field products per term; the two
 // authentication-path blocks through the TransactionAir evaluator's fused_merkle_auth_rest).  Exact arithmetic: the same sum.
@@ -2171,6 +2169,8 @@ __device__ __forceinline__ void merkle_linear_sections(AirSum &acc, const Frame 
     }
     acc.end(finish);
 }
+// MerkleAir, fused: the same body as k_eval_transitions_merkle behind the table-driven accumulator; one value per point of the
+// cosets of the constraint-evaluation domain (the others are left alone: k_air_combine writes their zeros).
 // AFTER_ROUNDS: k_merkle_rounds wrote the four round gadgets' sum first; this kernel adds every other constraint to it.
 template <bool AFTER_ROUNDS>
 __global__ __launch_bounds__(FNT, 2) void k_merkle_fused(AirCombineParams p, const fp *__restrict__ ptab) {
