@@ -48,6 +48,19 @@ def test_coset_subset_writes_only_its_leaves(oracle, backend):
     assert not got[:, :2].any() and not got[:, 5:].any()
 
 
+@pytest.mark.parametrize("log_leaves", list(range(1, 20)))
+def test_merkle_tree_every_size(oracle, backend, log_leaves):
+    """Every tree size from 2 to 2^19 leaves, every node: the paths of merkle_build change with the size (one four-lane workgroup up to
+    512 leaves, 256-parent workgroups + one more launch up to 2^18, lane-per-node double levels above)."""
+    import torch
+    L = 1 << log_leaves
+    leaves = np.random.default_rng(100 + log_leaves).integers(0, 256, size=(L, 32), dtype=np.uint8)
+    nodes = torch.zeros((2 * L, 32), dtype=torch.uint8, device=backend.device)
+    nodes[L:] = torch.from_numpy(leaves).to(backend.device)
+    backend.merkle_build(nodes)
+    assert (nodes.cpu().numpy()[1:] == oracle.merkle_build(leaves)[1:]).all()
+
+
 def test_large_tree_2_20_leaves_root(oracle, backend):
     """2^20 leaves on the GPU vs the oracle: exercises the multi-launch level path plus the one-workgroup top."""
     import torch
