@@ -9,6 +9,7 @@
 #include "fp.cuh"
 #include "../../include/cstark_conventions.h"
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 namespace cs {
 namespace {
@@ -368,6 +369,27 @@ hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, u
     return hipGetLastError();
 }
 
+// Proof of work (ProofOptions::grinding_factor): the smallest nonce >= base of this chunk whose Blake3(seed || le64(nonce))[0..8), read
+// as a little-endian integer, has its low `bits` bits zero.  One lane per nonce, atomicMin into *found (preset to ~0).
+struct GrindSeed { uint32_t w[8]; };
+__global__ __launch_bounds__(256) void k_grind(GrindSeed seed, uint64_t base, uint64_t count, uint64_t mask, unsigned long long *__restrict__ found) {
+    const uint64_t i = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t nonce = base + i;
+    uint32_t m[16] = {seed.w[0], seed.w[1], seed.w[2], seed.w[3], seed.w[4], seed.w[5], seed.w[6], seed.w[7], (uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0};
+    uint32_t cv[8] = {IV0, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+    compress(cv, m, 40, CHUNK_START | CHUNK_END | ROOT);
+    const uint64_t v = (uint64_t)cv[0] | (uint64_t)cv[1] << 32;
+    if ((v & mask) == 0) atomicMin(found, (unsigned long long)nonce);
+}
+hipError_t grind_chunk(const uint8_t seed[32], uint64_t base, uint64_t count, unsigned bits, unsigned long long *d_found, hipStream_t stream) {
+    GrindSeed s;
+    memcpy(s.w, seed, 32); // little-endian host: the digest bytes are the words
+    hipError_t e = hipMemsetAsync(d_found, 0xFF, 8, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_grind, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, s, base, count, bits >= 64 ? ~0ull : ((1ull << bits) - 1), d_found);
+    return hipGetLastError();
+}
 hipError_t fri_coin(uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, hipStream_t stream) {
     hipLaunchKernelGGL(k_fri_coin, dim3(1), dim3(64), 0, stream, d_seed, d_root, d_alpha, d_root_out);
     return hipGetLastError();

@@ -392,6 +392,37 @@ int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hi
 
 } // namespace
 
+// Proof of work: the smallest nonce >= 1 whose digest with the seed has `bits` low zero bits (0 bits: nonce 1).  A search of 2^bits
+// hashes in sequence on the host costs 10 ms at 16 bits; from 12 bits on (Blake3 coin) the GPU searches 2^22 nonces per launch --
+// chunks in increasing order and an atomic minimum inside a chunk, so the nonce is the one the sequential search finds.
+// CSTARK_GRIND_DEVICE=0: always on the host.
+int grind_nonce(cstark_ctx *c, ProveArena *a, const Coin &coin, unsigned bits, uint64_t *nonce_out) {
+    static const bool dev_env = [] { const char *e = getenv("CSTARK_GRIND_DEVICE"); return !e || atoi(e) != 0; }();
+    if (bits == 0 || !dev_env || coin.hash_fn != 0 || bits < 12) {
+        uint64_t nonce = 1;
+        for (;; nonce++) {
+            uint8_t out[32];
+            coin.with_int(coin.seed, nonce, out);
+            uint64_t v = 0;
+            for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
+            if (bits == 0 || (v & ((1ull << bits) - 1)) == 0) break;
+        }
+        *nonce_out = nonce;
+        return CSTARK_OK;
+    }
+    unsigned long long *d_found;
+    RC_TRY(arena_extra(c, a, 42, &d_found, 64));
+    constexpr uint64_t CHUNK = (uint64_t)1 << 22;
+    for (uint64_t base = 1;; base += CHUNK) {
+        HIP_TRY(cs::grind_chunk(coin.seed, base, CHUNK, bits, d_found, c->stream));
+        unsigned long long found = 0;
+        HIP_TRY(hipMemcpyAsync(&found, d_found, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(cs::stream_wait(c->stream));
+        if (found != ~0ull) { *nonce_out = found; return CSTARK_OK; }
+        if (base > ((uint64_t)1 << 44)) return fail(CSTARK_ERR_HIP, "proof of work: no nonce found"); // 2^-(2^12) to get here at 32 bits
+    }
+}
+
 // Prover::prove for any of the AIRs over the base field, as a sequence of phases.  On one GPU (prove_core) they run back to back;
 // the sharded entry points (cstark_tx_shard_*: one proof across several GPUs by LDE coset) run them with the ranks' all-gathers in
 // between -- leaf digests after `commit`, merged evaluations after `evaluate`, the opened trace rows after `compose`.
@@ -602,13 +633,7 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
 
     // ---- proof of work, query positions -------------------------------------------------------------------------------------
     uint64_t nonce = 1;
-    for (;; nonce++) {
-        uint8_t out[32];
-        coin.with_int(coin.seed, nonce, out);
-        uint64_t v = 0;
-        for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
-        if (opt->grinding_factor == 0 || (v & ((1ull << opt->grinding_factor) - 1)) == 0) break;
-    }
+    RC_TRY(grind_nonce(c, a, coin, opt->grinding_factor, &nonce));
     R.nonce = nonce;
     coin.reseed_int(nonce);
     coin.draw_integers(nq, N, R.positions);
@@ -1071,13 +1096,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     STAGE();
 
     uint64_t nonce = 1;
-    for (;; nonce++) {
-        uint8_t out[32];
-        coin.with_int(coin.seed, nonce, out);
-        uint64_t v = 0;
-        for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
-        if (opt->grinding_factor == 0 || (v & ((1ull << opt->grinding_factor) - 1)) == 0) break;
-    }
+    RC_TRY(grind_nonce(c, a, coin, opt->grinding_factor, &nonce));
     coin.reseed_int(nonce);
     std::vector<uint32_t> positions;
     coin.draw_integers(nq, N, positions);
