@@ -390,6 +390,25 @@ hipError_t grind_chunk(const uint8_t seed[32], uint64_t base, uint64_t count, un
     hipLaunchKernelGGL(k_grind, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, s, base, count, bits >= 64 ? ~0ull : ((1ull << bits) - 1), d_found);
     return hipGetLastError();
 }
+// the same for `batch` seeds at once (the batched range prover): grid.y = proof; found[t] preset to ~0 by the caller before the first chunk
+__global__ __launch_bounds__(256) void k_grind_batch(const uint32_t *__restrict__ seeds, uint64_t base, uint64_t count, uint64_t mask,
+                                                     unsigned long long *__restrict__ found) {
+    const uint64_t i = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    const unsigned t = blockIdx.y;
+    if (i >= count || found[t] < base) return; // (found in an earlier chunk: nothing smaller is left to find)
+    const uint64_t nonce = base + i;
+    const uint32_t *s = seeds + 8 * (size_t)t;
+    uint32_t m[16] = {s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], (uint32_t)nonce, (uint32_t)(nonce >> 32), 0, 0, 0, 0, 0, 0};
+    uint32_t cv[8] = {IV0, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+    compress(cv, m, 40, CHUNK_START | CHUNK_END | ROOT);
+    const uint64_t v = (uint64_t)cv[0] | (uint64_t)cv[1] << 32;
+    if ((v & mask) == 0) atomicMin(found + t, (unsigned long long)nonce);
+}
+hipError_t grind_batch_chunk(const uint32_t *d_seeds, unsigned batch, uint64_t base, uint64_t count, unsigned bits, unsigned long long *d_found, hipStream_t stream) {
+    hipLaunchKernelGGL(k_grind_batch, dim3((unsigned)((count + 255) / 256), batch), dim3(256), 0, stream, d_seeds, base, count,
+                       bits >= 64 ? ~0ull : ((1ull << bits) - 1), d_found);
+    return hipGetLastError();
+}
 hipError_t fri_coin(uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, hipStream_t stream) {
     hipLaunchKernelGGL(k_fri_coin, dim3(1), dim3(64), 0, stream, d_seed, d_root, d_alpha, d_root_out);
     return hipGetLastError();

@@ -1379,8 +1379,8 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
     if (c->arena) c->arena->timed = false; // cstark_prove_stage_ms describes the generic prover's last proof: none after a batch
 
     // ---- buffers: one device block, one pinned host block ----------------------------------------------------------------------------
-    const size_t dev_need = B * (16 + 1024 * 2 + 8192 + 32768 + 64 + 1024 + 1024 + 8192 + 32768 + 8 + 48 + 64 + 4096 + 8192 + 8 + 8 * rem_len + 8 * nq + 4 + slot) + 64 * 256;
-    const size_t host_need = B * (32 * 3 + 64 + 48 + 64 + 8 + 8 + 8 * rem_len + 8 * nq + 4 + slot) + 32 * 256;
+    const size_t dev_need = B * (16 + 1024 * 2 + 8192 + 32768 + 64 + 1024 + 1024 + 8192 + 32768 + 8 + 48 + 64 + 4096 + 8192 + 8 + 8 * rem_len + 8 * nq + 4 + slot + 40) + 66 * 256;
+    const size_t host_need = B * (32 * 3 + 64 + 48 + 64 + 8 + 8 + 8 * rem_len + 8 * nq + 4 + slot + 40) + 34 * 256;
     if (c->rb_dev_bytes < dev_need) {
         HIP_TRY(hipStreamSynchronize(st));
         if (c->rb_dev) { HIP_TRY(hipFree(c->rb_dev)); c->rb_dev = nullptr; c->rb_dev_bytes = 0; }
@@ -1401,11 +1401,15 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
     uint8_t *d_tnodes = D.take<uint8_t>(B * 32768), *d_cnodes = D.take<uint8_t>(B * 32768), *d_lnodes = D.take<uint8_t>(B * 8192);
     uint32_t *d_pos = D.take<uint32_t>(B * nq * 4), *d_lpos = D.take<uint32_t>(B * nq * 4), *d_lcount = D.take<uint32_t>(B * 4);
     uint8_t *d_open = D.take<uint8_t>(B * slot);
+    uint32_t *d_gseed = D.take<uint32_t>(B * 32);
+    unsigned long long *d_gfound = D.take<unsigned long long>(B * 8);
     uint8_t *h_troot = H.take<uint8_t>(B * 32), *h_croot = H.take<uint8_t>(B * 32), *h_lroot = H.take<uint8_t>(B * 32);
     uint64_t *h_coefs = H.take<uint64_t>(B * 64), *h_ood = H.take<uint64_t>(B * 48), *h_dcoef = H.take<uint64_t>(B * 64), *h_z = H.take<uint64_t>(B * 8);
     uint64_t *h_alpha = H.take<uint64_t>(B * 8), *h_rem = H.take<uint64_t>(B * 8 * rem_len);
     uint32_t *h_pos = H.take<uint32_t>(B * nq * 4), *h_lpos = H.take<uint32_t>(B * nq * 4), *h_lcount = H.take<uint32_t>(B * 4);
     uint8_t *h_open = H.take<uint8_t>(B * slot);
+    uint32_t *h_gseed = H.take<uint32_t>(B * 32);
+    unsigned long long *h_gfound = H.take<unsigned long long>(B * 8);
 
     RangeBatchConsts K{};
     {
@@ -1523,17 +1527,47 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
     mark("deep + fri (gpu + host)");
     std::vector<uint64_t> nonces(B);
     std::vector<uint8_t> rem_commit(32 * B);
+    // proof of work: from 12 bits on (Blake3 coin) all B searches run on the device, chunk after chunk in increasing order, until every
+    // proof has its smallest nonce (grind_nonce above: the single-proof form)
+    static const bool grind_dev_env = [] { const char *e = getenv("CSTARK_GRIND_DEVICE"); return !e || atoi(e) != 0; }();
+    const bool grind_dev = grind_dev_env && hf == 0 && opt->grinding_factor >= 12;
+    if (grind_dev) {
+        parallel_for(B, [&](size_t t) {
+            hash_elements(hf, h_rem + rem_len * t, rem_len, &rem_commit[32 * t]);
+            coins[t].reseed(&rem_commit[32 * t]);
+            memcpy(h_gseed + 8 * t, coins[t].seed, 32);
+            h_gfound[t] = ~0ull;
+        });
+        HIP_TRY(hipMemcpyAsync(d_gseed, h_gseed, B * 32, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_gfound, h_gfound, B * 8, hipMemcpyHostToDevice, st));
+        uint64_t chunk = (uint64_t)4 << opt->grinding_factor; // four expected hits per proof and chunk
+        while (chunk * B > ((uint64_t)1 << 28)) chunk >>= 1;   // at most 2^28 nonces per launch
+        if (chunk < 256) chunk = 256;
+        for (uint64_t base = 1;; base += chunk) {
+            HIP_TRY(cs::grind_batch_chunk(d_gseed, (unsigned)B, base, chunk, opt->grinding_factor, d_gfound, st));
+            HIP_TRY(hipMemcpyAsync(h_gfound, d_gfound, B * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(cs::stream_wait(st));
+            bool all = true;
+            for (size_t t = 0; t < B; t++) all = all && h_gfound[t] != ~0ull;
+            if (all) break;
+            if (base > ((uint64_t)1 << 44)) return fail(CSTARK_ERR_HIP, "proof of work: no nonce found");
+        }
+    }
     parallel_for(B, [&](size_t t) {
         Coin &coin = coins[t];
-        hash_elements(hf, h_rem + rem_len * t, rem_len, &rem_commit[32 * t]);
-        coin.reseed(&rem_commit[32 * t]);
         uint64_t nonce = 1;
-        for (;; nonce++) {
-            uint8_t out[32];
-            coin.with_int(coin.seed, nonce, out);
-            uint64_t v = 0;
-            for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
-            if (opt->grinding_factor == 0 || (v & ((1ull << opt->grinding_factor) - 1)) == 0) break;
+        if (grind_dev) {
+            nonce = h_gfound[t];
+        } else {
+            hash_elements(hf, h_rem + rem_len * t, rem_len, &rem_commit[32 * t]);
+            coin.reseed(&rem_commit[32 * t]);
+            for (;; nonce++) {
+                uint8_t out[32];
+                coin.with_int(coin.seed, nonce, out);
+                uint64_t v = 0;
+                for (int i = 0; i < 8; i++) v |= (uint64_t)out[i] << (8 * i);
+                if (opt->grinding_factor == 0 || (v & ((1ull << opt->grinding_factor) - 1)) == 0) break;
+            }
         }
         nonces[t] = nonce;
         coin.reseed_int(nonce);
