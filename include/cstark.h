@@ -80,9 +80,9 @@ typedef struct cstark_tx_witness {
 typedef struct cstark_options {
     uint32_t num_queries;      /* 42 */
     uint32_t blowup_factor;    /* 8 */
-    uint32_t grinding_factor;  /* 0 */
+    uint32_t grinding_factor;  /* 0; up to 32 bits of proof of work (Blake3 coin, 12 bits and more: searched on the device) */
     uint32_t hash_fn;          /* 0 = Blake3_256, 1 = Sha3_256 */
-    uint32_t field_extension;  /* 0 = None, 1 = Quadratic, 2 = Cubic (extensions: TransactionAir proofs) */
+    uint32_t field_extension;  /* 0 = None, 1 = Quadratic, 2 = Cubic */
     uint32_t fri_folding_factor; /* 4 */
     uint32_t fri_max_remainder;  /* 256 */
 } cstark_options;
