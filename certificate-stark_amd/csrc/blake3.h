@@ -14,6 +14,9 @@ hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, u
 hipError_t grind_chunk(const uint8_t seed[32], uint64_t base, uint64_t count, unsigned bits, unsigned long long *d_found, hipStream_t stream);
 // one chunk of the same search for `batch` seeds ([batch][8] words) at once; d_found[batch] must hold ~0 before the first chunk
 hipError_t grind_batch_chunk(const uint32_t *d_seeds, unsigned batch, uint64_t base, uint64_t count, unsigned bits, unsigned long long *d_found, hipStream_t stream);
+// ... with the Sha3 coin (sha3.hip); d_seeds = [batch][4] 64-bit words
+hipError_t grind_batch_chunk_sha3(const uint64_t *d_seeds, unsigned batch, uint64_t base, uint64_t count, unsigned bits, unsigned long long *d_found,
+                                  hipStream_t stream);
 // The Blake3 coin of one FRI layer on the device: d_seed (8 words) <- Blake3(seed || root), *d_alpha = the drawn field element (memory
 // form), d_root_out <- the root (8 words).  Same bytes as the host coin of prove.hip.
 hipError_t fri_coin(uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, hipStream_t stream);

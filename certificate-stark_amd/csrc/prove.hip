@@ -393,12 +393,12 @@ int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hi
 } // namespace
 
 // Proof of work: the smallest nonce >= 1 whose digest with the seed has `bits` low zero bits (0 bits: nonce 1).  A search of 2^bits
-// hashes in sequence on the host costs 10 ms at 16 bits; from 12 bits on (Blake3 coin) the GPU searches 2^22 nonces per launch --
+// hashes in sequence on the host costs 10 ms at 16 bits (43 ms with the Sha3 coin); from 12 bits on the GPU searches 2^22 nonces per launch --
 // chunks in increasing order and an atomic minimum inside a chunk, so the nonce is the one the sequential search finds.
 // CSTARK_GRIND_DEVICE=0: always on the host.
 int grind_nonce(cstark_ctx *c, ProveArena *a, const Coin &coin, unsigned bits, uint64_t *nonce_out) {
     static const bool dev_env = [] { const char *e = getenv("CSTARK_GRIND_DEVICE"); return !e || atoi(e) != 0; }();
-    if (bits == 0 || !dev_env || coin.hash_fn != 0 || bits < 12) {
+    if (bits == 0 || !dev_env || bits < 12) {
         uint64_t nonce = 1;
         for (;; nonce++) {
             uint8_t out[32];
@@ -410,11 +410,16 @@ int grind_nonce(cstark_ctx *c, ProveArena *a, const Coin &coin, unsigned bits, u
         *nonce_out = nonce;
         return CSTARK_OK;
     }
-    unsigned long long *d_found;
+    unsigned long long *d_found; // [found | seed (Sha3 coin: read from device memory)]
     RC_TRY(arena_extra(c, a, 42, &d_found, 64));
     constexpr uint64_t CHUNK = (uint64_t)1 << 22;
+    if (coin.hash_fn == 1) {
+        HIP_TRY(hipMemcpyAsync(d_found + 1, coin.seed, 32, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(d_found, 0xFF, 8, c->stream));
+    }
     for (uint64_t base = 1;; base += CHUNK) {
-        HIP_TRY(cs::grind_chunk(coin.seed, base, CHUNK, bits, d_found, c->stream));
+        if (coin.hash_fn == 1) HIP_TRY(cs::grind_batch_chunk_sha3((const uint64_t *)(d_found + 1), 1, base, CHUNK, bits, d_found, c->stream));
+        else HIP_TRY(cs::grind_chunk(coin.seed, base, CHUNK, bits, d_found, c->stream));
         unsigned long long found = 0;
         HIP_TRY(hipMemcpyAsync(&found, d_found, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(cs::stream_wait(c->stream));
@@ -1530,7 +1535,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
     // proof of work: from 12 bits on (Blake3 coin) all B searches run on the device, chunk after chunk in increasing order, until every
     // proof has its smallest nonce (grind_nonce above: the single-proof form)
     static const bool grind_dev_env = [] { const char *e = getenv("CSTARK_GRIND_DEVICE"); return !e || atoi(e) != 0; }();
-    const bool grind_dev = grind_dev_env && hf == 0 && opt->grinding_factor >= 12;
+    const bool grind_dev = grind_dev_env && opt->grinding_factor >= 12;
     if (grind_dev) {
         parallel_for(B, [&](size_t t) {
             hash_elements(hf, h_rem + rem_len * t, rem_len, &rem_commit[32 * t]);
@@ -1544,7 +1549,8 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
         while (chunk * B > ((uint64_t)1 << 28)) chunk >>= 1;   // at most 2^28 nonces per launch
         if (chunk < 256) chunk = 256;
         for (uint64_t base = 1;; base += chunk) {
-            HIP_TRY(cs::grind_batch_chunk(d_gseed, (unsigned)B, base, chunk, opt->grinding_factor, d_gfound, st));
+            if (hf == 1) HIP_TRY(cs::grind_batch_chunk_sha3((const uint64_t *)d_gseed, (unsigned)B, base, chunk, opt->grinding_factor, d_gfound, st));
+            else HIP_TRY(cs::grind_batch_chunk(d_gseed, (unsigned)B, base, chunk, opt->grinding_factor, d_gfound, st));
             HIP_TRY(hipMemcpyAsync(h_gfound, d_gfound, B * 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(cs::stream_wait(st));
             bool all = true;

@@ -143,6 +143,31 @@ hipError_t hash_rows_sha3(const uint64_t *d_lde, uint8_t *d_leaves, unsigned wid
     hipLaunchKernelGGL(k_hash_rows_sha3, dim3((unsigned)((n + 255) / 256), nk), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b, k0);
     return hipGetLastError();
 }
+// Proof of work with the Sha3 coin (blake3.hip k_grind / k_grind_batch are the Blake3 forms): SHA3-256(seed || le64(nonce)), one
+// Keccak block; seeds = [batch][4] 64-bit words, found[batch] preset to ~0, grid.y = proof
+__global__ __launch_bounds__(256) void k_grind_sha3(const uint64_t *__restrict__ seeds, uint64_t base, uint64_t count, uint64_t mask,
+                                                    unsigned long long *__restrict__ found) {
+    const uint64_t i = blockIdx.x * (uint64_t)256 + threadIdx.x;
+    const unsigned t = blockIdx.y;
+    if (i >= count || found[t] < base) return;
+    const uint64_t nonce = base + i;
+    uint64_t s[25];
+#pragma unroll
+    for (int q = 0; q < 25; q++) s[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) s[q] = seeds[4 * (size_t)t + q];
+    s[4] = nonce;
+    s[5] = 0x06;                       // pad10*1 with the SHA-3 domain bits after the 40-byte message
+    s[16] = 0x8000000000000000ULL;     // ... and at the end of the 136-byte rate
+    keccak::permute(s);
+    if ((s[0] & mask) == 0) atomicMin(found + t, (unsigned long long)nonce);
+}
+hipError_t grind_batch_chunk_sha3(const uint64_t *d_seeds, unsigned batch, uint64_t base, uint64_t count, unsigned bits, unsigned long long *d_found,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(k_grind_sha3, dim3((unsigned)((count + 255) / 256), batch), dim3(256), 0, stream, d_seeds, base, count,
+                       bits >= 64 ? ~0ull : ((1ull << bits) - 1), d_found);
+    return hipGetLastError();
+}
 hipError_t merkle_build_sha3(uint8_t *d_nodes, unsigned log_leaves, hipStream_t stream) {
     size_t cnt = ((size_t)1 << log_leaves) >> 1;
     for (; cnt > 1024; cnt >>= 1)

@@ -211,7 +211,7 @@ def test_merkle_fused_evaluator_at_2_18_depth_15(oracle, backend):
 
 # ---- the batched range prover ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opts", [OPTS, (30, 8, 3, 1, 0, 4, 128), (42, 8, 0, 0, 0, 4, 512), (96, 8, 0, 0, 0, 4, 1024),
-                                  (20, 8, 13, 0, 0, 4, 256)])   # the last one: proof of work by the device-side search, all proofs at once
+                                  (20, 8, 13, 0, 0, 4, 256), (20, 8, 12, 1, 0, 4, 256)])   # the last two: proof of work by the device-side search, all proofs at once
 def test_batched_range_proofs_equal_single_proofs(oracle, backend, opts):
     """cstark_range_prove_batch: B reference-shaped proofs in one call (benches/range.rs:15-37 proves them one by one); every proof
     must equal cstark_air_prove's bytes -- and, for a sample, the CPU prover's -- and verify."""

@@ -101,11 +101,12 @@ def test_unsupported_options_are_refused():
 
 @pytest.mark.parametrize("n_tx,depth,opts", [(2, 3, (42, 8, 0, 0, 0, 4, 256)), (8, 15, (28, 8, 0, 0, 0, 4, 128)),
                                              (4, 7, (16, 8, 8, 0, 0, 4, 1024)), (64, 15, (96, 8, 0, 0, 0, 4, 256)),
-                                             (2, 3, (20, 8, 15, 0, 0, 4, 256)), (2, 3, (20, 8, 13, 0, 1, 4, 256))])
+                                             (2, 3, (20, 8, 15, 0, 0, 4, 256)), (2, 3, (20, 8, 13, 0, 1, 4, 256)),
+                                             (2, 3, (20, 8, 13, 1, 0, 4, 256))])
 def test_proof_bytes_equal_the_cpu_restatement(n_tx, depth, opts):
     """Bit-exact whole-pipeline parity (trace -> LDE -> commitments -> constraints -> composition -> DEEP -> FRI -> openings),
     including a proof-of-work nonce search (grinding 8 on the host; 15 and, with the quadratic extension, 13 bits by the device-side
-    search) and the other remainder sizes."""
+    search, the last case with the Sha3 coin) and the other remainder sizes."""
     from oracle import oracle as O
     from oracle import prover as OP
     from oracle import verifier as V
