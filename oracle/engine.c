@@ -386,26 +386,30 @@ void cso_evaluate_polys_at(const uint64_t *coeffs, uint32_t width, unsigned log_
 }
 
 
-/* ---- FRI layer folding (folding factor 4) [UPSTREAM-RECALL winterfell-fri v0.3 apply_drp] --------------------------------
- * evals: N evaluations of f over offset * <w_N> in natural order.  Output: N/4 evaluations over offset^4 * <w_{N/4}> of
- * f'(y) = sum_k alpha^k f_k(y) where f(x) = sum_k x^k f_k(x^4): row i = { evals[i + t N/4] } are f at x_i zeta^t
- * (zeta = w_N^(N/4)), the degree-3 polynomial through them is evaluated at alpha. */
-void cso_fri_fold4(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, uint64_t alpha) {
-    const size_t N = (size_t)1 << log_n, Q = N / 4;
-    fp w = fp_root_of_unity(log_n), zeta_inv = fp_inv(fp_pow(w, Q)), inv4 = fp_inv(fp_from_u64(4));
+/* ---- FRI layer folding (folding factor f = 2^log_f: 4, 8, 16) [UPSTREAM-RECALL winterfell-fri v0.3 apply_drp] ----------------
+ * evals: N evaluations of p over offset * <w_N> in natural order.  Output: N/f evaluations over offset^f * <w_{N/f}> of
+ * p'(y) = sum_k alpha^k p_k(y) where p(x) = sum_k x^k p_k(x^f): row i = { evals[i + t N/f] } are p at x_i zeta^t
+ * (zeta = w_N^(N/f)), the degree-(f-1) polynomial through them is evaluated at alpha:
+ * (1/f) sum_k (alpha / x_i)^k sum_t v_t zeta^(-t k).  FriOptions::folding_factor: examples/state-transition.rs:46-47 (-f). */
+void cso_fri_fold(const uint64_t *evals, uint64_t *out, unsigned log_n, unsigned log_f, uint64_t offset, uint64_t alpha) {
+    const size_t N = (size_t)1 << log_n, F = (size_t)1 << log_f, Q = N / F;
+    fp w = fp_root_of_unity(log_n), zeta_inv = fp_inv(fp_pow(w, Q)), invf = fp_inv(fp_from_u64(F));
     fp winv = fp_inv(w), oinv = fp_inv(offset);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < Q; i++) {
         fp xinv = fp_mul(oinv, fp_pow(winv, i));      /* 1 / x_i */
         fp r = fp_mul(alpha, xinv), rk = FP_ONE, acc = 0; /* (alpha / x)^k */
-        for (int k = 0; k < 4; k++) {
+        for (size_t k = 0; k < F; k++) {
             fp zk = fp_pow(zeta_inv, k), zt = FP_ONE, s = 0; /* sum_t v_t zeta^(-t k) */
-            for (int t = 0; t < 4; t++) { s = fp_add(s, fp_mul(evals[i + t * Q], zt)); zt = fp_mul(zt, zk); }
+            for (size_t t = 0; t < F; t++) { s = fp_add(s, fp_mul(evals[i + t * Q], zt)); zt = fp_mul(zt, zk); }
             acc = fp_add(acc, fp_mul(rk, s));
             rk = fp_mul(rk, r);
         }
-        out[i] = fp_mul(acc, inv4);
+        out[i] = fp_mul(acc, invf);
     }
+}
+void cso_fri_fold4(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, uint64_t alpha) {
+    cso_fri_fold(evals, out, log_n, 2, offset, alpha);
 }
 
 /* ---- SHA3-256 (FIPS 202): HashFunction::Sha3_256 of the reference's ProofOptions (examples/state-transition.rs:67-71) ------ */

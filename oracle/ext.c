@@ -118,10 +118,10 @@ void cso_deep_composition_ext(const uint64_t *trace_lde, const uint64_t *comp_ld
         }
 }
 
-/* FRI folding by 4 over the extension: evals [m][N] component-major over offset * <w_N>; out [m][N/4] */
-void cso_fri_fold4_ext(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, const uint64_t *alphap, int m) {
-    const size_t N = (size_t)1 << log_n, Q = N / 4;
-    const fp w = fp_root_of_unity(log_n), zeta_inv = fp_inv(fp_pow(w, Q)), inv4 = fp_inv(fp_from_u64(4));
+/* FRI folding by f = 2^log_f over the extension: evals [m][N] component-major over offset * <w_N>; out [m][N/f] */
+void cso_fri_fold_ext(const uint64_t *evals, uint64_t *out, unsigned log_n, unsigned log_f, uint64_t offset, const uint64_t *alphap, int m) {
+    const size_t N = (size_t)1 << log_n, F = (size_t)1 << log_f, Q = N / F;
+    const fp w = fp_root_of_unity(log_n), zeta_inv = fp_inv(fp_pow(w, Q)), invf = fp_inv(fp_from_u64(F));
     const fp winv = fp_inv(w), oinv = fp_inv(offset);
     const E alpha = e_load(alphap, m);
 #pragma omp parallel for schedule(static)
@@ -129,11 +129,11 @@ void cso_fri_fold4_ext(const uint64_t *evals, uint64_t *out, unsigned log_n, uin
         const fp xinv = fp_mul(oinv, fp_pow(winv, i));
         const E r = e_scale(alpha, xinv);
         E rk = e_one(), acc = e_zero();
-        for (int k = 0; k < 4; k++) {
+        for (size_t k = 0; k < F; k++) {
             const fp zk = fp_pow(zeta_inv, k);
             fp zt = FP_ONE;
             E s = e_zero();
-            for (int t = 0; t < 4; t++) {
+            for (size_t t = 0; t < F; t++) {
                 E v = e_zero();
                 for (int q = 0; q < m; q++) v.c[q] = evals[(size_t)q * N + i + t * Q];
                 s = e_add(s, e_scale(v, zt));
@@ -142,7 +142,10 @@ void cso_fri_fold4_ext(const uint64_t *evals, uint64_t *out, unsigned log_n, uin
             acc = e_add(acc, e_mul(rk, s, m));
             rk = e_mul(rk, r, m);
         }
-        acc = e_scale(acc, inv4);
+        acc = e_scale(acc, invf);
         for (int q = 0; q < m; q++) out[(size_t)q * Q + i] = acc.c[q];
     }
+}
+void cso_fri_fold4_ext(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, const uint64_t *alphap, int m) {
+    cso_fri_fold_ext(evals, out, log_n, 2, offset, alphap, m);
 }

@@ -89,6 +89,8 @@ void cso_deep_composition_ext(const uint64_t *trace_lde, const uint64_t *comp_ld
                               const uint64_t *delta, const uint64_t *deg_ap, const uint64_t *deg_bp, uint64_t *out, unsigned log_n, unsigned log_b, int m);
 void cso_fri_fold4_ext(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, const uint64_t *alphap, int m);
 void cso_fri_fold4(const uint64_t *evals, uint64_t *out, unsigned log_n, uint64_t offset, uint64_t alpha);
+void cso_fri_fold(const uint64_t *evals, uint64_t *out, unsigned log_n, unsigned log_f, uint64_t offset, uint64_t alpha);
+void cso_fri_fold_ext(const uint64_t *evals, uint64_t *out, unsigned log_n, unsigned log_f, uint64_t offset, const uint64_t *alphap, int m);
 uint64_t cso_poly_eval(const uint64_t *co, size_t n, uint64_t x);
 uint64_t cso_tx_combined_from_frame(const uint64_t *cur, const uint64_t *next, const cstark_tx_coeffs *cf, const uint64_t pub_inputs[4],
                                     unsigned depth, unsigned log_n, unsigned log_b, uint64_t z);

@@ -589,11 +589,17 @@ def deep_composition(trace_lde, comp_lde, z, ood_trace, ood_comp, alpha, beta, d
     return out
 
 
-def fri_fold4(evals, offset, alpha):
+def fri_fold(evals, offset, alpha, folding=4):
+    """one FRI layer: N evaluations over offset <w_N> (natural order) -> N / folding over offset^folding <w_(N/folding)>"""
     evals = _u64(evals)
-    out = np.zeros(evals.size // 4, np.uint64)
-    lib().cso_fri_fold4(_p(evals), _p(out), C.c_uint(evals.size.bit_length() - 1), C.c_uint64(offset), C.c_uint64(alpha))
+    out = np.zeros(evals.size // folding, np.uint64)
+    lib().cso_fri_fold(_p(evals), _p(out), C.c_uint(evals.size.bit_length() - 1), C.c_uint(folding.bit_length() - 1), C.c_uint64(offset),
+                       C.c_uint64(alpha))
     return out
+
+
+def fri_fold4(evals, offset, alpha):
+    return fri_fold(evals, offset, alpha, 4)
 
 
 # ---- FieldExtension::Quadratic / Cubic (oracle/ext.c): elements as m-tuples of memory-form base elements ---------------------------
@@ -618,9 +624,14 @@ def deep_composition_ext(trace_lde, comp_lde, zp, ood_trace, ood_comp, alpha, be
     return out
 
 
-def fri_fold4_ext(evals, offset, alphap):
+def fri_fold_ext(evals, offset, alphap, folding=4):
     evals, alphap = _u64(evals), _u64(alphap)
     m, N = evals.shape
-    out = np.zeros((m, N // 4), np.uint64)
-    lib().cso_fri_fold4_ext(_p(evals), _p(out), C.c_uint(N.bit_length() - 1), C.c_uint64(offset), _p(alphap), C.c_int(m))
+    out = np.zeros((m, N // folding), np.uint64)
+    lib().cso_fri_fold_ext(_p(evals), _p(out), C.c_uint(N.bit_length() - 1), C.c_uint(folding.bit_length() - 1), C.c_uint64(offset), _p(alphap),
+                           C.c_int(m))
     return out
+
+
+def fri_fold4_ext(evals, offset, alphap):
+    return fri_fold_ext(evals, offset, alphap, 4)

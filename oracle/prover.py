@@ -42,12 +42,9 @@ class TxJob:
         return O.tx_evaluate_constraints(lde, cf, pub4, self.w.depth, 3, k0=k0)
 
 
-def _on_ce_cosets(evaluate, lde, nc, log_ce):
-    """transition values [8][nc][n] on the cosets of the constraint-evaluation domain only (every (8 >> log_ce)-th), zeros elsewhere"""
-    out = np.zeros((8, nc, lde.shape[2]), np.uint64)
-    for k in range(0, 8, 8 >> log_ce):
-        out[k] = evaluate(lde[k:k + 1], k)[0]
-    return out
+# combine(trace, ce_lde, ...): ce_lde [ce][width][n] is the trace on the CONSTRAINT-EVALUATION domain -- the ce = 2^log_ce cosets
+# g w_(ce n)^k <w_n> the AIR's degrees need -- which is every (blowup / ce)-th coset of the LDE domain (the same points, whatever the blowup
+# factor); the merged evaluations come back as [ce][n].  (TxJob also takes a window [k0, k0 + nk) of its 8 cosets: sharded proofs.)
 
 
 class MerkleJob:
@@ -65,12 +62,12 @@ class MerkleJob:
         return [int(trace[58 + i, 0]) for i in range(7)] + [int(trace[58 + i, n - 1]) for i in range(7)], b""
 
     def combine(self, trace, lde, ta, tb, ba, bb, k0=0):
-        assert k0 == 0 and lde.shape[0] == 8
+        assert k0 == 0 and lde.shape[0] == 4
         log_n = trace.shape[1].bit_length() - 1
         if not hasattr(self, "ev"):  # once per proof (extension proofs merge m coefficient sets)
-            ptab = O.periodic_table(O.merkle_periodic_columns(self.w.depth), log_n, 3)
-            self.ev = _on_ce_cosets(lambda l, k: O.air_evaluate_transitions(O.AIR_MERKLE, l, ptab, 106, k0=k), lde, 106, 2)
-        return O.air_combine(O.merkle_desc(trace), lde, self.ev, ta, tb, ba, bb, 3)
+            ptab = O.periodic_table(O.merkle_periodic_columns(self.w.depth), log_n, 2)
+            self.ev = O.air_evaluate_transitions(O.AIR_MERKLE, lde, ptab, 106)
+        return O.air_combine(O.merkle_desc(trace), lde, self.ev, ta, tb, ba, bb, 2)
 
 
 class RangeJob:
@@ -91,10 +88,10 @@ class RangeJob:
         return [int(self.number)], b""
 
     def combine(self, trace, lde, ta, tb, ba, bb, k0=0):
-        assert k0 == 0 and lde.shape[0] == 8
+        assert k0 == 0 and lde.shape[0] == 2
         if not hasattr(self, "ev"):
-            self.ev = _on_ce_cosets(lambda l, k: O.air_evaluate_transitions(O.AIR_RANGE, l, None, 2, k0=k), lde, 2, 1)
-        return O.air_combine(O.range_desc(V.from_mont(self.number)), lde, self.ev, ta, tb, ba, bb, 3)
+            self.ev = O.air_evaluate_transitions(O.AIR_RANGE, lde, None, 2)
+        return O.air_combine(O.range_desc(V.from_mont(self.number)), lde, self.ev, ta, tb, ba, bb, 1)
 
 
 class SchnorrJob:
@@ -122,15 +119,47 @@ class SchnorrJob:
         return O.air_combine(O.schnorr_desc(w), lde, self.ev, ta, tb, ba, bb, 3, avals=self.avals)
 
 
+# the ProofOptions values the reference itself passes: blowup 4 / 8 (src/merkle/update/tests.rs:41-44, src/range/tests.rs:87-90,
+# benches/rescue.rs:370-378, src/lib.rs:78-86), any blowup / FRI folding factor from the command line (examples/state-transition.rs:33-34,
+# :46-47).  Supported here and by the product: blowup 2 .. 16 (at least the AIR's constraint-evaluation blowup), folding 4 / 8 / 16.
+BLOWUPS, FOLDINGS = (2, 4, 8, 16), (4, 8, 16)
+
+
+def check_options(options, job):
+    nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
+    assert blowup in BLOWUPS and blowup >= job.ce, "blowup factor below the AIR's constraint-evaluation blowup"
+    assert folding in FOLDINGS and hash_fn in (0, 1) and ext in (0, 1, 2)
+    assert max_rem in (128, 256, 512, 1024)
+
+
+def num_fri_layers(log_N, log_rem, log_f):
+    """FriOptions::num_fri_layers [UPSTREAM-RECALL]: fold while the domain exceeds fri_max_remainder"""
+    layers = 0
+    while log_N > log_rem:
+        log_N -= log_f
+        layers += 1
+    return layers
+
+
+def _path(nodes, leaves_log, pos):
+    L = 1 << leaves_log
+    return b"".join(nodes[((L + pos) >> lvl) ^ 1].tobytes() for lvl in range(leaves_log))
+
+
 class ShardedProver:
     """The base-field prover as the phases of the product's sharded entry points (cstark_tx_shard_*, include/cstark.h): one proof
-    across `world` ranks by LDE coset.  Rank r owns cosets [k0, k0 + nk); prove() below is the one-rank case.  A phase's output that
-    other ranks need is returned as a numpy array; the caller exchanges it (all-gather / broadcast / sum)."""
+    across `world` ranks by LDE coset.  Rank r owns cosets [k0, k0 + nk); prove() below is the one-rank case (nk = blowup: any supported
+    blowup factor; several ranks: blowup 8).  A phase's output that other ranks need is returned as a numpy array; the caller exchanges
+    it (all-gather / broadcast / sum)."""
 
-    def __init__(self, w, options, k0=0, nk=8, job=None):
+    def __init__(self, w, options, k0=0, nk=None, job=None):
         nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
-        assert blowup == 8 and hash_fn in (0, 1) and ext == 0 and folding == 4
         self.job = job if job is not None else TxJob(w)
+        check_options(options, self.job)
+        assert ext == 0
+        self.b, self.log_b, self.log_f = blowup, blowup.bit_length() - 1, folding.bit_length() - 1
+        nk = blowup if nk is None else nk
+        assert nk == blowup or (blowup == 8 and self.job.ce == 8), "sharded proofs: blowup 8, an AIR that is evaluated on all eight cosets"
         self.w, self.options, self.k0, self.nk = w, tuple(options), k0, nk
         self.H = lambda data: O.digest(data, hash_fn)
 
@@ -141,21 +170,22 @@ class ShardedProver:
         self.n = self.trace.shape[1]
         self.log_n = self.n.bit_length() - 1
         self.coeffs = O.interpolate_columns(self.trace.copy())
-        self.lde = O.lde_columns(self.coeffs, 3, k0=self.k0, nk=self.nk)
+        self.lde = O.lde_columns(self.coeffs, self.log_b, k0=self.k0, nk=self.nk)
         return np.stack([O.hash_rows(self.lde[i:i + 1], 0, hash_fn=hash_fn) for i in range(self.nk)])
 
     def evaluate(self, leaves_all):
-        """leaves_all [8][n][32] coset-major -> tree, channel, coefficients, merged evaluations of the owned cosets [nk][n]"""
+        """leaves_all [b][n][32] coset-major -> tree, channel, coefficients, merged evaluations: [ce][n] on the constraint-evaluation
+        domain (one rank), or of the owned cosets (several ranks)"""
         nq, blowup, grinding, hash_fn, ext, folding, max_rem = self.options
-        n, log_n, trace = self.n, self.log_n, self.trace
-        natural = np.ascontiguousarray(np.transpose(leaves_all, (1, 0, 2))).reshape(8 * n, 32)  # leaf 8 j + k
+        n, log_n, trace, b = self.n, self.log_n, self.trace, self.b
+        natural = np.ascontiguousarray(np.transpose(leaves_all, (1, 0, 2))).reshape(b * n, 32)  # leaf b j + k
         self.tnodes = O.merkle_build(natural, hash_fn)
         self.trace_root = self.tnodes[1].tobytes()
         self.log_rem = max_rem.bit_length() - 1
         job = self.job
         pub_m, pub_bytes = job.public(trace)
         pub = [V.from_mont(v) for v in pub_m]
-        seed = bytes([job.width, log_n]) + struct.pack("<Q", V.P) + bytes([nq, 3, grinding, hash_fn, ext, folding, self.log_rem])
+        seed = bytes([job.width, log_n]) + struct.pack("<Q", V.P) + bytes([nq, self.log_b, grinding, hash_fn, ext, folding, self.log_rem])
         seed += b"".join(struct.pack("<Q", v) for v in pub) + pub_bytes
         self.coin = coin = V.Coin(seed, hash_fn)
         coin.reseed(self.trace_root)
@@ -164,6 +194,8 @@ class ShardedProver:
             ta[i], tb[i] = _mont(coin.draw()), _mont(coin.draw())
         for i in range(job.na):
             ba[i], bb[i] = _mont(coin.draw()), _mont(coin.draw())
+        if self.nk == b:  # the constraint-evaluation domain: every (b / ce)-th coset of the LDE domain
+            return job.combine(trace, np.ascontiguousarray(self.lde[::b // job.ce]), ta, tb, ba, bb)
         own = job.combine(trace, self.lde, ta, tb, ba, bb, k0=self.k0)
         if self.nk not in (2, 4):
             return own
@@ -178,10 +210,10 @@ class ShardedProver:
         return rows
 
     def compose(self, combined):
-        """combined: the ranks' rows of evaluate() side by side ([8][n] when every rank hands over whole cosets); the owner of coset 0:
-        composition .. FRI -> query positions"""
+        """combined: the merged evaluations on the constraint-evaluation domain [ce][n] (several ranks: their rows of evaluate() side by
+        side); the owner of coset 0: composition .. FRI -> query positions"""
         assert self.k0 == 0
-        if self.nk in (2, 4) and combined.shape[0] != 8:
+        if self.nk in (2, 4) and self.nk != self.b and combined.shape[0] != 8:
             world, nkc, rows = 8 // self.nk, self.nk // 2, self.nk // 2 + 4
             parts = combined.reshape(world, rows, self.n)
             full = np.zeros((8, self.n), np.uint64)
@@ -195,10 +227,10 @@ class ShardedProver:
             combined = full
         nq, blowup, grinding, hash_fn, ext, folding, max_rem = self.options
         H, coin, log_n, n = self.H, self.coin, self.log_n, self.n
-        log_b, b, W, ce = 3, 8, self.job.width, self.job.ce
-        log_N, N = log_n + 3, n * 8
-        # a constraint-evaluation domain smaller than the LDE domain is the sub-domain of every (b / ce)-th LDE coset
-        self.ccoef = ccoef = O.composition_columns(np.ascontiguousarray(combined[::b // ce]))
+        log_b, b, W, ce, log_f = self.log_b, self.b, self.job.width, self.job.ce, self.log_f
+        log_N, N = log_n + log_b, n * b
+        assert combined.shape == (ce, n)
+        self.ccoef = ccoef = O.composition_columns(np.ascontiguousarray(combined))
         self.clde = clde = O.lde_columns(ccoef, log_b)
         self.cnodes = O.merkle_build(O.hash_rows(clde, log_b, hash_fn=hash_fn), hash_fn)
         self.cons_root = self.cnodes[1].tobytes()
@@ -217,23 +249,23 @@ class ShardedProver:
         d_delta = [_mont(coin.draw()) for _ in range(ce)]
         deg_a, deg_b = _mont(coin.draw()), _mont(coin.draw())
         # the DEEP composition polynomial has degree < n: coset 0 of the extended trace determines it (as the product computes it)
-        if self.nk == 8:
+        if self.nk == b:
             deep = O.deep_composition(self.lde, clde, zm, ood_trace.reshape(-1), ood_comp, d_alpha, d_beta, d_delta, deg_a, deg_b, log_b)
         else:
             d0 = O.deep_composition(self.lde[:1], clde[:1], zm, ood_trace.reshape(-1), ood_comp, d_alpha, d_beta, d_delta, deg_a, deg_b, log_b)
             deep = O.lde_columns(O.interpolate_columns(d0.reshape(1, n).copy()), log_b, offset=int(O.to_mont([1])[0]))[:, 0, :]
-        layer = np.ascontiguousarray(deep.T).reshape(-1)            # natural order i = 8 j + k
+        layer = np.ascontiguousarray(deep.T).reshape(-1)            # natural order i = b j + k
         self.layers, self.trees, self.roots = [], [], []
         offset, lg = V.GEN, log_N
         while lg > self.log_rem:
-            rows = 1 << (lg - 2)
-            nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 4, rows), 0, hash_fn=hash_fn), hash_fn)
+            rows = 1 << (lg - log_f)  # row i of a layer: the `folding` evaluations { e[i + t rows] } that fold into position i
+            nodes = O.merkle_build(O.hash_rows(layer.reshape(1, folding, rows), 0, hash_fn=hash_fn), hash_fn)
             self.layers.append(layer); self.trees.append(nodes); self.roots.append(nodes[1].tobytes())
             coin.reseed(self.roots[-1])
             alpha = coin.draw()
-            layer = O.fri_fold4(layer, _mont(offset), _mont(alpha))
-            offset = pow(offset, 4, V.P)
-            lg -= 2
+            layer = O.fri_fold(layer, _mont(offset), _mont(alpha), folding)
+            offset = pow(offset, folding, V.P)
+            lg -= log_f
         self.remainder = layer
         self.rem_commit = H(V.elem_bytes(layer))
         coin.reseed(self.rem_commit)
@@ -246,42 +278,38 @@ class ShardedProver:
         return np.array(self.positions, np.uint32)
 
     def open_rows(self, positions):
-        """rows of the extended trace at the positions that lie in the owned cosets, zeros elsewhere: [nq][94]"""
+        """rows of the extended trace at the positions that lie in the owned cosets, zeros elsewhere: [nq][width]"""
         out = np.zeros((len(positions), self.job.width), np.uint64)
         for q, p in enumerate(positions):
-            k, j = int(p) & 7, int(p) >> 3
+            k, j = int(p) & (self.b - 1), int(p) >> self.log_b
             if self.k0 <= k < self.k0 + self.nk:
                 out[q] = self.lde[k - self.k0, :, j]
         return out
 
     def finish(self, rows):
-        """rows [nq][94] complete -> proof bytes (layout: include/cstark.h)"""
-        positions, log_n = self.positions, self.log_n
-        log_N = log_n + 3
-
-        def path(nodes, leaves_log, pos):
-            L = 1 << leaves_log
-            return b"".join(nodes[((L + pos) >> lvl) ^ 1].tobytes() for lvl in range(leaves_log))
+        """rows [nq][width] complete -> proof bytes (layout: include/cstark.h)"""
+        positions, log_n, log_f, folding = self.positions, self.log_n, self.log_f, self.options[5]
+        log_N = log_n + self.log_b
 
         def row(tab, pos):  # tab [b][width][n] coset-major
-            return np.ascontiguousarray(tab[pos & 7, :, pos >> 3]).tobytes()
+            return np.ascontiguousarray(tab[pos & (self.b - 1), :, pos >> self.log_b]).tobytes()
 
         roots = self.roots
         out = [b"CSTK", struct.pack("<IIIII", 1, self.job.air, self.job.width, log_n, self.job.item), struct.pack("<7I", *self.options),
                self.trace_root, self.cons_root, struct.pack("<I", len(roots))] + roots + [self.rem_commit, self.ood_trace.tobytes(),
                                                                                          self.ood_comp.tobytes(), struct.pack("<Q", self.nonce)]
-        out += [np.ascontiguousarray(rows[q]).tobytes() for q in range(len(positions))] + [path(self.tnodes, log_N, p) for p in positions]
-        out += [row(self.clde, p) for p in positions] + [path(self.cnodes, log_N, p) for p in positions]
+        out += [np.ascontiguousarray(rows[q]).tobytes() for q in range(len(positions))] + [_path(self.tnodes, log_N, p) for p in positions]
+        out += [row(self.clde, p) for p in positions] + [_path(self.cnodes, log_N, p) for p in positions]
         cur, lg = positions, log_N
         for l in range(len(self.layers)):
-            rows_l = 1 << (lg - 2)
+            rows_l = 1 << (lg - log_f)
             fpos = V.fold_positions(cur, rows_l)
             out.append(struct.pack("<I", len(fpos)))
-            tab = self.layers[l].reshape(4, rows_l)
+            tab = self.layers[l].reshape(folding, rows_l)
             out += [np.ascontiguousarray(tab[:, p]).tobytes() for p in fpos]
-            out += [path(self.trees[l], lg - 2, p) for p in fpos]
+            out += [_path(self.trees[l], lg - log_f, p) for p in fpos]
             cur = fpos
-            lg -= 2
+            lg -= log_f
         out += [struct.pack("<I", self.remainder.size), self.remainder.tobytes()]
         return b"".join(out)
 
@@ -323,18 +351,19 @@ def prove_air(air, witness, options=(42, 8, 0, 0, 0, 4, 256), log_n=6):
 def prove_ext(job, options):
     """FieldExtension::Quadratic / Cubic: base-field trace, everything drawn from the coin in the degree-m extension (oracle/ext.c).
     Layout differences: out-of-domain values are m-tuples; composition rows hold ce m-tuples; FRI rows and the remainder are
-    component-major (component 0 of the four points, then component 1, ...)."""
+    component-major (component 0 of the `folding` points, then component 1, ...)."""
     if not hasattr(job, "combine"):
         job = TxJob(job)  # a TxWitness
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = options
-    assert blowup == 8 and hash_fn in (0, 1) and ext in (1, 2) and folding == 4
+    check_options(options, job)
+    assert ext in (1, 2)
     m = ext + 1
     H = lambda data: O.digest(data, hash_fn)
-    log_b, b, W, ce = 3, 8, job.width, job.ce
+    log_b, b, W, ce, log_f = blowup.bit_length() - 1, blowup, job.width, job.ce, folding.bit_length() - 1
     trace = job.build()
     n = trace.shape[1]
     log_n = n.bit_length() - 1
-    log_N, N = log_n + 3, n * 8
+    log_N, N = log_n + log_b, n * b
     log_rem = max_rem.bit_length() - 1
     pub_m, pub_bytes = job.public(trace)
     pub = [V.from_mont(v) for v in pub_m]
@@ -357,8 +386,9 @@ def prove_ext(job, options):
         for k in range(m):
             ba[k, i], bb[k, i] = _mont(a[k]), _mont(bt[k])
     # coefficients multiply base-field values: the components of the merged evaluations are independent base-field merges (on the
-    # cosets of the constraint-evaluation domain: every (b / ce)-th LDE coset)
-    cc = [O.composition_columns(np.ascontiguousarray(job.combine(trace, lde, ta[k], tb[k], ba[k], bb[k])[::b // ce])) for k in range(m)]
+    # constraint-evaluation domain: every (b / ce)-th LDE coset)
+    ce_lde = np.ascontiguousarray(lde[::b // ce])
+    cc = [O.composition_columns(np.ascontiguousarray(job.combine(trace, ce_lde, ta[k], tb[k], ba[k], bb[k]))) for k in range(m)]
     ccoef = np.ascontiguousarray(np.stack(cc, axis=1).reshape(m * ce, n))  # column m i + k = component k of H_i
     clde = O.lde_columns(ccoef, log_b)
     cnodes = O.merkle_build(O.hash_rows(clde, log_b, hash_fn=hash_fn), hash_fn)
@@ -370,7 +400,7 @@ def prove_ext(job, options):
     zb = V.e_pow(z, ce)
     ood_cur = O.evaluate_polys_at_ext(coeffs, V.e_mont(z))
     ood_next = O.evaluate_polys_at_ext(coeffs, V.e_mont(zw))
-    raw = O.evaluate_polys_at_ext(ccoef, V.e_mont(zb))                     # each component polynomial at z^8
+    raw = O.evaluate_polys_at_ext(ccoef, V.e_mont(zb))                     # each component polynomial at z^ce
     ood_comp = np.zeros((ce, m), np.uint64)
     for i in range(ce):
         h, gk = V.e_base(0, m), V.e_base(1, m)
@@ -394,14 +424,14 @@ def prove_ext(job, options):
     layers, trees, roots = [], [], []
     offset, lg = V.GEN, log_N
     while lg > log_rem:
-        rows = 1 << (lg - 2)
-        nodes = O.merkle_build(O.hash_rows(layer.reshape(1, 4 * m, rows), 0, hash_fn=hash_fn), hash_fn)
+        rows = 1 << (lg - log_f)
+        nodes = O.merkle_build(O.hash_rows(layer.reshape(1, folding * m, rows), 0, hash_fn=hash_fn), hash_fn)
         layers.append(layer); trees.append(nodes); roots.append(nodes[1].tobytes())
         coin.reseed(roots[-1])
         alpha = coin.draw_e(m)
-        layer = O.fri_fold4_ext(layer, _mont(offset), V.e_mont(alpha))
-        offset = pow(offset, 4, V.P)
-        lg -= 2
+        layer = O.fri_fold_ext(layer, _mont(offset), V.e_mont(alpha), folding)
+        offset = pow(offset, folding, V.P)
+        lg -= log_f
     remainder = layer
     rem_commit = H(V.elem_bytes(remainder))
     coin.reseed(rem_commit)
@@ -411,27 +441,23 @@ def prove_ext(job, options):
     coin.reseed_int(nonce)
     positions = coin.draw_integers(nq, N)
 
-    def path(nodes, leaves_log, pos):
-        L = 1 << leaves_log
-        return b"".join(nodes[((L + pos) >> lvl) ^ 1].tobytes() for lvl in range(leaves_log))
-
     def row(tab, pos):
-        return np.ascontiguousarray(tab[pos & 7, :, pos >> 3]).tobytes()
+        return np.ascontiguousarray(tab[pos & (b - 1), :, pos >> log_b]).tobytes()
 
     out = [b"CSTK", struct.pack("<IIIII", 1, job.air, W, log_n, job.item), struct.pack("<7I", *options),
            trace_root, cons_root, struct.pack("<I", len(roots))] + roots + [rem_commit, ood_trace.tobytes(), ood_comp.tobytes(),
                                                                            struct.pack("<Q", nonce)]
-    out += [row(lde, p) for p in positions] + [path(tnodes, log_N, p) for p in positions]
-    out += [row(clde, p) for p in positions] + [path(cnodes, log_N, p) for p in positions]
+    out += [row(lde, p) for p in positions] + [_path(tnodes, log_N, p) for p in positions]
+    out += [row(clde, p) for p in positions] + [_path(cnodes, log_N, p) for p in positions]
     cur, lg = positions, log_N
     for l in range(len(layers)):
-        rows = 1 << (lg - 2)
+        rows = 1 << (lg - log_f)
         fpos = V.fold_positions(cur, rows)
         out.append(struct.pack("<I", len(fpos)))
-        tab = layers[l].reshape(4 * m, rows)
+        tab = layers[l].reshape(folding * m, rows)
         out += [np.ascontiguousarray(tab[:, p]).tobytes() for p in fpos]
-        out += [path(trees[l], lg - 2, p) for p in fpos]
+        out += [_path(trees[l], lg - log_f, p) for p in fpos]
         cur = fpos
-        lg -= 2
+        lg -= log_f
     out += [struct.pack("<I", remainder.shape[1]), remainder.tobytes()]
     return b"".join(out)

@@ -7,7 +7,7 @@ Restates `winterfell::verify::<TransactionAir>(proof, pub_inputs)` as called at 
      (oracle C code, cso_tx_combined_from_frame) must equal sum_i z^i H_i(z^8);
   3. Merkle openings of the queried trace / composition rows against the two roots (BLAKE3);
   4. DEEP composition values at the queried points from the opened rows;
-  5. FRI: layer openings, folding consistency layer to layer (factor 4), remainder commitment, remainder degree.
+  5. FRI: layer openings, folding consistency layer to layer (factor 4, 8 or 16), remainder commitment, remainder degree.
 Field arithmetic here is Python integers on canonical values -- deliberately independent of the Montgomery code paths.
 """
 import ctypes as C
@@ -232,13 +232,14 @@ def parse(proof):
     W, ce = shapes[d["air"]]
     d["ce"] = ce
     nq, blowup = d["options"][0], d["options"][1]
-    if blowup != 8 or not (6 <= d["log_n"] <= 21) or not (1 <= nq <= 128):
-        raise VerifierError("unsupported parameters")
+    folding = d["options"][5]
+    if blowup not in (2, 4, 8, 16) or blowup < ce or folding not in (4, 8, 16) or not (6 <= d["log_n"] <= 21) or not (1 <= nq <= 128):
+        raise VerifierError("unsupported parameters")  # (blowup below the AIR's constraint-evaluation blowup: the engine refuses it too)
     ext = d["options"][4]
     if ext not in (0, 1, 2):
         raise VerifierError("unsupported field extension")
     em = ext + 1  # words per element of the field the coin draws from
-    log_N = d["log_n"] + 3
+    log_N, log_f = d["log_n"] + blowup.bit_length() - 1, folding.bit_length() - 1
     d["trace_root"], d["cons_root"] = r.take(32), r.take(32)
     nl = r.u32()
     if nl > 16:
@@ -254,15 +255,15 @@ def parse(proof):
     d["layers"] = []
     lg = log_N
     for _ in range(nl):
-        if lg < 2:
+        if lg < log_f:
             raise VerifierError("too many layers")
         npos = r.u32()
         if npos > nq:
             raise VerifierError("bad layer opening count")
-        rows = r.elems(npos * 4 * em).reshape(npos, 4 * em)
-        paths = [[r.take(32) for _ in range(lg - 2)] for _ in range(npos)]
+        rows = r.elems(npos * folding * em).reshape(npos, folding * em)
+        paths = [[r.take(32) for _ in range(lg - log_f)] for _ in range(npos)]
         d["layers"].append((rows, paths))
-        lg -= 2
+        lg -= log_f
     rl = r.u32()
     if rl > 1024:
         raise VerifierError("bad remainder length")
@@ -568,15 +569,16 @@ def _verify(d, air, options):
     nq, blowup, grinding, hash_fn, ext, folding, max_rem = d["options"]
     if options is not None and list(options) != d["options"]:
         raise VerifierError("proof options differ from the expected ones")
-    if hash_fn not in (0, 1) or ext != 0 or folding != 4 or max_rem & (max_rem - 1) or not (128 <= max_rem <= 1024):
+    if hash_fn not in (0, 1) or ext != 0 or max_rem & (max_rem - 1) or not (128 <= max_rem <= 1024):
         raise VerifierError("unsupported options")
     log_n = d["log_n"]
-    log_b, log_N = 3, log_n + 3
-    n, N, W, b, ce = 1 << log_n, 1 << log_N, air.width, 8, air.ce
+    log_b, log_f = blowup.bit_length() - 1, folding.bit_length() - 1
+    log_N = log_n + log_b
+    n, N, W, b, ce = 1 << log_n, 1 << log_N, air.width, blowup, air.ce
     log_rem = max_rem.bit_length() - 1
     n_layers, lg = 0, log_N
     while lg > log_rem:
-        lg -= 2
+        lg -= log_f
         n_layers += 1
     if n_layers != len(d["layer_roots"]) or len(d["remainder"]) != 1 << lg:
         raise VerifierError("FRI layer structure does not match the options")
@@ -651,9 +653,9 @@ def _verify(d, air, options):
     # 5. FRI
     cur_pos, cur_val = positions, deep
     offset, lgl = GEN, log_N
-    inv4 = pow(4, -1, P)
+    invf = pow(folding, -1, P)
     for l in range(n_layers):
-        rows_n = 1 << (lgl - 2)
+        rows_n = 1 << (lgl - log_f)
         rows, paths = d["layers"][l]
         fpos = fold_positions(cur_pos, rows_n)
         if len(fpos) != len(rows):
@@ -662,9 +664,9 @@ def _verify(d, air, options):
             if merkle_root_from_path(H(elem_bytes(rows[t])), rp, paths[t], hash_fn) != d["layer_roots"][l]:
                 raise VerifierError("layer %d opening does not match its commitment" % l)
         for p, v in zip(cur_pos, cur_val):
-            if from_mont(rows[fpos.index(p & (rows_n - 1))][p >> (lgl - 2)]) != v:
+            if from_mont(rows[fpos.index(p & (rows_n - 1))][p >> (lgl - log_f)]) != v:
                 raise VerifierError("layer %d: evaluation differs from the previous layer's folding" % l)
-        # fold each opened row: 4 evaluations on the coset x * <zeta>, zeta = w^(N_l/4)
+        # fold each opened row: `folding` evaluations on the coset x * <zeta>, zeta = w^(N_l / folding)
         wl = root_of_unity(lgl)
         zeta_inv = pow(pow(wl, rows_n, P), -1, P)
         nxt_val = []
@@ -673,14 +675,14 @@ def _verify(d, air, options):
             x = offset * pow(wl, rp, P) % P
             r = alphas[l] * pow(x, -1, P) % P
             acc, rs = 0, 1
-            for s in range(4):
-                cs = sum(v[k] * pow(zeta_inv, s * k, P) for k in range(4)) % P * inv4 % P
+            for s in range(folding):
+                cs = sum(v[k] * pow(zeta_inv, s * k, P) for k in range(folding)) % P * invf % P
                 acc += cs * rs
                 rs = rs * r % P
             nxt_val.append(acc % P)
         cur_pos, cur_val = fpos, nxt_val
-        offset = pow(offset, 4, P)
-        lgl -= 2
+        offset = pow(offset, folding, P)
+        lgl -= log_f
     rem = [from_mont(v) for v in d["remainder"]]
     for p, v in zip(cur_pos, cur_val):
         if rem[p] != v:
@@ -737,15 +739,15 @@ def _verify_ext(d, air, options):
     m = ext + 1
     if options is not None and list(options) != d["options"]:
         raise VerifierError("proof options differ from the expected ones")
-    if hash_fn not in (0, 1) or folding != 4 or max_rem & (max_rem - 1) or not (128 <= max_rem <= 1024):
+    if hash_fn not in (0, 1) or max_rem & (max_rem - 1) or not (128 <= max_rem <= 1024):
         raise VerifierError("unsupported options")
-    log_n, log_b = d["log_n"], 3
-    log_N = log_n + 3
-    n, N, W, b, ce = 1 << log_n, 1 << log_N, air.width, 8, air.ce
+    log_n, log_b, log_f = d["log_n"], blowup.bit_length() - 1, folding.bit_length() - 1
+    log_N = log_n + log_b
+    n, N, W, b, ce = 1 << log_n, 1 << log_N, air.width, blowup, air.ce
     log_rem = max_rem.bit_length() - 1
     n_layers, lg = 0, log_N
     while lg > log_rem:
-        lg -= 2
+        lg -= log_f
         n_layers += 1
     if n_layers != len(d["layer_roots"]) or len(d["remainder"]) != m << lg:
         raise VerifierError("FRI layer structure does not match the options")
@@ -818,9 +820,9 @@ def _verify_ext(d, air, options):
     # FRI over the extension (rows and remainder component-major)
     cur_pos, cur_val = positions, deep
     offset, lgl = GEN, log_N
-    inv4 = pow(4, -1, P)
+    invf = pow(folding, -1, P)
     for l in range(n_layers):
-        rows_n = 1 << (lgl - 2)
+        rows_n = 1 << (lgl - log_f)
         rows, paths = d["layers"][l]
         fpos = fold_positions(cur_pos, rows_n)
         if len(fpos) != len(rows):
@@ -830,9 +832,9 @@ def _verify_ext(d, air, options):
             if merkle_root_from_path(H(elem_bytes(rows[t])), rp, paths[t], hash_fn) != d["layer_roots"][l]:
                 raise VerifierError("layer %d opening does not match its commitment" % l)
             r = [from_mont(e) for e in rows[t]]
-            vals.append([tuple(r[4 * q + k] for q in range(m)) for k in range(4)])
+            vals.append([tuple(r[folding * q + k] for q in range(m)) for k in range(folding)])
         for p, v in zip(cur_pos, cur_val):
-            if vals[fpos.index(p & (rows_n - 1))][p >> (lgl - 2)] != v:
+            if vals[fpos.index(p & (rows_n - 1))][p >> (lgl - log_f)] != v:
                 raise VerifierError("layer %d: evaluation differs from the previous layer's folding" % l)
         wl = root_of_unity(lgl)
         zeta_inv = pow(pow(wl, rows_n, P), -1, P)
@@ -841,16 +843,16 @@ def _verify_ext(d, air, options):
             x = offset * pow(wl, rp, P) % P
             r = e_scale(alphas[l], pow(x, -1, P))
             acc, rs = B(0), B(1)
-            for s_ in range(4):
+            for s_ in range(folding):
                 cs = B(0)
-                for k in range(4):
+                for k in range(folding):
                     cs = e_add(cs, e_scale(vals[t][k], pow(zeta_inv, s_ * k, P)))
-                acc = e_add(acc, e_mul(e_scale(cs, inv4), rs))
+                acc = e_add(acc, e_mul(e_scale(cs, invf), rs))
                 rs = e_mul(rs, r)
             nxt_val.append(acc)
         cur_pos, cur_val = fpos, nxt_val
-        offset = pow(offset, 4, P)
-        lgl -= 2
+        offset = pow(offset, folding, P)
+        lgl -= log_f
     R = len(d["remainder"]) // m
     comps = [d["remainder"][q * R:(q + 1) * R] for q in range(m)]
     for p, v in zip(cur_pos, cur_val):

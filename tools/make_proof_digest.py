@@ -29,7 +29,7 @@ def section_digests(proof, n_queries, width=94, n_comp=8):
     drawn-field element (1, 2 or 3) are read from the header's field_extension."""
     log_n = struct.unpack_from("<I", proof, 16)[0]
     m = struct.unpack_from("<I", proof, 24 + 16)[0] + 1
-    log_N = log_n + 3
+    log_N = log_n + struct.unpack_from("<I", proof, 24 + 4)[0].bit_length() - 1  # the LDE domain: blowup_factor of the header
     off = 4 + 4 + 16 + 28
     out = {}
 
