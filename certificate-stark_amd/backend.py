@@ -406,12 +406,29 @@ class Backend:
                                         C.c_uint64(int(alpha))))
         return out
 
-    def fri_commit_layer(self, evals):
-        """Merkle tree over the rows { e[i + t N/4] } of a layer; returns the node array (nodes[1] = root)."""
+    def fri_fold(self, evals, offset, alpha, folding=4):
+        """cstark_fri_fold: one FRI layer with folding factor 4, 8 or 16"""
         N = evals.numel()
-        q = N // 4
+        out = self.empty_u64(N // folding)
+        check(self.lib.cstark_fri_fold(self.ctx, self._ptr(evals), self._ptr(out), C.c_uint32(N.bit_length() - 1), C.c_uint32(folding),
+                                       C.c_uint64(int(offset)), C.c_uint64(int(alpha))))
+        return out
+
+    def fri_fold_ext(self, evals, offset, alpha, folding=4):
+        """cstark_fri_fold_ext: evals [m][N] component-major, alpha: m memory-form words"""
+        m, N = evals.shape
+        out = self.empty_u64(m, N // folding)
+        al = (C.c_uint64 * m)(*[int(v) for v in alpha])
+        check(self.lib.cstark_fri_fold_ext(self.ctx, self._ptr(evals), self._ptr(out), C.c_uint32(N.bit_length() - 1), C.c_uint32(folding),
+                                           C.c_uint64(int(offset)), C.c_uint32(m), al))
+        return out
+
+    def fri_commit_layer(self, evals, folding=4):
+        """Merkle tree over the rows { e[i + t N/f] } of a layer; returns the node array (nodes[1] = root)."""
+        N = evals.numel()
+        q = N // folding
         nodes = torch.zeros((2 * q, 32), dtype=torch.uint8, device=self.device)
-        self.hash_rows(evals.view(1, 4, q), 0, leaves=nodes[q:])
+        self.hash_rows(evals.view(1, folding, q), 0, leaves=nodes[q:])
         self.merkle_build(nodes)
         return nodes
 

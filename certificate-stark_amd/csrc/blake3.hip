@@ -48,9 +48,11 @@ __device__ __forceinline__ void compress(uint32_t (&cv)[8], const uint32_t (&m)[
     cv[4] = s4 ^ s12; cv[5] = s5 ^ s13; cv[6] = s6 ^ s14; cv[7] = s7 ^ s15;
 }
 
-// grid = (ceil(n / 256), nk); one lane per row j of coset k0 + blockIdx.y
+// grid = (ceil(n / 256), nk); one lane per row j of coset k0 + blockIdx.y.
+// log_s > 0: the table holds the cosets in BLOCK ORDER (blake3.h, lde_slot_coset): slot kk is LDE coset (kk mod ce) 2^log_s + kk / ce,
+// ce = 2^(log_b - log_s) -- the prover's trace table when the blowup factor exceeds the AIR's constraint-evaluation blowup.
 __global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ lde, uint8_t *__restrict__ leaves, unsigned width, unsigned log_n,
-                                                   unsigned log_b, unsigned k0) {
+                                                   unsigned log_b, unsigned k0, unsigned log_s) {
     const size_t n = (size_t)1 << log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
     if (j >= n) return;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ 
         const uint32_t flags = (b == 0 ? CHUNK_START : 0u) | (b + 1 == nblocks ? (CHUNK_END | ROOT) : 0u);
         compress(cv, m, cnt * 8, flags);
     }
-    const size_t leaf = (j << log_b) + k0 + kk;
+    const size_t leaf = (j << log_b) + lde_slot_coset(k0 + kk, log_b, log_s);
     uint4 *dst = reinterpret_cast<uint4 *>(leaves + 32 * leaf);
     dst[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
     dst[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
@@ -89,12 +91,12 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ 
 // them 32 bytes at a stride of 32 b -- hidden behind twelve compressions for the trace, not behind one: the composition stage 1.55 -> 1.49 ms for the
 // 8 x 2^23 composition table.  Reads become 64-byte segments (8 consecutive rows of one coset and column).  All b cosets present.
 __global__ __launch_bounds__(256) void k_hash_rows_narrow(const uint64_t *__restrict__ lde, uint8_t *__restrict__ leaves, unsigned width, unsigned log_n,
-                                                          unsigned log_b) {
+                                                          unsigned log_b, unsigned log_s) {
     const size_t n = (size_t)1 << log_n;
     const size_t leaf = blockIdx.x * (size_t)256 + threadIdx.x;
     if (leaf >= (n << log_b)) return;
     const size_t j = leaf >> log_b;
-    const unsigned kk = (unsigned)(leaf & ((1u << log_b) - 1));
+    const unsigned kk = lde_coset_slot((unsigned)(leaf & ((1u << log_b) - 1)), log_b, log_s);
     const uint64_t *col = lde + (size_t)kk * width * n + j;
     uint32_t cv[8] = {IV0, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
     const unsigned nblocks = (width + 7) / 8;
@@ -358,14 +360,14 @@ hipError_t merkle_build_batch(uint8_t *d_nodes, unsigned log_leaves, unsigned ba
 #define CS_HASH_NARROW_MAX 16 // widest table hashed leaf-per-lane (the 94-column trace table that way: 2.47 vs 2.29 ms)
 #endif
 hipError_t hash_rows(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, unsigned log_n, unsigned log_b, unsigned k0, unsigned nk,
-                     hipStream_t stream) {
-    if (width == 0 || width > 128) return hipErrorInvalidValue; // single-chunk rows only
+                     hipStream_t stream, unsigned log_s) {
+    if (width == 0 || width > 128 || log_s > log_b) return hipErrorInvalidValue; // single-chunk rows only
     const size_t n = (size_t)1 << log_n;
     if (width <= CS_HASH_NARROW_MAX && log_b >= 1 && k0 == 0 && nk == (1u << log_b)) {
-        hipLaunchKernelGGL(k_hash_rows_narrow, dim3((unsigned)(((n << log_b) + 255) / 256)), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b);
+        hipLaunchKernelGGL(k_hash_rows_narrow, dim3((unsigned)(((n << log_b) + 255) / 256)), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b, log_s);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + 255) / 256), nk), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b, k0);
+    hipLaunchKernelGGL(k_hash_rows, dim3((unsigned)((n + 255) / 256), nk), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b, k0, log_s);
     return hipGetLastError();
 }
 

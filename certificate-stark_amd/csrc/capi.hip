@@ -565,6 +565,19 @@ int cstark_fri_fold4(cstark_ctx *c, const uint64_t *d_evals, uint64_t *d_out, ui
     HIP_TRY(cs::fri_fold4(d_evals, d_out, log_n, p->winv, cs::host::inv(domain_offset), alpha, cs::host::inv(cs::host::from_u64(4)), c->stream));
     return CSTARK_OK;
 }
+// folding_factor = 4, 8 or 16 (FriOptions, examples/state-transition.rs:46-47)
+int cstark_fri_fold(cstark_ctx *c, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint32_t folding_factor, uint64_t domain_offset, uint64_t alpha) {
+    if (!c || !d_evals || !d_out || d_evals == d_out) return fail(CSTARK_ERR_INVALID_ARG, "cstark_fri_fold: bad argument");
+    if (folding_factor != 4 && folding_factor != 8 && folding_factor != 16) return fail(CSTARK_ERR_UNSUPPORTED, "FRI folding factor must be 4, 8 or 16");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "layer size must be 2^6 .. 2^24");
+    if (domain_offset == 0 || domain_offset >= cs::host::P || alpha >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "offset / alpha must be field elements");
+    HIP_TRY(hipSetDevice(c->device));
+    const NttPlan *p;
+    RC_TRY(get_plan(c, log_n, &p));
+    const unsigned log_f = folding_factor == 4 ? 2 : folding_factor == 8 ? 3 : 4;
+    HIP_TRY(cs::fri_fold(d_evals, d_out, log_n, log_f, p->winv, cs::host::inv(domain_offset), alpha, cs::host::inv(cs::host::from_u64(folding_factor)), c->stream));
+    return CSTARK_OK;
+}
 
 // ---- FieldExtension::Quadratic / Cubic: the same three stages over the degree-m extension (ext.hip) ---------------------------
 int cstark_evaluate_polys_at_ext(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, uint32_t log_n, uint32_t m, const uint64_t *z, uint64_t *out) {
@@ -588,13 +601,22 @@ int cstark_evaluate_polys_at_ext(cstark_ctx *c, const uint64_t *d_coeffs, uint32
 
 // internal (ctx.h): one FRI layer's coin on the device (Blake3 coin: reseed with the layer root at d_root, draw the folding point) and the
 // fold with that point; d_state = [seed: 8 words][alpha: one element per layer][roots: 8 words per layer]
-int fri_coin_fold4_dev(cstark_ctx *c, uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, const uint64_t *d_evals,
-                       uint64_t *d_out, uint32_t log_n, uint64_t domain_offset) {
+int fri_coin_fold_dev(cstark_ctx *c, uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, const uint64_t *d_evals,
+                      uint64_t *d_out, uint32_t log_n, uint32_t log_f, uint64_t domain_offset) {
     if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "layer size must be 2^6 .. 2^24");
     const NttPlan *p;
     RC_TRY(get_plan(c, log_n, &p));
     HIP_TRY(cs::fri_coin(d_seed, d_root, d_alpha, d_root_out, c->stream));
-    HIP_TRY(cs::fri_fold4(d_evals, d_out, log_n, p->winv, cs::host::inv(domain_offset), 0, cs::host::inv(cs::host::from_u64(4)), c->stream, d_alpha));
+    HIP_TRY(cs::fri_fold(d_evals, d_out, log_n, log_f, p->winv, cs::host::inv(domain_offset), 0, cs::host::inv(cs::host::from_u64(1ull << log_f)), c->stream, d_alpha));
+    return CSTARK_OK;
+}
+// internal (ctx.h): row hashes of a whole table whose cosets are in block order (blake3.h, lde_coset_slot): leaf b j + k = row j of LDE coset k
+int hash_rows_slots(cstark_ctx *c, uint32_t hash_fn, const uint64_t *d_lde, uint8_t *d_leaves, uint32_t width, uint32_t log_n, uint32_t log_blowup, uint32_t log_s) {
+    if (!c || !d_lde || !d_leaves || width == 0 || width > 128 || hash_fn > 1 || log_blowup > 6 || log_s > log_blowup || ((uintptr_t)d_leaves & 15) != 0)
+        return fail(CSTARK_ERR_INVALID_ARG, "hash_rows_slots: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (hash_fn == 1) HIP_TRY(cs::hash_rows_sha3(d_lde, d_leaves, width, log_n, log_blowup, 0, 1u << log_blowup, c->stream, log_s));
+    else HIP_TRY(cs::hash_rows(d_lde, d_leaves, width, log_n, log_blowup, 0, 1u << log_blowup, c->stream, log_s));
     return CSTARK_OK;
 }
 // internal (ctx.h): both halves of the out-of-domain frame with ONE upload, one readback and one wait -- the trace polynomials at
@@ -689,6 +711,20 @@ int cstark_fri_fold4_ext(cstark_ctx *c, const uint64_t *d_evals, uint64_t *d_out
     const NttPlan *p;
     RC_TRY(get_plan(c, log_n, &p));
     HIP_TRY(cs::fri_fold4_ext(d_evals, d_out, log_n, p->winv, cs::host::inv(domain_offset), alpha, m, cs::host::inv(cs::host::from_u64(4)), c->stream));
+    return CSTARK_OK;
+}
+int cstark_fri_fold_ext(cstark_ctx *c, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint32_t folding_factor, uint64_t domain_offset, uint32_t m,
+                        const uint64_t *alpha) {
+    if (!c || !d_evals || !d_out || !alpha || d_evals == d_out || (m != 2 && m != 3)) return fail(CSTARK_ERR_INVALID_ARG, "cstark_fri_fold_ext: bad argument");
+    if (folding_factor != 4 && folding_factor != 8 && folding_factor != 16) return fail(CSTARK_ERR_UNSUPPORTED, "FRI folding factor must be 4, 8 or 16");
+    if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_UNSUPPORTED, "layer size must be 2^6 .. 2^24");
+    if (domain_offset == 0 || domain_offset >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "offset must be a nonzero field element");
+    for (uint32_t i = 0; i < m; i++) if (alpha[i] >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "alpha is not an extension element");
+    HIP_TRY(hipSetDevice(c->device));
+    const NttPlan *p;
+    RC_TRY(get_plan(c, log_n, &p));
+    const unsigned log_f = folding_factor == 4 ? 2 : folding_factor == 8 ? 3 : 4;
+    HIP_TRY(cs::fri_fold_ext(d_evals, d_out, log_n, log_f, p->winv, cs::host::inv(domain_offset), alpha, m, cs::host::inv(cs::host::from_u64(folding_factor)), c->stream));
     return CSTARK_OK;
 }
 

@@ -124,8 +124,10 @@ struct cstark_ctx {
     size_t rb_dev_bytes = 0, rb_host_bytes = 0;
 };
 // internal (capi.hip): the coin of one FRI layer on the device followed by the fold with the drawn point (prove.hip)
-int fri_coin_fold4_dev(cstark_ctx *c, uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, const uint64_t *d_evals,
-                       uint64_t *d_out, uint32_t log_n, uint64_t domain_offset);
+int fri_coin_fold_dev(cstark_ctx *c, uint32_t *d_seed, const uint8_t *d_root, uint64_t *d_alpha, uint32_t *d_root_out, const uint64_t *d_evals,
+                      uint64_t *d_out, uint32_t log_n, uint32_t log_f, uint64_t domain_offset);
+// internal (capi.hip): row hashes of a whole table whose cosets are in block order (blake3.h): leaf b j + k = row j of LDE coset k
+int hash_rows_slots(cstark_ctx *c, uint32_t hash_fn, const uint64_t *d_lde, uint8_t *d_leaves, uint32_t width, uint32_t log_n, uint32_t log_blowup, uint32_t log_s);
 // internal (capi.hip): the cached twiddle tables of a 2^log_n-point domain: powers of w and of its inverse (device, n entries each)
 int plan_tables(cstark_ctx *c, unsigned log_n, const uint64_t **w, const uint64_t **winv);
 

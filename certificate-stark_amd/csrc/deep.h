@@ -26,5 +26,8 @@ hipError_t deep_composition(const DeepParams &p, unsigned nk, hipStream_t stream
 // d_alpha != null: the folding point is read from device memory instead of `alpha`
 hipError_t fri_fold4(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, const uint64_t *d_winv, uint64_t offset_inv, uint64_t alpha,
                      uint64_t inv4, hipStream_t stream, const uint64_t *d_alpha = nullptr);
+// folding factor 2^log_f = 4, 8, 16; inv_f = 1 / 2^log_f (memory form)
+hipError_t fri_fold(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, unsigned log_f, const uint64_t *d_winv, uint64_t offset_inv, uint64_t alpha,
+                    uint64_t inv_f, hipStream_t stream, const uint64_t *d_alpha = nullptr);
 
 } // namespace cs

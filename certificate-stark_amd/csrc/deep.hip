@@ -104,12 +104,63 @@ __global__ __launch_bounds__(256) void k_fri_fold4(const fp *__restrict__ evals,
     out[i] = fp_mul(acc, inv4);
 }
 
+// Folding factor F = 2^LOG_F = 8, 16 (FriOptions::folding_factor, examples/state-transition.rs:46-47): row i = { f(x_i zeta^t) } =
+// evals[i + t N/F], zeta = w_N^(N/F); the polynomial of degree F - 1 through the row evaluated at alpha:
+// (1/F) sum_k (alpha / x_i)^k s_k,  s_k = sum_t v_t zeta^(-t k): an F-point inverse DFT by radix-2 steps in registers (exact
+// arithmetic: the same values as the direct sums of the CPU restatement), then Horner in alpha / x_i.
+template <int LOG_F>
+__global__ __launch_bounds__(256) void k_fri_fold(const fp *__restrict__ evals, fp *__restrict__ out, size_t q, const fp *__restrict__ winv,
+                                                  fp offset_inv, fp alpha, fp inv_f, const fp *__restrict__ alpha_dev) {
+    constexpr int F = 1 << LOG_F;
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i >= q) return;
+    if (alpha_dev) alpha = *alpha_dev;
+    fp v[F];
+#pragma unroll
+    for (int t = 0; t < F; t++) v[t] = evals[i + (size_t)t * q];
+    // decimation in frequency with the inverse root zeta^-1 = winv[q] (zeta^-e = winv[e q]): outputs in bit-reversed order
+#pragma unroll
+    for (int len = F; len >= 2; len >>= 1) {
+        const int half = len >> 1, step = F / len;
+#pragma unroll
+        for (int base = 0; base < F; base += len) {
+#pragma unroll
+            for (int t = 0; t < half; t++) {
+                const fp a = v[base + t], b = v[base + t + half];
+                v[base + t] = fp_add(a, b);
+                const fp d = fp_sub(a, b);
+                v[base + t + half] = (t == 0) ? d : fp_mul(d, winv[(size_t)(t * step) * q]);
+            }
+        }
+    }
+    const fp r = fp_mul(alpha, fp_mul(offset_inv, winv[i]));
+    fp acc = 0; // Horner from s_(F-1) down: s_k sits at the bit-reversed index
+#pragma unroll
+    for (int k = F - 1; k >= 0; k--) {
+        int br = 0;
+#pragma unroll
+        for (int bit = 0; bit < LOG_F; bit++) br |= ((k >> bit) & 1) << (LOG_F - 1 - bit);
+        acc = fp_add(fp_mul(acc, r), v[br]);
+    }
+    out[i] = fp_mul(acc, inv_f);
+}
+
 } // namespace
 
 hipError_t fri_fold4(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, const uint64_t *d_winv, uint64_t offset_inv, uint64_t alpha,
                      uint64_t inv4, hipStream_t stream, const uint64_t *d_alpha) {
     const size_t q = ((size_t)1 << log_n) / 4;
     hipLaunchKernelGGL(k_fri_fold4, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, alpha, inv4, d_alpha);
+    return hipGetLastError();
+}
+hipError_t fri_fold(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, unsigned log_f, const uint64_t *d_winv, uint64_t offset_inv, uint64_t alpha,
+                    uint64_t inv_f, hipStream_t stream, const uint64_t *d_alpha) {
+    if (log_f == 2) return fri_fold4(d_evals, d_out, log_n, d_winv, offset_inv, alpha, inv_f, stream, d_alpha);
+    if ((log_f != 3 && log_f != 4) || log_n < log_f) return hipErrorInvalidValue;
+    const size_t q = ((size_t)1 << log_n) >> log_f;
+    const dim3 grid((unsigned)((q + 255) / 256));
+    if (log_f == 3) hipLaunchKernelGGL(k_fri_fold<3>, grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, alpha, inv_f, d_alpha);
+    else hipLaunchKernelGGL(k_fri_fold<4>, grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, alpha, inv_f, d_alpha);
     return hipGetLastError();
 }
 

@@ -26,5 +26,7 @@ hipError_t deep_composition_ext(const DeepExtParams &p, hipStream_t stream);
 // evals [m][N] component-major over offset * <w_N> -> [m][N/4]
 hipError_t fri_fold4_ext(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, const uint64_t *d_winv, uint64_t offset_inv, const uint64_t *alpha,
                          unsigned m, uint64_t inv4, hipStream_t stream);
+hipError_t fri_fold_ext(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, unsigned log_f, const uint64_t *d_winv, uint64_t offset_inv,
+                        const uint64_t *alpha, unsigned m, uint64_t inv_f, hipStream_t stream);
 
 } // namespace cs

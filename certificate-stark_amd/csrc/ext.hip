@@ -197,6 +197,52 @@ __global__ __launch_bounds__(256) void k_fri_fold4_ext(const fp *__restrict__ ev
     for (int comp = 0; comp < M; comp++) out[comp * q + i] = acc.c[comp];
 }
 
+// folding factor F = 2^LOG_F = 8, 16 over the extension (deep.hip, k_fri_fold: the F-point inverse DFT is linear over the base field --
+// per component -- and the Horner steps in alpha / x_i are extension products)
+template <int M, int LOG_F>
+__global__ __launch_bounds__(256) void k_fri_fold_ext(const fp *__restrict__ evals, fp *__restrict__ out, size_t q, const fp *__restrict__ winv,
+                                                      fp offset_inv, Ext<M> alpha, fp inv_f) {
+    constexpr int F = 1 << LOG_F;
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i >= q) return;
+    const size_t N = (size_t)F * q;
+    Ext<M> s[F];
+#pragma unroll
+    for (int comp = 0; comp < M; comp++) {
+        fp v[F];
+#pragma unroll
+        for (int t = 0; t < F; t++) v[t] = evals[comp * N + i + (size_t)t * q];
+#pragma unroll
+        for (int len = F; len >= 2; len >>= 1) {
+            const int half = len >> 1, step = F / len;
+#pragma unroll
+            for (int base = 0; base < F; base += len) {
+#pragma unroll
+                for (int t = 0; t < half; t++) {
+                    const fp a = v[base + t], b = v[base + t + half];
+                    v[base + t] = fp_add(a, b);
+                    const fp d = fp_sub(a, b);
+                    v[base + t + half] = (t == 0) ? d : fp_mul(d, winv[(size_t)(t * step) * q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < F; t++) s[t].c[comp] = v[t]; // bit-reversed order
+    }
+    const Ext<M> r = x_scale(alpha, fp_mul(offset_inv, winv[i]));
+    Ext<M> acc = x_zero<M>();
+#pragma unroll
+    for (int k = F - 1; k >= 0; k--) {
+        int br = 0;
+#pragma unroll
+        for (int bit = 0; bit < LOG_F; bit++) br |= ((k >> bit) & 1) << (LOG_F - 1 - bit);
+        acc = x_add(x_mul(acc, r), s[br]);
+    }
+    acc = x_scale(acc, inv_f);
+#pragma unroll
+    for (int comp = 0; comp < M; comp++) out[comp * q + i] = acc.c[comp];
+}
+
 } // namespace
 
 size_t poly_eval_ext_scratch_words(unsigned width, unsigned log_n, unsigned m) {
@@ -228,6 +274,19 @@ hipError_t fri_fold4_ext(const uint64_t *d_evals, uint64_t *d_out, unsigned log_
     if (m == 2) hipLaunchKernelGGL(k_fri_fold4_ext<2>, grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, Ext<2>{{alpha[0], alpha[1]}}, inv4);
     else if (m == 3) hipLaunchKernelGGL(k_fri_fold4_ext<3>, grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, Ext<3>{{alpha[0], alpha[1], alpha[2]}}, inv4);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t fri_fold_ext(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, unsigned log_f, const uint64_t *d_winv, uint64_t offset_inv,
+                        const uint64_t *alpha, unsigned m, uint64_t inv_f, hipStream_t stream) {
+    if (log_f == 2) return fri_fold4_ext(d_evals, d_out, log_n, d_winv, offset_inv, alpha, m, inv_f, stream);
+    if ((log_f != 3 && log_f != 4) || log_n < log_f || (m != 2 && m != 3)) return hipErrorInvalidValue;
+    const size_t q = ((size_t)1 << log_n) >> log_f;
+    const dim3 grid((unsigned)((q + 255) / 256));
+    if (m == 2 && log_f == 3) hipLaunchKernelGGL((k_fri_fold_ext<2, 3>), grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, Ext<2>{{alpha[0], alpha[1]}}, inv_f);
+    else if (m == 2) hipLaunchKernelGGL((k_fri_fold_ext<2, 4>), grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, Ext<2>{{alpha[0], alpha[1]}}, inv_f);
+    else if (log_f == 3) hipLaunchKernelGGL((k_fri_fold_ext<3, 3>), grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, Ext<3>{{alpha[0], alpha[1], alpha[2]}}, inv_f);
+    else hipLaunchKernelGGL((k_fri_fold_ext<3, 4>), grid, dim3(256), 0, stream, d_evals, d_out, q, d_winv, offset_inv, Ext<3>{{alpha[0], alpha[1], alpha[2]}}, inv_f);
     return hipGetLastError();
 }
 

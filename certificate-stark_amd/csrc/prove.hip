@@ -9,8 +9,12 @@
 //   order     trace root -> 115+4 coefficient pairs -> constraint root -> z -> H(T(z) || T(z w)), H(H_i(z^b)) ->
 //             DEEP coefficients (alpha, beta, gamma per register; one per composition column; two for the degree
 //             adjustment) -> per FRI layer: root, alpha -> H(remainder) -> proof-of-work nonce -> query positions
-//   FRI       folding factor 4, layers while the domain exceeds fri_max_remainder; layer rows are the 4 evaluations
-//             { e[i + t N/4] } that fold into position i
+//   FRI       folding factor f = 4, 8 or 16, layers while the domain exceeds fri_max_remainder; layer rows are the f evaluations
+//             { e[i + t N/f] } that fold into position i
+//   domains   blowup factor b = 2, 4, 8 or 16, at least the AIR's constraint-evaluation blowup ce (8 / 4 / 8 / 2).  b > ce: the trace
+//             table is kept in BLOCK ORDER (blake3.h, lde_coset_slot) -- b / ce blocks of ce cosets, block 0 = the constraint-
+//             evaluation domain -- so the evaluators always read a plain [ce][width][n] table; commitment leaves, query positions and
+//             the proof bytes are in natural order (leaf b j + k)
 // The byte layout of the proof is this library's own (documented in include/cstark.h); the tests check it with a restated verifier.
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -22,6 +26,7 @@
 #include "../../include/cstark.h"
 #include "ctx.h"
 #include "blake3.h"
+#include "deep.h"
 #include "range_batch.h"
 #include "hostblake3.h"
 #include "keccak.cuh"
@@ -34,8 +39,8 @@ enum { PROVE_EVENTS = CSTARK_PROVE_NUM_STAGES + 1 };
 
 struct ProveArena {
     int air = -1;
-    unsigned log_n = 0, log_b = 0;
-    uint64_t *trace = nullptr, *coeffs = nullptr, *lde = nullptr, *combined = nullptr, *cegather = nullptr, *ccoef = nullptr, *clde = nullptr, *deep = nullptr;
+    unsigned log_n = 0, log_b = 0, log_f = 0;
+    uint64_t *trace = nullptr, *coeffs = nullptr, *lde = nullptr, *combined = nullptr, *ccoef = nullptr, *clde = nullptr, *deep = nullptr;
     std::vector<void *> extra; // per-AIR buffers (materialised transition evaluations, SchnorrAir's public columns)
     std::vector<size_t> extra_bytes; // allocated size of every slot of `extra`
     uint8_t *tnodes = nullptr, *cnodes = nullptr;
@@ -197,7 +202,7 @@ __global__ void k_gather_paths(const uint4 *__restrict__ nodes, uint32_t log_lea
 // All opening gathers of a proof in ONE launch (they were twenty launches of a few microseconds each, 0.14 ms of launch latency):
 // job = blockIdx.y, query = blockIdx.x.  kind 0: row pos[q] of a coset-major table (as k_gather_rows); kind 1: authentication path
 // of leaf pos[q] (as k_gather_paths; a = log2 of the leaf count).
-struct GatherJob { const void *src; void *out; const uint32_t *pos; uint32_t kind, a, log_n, log_b, count; };
+struct GatherJob { const void *src; void *out; const uint32_t *pos; uint32_t kind, a, log_n, log_b, count, log_s; }; // log_s: block order of the table's cosets (blake3.h)
 constexpr int MAX_GATHER_JOBS = 32;
 struct GatherBatch { GatherJob job[MAX_GATHER_JOBS]; };
 __global__ void k_gather_batch(GatherBatch b) {
@@ -207,7 +212,7 @@ __global__ void k_gather_batch(GatherBatch b) {
     if (g.kind == 0) {
         const uint64_t *lde = (const uint64_t *)g.src;
         uint64_t *out = (uint64_t *)g.out;
-        const uint32_t width = g.a, i = g.pos[q], k = i & ((1u << g.log_b) - 1), j = i >> g.log_b;
+        const uint32_t width = g.a, i = g.pos[q], k = lde_coset_slot(i & ((1u << g.log_b) - 1), g.log_b, g.log_s), j = i >> g.log_b;
         for (uint32_t c = threadIdx.x; c < width; c += blockDim.x) out[(size_t)q * width + c] = lde[(((size_t)k * width + c) << g.log_n) + j];
     } else {
         const uint4 *nodes = (const uint4 *)g.src;
@@ -224,12 +229,12 @@ struct GatherList {
     GatherBatch b{};
     int n = 0;
     uint32_t max_count = 0;
-    void rows(const uint64_t *lde, uint32_t width, uint32_t log_n, uint32_t log_b, const uint32_t *pos, void *out, uint32_t count) {
-        b.job[n++] = GatherJob{lde, out, pos, 0u, width, log_n, log_b, count};
+    void rows(const uint64_t *lde, uint32_t width, uint32_t log_n, uint32_t log_b, const uint32_t *pos, void *out, uint32_t count, uint32_t log_s = 0) {
+        b.job[n++] = GatherJob{lde, out, pos, 0u, width, log_n, log_b, count, log_s};
         if (count > max_count) max_count = count;
     }
     void paths(const uint8_t *nodes, uint32_t log_leaves, const uint32_t *pos, void *out, uint32_t count) {
-        b.job[n++] = GatherJob{nodes, out, pos, 1u, log_leaves, 0u, 0u, count};
+        b.job[n++] = GatherJob{nodes, out, pos, 1u, log_leaves, 0u, 0u, count, 0u};
         if (count > max_count) max_count = count;
     }
     hipError_t launch(hipStream_t st) {
@@ -272,9 +277,9 @@ int arena_extra(cstark_ctx *c, ProveArena *a, size_t slot, T **p, size_t bytes) 
     return CSTARK_OK;
 }
 
-unsigned num_fri_layers(unsigned log_domain, unsigned log_max_remainder) {
+unsigned num_fri_layers(unsigned log_domain, unsigned log_max_remainder, unsigned log_f) {
     unsigned l = 0;
-    while (log_domain > log_max_remainder) { log_domain -= 2; l++; }
+    while (log_domain > log_max_remainder) { log_domain -= log_f; l++; }
     return l;
 }
 
@@ -299,7 +304,9 @@ struct AirJob {
     const uint64_t *pub_staging = nullptr; // pinned host copy of the public inputs, valid once every batch has been waited for
     bool public_ready = false;      // SchnorrAir: the extended public-input columns of this proof are in the arena
     bool evals_ready = false;       // sub-AIRs: the materialised transition evaluations of this proof are already in the arena
-    uint32_t k0 = 0, nk = 8;        // LDE cosets this GPU owns (all of them unless the proof is sharded)
+    uint32_t k0 = 0, nk = 8;        // sharded proofs (blowup 8): the LDE cosets this GPU owns
+    bool sharded = false;
+    uint32_t log_b = 3;             // log2 of the blowup factor; the trace table holds its cosets in block order when log_b > log_ce
     uint64_t number = 0;            // RangeProofAir
     const uint64_t *bits = nullptr; // RangeProofAir, long form: the n/64 words of the value (host)
 };
@@ -311,22 +318,21 @@ void drop_run(ProveArena *a) {
     if (a && a->run) { proof_run_free(a->run); a->run = nullptr; }
 }
 
-int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned n_layers, size_t nq, ProveArena **out) {
+int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned log_f, unsigned n_layers, size_t nq, ProveArena **out) {
     drop_run(c->arena);
-    if (c->arena && c->arena->air == job.air && c->arena->log_n == job.log_n && c->arena->log_b == log_b && c->arena->layer.size() == n_layers + 1 &&
-        c->arena->open_bytes >= nq) { *out = c->arena; return CSTARK_OK; }
+    if (c->arena && c->arena->air == job.air && c->arena->log_n == job.log_n && c->arena->log_b == log_b && c->arena->log_f == log_f &&
+        c->arena->layer.size() == n_layers + 1 && c->arena->open_bytes >= nq) { *out = c->arena; return CSTARK_OK; }
     if (c->arena) { HIP_TRY(hipStreamSynchronize(c->stream)); prove_arena_free(c->arena); c->arena = nullptr; }
     ProveArena *a = new (std::nothrow) ProveArena();
     if (!a) return fail(CSTARK_ERR_OOM, "host allocation failed");
     c->arena = a; // owned by the context from here on (freed with it, also after a partial failure)
-    a->air = job.air; a->log_n = job.log_n; a->log_b = log_b;
-    const size_t n = (size_t)1 << job.log_n, b = (size_t)1 << log_b, N = n * b, W = job.width, ce = (size_t)1 << job.log_ce;
+    a->air = job.air; a->log_n = job.log_n; a->log_b = log_b; a->log_f = log_f;
+    const size_t n = (size_t)1 << job.log_n, b = (size_t)1 << log_b, N = n * b, W = job.width, ce = (size_t)1 << job.log_ce, f = (size_t)1 << log_f;
     RC_TRY(dev_alloc(a, &a->trace, W * n * 8));
     RC_TRY(dev_alloc(a, &a->coeffs, W * n * 8));
     RC_TRY(dev_alloc(a, &a->lde, W * N * 8));
     RC_TRY(dev_alloc(a, &a->tnodes, 2 * N * 32));
-    RC_TRY(dev_alloc(a, &a->combined, N * 8));
-    RC_TRY(dev_alloc(a, &a->cegather, ce * n * 8));
+    RC_TRY(dev_alloc(a, &a->combined, N * 8)); // merged evaluations on the constraint-evaluation domain, [ce][n]
     RC_TRY(dev_alloc(a, &a->ccoef, ce * n * 8));
     RC_TRY(dev_alloc(a, &a->clde, b * ce * n * 8)); // [b cosets][ce columns][n]
     RC_TRY(dev_alloc(a, &a->cnodes, 2 * N * 32));
@@ -335,26 +341,33 @@ int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned n_layer
     for (unsigned l = 0; l <= n_layers; l++) {
         uint64_t *e; uint8_t *t = nullptr;
         RC_TRY(dev_alloc(a, &e, sz * 8));
-        if (l < n_layers) RC_TRY(dev_alloc(a, &t, 2 * (sz / 4) * 32));
+        if (l < n_layers) RC_TRY(dev_alloc(a, &t, 2 * (sz / f) * 32));
         a->layer.push_back(e); a->lnodes.push_back(t);
-        sz /= 4;
+        sz /= f;
     }
     RC_TRY(dev_alloc(a, &a->d_pos, 4 * 256 * (n_layers + 2)));
-    // openings: per query a trace row + path, a composition row + path, per layer a row of 4 + path
+    // openings: per query a trace row + path, a composition row + path, per layer a row of f + path
     a->open_bytes = nq;
     const size_t log_N = job.log_n + log_b;
-    const size_t per_q = W * 8 + ce * 8 + 2 * log_N * 32 + (size_t)n_layers * (32 + log_N * 32);
+    const size_t per_q = W * 8 + ce * 8 + 2 * log_N * 32 + (size_t)n_layers * (f * 8 + log_N * 32);
     RC_TRY(dev_alloc(a, &a->d_open, per_q * nq + 256));
     for (hipEvent_t &e : a->ev) HIP_TRY(hipEventCreate(&e));
     *out = a;
     return CSTARK_OK;
 }
 
-int check_options(const cstark_options *opt, unsigned *log_rem_out) {
-    if (opt->blowup_factor != 8) return fail(CSTARK_ERR_UNSUPPORTED, "proofs use blowup factor 8 (src/lib.rs:78-86)");
+// The option values the reference passes (src/lib.rs:78-86; blowup 4 in src/merkle/update/tests.rs:41-52, src/range/tests.rs:87-98 and
+// benches/rescue.rs:370-378; -b / -f on the command line, examples/state-transition.rs:33-34, :46-47).  log_ce: the AIR's
+// constraint-evaluation blowup -- a blowup factor below it cannot hold the composition polynomial (the engine refuses it too).
+int check_options(const cstark_options *opt, unsigned log_ce, unsigned *log_rem_out, unsigned *log_b_out, unsigned *log_f_out) {
+    const uint32_t b = opt->blowup_factor, f = opt->fri_folding_factor;
+    if (b != 2 && b != 4 && b != 8 && b != 16) return fail(CSTARK_ERR_UNSUPPORTED, "blowup_factor must be 2, 4, 8 or 16");
+    if (b < (1u << log_ce)) return fail(CSTARK_ERR_INVALID_ARG, "blowup_factor below the AIR's constraint-evaluation blowup (TransactionAir / SchnorrAir 8, MerkleAir 4, RangeProofAir 2)");
     if (opt->hash_fn > 1) return fail(CSTARK_ERR_UNSUPPORTED, "hash_fn must be Blake3_256 (0) or Sha3_256 (1)");
     if (opt->field_extension > 2) return fail(CSTARK_ERR_INVALID_ARG, "field_extension must be None (0), Quadratic (1) or Cubic (2)");
-    if (opt->fri_folding_factor != 4) return fail(CSTARK_ERR_UNSUPPORTED, "only FRI folding factor 4 is implemented");
+    if (f != 4 && f != 8 && f != 16) return fail(CSTARK_ERR_UNSUPPORTED, "fri_folding_factor must be 4, 8 or 16");
+    *log_b_out = b == 2 ? 1 : b == 4 ? 2 : b == 8 ? 3 : 4;
+    *log_f_out = f == 4 ? 2 : f == 8 ? 3 : 4;
     if (opt->num_queries == 0 || opt->num_queries > 128) return fail(CSTARK_ERR_INVALID_ARG, "num_queries must be 1..128");
     if (opt->grinding_factor > 32) return fail(CSTARK_ERR_INVALID_ARG, "grinding_factor must be at most 32");
     unsigned log_rem = 0;
@@ -368,13 +381,27 @@ int check_options(const cstark_options *opt, unsigned *log_rem_out) {
 // interpolation, after the extension).  With column batches (AirJob::batches) the complete columns go first -- interpolated AND
 // extended while the internal streams still write the later ones -- so the "interpolate" stage time then also holds the extension
 // of the earlier batches.
-int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hipStream_t st, int &evi) {
+// Extension of columns [col0, col0 + ncols) of the trace: the cosets [k0, k0 + nk) of a sharded proof, or all of them -- in block
+// order when the blowup factor exceeds the AIR's constraint-evaluation blowup: block r = the blowup-ce extension with offset g w_(b n)^r
+int lde_trace(cstark_ctx *c, ProveArena *a, const AirJob &job, uint32_t col0, uint32_t ncols) {
+    const uint32_t W = job.width, log_n = job.log_n, log_b = job.log_b;
+    if (job.sharded || log_b <= job.log_ce) return lde_column_range(c, a->coeffs, a->lde, W, col0, ncols, log_n, log_b, host::lde_offset(), job.k0, job.nk);
+    const size_t n = (size_t)1 << log_n, ce = (size_t)1 << job.log_ce;
+    const uint64_t wbn = host::root_of_unity(log_n + log_b);
+    uint64_t offset = host::lde_offset();
+    for (uint32_t r = 0; r < (1u << (log_b - job.log_ce)); r++) {
+        RC_TRY(lde_column_range(c, a->coeffs, a->lde + (size_t)r * ce * W * n, W, col0, ncols, log_n, job.log_ce, offset, 0, (uint32_t)ce));
+        offset = host::mul(offset, wbn);
+    }
+    return CSTARK_OK;
+}
+int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, hipStream_t st, int &evi) {
     const uint32_t W = job.width, log_n = job.log_n;
     const size_t n = (size_t)1 << log_n;
     if (job.batches.empty()) {
         RC_TRY(cstark_interpolate_columns(c, a->trace, a->coeffs, W, log_n));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
-        RC_TRY(cstark_lde_columns(c, a->coeffs, a->lde, W, log_n, log_b, host::lde_offset(), job.k0, job.nk));
+        RC_TRY(lde_trace(c, a, job, 0, W));
         HIP_TRY(hipEventRecord(a->ev[evi++], st));
         return CSTARK_OK;
     }
@@ -384,7 +411,7 @@ int commit_columns(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned log_b, hi
             if (e) HIP_TRY(hipStreamWaitEvent(st, e, 0));
         RC_TRY(cstark_interpolate_columns(c, a->trace + (size_t)cb.col0 * n, a->coeffs + (size_t)cb.col0 * n, cb.ncols, log_n));
         if (i + 1 == job.batches.size()) HIP_TRY(hipEventRecord(a->ev[evi++], st));
-        RC_TRY(lde_column_range(c, a->coeffs, a->lde, W, cb.col0, cb.ncols, log_n, log_b, host::lde_offset(), job.k0, job.nk));
+        RC_TRY(lde_trace(c, a, job, cb.col0, cb.ncols));
     }
     HIP_TRY(hipEventRecord(a->ev[evi++], st));
     return CSTARK_OK;
@@ -434,7 +461,7 @@ int grind_nonce(cstark_ctx *c, ProveArena *a, const Coin &coin, unsigned bits, u
 struct ProofRun {
     cstark_options opt{};
     AirJob job;
-    unsigned log_rem = 0, n_layers = 0;
+    unsigned log_rem = 0, n_layers = 0, log_b = 3, log_f = 2;
     Coin coin;
     uint8_t trace_root[32] = {}, cons_root[32] = {}, rem_commit[32] = {};
     std::vector<uint64_t> ta, tb, ba, bb, ood_trace, ood_comp, remainder;
@@ -443,7 +470,8 @@ struct ProofRun {
     std::vector<uint32_t> positions;
     std::vector<std::vector<uint32_t>> lpos;
     int evi = 0, phase = 0; // phase: 1 commit, 2 evaluate, 3 compose done
-    bool sharded() const { return job.nk != 8; }
+    bool sharded() const { return job.sharded; }
+    unsigned log_s() const { return job.sharded ? 0 : log_b - job.log_ce; } // block order of the trace table's cosets
 };
 void proof_run_free(ProofRun *r) { delete r; }
 
@@ -455,18 +483,18 @@ namespace {
 // d_leaves_local (sharded only): compact digests [nk][n][32] of this rank's rows; otherwise the leaves go straight into the tree.
 int phase_commit(cstark_ctx *c, ProveArena *a, ProofRun &R, uint8_t *d_leaves_local) {
     AirJob &job = R.job;
-    const unsigned log_n = job.log_n, log_b = 3;
-    const size_t n = (size_t)1 << log_n, N = n * 8, W = job.width;
+    const unsigned log_n = job.log_n, log_b = R.log_b;
+    const size_t n = (size_t)1 << log_n, N = n << log_b, W = job.width;
     hipStream_t st = c->stream;
     a->timed = false;
     R.evi = 0;
     STAGE();
     RC_TRY(job.build(c, a, job));
     STAGE();
-    RC_TRY(commit_columns(c, a, job, log_b, st, R.evi));
+    RC_TRY(commit_columns(c, a, job, st, R.evi));
     const uint32_t hf = R.opt.hash_fn;
     if (!R.sharded()) {
-        RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, 8));
+        RC_TRY(hash_rows_slots(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, R.log_s()));
     } else {
         for (uint32_t i = 0; i < job.nk; i++) // a coset alone is a blowup-1 domain: leaf j of the call = row j of the coset
             RC_TRY(cstark_hash_rows_fn(c, hf, a->lde + (size_t)i * W * n, d_leaves_local + (size_t)i * n * 32, (uint32_t)W, log_n, 0, 0, 1));
@@ -479,8 +507,8 @@ int phase_commit(cstark_ctx *c, ProveArena *a, ProofRun &R, uint8_t *d_leaves_lo
 // d_leaves_all (sharded only): the all-gathered digests [8][n][32], coset-major.  d_out: [nk][n].
 int phase_evaluate(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint8_t *d_leaves_all, uint64_t *d_out) {
     AirJob &job = R.job;
-    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b;
-    const size_t n = (size_t)1 << log_n, N = n * 8, W = job.width;
+    const unsigned log_n = job.log_n, log_b = R.log_b, log_N = log_n + log_b;
+    const size_t n = (size_t)1 << log_n, N = n << log_b, W = job.width;
     hipStream_t st = c->stream;
     const uint32_t hf = R.opt.hash_fn;
     if (R.sharded()) {
@@ -531,24 +559,19 @@ int phase_evaluate(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint8_t *d_l
 }
 
 // ---- phase 3: composition polynomial and its commitment, out-of-domain frame, DEEP composition, FRI, query positions -----------------
-// Needs the merged evaluations of ALL cosets in a->combined and coset 0 of the extended trace at a->lde (the owner of coset 0).
+// Needs the merged evaluations on the constraint-evaluation domain, [ce][n], in a->combined and coset 0 of the extended trace at a->lde
+// (the owner of coset 0).
 int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
     AirJob &job = R.job;
     const cstark_options *opt = &R.opt;
-    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b, log_ce = job.log_ce, n_layers = R.n_layers;
-    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = job.width, ce = (size_t)1 << log_ce, nq = opt->num_queries;
+    const unsigned log_n = job.log_n, log_b = R.log_b, log_f = R.log_f, log_N = log_n + log_b, log_ce = job.log_ce, n_layers = R.n_layers;
+    const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b, N = n * b, W = job.width, ce = (size_t)1 << log_ce, nq = opt->num_queries;
+    const uint32_t fold = 1u << log_f;
     hipStream_t st = c->stream;
     const uint32_t hf = opt->hash_fn;
     Coin &coin = R.coin;
     if (job.k0 != 0) return fail(CSTARK_ERR_INVALID_ARG, "the composition phase runs on the rank that owns coset 0");
-    const uint64_t *ce_evals = a->combined;
-    if (log_ce < log_b) { // the constraint-evaluation domain is the sub-domain of every (b / ce)-th LDE coset
-        const size_t stride = b >> log_ce;
-        for (size_t k = 0; k < ce; k++)
-            HIP_TRY(hipMemcpyAsync(a->cegather + k * n, a->combined + k * stride * n, n * 8, hipMemcpyDeviceToDevice, st));
-        ce_evals = a->cegather;
-    }
-    RC_TRY(cstark_composition_columns(c, ce_evals, a->ccoef, log_n, log_ce));
+    RC_TRY(cstark_composition_columns(c, a->combined, a->ccoef, log_n, log_ce));
     RC_TRY(cstark_lde_columns(c, a->ccoef, a->clde, (uint32_t)ce, log_n, log_b, host::lde_offset(), 0, (uint32_t)b));
     RC_TRY(cstark_hash_rows_fn(c, hf, a->clde, a->cnodes + 32 * N, (uint32_t)ce, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
@@ -611,20 +634,20 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
         HIP_TRY(hipMemcpyAsync(d_fri, coin.seed, 32, hipMemcpyHostToDevice, st));
     }
     for (unsigned l = 0; l < n_layers; l++) {
-        const size_t rows = (size_t)1 << (lg - 2);
-        RC_TRY(cstark_hash_rows_fn(c, hf, a->layer[l], a->lnodes[l] + 32 * rows, 4, lg - 2, 0, 0, 1));
-        RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - 2));
+        const size_t rows = (size_t)1 << (lg - log_f);
+        RC_TRY(cstark_hash_rows_fn(c, hf, a->layer[l], a->lnodes[l] + 32 * rows, fold, lg - log_f, 0, 0, 1));
+        RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - log_f));
         if (dev_coin) {
-            RC_TRY(fri_coin_fold4_dev(c, d_fri, a->lnodes[l] + 32, (uint64_t *)(d_fri + 8) + l, d_fri + 8 + 2 * 32 + 8 * l, a->layer[l], a->layer[l + 1], lg, offset));
+            RC_TRY(fri_coin_fold_dev(c, d_fri, a->lnodes[l] + 32, (uint64_t *)(d_fri + 8) + l, d_fri + 8 + 2 * 32 + 8 * l, a->layer[l], a->layer[l + 1], lg, log_f, offset));
         } else {
             HIP_TRY(hipMemcpyAsync(&R.layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
             HIP_TRY(cs::stream_wait(st));
             coin.reseed(&R.layer_roots[32 * l]);
             const uint64_t alpha = coin.draw();
-            RC_TRY(cstark_fri_fold4(c, a->layer[l], a->layer[l + 1], lg, offset, alpha));
+            RC_TRY(cstark_fri_fold(c, a->layer[l], a->layer[l + 1], lg, fold, offset, alpha));
         }
-        offset = host::pow(offset, 4);
-        lg -= 2;
+        offset = host::pow(offset, fold);
+        lg -= log_f;
     }
     R.remainder.assign((size_t)1 << lg, 0);
     if (dev_coin) HIP_TRY(hipMemcpyAsync(R.layer_roots.data(), d_fri + 8 + 2 * 32, 32 * (size_t)n_layers, hipMemcpyDeviceToHost, st));
@@ -646,7 +669,7 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
     {
         std::vector<uint32_t> cur = R.positions;
         unsigned g2 = log_N;
-        for (unsigned l = 0; l < n_layers; l++) { R.lpos[l] = fold_positions(cur, 1u << (g2 - 2)); cur = R.lpos[l]; g2 -= 2; }
+        for (unsigned l = 0; l < n_layers; l++) { R.lpos[l] = fold_positions(cur, 1u << (g2 - log_f)); cur = R.lpos[l]; g2 -= log_f; }
     }
     R.phase = 3;
     return CSTARK_OK;
@@ -657,8 +680,8 @@ int phase_compose(cstark_ctx *c, ProveArena *a, ProofRun &R) {
 int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trace_rows, uint8_t *proof, size_t capacity, size_t *proof_len) {
     AirJob &job = R.job;
     const cstark_options *opt = &R.opt;
-    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b, log_ce = job.log_ce, n_layers = R.n_layers;
-    const size_t W = job.width, ce = (size_t)1 << log_ce, nq = opt->num_queries;
+    const unsigned log_n = job.log_n, log_b = R.log_b, log_f = R.log_f, log_N = log_n + log_b, log_ce = job.log_ce, n_layers = R.n_layers;
+    const size_t W = job.width, ce = (size_t)1 << log_ce, nq = opt->num_queries, fold = (size_t)1 << log_f;
     hipStream_t st = c->stream;
     const std::vector<uint32_t> &positions = R.positions;
     const std::vector<std::vector<uint32_t>> &lpos = R.lpos;
@@ -675,7 +698,7 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
     if (2 * (size_t)n_layers + 4 > MAX_GATHER_JOBS) return fail(CSTARK_ERR_UNSUPPORTED, "too many FRI layers for one opening launch");
     GatherList gl;
     if (d_trace_rows) HIP_TRY(hipMemcpyAsync(o + o_trows, d_trace_rows, nq * W * 8, hipMemcpyDeviceToDevice, st));
-    else gl.rows(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, o + o_trows, (uint32_t)nq);
+    else gl.rows(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, o + o_trows, (uint32_t)nq, R.log_s());
     gl.paths(a->tnodes, log_N, a->d_pos, o + o_tpath, (uint32_t)nq);
     gl.rows(a->clde, (uint32_t)ce, log_n, log_b, a->d_pos, o + o_crows, (uint32_t)nq);
     gl.paths(a->cnodes, log_N, a->d_pos, o + o_cpath, (uint32_t)nq);
@@ -683,12 +706,12 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
     {
         unsigned g2 = log_N;
         for (unsigned l = 0; l < n_layers; l++) {
-            const unsigned np = (unsigned)lpos[l].size(), lr = g2 - 2;
-            o_lrows[l] = off; off += (size_t)np * 32;
+            const unsigned np = (unsigned)lpos[l].size(), lr = g2 - log_f;
+            o_lrows[l] = off; off += (size_t)np * fold * 8;
             o_lpath[l] = off; off += (size_t)np * lr * 32;
-            gl.rows(a->layer[l], 4, lr, 0, a->d_pos + 256 * (l + 1), o + o_lrows[l], np);
+            gl.rows(a->layer[l], (uint32_t)fold, lr, 0, a->d_pos + 256 * (l + 1), o + o_lrows[l], np);
             gl.paths(a->lnodes[l], lr, a->d_pos + 256 * (l + 1), o + o_lpath[l], np);
-            g2 -= 2;
+            g2 -= log_f;
         }
     }
     HIP_TRY(gl.launch(st));
@@ -720,9 +743,9 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
         for (unsigned l = 0; l < n_layers; l++) {
             const size_t np = lpos[l].size();
             wr.u32((uint32_t)np);
-            wr.raw(open.data() + o_lrows[l], np * 32);
-            wr.raw(open.data() + o_lpath[l], np * (g2 - 2) * 32);
-            g2 -= 2;
+            wr.raw(open.data() + o_lrows[l], np * fold * 8);
+            wr.raw(open.data() + o_lpath[l], np * (g2 - log_f) * 32);
+            g2 -= log_f;
         }
     }
     wr.u32((uint32_t)R.remainder.size()); wr.raw(R.remainder.data(), R.remainder.size() * 8);
@@ -739,14 +762,17 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
 
 // options / sizes of a run, its arena
 int run_setup(cstark_ctx *c, const cstark_options *opt, const AirJob &job, ProofRun &R, ProveArena **a) {
-    RC_TRY(check_options(opt, &R.log_rem));
-    const unsigned log_N = job.log_n + 3;
-    if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "at most 2^21 trace rows");
+    RC_TRY(check_options(opt, job.log_ce, &R.log_rem, &R.log_b, &R.log_f));
+    const unsigned log_N = job.log_n + R.log_b;
+    if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "the LDE domain holds at most 2^24 points (2^21 trace rows at blowup 8)");
+    if (job.sharded && R.log_b != 3) return fail(CSTARK_ERR_UNSUPPORTED, "sharded proofs use blowup factor 8 (one to four of its eight cosets per rank)");
     R.opt = *opt; R.job = job;
-    R.n_layers = num_fri_layers(log_N, R.log_rem);
-    if (opt->num_queries > ((size_t)1 << log_N) / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
+    R.job.log_b = R.log_b;
+    if (!job.sharded) { R.job.k0 = 0; R.job.nk = 1u << R.log_b; }
+    R.n_layers = num_fri_layers(log_N, R.log_rem, R.log_f);
+    if (opt->num_queries > ((size_t)1 << log_N) / 2) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports"); // (distinct positions are drawn)
     HIP_TRY(hipSetDevice(c->device));
-    return get_arena(c, job, 3, R.n_layers, opt->num_queries, a);
+    return get_arena(c, R.job, R.log_b, R.log_f, R.n_layers, opt->num_queries, a);
 }
 
 int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *proof, size_t capacity, size_t *proof_len) {
@@ -819,8 +845,10 @@ int tx_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, co
     uint64_t *outs[1] = {out};
     // all cosets on this GPU: the degree-split evaluation (the table is this prover's own extension); a window of 2 or 4 cosets of a
     // sharded proof: the rank's share of the split evaluation (rows: shard_rows); a single coset (8 ranks): every point directly
+    // (blowup 16: block 0 of the trace table is the eight cosets of the constraint-evaluation domain)
+    if (!job.sharded) return tx_evaluate_constraints_sets(c, a->lde, &cf, 1, pub4, outs, job.item, job.log_n, 3, 0, 8, true);
     if (shard_split(job.nk)) return tx_evaluate_constraints_shard(c, a->lde, a->coeffs, &cf, pub4, out, job.item, job.log_n, job.k0, job.nk);
-    return tx_evaluate_constraints_sets(c, a->lde, &cf, 1, pub4, outs, job.item, job.log_n, 3, job.k0, job.nk, job.nk == 8);
+    return tx_evaluate_constraints_sets(c, a->lde, &cf, 1, pub4, outs, job.item, job.log_n, 3, job.k0, job.nk, false);
 }
 int tx_combine_sets(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned m, const uint64_t *const *ta, const uint64_t *const *tb, const uint64_t *const *ba,
                     const uint64_t *const *bb, uint64_t *const *outs) {
@@ -832,17 +860,8 @@ int tx_combine_sets(cstark_ctx *c, ProveArena *a, AirJob &job, unsigned m, const
     const uint64_t pub4[4] = {job.pub[0], job.pub[1], job.pub[7], job.pub[8]};
     return tx_evaluate_constraints_sets(c, a->lde, cf, m, pub4, outs, job.item, job.log_n, 3, 0, 8, true);
 }
-// Transition evaluations of a sub-AIR on the cosets of its constraint-evaluation domain only: an AIR whose constraints need a blowup
-// 2^log_ce below the LDE blowup 8 (MerkleAir 4, RangeProofAir 2) is evaluated on every (8 >> log_ce)-th coset; the merge
-// (cstark_air_combine) reads nothing else.  evals keeps the [8][n_constraints][n] layout.
-int evaluate_on_ce_cosets(cstark_ctx *c, ProveArena *a, AirJob &job, int air, uint64_t *evals) {
-    const size_t n = (size_t)1 << job.log_n;
-    const uint32_t stride = 8u >> job.log_ce;
-    for (uint32_t k = 0; k < 8; k += stride)
-        RC_TRY(cstark_air_evaluate_transitions(c, air, a->lde + (size_t)k * job.width * n, evals + (size_t)k * job.n_constraints * n, job.item, job.log_n,
-                                               3, k, 1));
-    return CSTARK_OK;
-}
+// The sub-AIRs are evaluated on their constraint-evaluation domain -- blowup 2^log_ce: MerkleAir 4, RangeProofAir 2 -- which is block 0 of
+// the trace table whatever the blowup factor of the proof: a plain [ce][width][n] extension with the domain offset.
 // ---- MerkleAir (src/merkle/update) ---------------------------------------------------------------------------------------------
 int merkle_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
     RC_TRY(cstark_merkle_build_trace(c, a->trace));
@@ -850,14 +869,15 @@ int merkle_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
 }
 int merkle_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
+    const uint32_t log_ce = job.log_ce, ce = 1u << log_ce;
     // CSTARK_MERKLE_FUSED=0 (tuning / debugging): materialise the 106 transition values and merge them generically
     static const bool fused = [] { const char *e = getenv("CSTARK_MERKLE_FUSED"); return !e || atoi(e) != 0; }();
-    if (fused) return cstark_merkle_evaluate_constraints(c, job.item, a->lde, ta, tb, ba, bb, job.pub.data(), out, job.log_n, 3, 0, 8);
+    if (fused) return cstark_merkle_evaluate_constraints(c, job.item, a->lde, ta, tb, ba, bb, job.pub.data(), out, job.log_n, log_ce, 0, ce);
     uint64_t *evals;
-    RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
-    if (!job.evals_ready) RC_TRY(evaluate_on_ce_cosets(c, a, job, CSTARK_AIR_MERKLE_UPDATE, evals));
+    RC_TRY(arena_extra(c, a, 0, &evals, (size_t)ce * job.n_constraints * n * 8));
+    if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_MERKLE_UPDATE, a->lde, evals, job.item, job.log_n, log_ce, 0, ce));
     job.evals_ready = true;
-    return cstark_air_combine(c, CSTARK_AIR_MERKLE_UPDATE, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, out, job.log_n, 3, 0, 8);
+    return cstark_air_combine(c, CSTARK_AIR_MERKLE_UPDATE, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, out, job.log_n, log_ce, 0, ce);
 }
 // ---- RangeProofAir (src/range) -------------------------------------------------------------------------------------------------------
 int range_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
@@ -866,16 +886,18 @@ int range_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
 }
 int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
     const size_t n = (size_t)1 << job.log_n;
+    const uint32_t log_ce = job.log_ce, ce = 1u << log_ce;
     uint64_t *evals;
-    RC_TRY(arena_extra(c, a, 0, &evals, 8 * (size_t)job.n_constraints * n * 8));
-    if (!job.evals_ready) RC_TRY(evaluate_on_ce_cosets(c, a, job, CSTARK_AIR_RANGE, evals));
+    RC_TRY(arena_extra(c, a, 0, &evals, (size_t)ce * job.n_constraints * n * 8));
+    if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RANGE, a->lde, evals, job.item, job.log_n, log_ce, 0, ce));
     job.evals_ready = true;
     const uint64_t vals[2] = {0, job.number}; // get_assertions, src/range/air.rs:79-86
-    return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, out, job.log_n, 3, 0, 8);
+    return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, out, job.log_n, log_ce, 0, ce);
 }
 // ---- SchnorrAir (src/schnorr) ---------------------------------------------------------------------------------------------------------
 // the public-input columns (src/schnorr/air.rs:228-290; not committed: both sides derive them from the messages) and the sequence
-// polynomials of the assertions, extended: they depend on the public inputs only
+// polynomials of the assertions, extended over the constraint-evaluation domain (blowup 8, whatever the proof's blowup factor): they
+// depend on the public inputs only
 int schnorr_public_columns(cstark_ctx *c, ProveArena *a, AirJob &job, uint64_t **aux_lde_out, uint64_t **av_lde_out, bool compute) {
     const size_t n = (size_t)1 << job.log_n;
     uint64_t *aux, *aux_co, *aux_lde, *av_co, *av_lde;
@@ -935,29 +957,32 @@ int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *t
 int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *proof, size_t capacity, size_t *proof_len) {
     using namespace host;
     const unsigned m = opt->field_extension + 1;
-    unsigned log_rem = 0;
-    RC_TRY(check_options(opt, &log_rem));
-    const unsigned log_n = job.log_n, log_b = 3, log_N = log_n + log_b, log_ce = job.log_ce;
-    if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "at most 2^21 trace rows");
-    const size_t n = (size_t)1 << log_n, b = 8, N = n * b, W = job.width, ce = (size_t)1 << log_ce, CW = m * ce; // CW: base columns of the composition table
-    const unsigned n_layers = num_fri_layers(log_N, log_rem);
+    unsigned log_rem = 0, log_b = 3, log_f = 2;
+    RC_TRY(check_options(opt, job.log_ce, &log_rem, &log_b, &log_f));
+    job.log_b = log_b; job.k0 = 0; job.nk = 1u << log_b; job.sharded = false;
+    const unsigned log_n = job.log_n, log_N = log_n + log_b, log_ce = job.log_ce, log_s = log_b - log_ce;
+    if (log_N > 24) return fail(CSTARK_ERR_UNSUPPORTED, "the LDE domain holds at most 2^24 points (2^21 trace rows at blowup 8)");
+    const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b, N = n * b, W = job.width, ce = (size_t)1 << log_ce, CW = m * ce; // CW: base columns of the composition table
+    const size_t CN = ce * n; // points of the constraint-evaluation domain
+    const unsigned n_layers = num_fri_layers(log_N, log_rem, log_f);
+    const uint32_t fold = 1u << log_f;
     const size_t nq = opt->num_queries;
-    if (nq > N / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
+    if (nq > N / 2) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
     HIP_TRY(hipSetDevice(c->device));
     ProveArena *a;
-    RC_TRY(get_arena(c, job, log_b, n_layers, nq, &a));
+    RC_TRY(get_arena(c, job, log_b, log_f, n_layers, nq, &a));
     uint64_t *combined_x, *ccoef_x, *ccoefs, *cldes, *deepx;
     uint8_t *d_open;
-    RC_TRY(arena_extra(c, a, 16, &combined_x, 2 * N * 8));   // components 1, 2 of the merged evaluations
-    RC_TRY(arena_extra(c, a, 17, &ccoef_x, 2 * N * 8));      // their column coefficients
-    RC_TRY(arena_extra(c, a, 18, &ccoefs, 3 * N * 8));       // interleaved: column m i + k
-    RC_TRY(arena_extra(c, a, 19, &cldes, 3 * b * N * 8));
+    RC_TRY(arena_extra(c, a, 16, &combined_x, 2 * CN * 8));  // components 1, 2 of the merged evaluations
+    RC_TRY(arena_extra(c, a, 17, &ccoef_x, 2 * CN * 8));     // their column coefficients
+    RC_TRY(arena_extra(c, a, 18, &ccoefs, 3 * CN * 8));      // interleaved: column m i + k
+    RC_TRY(arena_extra(c, a, 19, &cldes, 3 * b * CN * 8));
     RC_TRY(arena_extra(c, a, 20, &deepx, 3 * N * 8));
-    RC_TRY(arena_extra(c, a, 21, &d_open, nq * (W * 8 + 192 + 2 * log_N * 32 + (size_t)n_layers * (96 + log_N * 32)) + 256));
+    RC_TRY(arena_extra(c, a, 21, &d_open, nq * (W * 8 + 192 + 2 * log_N * 32 + (size_t)n_layers * (fold * 24 + log_N * 32)) + 256));
     std::vector<uint64_t *> layer(n_layers + 1);
     {
         size_t sz = N;
-        for (unsigned l = 0; l <= n_layers; l++) { RC_TRY(arena_extra(c, a, 22 + l, &layer[l], 3 * sz * 8)); sz /= 4; }
+        for (unsigned l = 0; l <= n_layers; l++) { RC_TRY(arena_extra(c, a, 22 + l, &layer[l], 3 * sz * 8)); sz >>= log_f; }
     }
     hipStream_t st = c->stream;
     int evi = 0;
@@ -968,8 +993,8 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     STAGE();
     RC_TRY(job.build(c, a, job));
     STAGE();
-    RC_TRY(commit_columns(c, a, job, log_b, st, evi));
-    RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, 0, (uint32_t)b));
+    RC_TRY(commit_columns(c, a, job, st, evi));
+    RC_TRY(hash_rows_slots(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, log_s));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
     uint8_t trace_root[32], cons_root[32];
     HIP_TRY(hipMemcpyAsync(trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
@@ -1004,7 +1029,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
         const EX al = draw_e(), be = draw_e();
         for (unsigned q = 0; q < m; q++) { ba[q][i] = al.c[q]; bb[q][i] = be.c[q]; }
     }
-    uint64_t *comb[3] = {a->combined, combined_x, combined_x + N}, *cco[3] = {a->ccoef, ccoef_x, ccoef_x + N};
+    uint64_t *comb[3] = {a->combined, combined_x, combined_x + CN}, *cco[3] = {a->ccoef, ccoef_x, ccoef_x + CN};
     if (job.combine_sets) {
         const uint64_t *pa[3], *pb[3], *qa[3], *qb[3];
         for (unsigned q = 0; q < m; q++) { pa[q] = ta[q].data(); pb[q] = tb[q].data(); qa[q] = ba[q].data(); qb[q] = bb[q].data(); }
@@ -1013,15 +1038,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
         for (unsigned q = 0; q < m; q++) RC_TRY(job.combine(c, a, job, ta[q].data(), tb[q].data(), ba[q].data(), bb[q].data(), comb[q]));
     }
     STAGE();
-    for (unsigned q = 0; q < m; q++) {
-        const uint64_t *ce_evals = comb[q];
-        if (log_ce < log_b) { // the constraint-evaluation domain is the sub-domain of every (b / ce)-th LDE coset
-            const size_t stride = b >> log_ce;
-            for (size_t k = 0; k < ce; k++) HIP_TRY(hipMemcpyAsync(a->cegather + k * n, comb[q] + k * stride * n, n * 8, hipMemcpyDeviceToDevice, st));
-            ce_evals = a->cegather;
-        }
-        RC_TRY(cstark_composition_columns(c, ce_evals, cco[q], log_n, log_ce));
-    }
+    for (unsigned q = 0; q < m; q++) RC_TRY(cstark_composition_columns(c, comb[q], cco[q], log_n, log_ce)); // [ce][n] each
     for (size_t i = 0; i < ce; i++) // column m i + q = component q of composition column i
         for (unsigned q = 0; q < m; q++) HIP_TRY(hipMemcpyAsync(ccoefs + (m * i + q) * n, cco[q] + i * n, n * 8, hipMemcpyDeviceToDevice, st));
     RC_TRY(cstark_lde_columns(c, ccoefs, cldes, (uint32_t)CW, log_n, log_b, lde_offset(), 0, (uint32_t)b));
@@ -1080,16 +1097,16 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     uint64_t offset = lde_offset();
     unsigned lg = log_N;
     for (unsigned l = 0; l < n_layers; l++) {
-        const size_t rows = (size_t)1 << (lg - 2);
-        RC_TRY(cstark_hash_rows_fn(c, hf, layer[l], a->lnodes[l] + 32 * rows, 4 * m, lg - 2, 0, 0, 1)); // [m][4][rows]: component-major rows
-        RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - 2));
+        const size_t rows = (size_t)1 << (lg - log_f);
+        RC_TRY(cstark_hash_rows_fn(c, hf, layer[l], a->lnodes[l] + 32 * rows, fold * m, lg - log_f, 0, 0, 1)); // [m][f][rows]: component-major rows
+        RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - log_f));
         HIP_TRY(hipMemcpyAsync(&layer_roots[32 * l], a->lnodes[l] + 32, 32, hipMemcpyDeviceToHost, st));
         HIP_TRY(cs::stream_wait(st));
         coin.reseed(&layer_roots[32 * l]);
         const EX alpha = draw_e();
-        RC_TRY(cstark_fri_fold4_ext(c, layer[l], layer[l + 1], lg, offset, m, alpha.c));
-        offset = pow(offset, 4);
-        lg -= 2;
+        RC_TRY(cstark_fri_fold_ext(c, layer[l], layer[l + 1], lg, fold, offset, m, alpha.c));
+        offset = pow(offset, fold);
+        lg -= log_f;
     }
     const size_t R = (size_t)1 << lg;
     std::vector<uint64_t> remainder(m * R);
@@ -1109,7 +1126,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     {
         std::vector<uint32_t> cur = positions;
         unsigned g2 = log_N;
-        for (unsigned l = 0; l < n_layers; l++) { lpos[l] = fold_positions(cur, 1u << (g2 - 2)); cur = lpos[l]; g2 -= 2; }
+        for (unsigned l = 0; l < n_layers; l++) { lpos[l] = fold_positions(cur, 1u << (g2 - log_f)); cur = lpos[l]; g2 -= log_f; }
     }
     std::vector<uint32_t> hpos(256 * (n_layers + 1), 0);
     memcpy(hpos.data(), positions.data(), nq * 4);
@@ -1123,7 +1140,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     const size_t o_cpath = off; off += nq * log_N * 32;
     if (2 * (size_t)n_layers + 4 > MAX_GATHER_JOBS) return fail(CSTARK_ERR_UNSUPPORTED, "too many FRI layers for one opening launch");
     GatherList gl;
-    gl.rows(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, o + o_trows, (uint32_t)nq);
+    gl.rows(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, o + o_trows, (uint32_t)nq, log_s);
     gl.paths(a->tnodes, log_N, a->d_pos, o + o_tpath, (uint32_t)nq);
     gl.rows(cldes, (uint32_t)CW, log_n, log_b, a->d_pos, o + o_crows, (uint32_t)nq);
     gl.paths(a->cnodes, log_N, a->d_pos, o + o_cpath, (uint32_t)nq);
@@ -1131,12 +1148,12 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     {
         unsigned g2 = log_N;
         for (unsigned l = 0; l < n_layers; l++) {
-            const unsigned np = (unsigned)lpos[l].size(), lr = g2 - 2;
-            o_lrows[l] = off; off += (size_t)np * 32 * m;
+            const unsigned np = (unsigned)lpos[l].size(), lr = g2 - log_f;
+            o_lrows[l] = off; off += (size_t)np * fold * 8 * m;
             o_lpath[l] = off; off += (size_t)np * lr * 32;
-            gl.rows(layer[l], 4 * m, lr, 0, a->d_pos + 256 * (l + 1), o + o_lrows[l], np);
+            gl.rows(layer[l], fold * m, lr, 0, a->d_pos + 256 * (l + 1), o + o_lrows[l], np);
             gl.paths(a->lnodes[l], lr, a->d_pos + 256 * (l + 1), o + o_lpath[l], np);
-            g2 -= 2;
+            g2 -= log_f;
         }
     }
     HIP_TRY(gl.launch(st));
@@ -1169,9 +1186,9 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
         for (unsigned l = 0; l < n_layers; l++) {
             const size_t np = lpos[l].size();
             wr.u32((uint32_t)np);
-            wr.raw(open.data() + o_lrows[l], np * 32 * m);
-            wr.raw(open.data() + o_lpath[l], np * (g2 - 2) * 32);
-            g2 -= 2;
+            wr.raw(open.data() + o_lrows[l], np * fold * 8 * m);
+            wr.raw(open.data() + o_lpath[l], np * (g2 - log_f) * 32);
+            g2 -= log_f;
         }
     }
     wr.u32((uint32_t)R); wr.raw(remainder.data(), remainder.size() * 8);
@@ -1235,7 +1252,7 @@ int cstark_air_prove(cstark_ctx *c, int air, const cstark_options *opt, uint64_t
         // instead of ~150 (CSTARK_RANGE_VIA_BATCH=1): 0.30 against 0.36 ms in a process that does nothing else, but 0.48 against 0.38 ms
         // inside bench.py's process (other contexts alive) -- so the generic path stays the default (profiles/r03_range_single.txt).
         static const bool via_batch = [] { const char *e = getenv("CSTARK_RANGE_VIA_BATCH"); return e && atoi(e) != 0; }();
-        if (via_batch && opt->field_extension == 0 && proof && capacity >= cstark_tx_proof_size_bound(1, opt))
+        if (via_batch && opt->field_extension == 0 && opt->blowup_factor == 8 && opt->fri_folding_factor == 4 && proof && capacity >= cstark_tx_proof_size_bound(1, opt))
             return cstark_range_prove_batch(c, opt, &number, 1, proof, capacity, proof_len);
         host::air_shape(air, s, 0);
         job.log_n = 6; job.item = 0; job.number = number; // RANGE_LOG = 64 rows, src/range/mod.rs:34
@@ -1278,7 +1295,7 @@ int cstark_tx_shard_commit(cstark_ctx *c, const cstark_options *opt, uint32_t k0
     job.air = CSTARK_AIR_STATE_TRANSITION; job.width = CSTARK_TX_TRACE_WIDTH; job.log_n = 10 + ceil_log2(c->wit.n_tx); job.log_ce = 3;
     job.n_constraints = CSTARK_TX_NUM_CONSTRAINTS; job.n_assertions = 4; job.item = c->wit.depth;
     job.build = tx_build; job.combine = tx_combine;
-    job.k0 = k0; job.nk = nk;
+    job.k0 = k0; job.nk = nk; job.sharded = true;
     ProofRun *R = new (std::nothrow) ProofRun();
     if (!R) return fail(CSTARK_ERR_OOM, "host allocation failed");
     ProveArena *a = nullptr;
@@ -1362,11 +1379,19 @@ int cstark_range_prove_bits(cstark_ctx *c, const cstark_options *opt, const uint
 int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uint64_t *numbers, uint32_t count, uint8_t *proofs, size_t stride, size_t *lens) {
     using namespace cs::host;
     if (!c || !opt || !numbers || !proofs || !lens || count == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_prove_batch: null argument");
-    if (count > 65535) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_prove_batch: at most 65535 proofs per call");
+    // the transforms of the 2 * count columns are one launch with the column index in grid.y (at most 65535): 32768 proofs per call
+    if (count > 32768) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_prove_batch: at most 32768 proofs per call");
     if (opt->field_extension != 0) return fail(CSTARK_ERR_UNSUPPORTED, "cstark_range_prove_batch: FieldExtension::None only (use cstark_air_prove)");
-    unsigned log_rem = 0;
-    RC_TRY(check_options(opt, &log_rem));
-    const unsigned log_n = RB_LOG_N, log_N = log_n + 3, n_layers = num_fri_layers(log_N, log_rem);
+    unsigned log_rem = 0, log_b_opt = 3, log_f_opt = 2;
+    RC_TRY(check_options(opt, 1, &log_rem, &log_b_opt, &log_f_opt));
+    if (log_b_opt != 3 || log_f_opt != 2) {
+        // the one-launch-per-stage kernels (range_batch.hip) are laid out for the reference's get_example options (blowup 8, folding 4,
+        // src/range/mod.rs:44-50); other option values go through the generic prover one proof at a time -- same bytes
+        for (uint32_t t = 0; t < count; t++)
+            RC_TRY(cstark_air_prove(c, CSTARK_AIR_RANGE, opt, numbers[t], proofs + stride * t, stride, &lens[t]));
+        return CSTARK_OK;
+    }
+    const unsigned log_n = RB_LOG_N, log_N = log_n + 3, n_layers = num_fri_layers(log_N, log_rem, 2);
     const size_t B = count, n = RB_N, N = RB_LDE, nq = opt->num_queries, W = 2, ce = RB_CE;
     if (nq > N / 4) return fail(CSTARK_ERR_INVALID_ARG, "more queries than the domain supports");
     std::vector<uint64_t> canon(B);
@@ -1633,11 +1658,14 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
 
 size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt) {
     if (!opt || n_tx == 0) return 0;
-    unsigned log_N = 13;
-    while ((1u << (log_N - 13)) < n_tx) log_N++;
-    const size_t nq = opt->num_queries, layers = log_N / 2 + 1, em = opt->field_extension + 1; // em: words per drawn-field element
-    return 4096 + 32 * layers + (2 * 94 + 8) * 8 * em + nq * (94 * 8 + 8 * 8 * em + 2 * log_N * 32) + layers * (4 + nq * (32 * em + log_N * 32)) +
-           8 * em * (size_t)opt->fri_max_remainder;
+    unsigned log_b = 0, log_f = 2;
+    while ((1u << log_b) < opt->blowup_factor && log_b < 6) log_b++;
+    while ((1u << log_f) < opt->fri_folding_factor && log_f < 4) log_f++;
+    unsigned log_N = 10 + log_b;
+    while ((1u << (log_N - 10 - log_b)) < n_tx) log_N++;
+    const size_t nq = opt->num_queries, layers = log_N / log_f + 1, em = opt->field_extension + 1; // em: words per drawn-field element
+    return 4096 + 32 * layers + (2 * 94 + 8) * 8 * em + nq * (94 * 8 + 8 * 8 * em + 2 * log_N * 32) +
+           layers * (4 + nq * (((size_t)8 << log_f) * em + log_N * 32)) + 8 * em * (size_t)opt->fri_max_remainder;
 }
 
 int cstark_prove_stage_ms(cstark_ctx *c, float *ms /* [CSTARK_PROVE_NUM_STAGES] */) {

@@ -10,7 +10,7 @@ namespace cs {
 namespace {
 
 __global__ __launch_bounds__(256) void k_hash_rows_sha3(const uint64_t *__restrict__ lde, uint8_t *__restrict__ leaves, unsigned width, unsigned log_n,
-                                                        unsigned log_b, unsigned k0) {
+                                                        unsigned log_b, unsigned k0, unsigned log_s) {
     const size_t n = (size_t)1 << log_n;
     const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
     if (j >= n) return;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_hash_rows_sha3(const uint64_t *__restri
         }
         keccak::permute(s);
     }
-    const size_t leaf = (j << log_b) + k0 + kk;
+    const size_t leaf = (j << log_b) + lde_slot_coset(k0 + kk, log_b, log_s); // block order of the cosets: blake3.h
     uint4 *dst = reinterpret_cast<uint4 *>(leaves + 32 * leaf);
     dst[0] = make_uint4((uint32_t)s[0], (uint32_t)(s[0] >> 32), (uint32_t)s[1], (uint32_t)(s[1] >> 32));
     dst[1] = make_uint4((uint32_t)s[2], (uint32_t)(s[2] >> 32), (uint32_t)s[3], (uint32_t)(s[3] >> 32));
@@ -137,10 +137,10 @@ hipError_t merkle_build_batch_sha3(uint8_t *d_nodes, unsigned log_leaves, unsign
 }
 
 hipError_t hash_rows_sha3(const uint64_t *d_lde, uint8_t *d_leaves, unsigned width, unsigned log_n, unsigned log_b, unsigned k0, unsigned nk,
-                          hipStream_t stream) {
-    if (width == 0 || width > 128) return hipErrorInvalidValue;
+                          hipStream_t stream, unsigned log_s) {
+    if (width == 0 || width > 128 || log_s > log_b) return hipErrorInvalidValue;
     const size_t n = (size_t)1 << log_n;
-    hipLaunchKernelGGL(k_hash_rows_sha3, dim3((unsigned)((n + 255) / 256), nk), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b, k0);
+    hipLaunchKernelGGL(k_hash_rows_sha3, dim3((unsigned)((n + 255) / 256), nk), dim3(256), 0, stream, d_lde, d_leaves, width, log_n, log_b, k0, log_s);
     return hipGetLastError();
 }
 // Proof of work with the Sha3 coin (blake3.hip k_grind / k_grind_batch are the Blake3 forms): SHA3-256(seed || le64(nonce)), one

@@ -139,7 +139,7 @@ int cstark_lde_columns(cstark_ctx *ctx, const uint64_t *d_coeffs, uint64_t *d_ld
  *   cstark_evaluate_polys_at_ext: base-coefficient columns at one point; out[c][m] on the host.
  *   cstark_deep_composition_ext: all cosets; d_comp_lde holds m n_comp base columns per coset (column m i + k = component k of
  *     composition column i); coefficient / OOD arrays are host arrays of m-tuples; d_out = [m][b][n], component-major.
- *   cstark_fri_fold4_ext: d_evals = [m][N] component-major -> d_out = [m][N/4]. */
+ *   cstark_fri_fold4_ext / cstark_fri_fold_ext: d_evals = [m][N] component-major -> d_out = [m][N/4] / [m][N/folding_factor]. */
 int cstark_evaluate_polys_at_ext(cstark_ctx *ctx, const uint64_t *d_coeffs, uint32_t width, uint32_t log_n, uint32_t m, const uint64_t *z, uint64_t *out);
 int cstark_deep_composition_ext(cstark_ctx *ctx, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
                                 const uint64_t *z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha,
@@ -147,6 +147,8 @@ int cstark_deep_composition_ext(cstark_ctx *ctx, const uint64_t *d_trace_lde, co
                                 uint32_t log_n, uint32_t log_blowup);
 int cstark_fri_fold4_ext(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, uint32_t m,
                          const uint64_t *alpha);
+int cstark_fri_fold_ext(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint32_t folding_factor, uint64_t domain_offset,
+                        uint32_t m, const uint64_t *alpha);
 
 /* ---- K4/K5: Blake3 row hashing + Merkle tree (engine: build_commitment) ---------------------- */
 /* Hash row j of coset k (width elements, 8 bytes LE each, memory form) into leaf i = b*j + k:
@@ -192,8 +194,8 @@ int cstark_tx_evaluate_constraints_ext(cstark_ctx *ctx, const uint64_t *d_lde, c
  * (Rescue windows; doubling / mixed addition of s*G; of h*P; final addition; three linear groups) on the context's
  * stream; cstark_tx_constraint_part_ms waits for the last one and returns the 9 durations in milliseconds. */
 /* Inside cstark_tx_prove (base field) the parts run as the degree-split evaluation: every part except the final
- * addition on the even cosets only; the last figure (third linear group) then also holds the extension of the 14 merged
- * polynomials to the odd cosets and the recombination over all cosets. */
+ * addition on the even cosets only; the last figure (third linear group) then also holds the extension of the 13 merged
+ * polynomials (11 + the final addition's 2) to the odd cosets and the recombination over all cosets. */
 int cstark_ctx_set_part_timing(cstark_ctx *ctx, int enable);
 int cstark_tx_constraint_part_ms(cstark_ctx *ctx, float *ms /* [9] */);
 /* With part timing enabled every low-degree extension on this context (cstark_lde_columns and the prover's own extensions: trace,
@@ -223,29 +225,36 @@ int cstark_deep_composition(cstark_ctx *ctx, const uint64_t *d_trace_lde, const 
                             const uint64_t *beta, const uint64_t *delta, uint64_t deg_a, uint64_t deg_b, uint64_t *d_out,
                             uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk);
 
-/* FRI (folding factor 4).  cstark_interleave_cosets: [b][n] coset-major -> natural LDE order (i = b*j + k).
- * cstark_fri_fold4: N = 2^log_n evaluations over domain_offset * <w_N> (natural order) -> N/4 evaluations of the
- * alpha-folded polynomial over domain_offset^4 * <w_{N/4}>.  A layer is committed by viewing its N evaluations as the
- * 4 x (N/4) column-major table of rows { e[i + t N/4] } and calling cstark_hash_rows (width 4, log_blowup 0) and
- * cstark_merkle_build. */
+/* FRI (FriOptions::folding_factor f = 4, 8 or 16; the reference's examples pass -f, examples/state-transition.rs:46-47).
+ * cstark_interleave_cosets: [b][n] coset-major -> natural LDE order (i = b*j + k).
+ * cstark_fri_fold: N = 2^log_n evaluations over domain_offset * <w_N> (natural order) -> N/f evaluations of the
+ * alpha-folded polynomial over domain_offset^f * <w_{N/f}>.  A layer is committed by viewing its N evaluations as the
+ * f x (N/f) column-major table of rows { e[i + t N/f] } and calling cstark_hash_rows (width f, log_blowup 0) and
+ * cstark_merkle_build.  cstark_fri_fold4 = cstark_fri_fold with f = 4. */
 int cstark_interleave_cosets(cstark_ctx *ctx, const uint64_t *d_coset_major, uint64_t *d_natural, uint32_t log_n, uint32_t log_blowup);
 int cstark_fri_fold4(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint64_t domain_offset, uint64_t alpha);
+int cstark_fri_fold(cstark_ctx *ctx, const uint64_t *d_evals, uint64_t *d_out, uint32_t log_n, uint32_t folding_factor, uint64_t domain_offset,
+                    uint64_t alpha);
 
 /* ---- whole proof (replaces TransactionExample::prove, src/lib.rs:116-141 = build_trace + Prover::prove) ------------
  * Proves the uploaded witness (cstark_tx_witness_upload) under `opt` and writes the serialised proof to `proof`
  * (host, `capacity` bytes; cstark_tx_proof_size_bound gives a sufficient capacity).  *proof_len receives the length; if the
  * buffer is too small the call fails with CSTARK_ERR_INVALID_ARG and *proof_len still holds the required size.
  * The public inputs are read from the trace as TransactionProver::get_pub_inputs does (src/prover.rs:106-129).
- * Supported options: blowup 8, Blake3_256 or Sha3_256, FieldExtension::None / Quadratic / Cubic, FRI folding 4, remainder 128..1024 (the reference's
- * get_example options, src/lib.rs:78-86, qualify).
+ * Supported options (the values the reference's own tests, benches and command line pass: src/lib.rs:78-86, src/merkle/update/tests.rs:41-52,
+ * src/range/tests.rs:87-98, benches/rescue.rs:370-378, examples/state-transition.rs:33-34, :46-47): blowup_factor 2, 4, 8 or 16 and at least
+ * the AIR's constraint-evaluation blowup (TransactionAir / SchnorrAir 8, MerkleAir 4, RangeProofAir 2 -- below it the engine refuses the
+ * options too); Blake3_256 or Sha3_256; FieldExtension::None / Quadratic / Cubic; fri_folding_factor 4, 8 or 16; fri_max_remainder 128..1024;
+ * num_queries 1..128; grinding_factor 0..32.  The sharded entry points and cstark_range_prove_batch's one-launch-per-stage path take
+ * blowup 8 / folding 4 (the batch call falls back to one proof at a time for other values).
  *
  * Proof layout (little-endian; field elements as 8-byte memory form; this library's own format, the engine's
  * StarkProof::to_bytes layout is not available in the reference tree):
  *   "CSTK" u32 version | u32 air, trace_width, log2(trace_length), merkle_depth | u32 x 7 options
  *   trace_root[32] constraint_root[32] | u32 n_layers, layer_root[n_layers][32], remainder_commitment[32]
- *   T(z)[94] T(z w)[94] H_i(z^8)[8] | u64 pow_nonce
- *   trace rows [q][94], paths [q][log N][32] | composition rows [q][8], paths [q][log N][32]      (q = num_queries)
- *   per layer: u32 n_positions, rows [n_positions][4], paths [n_positions][log rows][32]
+ *   T(z)[94] T(z w)[94] H_i(z^8)[8] | u64 pow_nonce                                 (8 = the AIR's composition columns: 8 / 4 / 8 / 2)
+ *   trace rows [q][94], paths [q][log N][32] | composition rows [q][8], paths [q][log N][32]      (q = num_queries, N = blowup * n)
+ *   per layer: u32 n_positions, rows [n_positions][f], paths [n_positions][log rows][32]          (f = fri_folding_factor, rows = N_layer / f)
  *   u32 remainder_len, remainder[remainder_len]
  * Query positions are not stored: the verifier re-derives them from the channel.  Paths list siblings leaf-upwards. */
 #define CSTARK_PROOF_VERSION 1

@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 P = 2**62 + 2**56 + 2**55 + 1
-OPTS = (42, 8, 0, 0, 0, 4, 256)  # build_options(1) of the reference's tests
+OPTS = (42, 8, 0, 0, 0, 4, 256)  # build_options(1) of src/schnorr/tests.rs:40-54 and src/tests.rs (blowup 8); the MerkleAir / RangeProofAir tests use blowup 4: tests/test_gpu_options.py mirrors them at their own options
 
 
 @pytest.fixture(scope="module")
