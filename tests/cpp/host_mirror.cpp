@@ -23,10 +23,10 @@ int main(int argc, char **argv) {
         uint64_t pi[14];
         for (int i = 0; i < 7; i++) { pi[i] = pub.initial_root[i]; pi[7 + i] = pub.final_root[i]; }
         dump(prefix + ".pub", pi, sizeof pi);
-        // error behaviour: an unsupported option is refused, the metadata length check fires (src/lib.rs:211-218)
+        // error behaviour: a blowup factor below the AIR's constraint-evaluation blowup is refused, the metadata length check fires (src/lib.rs:211-218)
         bool refused = false, length_checked = false;
         try {
-            cstark::TransactionExample bad(cstark::ProofOptions(42, 16, 0, cstark::HashFunction::Blake3_256, cstark::FieldExtension::None, 4, 256), 2, ctx, 3);
+            cstark::TransactionExample bad(cstark::ProofOptions(42, 4, 0, cstark::HashFunction::Blake3_256, cstark::FieldExtension::None, 4, 256), 2, ctx, 3);
             bad.prove();
         } catch (const cstark::Error &) { refused = true; }
         try {
