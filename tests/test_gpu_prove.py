@@ -93,7 +93,8 @@ def test_production_depth_proofs(n_tx, depth, queries):
 def test_unsupported_options_are_refused():
     from certificate_stark_amd._lib import CstarkError
     from certificate_stark_amd.prover import ProofOptions
-    for opt in (ProofOptions(42, 16), ProofOptions(42, 8, 0, 2), ProofOptions(42, 8, 0, 0, 3), ProofOptions(42, 8, 0, 0, 0, 8)):
+    for opt in (ProofOptions(42, 4), ProofOptions(42, 32), ProofOptions(42, 8, 0, 2), ProofOptions(42, 8, 0, 0, 3), ProofOptions(42, 8, 0, 0, 0, 2),
+                ProofOptions(42, 8, 0, 0, 0, 32)):  # (blowup 16, folding 8 / 16: supported, tests/test_gpu_options.py)
         tx = example(2, 3, options=opt)
         with pytest.raises(CstarkError):
             tx.prove()
