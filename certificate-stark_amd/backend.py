@@ -472,14 +472,17 @@ class Backend:
         assert tuple(leaves_all.shape) == (8, n, 32) and leaves_all.dtype == torch.uint8
         self.lib.cstark_tx_shard_rows.restype = C.c_uint32
         out = self.empty_u64(int(self.lib.cstark_tx_shard_rows(C.c_uint32(self._shard_nk))), n)
-        check(self.lib.cstark_tx_shard_evaluate(self.ctx, self._ptr(leaves_all.contiguous(), u8p), self._ptr(out)))
+        check(self.lib.cstark_tx_shard_evaluate(self.ctx, self._ptr(leaves_all.contiguous(), u8p), self._ptr(out), C.c_uint32(out.shape[0])))
         return out
 
     def shard_compose(self, combined_all):
         """phase 3 (the rank that owns coset 0): the ranks' shares [W * R][n] -> query positions, int32 [num_queries]"""
         nq = self._shard_options.num_queries
         pos = np.zeros(nq, np.uint32)
-        check(self.lib.cstark_tx_shard_compose(self.ctx, self._ptr(combined_all.contiguous()), pos.ctypes.data_as(C.POINTER(C.c_uint32))))
+        n = self.n_tx * _lib.TX_CYCLE_LENGTH
+        assert combined_all.dim() == 2 and combined_all.shape[1] == n
+        check(self.lib.cstark_tx_shard_compose(self.ctx, self._ptr(combined_all.contiguous()), C.c_uint32(combined_all.shape[0]),
+                                               pos.ctypes.data_as(C.POINTER(C.c_uint32))))
         return torch.from_numpy(pos.view(np.int32)).to(self.device)
 
     def shard_open_rows(self, positions):

@@ -144,7 +144,15 @@ int lde_mark(cstark_ctx *c) {
 // All cosets of an extension go into ONE launch pair (the grid's batch dimension) when their intermediate fits this budget: the eight
 // cosets of a coefficient tile then run together on one XCD and the coefficients are read from HBM once (ntt.hip, k_ntt_cols_v5).  7 GiB
 // covers the 94 x 2^20 x 8 trace (6.3 GB; HBM holds 288 GB); CSTARK_LDE_BATCH_MB overrides (tuning; 0 = coset by coset as in round 2).
-const size_t LDE_BATCH_WS_BYTES = [] { const char *e = getenv("CSTARK_LDE_BATCH_MB"); return e ? (size_t)atoll(e) << 20 : (size_t)7 << 30; }();
+// (clamped to 0 .. 64 GiB: a negative or absurd value must not become a huge size_t).  Footprint: the workspace of a context grows to the
+// largest batch it has extended -- 6.3 GB for the 94 x 2^20 x 8 trace -- and stays: every context (ProverPool worker, shard rank) holds
+// its own.  If that allocation fails the extension falls back to one coset at a time (0.8 GB).
+const size_t LDE_BATCH_WS_BYTES = [] {
+    const char *e = getenv("CSTARK_LDE_BATCH_MB");
+    if (!e) return (size_t)7 << 30;
+    const long long mb = atoll(e);
+    return mb <= 0 ? (size_t)0 : mb > (64ll << 10) ? (size_t)64 << 30 : (size_t)mb << 20;
+}();
 constexpr uint32_t LDE_COLUMN_GROUP = 1u << 30; // columns per group of the LDE (see lde_impl); 2^30 = all columns at once
 int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uint32_t width, uint32_t col0, uint32_t ncols, uint32_t log_n,
                    uint32_t log_blowup, uint64_t domain_offset, uint32_t k0, uint32_t nk);
@@ -185,9 +193,15 @@ int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uin
     if (nk > 1 && (size_t)nk * (group < ncols ? group : ncols) * n * 8 <= LDE_BATCH_WS_BYTES) {
         // (with CSTARK_NTT_GROUP: column groups, all cosets of a group in one launch pair -- the group's intermediate, nk x group x n
         // words, is then written and read back within a short window)
+        bool batched_ok = true;
         for (uint32_t g0 = col0; g0 < col0 + ncols; g0 += group) {
             const uint32_t gw = col0 + ncols - g0 < group ? col0 + ncols - g0 : group;
-            RC_TRY(ensure_ws(c, (size_t)nk * gw * n * 8));
+            if (ensure_ws(c, (size_t)nk * gw * n * 8) != CSTARK_OK) { // no room for the batched intermediate: coset by coset below
+                (void)hipGetLastError();
+                if (g0 != col0) return fail(CSTARK_ERR_OOM, "workspace allocation failed in the middle of an extension");
+                batched_ok = false;
+                break;
+            }
             cs::NttArgs a{};
             a.in = d_coeffs + (size_t)g0 * n; a.scratch = (uint64_t *)c->ws; a.out = d_lde + (size_t)g0 * n;
             a.width = gw; a.batch = nk; a.log_n = log_n;
@@ -196,7 +210,8 @@ int lde_impl_inner(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, uin
             a.in_batch_stride = 0; a.scratch_batch_stride = (size_t)gw * n; a.out_batch_stride = (size_t)width * n;
             HIP_TRY(cs::ntt_columns(a, c->stream));
         }
-        return CSTARK_OK;
+        if (batched_ok) return CSTARK_OK;
+        RC_TRY(ensure_ws(c, (size_t)width * n * 8));
     }
     for (uint32_t g0 = col0; g0 < col0 + ncols; g0 += group) {
         const uint32_t gw = col0 + ncols - g0 < group ? col0 + ncols - g0 : group;
@@ -286,7 +301,7 @@ int ce_params(cstark_ctx *c, const uint64_t *d_lde, uint64_t *d_out, uint32_t me
 extern "C" {
 
 const char *cstark_last_error(void) { return g_err; }
-const char *cstark_version(void) { return "certificate-stark_amd 0.1 (gfx950)"; }
+const char *cstark_version(void) { return "certificate-stark_amd 0.2 (gfx950)"; }
 
 int cstark_ctx_create(int device, void *stream, cstark_ctx **out) {
     if (!out) return fail(CSTARK_ERR_INVALID_ARG, "cstark_ctx_create: out is null");

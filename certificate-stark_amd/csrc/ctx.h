@@ -24,7 +24,9 @@ inline hipError_t stream_wait(hipStream_t st) {
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e;
     for (unsigned it = 0; (e = hipStreamQuery(st)) == hipErrorNotReady; it++) {
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
         if ((it & 15) == 15 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us)
             return hipStreamSynchronize(st);
     }

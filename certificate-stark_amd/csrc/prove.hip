@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <new>
 #include <chrono>
 #include <thread>
@@ -1202,15 +1203,29 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
 } // namespace cs
 
 namespace {
+// f(i) for every i < count on up to eight host threads.  Nothing escapes: an exception inside a worker (the channel code allocates) or a
+// thread that cannot be created ends in CSTARK_ERR_OOM -- these lambdas run inside extern "C" functions, where an escaping exception
+// would be std::terminate.
 template <class F>
-void parallel_for(size_t count, F f) {
+int parallel_for(size_t count, F f) {
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt == 0 ? 1 : nt > 8 ? 8 : nt;
-    if (count < 64 || nt == 1) { for (size_t i = 0; i < count; i++) f(i); return; }
-    std::vector<std::thread> th;
-    for (unsigned w = 0; w < nt; w++)
-        th.emplace_back([=] { for (size_t i = w; i < count; i += nt) f(i); });
-    for (std::thread &t : th) t.join();
+    std::atomic<bool> failed{false};
+    auto guarded = [&](size_t first, size_t step) {
+        try { for (size_t i = first; i < count && !failed.load(std::memory_order_relaxed); i += step) f(i); }
+        catch (...) { failed.store(true); }
+    };
+    if (count < 64 || nt == 1) {
+        guarded(0, 1);
+    } else {
+        std::vector<std::thread> th;
+        try {
+            th.reserve(nt);
+            for (unsigned w = 0; w < nt; w++) th.emplace_back(guarded, (size_t)w, (size_t)nt);
+        } catch (...) { failed.store(true); }
+        for (std::thread &t : th) t.join();
+    }
+    return failed.load() ? cs::fail(CSTARK_ERR_OOM, "host allocation or thread creation failed inside a batched channel step") : CSTARK_OK;
 }
 struct Carver { // consecutive 256-byte aligned pieces of one block
     uint8_t *base; size_t off = 0;
@@ -1307,16 +1322,20 @@ int cstark_tx_shard_commit(cstark_ctx *c, const cstark_options *opt, uint32_t k0
     return rc;
 }
 uint32_t cstark_tx_shard_rows(uint32_t nk) { return (nk == 1 || nk == 2 || nk == 4) ? shard_rows(nk) : 0; }
-int cstark_tx_shard_evaluate(cstark_ctx *c, const uint8_t *d_leaves_all, uint64_t *d_combined_local) {
+int cstark_tx_shard_evaluate(cstark_ctx *c, const uint8_t *d_leaves_all, uint64_t *d_combined_local, uint32_t rows) {
     ProofRun *R;
     RC_TRY(shard_run(c, 1, &R));
     if (!d_leaves_all || !d_combined_local) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_evaluate: null argument");
+    // the caller sized d_combined_local [rows][n]: the count depends on nk AND on the evaluation mode of this process (shard_rows)
+    if (rows != shard_rows(R->job.nk)) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_evaluate: rows differs from cstark_tx_shard_rows(nk)");
     return phase_evaluate(c, c->arena, *R, d_leaves_all, d_combined_local);
 }
-int cstark_tx_shard_compose(cstark_ctx *c, const uint64_t *d_combined_all, uint32_t *positions /* host [num_queries] */) {
+int cstark_tx_shard_compose(cstark_ctx *c, const uint64_t *d_combined_all, uint32_t total_rows, uint32_t *positions /* host [num_queries] */) {
     ProofRun *R;
     RC_TRY(shard_run(c, 2, &R));
     if (!d_combined_all || !positions) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_compose: null argument");
+    // every rank must have handed over the same number of rows (ranks whose CSTARK_SHARD_SPLIT differs would not)
+    if (total_rows != (8 / R->job.nk) * shard_rows(R->job.nk)) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_compose: total_rows differs from W * cstark_tx_shard_rows(nk)");
     ProveArena *a = c->arena;
     const size_t N = (size_t)8 << R->job.log_n;
     if (shard_split(R->job.nk)) RC_TRY(tx_shard_combine(c, d_combined_all, a->combined, R->job.log_n, R->job.nk)); // the ranks' shares -> [8][n]
@@ -1487,7 +1506,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
 
     mark("trace..trace roots (gpu)");
     std::vector<Coin> coins(B);
-    parallel_for(B, [&](size_t t) {
+    RC_TRY(parallel_for(B, [&](size_t t) {
         Coin &coin = coins[t];
         coin.hash_fn = hf;
         Writer sd;
@@ -1503,7 +1522,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
         uint64_t *cf = h_coefs + 8 * t; // t_alpha[2] t_beta[2] b_alpha[2] b_beta[2]
         for (int i = 0; i < 2; i++) { cf[i] = coin.draw(); cf[2 + i] = coin.draw(); }
         for (int i = 0; i < 2; i++) { cf[4 + i] = coin.draw(); cf[6 + i] = coin.draw(); }
-    });
+    }));
     mark("coefficients (host)");
     HIP_TRY(hipMemcpyAsync(d_coefs, h_coefs, B * 64, hipMemcpyHostToDevice, st));
 
@@ -1516,14 +1535,14 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
     HIP_TRY(hipMemcpy2DAsync(h_croot, 32, d_cnodes + 32, 2 * N * 32, 32, B, hipMemcpyDeviceToHost, st));
     HIP_TRY(cs::stream_wait(st));
     mark("constraints..comp roots (gpu)");
-    parallel_for(B, [&](size_t t) { coins[t].reseed(h_croot + 32 * t); h_z[t] = coins[t].draw(); });
+    RC_TRY(parallel_for(B, [&](size_t t) { coins[t].reseed(h_croot + 32 * t); h_z[t] = coins[t].draw(); }));
     HIP_TRY(hipMemcpyAsync(d_z, h_z, B * 8, hipMemcpyHostToDevice, st));
 
     // ---- out-of-domain frame, DEEP composition -----------------------------------------------------------------------------------------
     HIP_TRY(rb_ood(K, d_coeffs, d_ccoef, d_z, d_ood, (unsigned)B, st));
     HIP_TRY(hipMemcpyAsync(h_ood, d_ood, B * 48, hipMemcpyDeviceToHost, st));
     HIP_TRY(cs::stream_wait(st));
-    parallel_for(B, [&](size_t t) {
+    RC_TRY(parallel_for(B, [&](size_t t) {
         Coin &coin = coins[t];
         uint8_t dg[32];
         hash_elements(hf, h_ood + 6 * t, 4, dg); coin.reseed(dg);
@@ -1535,7 +1554,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
         }
         for (int i = 0; i < 2; i++) cf[4 + i] = coin.draw();
         cf[6] = coin.draw(); cf[7] = coin.draw();
-    });
+    }));
     mark("ood + deep coefficients");
     HIP_TRY(hipMemcpyAsync(d_dcoef, h_dcoef, B * 64, hipMemcpyHostToDevice, st));
     HIP_TRY(rb_deep(K, d_lde, d_clde, d_z, d_ood, d_dcoef, d_layer, (unsigned)B, st));
@@ -1546,7 +1565,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
         HIP_TRY(merkle_b(d_lnodes, 7, 256 * 32));
         HIP_TRY(hipMemcpy2DAsync(h_lroot, 32, d_lnodes + 32, 256 * 32, 32, B, hipMemcpyDeviceToHost, st));
         HIP_TRY(cs::stream_wait(st));
-        parallel_for(B, [&](size_t t) { coins[t].reseed(h_lroot + 32 * t); h_alpha[t] = coins[t].draw(); });
+        RC_TRY(parallel_for(B, [&](size_t t) { coins[t].reseed(h_lroot + 32 * t); h_alpha[t] = coins[t].draw(); }));
         HIP_TRY(hipMemcpyAsync(d_alpha, h_alpha, B * 8, hipMemcpyHostToDevice, st));
         HIP_TRY(rb_fold(K, d_layer, d_alpha, d_rem, (unsigned)B, st));
         HIP_TRY(hipMemcpyAsync(h_rem, d_rem, B * 8 * rem_len, hipMemcpyDeviceToHost, st));
@@ -1562,12 +1581,12 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
     static const bool grind_dev_env = [] { const char *e = getenv("CSTARK_GRIND_DEVICE"); return !e || atoi(e) != 0; }();
     const bool grind_dev = grind_dev_env && opt->grinding_factor >= 12;
     if (grind_dev) {
-        parallel_for(B, [&](size_t t) {
+        RC_TRY(parallel_for(B, [&](size_t t) {
             hash_elements(hf, h_rem + rem_len * t, rem_len, &rem_commit[32 * t]);
             coins[t].reseed(&rem_commit[32 * t]);
             memcpy(h_gseed + 8 * t, coins[t].seed, 32);
             h_gfound[t] = ~0ull;
-        });
+        }));
         HIP_TRY(hipMemcpyAsync(d_gseed, h_gseed, B * 32, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d_gfound, h_gfound, B * 8, hipMemcpyHostToDevice, st));
         uint64_t chunk = (uint64_t)4 << opt->grinding_factor; // four expected hits per proof and chunk
@@ -1584,7 +1603,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
             if (base > ((uint64_t)1 << 44)) return fail(CSTARK_ERR_HIP, "proof of work: no nonce found");
         }
     }
-    parallel_for(B, [&](size_t t) {
+    RC_TRY(parallel_for(B, [&](size_t t) {
         Coin &coin = coins[t];
         uint64_t nonce = 1;
         if (grind_dev) {
@@ -1611,7 +1630,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
             memcpy(h_lpos + nq * t, lp.data(), lp.size() * 4);
             for (size_t q = lp.size(); q < nq; q++) h_lpos[nq * t + q] = 0;
         } else h_lcount[t] = 0;
-    });
+    }));
 
     mark("remainder, positions (host)");
     // ---- openings, proof bytes ----------------------------------------------------------------------------------------------------------------
@@ -1622,7 +1641,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
     HIP_TRY(rb_open(o, st));
     HIP_TRY(hipMemcpyAsync(h_open, d_open, B * slot, hipMemcpyDeviceToHost, st));
     HIP_TRY(cs::stream_wait(st));
-    parallel_for(B, [&](size_t t) {
+    RC_TRY(parallel_for(B, [&](size_t t) {
         const uint8_t *op = h_open + slot * t;
         const size_t o_trows = 0, o_tpath = o_trows + nq * 16, o_crows = o_tpath + nq * 288, o_cpath = o_crows + nq * 16, o_lrows = o_cpath + nq * 288,
                      o_lpath = o_lrows + nq * 32;
@@ -1649,7 +1668,7 @@ int cstark_range_prove_batch(cstark_ctx *c, const cstark_options *opt, const uin
         wr.u32((uint32_t)rem_len); wr.raw(h_rem + rem_len * t, rem_len * 8);
         lens[t] = wr.b.size();
         if (wr.b.size() <= stride) memcpy(proofs + stride * t, wr.b.data(), wr.b.size());
-    });
+    }));
     mark("openings + serialise");
     for (size_t t = 0; t < B; t++)
         if (lens[t] > stride) return fail(CSTARK_ERR_INVALID_ARG, "cstark_range_prove_batch: stride too small");

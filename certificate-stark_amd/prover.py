@@ -185,7 +185,36 @@ class TransactionExample:
 
 
 # ---- the standalone examples of the reference: same prove() surface over cstark_air_prove ---------------------------------------
-class MerkleExample:
+class _ResidentWitness:
+    """An example's witness is uploaded by its first prove() and stays in device memory (any other upload on the same backend replaces
+    it).  While it is resident the host arrays it was uploaded from are READ-ONLY (numpy refuses writes), so a changed witness can never
+    be proved from the stale device copy: call invalidate() before editing them (or assign new arrays: that is detected)."""
+
+    def _witness_arrays(self):
+        raise NotImplementedError
+
+    def _ensure_resident(self, upload):
+        arrays = self._witness_arrays()
+        key = tuple(id(a) for a in arrays)
+        if getattr(self.backend, "resident", None) is not self or getattr(self, "_resident_key", None) != key:
+            upload()
+            self.backend.resident, self._resident_key = self, key
+            self._was_writeable = [bool(a.flags.writeable) for a in arrays]
+            for a in arrays:
+                a.flags.writeable = False
+
+    def invalidate(self):
+        """the host witness is about to change: make it writable again and upload it anew at the next prove()"""
+        if getattr(self, "_resident_key", None) is not None:
+            for a, w in zip(self._witness_arrays(), self._was_writeable):
+                if w:
+                    a.flags.writeable = True
+        self._resident_key = None
+        if getattr(self.backend, "resident", None) is self:
+            self.backend.resident = None
+
+
+class MerkleExample(_ResidentWitness):
     """merkle::update::MerkleExample (src/merkle/update/mod.rs:36-127): proves the Merkle-update half of the transfers with the
     65-register MerkleAir."""
 
@@ -193,18 +222,19 @@ class MerkleExample:
         self.options, self.tx_metadata = options, tx_metadata
         self.backend = backend or Backend()
 
+    def _witness_arrays(self):
+        return [getattr(self.tx_metadata, f) for f in TransactionMetadata.FIELDS]
+
     def prove(self):
-        """The witness is uploaded by the first call and stays resident (any other upload on the same backend replaces it)."""
-        if getattr(self.backend, "resident", None) is not self:
-            self.backend.upload_witness(self.tx_metadata)
-            self.backend.resident = self
+        """The witness is uploaded by the first call and stays resident (_ResidentWitness: read-only on the host until invalidate())."""
+        self._ensure_resident(lambda: self.backend.upload_witness(self.tx_metadata))
         return self.backend.air_prove(Backend.AIR_MERKLE, self.options)
 
     def pub_inputs(self):
         return self.tx_metadata.initial_roots[0], self.tx_metadata.final_root
 
 
-class SchnorrExample:
+class SchnorrExample(_ResidentWitness):
     """schnorr::SchnorrExample (src/schnorr/mod.rs:52-186): messages [n][28] (public key || 16 elements) with signatures."""
 
     def __init__(self, options, messages, sig_rx, sig_s, backend=None):
@@ -220,11 +250,12 @@ class SchnorrExample:
                                                                rx.ctypes.data_as(_lib.u64p), s.ctypes.data_as(_lib.u8p)))
         return cls(options, msg, rx, s, backend)
 
+    def _witness_arrays(self):
+        return [self.messages, self.sig_rx, self.sig_s]
+
     def prove(self):
-        """The witness is uploaded by the first call and stays resident (any other upload on the same backend replaces it)."""
-        if getattr(self.backend, "resident", None) is not self:
-            self.backend.upload_schnorr_witness(self.messages, self.sig_rx, self.sig_s)
-            self.backend.resident = self
+        """The witness is uploaded by the first call and stays resident (_ResidentWitness: read-only on the host until invalidate())."""
+        self._ensure_resident(lambda: self.backend.upload_schnorr_witness(self.messages, self.sig_rx, self.sig_s))
         return self.backend.air_prove(Backend.AIR_SCHNORR, self.options)
 
 

@@ -289,8 +289,10 @@ size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt);
  *   5 cstark_tx_shard_finish     rank 0: paths, remaining openings, proof bytes. */
 uint32_t cstark_tx_shard_rows(uint32_t nk); /* rows of n evaluations a rank with nk cosets contributes in phase 2 (0: invalid nk) */
 int cstark_tx_shard_commit(cstark_ctx *ctx, const cstark_options *opt, uint32_t k0, uint32_t nk, uint8_t *d_leaves_local);
-int cstark_tx_shard_evaluate(cstark_ctx *ctx, const uint8_t *d_leaves_all, uint64_t *d_combined_local);
-int cstark_tx_shard_compose(cstark_ctx *ctx, const uint64_t *d_combined_all, uint32_t *positions);
+/* rows / total_rows: the row counts the caller sized d_combined_local ([rows][n]) and d_combined_all ([total_rows][n]) by; a value other
+ * than cstark_tx_shard_rows(nk) / W * cstark_tx_shard_rows(nk) is refused before anything is written (version 0.2 of this library). */
+int cstark_tx_shard_evaluate(cstark_ctx *ctx, const uint8_t *d_leaves_all, uint64_t *d_combined_local, uint32_t rows);
+int cstark_tx_shard_compose(cstark_ctx *ctx, const uint64_t *d_combined_all, uint32_t total_rows, uint32_t *positions);
 int cstark_tx_shard_open_rows(cstark_ctx *ctx, const uint32_t *positions, uint32_t nq, uint64_t *d_rows);
 int cstark_tx_shard_finish(cstark_ctx *ctx, const uint64_t *d_rows, uint8_t *proof, size_t capacity, size_t *proof_len);
 /* Wall-clock of the stages of the last cstark_tx_prove on this context (HIP events on its stream), milliseconds:

@@ -171,7 +171,14 @@ class ProverPool {
     explicit ProverPool(const ProofOptions &options, unsigned workers = 2, int device = -1) : options_(options) {
         if (workers == 0) throw Error(CSTARK_ERR_INVALID_ARG, "ProverPool: at least one worker");
         for (unsigned w = 0; w < workers; w++) ctx_.emplace_back(new Context(Context::OwnStream{}, device));
-        for (unsigned w = 0; w < workers; w++) threads_.emplace_back([this, w] { run(w); });
+        try {
+            for (unsigned w = 0; w < workers; w++) threads_.emplace_back([this, w] { run(w); });
+        } catch (...) { // a thread could not be created: stop and join the ones already running (a joinable std::thread must not be destroyed)
+            { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+            cv_.notify_all();
+            for (std::thread &t : threads_) t.join();
+            throw;
+        }
     }
     ~ProverPool() {
         { std::lock_guard<std::mutex> g(m_); stop_ = true; }

@@ -150,3 +150,38 @@ def test_vectorised_coin_candidates_equal_the_scalar_hash(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_coin_check.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
+def test_resident_witness_is_read_only_until_invalidated():
+    """MerkleExample / SchnorrExample keep their witness in device memory between prove() calls.  A host-side edit must never
+    be proved from the stale device copy: the uploaded arrays are read-only while resident, invalidate() or a replaced array uploads anew."""
+    import numpy as np
+    import pytest
+    from certificate_stark_amd.prover import ProofOptions, SchnorrExample
+
+    class FakeBackend:
+        resident = None
+        uploads = 0
+
+        def upload_schnorr_witness(self, *a):
+            self.uploads += 1
+
+        def air_prove(self, air, options, number=0):
+            return b"proof"
+
+    b = FakeBackend()
+    ex = SchnorrExample(ProofOptions(), np.zeros((2, 28), np.uint64), np.zeros((2, 6), np.uint64), np.zeros((2, 32), np.uint8), backend=b)
+    ex.prove(); ex.prove()
+    assert b.uploads == 1
+    with pytest.raises(ValueError):          # numpy: assignment destination is read-only
+        ex.sig_s[1, 3] ^= 1
+    ex.invalidate()
+    ex.sig_s[1, 3] ^= 1
+    ex.prove()
+    assert b.uploads == 2
+    ex.messages = ex.messages.copy()         # a replaced array is a new witness too
+    ex.prove()
+    assert b.uploads == 3
+    other = SchnorrExample(ProofOptions(), np.zeros((2, 28), np.uint64), np.zeros((2, 6), np.uint64), np.zeros((2, 32), np.uint8), backend=b)
+    other.prove(); ex.prove()                # another example took the device copy
+    assert b.uploads == 5

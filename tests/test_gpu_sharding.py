@@ -48,12 +48,16 @@ def test_sharded_proof_equals_single_gpu_proof(oracle, world, n_tx, depth, opts)
     assert V.verify(proof, w.initial_roots[0], w.final_root, options=list(opts))
 
 
-def test_sharded_proof_at_full_size():
-    """BASELINE's headline configuration split over two ranks' worth of cosets: the digests of the CPU prover's proof."""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_proof_at_full_size(world):
+    """BASELINE's headline configuration (config 4: 2^20 steps "sharded across 8 x MI355X") split over 2, 4 and 8 ranks' worth of cosets,
+    the W contexts in one process on the one GPU of the box: the digests of the CPU prover's proof.  W = 2, 4: the ranks' shares of the
+    degree-split evaluation; W = 8: one coset per rank, evaluated point by point.  (The eight-PROCESS form of the rehearsal below cannot
+    run on a one-GPU box: it admits six GPU processes.)  Unmeasured across GPUs: this is a correctness test."""
     from certificate_stark_amd.prover import ProofOptions, TransactionMetadata
     from tools.make_proof_digest import section_digests
     meta = TransactionMetadata.load(os.path.join(ROOT, "tests", "golden", "witness_1024_d15.npz"))
-    proof = _sharded_proof(meta, ProofOptions(96, 8, 0, 0, 0, 4, 256), 2)
+    proof = _sharded_proof(meta, ProofOptions(96, 8, 0, 0, 0, 4, 256), world)
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proof_1024tx_d15_q96.json")))
     assert section_digests(proof, 96) == gold["sections"]
     assert hashlib.sha256(proof).hexdigest() == gold["sha256"]
