@@ -208,7 +208,25 @@ class Backend:
         return out
 
     # ---- standalone sub-AIRs (MerkleAir, RangeProofAir) ----
-    AIR_MERKLE, AIR_SCHNORR, AIR_RANGE = 1, 2, 3
+    AIR_MERKLE, AIR_SCHNORR, AIR_RANGE, AIR_RESCUE_CHAIN = 1, 2, 3, 4
+
+    def rescue_chain_build_trace(self, seed, chain_length):
+        """cstark_rescue_chain_build_trace: 14 x 8 * chain_length (benches/rescue.rs:277-322); seed: 7 elements, memory form"""
+        s = _np_u64(seed)
+        out = self.empty_u64(14, 8 * chain_length)
+        check(self.lib.cstark_rescue_chain_build_trace(self.ctx, self._hptr(s), C.c_uint32(chain_length), self._ptr(out)))
+        return out
+
+    def rescue_prove(self, options, seed, chain_length):
+        """cstark_rescue_prove: complete RescueAir proof of a chain of `chain_length` hashes from `seed` (benches/rescue.rs:66-86)"""
+        s = _np_u64(seed)
+        o = self._options_struct(options)
+        self.lib.cstark_tx_proof_size_bound.restype = C.c_size_t
+        cap = 2 * self.lib.cstark_tx_proof_size_bound(C.c_uint32(max(1, chain_length // 128)), C.byref(o))
+        buf = (C.c_uint8 * cap)()
+        n = C.c_size_t(0)
+        check(self.lib.cstark_rescue_prove(self.ctx, C.byref(o), self._hptr(s), C.c_uint32(chain_length), buf, C.c_size_t(cap), C.byref(n)))
+        return bytes(memoryview(buf)[:n.value])
 
     def merkle_build_trace(self):
         out = self.empty_u64(65, self.n_tx * 512)

@@ -91,6 +91,15 @@ inline void schnorr_mask_columns(std::vector<uint64_t> &out) {
         for (unsigned i = 0; i < 512; i++) col(8 + j)[i] = CS_ARK_MONT[(i % 8) * 28 + j];
 }
 
+// RescueAir periodic columns (benches/rescue.rs:133-142, :245-249): the cycle mask (seven ones, one zero), then the 28 round constants;
+// 29 columns x 8 rows
+inline void rescue_chain_periodic_columns(std::vector<uint64_t> &out) {
+    out.assign((size_t)29 * 8, 0);
+    for (unsigned i = 0; i < 7; i++) out[i] = ONE;
+    for (int j = 0; j < 28; j++)
+        for (unsigned i = 0; i < 8; i++) out[(size_t)(1 + j) * 8 + i] = CS_ARK_MONT[i * 28 + j];
+}
+
 // Static description of an AIR as the engine sees it: width, constraint degrees (base; cycles of length cycle_len),
 // single-step assertions.  air ids as in cstark_air_id.
 struct AirShape {
@@ -143,6 +152,12 @@ inline bool air_shape(int air, AirShape &s, uint32_t n_items = 2) {
         for (int k = 0; k < 6; k++) add(42 + k, 0, 0, k);
         for (int i = 0; i < 7; i++) add(48 + i, 0, 0, -1);
         for (int k = 0; k < 6; k++) add(k, 511, 0, 6 + k);
+        return true;
+    }
+    if (air == 4) { // RescueAir of benches/rescue.rs: 14 x (3; one cycle of 8) :169-191, seed / result assertions :224-243
+        s.width = 14; s.n_constraints = 14; s.cycle_len = 8; s.n_periodic = 29;
+        s.base.assign(14, 3); s.cycles.assign(14, 1);
+        for (int a = 0; a < 14; a++) { s.a_reg.push_back(a % 7); s.a_last.push_back(a / 7); }
         return true;
     }
     if (air == 3) { // RangeProofAir: degrees (2), (1), src/range/air.rs:100-105; assertions :79-86

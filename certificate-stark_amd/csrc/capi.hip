@@ -1189,6 +1189,58 @@ int cstark_merkle_periodic_columns(uint32_t merkle_depth, uint64_t *out /* [33][
 }
 
 static int merkle_periodic(cstark_ctx *c, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, const PeriodicTable **out);
+// RescueAir's 29 periodic columns (cycle 8) over the LDE domain, [b][29][8]: a column of period 8 is a polynomial of degree < 8 in
+// x^(n/8); 8 x 8 x 29 x b values, computed on the host (the transform kernels start at 64 points)
+static int rescue_periodic(cstark_ctx *c, uint32_t log_n, uint32_t log_blowup, const PeriodicTable **out) {
+    const int air = CSTARK_AIR_RESCUE_CHAIN;
+    for (const PeriodicTable &t : c->small_periodic)
+        if (t.air == air && t.log_n == log_n && t.log_b == log_blowup) { *out = &t; return CSTARK_OK; }
+    using namespace cs::host;
+    std::vector<uint64_t> cols;
+    rescue_chain_periodic_columns(cols);
+    const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_blowup;
+    for (int cidx = 0; cidx < 29; cidx++) intt_small(cols.data() + (size_t)cidx * 8, 3);
+    std::vector<uint64_t> tab(b * 29 * 8);
+    const uint64_t wbn = root_of_unity(log_n + log_blowup), w8 = root_of_unity(3);
+    uint64_t shift = lde_offset();
+    for (size_t k = 0; k < b; k++) {
+        uint64_t x = pow(shift, n / 8); // point m of coset k in the variable x^(n/8): shift^(n/8) w_8^m
+        for (int m = 0; m < 8; m++) {
+            for (int cidx = 0; cidx < 29; cidx++) {
+                const uint64_t *co = cols.data() + (size_t)cidx * 8;
+                uint64_t v = 0;
+                for (int d = 7; d >= 0; d--) v = add(mul(v, x), co[d]);
+                tab[(k * 29 + cidx) * 8 + m] = v;
+            }
+            x = mul(x, w8);
+        }
+        shift = mul(shift, wbn);
+    }
+    PeriodicTable t{0, log_n, log_blowup, nullptr, nullptr, nullptr, air};
+    HIP_TRY(hipMalloc((void **)&t.tab, tab.size() * 8));
+    HIP_TRY(hipMemcpyAsync(t.tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->small_periodic.push_back(t);
+    *out = &c->small_periodic.back();
+    return CSTARK_OK;
+}
+int cstark_rescue_chain_periodic_columns(uint64_t *out /* [29][8] host */) {
+    if (!out) return fail(CSTARK_ERR_INVALID_ARG, "null argument");
+    std::vector<uint64_t> cols;
+    cs::host::rescue_chain_periodic_columns(cols);
+    memcpy(out, cols.data(), cols.size() * 8);
+    return CSTARK_OK;
+}
+// RescueProver::build_trace (benches/rescue.rs:277-322): 14 x 8 * chain_length
+int cstark_rescue_chain_build_trace(cstark_ctx *c, const uint64_t seed[7], uint32_t chain_length, uint64_t *d_trace) {
+    if (!c || !seed || !d_trace) return fail(CSTARK_ERR_INVALID_ARG, "cstark_rescue_chain_build_trace: null argument");
+    if (chain_length < 8 || (chain_length & (chain_length - 1)) || chain_length > (1u << 21)) // benches/rescue.rs:34-37: a power of two
+        return fail(CSTARK_ERR_INVALID_ARG, "chain length must be a power of two, 8 .. 2^21 (64 .. 2^24 trace rows)");
+    for (int i = 0; i < 7; i++) if (seed[i] >= cs::host::P) return fail(CSTARK_ERR_INVALID_ARG, "seed is not a field element");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(cs::launch_rescue_chain_trace(seed, chain_length, d_trace, c->stream));
+    return CSTARK_OK;
+}
 int cstark_air_evaluate_transitions(cstark_ctx *c, int air, const uint64_t *d_lde, uint64_t *d_out, uint32_t merkle_depth, uint32_t log_n,
                                     uint32_t log_blowup, uint32_t k0, uint32_t nk) {
     if (!c || !d_lde || !d_out || nk == 0) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_evaluate_transitions: bad argument");
@@ -1197,6 +1249,12 @@ int cstark_air_evaluate_transitions(cstark_ctx *c, int air, const uint64_t *d_ld
     HIP_TRY(hipSetDevice(c->device));
     if (air == CSTARK_AIR_RANGE) {
         HIP_TRY(cs::launch_eval_transitions_range(d_lde, d_out, log_n, nk, c->stream));
+        return CSTARK_OK;
+    }
+    if (air == CSTARK_AIR_RESCUE_CHAIN) {
+        const PeriodicTable *pt;
+        RC_TRY(rescue_periodic(c, log_n, log_blowup, &pt));
+        HIP_TRY(cs::launch_eval_transitions_rescue(d_lde, pt->tab, d_out, log_n, k0, nk, c->stream));
         return CSTARK_OK;
     }
     if (air != CSTARK_AIR_MERKLE_UPDATE) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");

@@ -95,6 +95,9 @@ hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t
 hipError_t launch_schnorr_final_split(const AirCombineParams &p, const uint64_t *d_coefs_tx_layout, uint64_t *d_out, int coset, hipStream_t stream);
 hipError_t launch_schnorr_final_hi(const AirCombineParams &p, const uint64_t *d_odd, const uint64_t *d_direct, uint64_t *d_hi, uint64_t half_m, hipStream_t stream);
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream);
+// RescueAir (benches/rescue.rs): ptab [b][29][8]
+hipError_t launch_eval_transitions_rescue(const uint64_t *lde, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0, unsigned nk,
+                                          hipStream_t stream);
 
 hipError_t launch_eval_transitions(const CeParams &p, unsigned nk, hipStream_t stream);
 constexpr int CE_NUM_PARTS = 9; // launches of the fused evaluation: rounds, dbl0, add0, dbl1, add1, final, lin_a, lin_b, lin_c

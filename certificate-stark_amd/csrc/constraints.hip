@@ -2468,6 +2468,38 @@ hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, 
     hipLaunchKernelGGL(k_merkle_fused<true>, grid, dim3(FNT), 0, stream, p, ptab);
     return hipGetLastError();
 }
+// RescueAir::evaluate_transition, benches/rescue.rs:200-222 (+ enforce_hash_copy :254-264): the round gadget under the cycle mask, the
+// copy of the rate half / reset of the capacity half under its complement.  ptab: [b][29][8] (mask, 28 round constants)
+__global__ __launch_bounds__(NT) void k_eval_transitions_rescue(const fp *lde, const fp *ptab, fp *out, unsigned log_n, unsigned k0) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = blockIdx.x * (size_t)NT + threadIdx.x;
+    if (j >= n) return;
+    const unsigned kk = blockIdx.y;
+    const fp *base = lde + (size_t)kk * 14 * n;
+    Frame f;
+    f.n = n;
+    f.cur_p = base + j;
+    f.next_p = base + ((j + 1) & (n - 1));
+    f.per_p = ptab + (size_t)(k0 + kk) * 29 * 8 + (j & 7);
+    f.pcycle = 8;
+    AccAll acc{out + (size_t)kk * 14 * n + j, n};
+    const fp hash_flag = f.pv(0), copy_flag = c_not(hash_flag);
+    Frame fr = f; // the gadget reads the round constants at P_ARK + i relative to per_p: a view shifted by (1 - P_ARK) columns
+    fr.per_p = f.per_p - (size_t)(P_ARK - 1) * 8;
+    enforce_round(acc, fr, 0, 0, hash_flag, 0, 0, false);
+    for (int i = 0; i < 7; i++) {
+        acc.add(i, copy_flag, fp_sub(f.cur(i), f.next(i)));
+        acc.add(7 + i, copy_flag, f.next(7 + i));
+    }
+}
+hipError_t launch_eval_transitions_rescue(const uint64_t *lde, const uint64_t *ptab, uint64_t *out, unsigned log_n, unsigned k0, unsigned nk,
+                                          hipStream_t stream) {
+    const size_t n = (size_t)1 << log_n;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)nk * 14 * n * sizeof(fp), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_eval_transitions_rescue, dim3((unsigned)((n + NT - 1) / NT), nk), dim3(NT), 0, stream, lde, ptab, out, log_n, k0);
+    return hipGetLastError();
+}
 hipError_t launch_eval_transitions_range(const uint64_t *lde, uint64_t *out, unsigned log_n, unsigned nk, hipStream_t stream) {
     const size_t n = (size_t)1 << log_n;
     hipLaunchKernelGGL(k_eval_transitions_range, dim3((unsigned)((n + 63) / 64), nk), dim3(64), 0, stream, lde, out, log_n);

@@ -244,9 +244,10 @@ struct GatherList {
         return hipGetLastError();
     }
 };
-__global__ void k_gather_pub(const uint64_t *__restrict__ trace, size_t n, uint64_t *__restrict__ out) {
+// first / last row of seven registers from reg0: 58 = PREV_TREE_ROOT_POS (src/prover.rs:106-129), 0 = the hash chain (benches/rescue.rs:331-354)
+__global__ void k_gather_pub(const uint64_t *__restrict__ trace, size_t n, uint64_t *__restrict__ out, uint32_t reg0) {
     const uint32_t t = threadIdx.x;
-    if (t < 14) out[t] = trace[(size_t)(58 + (t % 7)) * n + (t < 7 ? 0 : n - 1)]; // PREV_TREE_ROOT_POS, src/prover.rs:106-129
+    if (t < 14) out[t] = trace[(size_t)(reg0 + (t % 7)) * n + (t < 7 ? 0 : n - 1)];
 }
 
 template <class T>
@@ -308,6 +309,7 @@ struct AirJob {
     uint32_t k0 = 0, nk = 8;        // sharded proofs (blowup 8): the LDE cosets this GPU owns
     bool sharded = false;
     uint32_t log_b = 3;             // log2 of the blowup factor; the trace table holds its cosets in block order when log_b > log_ce
+    uint64_t seed[7] = {};          // RescueAir
     uint64_t number = 0;            // RangeProofAir
     const uint64_t *bits = nullptr; // RangeProofAir, long form: the n/64 words of the value (host)
 };
@@ -796,9 +798,9 @@ bool shard_split(uint32_t nk) {
 uint32_t shard_rows(uint32_t nk) { return shard_split(nk) ? nk / 2 + 4 : nk; }
 
 // first / last row of registers 58..64 -> job.pub (TransactionProver::get_pub_inputs src/prover.rs:106-129; MerkleProver alike)
-int gather_roots(cstark_ctx *c, ProveArena *a, AirJob &job) {
+int gather_roots(cstark_ctx *c, ProveArena *a, AirJob &job, uint32_t reg0 = 58) {
     const size_t n = (size_t)1 << job.log_n;
-    k_gather_pub<<<1, 64, 0, c->stream>>>(a->trace, n, (uint64_t *)a->d_open);
+    k_gather_pub<<<1, 64, 0, c->stream>>>(a->trace, n, (uint64_t *)a->d_open, reg0);
     HIP_TRY(hipGetLastError());
     job.pub.assign(14, 0);
     HIP_TRY(hipMemcpyAsync(job.pub.data(), a->d_open, 14 * 8, hipMemcpyDeviceToHost, c->stream)); // complete at the commitment sync
@@ -825,7 +827,7 @@ int tx_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
     // second batch waits for, into pinned memory; collected after the commitment sync
     const size_t n = (size_t)1 << job.log_n;
     if (!a->h_pub) HIP_TRY(hipHostMalloc((void **)&a->h_pub, 14 * 8, hipHostMallocDefault));
-    k_gather_pub<<<1, 64, 0, c->side>>>(a->trace, n, (uint64_t *)a->d_open);
+    k_gather_pub<<<1, 64, 0, c->side>>>(a->trace, n, (uint64_t *)a->d_open, 58u);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(a->h_pub, a->d_open, 14 * 8, hipMemcpyDeviceToHost, c->side));
     HIP_TRY(hipEventRecord(c->ev_join, c->side));
@@ -894,6 +896,20 @@ int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta,
     job.evals_ready = true;
     const uint64_t vals[2] = {0, job.number}; // get_assertions, src/range/air.rs:79-86
     return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, out, job.log_n, log_ce, 0, ce);
+}
+// ---- RescueAir (benches/rescue.rs:145-356) ---------------------------------------------------------------------------------------------
+int rescue_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
+    RC_TRY(cstark_rescue_chain_build_trace(c, job.seed, job.item, a->trace));
+    return gather_roots(c, a, job, 0); // get_pub_inputs :331-354: seed and result are the first / last row of registers 0..6
+}
+int rescue_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta, const uint64_t *tb, const uint64_t *ba, const uint64_t *bb, uint64_t *out) {
+    const size_t n = (size_t)1 << job.log_n;
+    const uint32_t log_ce = job.log_ce, ce = 1u << log_ce;
+    uint64_t *evals;
+    RC_TRY(arena_extra(c, a, 0, &evals, (size_t)ce * job.n_constraints * n * 8));
+    if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RESCUE_CHAIN, a->lde, evals, 0, job.log_n, log_ce, 0, ce));
+    job.evals_ready = true;
+    return cstark_air_combine(c, CSTARK_AIR_RESCUE_CHAIN, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, out, job.log_n, log_ce, 0, ce);
 }
 // ---- SchnorrAir (src/schnorr) ---------------------------------------------------------------------------------------------------------
 // the public-input columns (src/schnorr/air.rs:228-290; not committed: both sides derive them from the messages) and the sequence
@@ -1368,6 +1384,25 @@ int cstark_tx_shard_finish(cstark_ctx *c, const uint64_t *d_rows, uint8_t *proof
     const int rc = phase_open(c, c->arena, *R, d_rows, proof, capacity, proof_len);
     if (rc == CSTARK_OK) { proof_run_free(c->arena->run); c->arena->run = nullptr; }
     return rc;
+}
+
+// RescueExample::prove (benches/rescue.rs:66-86): a chain of `chain_length` Rescue hashes from `seed` (7 elements, memory form)
+int cstark_rescue_prove(cstark_ctx *c, const cstark_options *opt, const uint64_t seed[7], uint32_t chain_length, uint8_t *proof, size_t capacity,
+                        size_t *proof_len) {
+    if (!c || !opt || !seed || !proof_len) return fail(CSTARK_ERR_INVALID_ARG, "cstark_rescue_prove: null argument");
+    if (chain_length < 8 || (chain_length & (chain_length - 1)) || chain_length > (1u << 21))
+        return fail(CSTARK_ERR_INVALID_ARG, "chain length must be a power of two, 8 .. 2^21 (benches/rescue.rs:34-37)");
+    for (int i = 0; i < 7; i++) if (seed[i] >= host::P) return fail(CSTARK_ERR_INVALID_ARG, "seed is not a field element");
+    AirJob job;
+    job.air = CSTARK_AIR_RESCUE_CHAIN;
+    host::AirShape s;
+    host::air_shape(CSTARK_AIR_RESCUE_CHAIN, s, 0);
+    job.log_n = 3 + ceil_log2(chain_length); job.item = chain_length;
+    memcpy(job.seed, seed, sizeof job.seed);
+    job.build = rescue_build; job.combine = rescue_combine;
+    job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
+    if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
+    return prove_core(c, opt, job, proof, capacity, proof_len);
 }
 
 // RangeProofAir over 2^log_n rows (synthetic long form; log_n = 6 with a one-word value is cstark_air_prove(CSTARK_AIR_RANGE))

@@ -26,6 +26,8 @@ hipError_t launch_trace_gen_split(const TxWitnessDev &w, uint64_t *d_trace, hipS
 // standalone sub-AIR traces
 hipError_t launch_merkle_trace(const TxWitnessDev &w, uint64_t *d_trace, hipStream_t stream); // 65 x 512*n_tx
 hipError_t launch_range_trace(uint64_t number_canonical, uint64_t *d_trace, hipStream_t stream); // 2 x 64
+// RescueProver::build_trace (benches/rescue.rs:277-322): 14 x 8*iterations, seed = 7 elements in memory form; iterations a multiple of 8
+hipError_t launch_rescue_chain_trace(const uint64_t seed[7], unsigned iterations, uint64_t *d_trace, hipStream_t stream);
 // the same accumulator over 2^log_n rows of an (n-1)-bit integer (d_words: n/64 little-endian words; d_prefix: n/64 words scratch)
 hipError_t launch_range_trace_bits(const uint64_t *d_words, uint64_t *d_prefix, uint64_t *d_trace, unsigned log_n, hipStream_t stream);
 // SchnorrProver::build_trace (src/schnorr/prover.rs:40-67): 56 x 512*n; the witness view holds message[0..12] in s_old,

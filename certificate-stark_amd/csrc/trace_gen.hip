@@ -678,6 +678,40 @@ hipError_t launch_schnorr_aux_columns(const TxWitnessDev &w, fp *d_out, hipStrea
     return hipGetLastError();
 }
 
+// RescueProver::build_trace (benches/rescue.rs:277-322): ONE chain -- 8 rows per link: seven Rescue rounds, then the capacity half reset
+// to zero -- is a single sequential recurrence: one wave, lane e < 14 = state element e, 64 rows staged in LDS per coalesced flush.
+// n = 8 * iterations rows, a multiple of 64.
+struct RescueSeed { fp s[7]; };
+__global__ __launch_bounds__(64) void k_trace_rescue_chain(RescueSeed seed, fp *__restrict__ trace, size_t n) {
+    __shared__ fp tile[64][15];
+    __shared__ fp xch[14];
+    const int lane = threadIdx.x, e = lane < 14 ? lane : 0;
+    const bool active = lane < 14;
+    fp mrow[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) mrow[j] = c_mds[e * 14 + j];
+    fp v = (active && lane < 7) ? seed.s[lane] : 0;
+    if (active) tile[0][e] = v;
+    for (size_t step = 0; step + 1 < n; step++) {
+        const int cyc = (int)(step & 7);
+        if (cyc < 7) v = rescue_round_lane(v, xch, mrow, e, cyc, active); // rescue::apply_round(state, step)
+        else if (lane >= 7) v = 0;
+        const int r = (int)((step + 1) & 63);
+        if (active) tile[r][e] = v;
+        if (r == 63) {
+            __syncthreads();
+            for (int c = 0; c < 14; c++) trace[(size_t)c * n + (step + 1 - 63) + lane] = tile[lane][c];
+            __syncthreads();
+        }
+    }
+}
+hipError_t launch_rescue_chain_trace(const uint64_t seed[7], unsigned iterations, fp *d_trace, hipStream_t stream) {
+    RescueSeed s;
+    for (int i = 0; i < 7; i++) s.s[i] = seed[i];
+    hipLaunchKernelGGL(k_trace_rescue_chain, dim3(1), dim3(64), 0, stream, s, d_trace, (size_t)iterations * 8);
+    return hipGetLastError();
+}
+
 hipError_t launch_merkle_trace(const TxWitnessDev &w, fp *d_trace, hipStream_t stream) {
     const size_t n = (size_t)w.n_tx * MERKLE_LEN;
     hipLaunchKernelGGL((k_trace_merkle<true, 64>), dim3(w.n_tx), dim3(64), 0, stream, w, d_trace, n);

@@ -11,6 +11,8 @@ Names and argument meaning follow the reference so tests read like its own:
 All device work goes through the C ABI (include/cstark.h); there is no CPU path here.
 """
 import numpy as np
+
+_P = 2**62 + 2**56 + 2**55 + 1  # the prime of f63::BaseElement
 import torch
 
 from . import _lib
@@ -257,6 +259,22 @@ class SchnorrExample(_ResidentWitness):
         """The witness is uploaded by the first call and stays resident (_ResidentWitness: read-only on the host until invalidate())."""
         self._ensure_resident(lambda: self.backend.upload_schnorr_witness(self.messages, self.sig_rx, self.sig_s))
         return self.backend.air_prove(Backend.AIR_SCHNORR, self.options)
+
+
+class RescueExample:
+    """RescueExample of benches/rescue.rs:25-102: a chain of `chain_length` Rescue hashes from the bench's seed 42..48 (held in memory
+    form, R = 2^64).  The public inputs -- seed and result -- are read from the trace inside the prover, as get_pub_inputs does."""
+
+    def __init__(self, chain_length, options, backend=None, seed=None):
+        if chain_length & (chain_length - 1) or chain_length < 8:
+            raise ValueError("chain length must a power of 2")   # benches/rescue.rs:34-37 (at least 8 links: 64 trace rows)
+        self.options, self.chain_length = options, int(chain_length)
+        self.backend = backend or Backend()
+        r2 = pow(2, 64, _P)
+        self.seed = np.array([(v * r2) % _P for v in range(42, 49)], np.uint64) if seed is None else np.ascontiguousarray(seed, np.uint64)
+
+    def prove(self):
+        return self.backend.rescue_prove(self.options, self.seed, self.chain_length)
 
 
 class RangeProofExample:

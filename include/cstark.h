@@ -49,7 +49,7 @@ typedef enum cstark_air_id {
     CSTARK_AIR_MERKLE_UPDATE = 1,    /* MerkleAir, src/merkle/update/air.rs:36-177; 65 registers, 512 rows / tx */
     CSTARK_AIR_SCHNORR = 2,          /* SchnorrAir, src/schnorr/air.rs:41-300; 56 registers, 512 rows / sig */
     CSTARK_AIR_RANGE = 3,            /* RangeProofAir, src/range/air.rs:23-105; 2 registers, 64 rows */
-    CSTARK_AIR_RESCUE_CHAIN = 4      /* benches/rescue.rs:128-360; 14 registers, 8 rows / link */
+    CSTARK_AIR_RESCUE_CHAIN = 4      /* RescueAir, benches/rescue.rs:128-360; 14 registers, 8 rows / link (cstark_rescue_prove) */
 } cstark_air_id;
 
 #define CSTARK_TX_TRACE_WIDTH 94      /* src/constants.rs:35 */
@@ -267,6 +267,15 @@ int cstark_tx_prove(cstark_ctx *ctx, const cstark_options *opt, uint8_t *proof, 
  * holds the Merkle depth / the number of signatures / 0.  Use cstark_tx_proof_size_bound(rows / 1024 rounded up, opt) * 2 as capacity. */
 int cstark_air_prove(cstark_ctx *ctx, int air, const cstark_options *opt, uint64_t number, uint8_t *proof, size_t capacity, size_t *proof_len);
 size_t cstark_tx_proof_size_bound(uint32_t n_tx, const cstark_options *opt);
+/* RescueExample::prove (benches/rescue.rs:66-86, options :370-378: blowup 4): a chain of chain_length Rescue hashes from `seed` (7
+ * elements, memory form; the bench uses 42..48); chain_length a power of two, 8 .. 2^21; the trace is 14 x 8 chain_length.  Same proof
+ * layout (4 composition columns; the header's 4th word holds chain_length); public inputs = seed and result, read from the trace as
+ * RescueProver::get_pub_inputs does (:331-354).  cstark_tx_proof_size_bound(chain_length / 128 rounded up, opt) is a sufficient capacity. */
+int cstark_rescue_prove(cstark_ctx *ctx, const cstark_options *opt, const uint64_t seed[7], uint32_t chain_length, uint8_t *proof, size_t capacity,
+                        size_t *proof_len);
+/* RescueProver::build_trace (benches/rescue.rs:277-322) and the AIR's 29 periodic columns [29][8] (host; :245-249) */
+int cstark_rescue_chain_build_trace(cstark_ctx *ctx, const uint64_t seed[7], uint32_t chain_length, uint64_t *d_trace);
+int cstark_rescue_chain_periodic_columns(uint64_t *out);
 
 /* ---- one proof across several GPUs, sharded by LDE coset (the reference's only parallel axis is the rayon loop
  * over trace fragments, src/prover.rs:50-52) -------------------------------------------------------------------------------------

@@ -94,6 +94,29 @@ class RangeJob:
         return O.air_combine(O.range_desc(V.from_mont(self.number)), lde, self.ev, ta, tb, ba, bb, 1)
 
 
+class RescueJob:
+    """RescueAir, the hash-chain AIR of benches/rescue.rs:145-356 (RescueProver :266-356; prove :66-86; options :370-378: blowup 4)"""
+    air, width, ce, nc, na = 4, 14, 4, 14, 14
+
+    def __init__(self, seed, chain_length):
+        self.seed, self.item = np.ascontiguousarray(seed, np.uint64), int(chain_length)
+
+    def build(self):
+        return O.rescue_chain_build_trace(self.seed, self.item)
+
+    def public(self, trace):  # seed then result: the first / last row of registers 0..6 (get_pub_inputs :331-354)
+        n = trace.shape[1]
+        return [int(trace[i, 0]) for i in range(7)] + [int(trace[i, n - 1]) for i in range(7)], b""
+
+    def combine(self, trace, lde, ta, tb, ba, bb, k0=0):
+        assert k0 == 0 and lde.shape[0] == 4
+        log_n = trace.shape[1].bit_length() - 1
+        if not hasattr(self, "ev"):
+            ptab = O.periodic_table(O.rescue_chain_periodic_columns(), log_n, 2)
+            self.ev = O.air_evaluate_transitions(O.AIR_RESCUE_CHAIN, lde, ptab, 14)
+        return O.air_combine(O.rescue_chain_desc(trace), lde, self.ev, ta, tb, ba, bb, 2)
+
+
 class SchnorrJob:
     """SchnorrAir (src/schnorr/air.rs:41-300; SchnorrProver src/schnorr/prover.rs:21-90; prove: src/schnorr/mod.rs:143-172)"""
     air, width, ce, nc, na = 2, 56, 8, 56, 61
@@ -334,13 +357,16 @@ def prove_air(air, witness, options=(42, 8, 0, 0, 0, 4, 256), log_n=6):
     O.AIR_MERKLE   witness = TxWitness          (src/merkle/update/mod.rs:81-106)
     O.AIR_SCHNORR  witness = SchnorrWitness     (src/schnorr/mod.rs:143-172)
     O.AIR_RANGE    witness = field element in memory form (src/range/mod.rs:75-100), or -- the synthetic long accumulator -- the
-                   n / 64 little-endian words of the value together with log_n."""
+                   n / 64 little-endian words of the value together with log_n.
+    O.AIR_RESCUE_CHAIN  witness = (seed: 7 elements in memory form, chain_length)   (benches/rescue.rs:66-86)"""
     if air == O.AIR_STATE_TRANSITION:
         return prove(witness, options)
     if air == O.AIR_MERKLE:
         return _prove_job(MerkleJob(witness), options)
     if air == O.AIR_SCHNORR:
         return _prove_job(SchnorrJob(witness), options)
+    if air == O.AIR_RESCUE_CHAIN:
+        return _prove_job(RescueJob(*witness), options)
     if air == O.AIR_RANGE:
         if isinstance(witness, (int, np.integer)):
             return _prove_job(RangeJob(number=int(witness)), options)

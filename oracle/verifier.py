@@ -226,7 +226,7 @@ def parse(proof):
         raise VerifierError("bad magic")
     d = {"version": r.u32(), "air": r.u32(), "width": r.u32(), "log_n": r.u32(), "depth": r.u32()}
     d["options"] = [r.u32() for _ in range(7)]
-    shapes = {0: (94, 8), 1: (65, 4), 2: (56, 8), 3: (2, 2)}  # air id -> (trace width, composition columns)
+    shapes = {0: (94, 8), 1: (65, 4), 2: (56, 8), 3: (2, 2), 4: (14, 4)}  # air id -> (trace width, composition columns)
     if d["version"] != 1 or d["air"] not in shapes or d["width"] != shapes[d["air"]][0]:
         raise VerifierError("unsupported proof header")
     W, ce = shapes[d["air"]]
@@ -465,6 +465,41 @@ class _RangeAir(_GenericAir):
         return _merge_e(self, log_n, z, res, ta, tb, ba, bb, cur, assertions, m)
 
 
+class _RescueAir(_GenericAir):
+    """RescueAir of benches/rescue.rs:145-250: 14 x degree (3; one cycle of 8), seed / result assertions on registers 0..6"""
+    air, width, ce = 4, 14, 4
+
+    def __init__(self, d, seed, result):
+        self.pub = [from_mont(v) for v in list(seed) + list(result)]
+        self.pub_bytes = b""
+        self.base, self.cycles, self.cycle_len, self.nc, self.na = [3] * 14, [1] * 14, 8, 14, 14
+
+    def _assertions(self, n, wrap):
+        return [(a % 7, (n - 1) if a >= 7 else 0, 0, wrap(self.pub[a])) for a in range(14)]  # get_assertions :224-243
+
+    def ood_combined(self, d, log_n, z, ta, tb, ba, bb):
+        n = 1 << log_n
+        pcols = O.interpolate_columns(O.rescue_chain_periodic_columns())
+        pv = np.array([to_mont(v) for v in _poly_at(pcols, pow(z, n // 8, P))], np.uint64)
+        cur, nxt = np.ascontiguousarray(d["ood_cur"]), np.ascontiguousarray(d["ood_next"])
+        res = np.zeros(16, np.uint64)
+        O.lib().cso_rescue_chain_evaluate_transition(O._p(cur), O._p(nxt), O._p(pv), O._p(res))
+        return self._merge(log_n, z, [from_mont(v) for v in res[:14]], ta, tb, ba, bb, [from_mont(v) for v in cur], self._assertions(n, lambda v: v))
+
+    def ood_combined_ext(self, d, log_n, z, ta, tb, ba, bb, m):
+        n = 1 << log_n
+        pco = O.interpolate_columns(O.rescue_chain_periodic_columns())
+        per = _tuples(O.evaluate_polys_at_ext(pco, e_mont(e_pow(z, n // 8))).reshape(-1), m)
+        cur, nxt = _tuples(d["ood_cur"], m), _tuples(d["ood_next"], m)
+
+        def evalfn(arrs):
+            res = np.zeros(16, np.uint64)
+            O.lib().cso_rescue_chain_evaluate_transition(O._p(arrs[0]), O._p(arrs[1]), O._p(arrs[2]), O._p(res))
+            return res
+        res = _constraints_over_e(evalfn, [cur, nxt, per], 14, m)
+        return _merge_e(self, log_n, z, res, ta, tb, ba, bb, cur, self._assertions(n, lambda v: e_base(v, m)), m)
+
+
 class _SchnorrAir(_GenericAir):
     air, width, ce = 2, 56, 8
 
@@ -553,6 +588,16 @@ def verify_range(proof, number, options=None):
     if d["options"][4] in (1, 2):
         return _verify_ext(d, _RangeAir(d, number), options)
     return _verify(d, _RangeAir(d, number), options)
+
+
+def verify_rescue(proof, seed, result, options=None):
+    """RescueAir (benches/rescue.rs:88-94); seed / result: 7 elements each, memory form."""
+    d = parse(proof)
+    if d["air"] != 4:
+        raise VerifierError("not a RescueAir proof")
+    if d["options"][4] in (1, 2):
+        return _verify_ext(d, _RescueAir(d, seed, result), options)
+    return _verify(d, _RescueAir(d, seed, result), options)
 
 
 def verify_schnorr(proof, witness, options=None):

@@ -113,7 +113,12 @@ def test_small_air_host_descriptions_match_oracle(oracle):
             b, c = C.c_uint32(), C.c_uint32()
             assert lib.cstark_air_constraint_degree(C.c_int(2), C.c_uint32(n_sig), C.c_uint32(i), C.byref(b), C.byref(c)) == 0
             assert (b.value, c.value) == (int(sb[i]), int(sc[i]))
-    assert lib.cstark_air_shape(C.c_int(4), C.c_uint32(1), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == -5   # rescue chain: CPU only
+    assert lib.cstark_air_shape(C.c_int(4), C.c_uint32(1), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == 0    # RescueAir, benches/rescue.rs
+    assert (w.value, nc.value, na.value, lce.value) == (14, 14, 14, 2)
+    out = np.zeros((29, 8), np.uint64)
+    assert lib.cstark_rescue_chain_periodic_columns(out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+    assert (out == oracle.rescue_chain_periodic_columns()).all()
+    assert lib.cstark_air_shape(C.c_int(5), C.c_uint32(1), C.byref(w), C.byref(nc), C.byref(na), C.byref(lce)) == -5   # no such AIR
     out = np.zeros((36, 512), np.uint64)
     assert lib.cstark_schnorr_mask_columns(out.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
     assert (out == oracle.schnorr_mask_columns()).all()
