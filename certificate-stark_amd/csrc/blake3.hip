@@ -7,24 +7,13 @@
 // read 64 consecutive rows of the same column, i.e. one contiguous 512-byte line per load.
 #include "blake3.h"
 #include "fp.cuh"
+#include "blake3_quad.cuh"
 #include "../../include/cstark_conventions.h"
 #include <hip/hip_runtime.h>
 #include <string.h>
 
 namespace cs {
 namespace {
-
-constexpr uint32_t IV0 = 0x6A09E667u, IV1 = 0xBB67AE85u, IV2 = 0x3C6EF372u, IV3 = 0xA54FF53Au, IV4 = 0x510E527Fu, IV5 = 0x9B05688Cu,
-                   IV6 = 0x1F83D9ABu, IV7 = 0x5BE0CD19u;
-enum : uint32_t { CHUNK_START = 1, CHUNK_END = 2, PARENT = 4, ROOT = 8 };
-
-__device__ __forceinline__ uint32_t rotr(uint32_t x, int r) { return __funnelshift_r(x, x, r); } // v_alignbit_b32
-
-#define B3_G(a, b, c, d, mx, my)            \
-    a = a + b + (mx); d = rotr(d ^ a, 16);  \
-    c = c + d;        b = rotr(b ^ c, 12);  \
-    a = a + b + (my); d = rotr(d ^ a, 8);   \
-    c = c + d;        b = rotr(b ^ c, 7);
 
 // message word indices for each of the 7 rounds (the BLAKE3 permutation applied repeatedly)
 #define B3_ROUND(m, i0, i1, i2, i3, i4, i5, i6, i7, i8, i9, i10, i11, i12, i13, i14, i15) \
@@ -187,44 +176,6 @@ __global__ __launch_bounds__(1024) void k_merkle_top(uint8_t *__restrict__ nodes
 // diagonal step another after rotating rows 1..3 by 1..3 lanes (DPP quad_perm, no LDS); 7 x (2 G + 6 moves) = ~210 dependent
 // instructions.  A workgroup of 256 quads takes 512 nodes and reduces them through nine levels in LDS (every level also goes to the
 // node array); a second launch of one workgroup finishes the tree.
-__constant__ uint32_t c_quad_sched[4][7] = { // lane c, round r: bytes = message word indices of (column mx, my, diagonal mx, my)
-#define QS(r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15, c) \
-    ((uint32_t)(c == 0 ? r0 : c == 1 ? r2 : c == 2 ? r4 : r6) | (uint32_t)(c == 0 ? r1 : c == 1 ? r3 : c == 2 ? r5 : r7) << 8 | \
-     (uint32_t)(c == 0 ? r8 : c == 1 ? r10 : c == 2 ? r12 : r14) << 16 | (uint32_t)(c == 0 ? r9 : c == 1 ? r11 : c == 2 ? r13 : r15) << 24)
-#define QROW(c)                                                                                                                       \
-    {QS(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, c), QS(2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8, c),         \
-     QS(3, 4, 10, 12, 13, 2, 7, 14, 6, 5, 9, 0, 11, 15, 8, 1, c), QS(10, 7, 12, 9, 14, 3, 13, 15, 4, 0, 11, 2, 5, 8, 1, 6, c),         \
-     QS(12, 13, 9, 11, 15, 10, 14, 8, 7, 2, 5, 3, 0, 1, 6, 4, c), QS(9, 14, 11, 5, 8, 12, 15, 1, 13, 3, 0, 10, 2, 6, 4, 7, c),         \
-     QS(11, 15, 5, 0, 1, 9, 8, 6, 14, 10, 2, 12, 3, 4, 7, 13, c)}
-    QROW(0), QROW(1), QROW(2), QROW(3)
-#undef QROW
-#undef QS
-};
-template <int CTRL>
-__device__ __forceinline__ uint32_t quad_perm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
-// Blake3 of the single-block message m[0..15] (LDS; block_len bytes, zero-padded) by the four lanes of a quad: lane c returns words c
-// and 4 + c of the digest
-__device__ __forceinline__ void quad_hash_block(const uint32_t *m, const uint32_t (&sched)[7], unsigned c, uint32_t block_len, uint32_t &lo, uint32_t &hi) {
-    uint32_t w[28];
-#pragma unroll
-    for (int r = 0; r < 7; r++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) w[4 * r + q] = m[(sched[r] >> (8 * q)) & 15];
-    const uint32_t iv_lo = c == 0 ? IV0 : c == 1 ? IV1 : c == 2 ? IV2 : IV3, iv_hi = c == 0 ? IV4 : c == 1 ? IV5 : c == 2 ? IV6 : IV7;
-    uint32_t a = iv_lo, b = iv_hi, cc = iv_lo, d = c == 2 ? block_len : c == 3 ? (uint32_t)(CHUNK_START | CHUNK_END | ROOT) : 0u;
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-        B3_G(a, b, cc, d, w[4 * r], w[4 * r + 1])
-        b = quad_perm<0x39>(b); cc = quad_perm<0x4E>(cc); d = quad_perm<0x93>(d);  // lane c <- lanes c + 1, c + 2, c + 3: the diagonals
-        B3_G(a, b, cc, d, w[4 * r + 2], w[4 * r + 3])
-        b = quad_perm<0x93>(b); cc = quad_perm<0x4E>(cc); d = quad_perm<0x39>(d);  // and back to columns
-    }
-    lo = a ^ cc;
-    hi = b ^ d;
-}
-__device__ __forceinline__ void quad_hash64(const uint32_t *m, const uint32_t (&sched)[7], unsigned c, uint32_t &lo, uint32_t &hi) {
-    quad_hash_block(m, sched, c, 64u, lo, hi);
-}
 // The public coin of a FRI layer on the device (prove.hip's Coin::reseed + Coin::draw for the Blake3 coin, same bytes):
 //   seed <- Blake3(seed || root);  alpha = the first of Blake3(seed || le64(counter))[0..8), counter = FIRST_COUNTER, ..., that is a field
 //   element (CSTARK_CONV_COIN_REJECT_ABOVE_P; otherwise the first one, reduced), in memory form.

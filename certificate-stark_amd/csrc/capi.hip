@@ -661,6 +661,24 @@ int evaluate_ood_frames(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width,
     return CSTARK_OK;
 }
 
+// internal (ctx.h): the same frame with the points and the values staying on the device (the device-side channel): d_pts = z, z w, z^b;
+// d_out = T(z)[width] | T(z w)[width] | H_i(z^b)[n_comp]
+int ood_frames_dev(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, const uint64_t *d_ccoef, uint32_t n_comp, uint32_t log_n, const uint64_t *d_pts,
+                   uint64_t *d_out) {
+    if (!c || !d_coeffs || !d_ccoef || !d_pts || !d_out || width == 0 || n_comp == 0) return fail(CSTARK_ERR_INVALID_ARG, "ood_frames_dev: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t scr_t = cs::poly_eval_scratch_words(width, log_n, 2), scr_c = cs::poly_eval_scratch_words(n_comp, log_n, 1);
+    const size_t need = (scr_t + scr_c) * 8;
+    if (need > c->desc_bytes) {
+        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); c->desc_buf = nullptr; c->desc_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->desc_buf, need));
+        c->desc_bytes = need;
+    }
+    uint64_t *d_scr = (uint64_t *)c->desc_buf;
+    HIP_TRY(cs::poly_eval(d_coeffs, width, log_n, d_pts, 2, d_out, d_scr, c->stream));
+    HIP_TRY(cs::poly_eval(d_ccoef, n_comp, log_n, d_pts + 2, 1, d_out + 2 * (size_t)width, d_scr + scr_t, c->stream));
+    return CSTARK_OK;
+}
 // internal (ctx.h): the first nk cosets only, d_out = [m][nk][n]
 int deep_composition_ext_cosets(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
                                 const uint64_t *z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
@@ -811,10 +829,23 @@ int tx_build_trace_split(cstark_ctx *c, uint64_t *d_trace) {
 // m coefficient sets over the same frame (the components of an extension-field proof): the constraint values are computed once.
 // The m coefficient sets of a proof into the context's device block (coefficients, then the per-proof tables of the Rescue windows):
 // the caller's struct may be transient, so it is copied into a pinned staging block and uploaded from there without waiting.
-static int upload_coeffs(cstark_ctx *c, const cstark_tx_coeffs *coeffs, uint32_t m, cs::CeParams &p) {
+static constexpr size_t TX_COEF_WORDS = (size_t)cs::CE_MAX_SETS * cs::CE_COEF_WORDS;
+static int ensure_coef_buf(cstark_ctx *c) {
     static_assert(sizeof(cstark_tx_coeffs) == cs::CE_COEF_WORDS * 8, "coefficient block layout");
-    constexpr size_t COEF_WORDS = (size_t)cs::CE_MAX_SETS * cs::CE_COEF_WORDS;
-    if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, (COEF_WORDS + (size_t)cs::CE_MAX_SETS * cs::CE_RTAB_WORDS) * 8));
+    if (!c->coef_buf) HIP_TRY(hipMalloc((void **)&c->coef_buf, (TX_COEF_WORDS + (size_t)cs::CE_MAX_SETS * cs::CE_RTAB_WORDS) * 8));
+    return CSTARK_OK;
+}
+// internal (ctx.h): the context's device block of composition coefficients (cstark_tx_coeffs layout, one set): the device-side channel
+// draws them there, tx_evaluate_constraints_sets(coeffs = null) reads them
+int tx_coef_device_block(cstark_ctx *c, uint64_t **d_coef) {
+    HIP_TRY(hipSetDevice(c->device));
+    RC_TRY(ensure_coef_buf(c));
+    *d_coef = c->coef_buf;
+    return CSTARK_OK;
+}
+static int upload_coeffs(cstark_ctx *c, const cstark_tx_coeffs *coeffs, uint32_t m, cs::CeParams &p) {
+    constexpr size_t COEF_WORDS = TX_COEF_WORDS;
+    RC_TRY(ensure_coef_buf(c));
     if (!c->coef_stage) { // the event first: the staging block is only published once both exist
         if (!c->coef_ev) HIP_TRY(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc(&c->coef_stage, (size_t)cs::CE_MAX_SETS * sizeof(cstark_tx_coeffs), hipHostMallocDefault));
@@ -833,16 +864,20 @@ static int upload_coeffs(cstark_ctx *c, const cstark_tx_coeffs *coeffs, uint32_t
 // (internal: declared in ctx.h for the prover)
 int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
                                  uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
-                                 bool input_is_lde) {
-    if (!coeffs || !pub_inputs || !d_outs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null argument");
+                                 bool input_is_lde, const uint64_t *d_pub) {
+    // coeffs == null: one coefficient set already in the context's device block (tx_coef_device_block); d_pub != null: the 14 public
+    // inputs on the device instead of pub_inputs (both: the device-side channel of prove.hip)
+    if ((!coeffs && m != 1) || (!pub_inputs && !d_pub) || !d_outs) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null argument");
     if (m < 1 || m > (uint32_t)cs::CE_MAX_SETS) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: 1..3 coefficient sets");
     for (uint32_t q = 1; q < m; q++)
         if (!d_outs[q]) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_evaluate_constraints: null output");
     cs::CeParams p;
     RC_TRY(ce_params(c, d_lde, d_outs[0], merkle_depth, log_n, log_blowup, k0, nk, &p));
-    RC_TRY(upload_coeffs(c, coeffs, m, p));
+    if (coeffs) RC_TRY(upload_coeffs(c, coeffs, m, p));
+    else { RC_TRY(ensure_coef_buf(c)); p.coef = c->coef_buf; p.rtab = c->coef_buf + TX_COEF_WORDS; p.m = 1; }
     for (uint32_t q = 1; q < m; q++) p.out_ext[q - 1] = d_outs[q];
-    for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs[i];
+    for (int i = 0; i < 4; i++) p.pub[i] = pub_inputs ? pub_inputs[i] : 0;
+    p.pubd = d_pub;
     static const bool split_env = [] { const char *e = getenv("CSTARK_ROUNDS_SPLIT"); return !e || atoi(e) != 0; }(); // tuning / debugging
     hipEvent_t *pev = c->part_timing ? c->part_ev : nullptr;
     // input_is_lde: d_lde is the extension of columns of degree < n (the prover's own table), which the split evaluation relies on;

@@ -32,6 +32,7 @@ struct CeParams {
     uint64_t *out_ext[CE_MAX_SETS - 1]; // ... of sets 1, 2 (m > 1)
     uint32_t m;            // number of coefficient sets (0 reads as 1)
     uint64_t pub[4];       // initial_root[0..2], final_root[0..2]
+    const uint64_t *pubd;  // non-null: the 14 public inputs on the device (first / last row of registers 58..64) -- [0], [1], [7], [8] replace pub[]
     uint64_t w_last;       // w_n^(n-1)
     uint32_t adj_mod_n[5]; // degree adjustments reduced mod n (x^adj = shift^adj * w^(j*adj mod n))
     uint32_t badj_mod_n;

@@ -887,8 +887,8 @@ __global__ __launch_bounds__(256) void k_split_finish(CeParams p, const fp *__re
         fp t = fp_mul(total, divisor);
         // boundary constraints on registers 58, 59 at the first and last step (src/air.rs:175-184), as in the last linear group
         const fp *ba = p.coef + c * CE_COEF_WORDS + 230, *bb = ba + 4;
-        const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
-        const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
+        const fp first = fp_add(fp_mul(fp_sub(r58, p.pubd ? p.pubd[0] : p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pubd ? p.pubd[1] : p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
+        const fp last = fp_add(fp_mul(fp_sub(r58, p.pubd ? p.pubd[7] : p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pubd ? p.pubd[8] : p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
         t = fp_add(t, fp_add(fp_mul(first, bi0), fp_mul(last, bi1)));
         fp *o = (c == 0 ? p.out : p.out_ext[c == 0 ? 0 : c - 1]) + (size_t)k * n + j;
         *o = t;
@@ -947,8 +947,8 @@ __global__ __launch_bounds__(256) void k_split_finish_shard(CeParams p, const fp
         const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
         const fp *bi = p.binv + (size_t)k * 2 * n + j;
         const fp *ba = p.coef + 230, *bb = ba + 4;
-        const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
-        const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
+        const fp first = fp_add(fp_mul(fp_sub(r58, p.pubd ? p.pubd[0] : p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pubd ? p.pubd[1] : p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
+        const fp last = fp_add(fp_mul(fp_sub(r58, p.pubd ? p.pubd[7] : p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pubd ? p.pubd[8] : p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
         t = fp_add(t, fp_add(fp_mul(first, bi[0]), fp_mul(last, bi[n])));
     }
     out[(size_t)y * n + j] = t;
@@ -1790,8 +1790,8 @@ __global__ __launch_bounds__(FNT, part_waves(PART, M)) void k_eval_fused(CeParam
             const fp xb = fp_mul(cc[7], p.w[(j * p.badj_mod_n) & (n - 1)]);
             const fp *ba = p.coef + c * CE_COEF_WORDS + 230, *bb = ba + 4;
             const fp r58 = f.cur(58), r59 = f.cur(59);
-            const fp first = fp_add(fp_mul(fp_sub(r58, p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
-            const fp last = fp_add(fp_mul(fp_sub(r58, p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
+            const fp first = fp_add(fp_mul(fp_sub(r58, p.pubd ? p.pubd[0] : p.pub[0]), fp_add(ba[0], fp_mul(bb[0], xb))), fp_mul(fp_sub(r59, p.pubd ? p.pubd[1] : p.pub[1]), fp_add(ba[1], fp_mul(bb[1], xb))));
+            const fp last = fp_add(fp_mul(fp_sub(r58, p.pubd ? p.pubd[7] : p.pub[2]), fp_add(ba[2], fp_mul(bb[2], xb))), fp_mul(fp_sub(r59, p.pubd ? p.pubd[8] : p.pub[3]), fp_add(ba[3], fp_mul(bb[3], xb))));
             // 1/(x - 1) and 1/(x - w^(n-1)) depend on the domain only: cached tables
             const fp *bi = p.binv + (size_t)(p.k0 + kk) * 2 * n + j;
             t = fp_add(t, fp_mul(first, bi[0]));

@@ -32,6 +32,24 @@ inline hipError_t stream_wait(hipStream_t st) {
     }
     return e;
 }
+// The ONE wait of a proof whose channel runs on the device (prove.hip, prove_core_dev): the host has enqueued the whole proof and would
+// poll for 25 ms; `near_end` is an event recorded before the last ~0.5 ms of work.  Sleep on that event, then poll the stream: the
+// blocking wait's wake-up latency (50 - 150 us) is paid while the GPU is still busy, not after the proof.
+inline hipError_t stream_wait_tail(hipStream_t st, hipEvent_t near_end) {
+    static const bool block = [] { const char *e = getenv("CSTARK_SYNC_BLOCK"); return e && atoi(e) != 0; }();
+    if (block) return hipStreamSynchronize(st);
+    hipError_t e = hipEventSynchronize(near_end);
+    if (e != hipSuccess) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0; (e = hipStreamQuery(st)) == hipErrorNotReady; it++) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((it & 15) == 15 && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 5000)
+            return hipStreamSynchronize(st);
+    }
+    return e;
+}
 } // namespace cs
 
 namespace cs {
@@ -139,7 +157,8 @@ struct cstark_tx_coeffs;
 // evaluation of the Rescue windows on half of the cosets
 int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cstark_tx_coeffs *coeffs, uint32_t m, const uint64_t pub_inputs[4],
                                  uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
-                                 bool input_is_lde);
+                                 bool input_is_lde, const uint64_t *d_pub = nullptr);
+int tx_coef_device_block(cstark_ctx *c, uint64_t **d_coef);
 // internal (capi.hip): one rank's share of the degree-split evaluation of a proof sharded by LDE coset.  d_lde: the rank's cosets
 // [k0, k0 + nk) (k0 even, nk = 2 or 4) of its own extension; d_coeffs: the 94 coefficient columns (register 37 is extended to all
 // cosets here: the recombination reads it on cosets the rank does not hold).  d_out [nk / 2 + 4][n]: merged evaluations of the rank's
@@ -160,6 +179,8 @@ int lde_column_range(cstark_ctx *c, const uint64_t *d_coeffs, uint64_t *d_lde, u
 // internal (capi.hip): cstark_deep_composition_ext restricted to the first nk cosets, d_out = [m][nk][n]
 int evaluate_ood_frames(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, const uint64_t *d_ccoef, uint32_t n_comp, uint32_t log_n,
                         const uint64_t zpts[2], uint64_t zb, uint64_t *out_trace, uint64_t *out_comp);
+int ood_frames_dev(cstark_ctx *c, const uint64_t *d_coeffs, uint32_t width, const uint64_t *d_ccoef, uint32_t n_comp, uint32_t log_n, const uint64_t *d_pts,
+                   uint64_t *d_out);
 int deep_composition_ext_cosets(cstark_ctx *c, const uint64_t *d_trace_lde, const uint64_t *d_comp_lde, uint32_t width, uint32_t n_comp, uint32_t m,
                                 const uint64_t *z, const uint64_t *ood_trace, const uint64_t *ood_comp, const uint64_t *alpha, const uint64_t *beta,
                                 const uint64_t *delta, const uint64_t *deg_a, const uint64_t *deg_b, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup,

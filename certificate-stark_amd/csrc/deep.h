@@ -14,6 +14,7 @@ struct DeepParams {
     uint64_t *out;                        // [nk][n]
     uint64_t z, zw, zb, deg_a, deg_b;
     uint32_t width, nb, log_n, k0;
+    const uint64_t *scal; // non-null: z, z w, z^nb, deg_a, deg_b are read from scal[0..5) (drawn on the device: channel.hip) instead of the fields above
 };
 
 // out[p * width + c] = value of coefficient column c at points[p]  (all device memory)

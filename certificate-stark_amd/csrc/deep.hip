@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_deep(DeepParams p) {
     if (j >= n) return;
     const unsigned kk = blockIdx.y;
     const fp x = fp_mul(p.shifts[p.k0 + kk], p.w[j]);
-    const fp d1 = fp_sub(x, p.z), d2 = fp_sub(x, p.zw), d3 = fp_sub(x, p.zb);
+    const fp pz = p.scal ? p.scal[0] : p.z, pzw = p.scal ? p.scal[1] : p.zw, pzb = p.scal ? p.scal[2] : p.zb;
+    const fp d1 = fp_sub(x, pz), d2 = fp_sub(x, pzw), d3 = fp_sub(x, pzb);
     const fp inv = fp_inv(fp_mul(fp_mul(d1, d2), d3)); // one inversion for the three divisors
     const fp i1 = fp_mul(inv, fp_mul(d2, d3)), i2 = fp_mul(inv, fp_mul(d1, d3)), i3 = fp_mul(inv, fp_mul(d1, d2));
     Acc128 s1 = acc_zero(), s2 = acc_zero(), s3 = acc_zero();
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(256) void k_deep(DeepParams p) {
     }
     acc_fold(s3);
     fp acc = fp_add(fp_add(fp_mul(acc_reduce(s1), i1), fp_mul(acc_reduce(s2), i2)), fp_mul(acc_reduce(s3), i3));
-    p.out[(size_t)kk * n + j] = fp_mul(acc, fp_add(p.deg_a, fp_mul(p.deg_b, x)));
+    const fp dga = p.scal ? p.scal[3] : p.deg_a, dgb = p.scal ? p.scal[4] : p.deg_b;
+    p.out[(size_t)kk * n + j] = fp_mul(acc, fp_add(dga, fp_mul(dgb, x)));
 }
 
 // FRI layer folding, factor 4 [UPSTREAM-RECALL winterfell-fri apply_drp]: row i = { f(x_i zeta^t) } = evals[i + t N/4];

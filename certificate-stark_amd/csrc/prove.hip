@@ -27,6 +27,7 @@
 #include "../../include/cstark.h"
 #include "ctx.h"
 #include "blake3.h"
+#include "channel.h"
 #include "deep.h"
 #include "range_batch.h"
 #include "hostblake3.h"
@@ -48,6 +49,8 @@ struct ProveArena {
     std::vector<uint64_t *> layer;   // FRI layer evaluations (layer[0] = DEEP composition in natural order), last = remainder
     std::vector<uint8_t *> lnodes;   // FRI layer trees
     uint32_t *d_pos = nullptr;
+    uint64_t *d_pub = nullptr;    // [16] the public inputs read from the trace (first / last row of seven registers)
+    uint64_t *d_shifts = nullptr; // [b] g w_(b n)^k: the coset offsets of the LDE domain (k_deep)
     uint8_t *d_open = nullptr;
     uint64_t *h_pub = nullptr; // pinned
     uint8_t *h_open = nullptr; // pinned: the openings land here (a pageable destination is staged by the runtime: ~60 us for 0.5 MB)
@@ -203,13 +206,15 @@ __global__ void k_gather_paths(const uint4 *__restrict__ nodes, uint32_t log_lea
 // All opening gathers of a proof in ONE launch (they were twenty launches of a few microseconds each, 0.14 ms of launch latency):
 // job = blockIdx.y, query = blockIdx.x.  kind 0: row pos[q] of a coset-major table (as k_gather_rows); kind 1: authentication path
 // of leaf pos[q] (as k_gather_paths; a = log2 of the leaf count).
-struct GatherJob { const void *src; void *out; const uint32_t *pos; uint32_t kind, a, log_n, log_b, count, log_s; }; // log_s: block order of the table's cosets (blake3.h)
+struct GatherJob { const void *src; void *out; const uint32_t *pos; uint32_t kind, a, log_n, log_b, count, log_s; const uint32_t *dcount; };
+// log_s: block order of the table's cosets (blake3.h); dcount != null: the number of positions is read from the device (at most `count`:
+// the device-side channel folds the query positions itself, channel.hip)
 constexpr int MAX_GATHER_JOBS = 32;
 struct GatherBatch { GatherJob job[MAX_GATHER_JOBS]; };
 __global__ void k_gather_batch(GatherBatch b) {
     const GatherJob g = b.job[blockIdx.y];
     const uint32_t q = blockIdx.x;
-    if (q >= g.count) return;
+    if (q >= (g.dcount ? *g.dcount : g.count)) return;
     if (g.kind == 0) {
         const uint64_t *lde = (const uint64_t *)g.src;
         uint64_t *out = (uint64_t *)g.out;
@@ -230,12 +235,13 @@ struct GatherList {
     GatherBatch b{};
     int n = 0;
     uint32_t max_count = 0;
-    void rows(const uint64_t *lde, uint32_t width, uint32_t log_n, uint32_t log_b, const uint32_t *pos, void *out, uint32_t count, uint32_t log_s = 0) {
-        b.job[n++] = GatherJob{lde, out, pos, 0u, width, log_n, log_b, count, log_s};
+    void rows(const uint64_t *lde, uint32_t width, uint32_t log_n, uint32_t log_b, const uint32_t *pos, void *out, uint32_t count, uint32_t log_s = 0,
+              const uint32_t *dcount = nullptr) {
+        b.job[n++] = GatherJob{lde, out, pos, 0u, width, log_n, log_b, count, log_s, dcount};
         if (count > max_count) max_count = count;
     }
-    void paths(const uint8_t *nodes, uint32_t log_leaves, const uint32_t *pos, void *out, uint32_t count) {
-        b.job[n++] = GatherJob{nodes, out, pos, 1u, log_leaves, 0u, 0u, count, 0u};
+    void paths(const uint8_t *nodes, uint32_t log_leaves, const uint32_t *pos, void *out, uint32_t count, const uint32_t *dcount = nullptr) {
+        b.job[n++] = GatherJob{nodes, out, pos, 1u, log_leaves, 0u, 0u, count, 0u, dcount};
         if (count > max_count) max_count = count;
     }
     hipError_t launch(hipStream_t st) {
@@ -308,6 +314,7 @@ struct AirJob {
     bool evals_ready = false;       // sub-AIRs: the materialised transition evaluations of this proof are already in the arena
     uint32_t k0 = 0, nk = 8;        // sharded proofs (blowup 8): the LDE cosets this GPU owns
     bool sharded = false;
+    bool dev_channel = false;       // the Fiat-Shamir channel runs on the device (prove_core_dev): the host never reads the public inputs
     uint32_t log_b = 3;             // log2 of the blowup factor; the trace table holds its cosets in block order when log_b > log_ce
     uint64_t seed[7] = {};          // RescueAir
     uint64_t number = 0;            // RangeProofAir
@@ -349,6 +356,15 @@ int get_arena(cstark_ctx *c, const AirJob &job, unsigned log_b, unsigned log_f, 
         sz /= f;
     }
     RC_TRY(dev_alloc(a, &a->d_pos, 4 * 256 * (n_layers + 2)));
+    RC_TRY(dev_alloc(a, &a->d_pub, 16 * 8));
+    RC_TRY(dev_alloc(a, &a->d_shifts, b * 8));
+    {
+        std::vector<uint64_t> sh(b);
+        const uint64_t wbn = host::root_of_unity(job.log_n + log_b);
+        uint64_t v = host::lde_offset();
+        for (size_t k = 0; k < b; k++) { sh[k] = v; v = host::mul(v, wbn); }
+        HIP_TRY(hipMemcpy(a->d_shifts, sh.data(), b * 8, hipMemcpyHostToDevice)); // once per arena
+    }
     // openings: per query a trace row + path, a composition row + path, per layer a row of f + path
     a->open_bytes = nq;
     const size_t log_N = job.log_n + log_b;
@@ -788,6 +804,216 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
     return phase_open(c, a, R, nullptr, proof, capacity, proof_len);
 }
 
+// ---- the same proof with the Fiat-Shamir channel on the device (channel.hip) ---------------------------------------------------------
+// TransactionAir, base field, Blake3 coin, no proof of work: every channel step -- seed, reseeds, the 238 coefficient draws, the
+// out-of-domain point, the DEEP coefficients, the FRI layers' folding points (k_fri_coin), the remainder commitment, the query positions
+// and their folded forms -- is a launch on the context's stream, the kernels read what was drawn from device memory, and the host waits
+// ONCE, for the block that holds everything the proof bytes are written from.  Same bytes as prove_core (the tests compare both with the
+// CPU prover); CSTARK_HOST_CHANNEL=1 keeps the host channel for the A/B.  One-at-a-time proving on the host channel leaves the GPU idle
+// for 0.6 ms of a 28.4 ms proof, 0.39 ms of it in the five waits (profiles/r04_timeline_host_channel.txt).
+int prove_core_dev(cstark_ctx *c, const cstark_options *opt, AirJob &job0, uint8_t *proof, size_t capacity, size_t *proof_len) {
+    const auto hp0 = std::chrono::steady_clock::now();
+    ProofRun R;
+    ProveArena *a;
+    job0.dev_channel = true;
+    RC_TRY(run_setup(c, opt, job0, R, &a));
+    AirJob &job = R.job;
+    const unsigned log_n = job.log_n, log_b = R.log_b, log_f = R.log_f, log_N = log_n + log_b, log_ce = job.log_ce, n_layers = R.n_layers;
+    const size_t n = (size_t)1 << log_n, b = (size_t)1 << log_b, N = n * b, W = job.width, ce = (size_t)1 << log_ce, nq = opt->num_queries;
+    const uint32_t fold = 1u << log_f, hf = 0;
+    const size_t rem_len = (size_t)1 << (log_N - n_layers * log_f), n_ood = 2 * W + ce;
+    hipStream_t st = c->stream;
+    // ---- the result block: everything the proof bytes are written from, one copy to the host at the end ------------------------------------
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_troot = take(32), o_croot = take(32), o_rem = take(32), o_cnt = take(4 * 64), o_ood = take(n_ood * 8), o_lroots = take(32 * (size_t)n_layers),
+                 o_remainder = take(rem_len * 8);
+    const size_t o_trows = take(nq * W * 8), o_tpath = take(nq * log_N * 32), o_crows = take(nq * ce * 8), o_cpath = take(nq * log_N * 32);
+    std::vector<size_t> o_lrows(n_layers), o_lpath(n_layers);
+    {
+        unsigned g2 = log_N;
+        for (unsigned l = 0; l < n_layers; l++) { o_lrows[l] = take(nq * fold * 8); o_lpath[l] = take(nq * (g2 - log_f) * 32); g2 -= log_f; }
+    }
+    uint8_t *d_res;
+    uint32_t *d_fri;   // [seed 8 words][alpha: 2 words per layer x 32]: the coin and the layers' folding points
+    uint64_t *d_chan;  // [pts 4][scal 8][deep coefficients 2 W + ce]
+    uint64_t *dcoef;
+    RC_TRY(arena_extra(c, a, 44, &d_res, off));
+    RC_TRY(arena_extra(c, a, 41, &d_fri, (size_t)(8 + 10 * 32) * 4));
+    RC_TRY(arena_extra(c, a, 43, &d_chan, (12 + n_ood) * 8));
+    RC_TRY(arena_extra(c, a, 40, &dcoef, n * 8));
+    uint64_t *d_pts = d_chan, *d_scal = d_chan + 4, *d_deepc = d_chan + 12, *d_ood = (uint64_t *)(d_res + o_ood);
+    uint32_t *d_cnt = (uint32_t *)(d_res + o_cnt);
+    if (a->h_open_bytes < off) {
+        if (a->h_open) { HIP_TRY(hipHostFree(a->h_open)); a->h_open = nullptr; a->h_open_bytes = 0; }
+        HIP_TRY(hipHostMalloc((void **)&a->h_open, off, hipHostMallocDefault));
+        a->h_open_bytes = off;
+    }
+    uint64_t *d_coef_block;
+    RC_TRY(tx_coef_device_block(c, &d_coef_block));
+    const uint64_t *pw, *pwinv;
+    RC_TRY(plan_tables(c, log_n, &pw, &pwinv));
+
+#define STAGE() HIP_TRY(hipEventRecord(a->ev[R.evi++], st))
+    a->timed = false;
+    R.evi = 0;
+    STAGE();
+    RC_TRY(job.build(c, a, job));
+    STAGE();
+    RC_TRY(commit_columns(c, a, job, st, R.evi));
+    RC_TRY(hash_rows_slots(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, R.log_s()));
+    RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
+    STAGE();
+    {   // the coin: context || public inputs (read from the trace, on the device), the trace root, the coefficient pairs
+        ChanStep s{};
+        s.seed = d_fri; s.init = 1; s.pub = a->d_pub; s.npub = 14;
+        const uint8_t hdr[17] = {(uint8_t)W, (uint8_t)log_n, (uint8_t)host::P, (uint8_t)(host::P >> 8), (uint8_t)(host::P >> 16), (uint8_t)(host::P >> 24),
+                                 (uint8_t)(host::P >> 32), (uint8_t)(host::P >> 40), (uint8_t)(host::P >> 48), (uint8_t)(host::P >> 56),
+                                 (uint8_t)opt->num_queries, (uint8_t)log_b, (uint8_t)opt->grinding_factor, (uint8_t)opt->hash_fn, (uint8_t)opt->field_extension,
+                                 (uint8_t)opt->fri_folding_factor, (uint8_t)R.log_rem};
+        memcpy(s.prefix, hdr, sizeof hdr); s.prefix_len = sizeof hdr;
+        s.absorb[0].kind = CHAN_DIGEST; s.absorb[0].ptr = a->tnodes + 32; s.absorb[0].copy_out = d_res + o_troot;
+        s.draw = CHAN_DRAW_COEFFS; s.a = job.n_constraints; s.b = job.n_assertions; s.stride = CSTARK_TX_NUM_CONSTRAINTS;
+        s.count = 2 * (job.n_constraints + job.n_assertions); s.out = d_coef_block;
+        HIP_TRY(channel_step(s, st));
+    }
+    {
+        uint64_t *outs[1] = {a->combined};
+        RC_TRY(tx_evaluate_constraints_sets(c, a->lde, nullptr, 1, nullptr, outs, job.item, log_n, 3, 0, 8, true, a->d_pub));
+    }
+    STAGE();
+    RC_TRY(cstark_composition_columns(c, a->combined, a->ccoef, log_n, log_ce));
+    RC_TRY(cstark_lde_columns(c, a->ccoef, a->clde, (uint32_t)ce, log_n, log_b, host::lde_offset(), 0, (uint32_t)b));
+    RC_TRY(cstark_hash_rows_fn(c, hf, a->clde, a->cnodes + 32 * N, (uint32_t)ce, log_n, log_b, 0, (uint32_t)b));
+    RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
+    STAGE();
+    {   // the constraint root -> the out-of-domain point z; z w and z^ce beside it
+        ChanStep s{};
+        s.seed = d_fri;
+        s.absorb[0].kind = CHAN_DIGEST; s.absorb[0].ptr = a->cnodes + 32; s.absorb[0].copy_out = d_res + o_croot;
+        s.draw = CHAN_DRAW_POINT; s.count = 1; s.b = (uint32_t)ce; s.w = host::root_of_unity(log_n); s.out = d_pts; s.out2 = d_scal;
+        HIP_TRY(channel_step(s, st));
+    }
+    RC_TRY(ood_frames_dev(c, a->coeffs, (uint32_t)W, a->ccoef, (uint32_t)ce, log_n, d_pts, d_ood));
+    STAGE();
+    {   // the two halves of the frame -> the DEEP coefficients
+        ChanStep s{};
+        s.seed = d_fri;
+        s.absorb[0].kind = CHAN_ELEMS; s.absorb[0].ptr = d_ood; s.absorb[0].count = (uint32_t)(2 * W);
+        s.absorb[1].kind = CHAN_ELEMS; s.absorb[1].ptr = d_ood + 2 * W; s.absorb[1].count = (uint32_t)ce;
+        s.draw = CHAN_DRAW_DEEP; s.a = (uint32_t)W; s.b = (uint32_t)ce; s.per = CSTARK_CONV_DEEP_DRAWS_PER_REGISTER;
+        s.count = (uint32_t)(s.per * W + ce + 2); s.out = d_deepc; s.out2 = d_scal;
+        HIP_TRY(channel_step(s, st));
+    }
+    {   // degree < n: the quotient sums on coset 0, interpolation, extension (prove_core)
+        cs::DeepParams p{};
+        p.trace_lde = a->lde; p.comp_lde = a->clde; p.w = pw; p.coef = d_deepc; p.ood = d_ood; p.shifts = a->d_shifts; p.out = a->deep;
+        p.width = (uint32_t)W; p.nb = (uint32_t)ce; p.log_n = log_n; p.k0 = 0; p.scal = d_scal;
+        HIP_TRY(cs::deep_composition(p, 1, st));
+        RC_TRY(cstark_interpolate_columns(c, a->deep, dcoef, 1, log_n));
+        RC_TRY(cstark_lde_columns(c, dcoef, a->deep, 1, log_n, log_b, host::from_u64(1), 0, (uint32_t)b));
+    }
+    RC_TRY(cstark_interleave_cosets(c, a->deep, a->layer[0], log_n, log_b));
+    STAGE();
+    {
+        uint64_t offset = host::lde_offset();
+        unsigned lg = log_N;
+        for (unsigned l = 0; l < n_layers; l++) {
+            const size_t rows = (size_t)1 << (lg - log_f);
+            RC_TRY(cstark_hash_rows_fn(c, hf, a->layer[l], a->lnodes[l] + 32 * rows, fold, lg - log_f, 0, 0, 1));
+            RC_TRY(cstark_merkle_build_fn(c, hf, a->lnodes[l], lg - log_f));
+            uint64_t *next = l + 1 == n_layers ? (uint64_t *)(d_res + o_remainder) : a->layer[l + 1]; // the remainder lands in the result block
+            RC_TRY(fri_coin_fold_dev(c, d_fri, a->lnodes[l] + 32, (uint64_t *)(d_fri + 8) + l, (uint32_t *)(d_res + o_lroots + 32 * (size_t)l), a->layer[l], next, lg,
+                                     log_f, offset));
+            offset = host::pow(offset, fold);
+            lg -= log_f;
+        }
+    }
+    STAGE();
+    {   // remainder commitment, proof of work (none: nonce 1), query positions and their folded forms
+        ChanStep s{};
+        s.seed = d_fri;
+        s.absorb[0].kind = CHAN_ELEMS; s.absorb[0].ptr = d_res + o_remainder; s.absorb[0].count = (uint32_t)rem_len; s.absorb[0].copy_out = d_res + o_rem;
+        s.absorb[1].kind = CHAN_INT; s.absorb[1].value = 1;
+        s.draw = CHAN_DRAW_QUERIES; s.count = (uint32_t)nq; s.log_domain = log_N; s.log_f = log_f; s.n_layers = n_layers; s.slot = 256;
+        s.pos = a->d_pos; s.cnt = d_cnt;
+        HIP_TRY(channel_step(s, st));
+    }
+    if (2 * (size_t)n_layers + 4 > MAX_GATHER_JOBS) return fail(CSTARK_ERR_UNSUPPORTED, "too many FRI layers for one opening launch");
+    {
+        GatherList gl;
+        gl.rows(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, d_res + o_trows, (uint32_t)nq, R.log_s());
+        gl.paths(a->tnodes, log_N, a->d_pos, d_res + o_tpath, (uint32_t)nq);
+        gl.rows(a->clde, (uint32_t)ce, log_n, log_b, a->d_pos, d_res + o_crows, (uint32_t)nq);
+        gl.paths(a->cnodes, log_N, a->d_pos, d_res + o_cpath, (uint32_t)nq);
+        unsigned g2 = log_N;
+        for (unsigned l = 0; l < n_layers; l++) { // at most nq rows per layer; how many: cnt[l + 1], on the device
+            const unsigned lr = g2 - log_f;
+            gl.rows(a->layer[l], fold, lr, 0, a->d_pos + 256 * (l + 1), d_res + o_lrows[l], (uint32_t)nq, 0, d_cnt + l + 1);
+            gl.paths(a->lnodes[l], lr, a->d_pos + 256 * (l + 1), d_res + o_lpath[l], (uint32_t)nq, d_cnt + l + 1);
+            g2 -= log_f;
+        }
+        HIP_TRY(gl.launch(st));
+    }
+    HIP_TRY(hipMemcpyAsync(a->h_open, d_res, off, hipMemcpyDeviceToHost, st));
+    STAGE();
+    static const bool hostprof = getenv("CSTARK_HOSTPROF") != nullptr; // debugging: where the host's time goes
+    const auto hp1 = std::chrono::steady_clock::now();
+    HIP_TRY(cs::stream_wait_tail(st, a->ev[8])); // the only wait of the proof: sleep until the DEEP stage is done (event 8), poll through the FRI tail
+    const auto hp2 = std::chrono::steady_clock::now();
+    a->timed = true;
+#undef STAGE
+    const uint8_t *h = a->h_open;
+    const uint32_t *cnt = (const uint32_t *)(h + o_cnt);
+    if (cnt[0] != nq) return fail(CSTARK_ERR_HIP, "device channel: the query positions could not be drawn");
+    for (unsigned l = 0; l < n_layers; l++)
+        if (cnt[l + 1] == 0 || cnt[l + 1] > nq) return fail(CSTARK_ERR_HIP, "device channel: bad folded position count");
+    auto emit = [&](ProofWriter &wr) {
+        wr.raw("CSTK", 4); wr.u32(CSTARK_PROOF_VERSION);
+        wr.u32((uint32_t)job.air); wr.u32((uint32_t)W); wr.u32(log_n); wr.u32(job.item);
+        wr.u32(opt->num_queries); wr.u32(opt->blowup_factor); wr.u32(opt->grinding_factor); wr.u32(opt->hash_fn); wr.u32(opt->field_extension);
+        wr.u32(opt->fri_folding_factor); wr.u32(opt->fri_max_remainder);
+        wr.raw(h + o_troot, 32); wr.raw(h + o_croot, 32);
+        wr.u32(n_layers); wr.raw(h + o_lroots, 32 * (size_t)n_layers); wr.raw(h + o_rem, 32);
+        wr.raw(h + o_ood, n_ood * 8);
+        wr.u64(1); // pow nonce: grinding_factor 0
+        wr.raw(h + o_trows, nq * W * 8); wr.raw(h + o_tpath, nq * log_N * 32);
+        wr.raw(h + o_crows, nq * ce * 8); wr.raw(h + o_cpath, nq * log_N * 32);
+        unsigned g2 = log_N;
+        for (unsigned l = 0; l < n_layers; l++) {
+            const size_t np = cnt[l + 1];
+            wr.u32((uint32_t)np);
+            wr.raw(h + o_lrows[l], np * fold * 8);
+            wr.raw(h + o_lpath[l], np * (g2 - log_f) * 32);
+            g2 -= log_f;
+        }
+        wr.u32((uint32_t)rem_len); wr.raw(h + o_remainder, rem_len * 8);
+    };
+    ProofWriter count, out;
+    emit(count);
+    *proof_len = count.len;
+    if (!proof || capacity < count.len) return fail(CSTARK_ERR_INVALID_ARG, "proof buffer too small (required size returned in *proof_len)");
+    out.dst = proof;
+    emit(out);
+    if (hostprof) {
+        const auto hp3 = std::chrono::steady_clock::now();
+        auto us = [](auto d) { return std::chrono::duration<double, std::micro>(d).count(); };
+        fprintf(stderr, "[cstark hostprof] device channel: enqueued in %.0f us, waited %.0f us, proof written in %.0f us\n", us(hp1 - hp0), us(hp2 - hp1), us(hp3 - hp2));
+    }
+    return CSTARK_OK;
+}
+// which channel: the device's for what prove_core_dev covers, unless CSTARK_HOST_CHANNEL=1
+bool use_dev_channel(const cstark_options *opt, const AirJob &job) {
+    static const bool host_env = [] { const char *e = getenv("CSTARK_HOST_CHANNEL"); return e && atoi(e) != 0; }();
+    if (host_env || job.air != CSTARK_AIR_STATE_TRANSITION || job.sharded) return false;
+    if (opt->hash_fn != 0 || opt->field_extension != 0 || opt->grinding_factor != 0) return false;
+    uint32_t lb = 0, lf = 0, lr = 0;
+    while ((1u << lb) < opt->blowup_factor && lb < 8) lb++;
+    while ((1u << lf) < opt->fri_folding_factor && lf < 8) lf++;
+    while ((1u << lr) < opt->fri_max_remainder && lr < 12) lr++;
+    return lf >= 2 && job.log_n + lb > lr; // at least one FRI layer (always, for a TransactionAir trace)
+}
+
 // Sharded proofs: a rank that holds 2 or 4 cosets evaluates its share of the degree-split form (CSTARK_SHARD_SPLIT=0, tuning /
 // debugging: every point of its cosets directly, as a rank with a single coset always does).  shard_rows = rows of n merged
 // evaluations the rank hands to the all-gather: its nk cosets, or its nk / 2 even cosets + its share of the four odd ones.
@@ -800,10 +1026,10 @@ uint32_t shard_rows(uint32_t nk) { return shard_split(nk) ? nk / 2 + 4 : nk; }
 // first / last row of registers 58..64 -> job.pub (TransactionProver::get_pub_inputs src/prover.rs:106-129; MerkleProver alike)
 int gather_roots(cstark_ctx *c, ProveArena *a, AirJob &job, uint32_t reg0 = 58) {
     const size_t n = (size_t)1 << job.log_n;
-    k_gather_pub<<<1, 64, 0, c->stream>>>(a->trace, n, (uint64_t *)a->d_open, reg0);
+    k_gather_pub<<<1, 64, 0, c->stream>>>(a->trace, n, a->d_pub, reg0);
     HIP_TRY(hipGetLastError());
     job.pub.assign(14, 0);
-    HIP_TRY(hipMemcpyAsync(job.pub.data(), a->d_open, 14 * 8, hipMemcpyDeviceToHost, c->stream)); // complete at the commitment sync
+    HIP_TRY(hipMemcpyAsync(job.pub.data(), a->d_pub, 14 * 8, hipMemcpyDeviceToHost, c->stream)); // complete at the commitment sync
     return CSTARK_OK;
 }
 
@@ -827,9 +1053,9 @@ int tx_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
     // second batch waits for, into pinned memory; collected after the commitment sync
     const size_t n = (size_t)1 << job.log_n;
     if (!a->h_pub) HIP_TRY(hipHostMalloc((void **)&a->h_pub, 14 * 8, hipHostMallocDefault));
-    k_gather_pub<<<1, 64, 0, c->side>>>(a->trace, n, (uint64_t *)a->d_open, 58u);
+    k_gather_pub<<<1, 64, 0, c->side>>>(a->trace, n, a->d_pub, 58u);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(a->h_pub, a->d_open, 14 * 8, hipMemcpyDeviceToHost, c->side));
+    if (!job.dev_channel) HIP_TRY(hipMemcpyAsync(a->h_pub, a->d_pub, 14 * 8, hipMemcpyDeviceToHost, c->side));
     HIP_TRY(hipEventRecord(c->ev_join, c->side));
     job.pub_staging = a->h_pub;
     if (mode == 3) // two batches: everything but the curve registers once the Merkle recurrence and the message hash are done
@@ -1262,6 +1488,7 @@ int cstark_tx_prove(cstark_ctx *c, const cstark_options *opt, uint8_t *proof, si
     job.n_constraints = CSTARK_TX_NUM_CONSTRAINTS; job.n_assertions = 4; job.item = c->wit.depth;
     job.build = tx_build; job.combine = tx_combine; job.combine_sets = tx_combine_sets;
     if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
+    if (use_dev_channel(opt, job)) return prove_core_dev(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);
 }
 
