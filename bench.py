@@ -99,6 +99,20 @@ def b_core(n, w, b=8):
     return 8 * n * w * (4 + 3 * b) + 104 * b * n
 
 
+def _config_traffic(name):
+    """HBM bytes per proof of a sub-AIR configuration: every kernel of the newest profiles/r*_<name>_hbm_traffic_pmc.csv (tools/profile.sh
+    over tools/bench_air_one.py; 2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), or None"""
+    import csv
+    import glob
+    import re
+    key = lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_hbm_traffic_pmc.csv" % name)), key=key, reverse=True)
+    if not files:
+        return None, None
+    rows = list(csv.DictReader(open(files[0])))
+    return int(sum(float(r["fetch_x2_plus_write_GB_per_proof"]) for r in rows) * 1e9), "profiles/" + os.path.basename(files[0])
+
+
 def other_configs(backend, queries=42):
     """BASELINE.json configs 1-3 (range / merkle / schnorr) through the product path, after the timed headline region: complete proofs
     (cstark_air_prove / cstark_range_prove_bits), milliseconds per proof from the host clock around `reps` back-to-back proofs, proof
@@ -110,7 +124,7 @@ def other_configs(backend, queries=42):
     opt = ProofOptions(queries, 8, 0, 0, 0, 4, 256)
     out = []
 
-    def timed(name, workload, prove, rows, width, reps, note=None, stages=True):
+    def timed(name, workload, prove, rows, width, reps, note=None, stages=True, blowup=8):
         proof = prove()
         prove()
         t0 = time.perf_counter()
@@ -123,11 +137,13 @@ def other_configs(backend, queries=42):
             return
         st = backend.prove_stage_ms()
         hot = sum(st[k] for k in ("trace", "interpolate", "lde", "commit", "constraints"))
-        alg = b_core(rows, width)
+        alg = b_core(rows, width, blowup)
+        traffic, tsrc = _config_traffic({"merkle_2_18_d15": "merkle_2_18", "schnorr_2_18": "schnorr_2_18", "range_2_16": "range_2_16"}.get(name, name))
         e = {"config": name, "workload": workload, "ms_per_proof": round(ms, 3), "proofs_per_s": round(1e3 / ms, 2), "proof_bytes": len(proof),
              "stage_ms": {k: round(v, 3) for k, v in st.items()},
              "roofline": {"bound": "hbm", "achieved": round(alg / (hot * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(alg / (hot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg, "hot_path_ms": round(hot, 3), "traffic": None}}
+                          "frac": round(alg / (hot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg, "hot_path_ms": round(hot, 3), "traffic": traffic,
+                          "traffic_source": tsrc, "traffic_scope": None if traffic is None else "every kernel of a whole proof (hot path and the stages after it)"}}
         if note:
             e["note"] = note
         out.append(e)
@@ -159,13 +175,20 @@ def other_configs(backend, queries=42):
     full = TransactionMetadata.load(FIXTURE)
     m512 = TransactionMetadata(*[getattr(full, f) if f == "final_root" else getattr(full, f)[:512] for f in TransactionMetadata.FIELDS])
     m512.final_root = full.initial_roots[512].copy()
-    timed("merkle_2_18_d15", "benches/merkle.rs Merkle AIR, 512 transfers = 2^18 steps, depth 15 (the reference's constant)",
+    # (MerkleExample / SchnorrExample keep their witness in device memory after the first call: the timed proofs exclude the upload, as
+    # the headline does -- "witness resident" in the workload strings)
+    timed("merkle_2_18_d15", "benches/merkle.rs Merkle AIR, 512 transfers = 2^18 steps, depth 15 (the reference's constant); witness resident, upload excluded",
           MerkleExample(opt, m512, backend).prove, 1 << 18, 65, 5)
     m31 = TransactionMetadata.build_random(512, 31, seed=31)
-    timed("merkle_2_18_d31", "benches/merkle.rs Merkle AIR, 512 transfers = 2^18 steps, depth 31 (nearest legal depth to BASELINE's 32: depth + 1 must be a power of two)",
+    timed("merkle_2_18_d31", "benches/merkle.rs Merkle AIR, 512 transfers = 2^18 steps, depth 31 (nearest legal depth to BASELINE's 32: depth + 1 must be a power of two); witness resident, upload excluded",
           MerkleExample(opt, m31, backend).prove, 1 << 18, 65, 5)
     sch = SchnorrExample.build_random(opt, 512, seed=1, backend=backend)
-    timed("schnorr_2_18", "benches/schnorr.rs Schnorr AIR, 512 signatures = 2^18 steps", sch.prove, 1 << 18, 56, 5)
+    timed("schnorr_2_18", "benches/schnorr.rs Schnorr AIR, 512 signatures = 2^18 steps; witness resident, upload excluded", sch.prove, 1 << 18, 56, 5)
+    if hasattr(backend, "rescue_prove"):  # BASELINE config 0: the reference times it on the CPU; here the same AIR through cstark_rescue_prove
+        from certificate_stark_amd.prover import RescueExample
+        rex = RescueExample(512, ProofOptions(queries, 4, 0, 0, 0, 4, 256), backend)
+        timed("rescue_2_12", "benches/rescue.rs Rescue-Prime hash chain, 512 links = 2^12 trace steps, blowup 4 (the bench's options, :370-378); one "
+              "sequential chain: the trace is a single wave's recurrence", rex.prove, 1 << 12, 14, 10, blowup=4)
     return out
 
 
@@ -216,7 +239,8 @@ class PmcTraffic:
         import glob
         import re
         self.gb, self.source = {}, None
-        files = glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.csv"))
+        files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.csv"))
+                 if re.match(r"r\d+_[a-z0-9]+_hbm_traffic_pmc.csv", os.path.basename(f))]  # the headline's set (<round>_<tag>_...), not a sub-AIR configuration's
         key = lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))]
         for f in sorted(files, key=key, reverse=True):
             rows = list(csv.DictReader(open(f)))
@@ -231,6 +255,45 @@ class PmcTraffic:
             return None
         hit = [v for k, v in self.gb.items() if any(k == nm or (nm.endswith("<") and k.startswith(nm)) for nm in names)]
         return sum(hit) if hit else None
+
+
+class PmcValu:
+    """The vector-instruction counters of the newest profile set under profiles/ (tools/profile.sh: <tag>_valu_pmc.csv, one row per
+    kernel: SQ_INSTS_VALU, SQ_BUSY_CYCLES, SQ_WAVES, GRBM_GUI_ACTIVE per dispatch) together with the static issue cost per instruction
+    of the same kernels (tools/isa_mix.py --csv -> <tag>_isa_mix.csv: 4 SIMD cycles for v_mad_u64_u32 / 64-bit adds / carries / VOP3,
+    2 for the other 32-bit vector instructions, profiles/r02_valu_issue_bench*.txt).  Nothing here is a literal: no file, no entry."""
+    N_SIMD, N_XCD = 1024, 8  # 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
+
+    def __init__(self, suffix="_valu_pmc.csv"):
+        import csv
+        import glob
+        import re
+        self.rows, self.cpi, self.source, self.cpi_source = {}, {}, None, None
+        key = lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))]
+        files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*" + suffix)) if (suffix != "_valu_pmc.csv" or re.match(r"r\d+_[a-z0-9]+_valu_pmc.csv", os.path.basename(f)))]
+        for f in sorted(files, key=key, reverse=True)[:1]:
+            self.rows = {r["kernel"]: r for r in csv.DictReader(open(f))}
+            self.source = "profiles/" + os.path.basename(f)
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_mix.csv")), key=key, reverse=True)[:1]:
+            self.cpi = {r["kernel"]: float(r["cycles_per_valu_instruction"]) for r in csv.DictReader(open(f))}
+            self.cpi_source = "profiles/" + os.path.basename(f)
+
+    def entry(self, kernel, points):
+        """kernel: exact name in the PMC summary; points: evaluation points (or elements) one dispatch processes"""
+        r = self.rows.get(kernel)
+        if r is None:
+            return None
+        insts = float(r["SQ_INSTS_VALU_per_dispatch"])
+        gui = float(r["GRBM_GUI_ACTIVE_per_dispatch"]) / self.N_XCD
+        ns = float(r["avg_ns_under_pmc"])
+        e = {"kernel": kernel, "wave_instructions": int(insts), "insts_per_point": round(insts * 64 / points, 1) if points else None,
+             "gui_cycles": int(gui), "clock_ghz": round(gui / ns, 3) if ns else None, "kernel_us_under_pmc": round(ns / 1e3, 1), "source": self.source}
+        cpi = self.cpi.get(kernel)
+        if cpi is not None:
+            issue = insts * cpi / self.N_SIMD
+            e.update({"cycles_per_instruction_static": cpi, "issue_cycles_est": int(issue), "frac_of_issue": round(issue / gui, 3) if gui else None,
+                      "cpi_source": self.cpi_source})
+        return e
 
 
 def spawn_ranks(n):
@@ -523,6 +586,22 @@ def main():
                                 ["k_rounds_split<1>"] if split else ["k_eval_fused<0, 1>"],
                                 "longest single launch; bound by vector-instruction issue: 22.9 k instructions per point at 4.5 cycles each "
                                 "(profiles/*_valu_pmc.csv, *_valu_issue_bench.txt)")
+        valu = PmcValu()
+        pts_headline = n_tx == 1024 and args.mode == "prove" and field_ext == 0 and hash_fn == 0  # the workload the profile set was taken on
+        if pts_headline:
+            # the transform pair: one dispatch = all 8 cosets of a table; the trace table (94 columns) dominates the per-dispatch average
+            # of the counter file, whose rows average over EVERY dispatch of a kernel name in a proof: points = elements per average dispatch
+            # are not recoverable from it, so the per-element figure is taken from the instruction and element totals of a proof
+            cols, rows_ = valu.entry("k_ntt_cols_v5<4, 3, 3, false>", 0), valu.entry("k_ntt_rows_v5<4, 3, 3, false>", 0)
+            if cols and rows_:
+                disp = {k: float(valu.rows[k]["dispatches"]) / 4 for k in ("k_ntt_cols_v5<4, 3, 3, false>", "k_ntt_rows_v5<4, 3, 3, false>")}  # per proof (4 proofs per profiled run)
+                elems = lde_elements / per + 58 * n  # forward transforms of a proof: the LDE calls + the 58 split-polynomial columns
+                tot = cols["wave_instructions"] * disp["k_ntt_cols_v5<4, 3, 3, false>"] + rows_["wave_instructions"] * disp["k_ntt_rows_v5<4, 3, 3, false>"]
+                roofline_lde["valu"] = {"column_pass": cols, "row_pass": rows_, "insts_per_element": round(tot * 64 / elems, 1),
+                                        "note": "lane-instructions per output element of the forward transform pair, all forward transforms of a proof"}
+            r = valu.entry("k_rounds_split<1>", 4 * n)
+            if r:
+                roofline_rounds["valu"] = r
         roofline_stages = [roofline_lde] + ([] if coset_mode else [roofline_rounds])
         if args.mode == "prove":
             roofline_stages.append(entry("row hashes + Merkle tree of the trace commitment (k_hash_rows + k_merkle_level2 / k_merkle_quad)", ab["hash_rows"] + ab["merkle"],
@@ -534,6 +613,14 @@ def main():
                                           "k_coset_even_to_odd", "k_split_finish<"] if split else ["k_eval_fused<", "k_rounds_setup"],
                                          "`traffic` = the stage's own kernels; the interpolation and extension of its split polynomials run through the "
                                          "transform kernels and are counted in the first entry (about 4 GB)" if split else None))
+        # ---- the bound that explains the times: vector-instruction issue.  Per kernel: wave-instructions and active cycles from the counter
+        # pass, the static issue cost per instruction, and their ratio = the fraction of the kernel's cycles spent issuing VALU work ----
+        issue_roofline = None
+        if pts_headline and args.mode == "prove":
+            pts = {"k_ntt_cols_v5<4, 3, 3, false>": 0, "k_ntt_rows_v5<4, 3, 3, false>": 0, "k_rounds_split<1>": 4 * n, "k_ec_split<1, false, 1>": 4 * n,
+                   "k_ec_split<2, false, 1>": 4 * n, "k_ec_split<3, true, 1>": 4 * n, "k_ec_split<4, false, 1>": 4 * n, "k_final_split<1>": 4 * n,
+                   "k_lin_all": 4 * n, "k_split_finish<1>": 8 * n, "k_hash_rows": 0, "k_trace_schnorr_ec<false, 16>": 2 * n_tx * 511, "k_deep": n}
+            issue_roofline = [e for e in (valu.entry(k, p) for k, p in pts.items()) if e is not None] or None
         out = {
             "metric": ("proofs/sec, state_transition AIR @ 2^%d steps (complete prove(): trace gen, LDE, Blake3 commitments, constraint "
                        "evaluation, composition, DEEP, FRI, %d queries)" % (log_n, args.queries)) if prove_mode else
@@ -567,6 +654,7 @@ def main():
                                      "extension of the 11 + 2 split polynomials to the odd cosets and the recombination over all cosets") if split else None,
             "roofline": roofline_lde,
             "roofline_stages": roofline_stages,
+            "issue_roofline": issue_roofline,  # per kernel: the vector-instruction issue fraction (PmcValu), the bound DESIGN.md 5.2 names
         }
         if extra:
             out["extra_stage_ms"] = extra

@@ -474,20 +474,20 @@ class Backend:
                                   options.field_extension, options.fri_folding_factor, options.fri_max_remainder)
 
     def shard_commit(self, options, k0, nk):
-        """phase 1 -> digests of this rank's rows, uint8 [nk][n][32]"""
+        """phase 1 -> the roots of this rank's subtrees (its nk leaves of every row), uint8 [1][n][32]"""
         self._shard_options = options
         n = self.n_tx * _lib.TX_CYCLE_LENGTH
-        leaves = self.empty_u8(nk, n, 32)
+        leaves = self.empty_u8(1, n, 32)
         o = self._options_struct(options)
         check(self.lib.cstark_tx_shard_commit(self.ctx, C.byref(o), C.c_uint32(k0), C.c_uint32(nk), self._ptr(leaves, u8p)))
         self._shard_nk = nk
         return leaves
 
     def shard_evaluate(self, leaves_all):
-        """phase 2: all-gathered digests [8][n][32] -> this rank's share of the merged constraint evaluations, int64 [R][n]
+        """phase 2: all-gathered subtree roots [W][n][32] -> this rank's share of the merged constraint evaluations, int64 [R][n]
         (R = cstark_tx_shard_rows(nk): its cosets, or its even cosets + its share of the four odd ones; include/cstark.h)"""
         n = self.n_tx * _lib.TX_CYCLE_LENGTH
-        assert tuple(leaves_all.shape) == (8, n, 32) and leaves_all.dtype == torch.uint8
+        assert tuple(leaves_all.shape) == (8 // self._shard_nk, n, 32) and leaves_all.dtype == torch.uint8
         self.lib.cstark_tx_shard_rows.restype = C.c_uint32
         out = self.empty_u64(int(self.lib.cstark_tx_shard_rows(C.c_uint32(self._shard_nk))), n)
         check(self.lib.cstark_tx_shard_evaluate(self.ctx, self._ptr(leaves_all.contiguous(), u8p), self._ptr(out), C.c_uint32(out.shape[0])))
@@ -504,9 +504,11 @@ class Backend:
         return torch.from_numpy(pos.view(np.int32)).to(self.device)
 
     def shard_open_rows(self, positions):
-        """phase 4: rows of the extended trace at `positions` that lie in this rank's cosets (zeros elsewhere), int64 [nq][94]"""
+        """phase 4: rows of the extended trace at `positions` that lie in this rank's cosets, each with the bottom log2(nk) siblings of
+        its authentication path (zeros elsewhere), int64 [nq][94 + 4 log2(nk)]"""
         pos = np.ascontiguousarray(positions.detach().cpu().numpy().view(np.uint32))
-        rows = self.empty_u64(pos.size, _lib.TX_TRACE_WIDTH)
+        self.lib.cstark_tx_shard_open_words.restype = C.c_uint32
+        rows = self.empty_u64(pos.size, int(self.lib.cstark_tx_shard_open_words(C.c_uint32(self._shard_nk))))
         check(self.lib.cstark_tx_shard_open_rows(self.ctx, pos.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(pos.size), self._ptr(rows)))
         return rows
 

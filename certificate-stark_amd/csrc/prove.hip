@@ -179,13 +179,26 @@ __global__ void k_gather_rows(const uint64_t *__restrict__ lde, uint32_t width, 
     const uint32_t q = blockIdx.x, i = pos[q], k = i & ((1u << log_b) - 1), j = i >> log_b;
     for (uint32_t c = threadIdx.x; c < width; c += blockDim.x) out[(size_t)q * width + c] = lde[(((size_t)k * width + c) << log_n) + j];
 }
-// the same for a table that holds cosets [k0, k0 + nk) only: rows of other cosets are written as zeros (the owners' rows are summed in)
+// the same for a table that holds cosets [k0, k0 + nk) only, each row followed by the bottom log2(nk) siblings of its authentication path
+// from the rank's own subtree heap `sub` (leaf nk j + (k - k0) at nk n + ...; phase_commit): [nq][width + 4 log_nk] words.  Rows of
+// other cosets are written as zeros (the owners' rows are summed in).
 __global__ void k_gather_rows_window(const uint64_t *__restrict__ lde, uint32_t width, uint32_t log_n, uint32_t log_b, uint32_t k0, uint32_t nk,
-                                     const uint32_t *__restrict__ pos, uint64_t *__restrict__ out) {
-    const uint32_t q = blockIdx.x, i = pos[q], k = i & ((1u << log_b) - 1), j = i >> log_b;
+                                     const uint32_t *__restrict__ pos, uint64_t *__restrict__ out, const uint64_t *__restrict__ sub, uint32_t log_nk) {
+    const uint32_t q = blockIdx.x, i = pos[q], k = i & ((1u << log_b) - 1), j = i >> log_b, stride = width + 4 * log_nk;
     const bool mine = k >= k0 && k < k0 + nk;
     for (uint32_t c = threadIdx.x; c < width; c += blockDim.x)
-        out[(size_t)q * width + c] = mine ? lde[(((size_t)(k - k0) * width + c) << log_n) + j] : 0;
+        out[(size_t)q * stride + c] = mine ? lde[(((size_t)(k - k0) * width + c) << log_n) + j] : 0;
+    const size_t leaf = ((size_t)nk << log_n) + ((size_t)j << log_nk) + (k - k0);
+    for (uint32_t t = threadIdx.x; t < 4 * log_nk; t += blockDim.x)
+        out[(size_t)q * stride + width + t] = mine ? sub[4 * ((leaf >> (t >> 2)) ^ 1) + (t & 3)] : 0;
+}
+// the summed rows of the ranks [nq][width + 4 log_nk] -> the opened rows [nq][width] and levels [0, log_nk) of the authentication paths
+// [nq][log_leaves][32 bytes] (the levels above come from the upper tree: GatherJob::lvl0)
+__global__ void k_split_shard_rows(const uint64_t *__restrict__ rows, uint32_t width, uint32_t log_nk, uint32_t log_leaves, uint64_t *__restrict__ out_rows,
+                                   uint64_t *__restrict__ out_paths) {
+    const uint32_t q = blockIdx.x, stride = width + 4 * log_nk;
+    for (uint32_t c = threadIdx.x; c < width; c += blockDim.x) out_rows[(size_t)q * width + c] = rows[(size_t)q * stride + c];
+    for (uint32_t t = threadIdx.x; t < 4 * log_nk; t += blockDim.x) out_paths[(size_t)q * log_leaves * 4 + t] = rows[(size_t)q * stride + width + t];
 }
 // leaf digests [b][n] (coset-major, as the ranks' all-gather delivers them) -> natural order: leaf b*j + k = digest (k, j)
 __global__ void k_interleave_leaves(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n, uint32_t log_b) {
@@ -206,9 +219,10 @@ __global__ void k_gather_paths(const uint4 *__restrict__ nodes, uint32_t log_lea
 // All opening gathers of a proof in ONE launch (they were twenty launches of a few microseconds each, 0.14 ms of launch latency):
 // job = blockIdx.y, query = blockIdx.x.  kind 0: row pos[q] of a coset-major table (as k_gather_rows); kind 1: authentication path
 // of leaf pos[q] (as k_gather_paths; a = log2 of the leaf count).
-struct GatherJob { const void *src; void *out; const uint32_t *pos; uint32_t kind, a, log_n, log_b, count, log_s; const uint32_t *dcount; };
+struct GatherJob { const void *src; void *out; const uint32_t *pos; uint32_t kind, a, log_n, log_b, count, log_s; const uint32_t *dcount; uint32_t lvl0; };
 // log_s: block order of the table's cosets (blake3.h); dcount != null: the number of positions is read from the device (at most `count`:
-// the device-side channel folds the query positions itself, channel.hip)
+// the device-side channel folds the query positions itself, channel.hip); lvl0 (paths): the levels below it are left alone (sharded
+// proofs: they come from the rank that owns the leaf)
 constexpr int MAX_GATHER_JOBS = 32;
 struct GatherBatch { GatherJob job[MAX_GATHER_JOBS]; };
 __global__ void k_gather_batch(GatherBatch b) {
@@ -224,7 +238,7 @@ __global__ void k_gather_batch(GatherBatch b) {
         const uint4 *nodes = (const uint4 *)g.src;
         uint4 *out = (uint4 *)g.out;
         const uint32_t log_leaves = g.a;
-        for (uint32_t t = threadIdx.x; t < 2 * log_leaves; t += blockDim.x) {
+        for (uint32_t t = threadIdx.x + 2 * g.lvl0; t < 2 * log_leaves; t += blockDim.x) {
             const uint32_t lvl = t >> 1, half = t & 1;
             const size_t node = ((((size_t)1 << log_leaves) + g.pos[q]) >> lvl) ^ 1;
             out[((size_t)q * log_leaves + lvl) * 2 + half] = nodes[2 * node + half];
@@ -237,11 +251,11 @@ struct GatherList {
     uint32_t max_count = 0;
     void rows(const uint64_t *lde, uint32_t width, uint32_t log_n, uint32_t log_b, const uint32_t *pos, void *out, uint32_t count, uint32_t log_s = 0,
               const uint32_t *dcount = nullptr) {
-        b.job[n++] = GatherJob{lde, out, pos, 0u, width, log_n, log_b, count, log_s, dcount};
+        b.job[n++] = GatherJob{lde, out, pos, 0u, width, log_n, log_b, count, log_s, dcount, 0u};
         if (count > max_count) max_count = count;
     }
-    void paths(const uint8_t *nodes, uint32_t log_leaves, const uint32_t *pos, void *out, uint32_t count, const uint32_t *dcount = nullptr) {
-        b.job[n++] = GatherJob{nodes, out, pos, 1u, log_leaves, 0u, 0u, count, 0u, dcount};
+    void paths(const uint8_t *nodes, uint32_t log_leaves, const uint32_t *pos, void *out, uint32_t count, const uint32_t *dcount = nullptr, uint32_t lvl0 = 0) {
+        b.job[n++] = GatherJob{nodes, out, pos, 1u, log_leaves, 0u, 0u, count, 0u, dcount, lvl0};
         if (count > max_count) max_count = count;
     }
     hipError_t launch(hipStream_t st) {
@@ -285,6 +299,7 @@ int arena_extra(cstark_ctx *c, ProveArena *a, size_t slot, T **p, size_t bytes) 
     return CSTARK_OK;
 }
 
+unsigned ceil_log2(uint64_t x) { unsigned l = 0; while ((1ull << l) < x) l++; return l; }
 unsigned num_fri_layers(unsigned log_domain, unsigned log_max_remainder, unsigned log_f) {
     unsigned l = 0;
     while (log_domain > log_max_remainder) { log_domain -= log_f; l++; }
@@ -499,7 +514,9 @@ namespace {
 #define STAGE() HIP_TRY(hipEventRecord(a->ev[R.evi++], st))
 
 // ---- phase 1: trace, its interpolation and extension, row hashes of the owned cosets ---------------------------------------------
-// d_leaves_local (sharded only): compact digests [nk][n][32] of this rank's rows; otherwise the leaves go straight into the tree.
+// d_leaves_local (sharded only): [n][32], the roots of the rank's subtrees -- the nk leaves 8 j + k0 .. 8 j + k0 + nk - 1 of row j are a
+// complete subtree of the trace tree, so the rank hashes the bottom log2(nk) levels itself (its own heap `sub`, kept for the openings)
+// and the all-gather moves 32 n bytes per rank at every world size.  Otherwise the leaves go straight into the tree.
 int phase_commit(cstark_ctx *c, ProveArena *a, ProofRun &R, uint8_t *d_leaves_local) {
     AirJob &job = R.job;
     const unsigned log_n = job.log_n, log_b = R.log_b;
@@ -515,26 +532,37 @@ int phase_commit(cstark_ctx *c, ProveArena *a, ProofRun &R, uint8_t *d_leaves_lo
     if (!R.sharded()) {
         RC_TRY(hash_rows_slots(c, hf, a->lde, a->tnodes + 32 * N, (uint32_t)W, log_n, log_b, R.log_s()));
     } else {
-        for (uint32_t i = 0; i < job.nk; i++) // a coset alone is a blowup-1 domain: leaf j of the call = row j of the coset
-            RC_TRY(cstark_hash_rows_fn(c, hf, a->lde + (size_t)i * W * n, d_leaves_local + (size_t)i * n * 32, (uint32_t)W, log_n, 0, 0, 1));
+        const unsigned log_nk = ceil_log2(job.nk);
+        if (log_nk == 0) { // one coset: its row digests are the subtree roots
+            RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, d_leaves_local, (uint32_t)W, log_n, 0, 0, 1));
+        } else {           // the rank's cosets as a tree of their own: leaf nk j + (k - k0); the level with n nodes = the subtree roots
+            uint8_t *sub;
+            RC_TRY(arena_extra(c, a, 45, &sub, 2 * ((size_t)job.nk << log_n) * 32));
+            RC_TRY(cstark_hash_rows_fn(c, hf, a->lde, sub + 32 * ((size_t)job.nk << log_n), (uint32_t)W, log_n, log_nk, 0, job.nk));
+            RC_TRY(cstark_merkle_build_fn(c, hf, sub, log_n + log_nk));
+            HIP_TRY(hipMemcpyAsync(d_leaves_local, sub + 32 * n, n * 32, hipMemcpyDeviceToDevice, st));
+        }
     }
     R.phase = 1;
     return CSTARK_OK;
 }
 
 // ---- phase 2: trace tree, channel, coefficients, merged constraint evaluations of the owned cosets -----------------------------------
-// d_leaves_all (sharded only): the all-gathered digests [8][n][32], coset-major.  d_out: [nk][n].
+// d_leaves_all (sharded only): the all-gathered subtree roots [W][n][32], rank-major (W = 8 / nk).  d_out: [nk][n].
 int phase_evaluate(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint8_t *d_leaves_all, uint64_t *d_out) {
     AirJob &job = R.job;
     const unsigned log_n = job.log_n, log_b = R.log_b, log_N = log_n + log_b;
     const size_t n = (size_t)1 << log_n, N = n << log_b, W = job.width;
     hipStream_t st = c->stream;
     const uint32_t hf = R.opt.hash_fn;
-    if (R.sharded()) {
-        k_interleave_leaves<<<(unsigned)((2 * N + 255) / 256), 256, 0, st>>>((const uint4 *)d_leaves_all, (uint4 *)(a->tnodes + 32 * N), n, log_b);
+    unsigned log_top = log_N; // leaves of the tree that is built here
+    if (R.sharded()) { // node W j + r of the level with W n nodes = rank r's subtree root of row j; the levels from there up
+        const unsigned log_w = log_b - ceil_log2(job.nk);
+        log_top = log_n + log_w;
+        k_interleave_leaves<<<(unsigned)(((2 * n << log_w) + 255) / 256), 256, 0, st>>>((const uint4 *)d_leaves_all, (uint4 *)(a->tnodes + 32 * (n << log_w)), n, log_w);
         HIP_TRY(hipGetLastError());
     }
-    RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_N));
+    RC_TRY(cstark_merkle_build_fn(c, hf, a->tnodes, log_top));
     HIP_TRY(hipMemcpyAsync(R.trace_root, a->tnodes + 32, 32, hipMemcpyDeviceToHost, st));
     STAGE();
     HIP_TRY(cs::stream_wait(st)); // also completes the public-input copy of job.build
@@ -716,9 +744,13 @@ int phase_open(cstark_ctx *c, ProveArena *a, ProofRun &R, const uint64_t *d_trac
     const size_t o_cpath = off; off += nq * log_N * 32;
     if (2 * (size_t)n_layers + 4 > MAX_GATHER_JOBS) return fail(CSTARK_ERR_UNSUPPORTED, "too many FRI layers for one opening launch");
     GatherList gl;
-    if (d_trace_rows) HIP_TRY(hipMemcpyAsync(o + o_trows, d_trace_rows, nq * W * 8, hipMemcpyDeviceToDevice, st));
-    else gl.rows(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, o + o_trows, (uint32_t)nq, R.log_s());
-    gl.paths(a->tnodes, log_N, a->d_pos, o + o_tpath, (uint32_t)nq);
+    uint32_t trace_lvl0 = 0;
+    if (d_trace_rows) { // sharded: rows and the bottom levels of the paths come from the owning ranks
+        trace_lvl0 = ceil_log2(job.nk);
+        k_split_shard_rows<<<(unsigned)nq, 128, 0, st>>>(d_trace_rows, (uint32_t)W, trace_lvl0, log_N, (uint64_t *)(o + o_trows), (uint64_t *)(o + o_tpath));
+        HIP_TRY(hipGetLastError());
+    } else gl.rows(a->lde, (uint32_t)W, log_n, log_b, a->d_pos, o + o_trows, (uint32_t)nq, R.log_s());
+    gl.paths(a->tnodes, log_N, a->d_pos, o + o_tpath, (uint32_t)nq, nullptr, trace_lvl0);
     gl.rows(a->clde, (uint32_t)ce, log_n, log_b, a->d_pos, o + o_crows, (uint32_t)nq);
     gl.paths(a->cnodes, log_N, a->d_pos, o + o_cpath, (uint32_t)nq);
     std::vector<size_t> o_lrows(n_layers), o_lpath(n_layers);
@@ -1033,7 +1065,6 @@ int gather_roots(cstark_ctx *c, ProveArena *a, AirJob &job, uint32_t reg0 = 58) 
     return CSTARK_OK;
 }
 
-unsigned ceil_log2(uint64_t x) { unsigned l = 0; while ((1ull << l) < x) l++; return l; }
 
 // ---- TransactionAir ---------------------------------------------------------------------------------------------------------------
 int tx_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
@@ -1565,6 +1596,7 @@ int cstark_tx_shard_commit(cstark_ctx *c, const cstark_options *opt, uint32_t k0
     return rc;
 }
 uint32_t cstark_tx_shard_rows(uint32_t nk) { return (nk == 1 || nk == 2 || nk == 4) ? shard_rows(nk) : 0; }
+uint32_t cstark_tx_shard_open_words(uint32_t nk) { return (nk == 1 || nk == 2 || nk == 4) ? CSTARK_TX_TRACE_WIDTH + 4 * ceil_log2(nk) : 0; }
 int cstark_tx_shard_evaluate(cstark_ctx *c, const uint8_t *d_leaves_all, uint64_t *d_combined_local, uint32_t rows) {
     ProofRun *R;
     RC_TRY(shard_run(c, 1, &R));
@@ -1598,7 +1630,9 @@ int cstark_tx_shard_open_rows(cstark_ctx *c, const uint32_t *positions, uint32_t
         if (positions[q] >= N) return fail(CSTARK_ERR_INVALID_ARG, "cstark_tx_shard_open_rows: position outside the LDE domain");
     ProveArena *a = c->arena;
     HIP_TRY(hipMemcpyAsync(a->d_pos, positions, nq * 4, hipMemcpyHostToDevice, c->stream));
-    k_gather_rows_window<<<nq, 128, 0, c->stream>>>(a->lde, R->job.width, R->job.log_n, 3, R->job.k0, R->job.nk, a->d_pos, d_rows);
+    const uint32_t log_nk = ceil_log2(R->job.nk);
+    const uint64_t *sub = log_nk ? (const uint64_t *)a->extra[45] : nullptr; // the rank's subtree heap (phase_commit)
+    k_gather_rows_window<<<nq, 128, 0, c->stream>>>(a->lde, R->job.width, R->job.log_n, 3, R->job.k0, R->job.nk, a->d_pos, d_rows, sub, log_nk);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream)); // the caller's positions may be transient
     return CSTARK_OK;

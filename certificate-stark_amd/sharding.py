@@ -3,7 +3,8 @@
 The b-times larger LDE domain is the union of b cosets of the trace domain; LDE index i = b*j + k belongs to coset k
 and the constraint frame pairs row i with row i + b (same coset), so extension, row hashing and constraint evaluation
 need no halo.  Rank r owns cosets [k0, k0 + nk).  Two real exchange steps remain, both all-gathers:
-  * leaf digests  (n * nk * 32 bytes per rank)  -> every rank (or rank 0) builds the Merkle tree
+  * subtree roots of the trace tree (n * 32 bytes per rank: a rank's nk leaves of a row are a complete subtree, whose bottom
+    log2(nk) levels it hashes itself) -> every rank builds the upper levels of the Merkle tree
   * combined constraint evaluations (n * nk * 8 bytes per rank) -> composition polynomial
 The functions work on any torch.distributed backend/device (RCCL on GPUs; gloo on CPU tensors in the tests).
 
@@ -75,7 +76,7 @@ def prove_sharded(backend, options, group=None):
     (certificate_stark_amd.backend.Backend over the C ABI; the CPU tests pass a stand-in built on the oracle)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     k0, nk = coset_range(rank, world, 8)
-    leaves = all_gather_cosets(backend.shard_commit(options, k0, nk), group)       # C2: [8][n][32] digests, coset-major
+    leaves = all_gather_cosets(backend.shard_commit(options, k0, nk), group)       # C2: [world][n][32] subtree roots, rank-major
     combined = all_gather_cosets(backend.shard_evaluate(leaves), group)            # C3: [8][n] merged evaluations
     if rank == 0:
         positions = backend.shard_compose(combined)
@@ -84,5 +85,5 @@ def prove_sharded(backend, options, group=None):
     src = dist.get_global_rank(group, 0) if group is not None else 0
     broadcast_(positions, src, group)
     rows = backend.shard_open_rows(positions)
-    reduce_sum_(rows, src, group)                                                   # every row is nonzero on exactly one rank
+    reduce_sum_(rows, src, group)                                                   # every row (+ path bottom) is nonzero on exactly one rank
     return backend.shard_finish(rows) if rank == 0 else None

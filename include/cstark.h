@@ -282,8 +282,10 @@ int cstark_rescue_chain_periodic_columns(uint64_t *out);
  * Every rank (one process per GPU, one cstark_ctx each) uploads the same witness and calls the phases in this order; the caller
  * moves three device buffers between the ranks -- RCCL collectives, see certificate-stark_amd/sharding.py.  Rank r of W in {2, 4, 8}
  * owns the nk = 8 / W cosets [k0, k0 + nk), k0 = r nk.  The proof bytes equal cstark_tx_prove's bit for bit.
- *   1 cstark_tx_shard_commit     trace + interpolation (replicated), extension and row hashes of the rank's cosets;
- *                                d_leaves_local [nk][n][32]               -> all-gather -> d_leaves_all [8][n][32] (coset-major)
+ *   1 cstark_tx_shard_commit     trace + interpolation (replicated), extension and row hashes of the rank's cosets.  The rank's nk leaves
+ *                                of a row are a complete subtree of the trace tree: it hashes the bottom log2(nk) levels itself and hands
+ *                                over the subtree roots, d_leaves_local [n][32] -> all-gather -> d_leaves_all [W][n][32] (rank-major):
+ *                                32 n bytes per rank at every world size (34 MB at 2^20 steps)
  *   2 cstark_tx_shard_evaluate   trace tree + root (every rank: the channel is replayed everywhere), coefficients, the rank's share of the
  *                                merged constraint evaluations: d_combined_local [R][n], R = cstark_tx_shard_rows(nk)
  *                                -> all-gather -> d_combined_all [W][R][n].  W = 8: R = 1, the rank's coset evaluated point by point.
@@ -293,10 +295,12 @@ int cstark_rescue_chain_periodic_columns(uint64_t *out);
  *   3 cstark_tx_shard_compose    rank 0 only (it owns coset 0, which the DEEP composition reads): sums the shares into the merged
  *                                evaluations of all cosets, composition polynomial and its commitment, out-of-domain frame, DEEP, FRI;
  *                                positions[num_queries] (host) -> broadcast
- *   4 cstark_tx_shard_open_rows  every rank: the opened rows of the extended trace that lie in its cosets, zeros elsewhere;
- *                                d_rows [nq][94] -> all-reduce (sum) -> complete rows
+ *   4 cstark_tx_shard_open_rows  every rank: the opened rows of the extended trace that lie in its cosets, each followed by the bottom
+ *                                log2(nk) siblings of its authentication path (the levels only the owner holds), zeros elsewhere;
+ *                                d_rows [nq][cstark_tx_shard_open_words(nk)] -> all-reduce (sum) -> complete rows and path bottoms
  *   5 cstark_tx_shard_finish     rank 0: paths, remaining openings, proof bytes. */
 uint32_t cstark_tx_shard_rows(uint32_t nk); /* rows of n evaluations a rank with nk cosets contributes in phase 2 (0: invalid nk) */
+uint32_t cstark_tx_shard_open_words(uint32_t nk); /* 64-bit words per query in phase 4: 94 + 4 log2(nk) (0: invalid nk) */
 int cstark_tx_shard_commit(cstark_ctx *ctx, const cstark_options *opt, uint32_t k0, uint32_t nk, uint8_t *d_leaves_local);
 /* rows / total_rows: the row counts the caller sized d_combined_local ([rows][n]) and d_combined_all ([total_rows][n]) by; a value other
  * than cstark_tx_shard_rows(nk) / W * cstark_tx_shard_rows(nk) is refused before anything is written (version 0.2 of this library). */

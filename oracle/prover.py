@@ -187,22 +187,29 @@ class ShardedProver:
         self.H = lambda data: O.digest(data, hash_fn)
 
     def commit(self):
-        """trace + interpolation (replicated), extension and row hashes of the owned cosets -> digests [nk][n][32]"""
+        """trace + interpolation (replicated), extension and row hashes of the owned cosets.  The nk leaves b j + k0 .. b j + k0 + nk - 1 of
+        row j are a complete subtree of the trace tree: the rank hashes its bottom log2(nk) levels itself and hands over the n subtree
+        roots, [1][n][32] -- the same 32 n bytes at every world size (the subtree's lower nodes stay here for the openings)."""
         hash_fn = self.options[3]
         self.trace = self.job.build()
         self.n = self.trace.shape[1]
         self.log_n = self.n.bit_length() - 1
         self.coeffs = O.interpolate_columns(self.trace.copy())
         self.lde = O.lde_columns(self.coeffs, self.log_b, k0=self.k0, nk=self.nk)
-        return np.stack([O.hash_rows(self.lde[i:i + 1], 0, hash_fn=hash_fn) for i in range(self.nk)])
+        log_nk = self.nk.bit_length() - 1
+        leaves = O.hash_rows(self.lde, log_nk, hash_fn=hash_fn)                      # leaf nk j + (k - k0): a tree of its own
+        self.sub = O.merkle_build(leaves, hash_fn)                                    # heap: leaves at [nk n, 2 nk n); the level with n nodes at [n, 2 n)
+        return np.ascontiguousarray(self.sub[self.n:2 * self.n]).reshape(1, self.n, 32)
 
-    def evaluate(self, leaves_all):
-        """leaves_all [b][n][32] coset-major -> tree, channel, coefficients, merged evaluations: [ce][n] on the constraint-evaluation
-        domain (one rank), or of the owned cosets (several ranks)"""
+    def evaluate(self, roots_all):
+        """roots_all [world][n][32]: every rank's subtree roots -> the upper levels of the tree, channel, coefficients, merged evaluations:
+        [ce][n] on the constraint-evaluation domain (one rank), or of the owned cosets (several ranks)"""
         nq, blowup, grinding, hash_fn, ext, folding, max_rem = self.options
         n, log_n, trace, b = self.n, self.log_n, self.trace, self.b
-        natural = np.ascontiguousarray(np.transpose(leaves_all, (1, 0, 2))).reshape(b * n, 32)  # leaf b j + k
-        self.tnodes = O.merkle_build(natural, hash_fn)
+        world = roots_all.shape[0]
+        assert world * self.nk == b
+        upper = np.ascontiguousarray(np.transpose(roots_all, (1, 0, 2))).reshape(world * n, 32)  # node of the level with world n nodes: world j + r
+        self.tnodes = O.merkle_build(upper, hash_fn)  # the tree's levels from there up: the same heap indices as the whole tree's top
         self.trace_root = self.tnodes[1].tobytes()
         self.log_rem = max_rem.bit_length() - 1
         job = self.job
@@ -301,18 +308,28 @@ class ShardedProver:
         return np.array(self.positions, np.uint32)
 
     def open_rows(self, positions):
-        """rows of the extended trace at the positions that lie in the owned cosets, zeros elsewhere: [nq][width]"""
-        out = np.zeros((len(positions), self.job.width), np.uint64)
+        """rows of the extended trace at the positions that lie in the owned cosets, each followed by the bottom log2(nk) siblings of its
+        authentication path (the part of the tree only this rank holds); zeros elsewhere: [nq][width + 4 log2(nk)] words"""
+        log_nk = self.nk.bit_length() - 1
+        out = np.zeros((len(positions), self.job.width + 4 * log_nk), np.uint64)
         for q, p in enumerate(positions):
             k, j = int(p) & (self.b - 1), int(p) >> self.log_b
             if self.k0 <= k < self.k0 + self.nk:
-                out[q] = self.lde[k - self.k0, :, j]
+                out[q, :self.job.width] = self.lde[k - self.k0, :, j]
+                li = self.nk * self.n + j * self.nk + (k - self.k0)   # the leaf in the rank's own heap
+                for lvl in range(log_nk):
+                    out[q, self.job.width + 4 * lvl:self.job.width + 4 * lvl + 4] = np.frombuffer(self.sub[(li >> lvl) ^ 1].tobytes(), np.uint64)
         return out
 
     def finish(self, rows):
-        """rows [nq][width] complete -> proof bytes (layout: include/cstark.h)"""
+        """rows [nq][width + 4 log2(nk)] complete (summed over the ranks) -> proof bytes (layout: include/cstark.h)"""
         positions, log_n, log_f, folding = self.positions, self.log_n, self.log_f, self.options[5]
         log_N = log_n + self.log_b
+        log_nk, W = self.nk.bit_length() - 1, self.job.width
+
+        def trace_path(q, pos):  # bottom levels from the owning rank, the rest from the upper tree (its leaves: the subtree roots)
+            low = b"".join(np.ascontiguousarray(rows[q, W + 4 * lvl:W + 4 * lvl + 4]).tobytes() for lvl in range(log_nk))
+            return low + _path(self.tnodes, log_N - log_nk, pos >> log_nk)
 
         def row(tab, pos):  # tab [b][width][n] coset-major
             return np.ascontiguousarray(tab[pos & (self.b - 1), :, pos >> self.log_b]).tobytes()
@@ -321,7 +338,7 @@ class ShardedProver:
         out = [b"CSTK", struct.pack("<IIIII", 1, self.job.air, self.job.width, log_n, self.job.item), struct.pack("<7I", *self.options),
                self.trace_root, self.cons_root, struct.pack("<I", len(roots))] + roots + [self.rem_commit, self.ood_trace.tobytes(),
                                                                                          self.ood_comp.tobytes(), struct.pack("<Q", self.nonce)]
-        out += [np.ascontiguousarray(rows[q]).tobytes() for q in range(len(positions))] + [_path(self.tnodes, log_N, p) for p in positions]
+        out += [np.ascontiguousarray(rows[q, :W]).tobytes() for q in range(len(positions))] + [trace_path(q, p) for q, p in enumerate(positions)]
         out += [row(self.clde, p) for p in positions] + [_path(self.cnodes, log_N, p) for p in positions]
         cur, lg = positions, log_N
         for l in range(len(self.layers)):
@@ -341,8 +358,8 @@ def _prove_job(job, options):
     if options[4] in (1, 2):
         return prove_ext(job, options)
     p = ShardedProver(None, options, job=job)
-    leaves = p.commit()
-    combined = p.evaluate(leaves)
+    roots = p.commit()
+    combined = p.evaluate(roots)
     positions = p.compose(combined)
     return p.finish(p.open_rows(positions))
 

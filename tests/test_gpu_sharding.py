@@ -72,7 +72,7 @@ def test_phases_out_of_order_are_refused():
     b.upload_witness(TransactionMetadata.build_random(2, 3, seed=5))
     b._shard_options, b._shard_nk = ProofOptions(), 4
     with pytest.raises(CstarkError):
-        b.shard_evaluate(torch.zeros((8, 2048, 32), dtype=torch.uint8, device=b.device))
+        b.shard_evaluate(torch.zeros((2, 2048, 32), dtype=torch.uint8, device=b.device))
     with pytest.raises(CstarkError):
         b.shard_commit(ProofOptions(), 0, 8)      # a single rank uses cstark_tx_prove
     with pytest.raises(CstarkError):

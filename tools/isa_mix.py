@@ -3,6 +3,7 @@ tools/micro/valu_bench.hip (profiles/r02_valu_issue_bench.txt): 4 SIMD cycles fo
 carry arithmetic, 32-bit multiplies and three-operand VOP3, 2 for the other 32-bit vector instructions.
 
     python tools/isa_mix.py ntt.hip [kernel-substring]
+    python tools/isa_mix.py --csv out.csv file.hip[:substring] ...      kernel, VALU instructions, issue cycles, cycles per instruction
 
 Straight-line kernels only (loops are counted once), so use it for ratios: how much of a kernel's issue time is the
 multiply-adds, how much the glue around them.
@@ -44,8 +45,24 @@ def classify(op):
 
 
 def main():
-    src = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else ""
+    if sys.argv[1] == "--csv":
+        rows, wants = [], collections.OrderedDict()
+        for spec in sys.argv[3:]:  # file.hip:substring -- every file is compiled once
+            src, _, want = spec.partition(":")
+            wants.setdefault(src, []).append(want)
+        for src, ws in wants.items():
+            rows += one(src, ws, quiet=True)
+        with open(sys.argv[2], "w") as f:
+            f.write("kernel,valu_instructions_static,issue_cycles_static,cycles_per_valu_instruction\n")
+            for name, valu, total in rows:
+                f.write('"%s",%d,%d,%.3f\n' % (name, valu, total, total / max(valu, 1)))
+        print(open(sys.argv[2]).read())
+        return
+    one(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
+
+
+def one(src, want, quiet=False):
+    rows = []
     path = src if os.path.exists(src) else os.path.join(B.CSRC, src)
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
@@ -55,7 +72,7 @@ def main():
     kernels = re.findall(r"^(_Z\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M)
     for name, body in kernels:
         dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-        if want and want not in dem:
+        if want and not any(w in dem for w in ([want] if isinstance(want, str) else want)):
             continue
         counts, cycles = collections.Counter(), collections.Counter()
         for line in body.splitlines():
@@ -70,9 +87,12 @@ def main():
         valu = sum(c for k, c in counts.items() if k not in ("mem", "scalar"))
         short = dem.replace("cs::(anonymous namespace)::", "").replace("void ", "").replace("cs::", "")
         short = re.sub(r"\(cs::.*|\((unsigned|const|cs|fp|uint).*", "", short)
-        print("%-44s valu %6d  cycles %7d  " % (short[:44], valu, total) +
+        rows.append((short, valu, total))
+        if not quiet:
+            print("%-44s valu %6d  cycles %7d  " % (short[:44], valu, total) +
               "  ".join("%s %d%%" % (k, round(100.0 * cycles[k] / max(total, 1))) for k in
                         ("mad64", "add64/carry", "cmp64", "mov", "select", "other4", "other2")) + "  mem %d" % counts["mem"])
+    return rows
 
 
 if __name__ == "__main__":

@@ -8,6 +8,7 @@
 #                                   column is 2 * FETCH + WRITE
 #   <tag>_valu_pmc.csv              SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_WAVES, SQ_WAVE_CYCLES, GRBM_GUI_ACTIVE per kernel
 #   <tag>_modmul.txt                tools/modmul_bench.py: raw Montgomery-product rate of the chip
+#   <tag>_<config>_{kernel_stats,hbm_traffic_pmc,valu_pmc}.csv   the same three for merkle_2_18, schnorr_2_18, range_2_16 (tools/bench_air_one.py)
 # rocprofv3 gets the program itself after `--` (python3 bench.py): no env / bash -c hop (the profiler initialises the GPU first).
 set -o pipefail
 TAG=${1:-r02}
@@ -26,3 +27,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 (cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_$TAG/pmc_valu -- python3 $R/bench.py $ARGS > $O/prof_$TAG.pmc_valu.log 2>&1) || exit 1
 python3 tools/pmc_summary.py $O/prof_$TAG $O/$TAG 4   # --steps 3 --warmup 1 = 4 proofs per profiled run
+# BASELINE's sub-AIR configurations (bench.py other_configs): kernel stats and the same counter passes over tools/bench_air_one.py,
+# 4 proofs per run -> <tag>_<config>_{kernel_stats,hbm_traffic_pmc,valu_pmc}.csv (bench.py fills other_configs[*].roofline.traffic from them)
+for CFG in merkle_2_18 schnorr_2_18 range_2_16; do
+  P=$O/prof_${TAG}_$CFG
+  rm -rf $P
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- python3 $R/tools/bench_air_one.py $CFG 4 > $P.stats.log 2>&1) || exit 1
+  cp $(ls $P/stats/*/*kernel_stats.csv | head -1) $O/${TAG}_${CFG}_kernel_stats.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $P/pmc_$c -- python3 $R/tools/bench_air_one.py $CFG 4 > $P.pmc_$c.log 2>&1) || exit 1
+  done
+  (cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $P/pmc_valu -- python3 $R/tools/bench_air_one.py $CFG 4 > $P.pmc_valu.log 2>&1) || exit 1
+  python3 tools/pmc_summary.py $P $O/${TAG}_$CFG 4
+done
