@@ -287,7 +287,9 @@ class PmcValu:
         gui = float(r["GRBM_GUI_ACTIVE_per_dispatch"]) / self.N_XCD
         ns = float(r["avg_ns_under_pmc"])
         e = {"kernel": kernel, "wave_instructions": int(insts), "insts_per_point": round(insts * 64 / points, 1) if points else None,
-             "gui_cycles": int(gui), "clock_ghz": round(gui / ns, 3) if ns else None, "kernel_us_under_pmc": round(ns / 1e3, 1), "source": self.source}
+             "gui_cycles": int(gui), "clock_ghz": round(gui / ns, 3) if ns else None, "kernel_us_under_pmc": round(ns / 1e3, 1), "source": self.source,
+             # bracket: every vector instruction at 4 SIMD cycles (v_mad_u64_u32, 64-bit adds, carries, VOP3) -- the ceiling of the estimate below
+             "frac_of_issue_at_4_cycles": round(insts * 4 / self.N_SIMD / gui, 3) if gui else None}
         cpi = self.cpi.get(kernel)
         if cpi is not None:
             issue = insts * cpi / self.N_SIMD

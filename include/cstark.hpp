@@ -288,6 +288,30 @@ inline std::vector<std::vector<uint8_t>> prove_range_batch(const ProofOptions &o
     for (size_t t = 0; t < numbers.size(); t++) out[t].assign(buf.begin() + t * stride, buf.begin() + t * stride + lens[t]);
     return out;
 }
+// RescueExample of benches/rescue.rs:25-102: a chain of chain_length Rescue hashes from the bench's seed 42..48; the public inputs (seed
+// and result) are read from the trace inside the prover, as RescueProver::get_pub_inputs does (:331-354)
+class RescueExample {
+  public:
+    RescueExample(size_t chain_length, const ProofOptions &options, Context &ctx) : options_(options), chain_length_(chain_length), ctx_(ctx) {
+        if (chain_length < 8 || (chain_length & (chain_length - 1))) throw Error(CSTARK_ERR_INVALID_ARG, "chain length must a power of 2"); // :34-37
+        const unsigned __int128 p = ((unsigned __int128)1 << 62) + ((unsigned __int128)1 << 56) + ((unsigned __int128)1 << 55) + 1;
+        for (int i = 0; i < 7; i++) seed[i] = (BaseElement)((((unsigned __int128)(42 + i)) << 64) % p); // BaseElement::from(42u8 + i): memory form, R = 2^64
+    }
+    std::vector<uint8_t> prove() {
+        const cstark_options o = options_.raw();
+        std::vector<uint8_t> proof(2 * cstark_tx_proof_size_bound((uint32_t)((chain_length_ + 127) / 128), &o));
+        size_t len = 0;
+        check(cstark_rescue_prove(ctx_.raw(), &o, seed, (uint32_t)chain_length_, proof.data(), proof.size(), &len));
+        proof.resize(len);
+        return proof;
+    }
+    BaseElement seed[7];
+
+  private:
+    ProofOptions options_;
+    size_t chain_length_;
+    Context &ctx_;
+};
 // schnorr::SchnorrExample (src/schnorr/mod.rs:52-186)
 class SchnorrExample {
   public:

@@ -45,6 +45,11 @@ int main(int argc, char **argv) {
             dump(prefix + ".range", proofs[1].data(), proofs[1].size());
         }
         if (!batch_ok) { std::fprintf(stderr, "batched range proofs differ from the single proofs\n"); return 4; }
+        {   // the rescue bench's example at its own options (benches/rescue.rs:370-378: blowup 4), chain length 16
+            cstark::RescueExample rescue(16, cstark::ProofOptions(42, 4, 0, cstark::HashFunction::Blake3_256, cstark::FieldExtension::None, 4, 256), ctx);
+            const std::vector<uint8_t> rp = rescue.prove();
+            dump(prefix + ".rescue", rp.data(), rp.size());
+        }
         // several proofs in flight on one GPU: every proof equals the one proved alone; a bad witness fails its own future only
         bool pool_ok = true;
         {

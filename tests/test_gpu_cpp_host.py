@@ -30,6 +30,13 @@ def test_cpp_host_mirror_proves_and_matches_python_host(tmp_path):
     assert V.verify(proof, pub[:7], pub[7:], options=[42, 8, 0, 0, 0, 4, 256])
     golden = np.load(os.path.join(ROOT, "tests", "golden", "proof_2tx_d3.npz"))
     assert proof == golden["proof"].tobytes()
+    # cstark::RescueExample(16, blowup 4): the bytes of the CPU prover, accepted by the restated verifier
+    from oracle import oracle as O
+    from oracle import prover as OP
+    seed = O.to_mont(np.arange(42, 49, dtype=np.uint64))
+    rp = open(prefix + ".rescue", "rb").read()
+    assert rp == OP.prove_air(O.AIR_RESCUE_CHAIN, (seed, 16), (42, 4, 0, 0, 0, 4, 256))
+    assert V.verify_rescue(rp, seed, O.rescue_chain_build_trace(seed, 16)[:7, -1].copy())
 
 
 def test_cpp_host_mirror_compiles():

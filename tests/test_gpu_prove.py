@@ -294,3 +294,31 @@ def test_direct_and_split_prover_paths_give_the_same_bytes():
     got = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert got.returncode == 0, got.stderr[-2000:]
     assert got.stdout.strip().splitlines()[-1] == want
+
+
+def _channel_digests():
+    """sha256 of TransactionAir proofs the device-side channel covers (Blake3 coin, base field, no proof of work) at several sizes and
+    option sets, on a fresh backend: printed by the child process of the test below, computed in-process by the test itself."""
+    import hashlib
+    from certificate_stark_amd.prover import ProofOptions, TransactionMetadata
+    out = []
+    for n_tx, depth, opts in [(2, 3, (42, 8, 0, 0, 0, 4, 256)), (8, 15, (96, 8, 0, 0, 0, 4, 128)), (4, 7, (28, 16, 0, 0, 0, 8, 1024)), (16, 15, (128, 8, 0, 0, 0, 16, 256))]:
+        tx = example(n_tx, depth, options=ProofOptions(*opts), seed=300 + n_tx)
+        out.append(hashlib.sha256(tx.prove()).hexdigest())
+    return out
+
+
+def test_host_and_device_channel_give_the_same_bytes():
+    """Round 4: the Fiat-Shamir channel of these proofs runs on the device (csrc/channel.hip: seed, reseeds, draws, query positions and
+    their folds); CSTARK_HOST_CHANNEL=1 -- read once per process -- keeps the C++ host channel.  Both must write the same proofs (and
+    test_proof_bytes_equal_the_cpu_restatement compares the device channel with the CPU prover)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_gpu_prove import _channel_digests\n"
+            "print(' '.join(_channel_digests()))\n") % (root, os.path.join(root, "tests"))
+    got = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTARK_HOST_CHANNEL="1"), capture_output=True, text=True, timeout=600)
+    assert got.returncode == 0, got.stderr[-2000:]
+    assert got.stdout.strip().splitlines()[-1].split() == _channel_digests()

@@ -86,7 +86,7 @@ def one(src, want, quiet=False):
         total = sum(cycles.values())
         valu = sum(c for k, c in counts.items() if k not in ("mem", "scalar"))
         short = dem.replace("cs::(anonymous namespace)::", "").replace("void ", "").replace("cs::", "")
-        short = re.sub(r"\(cs::.*|\((unsigned|const|cs|fp|uint).*", "", short)
+        short = re.sub(r"\(.*$", "", short).strip()  # the name as the profiler's per-kernel summaries (tools/pmc_summary.py) spell it
         rows.append((short, valu, total))
         if not quiet:
             print("%-44s valu %6d  cycles %7d  " % (short[:44], valu, total) +
