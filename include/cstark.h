@@ -78,13 +78,13 @@ typedef struct cstark_tx_witness {
 
 /* Mirror of the 7 ProofOptions fields (src/lib.rs:78-86). */
 typedef struct cstark_options {
-    uint32_t num_queries;      /* 42 */
-    uint32_t blowup_factor;    /* 8 */
+    uint32_t num_queries;      /* 42; 1..128 */
+    uint32_t blowup_factor;    /* 8; 2, 4, 8 or 16 and at least the AIR's constraint-evaluation blowup (see cstark_tx_prove) */
     uint32_t grinding_factor;  /* 0; up to 32 bits of proof of work (Blake3 coin, 12 bits and more: searched on the device) */
     uint32_t hash_fn;          /* 0 = Blake3_256, 1 = Sha3_256 */
     uint32_t field_extension;  /* 0 = None, 1 = Quadratic, 2 = Cubic */
-    uint32_t fri_folding_factor; /* 4 */
-    uint32_t fri_max_remainder;  /* 256 */
+    uint32_t fri_folding_factor; /* 4; 4, 8 or 16 */
+    uint32_t fri_max_remainder;  /* 256; 128, 256, 512 or 1024 */
 } cstark_options;
 
 /* Composition coefficients for the constraint-evaluation driver (what the engine draws from the
