@@ -21,7 +21,12 @@ ORACLE = os.path.join(ROOT, "oracle", "_build", "libcs_oracle_flip.so")
 TESTS = ["tests/test_gpu_prove.py::test_proof_bytes_equal_the_cpu_restatement", "tests/test_gpu_prove.py::test_one_context_across_options_reuses_its_arena_safely",
          "tests/test_gpu_prove.py::test_transaction_basic_proof_verification", "tests/test_gpu_prove.py::test_transaction_basic_proof_verification_fail",
          "tests/test_gpu_commit.py", "tests/test_gpu_composition.py", "tests/test_gpu_prove_small_airs.py", "tests/test_gpu_baseline_configs.py::test_long_range_proof_verifies",
-         "tests/test_gpu_sharding.py::test_sharded_proof_equals_single_gpu_proof"]
+         "tests/test_gpu_sharding.py::test_sharded_proof_equals_single_gpu_proof",
+         # round 4: the device-side channel (every TransactionAir proof of these files with the Blake3 coin and no proof of work), the other blowup /
+         # folding factors, RescueAir
+         "tests/test_gpu_prove.py::test_host_and_device_channel_give_the_same_bytes", "tests/test_gpu_options.py::test_transaction_proof_bytes_over_options",
+         "tests/test_gpu_options.py::test_merkle_proof_bytes_over_options", "tests/test_gpu_options.py::test_range_proof_bytes_over_options",
+         "tests/test_gpu_options.py::test_schnorr_proof_bytes_over_options", "tests/test_gpu_rescue_chain.py::test_proof_bytes_and_verification"]
 
 
 def build(defs):
