@@ -363,6 +363,13 @@ void cstark_ctx_destroy(cstark_ctx *c) {
     for (PeriodicTable &t : c->periodic) { (void)hipFree(t.tab); (void)hipFree(t.coset); (void)hipFree(t.binv); }
     for (PeriodicTable &t : c->small_periodic) (void)hipFree(t.tab);
     for (cs::AssertInverseTable &t : c->assert_inv) (void)hipFree(t.tab);
+    for (cs::AirCombineStatic &t : c->air_static) (void)hipFree(t.d_static);
+    if (c->air_coef_buf) (void)hipFree(c->air_coef_buf);
+    if (c->air_coef_stage) (void)hipHostFree(c->air_coef_stage);
+    if (c->air_coef_ev) (void)hipEventDestroy(c->air_coef_ev);
+    if (c->deep_buf) (void)hipFree(c->deep_buf);
+    if (c->deep_stage) (void)hipHostFree(c->deep_stage);
+    if (c->deep_ev) (void)hipEventDestroy(c->deep_ev);
     if (c->desc_buf) (void)hipFree(c->desc_buf);
     if (c->rb_dev) (void)hipFree(c->rb_dev);
     if (c->shard_bit37) (void)hipFree(c->shard_bit37);
@@ -538,22 +545,30 @@ int cstark_deep_composition(cstark_ctx *c, const uint64_t *d_trace_lde, const ui
     HIP_TRY(hipSetDevice(c->device));
     const NttPlan *plan;
     RC_TRY(get_plan(c, log_n, &plan));
-    const size_t b = (size_t)1 << log_blowup, nco = 2 * (size_t)width + n_comp;
-    std::vector<uint64_t> blk(2 * nco + b);
-    memcpy(blk.data(), alpha, width * 8); memcpy(blk.data() + width, beta, width * 8); memcpy(blk.data() + 2 * width, delta, n_comp * 8);
-    memcpy(blk.data() + nco, ood_trace, 2 * (size_t)width * 8); memcpy(blk.data() + nco + 2 * width, ood_comp, n_comp * 8);
+    const size_t b = (size_t)1 << log_blowup, nco = 2 * (size_t)width + n_comp, words = 2 * nco + b;
+    // coefficients | frame | coset offsets through a pinned staging block into a device block of the context: no wait between the upload
+    // and the launch (round 3 uploaded from a transient vector and waited)
+    if (c->deep_words < words) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->deep_buf) { HIP_TRY(hipFree(c->deep_buf)); c->deep_buf = nullptr; }
+        if (c->deep_stage) { HIP_TRY(hipHostFree(c->deep_stage)); c->deep_stage = nullptr; }
+        c->deep_words = 0;
+        HIP_TRY(hipMalloc((void **)&c->deep_buf, words * 8));
+        HIP_TRY(hipHostMalloc((void **)&c->deep_stage, words * 8, hipHostMallocDefault));
+        if (!c->deep_ev) HIP_TRY(hipEventCreateWithFlags(&c->deep_ev, hipEventDisableTiming));
+        c->deep_words = words;
+    } else {
+        HIP_TRY(hipEventSynchronize(c->deep_ev));
+    }
+    uint64_t *blk = c->deep_stage;
+    memcpy(blk, alpha, width * 8); memcpy(blk + width, beta, width * 8); memcpy(blk + 2 * width, delta, n_comp * 8);
+    memcpy(blk + nco, ood_trace, 2 * (size_t)width * 8); memcpy(blk + nco + 2 * width, ood_comp, n_comp * 8);
     const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
     uint64_t shift = cs::host::lde_offset();
     for (size_t k = 0; k < b; k++) { blk[2 * nco + k] = shift; shift = cs::host::mul(shift, wbn); }
-    const size_t bytes = blk.size() * 8;
-    if (bytes > c->desc_bytes) {
-        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); c->desc_buf = nullptr; c->desc_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->desc_buf, bytes));
-        c->desc_bytes = bytes;
-    }
-    HIP_TRY(hipMemcpyAsync(c->desc_buf, blk.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(cs::stream_wait(c->stream));
-    const uint64_t *d = (const uint64_t *)c->desc_buf;
+    HIP_TRY(hipMemcpyAsync(c->deep_buf, blk, words * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->deep_ev, c->stream));
+    const uint64_t *d = c->deep_buf;
     cs::DeepParams p{};
     p.trace_lde = d_trace_lde; p.comp_lde = d_comp_lde; p.w = plan->w; p.coef = d; p.ood = d + nco; p.shifts = d + 2 * nco; p.out = d_out;
     p.z = z; p.zw = cs::host::mul(z, cs::host::root_of_unity(log_n)); p.zb = cs::host::pow(z, n_comp);
@@ -1373,108 +1388,138 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
     bool needs_avals = false;
     for (int32_t q : s.a_seq) needs_avals |= q >= 0;
     if (needs_avals && (!d_avals_lde || n_avals == 0)) return fail(CSTARK_ERR_INVALID_ARG, "this AIR has sequence assertions: pass the extended value polynomials");
+    if (b > 8) return fail(CSTARK_ERR_UNSUPPORTED, "cstark_air_combine: blowup factor at most 8");
     HIP_TRY(hipSetDevice(c->device));
     const NttPlan *plan;
     RC_TRY(get_plan(c, log_n, &plan));
-    const uint64_t wn = cs::host::root_of_unity(log_n);
-    // one device block of u64: t_alpha | t_beta | b_alpha | b_beta | a_value | shifts, then u32: a_reg | a_seq | t_grp | a_grp
-    cs::AirCombineParams p{};
-    std::vector<uint32_t> t_grp(nc), a_grp(na);
-    for (size_t i = 0; i < nc; i++) { // distinct degree adjustments
-        const uint64_t adj = CSTARK_CONV_TRANSITION_ADJUSTMENT(ce, n, s.eval_degree(i, n));
-        uint32_t g = 0;
-        while (g < p.n_tgrp && p.tgrp_adj[g] != adj) g++;
-        if (g == p.n_tgrp) {
-            if (g == cs::AIR_MAX_GROUPS) return fail(CSTARK_ERR_UNSUPPORTED, "too many distinct constraint degrees");
-            p.tgrp_adj[p.n_tgrp++] = adj;
+    // ---- everything that depends on (AIR, trace length, blowup) only: degree / divisor groups, the powers of the coset offsets, the
+    // assertion tables on the device, the cached divisor inverses -- built once per context and key (round 3 rebuilt it per call: ~150
+    // modular exponentiations and a blocking upload between the trace root and the evaluation launches of EVERY sub-AIR proof)
+    cs::AirCombineStatic *st = nullptr;
+    for (cs::AirCombineStatic &q : c->air_static)
+        if (q.air == air && q.n_items == n_items && q.log_n == log_n && q.log_b == log_blowup) st = &q;
+    if (!st) {
+        cs::AirCombineStatic q{};
+        q.air = air; q.n_items = n_items; q.log_n = log_n; q.log_b = log_blowup;
+        cs::AirCombineParams &p = q.p;
+        const uint64_t wn = cs::host::root_of_unity(log_n);
+        q.t_grp.resize(nc);
+        std::vector<uint32_t> a_grp(na);
+        for (size_t i = 0; i < nc; i++) { // distinct degree adjustments
+            const uint64_t adj = CSTARK_CONV_TRANSITION_ADJUSTMENT(ce, n, s.eval_degree(i, n));
+            uint32_t g = 0;
+            while (g < p.n_tgrp && p.tgrp_adj[g] != adj) g++;
+            if (g == p.n_tgrp) {
+                if (g == cs::AIR_MAX_GROUPS) return fail(CSTARK_ERR_UNSUPPORTED, "too many distinct constraint degrees");
+                p.tgrp_adj[p.n_tgrp++] = adj;
+            }
+            q.t_grp[i] = g;
         }
-        t_grp[i] = g;
-    }
-    for (size_t a = 0; a < na; a++) { // distinct assertion divisors x^m - w^(first m)
-        const uint64_t first = s.a_stride.empty() ? (s.a_last[a] ? n - 1 : 0) : s.a_first[a];
-        const uint64_t m = (!s.a_stride.empty() && s.a_stride[a]) ? n / s.a_stride[a] : 1;
-        const uint64_t zc = cs::host::pow(wn, (first * m) % n);
-        uint32_t g = 0;
-        while (g < p.n_agrp && !(p.agrp_m[g] == m && p.agrp_zc[g] == zc)) g++;
-        if (g == p.n_agrp) {
-            if (g == cs::AIR_MAX_GROUPS) return fail(CSTARK_ERR_UNSUPPORTED, "too many distinct assertion divisors");
-            p.agrp_m[g] = m; p.agrp_zc[g] = zc; p.agrp_badj[g] = CSTARK_CONV_BOUNDARY_ADJUSTMENT(ce, n, m);
-            p.n_agrp++;
+        for (size_t a = 0; a < na; a++) { // distinct assertion divisors x^m - w^(first m)
+            const uint64_t first = s.a_stride.empty() ? (s.a_last[a] ? n - 1 : 0) : s.a_first[a];
+            const uint64_t m = (!s.a_stride.empty() && s.a_stride[a]) ? n / s.a_stride[a] : 1;
+            const uint64_t zc = cs::host::pow(wn, (first * m) % n);
+            uint32_t g = 0;
+            while (g < p.n_agrp && !(p.agrp_m[g] == m && p.agrp_zc[g] == zc)) g++;
+            if (g == p.n_agrp) {
+                if (g == cs::AIR_MAX_GROUPS) return fail(CSTARK_ERR_UNSUPPORTED, "too many distinct assertion divisors");
+                p.agrp_m[g] = m; p.agrp_zc[g] = zc; p.agrp_badj[g] = CSTARK_CONV_BOUNDARY_ADJUSTMENT(ce, n, m);
+                p.n_agrp++;
+            }
+            a_grp[a] = g;
         }
-        a_grp[a] = g;
+        // device block of the static part: shifts[b] (u64), then u32: a_reg | a_seq | a_grp | t_grp
+        std::vector<uint64_t> blk(b + (3 * na + nc + 1) / 2 + 1);
+        const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
+        {
+            uint64_t shift = cs::host::lde_offset();
+            for (uint64_t k = 0; k < b; k++) { blk[k] = shift; shift = cs::host::mul(shift, wbn); }
+        }
+        uint32_t *q32 = (uint32_t *)(blk.data() + b);
+        for (size_t a = 0; a < na; a++) q32[a] = s.a_reg[a];
+        for (size_t a = 0; a < na; a++) ((int32_t *)q32)[na + a] = s.a_seq.empty() ? -1 : s.a_seq[a];
+        for (size_t a = 0; a < na; a++) q32[2 * na + a] = a_grp[a];
+        for (size_t i = 0; i < nc; i++) q32[3 * na + i] = q.t_grp[i];
+        HIP_TRY(hipMalloc((void **)&q.d_static, blk.size() * 8));
+        HIP_TRY(hipMemcpy(q.d_static, blk.data(), blk.size() * 8, hipMemcpyHostToDevice));
+        p.shifts = q.d_static;
+        p.a_reg = (const uint32_t *)(q.d_static + b); p.a_seq = (const int32_t *)(p.a_reg + na);
+        p.a_grp = p.a_reg + 2 * na; p.t_grp = p.a_reg + 3 * na;
+        p.w = plan->w;
+        p.w_last = cs::host::inv(wn);
+        p.width = s.width; p.n_constraints = (uint32_t)nc; p.n_assertions = (uint32_t)na;
+        p.stride = 1u << (log_blowup - log_ce); p.log_n = log_n;
+        {   // per-coset powers of the coset shift (the kernel completes them with a twiddle-table product per point)
+            uint64_t sh = cs::host::lde_offset();
+            for (uint64_t k = 0; k < b; k++) {
+                for (uint32_t g = 0; g < p.n_tgrp; g++) p.tgrp_shift[k][g] = cs::host::pow(sh, p.tgrp_adj[g]);
+                for (uint32_t g = 0; g < p.n_agrp; g++) {
+                    p.agrp_bshift[k][g] = cs::host::pow(sh, p.agrp_badj[g]);
+                    p.agrp_mshift[k][g] = cs::host::pow(sh, p.agrp_m[g]);
+                }
+                p.zinv_coset[k] = cs::host::inv(cs::host::sub(cs::host::pow(sh, n), cs::host::ONE));
+                sh = cs::host::mul(sh, wbn);
+            }
+        }
+        {   // 1 / (x^m - zc) of every assertion divisor over the domain: cached per (m, zc, trace length, blowup).
+            // CSTARK_AIR_INV_TABLES=0 (tuning / debugging): one inversion per point inside k_air_combine
+            static const bool inv_tables = [] { const char *e = getenv("CSTARK_AIR_INV_TABLES"); return !e || atoi(e) != 0; }();
+            for (uint32_t g = 0; inv_tables && g < p.n_agrp; g++) {
+                const cs::AssertInverseTable *t = nullptr;
+                for (const cs::AssertInverseTable &qq : c->assert_inv)
+                    if (qq.log_n == log_n && qq.log_b == log_blowup && qq.m == p.agrp_m[g] && qq.zc == p.agrp_zc[g]) t = &qq;
+                if (!t) {
+                    cs::AssertInverseTable qq{log_n, log_blowup, p.agrp_m[g], p.agrp_zc[g], nullptr};
+                    HIP_TRY(hipMalloc((void **)&qq.tab, (size_t)b * (n / qq.m) * 8));
+                    uint64_t sm[8] = {};
+                    for (uint64_t k = 0; k < b; k++) sm[k] = p.agrp_mshift[k][g];
+                    const hipError_t e = cs::launch_assert_inverses(qq.tab, plan->w, sm, (unsigned)b, qq.m, qq.zc, log_n, c->stream);
+                    if (e != hipSuccess) { (void)hipFree(qq.tab); HIP_TRY(e); }
+                    c->assert_inv.push_back(qq);
+                    t = &c->assert_inv.back();
+                }
+                p.agrp_inv[g] = t->tab;
+            }
+        }
+        c->air_static.push_back(std::move(q));
+        st = &c->air_static.back();
     }
-    constexpr size_t TXL = 230; // SchnorrAir split evaluation: the transition coefficients once more, laid out alpha[i] | beta[115 + i]
-    std::vector<uint64_t> blk(2 * nc + 3 * na + b + 2 * na + (nc + 1) / 2 + 1 + TXL + cs::MERKLE_RTAB_WORDS);
-    const size_t txl_off = blk.size() - TXL - cs::MERKLE_RTAB_WORDS, mrt_off = blk.size() - cs::MERKLE_RTAB_WORDS; // (device scratch of k_merkle_rounds)
-    if (nc <= 115) {
-        memcpy(blk.data() + txl_off, t_alpha, nc * 8);
-        memcpy(blk.data() + txl_off + 115, t_beta, nc * 8);
+    const std::vector<uint32_t> &t_grp = st->t_grp;
+    // ---- per proof: coefficients and assertion values through a pinned staging block into the context's device block, no wait:
+    // t_alpha | t_beta | b_alpha | b_beta | a_value | the transition coefficients once more in the cstark_tx_coeffs layout (SchnorrAir's
+    // split evaluation reads alpha[i] at word i, beta[i] at word 115 + i) | device scratch of k_merkle_rounds
+    constexpr size_t TXL = 230;
+    const size_t words = 2 * nc + 3 * na + TXL, total = words + cs::MERKLE_RTAB_WORDS;
+    const size_t txl_off = 2 * nc + 3 * na, mrt_off = words;
+    if (c->air_coef_words < total) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->air_coef_buf) { HIP_TRY(hipFree(c->air_coef_buf)); c->air_coef_buf = nullptr; }
+        if (c->air_coef_stage) { HIP_TRY(hipHostFree(c->air_coef_stage)); c->air_coef_stage = nullptr; }
+        c->air_coef_words = 0;
+        HIP_TRY(hipMalloc((void **)&c->air_coef_buf, total * 8));
+        HIP_TRY(hipHostMalloc((void **)&c->air_coef_stage, total * 8, hipHostMallocDefault));
+        if (!c->air_coef_ev) HIP_TRY(hipEventCreateWithFlags(&c->air_coef_ev, hipEventDisableTiming));
+        c->air_coef_words = total;
+    } else {
+        HIP_TRY(hipEventSynchronize(c->air_coef_ev)); // the previous upload has left the staging block (long ago, normally)
     }
-    uint64_t *q = blk.data();
-    memcpy(q, t_alpha, nc * 8); q += nc;
-    memcpy(q, t_beta, nc * 8); q += nc;
-    memcpy(q, b_alpha, na * 8); q += na;
-    memcpy(q, b_beta, na * 8); q += na;
-    for (size_t a = 0; a < na; a++) *q++ = s.a_const.empty() ? assertion_values[a] : s.a_const[a];
-    const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
-    uint64_t shift = cs::host::lde_offset();
-    for (uint64_t k = 0; k < b; k++) { *q++ = shift; shift = cs::host::mul(shift, wbn); }
-    uint32_t *q32 = (uint32_t *)q;
-    for (size_t a = 0; a < na; a++) q32[a] = s.a_reg[a];
-    for (size_t a = 0; a < na; a++) ((int32_t *)q32)[na + a] = s.a_seq.empty() ? -1 : s.a_seq[a];
-    for (size_t a = 0; a < na; a++) q32[2 * na + a] = a_grp[a];
-    for (size_t i = 0; i < nc; i++) q32[3 * na + i] = t_grp[i];
-    const size_t bytes = blk.size() * 8;
-    if (bytes > c->desc_bytes) {
-        if (c->desc_buf) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->desc_buf)); c->desc_buf = nullptr; c->desc_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->desc_buf, bytes));
-        c->desc_bytes = bytes;
+    {
+        uint64_t *q = c->air_coef_stage;
+        memcpy(q, t_alpha, nc * 8); q += nc;
+        memcpy(q, t_beta, nc * 8); q += nc;
+        memcpy(q, b_alpha, na * 8); q += na;
+        memcpy(q, b_beta, na * 8); q += na;
+        for (size_t a = 0; a < na; a++) *q++ = s.a_const.empty() ? assertion_values[a] : s.a_const[a];
+        memset(q, 0, TXL * 8);
+        if (nc <= 115) { memcpy(q, t_alpha, nc * 8); memcpy(q + 115, t_beta, nc * 8); }
     }
-    HIP_TRY(hipMemcpyAsync(c->desc_buf, blk.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const uint64_t *d = (const uint64_t *)c->desc_buf;
-    p.lde = d_lde; p.evals = d_evals; p.w = plan->w; p.out = d_out; p.avals = d_avals_lde; p.n_avals = n_avals;
+    HIP_TRY(hipMemcpyAsync(c->air_coef_buf, c->air_coef_stage, words * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->air_coef_ev, c->stream));
+    const uint64_t *d = c->air_coef_buf;
+    cs::AirCombineParams p = st->p;
+    p.lde = d_lde; p.evals = d_evals; p.out = d_out; p.avals = d_avals_lde; p.n_avals = n_avals; p.k0 = k0;
     p.t_alpha = d; p.t_beta = d + nc;
-    const uint64_t *e = d + 2 * nc;
-    p.b_alpha = e; p.b_beta = e + na; p.a_value = e + 2 * na; p.shifts = e + 3 * na;
-    p.a_reg = (const uint32_t *)(e + 3 * na + b); p.a_seq = (const int32_t *)(p.a_reg + na);
-    p.a_grp = p.a_reg + 2 * na; p.t_grp = p.a_reg + 3 * na;
-    p.w_last = cs::host::inv(wn);
-    p.width = s.width; p.n_constraints = (uint32_t)nc; p.n_assertions = (uint32_t)na;
-    p.stride = 1u << (log_blowup - log_ce); p.log_n = log_n; p.k0 = k0;
-    if (b > 8) return fail(CSTARK_ERR_UNSUPPORTED, "cstark_air_combine: blowup factor at most 8");
-    {   // per-coset powers of the coset shift (the kernel completes them with a twiddle-table product per point)
-        uint64_t sh = cs::host::lde_offset();
-        for (uint64_t k = 0; k < b; k++) {
-            for (uint32_t g = 0; g < p.n_tgrp; g++) p.tgrp_shift[k][g] = cs::host::pow(sh, p.tgrp_adj[g]);
-            for (uint32_t g = 0; g < p.n_agrp; g++) {
-                p.agrp_bshift[k][g] = cs::host::pow(sh, p.agrp_badj[g]);
-                p.agrp_mshift[k][g] = cs::host::pow(sh, p.agrp_m[g]);
-            }
-            p.zinv_coset[k] = cs::host::inv(cs::host::sub(cs::host::pow(sh, n), cs::host::ONE));
-            sh = cs::host::mul(sh, wbn);
-        }
-    }
-    {   // 1 / (x^m - zc) of every assertion divisor over the domain: cached per (m, zc, trace length, blowup).
-        // CSTARK_AIR_INV_TABLES=0 (tuning / debugging): one inversion per point inside k_air_combine
-        static const bool inv_tables = [] { const char *e = getenv("CSTARK_AIR_INV_TABLES"); return !e || atoi(e) != 0; }();
-        for (uint32_t g = 0; inv_tables && g < p.n_agrp; g++) {
-            const cs::AssertInverseTable *t = nullptr;
-            for (const cs::AssertInverseTable &q : c->assert_inv)
-                if (q.log_n == log_n && q.log_b == log_blowup && q.m == p.agrp_m[g] && q.zc == p.agrp_zc[g]) t = &q;
-            if (!t) {
-                cs::AssertInverseTable q{log_n, log_blowup, p.agrp_m[g], p.agrp_zc[g], nullptr};
-                HIP_TRY(hipMalloc((void **)&q.tab, (size_t)b * (n / q.m) * 8));
-                uint64_t sm[8] = {};
-                for (uint64_t k = 0; k < b; k++) sm[k] = p.agrp_mshift[k][g];
-                const hipError_t e = cs::launch_assert_inverses(q.tab, plan->w, sm, (unsigned)b, q.m, q.zc, log_n, c->stream);
-                if (e != hipSuccess) { (void)hipFree(q.tab); HIP_TRY(e); }
-                c->assert_inv.push_back(q);
-                t = &c->assert_inv.back();
-            }
-            p.agrp_inv[g] = t->tab;
-        }
-    }
+    p.b_alpha = d + 2 * nc; p.b_beta = d + 2 * nc + na; p.a_value = d + 2 * nc + 2 * na;
     if (d_schnorr_aux_lde) {
         const PeriodicTable *pt;
         RC_TRY(schnorr_periodic(c, log_n, log_blowup, &pt));
@@ -1529,7 +1574,7 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
             // the round gadget of the message hash in the folded form (CSTARK_SCHNORR_ROUNDS=0: inside the frame evaluator)
             static const bool rounds_env = [] { const char *e = getenv("CSTARK_SCHNORR_ROUNDS"); return !e || atoi(e) != 0; }();
             HIP_TRY(cs::launch_schnorr_split_finish(p, d_schnorr_aux_lde, pt->tab, even, odd, t_grp[0], t_grp[6], c->stream,
-                                                    rounds_env ? (uint64_t *)c->desc_buf + mrt_off : nullptr, t_grp[42], final5 ? fin_hi : nullptr));
+                                                    rounds_env ? c->air_coef_buf + mrt_off : nullptr, t_grp[42], final5 ? fin_hi : nullptr));
         } else {
             HIP_TRY(cs::launch_schnorr_fused(p, d_schnorr_aux_lde, pt->tab, nk, c->stream));
         }
@@ -1541,7 +1586,7 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
         // the round gadgets in the folded form of the TransactionAir evaluator (CSTARK_MERKLE_ROUNDS=0: the generic frame evaluator)
         static const bool rounds_env = [] { const char *e = getenv("CSTARK_MERKLE_ROUNDS"); return !e || atoi(e) != 0; }();
         const bool folded = rounds_env && b <= 8 && log_n >= 9;
-        HIP_TRY(cs::launch_merkle_fused(p, pt->tab, nk, c->stream, folded ? (uint64_t *)c->desc_buf + mrt_off : nullptr, t_grp[0]));
+        HIP_TRY(cs::launch_merkle_fused(p, pt->tab, nk, c->stream, folded ? c->air_coef_buf + mrt_off : nullptr, t_grp[0]));
         p.tsum = d_out;
     }
     HIP_TRY(cs::launch_air_combine(p, nk, c->stream));

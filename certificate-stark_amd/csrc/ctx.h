@@ -97,6 +97,15 @@ struct AssertInverseTable {
     uint64_t m, zc;
     uint64_t *tab;
 };
+// what cstark_air_combine needs of an AIR that does not change from proof to proof (capi.hip, air_combine_impl): keyed by
+// (AIR, items, trace length, blowup)
+struct AirCombineStatic {
+    int air;
+    uint32_t n_items, log_n, log_b;
+    AirCombineParams p;          // groups, coset powers, device pointers of the static tables; the per-call fields are patched in
+    std::vector<uint32_t> t_grp; // degree group of every transition constraint (host copy)
+    uint64_t *d_static;          // device: shifts[b] | a_reg | a_seq | a_grp | t_grp
+};
 struct ProveArena; // prove.hip
 void prove_arena_free(ProveArena *a);
 
@@ -120,6 +129,13 @@ struct cstark_ctx {
     void *coef_stage = nullptr;   // pinned host staging of the same block: the upload is asynchronous, no wait for the caller's struct
     hipEvent_t coef_ev = nullptr; // recorded behind the upload; waited on before the staging block is rewritten
     std::deque<cs::AssertInverseTable> assert_inv;  // k_air_combine's divisor inverses, keyed by (m, zc, log_n, log_b)
+    std::deque<cs::AirCombineStatic> air_static;    // cstark_air_combine's per-AIR tables
+    uint64_t *air_coef_buf = nullptr, *air_coef_stage = nullptr; // its per-proof coefficient block (device) and the pinned staging of the upload
+    size_t air_coef_words = 0;
+    hipEvent_t air_coef_ev = nullptr;
+    uint64_t *deep_buf = nullptr, *deep_stage = nullptr; // cstark_deep_composition's coefficient / frame block, likewise
+    size_t deep_words = 0;
+    hipEvent_t deep_ev = nullptr;
     std::deque<cs::PeriodicTable> small_periodic; // standalone sub-AIRs: keyed by (air, depth, log_n, log_b); coset/binv unused
     void *desc_buf = nullptr;     // device copy of a generic AIR description (cstark_air_combine)
     hipEvent_t part_ev[cs::CE_NUM_PARTS + 1] = {}; // optional per-launch timing of the fused constraint evaluation
