@@ -1159,6 +1159,7 @@ int cstark_schnorr_witness_upload(cstark_ctx *c, uint32_t n_sig, const uint64_t 
     c->schnorr_pub.assign(messages, messages + (size_t)n_sig * 28);
     c->schnorr_pub.insert(c->schnorr_pub.end(), sig_rx, sig_rx + (size_t)n_sig * 6);
     c->schnorr_s.assign(sig_s, sig_s + (size_t)n_sig * 32);
+    memset(c->schnorr_seed_key, 0, sizeof c->schnorr_seed_key); // another witness: the cached channel seed is stale
     return CSTARK_OK;
 }
 int cstark_schnorr_build_trace(cstark_ctx *c, uint64_t *d_trace) {
@@ -1371,15 +1372,20 @@ int cstark_schnorr_assertion_polys(cstark_ctx *c, uint64_t *d_out, uint32_t log_
 static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint64_t *d_lde, const uint64_t *d_evals, const uint64_t *t_alpha,
                             const uint64_t *t_beta, const uint64_t *b_alpha, const uint64_t *b_beta, const uint64_t *assertion_values,
                             const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
-                            const uint64_t *d_schnorr_aux_lde, int merkle_depth_fused = -1, bool schnorr_input_is_lde = false) {
+                            const uint64_t *d_schnorr_aux_lde, int merkle_depth_fused = -1, bool schnorr_input_is_lde = false,
+                            const uint64_t *d_coefs = nullptr, const uint64_t *d_avalues = nullptr) {
+    // d_coefs != null (the device-side channel of prove.hip): the coefficients are already on the device, in the cstark_tx_coeffs-like
+    // block alpha[115] | beta[115] | b_alpha[na] | b_beta[na] (what channel.hip draws with stride 115); d_avalues: the assertion values on
+    // the device (null: the AIR's built-in constants)
     const bool fused_merkle = merkle_depth_fused >= 0;
-    if (!c || !d_lde || (!d_evals && !d_schnorr_aux_lde && !fused_merkle) || !t_alpha || !t_beta || !b_alpha || !b_beta || !d_out || nk == 0)
+    if (!c || !d_lde || (!d_evals && !d_schnorr_aux_lde && !fused_merkle) || (!d_coefs && (!t_alpha || !t_beta || !b_alpha || !b_beta)) || !d_out || nk == 0)
         return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: null argument");
     if (d_schnorr_aux_lde && (air != CSTARK_AIR_SCHNORR || log_n < 9)) return fail(CSTARK_ERR_INVALID_ARG, "the fused evaluator is SchnorrAir's");
     if (fused_merkle && (air != CSTARK_AIR_MERKLE_UPDATE || log_n < 9)) return fail(CSTARK_ERR_INVALID_ARG, "the fused evaluator is MerkleAir's");
     cs::host::AirShape s;
     if (!cs::host::air_shape(air, s, n_items)) return fail(CSTARK_ERR_UNSUPPORTED, "AIR not available through the generic entry points");
-    if (s.a_const.empty() && !assertion_values) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: assertion values required");
+    if (s.a_const.empty() && !assertion_values && !d_avalues) return fail(CSTARK_ERR_INVALID_ARG, "cstark_air_combine: assertion values required");
+    if (d_coefs && s.n_constraints > 115) return fail(CSTARK_ERR_UNSUPPORTED, "cstark_air_combine: device coefficient block holds at most 115 constraints");
     const uint32_t log_ce = s.log_ce_blowup();
     if (log_blowup < log_ce || log_blowup > 6 || (uint64_t)k0 + nk > (1ull << log_blowup)) return fail(CSTARK_ERR_INVALID_ARG, "blowup factor below the constraint degree");
     if (log_n < cs::NTT_MIN_LOG_N || log_n > cs::NTT_MAX_LOG_N) return fail(CSTARK_ERR_INVALID_ARG, "bad trace length");
@@ -1428,14 +1434,15 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
             }
             a_grp[a] = g;
         }
-        // device block of the static part: shifts[b] (u64), then u32: a_reg | a_seq | a_grp | t_grp
-        std::vector<uint64_t> blk(b + (3 * na + nc + 1) / 2 + 1);
+        // device block of the static part: shifts[b] | built-in assertion constants[na] (u64), then u32: a_reg | a_seq | a_grp | t_grp
+        std::vector<uint64_t> blk(b + na + (3 * na + nc + 1) / 2 + 1);
         const uint64_t wbn = cs::host::root_of_unity(log_n + log_blowup);
         {
             uint64_t shift = cs::host::lde_offset();
             for (uint64_t k = 0; k < b; k++) { blk[k] = shift; shift = cs::host::mul(shift, wbn); }
         }
-        uint32_t *q32 = (uint32_t *)(blk.data() + b);
+        for (size_t a = 0; a < na; a++) blk[b + a] = s.a_const.empty() ? 0 : s.a_const[a];
+        uint32_t *q32 = (uint32_t *)(blk.data() + b + na);
         for (size_t a = 0; a < na; a++) q32[a] = s.a_reg[a];
         for (size_t a = 0; a < na; a++) ((int32_t *)q32)[na + a] = s.a_seq.empty() ? -1 : s.a_seq[a];
         for (size_t a = 0; a < na; a++) q32[2 * na + a] = a_grp[a];
@@ -1443,7 +1450,7 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
         HIP_TRY(hipMalloc((void **)&q.d_static, blk.size() * 8));
         HIP_TRY(hipMemcpy(q.d_static, blk.data(), blk.size() * 8, hipMemcpyHostToDevice));
         p.shifts = q.d_static;
-        p.a_reg = (const uint32_t *)(q.d_static + b); p.a_seq = (const int32_t *)(p.a_reg + na);
+        p.a_reg = (const uint32_t *)(q.d_static + b + na); p.a_seq = (const int32_t *)(p.a_reg + na);
         p.a_grp = p.a_reg + 2 * na; p.t_grp = p.a_reg + 3 * na;
         p.w = plan->w;
         p.w_last = cs::host::inv(wn);
@@ -1492,6 +1499,7 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
     const size_t words = 2 * nc + 3 * na + TXL, total = words + cs::MERKLE_RTAB_WORDS;
     const size_t txl_off = 2 * nc + 3 * na, mrt_off = words;
     if (c->air_coef_words < total) {
+        if (d_coefs && c->air_coef_words) HIP_TRY(hipEventSynchronize(c->air_coef_ev));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->air_coef_buf) { HIP_TRY(hipFree(c->air_coef_buf)); c->air_coef_buf = nullptr; }
         if (c->air_coef_stage) { HIP_TRY(hipHostFree(c->air_coef_stage)); c->air_coef_stage = nullptr; }
@@ -1500,10 +1508,10 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
         HIP_TRY(hipHostMalloc((void **)&c->air_coef_stage, total * 8, hipHostMallocDefault));
         if (!c->air_coef_ev) HIP_TRY(hipEventCreateWithFlags(&c->air_coef_ev, hipEventDisableTiming));
         c->air_coef_words = total;
-    } else {
+    } else if (!d_coefs) {
         HIP_TRY(hipEventSynchronize(c->air_coef_ev)); // the previous upload has left the staging block (long ago, normally)
     }
-    {
+    if (!d_coefs) {
         uint64_t *q = c->air_coef_stage;
         memcpy(q, t_alpha, nc * 8); q += nc;
         memcpy(q, t_beta, nc * 8); q += nc;
@@ -1512,14 +1520,20 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
         for (size_t a = 0; a < na; a++) *q++ = s.a_const.empty() ? assertion_values[a] : s.a_const[a];
         memset(q, 0, TXL * 8);
         if (nc <= 115) { memcpy(q, t_alpha, nc * 8); memcpy(q + 115, t_beta, nc * 8); }
+        HIP_TRY(hipMemcpyAsync(c->air_coef_buf, c->air_coef_stage, words * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->air_coef_ev, c->stream));
     }
-    HIP_TRY(hipMemcpyAsync(c->air_coef_buf, c->air_coef_stage, words * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->air_coef_ev, c->stream));
     const uint64_t *d = c->air_coef_buf;
     cs::AirCombineParams p = st->p;
     p.lde = d_lde; p.evals = d_evals; p.out = d_out; p.avals = d_avals_lde; p.n_avals = n_avals; p.k0 = k0;
-    p.t_alpha = d; p.t_beta = d + nc;
-    p.b_alpha = d + 2 * nc; p.b_beta = d + 2 * nc + na; p.a_value = d + 2 * nc + 2 * na;
+    if (d_coefs) {
+        p.t_alpha = d_coefs; p.t_beta = d_coefs + 115; p.b_alpha = d_coefs + 230; p.b_beta = d_coefs + 230 + na;
+        p.a_value = d_avalues ? d_avalues : st->d_static + b;
+    } else {
+        p.t_alpha = d; p.t_beta = d + nc;
+        p.b_alpha = d + 2 * nc; p.b_beta = d + 2 * nc + na; p.a_value = d + 2 * nc + 2 * na;
+    }
+    const uint64_t *d_txl = d_coefs ? d_coefs : d + txl_off; // the transition coefficients in the cstark_tx_coeffs layout
     if (d_schnorr_aux_lde) {
         const PeriodicTable *pt;
         RC_TRY(schnorr_periodic(c, log_n, log_blowup, &pt));
@@ -1544,8 +1558,8 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
             RC_TRY(ensure_ws(c, (5 * region + 9 * hcol) * 8));
             uint64_t *even = (uint64_t *)c->ws, *sa = even + region, *sb = sa + region, *sc = sb + region, *odd = sc + region;
             uint64_t *fin_direct = odd + region, *fin_hi = fin_direct + hcol /* [4 odd cosets][3][n] */, *fin_co = fin_hi + 4 * hcol, *fin_scr = fin_co + hcol /* [3] */;
-            HIP_TRY(cs::launch_schnorr_ec_split(p, d_schnorr_aux_lde, d + txl_off, even, c->stream));
-            if (final5) HIP_TRY(cs::launch_schnorr_final_split(p, d + txl_off, even + (size_t)cs::SCHNORR_SPLIT_EC_TABLES * 4 * n, -1, c->stream));
+            HIP_TRY(cs::launch_schnorr_ec_split(p, d_schnorr_aux_lde, d_txl, even, c->stream));
+            if (final5) HIP_TRY(cs::launch_schnorr_final_split(p, d_txl, even + (size_t)cs::SCHNORR_SPLIT_EC_TABLES * 4 * n, -1, c->stream));
             cs::NttArgs a{};
             a.in = even; a.scratch = sa; a.out = sb; a.width = 4 * T; a.batch = 1; a.log_n = log_n;
             a.w = pn->winv; a.post_scale = pn->n_inv; a.do_scale = true; a.inverse = true; a.aux = pn->aux_winv;
@@ -1558,7 +1572,7 @@ static int air_combine_impl(cstark_ctx *c, int air, uint32_t n_items, const uint
             f.in_batch_stride = (size_t)T * n; f.scratch_batch_stride = (size_t)T * n; f.out_batch_stride = (size_t)T * n;
             HIP_TRY(cs::ntt_columns(f, c->stream));
             if (final5) { // H = (T - F) / 2 on LDE coset 1, interpolated there and extended to cosets 3, 5, 7 (as for TransactionAir)
-                HIP_TRY(cs::launch_schnorr_final_split(p, d + txl_off, fin_direct, 1, c->stream));
+                HIP_TRY(cs::launch_schnorr_final_split(p, d_txl, fin_direct, 1, c->stream));
                 HIP_TRY(cs::launch_schnorr_final_hi(p, odd, fin_direct, fin_hi, cs::host::inv(cs::host::from_u64(2)), c->stream));
                 cs::NttArgs hi_inv{};
                 hi_inv.in = fin_hi; hi_inv.scratch = fin_scr; hi_inv.out = fin_co; hi_inv.width = 3; hi_inv.batch = 1; hi_inv.log_n = log_n;
@@ -1621,6 +1635,23 @@ int cstark_schnorr_evaluate_constraints_lde(cstark_ctx *c, uint32_t n_sig, const
     return air_combine_impl(c, CSTARK_AIR_SCHNORR, n_sig, d_lde, nullptr, t_alpha, t_beta, b_alpha, b_beta, nullptr, d_avals_lde, n_avals, d_out, log_n, 3, 0,
                             8, d_aux_lde, -1, true);
 }
+
+} // extern "C"
+// internal (ctx.h): the merged evaluations of a sub-AIR with the coefficients already on the device (drawn there by the device-side
+// channel): d_coefs = alpha[115] | beta[115] | b_alpha[na] | b_beta[na]; d_avalues = the assertion values (null: built-in constants).
+// mode 0: from materialised transition values d_evals; 1: MerkleAir fused (depth); 2: SchnorrAir fused on the prover's own extensions
+int air_combine_dev(cstark_ctx *c, int air, uint32_t n_items, int mode, uint32_t merkle_depth, const uint64_t *d_lde, const uint64_t *d_evals,
+                    const uint64_t *d_aux_lde, const uint64_t *d_coefs, const uint64_t *d_avalues, const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out,
+                    uint32_t log_n, uint32_t log_blowup, uint32_t nk) {
+    if (!d_coefs) return fail(CSTARK_ERR_INVALID_ARG, "air_combine_dev: null argument");
+    if (mode == 1) return air_combine_impl(c, air, n_items, d_lde, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d_out, log_n, log_blowup, 0, nk,
+                                           nullptr, (int)merkle_depth, false, d_coefs, d_avalues);
+    if (mode == 2) return air_combine_impl(c, air, n_items, d_lde, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_avals_lde, n_avals, d_out, log_n, log_blowup, 0,
+                                           nk, d_aux_lde, -1, true, d_coefs, d_avalues);
+    return air_combine_impl(c, air, n_items, d_lde, d_evals, nullptr, nullptr, nullptr, nullptr, nullptr, d_avals_lde, n_avals, d_out, log_n, log_blowup, 0, nk, nullptr,
+                            -1, false, d_coefs, d_avalues);
+}
+extern "C" {
 
 // per-launch timing of the fused constraint evaluation (HIP events on the context's stream)
 int cstark_ctx_set_part_timing(cstark_ctx *c, int enable) {

@@ -149,6 +149,7 @@ struct cstark_ctx {
     std::vector<uint64_t> schnorr_rx; // host copy of the signatures' R.x ([n][6]) for the sequence assertions
     std::vector<uint64_t> schnorr_pub; // messages [n][28] then R.x [n][6]: SchnorrAir's public inputs, for the channel seed
     std::vector<uint8_t> schnorr_s;    // the s halves [n][32]
+    uint8_t schnorr_seed[32] = {}, schnorr_seed_key[12] = {}; // the channel seed of the uploaded Schnorr witness under one option set (key[11] = 1: valid)
     size_t tail_bytes = 0;
     size_t desc_bytes = 0;
     cs::ProveArena *arena = nullptr; // device buffers of cstark_tx_prove (prove.hip)
@@ -175,6 +176,10 @@ int tx_evaluate_constraints_sets(cstark_ctx *c, const uint64_t *d_lde, const cst
                                  uint64_t *const *d_outs, uint32_t merkle_depth, uint32_t log_n, uint32_t log_blowup, uint32_t k0, uint32_t nk,
                                  bool input_is_lde, const uint64_t *d_pub = nullptr);
 int tx_coef_device_block(cstark_ctx *c, uint64_t **d_coef);
+// internal (capi.hip): cstark_air_combine / the fused sub-AIR evaluators with coefficients (and assertion values) on the device
+int air_combine_dev(cstark_ctx *c, int air, uint32_t n_items, int mode, uint32_t merkle_depth, const uint64_t *d_lde, const uint64_t *d_evals,
+                    const uint64_t *d_aux_lde, const uint64_t *d_coefs, const uint64_t *d_avalues, const uint64_t *d_avals_lde, uint32_t n_avals, uint64_t *d_out,
+                    uint32_t log_n, uint32_t log_blowup, uint32_t nk);
 // internal (capi.hip): one rank's share of the degree-split evaluation of a proof sharded by LDE coset.  d_lde: the rank's cosets
 // [k0, k0 + nk) (k0 even, nk = 2 or 4) of its own extension; d_coeffs: the 94 coefficient columns (register 37 is extended to all
 // cosets here: the recombination reads it on cosets the rank does not hold).  d_out [nk / 2 + 4][n]: merged evaluations of the rank's

@@ -330,6 +330,8 @@ struct AirJob {
     uint32_t k0 = 0, nk = 8;        // sharded proofs (blowup 8): the LDE cosets this GPU owns
     bool sharded = false;
     bool dev_channel = false;       // the Fiat-Shamir channel runs on the device (prove_core_dev): the host never reads the public inputs
+    const uint64_t *d_coefs = nullptr;   // ... and the coefficients are drawn there: alpha[115] | beta[115] | b_alpha[na] | b_beta[na] (device)
+    const uint64_t *d_avalues = nullptr; // the assertion values on the device (null: the AIR's built-in constants)
     uint32_t log_b = 3;             // log2 of the blowup factor; the trace table holds its cosets in block order when log_b > log_ce
     uint64_t seed[7] = {};          // RescueAir
     uint64_t number = 0;            // RangeProofAir
@@ -837,7 +839,7 @@ int prove_core(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *p
 }
 
 // ---- the same proof with the Fiat-Shamir channel on the device (channel.hip) ---------------------------------------------------------
-// TransactionAir, base field, Blake3 coin, no proof of work: every channel step -- seed, reseeds, the 238 coefficient draws, the
+// Any of the AIRs, base field, Blake3 coin, no proof of work: every channel step -- seed, reseeds, the 238 coefficient draws, the
 // out-of-domain point, the DEEP coefficients, the FRI layers' folding points (k_fri_coin), the remainder commitment, the query positions
 // and their folded forms -- is a launch on the context's stream, the kernels read what was drawn from device memory, and the host waits
 // ONCE, for the block that holds everything the proof bytes are written from.  Same bytes as prove_core (the tests compare both with the
@@ -881,8 +883,12 @@ int prove_core_dev(cstark_ctx *c, const cstark_options *opt, AirJob &job0, uint8
         HIP_TRY(hipHostMalloc((void **)&a->h_open, off, hipHostMallocDefault));
         a->h_open_bytes = off;
     }
+    // the coefficient block the channel draws into: TransactionAir's evaluator reads the context's cstark_tx_coeffs block; the sub-AIRs'
+    // merge takes alpha[115] | beta[115] | b_alpha[na] | b_beta[na]
     uint64_t *d_coef_block;
-    RC_TRY(tx_coef_device_block(c, &d_coef_block));
+    const bool is_tx = job.air == CSTARK_AIR_STATE_TRANSITION;
+    if (is_tx) RC_TRY(tx_coef_device_block(c, &d_coef_block));
+    else RC_TRY(arena_extra(c, a, 46, &d_coef_block, (230 + 2 * (size_t)job.n_assertions) * 8));
     const uint64_t *pw, *pwinv;
     RC_TRY(plan_tables(c, log_n, &pw, &pwinv));
 
@@ -898,7 +904,24 @@ int prove_core_dev(cstark_ctx *c, const cstark_options *opt, AirJob &job0, uint8
     STAGE();
     {   // the coin: context || public inputs (read from the trace, on the device), the trace root, the coefficient pairs
         ChanStep s{};
-        s.seed = d_fri; s.init = 1; s.pub = a->d_pub; s.npub = 14;
+        s.seed = d_fri;
+        if (job.air == CSTARK_AIR_SCHNORR) {
+            // SchnorrAir's public inputs -- every message, R.x and s half: 304 bytes per signature -- are host data: the seed is hashed
+            // here (once per uploaded witness and option set: c->schnorr_seed) and uploaded
+            uint8_t key[12] = {(uint8_t)W, (uint8_t)log_n, (uint8_t)opt->num_queries, (uint8_t)log_b, (uint8_t)opt->grinding_factor, (uint8_t)opt->hash_fn,
+                               (uint8_t)opt->field_extension, (uint8_t)opt->fri_folding_factor, (uint8_t)R.log_rem, 0, 0, 1};
+            if (memcmp(key, c->schnorr_seed_key, sizeof key) != 0) {
+                Writer sd;
+                sd.raw(key, 2); sd.u64(host::P); sd.raw(key + 2, 7);
+                for (uint64_t v : job.pub) sd.u64(host::to_u64(v));
+                sd.raw(job.pub_bytes.data(), job.pub_bytes.size());
+                hostb3::hash(sd.b.data(), sd.b.size(), c->schnorr_seed);
+                memcpy(c->schnorr_seed_key, key, sizeof key);
+            }
+            HIP_TRY(hipMemcpyAsync(d_fri, c->schnorr_seed, 32, hipMemcpyHostToDevice, st));
+        } else {
+            s.init = 1; s.pub = a->d_pub; s.npub = job.air == CSTARK_AIR_RANGE ? 1 : 14;
+        }
         const uint8_t hdr[17] = {(uint8_t)W, (uint8_t)log_n, (uint8_t)host::P, (uint8_t)(host::P >> 8), (uint8_t)(host::P >> 16), (uint8_t)(host::P >> 24),
                                  (uint8_t)(host::P >> 32), (uint8_t)(host::P >> 40), (uint8_t)(host::P >> 48), (uint8_t)(host::P >> 56),
                                  (uint8_t)opt->num_queries, (uint8_t)log_b, (uint8_t)opt->grinding_factor, (uint8_t)opt->hash_fn, (uint8_t)opt->field_extension,
@@ -909,9 +932,13 @@ int prove_core_dev(cstark_ctx *c, const cstark_options *opt, AirJob &job0, uint8
         s.count = 2 * (job.n_constraints + job.n_assertions); s.out = d_coef_block;
         HIP_TRY(channel_step(s, st));
     }
-    {
+    if (is_tx) {
         uint64_t *outs[1] = {a->combined};
         RC_TRY(tx_evaluate_constraints_sets(c, a->lde, nullptr, 1, nullptr, outs, job.item, log_n, 3, 0, 8, true, a->d_pub));
+    } else { // the sub-AIRs: the assertion values are the public inputs (MerkleAir, RescueAir), (0, number) (RangeProofAir) or built in (SchnorrAir)
+        job.d_coefs = d_coef_block;
+        job.d_avalues = job.air == CSTARK_AIR_RANGE ? a->d_pub + 1 : job.air == CSTARK_AIR_SCHNORR ? nullptr : a->d_pub;
+        RC_TRY(job.combine(c, a, job, nullptr, nullptr, nullptr, nullptr, a->combined));
     }
     STAGE();
     RC_TRY(cstark_composition_columns(c, a->combined, a->ccoef, log_n, log_ce));
@@ -1037,13 +1064,13 @@ int prove_core_dev(cstark_ctx *c, const cstark_options *opt, AirJob &job0, uint8
 // which channel: the device's for what prove_core_dev covers, unless CSTARK_HOST_CHANNEL=1
 bool use_dev_channel(const cstark_options *opt, const AirJob &job) {
     static const bool host_env = [] { const char *e = getenv("CSTARK_HOST_CHANNEL"); return e && atoi(e) != 0; }();
-    if (host_env || job.air != CSTARK_AIR_STATE_TRANSITION || job.sharded) return false;
+    if (host_env || job.sharded || job.n_constraints > CSTARK_TX_NUM_CONSTRAINTS) return false;
     if (opt->hash_fn != 0 || opt->field_extension != 0 || opt->grinding_factor != 0) return false;
     uint32_t lb = 0, lf = 0, lr = 0;
     while ((1u << lb) < opt->blowup_factor && lb < 8) lb++;
     while ((1u << lf) < opt->fri_folding_factor && lf < 8) lf++;
     while ((1u << lr) < opt->fri_max_remainder && lr < 12) lr++;
-    return lf >= 2 && job.log_n + lb > lr; // at least one FRI layer (always, for a TransactionAir trace)
+    return lf >= 2 && job.log_n + lb > lr; // at least one FRI layer (always, but for a 64-row range proof with a large remainder)
 }
 
 // Sharded proofs: a rank that holds 2 or 4 cosets evaluates its share of the degree-split form (CSTARK_SHARD_SPLIT=0, tuning /
@@ -1060,6 +1087,7 @@ int gather_roots(cstark_ctx *c, ProveArena *a, AirJob &job, uint32_t reg0 = 58) 
     const size_t n = (size_t)1 << job.log_n;
     k_gather_pub<<<1, 64, 0, c->stream>>>(a->trace, n, a->d_pub, reg0);
     HIP_TRY(hipGetLastError());
+    if (job.dev_channel) return CSTARK_OK; // the device-side channel reads them where they are
     job.pub.assign(14, 0);
     HIP_TRY(hipMemcpyAsync(job.pub.data(), a->d_pub, 14 * 8, hipMemcpyDeviceToHost, c->stream)); // complete at the commitment sync
     return CSTARK_OK;
@@ -1132,15 +1160,21 @@ int merkle_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta
     const uint32_t log_ce = job.log_ce, ce = 1u << log_ce;
     // CSTARK_MERKLE_FUSED=0 (tuning / debugging): materialise the 106 transition values and merge them generically
     static const bool fused = [] { const char *e = getenv("CSTARK_MERKLE_FUSED"); return !e || atoi(e) != 0; }();
+    if (fused && job.d_coefs) return air_combine_dev(c, CSTARK_AIR_MERKLE_UPDATE, 0, 1, job.item, a->lde, nullptr, nullptr, job.d_coefs, job.d_avalues, nullptr, 0, out, job.log_n, log_ce, ce);
     if (fused) return cstark_merkle_evaluate_constraints(c, job.item, a->lde, ta, tb, ba, bb, job.pub.data(), out, job.log_n, log_ce, 0, ce);
     uint64_t *evals;
     RC_TRY(arena_extra(c, a, 0, &evals, (size_t)ce * job.n_constraints * n * 8));
     if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_MERKLE_UPDATE, a->lde, evals, job.item, job.log_n, log_ce, 0, ce));
     job.evals_ready = true;
+    if (job.d_coefs) return air_combine_dev(c, CSTARK_AIR_MERKLE_UPDATE, 0, 0, 0, a->lde, evals, nullptr, job.d_coefs, job.d_avalues, nullptr, 0, out, job.log_n, log_ce, ce);
     return cstark_air_combine(c, CSTARK_AIR_MERKLE_UPDATE, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, out, job.log_n, log_ce, 0, ce);
 }
 // ---- RangeProofAir (src/range) -------------------------------------------------------------------------------------------------------
 int range_build(cstark_ctx *c, ProveArena *a, AirJob &job) {
+    if (job.dev_channel) { // the public input (the number) and the two assertion values (0, the number: src/range/air.rs:79-86) for the device-side channel
+        const uint64_t v[3] = {job.number, 0, job.number};
+        HIP_TRY(hipMemcpyAsync(a->d_pub, v, sizeof v, hipMemcpyHostToDevice, c->stream)); // (a small pageable source is staged by the runtime before the call returns)
+    }
     if (job.bits) return cstark_range_build_trace_bits(c, job.bits, job.log_n, a->trace, nullptr);
     return cstark_range_build_trace(c, job.number, a->trace);
 }
@@ -1151,6 +1185,7 @@ int range_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta,
     RC_TRY(arena_extra(c, a, 0, &evals, (size_t)ce * job.n_constraints * n * 8));
     if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RANGE, a->lde, evals, job.item, job.log_n, log_ce, 0, ce));
     job.evals_ready = true;
+    if (job.d_coefs) return air_combine_dev(c, CSTARK_AIR_RANGE, 0, 0, 0, a->lde, evals, nullptr, job.d_coefs, job.d_avalues, nullptr, 0, out, job.log_n, log_ce, ce);
     const uint64_t vals[2] = {0, job.number}; // get_assertions, src/range/air.rs:79-86
     return cstark_air_combine(c, CSTARK_AIR_RANGE, 0, a->lde, evals, ta, tb, ba, bb, vals, nullptr, 0, out, job.log_n, log_ce, 0, ce);
 }
@@ -1166,6 +1201,7 @@ int rescue_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *ta
     RC_TRY(arena_extra(c, a, 0, &evals, (size_t)ce * job.n_constraints * n * 8));
     if (!job.evals_ready) RC_TRY(cstark_air_evaluate_transitions(c, CSTARK_AIR_RESCUE_CHAIN, a->lde, evals, 0, job.log_n, log_ce, 0, ce));
     job.evals_ready = true;
+    if (job.d_coefs) return air_combine_dev(c, CSTARK_AIR_RESCUE_CHAIN, 0, 0, 0, a->lde, evals, nullptr, job.d_coefs, job.d_avalues, nullptr, 0, out, job.log_n, log_ce, ce);
     return cstark_air_combine(c, CSTARK_AIR_RESCUE_CHAIN, 0, a->lde, evals, ta, tb, ba, bb, job.pub.data(), nullptr, 0, out, job.log_n, log_ce, 0, ce);
 }
 // ---- SchnorrAir (src/schnorr) ---------------------------------------------------------------------------------------------------------
@@ -1217,7 +1253,9 @@ int schnorr_combine(cstark_ctx *c, ProveArena *a, AirJob &job, const uint64_t *t
         if (!fused) RC_TRY(cstark_schnorr_evaluate_transitions(c, a->lde, aux_lde, evals, job.log_n, 3, 0, 8));
         job.evals_ready = true;
     }
+    if (fused && job.d_coefs) return air_combine_dev(c, CSTARK_AIR_SCHNORR, job.item, 2, 0, a->lde, nullptr, aux_lde, job.d_coefs, nullptr, av_lde, 12, out, job.log_n, 3, 8);
     if (fused) return cstark_schnorr_evaluate_constraints_lde(c, job.item, a->lde, aux_lde, ta, tb, ba, bb, av_lde, 12, out, job.log_n); // own extensions: split form
+    if (job.d_coefs) return air_combine_dev(c, CSTARK_AIR_SCHNORR, job.item, 0, 0, a->lde, evals, nullptr, job.d_coefs, nullptr, av_lde, 12, out, job.log_n, 3, 8);
     return cstark_air_combine(c, CSTARK_AIR_SCHNORR, job.item, a->lde, evals, ta, tb, ba, bb, nullptr, av_lde, 12, out, job.log_n, 3, 0, 8);
 }
 
@@ -1561,6 +1599,7 @@ int cstark_air_prove(cstark_ctx *c, int air, const cstark_options *opt, uint64_t
     }
     job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
     if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
+    if (use_dev_channel(opt, job)) return prove_core_dev(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);
 }
 
@@ -1663,6 +1702,7 @@ int cstark_rescue_prove(cstark_ctx *c, const cstark_options *opt, const uint64_t
     job.build = rescue_build; job.combine = rescue_combine;
     job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
     if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
+    if (use_dev_channel(opt, job)) return prove_core_dev(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);
 }
 
@@ -1684,6 +1724,7 @@ int cstark_range_prove_bits(cstark_ctx *c, const cstark_options *opt, const uint
     job.build = range_build; job.combine = range_combine;
     job.width = s.width; job.n_constraints = s.n_constraints; job.n_assertions = (uint32_t)s.a_reg.size(); job.log_ce = s.log_ce_blowup();
     if (opt->field_extension == 1 || opt->field_extension == 2) return prove_ext(c, opt, job, proof, capacity, proof_len);
+    if (use_dev_channel(opt, job)) return prove_core_dev(c, opt, job, proof, capacity, proof_len);
     return prove_core(c, opt, job, proof, capacity, proof_len);
 }
 
