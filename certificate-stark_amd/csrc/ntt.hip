@@ -31,6 +31,14 @@
 namespace cs {
 namespace {
 
+// The measurement hooks, kept out of the loops: in the product build (CS_NTT_SKIP == 0) mb_load is the load, mb_store the store, and
+// the MB_* conditions are compile-time false.
+__device__ __forceinline__ fp mb_load(const fp *row, unsigned lane_off, unsigned fake) { return (CS_NTT_SKIP & 16) ? (fp)fake : row[lane_off]; }
+__device__ __forceinline__ void mb_store(fp *row, unsigned lane_off, fp val) {
+    if (!(CS_NTT_SKIP & 8) || val == 0x123456789abcdefull) row[lane_off] = val; // (measurement: kept alive by an impossible condition)
+}
+constexpr bool MB_NO_TWIDDLE_FILL = (CS_NTT_SKIP & 1) != 0, MB_NO_PRESCALE = (CS_NTT_SKIP & 2) != 0, MB_NO_OUTPUT_FACTOR = (CS_NTT_SKIP & 4) != 0;
+
 constexpr int NT = 256; // threads per workgroup
 
 __device__ __forceinline__ unsigned bitrev(unsigned x, unsigned bits) { return __brev(x) >> (32 - bits); }
@@ -382,7 +390,7 @@ __device__ __forceinline__ void cols_v4_finish(fp *tile, const fp *tw, const fp 
         // output factor shift^c w_n^(k c), k = (k1 + A k2) + A Bn k3: a geometric sequence in k3 with ratio w_n^(A Bn c)
         const unsigned kb = k1 + A * k2;
         fp g, ratio;
-        if (CS_NTT_SKIP & 4) { g = kb + c; ratio = c; }
+        if (MB_NO_OUTPUT_FACTOR) { g = kb + c; ratio = c; }
         else if (outf) { // compact tables (ntt_build_aux_*): one 64-byte segment per (kb, tile) instead of 8 scattered sectors
             g = outf[((size_t)kb << log_c) + c];
             ratio = ratio_tab[c];
@@ -396,7 +404,7 @@ __device__ __forceinline__ void cols_v4_finish(fp *tile, const fp *tw, const fp 
         for (int k3 = 0; k3 < Cn; k3++) {
             fp *row = dst + ((size_t)(A * Bn * k3) << log_c);
             const fp val = fp_mul(x[cx_brev(k3, LC)], g);
-            if (!(CS_NTT_SKIP & 8) || val == 0x123456789abcdefull) row[lane_off] = val;
+            mb_store(row, lane_off, val);
             if (k3 + 1 < Cn) g = fp_mul(g, ratio);
         }
     }
@@ -427,14 +435,14 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
     const fp *outf = !aux ? nullptr : ps ? (ps_row ? ps_row + M : nullptr) : aux + M + ((size_t)2 << log_c);
     const fp *ratio_tab = aux ? aux + M + ((size_t)1 << log_c) : nullptr;
 
-    if (CS_NTT_SKIP & 1) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
+    if (MB_NO_TWIDDLE_FILL) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
     else if (aux) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
     fp nxt[A];
     {
         const unsigned lane_off = (t << log_c) + xcd_pair_tile(tile_id * V4_TILES) * L2 + l;
 #pragma unroll
-        for (int r1 = 0; r1 < A; r1++) nxt[r1] = (CS_NTT_SKIP & 16) ? (fp)(lane_off + r1) : (src + ((size_t)(r1 * T) << log_c))[lane_off];
+        for (int r1 = 0; r1 < A; r1++) nxt[r1] = mb_load(src + ((size_t)(r1 * T) << log_c), lane_off, lane_off + r1);
     }
     __syncthreads(); // tw[] ready
 #pragma unroll 1
@@ -450,7 +458,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_cols_v4(const f
                 for (int r1 = 0; r1 < A; r1++) nxt[r1] = (src + ((size_t)(r1 * T) << log_c))[lane_off];
             }
             __builtin_amdgcn_sched_barrier(0); // the prefetch is issued here, ahead of this tile's arithmetic
-            if (CS_NTT_SKIP & 2) {
+            if (MB_NO_PRESCALE) {
             } else if (ps_row) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
 #pragma unroll
                 for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], ps_row[r1 * T + t]);
@@ -490,7 +498,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const f
     const unsigned s1 = threadIdx.x % T, l1 = threadIdx.x / T; // step 1: s = c2 Cn + c3 fastest across lanes (coalesced row reads)
     const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2; // steps 2 and 3: l fastest across lanes (64-byte transposed stores)
 
-    if (CS_NTT_SKIP & 1) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
+    if (MB_NO_TWIDDLE_FILL) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
     else if (aux_tw) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux_tw[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_r];
     fp nxt[A];
@@ -498,7 +506,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const f
     {
         const unsigned k10 = xcd_pair_tile(blockIdx.y * V4_TILES) * L2;
 #pragma unroll
-        for (int c1 = 0; c1 < A; c1++) nxt[c1] = (CS_NTT_SKIP & 16) ? (fp)(in_lane + c1) : (src + ((size_t)k10 << LOGM) + c1 * T)[in_lane];
+        for (int c1 = 0; c1 < A; c1++) nxt[c1] = mb_load(src + ((size_t)k10 << LOGM) + c1 * T, in_lane, in_lane + c1);
     }
     __syncthreads(); // tw[] ready
 #pragma unroll 1
@@ -554,7 +562,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), 4) void k_ntt_rows_v4(const f
             for (int p = 0; p < Cn; p++) {
                 fp val = x[p];
                 if (do_scale) val = fp_mul(val, post_scale);
-                if (!(CS_NTT_SKIP & 8) || val == 0x123456789abcdefull) (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
+                mb_store(dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10, out_lane, val);
             }
         }
         __syncthreads(); // the tile is rewritten by the next iteration
@@ -610,16 +618,16 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_COLS_WAVES) void k_
     const fp *ratio_tab = aux ? aux + M + ((size_t)1 << log_c) : nullptr;
     const unsigned c = xcd_pair_tile(blockIdx.x) * L2 + l;
 
-    if (CS_NTT_SKIP & 1) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
+    if (MB_NO_TWIDDLE_FILL) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
     else if (aux) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_c];
     fp a[A];
     {
         const unsigned lane_off = (t << log_c) + c;
 #pragma unroll
-        for (int r1 = 0; r1 < A; r1++) a[r1] = (CS_NTT_SKIP & 16) ? (fp)(lane_off + r1) : (src + ((size_t)(r1 * T) << log_c))[lane_off];
+        for (int r1 = 0; r1 < A; r1++) a[r1] = mb_load(src + ((size_t)(r1 * T) << log_c), lane_off, lane_off + r1);
     }
-    if (CS_NTT_SKIP & 2) {
+    if (MB_NO_PRESCALE) {
     } else if (ps_row) { // row part shift^(r C) of the coset power; the column part shift^c is folded into the output factor
 #pragma unroll
         for (int r1 = 0; r1 < A; r1++) a[r1] = fp_mul(a[r1], ps_row[r1 * T + t]);
@@ -663,7 +671,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_COLS_WAVES) void k_
         // output factor shift^c w_n^(k c), k = (k1 + A k2) + A Bn k3: a geometric sequence in k3 with ratio w_n^(A Bn c)
         const unsigned kb = (k1s + AH * h) + A * k2;
         fp g, ratio;
-        if (CS_NTT_SKIP & 4) { g = kb + c; ratio = c; }
+        if (MB_NO_OUTPUT_FACTOR) { g = kb + c; ratio = c; }
         else if (outf) {
             g = outf[((size_t)kb << log_c) + c];
             ratio = ratio_tab[c];
@@ -677,7 +685,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_COLS_WAVES) void k_
         for (int k3 = 0; k3 < Cn; k3++) {
             fp *row = dst + ((size_t)(A * Bn * k3) << log_c);
             const fp val = fp_mul(x[cx_brev(k3, LC)], g);
-            if (!(CS_NTT_SKIP & 8) || val == 0x123456789abcdefull) row[lane_off] = val;
+            mb_store(row, lane_off, val);
             if (k3 + 1 < Cn) g = fp_mul(g, ratio);
         }
     }
@@ -701,7 +709,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_ROWS_WAVES) void k_
     fp *dst = out + blockIdx.x * out_batch_stride + (size_t)blockIdx.z * n;
     const unsigned s1 = threadIdx.x % T, l1 = threadIdx.x / T; // step 1: s = c2 Cn + c3 fastest across lanes (coalesced row reads)
     const unsigned l = threadIdx.x % L2, t = threadIdx.x / L2; // steps 2 and 3: l fastest across lanes (64-byte transposed stores)
-    if (CS_NTT_SKIP & 1) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
+    if (MB_NO_TWIDDLE_FILL) { for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = e; }
     else if (aux_tw) for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = aux_tw[e];
     else for (unsigned e = threadIdx.x; e < M; e += G::NT) tw[e] = w[(size_t)e << log_r];
     fp a[A];
@@ -709,7 +717,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_ROWS_WAVES) void k_
     {
         const unsigned k10 = xcd_pair_tile(blockIdx.y * V5_ROWS_TILES) * L2;
 #pragma unroll
-        for (int c1 = 0; c1 < A; c1++) a[c1] = (CS_NTT_SKIP & 16) ? (fp)(in_lane + c1) : (src + ((size_t)k10 << LOGM) + c1 * T)[in_lane];
+        for (int c1 = 0; c1 < A; c1++) a[c1] = mb_load(src + ((size_t)k10 << LOGM) + c1 * T, in_lane, in_lane + c1);
     }
     const unsigned jh = t / Cn, c3 = t % Cn;
     const unsigned j1s = t / Bn, j2s = t % Bn;
@@ -756,7 +764,7 @@ __global__ __launch_bounds__((V4<LA, LB, LC>::NT), CS_NTT_V5_ROWS_WAVES) void k_
             for (int p = 0; p < Cn; p++) {
                 fp val = x[p];
                 if (do_scale) val = fp_mul(val, post_scale);
-                if (!(CS_NTT_SKIP & 8) || val == 0x123456789abcdefull) (dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10)[out_lane] = val;
+                mb_store(dst + ((size_t)(A * Bn * cx_brev(p, LC)) << log_r) + k10, out_lane, val);
             }
         }
     }
