@@ -21,6 +21,7 @@
 //  * result slots are never materialised in the fused kernel: each flag*value is folded straight into the
 //    random linear combination (the index aliasing of src/constants.rs:56-68 is reproduced because every
 //    contribution still uses the coefficient of the slot the reference adds it to).
+#include <type_traits>
 #include "constraints.h"
 #include "mds_mfma.cuh"
 #include "rescue.cuh"
@@ -1356,14 +1357,18 @@ __device__ __forceinline__ void fused_linear_c(Fused<M> &acc, const Frame &f) {
 // ---- split evaluation of the linear groups (flags inside: every term has degree < 4n, see the degree table in DESIGN.md) ---------
 // Section accumulator for slots of any degree group: alpha-weighted sum and one beta-weighted sum per group.  The slot may be a
 // run-time value (rolled loops): its group is then a uniform condition.
-struct SectionAcc {
+constexpr unsigned G0 = 1, G1 = 2, G2 = 4, G3 = 8, G4 = 16;
+// GM: the groups this section's slots can be in -- only those get a beta accumulator (four registers each) and a test in term().
+template <unsigned GM>
+struct SectionAccT {
     const CS_CONST fp *coefs;
     Acc128 sa, sb[5];
     int ca, cb[5];
     __device__ __forceinline__ void begin() {
         sa = acc_zero(); ca = 0;
 #pragma unroll
-        for (int g = 0; g < 5; g++) { sb[g] = acc_zero(); cb[g] = 0; }
+        for (int g = 0; g < 5; g++)
+            if ((GM >> g) & 1u) { sb[g] = acc_zero(); cb[g] = 0; }
     }
     __device__ __forceinline__ void term(int i, fp v) {
         acc_mad(sa, coefs[i], v);
@@ -1371,14 +1376,26 @@ struct SectionAcc {
         const int g = tx_degree_group(i);
 #pragma unroll
         for (int q = 0; q < 5; q++)
-            if (g == q) {
+            if (((GM >> q) & 1u) && g == q) {
                 acc_mad(sb[q], coefs[115 + i], v);
                 if (++cb[q] == 7) { acc_fold(sb[q]); cb[q] = 0; }
             }
     }
+    // the sums so far are computed HERE: an empty volatile statement the optimiser cannot move arithmetic across (a scheduling barrier alone
+    // only binds the machine scheduler; the passes before it still sink a section's arithmetic towards the flush)
+    static __device__ __forceinline__ void pin128(const Acc128 &a) { // inputs only: no new value, so no copies
+        asm volatile("" : : "v"((uint32_t)a.lo), "v"((uint32_t)(a.lo >> 32)), "v"((uint32_t)a.hi), "v"((uint32_t)(a.hi >> 32)));
+    }
+    __device__ __forceinline__ void pin() {
+        pin128(sa);
+#pragma unroll
+        for (int g = 0; g < 5; g++)
+            if ((GM >> g) & 1u) pin128(sb[g]);
+    }
     // tot[0] += flag * alpha sum, tot[1 + g] += flag * beta sum of group g, for the groups in GMASK (the others received nothing)
     template <unsigned GMASK>
     __device__ __forceinline__ void flush(fp flag, fp (&tot)[6]) {
+        static_assert((GMASK & ~GM) == 0, "flushed group without an accumulator");
         acc_fold(sa);
         tot[0] = fp_add(tot[0], fp_mul(flag, acc_reduce(sa)));
 #pragma unroll
@@ -1389,7 +1406,7 @@ struct SectionAcc {
             }
     }
 };
-constexpr unsigned G0 = 1, G1 = 2, G2 = 4, G3 = 8, G4 = 16;
+using SectionAcc = SectionAccT<31u>;
 
 // setup + value-copy constraints: every slot is in group 4
 __device__ __forceinline__ void lin_a_split(const CS_CONST fp *coefs, const Frame &f, fp (&tot)[6]) {
@@ -1560,32 +1577,123 @@ __global__ __launch_bounds__(FNT, PART == PART_LIN_C ? CS_LIN_C_SPLIT_WAVES : PA
 #ifndef CS_LIN_ALL_WAVES
 #define CS_LIN_ALL_WAVES 3
 #endif
-#ifndef CS_LIN_ALL_UNROLL
-#define CS_LIN_ALL_UNROLL 1 // rolled: 162 VGPRs, no spills; unrolled (7) the scheduler hoists every load: 256 VGPRs + 98 spilled
-#endif
-__device__ __forceinline__ void lin_all_split(const CS_CONST fp *coefs, const Frame &f, fp (&tot)[6]) {
-    const fp setup = f.pv(P_SETUP), copy_values = f.pv(P_VALUE_COPY);
-    const fp tx_hash = f.pv(P_MERKLE), hash_input = f.pv(P_HASH_INPUT), finish = f.pv(P_FINISH), hash_flag = f.pv(P_HASH);
-    const fp hash_copy = fp_mul(tx_hash, c_not(fp_add(hash_flag, hash_input)));
-    const fp hash_init = fp_mul(tx_hash, hash_input);
-    SectionAcc s_set, s_cp, sa, sb;
-    s_set.coefs = s_cp.coefs = sa.coefs = sb.coefs = coefs;
+// The frame of k_lin_all: the same cells as Frame, read with buffer loads -- the column offset c * n * 8 is a scalar operand and the lane's
+// row offset one 32-bit register for all columns, so a load costs no vector instruction (the 64-bit pointer form spends a v_lshl_add_u64 on
+// every load: 1 100 of this kernel's 12 900 vector instructions).  One coset's table must stay below 4 GB (log_n <= 22: launch_lin_all).
+struct FrameB {
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t col_bytes, cur_off, next_off;
+    const fp *per_p;
+    __device__ __forceinline__ fp ld(uint32_t off, int c) const {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, (uint32_t)c * col_bytes, 0);
+        return ((uint64_t)v.y << 32) | v.x;
+    }
+    __device__ __forceinline__ fp cur(int c) const { return ld(cur_off, c); }
+    __device__ __forceinline__ fp next(int c) const { return ld(next_off, c); }
+    __device__ __forceinline__ fp pv(int c) const { return per_p[(size_t)c * 1024]; }
+};
+__device__ __forceinline__ FrameB make_frame_b(const CeParams &p, unsigned kk, size_t j) {
+    const size_t n = (size_t)1 << p.log_n;
+    FrameB f;
+    f.rs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.lde + (size_t)kk * 94 * n), 0, (uint32_t)(94 * n * 8), 0x00020000); // raw buffer, bounds = the table
+    f.col_bytes = (uint32_t)(n * 8);
+    f.cur_off = (uint32_t)(j * 8);
+    f.next_off = (uint32_t)(((j + 1) & (n - 1)) * 8);
+    f.per_p = p.ptab + (size_t)(p.k0 + kk) * 48 * 1024 + (j & 1023);
+    return f;
+}
+template <int... K, class Fn>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, K...>, Fn fn) { (fn(std::integral_constant<int, K>{}), ...); }
+
+// One pass over the frame for the three linear groups, as 21 straight-line stages: the seven elements of the sender's leaf pair, the seven of the
+// receiver's, the amount copies, the root carry (two stages), the Schnorr limbs, the hash copy (two stages), the range proofs.
+//   * every slot -- and so its degree group and its coefficient's address -- is a compile-time value: a term is two multiply-accumulates with a
+//     scalar operand.  (Round 3 kept the element loops rolled: the group was then a run-time value, and each term cost a scalar load waited for
+//     at once and a chain of scalar branches: 13 689 vector + 5 436 scalar instructions per wave, 425 branches.)
+//   * stage k + 1's cells are requested before stage k's arithmetic starts.  Every wave of a CU runs this same program nearly in step, so without
+//     the overlap inside a wave the CU alternates between all waves waiting on memory and all waves computing: the old kernel's 2.14 ms were its
+//     1.0 ms of memory time PLUS its 1.1 ms of issue time (profiles/r04_lin_all.txt).
+//   * scheduling barriers between the stages, and the sums pinned at the end of each (SectionAccT::pin), keep the order written here: left alone
+//     the scheduler lifts the kernel's ~300 loads above the arithmetic and spills, and the passes before it sink a stage's arithmetic to the flush.
+#define CS_LIN_SECTION() __builtin_amdgcn_sched_barrier(0)
+template <class F>
+__device__ __forceinline__ void lin_all_split(const CS_CONST fp *coefs, const F &f, fp (&tot)[6]) {
+    constexpr int NSTAGE = 21, NL = 32;
+    SectionAccT<G4> s_set, s_cp, ra;
+    SectionAccT<G0 | G1 | G2> sa, sb;
+    SectionAccT<G3 | G4> rb;
+    SectionAccT<G2> s;
+    SectionAccT<G2 | G3 | G4> sr;
+    s_set.coefs = s_cp.coefs = ra.coefs = sa.coefs = sb.coefs = rb.coefs = s.coefs = sr.coefs = coefs;
     s_set.begin(); s_cp.begin();
-    fp inp[7] = {0, 0, 0, 0, 0, 0, 0};                 // hash-internal inputs of LIN_C: inp[i] = sum_k pv(P_HASH_INTERNAL + k) cell(7 k + i)
-    const fp hi0 = f.pv(P_HASH_INTERNAL), hi1 = f.pv(P_HASH_INTERNAL + 1), hi2 = f.pv(P_HASH_INTERNAL + 2), hi3 = f.pv(P_HASH_INTERNAL + 3);
-    fp s_spent = 0, su12 = 0, si13 = 0;
+    fp bit = 0, not_bit = 0, s_spent = 0, su12 = 0, si13 = 0, schnorr_mask = 0;
+
+    // what stage k reads, in the order its arithmetic names them
+    auto load = [&](auto kc, fp (&L)[NL]) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < 14) {
+            constexpr int blk = k / 7, i = k % 7, base = blk == 0 ? S_INIT : R_INIT, key = blk == 0 ? S_KEY : R_KEY;
+            L[0] = f.cur(base + i); L[1] = f.next(base + i); L[2] = f.cur(base + 15 + i); L[3] = f.next(base + 15 + i);
+            L[4] = f.cur(base + 7 + i); L[5] = f.next(base + 7 + i); L[6] = f.cur(base + 22 + i); L[7] = f.next(base + 22 + i);
+            L[8] = f.next(key + i); L[9] = f.cur(key + i);
+            if constexpr (i < 5) { L[10] = f.next(key + 7 + i); L[11] = f.cur(key + 7 + i); }
+            if constexpr (i == 0) { L[12] = f.next(base + 14); L[13] = f.pv(P_MERKLE); }
+            if constexpr (i == 6) { L[12] = f.pv(P_HASH_INPUT); L[13] = f.pv(P_HASH); L[14] = f.pv(P_MERKLE); }
+        } else if constexpr (k == 14) {
+            L[0] = f.next(DELTA_COPY); L[1] = f.next(SIGMA_COPY); L[2] = f.next(NONCE_COPY);
+            L[3] = f.cur(DELTA_COPY); L[4] = f.cur(SIGMA_COPY); L[5] = f.cur(NONCE_COPY);
+            L[6] = f.pv(P_SETUP); L[7] = f.pv(P_VALUE_COPY);
+        } else if constexpr (k == 15 || k == 16) {
+            constexpr int i0 = k == 15 ? 0 : 4, cnt = k == 15 ? 4 : 3;
 #pragma unroll
-    for (int blk = 0; blk < 2; blk++) {
-        const int base = blk == 0 ? S_INIT : R_INIT, key = blk == 0 ? S_KEY : R_KEY, key_res = blk == 0 ? S_KEY_RES : R_KEY_RES;
-        const fp bit = f.next(base + 14), not_bit = c_not(bit);
-        sa.begin();
-        sa.term(base + 14, c_is_binary(bit));
-        sa.flush<G1 | G2>(tx_hash, tot); // slot 14: group 1, slot 43: group 2
-        sa.begin(); sb.begin();
-#pragma unroll CS_LIN_ALL_UNROLL
-        for (int i = 0; i < 7; i++) {
-            const fp ca = f.cur(base + i), na0 = f.next(base + i), cb = f.cur(base + 15 + i), nb0 = f.next(base + 15 + i);
-            const fp ca7 = f.cur(base + 7 + i), na7 = f.next(base + 7 + i), cb7 = f.cur(base + 22 + i), nb7 = f.next(base + 22 + i);
+            for (int q = 0; q < cnt; q++) {
+                const int i = i0 + q;
+                L[6 * q] = f.next(PREV_ROOT + i); L[6 * q + 1] = f.cur(PREV_ROOT + i); L[6 * q + 2] = f.next(R_UPD + i);
+                L[6 * q + 3] = f.cur(S_UPD + i); L[6 * q + 4] = f.cur(R_INIT + i); L[6 * q + 5] = f.next(S_INIT + i);
+            }
+            if constexpr (k == 16) L[18] = f.pv(P_FINISH);
+        } else if constexpr (k == 17) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { L[i] = f.cur(38 + i); L[4 + i] = f.next(38 + i); L[8 + i] = f.cur(42 + i); L[19 + i] = f.pv(P_DIGEST + i); }
+            L[12] = f.next(37); L[13] = f.cur(37); L[14] = f.cur(18); L[15] = f.next(18);
+            L[16] = f.pv(P_SCHNORR); L[17] = f.pv(P_SCALAR_MULT); L[18] = f.pv(P_DOUBLING);
+        } else if constexpr (k == 18 || k == 19) {
+            // hash copy.  Its hash-internal inputs: inp[i] = sum_k' pv(P_HASH_INTERNAL + k') cell(7 k' + i) over the 26 cells next(S_KEY ..+12),
+            // next(R_KEY ..+12), next(DELTA_COPY), next(NONCE_COPY)  (src/schnorr/air.rs:499-505)
+            constexpr int i0 = k == 18 ? 0 : 4, cnt = k == 18 ? 4 : 3;
+#pragma unroll
+            for (int q = 0; q < cnt; q++) {
+                const int i = i0 + q;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int m = 7 * kk + i;
+                    if (m < 26) L[7 * q + kk] = f.next(m < 12 ? S_KEY + m : m < 24 ? R_KEY + m - 12 : m == 24 ? DELTA_COPY : NONCE_COPY);
+                }
+                L[7 * q + 4] = f.cur(42 + i); L[7 * q + 5] = f.next(42 + i); L[7 * q + 6] = f.next(49 + i);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) L[28 + kk] = f.pv(P_HASH_INTERNAL + kk);
+            if constexpr (k == 19) L[21] = f.pv(P_SCHNORR_HASH);
+        } else {
+            L[0] = f.next(DELTA_BIT); L[1] = f.next(SIGMA_BIT); L[2] = f.next(DELTA_ACC); L[3] = f.cur(DELTA_ACC);
+            L[4] = f.next(SIGMA_ACC); L[5] = f.cur(SIGMA_ACC); L[6] = f.next(DELTA_COPY);
+            L[7] = f.pv(P_RANGE_STEP); L[8] = f.pv(P_RANGE_FINISH);
+        }
+    };
+
+    auto compute = [&](auto kc, const fp (&L)[NL]) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < 14) {
+            constexpr int blk = k / 7, i = k % 7, base = blk == 0 ? S_INIT : R_INIT, key_res = blk == 0 ? S_KEY_RES : R_KEY_RES;
+            if constexpr (i == 0) {
+                bit = L[12]; not_bit = c_not(bit);
+                sa.begin();
+                sa.term(base + 14, c_is_binary(bit));
+                sa.template flush<G1 | G2>(L[13], tot); // slot 14: group 1, slot 43: group 2
+                sa.begin(); sb.begin();
+            }
+            const fp ca = L[0], na0 = L[1], cb = L[2], nb0 = L[3], ca7 = L[4], na7 = L[5], cb7 = L[6], nb7 = L[7], kn = L[8], kc_ = L[9];
             const fp da = fp_sub(ca, na0), db = fp_sub(cb, nb0);
             // merkle::update, hash copy / hash input sections (LIN_B)
             sa.term(base + i, da);
@@ -1595,108 +1703,130 @@ __device__ __forceinline__ void lin_all_split(const CS_CONST fp *coefs, const Fr
             sb.term(base + 15 + i, fp_mul(not_bit, db));
             sb.term(base + 22 + i, fp_mul(bit, fp_sub(cb, nb7)));
             // setup / value-copy sections (LIN_A): elements i and 7 + i of the leaf pair (init, updated) and of the key copy
-            const fp kn = f.next(key + i), kc = f.cur(key + i);
             s_set.term(VALUE_RES + 12 * blk + i, fp_sub(ca, cb));
             s_set.term(key_res + i, fp_sub(kn, ca));
-            s_cp.term(key_res + i, fp_sub(kn, kc));
-            {   // cell m = 12 blk + i of the hash-internal inputs
-                const int m = 12 * blk + i;
-                inp[m % 7] = fp_add(inp[m % 7], fp_mul(m / 7 == 0 ? hi0 : m / 7 == 1 ? hi1 : hi2, kn));
-            }
-            if (i < 5) {
-                const fp kn7 = f.next(key + 7 + i), kc7 = f.cur(key + 7 + i);
+            s_cp.term(key_res + i, fp_sub(kn, kc_));
+            if constexpr (i < 5) {
+                const fp kn7 = L[10], kc7 = L[11];
                 s_set.term(VALUE_RES + 12 * blk + 7 + i, fp_sub(ca7, cb7));
                 s_set.term(key_res + 7 + i, fp_sub(kn7, ca7));
                 s_cp.term(key_res + 7 + i, fp_sub(kn7, kc7));
-                const int m = 12 * blk + 7 + i;
-                inp[m % 7] = fp_add(inp[m % 7], fp_mul(m / 7 == 0 ? hi0 : m / 7 == 1 ? hi1 : m / 7 == 2 ? hi2 : hi3, kn7));
-            } else if (i == 5) { // element 12: balances
-                if (blk == 0) { s_spent = fp_sub(ca7, cb7); su12 = cb7; }
+            } else if constexpr (i == 5) { // element 12: balances
+                if constexpr (blk == 0) { s_spent = fp_sub(ca7, cb7); su12 = cb7; }
                 else s_set.term(BALANCE_RES, fp_sub(s_spent, fp_sub(cb7, ca7)));
-            } else {             // element 13: nonces
-                if (blk == 0) { si13 = ca7; s_set.term(NONCE_UPD_RES, fp_sub(cb7, fp_add(ca7, FP_ONE))); }
+            } else {                       // element 13: nonces
+                if constexpr (blk == 0) { si13 = ca7; s_set.term(NONCE_UPD_RES, fp_sub(cb7, fp_add(ca7, FP_ONE))); }
                 else s_set.term(VALUE_RES + 24, fp_sub(ca7, cb7));
             }
+            if constexpr (i == 6) {
+                const fp hash_input = L[12], hash_flag = L[13], tx_hash = L[14];
+                sa.template flush<G0 | G1 | G2>(fp_mul(tx_hash, c_not(fp_add(hash_flag, hash_input))), tot); // hash copy
+                sb.template flush<G0 | G1 | G2>(fp_mul(tx_hash, hash_input), tot);                            // hash input
+            } else {
+                sa.pin(); sb.pin();
+            }
+            s_set.pin(); s_cp.pin();
+        } else if constexpr (k == 14) { // amount / balance / nonce copies (LIN_A)
+            const fp nd = L[0], ns = L[1], nn = L[2];
+            s_set.term(DELTA_COPY_RES, fp_sub(nd, s_spent));
+            s_set.term(SIGMA_COPY_RES, fp_sub(ns, su12));
+            s_set.term(NONCE_COPY_RES, fp_sub(nn, si13));
+            s_cp.term(DELTA_COPY_RES, fp_sub(nd, L[3]));
+            s_cp.term(SIGMA_COPY_RES, fp_sub(ns, L[4]));
+            s_cp.term(NONCE_COPY_RES, fp_sub(nn, L[5]));
+            s_set.template flush<G4>(L[6], tot);
+            s_cp.template flush<G4>(L[7], tot);
+        } else if constexpr (k == 15 || k == 16) { // root carry / finish of merkle::update (LIN_B)
+            constexpr int i0 = k == 15 ? 0 : 4, cnt = k == 15 ? 4 : 3;
+            if constexpr (k == 15) { ra.begin(); rb.begin(); }
+#pragma unroll
+            for (int q = 0; q < cnt; q++) {
+                const int i = i0 + q;
+                const fp nr = L[6 * q], cr = L[6 * q + 1];
+                ra.term(PREV_ROOT + i, fp_sub(nr, cr));
+                rb.term(PREV_ROOT + i, fp_sub(nr, L[6 * q + 2]));
+                rb.term(INT_ROOT_RES + i, fp_sub(L[6 * q + 3], L[6 * q + 4]));
+                rb.term(PREV_MATCH_RES + i, fp_sub(L[6 * q + 5], cr));
+            }
+            if constexpr (k == 16) {
+                const fp finish = L[18];
+                ra.template flush<G4>(c_not(finish), tot);
+                rb.template flush<G3 | G4>(finish, tot);
+            } else {
+                ra.pin(); rb.pin();
+            }
+        } else if constexpr (k == 17) { // schnorr: limbs of h, scalar bits (LIN_C).  The flags are part of the values here
+            schnorr_mask = L[16];
+            const fp scalar_mult = L[17], doubling = L[18];
+            const fp final_add = fp_mul(c_not(scalar_mult), schnorr_mask);
+            const fp addition = fp_mul(c_not(doubling), scalar_mult);
+            const fp n37 = L[12];
+            s.begin();
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const fp dflag = L[19 + i];
+                const fp c = L[3 - i], nx = L[7 - i]; // cur / next of register 41 - i
+                s.term(41 - i, fp_add(fp_mul(fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), n37))), fp_mul(fp_mul(c_not(dflag), doubling), fp_sub(c, nx))));
+                s.term(38 + i, fp_add(fp_mul(addition, fp_sub(L[i], L[4 + i])), fp_mul(final_add, fp_sub(L[i], L[8 + i]))));
+            }
+            const fp b37 = L[13], b18 = L[14];
+            s.term(18, fp_add(fp_mul(doubling, c_is_binary(b18)), fp_mul(addition, fp_sub(b18, L[15]))));
+            s.term(37, fp_add(fp_mul(doubling, c_is_binary(b37)), fp_mul(addition, fp_sub(b37, n37))));
+            s.template flush<G2>(FP_ONE, tot);
+        } else if constexpr (k == 18 || k == 19) { // hash copy (LIN_C)
+            constexpr int i0 = k == 18 ? 0 : 4, cnt = k == 18 ? 4 : 3;
+            if constexpr (k == 18) s.begin();
+#pragma unroll
+            for (int q = 0; q < cnt; q++) {
+                const int i = i0 + q;
+                fp inp = 0;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++)
+                    if (7 * kk + i < 26) inp = fp_add(inp, fp_mul(L[28 + kk], L[7 * q + kk]));
+                s.term(42 + i, fp_sub(L[7 * q + 4], L[7 * q + 5]));
+                s.term(49 + i, fp_sub(L[7 * q + 6], inp));
+            }
+            if constexpr (k == 19) s.template flush<G2>(fp_mul(c_not(L[21]), schnorr_mask), tot);
+            else s.pin();
+        } else { // range proofs (LIN_C)
+            const fp dbit = L[0], sbit = L[1];
+            sr.begin();
+            sr.term(DELTA_ACC, fp_sub(L[2], fp_add(fp_dbl(L[3]), dbit)));
+            sr.term(DELTA_BIT, c_is_binary(dbit));
+            sr.term(SIGMA_ACC, fp_sub(L[4], fp_add(fp_dbl(L[5]), sbit)));
+            sr.term(SIGMA_BIT, c_is_binary(sbit));
+            sr.template flush<G2 | G3 | G4>(L[7], tot);
+            const fp dr = fp_sub(L[2], L[6]);
+            sr.begin();
+            sr.term(DELTA_RANGE_RES, dr);
+            sr.term(SIGMA_RANGE_RES, dr);
+            sr.template flush<G4>(L[8], tot);
         }
-        sa.flush<G0 | G1 | G2>(hash_copy, tot);
-        sb.flush<G0 | G1 | G2>(hash_init, tot);
-    }
-    {   // amount / balance / nonce copies (LIN_A) and the last two cells of the hash-internal inputs (LIN_C)
-        const fp nd = f.next(DELTA_COPY), ns = f.next(SIGMA_COPY), nn = f.next(NONCE_COPY);
-        s_set.term(DELTA_COPY_RES, fp_sub(nd, s_spent));
-        s_set.term(SIGMA_COPY_RES, fp_sub(ns, su12));
-        s_set.term(NONCE_COPY_RES, fp_sub(nn, si13));
-        s_cp.term(DELTA_COPY_RES, fp_sub(nd, f.cur(DELTA_COPY)));
-        s_cp.term(SIGMA_COPY_RES, fp_sub(ns, f.cur(SIGMA_COPY)));
-        s_cp.term(NONCE_COPY_RES, fp_sub(nn, f.cur(NONCE_COPY)));
-        inp[24 % 7] = fp_add(inp[24 % 7], fp_mul(hi3, nd));
-        inp[25 % 7] = fp_add(inp[25 % 7], fp_mul(hi3, nn));
-    }
-    s_set.flush<G4>(setup, tot);
-    s_cp.flush<G4>(copy_values, tot);
-    // root carry / finish of merkle::update (LIN_B)
-    sa.begin(); sb.begin();
-#pragma unroll CS_LIN_ALL_UNROLL
-    for (int i = 0; i < 7; i++) {
-        const fp nr = f.next(PREV_ROOT + i), cr = f.cur(PREV_ROOT + i);
-        sa.term(PREV_ROOT + i, fp_sub(nr, cr));
-        sb.term(PREV_ROOT + i, fp_sub(nr, f.next(R_UPD + i)));
-        sb.term(INT_ROOT_RES + i, fp_sub(f.cur(S_UPD + i), f.cur(R_INIT + i)));
-        sb.term(PREV_MATCH_RES + i, fp_sub(f.next(S_INIT + i), cr));
-    }
-    sa.flush<G4>(c_not(finish), tot);
-    sb.flush<G3 | G4>(finish, tot);
-    // schnorr linear parts, hash copy, range proofs (LIN_C)
-    const fp schnorr_mask = f.pv(P_SCHNORR), scalar_mult = f.pv(P_SCALAR_MULT), doubling = f.pv(P_DOUBLING), schnorr_hash = f.pv(P_SCHNORR_HASH);
-    const fp range_flag = f.pv(P_RANGE_STEP), range_finish = f.pv(P_RANGE_FINISH);
-    const fp copy_hash = fp_mul(c_not(schnorr_hash), schnorr_mask);
-    const fp final_add = fp_mul(c_not(scalar_mult), schnorr_mask);
-    const fp addition = fp_mul(c_not(doubling), scalar_mult);
-    SectionAcc &s = sa;
-    s.begin(); // flags are part of the values here
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const fp dflag = f.pv(P_DIGEST + i);
-        const fp c = f.cur(41 - i), nx = f.next(41 - i);
-        s.term(41 - i, fp_add(fp_mul(fp_mul(dflag, doubling), fp_sub(nx, fp_add(fp_dbl(c), f.next(37)))), fp_mul(fp_mul(c_not(dflag), doubling), fp_sub(c, nx))));
-        s.term(38 + i, fp_add(fp_mul(addition, fp_sub(f.cur(38 + i), f.next(38 + i))), fp_mul(final_add, fp_sub(f.cur(38 + i), f.cur(42 + i)))));
-    }
-    {
-        const fp b18 = f.cur(18), b37 = f.cur(37);
-        s.term(18, fp_add(fp_mul(doubling, c_is_binary(b18)), fp_mul(addition, fp_sub(b18, f.next(18)))));
-        s.term(37, fp_add(fp_mul(doubling, c_is_binary(b37)), fp_mul(addition, fp_sub(b37, f.next(37)))));
-    }
-    s.flush<G2>(FP_ONE, tot);
-    s.begin();
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-        s.term(42 + i, fp_sub(f.cur(42 + i), f.next(42 + i)));
-        s.term(49 + i, fp_sub(f.next(49 + i), inp[i]));
-    }
-    s.flush<G2>(copy_hash, tot);
-    const fp dbit = f.next(DELTA_BIT), sbit = f.next(SIGMA_BIT);
-    s.begin();
-    s.term(DELTA_ACC, fp_sub(f.next(DELTA_ACC), fp_add(fp_dbl(f.cur(DELTA_ACC)), dbit)));
-    s.term(DELTA_BIT, c_is_binary(dbit));
-    s.term(SIGMA_ACC, fp_sub(f.next(SIGMA_ACC), fp_add(fp_dbl(f.cur(SIGMA_ACC)), sbit)));
-    s.term(SIGMA_BIT, c_is_binary(sbit));
-    s.flush<G2 | G3 | G4>(range_flag, tot);
-    const fp dr = fp_sub(f.next(DELTA_ACC), f.next(DELTA_COPY));
-    s.begin();
-    s.term(DELTA_RANGE_RES, dr);
-    s.term(SIGMA_RANGE_RES, dr);
-    s.flush<G4>(range_finish, tot);
+    };
+
+    fp LA[NL], LB[NL];
+    load(std::integral_constant<int, 0>{}, LA);
+    static_for(std::make_integer_sequence<int, NSTAGE>{}, [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k + 1 < NSTAGE) load(std::integral_constant<int, k + 1>{}, (k & 1) ? LA : LB);
+        CS_LIN_SECTION();
+        compute(kc, (k & 1) ? LB : LA);
+        CS_LIN_SECTION();
+    });
 }
-// adds to the four polynomials of the first family: out = [4][4 even cosets][n].  grid = (n / FNT, 4); one launch per coefficient set
+#undef CS_LIN_SECTION
+// adds to the four polynomials of the first family: out = [4][4 even cosets][n].  grid = (n / FNT, 4); one launch per coefficient set.
+// BUF: the frame is read with buffer loads (FrameB; a coset's table below 4 GB), else through 64-bit pointers.
+template <bool BUF>
 __global__ __launch_bounds__(FNT, CS_LIN_ALL_WAVES) void k_lin_all(CeParams p, fp *__restrict__ out, unsigned set) {
     const size_t n = (size_t)1 << p.log_n;
     const size_t j = blockIdx.x * (size_t)FNT + threadIdx.x;
     const unsigned kc = (p.k0 >> 1) + blockIdx.y; // (k_rounds_split)
-    const Frame f = make_frame(p, 2 * blockIdx.y, j);
     out += (size_t)set * SPLIT_TABLES * 4 * n;
     const CS_CONST fp *coefs = as_const(p.coef + (size_t)set * CE_COEF_WORDS);
     fp tot[6] = {0, 0, 0, 0, 0, 0};
-    lin_all_split(coefs, f, tot);
+    if constexpr (BUF) lin_all_split(coefs, make_frame_b(p, 2 * blockIdx.y, j), tot);
+    else lin_all_split(coefs, make_frame(p, 2 * blockIdx.y, j), tot);
     const fp xd1 = split_lift(p, 2 * kc, j);
     // beta of groups 2, 3, 4 in one table: S_2 + x^(n-1) S_3 + x^(2n-2) S_4
     tot[3] = fp_add(tot[3], fp_mul(xd1, fp_add(tot[4], fp_mul(xd1, tot[5]))));
@@ -2565,7 +2695,11 @@ hipError_t launch_lin_all(const CeParams &p, uint64_t *d_even_family0, hipStream
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), p.nkc ? p.nkc : 4), block(FNT);
     const unsigned m = p.m ? p.m : 1;
-    for (unsigned set = 0; set < m; set++) hipLaunchKernelGGL(k_lin_all, grid, block, 0, stream, p, d_even_family0, set);
+    const bool buf = p.log_n <= 22; // 94 n 8 bytes < 2^32: FrameB
+    for (unsigned set = 0; set < m; set++) {
+        if (buf) hipLaunchKernelGGL(k_lin_all<true>, grid, block, 0, stream, p, d_even_family0, set);
+        else hipLaunchKernelGGL(k_lin_all<false>, grid, block, 0, stream, p, d_even_family0, set);
+    }
     return hipGetLastError();
 }
 hipError_t launch_lin_split(const CeParams &p, int part, uint64_t *d_even_family0, hipStream_t stream) {

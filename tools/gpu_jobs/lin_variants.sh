@@ -1,10 +1,17 @@
+# A/B of k_lin_all builds (tools/build_variant_fast.py NAME constraints.hip -D...): stage timing on random data + parity of the stage
+# usage: bash tools/gpu_jobs/lin_variants.sh OUT.txt name1 name2 ...   ("base" = the regular library)
 mkdir -p gpurun_out
 R=$PWD
+OUT=$1; shift
 {
 for rep in 1 2; do
-echo "== old three launches"; CSTARK_LIN_MERGED=0 python3 tools/bench_ce.py 20 5 split | tail -2
-for v in "" linw2 linw4 linu7 linu7b; do
-  echo "== merged [$v]"; CSTARK_LIB=$R/certificate-stark_amd/libcstark_hip${v:+_$v}.so python3 tools/bench_ce.py 20 5 split | tail -2
+for v in "$@"; do
+  L=$R/certificate-stark_amd/libcstark_hip_$v.so; [ "$v" = base ] && L=$R/certificate-stark_amd/libcstark_hip.so
+  echo "== k_lin_all [$v]"; CSTARK_LIB=$L python3 tools/bench_ce.py 20 5 split | tail -2
 done
 done
-} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r03_lin_variants.txt
+for v in "$@"; do
+  [ "$v" = base ] && continue
+  echo "== parity [$v]"; CSTARK_LIB=$R/certificate-stark_amd/libcstark_hip_$v.so python3 -m pytest -q -x -m gpu tests/test_gpu_constraints.py tests/test_gpu_composition.py 2>&1 | tail -2
+done
+} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/$OUT
