@@ -621,7 +621,7 @@ def main():
         if pts_headline and args.mode == "prove":
             pts = {"k_ntt_cols_v5<4, 3, 3, false>": 0, "k_ntt_rows_v5<4, 3, 3, false>": 0, "k_rounds_split<1>": 4 * n, "k_ec_split<1, false, 1>": 4 * n,
                    "k_ec_split<2, false, 1>": 4 * n, "k_ec_split<3, true, 1>": 4 * n, "k_ec_split<4, false, 1>": 4 * n, "k_final_split<1>": 4 * n,
-                   "k_lin_all": 4 * n, "k_split_finish<1>": 8 * n, "k_hash_rows": 0, "k_trace_schnorr_ec<false, 16>": 2 * n_tx * 511, "k_deep": n}
+                   "k_lin_all<true>": 4 * n, "k_split_finish<1>": 8 * n, "k_hash_rows": 0, "k_trace_schnorr_ec<false, 16>": 2 * n_tx * 511, "k_deep": n}
             issue_roofline = [e for e in (valu.entry(k, p) for k, p in pts.items()) if e is not None] or None
         out = {
             "metric": ("proofs/sec, state_transition AIR @ 2^%d steps (complete prove(): trace gen, LDE, Blake3 commitments, constraint "
