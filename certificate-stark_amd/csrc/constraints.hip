@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "constraints.h"
 #include "mds_mfma.cuh"
+#include "rounds_layout.h"
 #include "rescue.cuh"
 #include "tower.cuh"
 
@@ -486,22 +487,9 @@ __device__ __forceinline__ void split_limbs(fp v, uint32_t *out4) {
     out4[0] = (uint32_t)v & 0x1fffffu; out4[1] = (uint32_t)(v >> 21) & 0x1fffffu; out4[2] = (uint32_t)(v >> 42); out4[3] = 0;
 }
 
-// the five Rescue windows: {first register, result base A, flag A, result base B, flag B (-1: none)}; flag 3 = setup + hash
-// (window 0 writes the same result slots under both flags, so one sum serves both)
-struct RoundWindow { int reg, res_a, flag_a, res_b, flag_b; }; // dwords: sub-dword constants cannot be scalar loads
-__constant__ RoundWindow c_windows[5] = {
-    {S_INIT, S_INIT, 3, 0, -1}, {S_UPD, S_UPD - 1, 0, S_UPD, 1}, {R_INIT, R_INIT - 1, 0, R_INIT, 1}, {R_UPD, R_UPD - 2, 0, R_UPD, 1},
-    {42, 42, 2, 0, -1}};
-// degree groups present among the 14 result slots of each (window, flag set); -1 = unused
-__constant__ int c_window_groups[5][2][3] = {
-    {{0, 1, -1}, {-1, -1, -1}}, {{1, 2, 0}, {1, 2, 0}}, {{0, 2, -1}, {0, 2, -1}}, {{2, -1, -1}, {2, -1, -1}}, {{2, -1, -1}, {-1, -1, -1}}};
-constexpr int RT_SECTIONS = 5 * 2 * 4;                 // (window, flag set, {alpha, beta of up to 3 groups})
-// CeParams::rtab (u64 words): A[sections][64] | limbs of U[sections][14] (4 dwords each) | matrix-core table of INV_MDS
-constexpr int RT_A = 0, RT_UL = RT_SECTIONS * 64, RT_ML = RT_UL + RT_SECTIONS * 14 * 2, RT_MT = RT_ML + 14 * 14 * 2;
-constexpr size_t MT_BYTES = (mdsmfma::table_bytes(14) + 15) & ~(size_t)15;
-constexpr int RT_G = RT_MT + (int)(MT_BYTES / 8);       // the sections' coefficient vectors themselves (split evaluation)
-constexpr int RT_SIZE = RT_G + RT_SECTIONS * 14;
-static_assert(RT_SIZE <= CE_RTAB_WORDS, "rtab size");
+// the five Rescue windows and the layout of CeParams::rtab: rounds_layout.h
+__constant__ RoundWindow c_windows[5] = CS_ROUND_WINDOWS_INIT;
+__constant__ int c_window_groups[5][2][3] = CS_WINDOW_GROUPS_INIT;
 constexpr size_t ROUNDS_LDS = MT_BYTES + (FNT / 64) * 64 * mdsmfma::ROW_BYTES; // table + one staging image per wave
 #ifdef CS_ROUNDS_MFMA
 constexpr size_t ROUNDS_DYN_LDS = ROUNDS_LDS;
@@ -2671,6 +2659,9 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), p.nkc ? p.nkc : 4), block(FNT);
     const unsigned m = p.m ? p.m : 1;
+    // one coefficient set: the matrix-core kernel (rounds_mfma.hip; same values).  CSTARK_ROUNDS_MFMA=0: the vector-ALU kernel below
+    static const bool mfma_env = [] { const char *e = getenv("CSTARK_ROUNDS_MFMA"); return !e || atoi(e) != 0; }();
+    if (m == 1 && mfma_env && n % 512 == 0) return launch_rounds_mfma(p, d_even, stream);
     if (m == 1) hipLaunchKernelGGL(k_rounds_split<1>, grid, block, 0, stream, p, d_even);
     else if (m == 2) hipLaunchKernelGGL(k_rounds_split<2>, grid, block, 0, stream, p, d_even);
     else if (m == 3) hipLaunchKernelGGL(k_rounds_split<3>, grid, block, 0, stream, p, d_even);
