@@ -32,8 +32,8 @@ constexpr int RT_MF = (RT_G + RT_SECTIONS * 14 + 1) & ~1; // 16-byte aligned
 constexpr int MF_TILES_INV = 7, MF_TILES_SEC = 13, MF_KS_INV = 4, MF_KS_SEC = 7;
 constexpr int MF_INV_D = RT_MF;                                  // [7][2 g][2 h][8 m]
 constexpr int MF_SEC_D = MF_INV_D + MF_TILES_INV * 4 * 8;        // [13][2 g][2 h][16 m]
-constexpr int MF_K = MF_SEC_D + MF_TILES_SEC * 4 * 16;           // [14 + 26][2]: 128-bit row constants (lo, hi)
-constexpr int RT_SIZE = MF_K + (14 + 2 * MF_TILES_SEC) * 2;
+constexpr int MF_K = MF_SEC_D + MF_TILES_SEC * 4 * 16;           // [14 + 26][4]: the 32-bit words of the 128-bit row constants, one per u64
+constexpr int RT_SIZE = MF_K + (14 + 2 * MF_TILES_SEC) * 4;
 static_assert(RT_SIZE <= CE_RTAB_WORDS, "rtab size");
 // section tile t -> (window, flag set, pair); window w owns the tiles [mf_tile_base(w), mf_tile_base(w + 1))
 __host__ __device__ constexpr int mf_tile_base(int w) { return w == 0 ? 0 : w == 1 ? 2 : w == 2 ? 6 : w == 3 ? 10 : w == 4 ? 12 : 13; }

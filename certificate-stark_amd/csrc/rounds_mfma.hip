@@ -31,7 +31,13 @@ using mdsmfma::v16i;
 using mdsmfma::v4i;
 typedef unsigned __int128 u128;
 
-constexpr int RM_NT = 512;                      // threads per workgroup: eight waves share one expanded inverse table
+#ifndef RM_NT_
+#define RM_NT_ 256
+#endif
+#ifndef RM_WAVES
+#define RM_WAVES 2
+#endif
+constexpr int RM_NT = RM_NT_;                    // threads per workgroup: eight waves share one expanded inverse table
 constexpr int RW_ROWS = 66, RW_IMG = 14 * RW_ROWS; // window image of a wave: 14 columns x rows j0 .. j0 + 65 (k_rounds_split's)
 constexpr uint64_t X0 = mdsmfma::X0;
 constexpr uint64_t HALF_P = (FP_P - 1) / 2;
@@ -71,8 +77,7 @@ __global__ void k_rounds_mfma_tables(fp *__restrict__ rtab) {
             u128 k = 0;
             for (int j = 0; j < 14; j++) k += (u128)c_inv_mds[i * 14 + j] * X0;
             k -= acc0_offset();
-            rtab[MF_K + 2 * i] = (uint64_t)k;
-            rtab[MF_K + 2 * i + 1] = (uint64_t)(k >> 64);
+            for (int q = 0; q < 4; q++) rtab[MF_K + 4 * i + q] = (uint32_t)(k >> (32 * q));
         }
         return;
     }
@@ -100,8 +105,7 @@ __global__ void k_rounds_mfma_tables(fp *__restrict__ rtab) {
         const fp kc = fp_mul(fp_mul(X0 + HALF_P, s), FP_R2); // the plain product of the two integers mod p
         u128 k = (u128)kc + ((u128)(2 * FP_P) << 64);
         k -= acc0_offset();
-        rtab[MF_K + 2 * (14 + 2 * tile + t)] = (uint64_t)k;
-        rtab[MF_K + 2 * (14 + 2 * tile + t) + 1] = (uint64_t)(k >> 64);
+        for (int q = 0; q < 4; q++) rtab[MF_K + 4 * (14 + 2 * tile + t) + q] = (uint32_t)(k >> (32 * q));
     }
 }
 
@@ -135,22 +139,42 @@ __device__ __forceinline__ v16i acc_start() {
     for (int v = 0; v < 16; v++) a[v] = mdsmfma::ACC0;
     return a;
 }
-__device__ __forceinline__ void tot_add(fp (&t)[4], int q, fp v) { // q uniform
-    if (q == 0) t[0] = fp_add(t[0], v);
-    else if (q == 1) t[1] = fp_add(t[1], v);
-    else if (q == 2) t[2] = fp_add(t[2], v);
-    else t[3] = fp_add(t[3], v);
+// The 15 byte diagonals of one output (non-negative, below 2^24) and the row constant -> Montgomery-reduced field element.
+// Diagonal d sits at bit 8 d: the four diagonals 4 q .. 4 q + 3 of 32-bit word q are summed with their shifts by three
+// v_mad_u64_u32 on top of the constant's word q (a fourth carries diagonal 4 q into the 64-bit sum: multiplication by an opaque
+// one), and the four sums S_q < 2^49 overlap by their high words only: three carry additions.  18 instructions, where packing the
+// diagonals into three carry-free 128-bit words and adding those (mdsmfma::recombine) takes 29.
+__device__ __forceinline__ fp recombine_mad(const v16i &acc, const uint64_t (&k)[4], uint32_t one) {
+    uint64_t s[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint64_t t = mad_u64_u32((uint32_t)acc[4 * q], one, k[q]);
+        t = mad_u64_u32((uint32_t)acc[4 * q + 1], 1u << 8, t);
+        t = mad_u64_u32((uint32_t)acc[4 * q + 2], 1u << 16, t);
+        if (4 * q + 3 < 15) t = mad_u64_u32((uint32_t)acc[4 * q + 3], 1u << 24, t);
+        s[q] = t;
+    }
+    unsigned c;
+    const uint32_t w0 = (uint32_t)s[0];
+    const uint32_t w1 = __builtin_addc((uint32_t)(s[0] >> 32), (uint32_t)s[1], 0u, &c);
+    const uint32_t w2 = __builtin_addc((uint32_t)(s[1] >> 32), (uint32_t)s[2], c, &c);
+    const uint32_t w3 = (uint32_t)(s[2] >> 32) + (uint32_t)s[3] + c;
+    Acc128 a{((uint64_t)w1 << 32) | w0, ((uint64_t)w3 << 32) | w2};
+    acc_fold(a);
+    return acc_reduce(a);
 }
 
 constexpr size_t RM_LDS_INV = (size_t)MF_TILES_INV * MF_KS_INV * 64 * 16;                 // expanded inverse table
 constexpr size_t RM_LDS_IMG = (size_t)(RM_NT / 64) * RW_IMG * 8;
 constexpr size_t RM_LDS_SEC = (size_t)MF_TILES_SEC * 4 * 16 * 8;                          // compact section tables
-constexpr size_t RM_LDS_K = (size_t)(14 + 2 * MF_TILES_SEC) * 16;
-constexpr size_t RM_LDS_ARK = 8 * 14 * 8 + 16, RM_LDS_ATAB = (size_t)RT_SECTIONS * 8 * 8; // + 16: the padded columns 14, 15 of row 7
+constexpr size_t RM_LDS_K = (size_t)(14 + 2 * MF_TILES_SEC) * 32;
+constexpr size_t RM_LDS_ARK = 8 * 14 * 8, RM_LDS_ATAB = (size_t)RT_SECTIONS * 8 * 8;
 constexpr size_t RM_LDS = RM_LDS_INV + RM_LDS_IMG + RM_LDS_SEC + RM_LDS_K + RM_LDS_ARK + RM_LDS_ATAB;
+constexpr unsigned RM_RESIDENT = 2 * 256; // workgroups that are resident at once (two per CU: LDS and registers): the grid
 
-// out = [4 polynomials][4 even cosets][n] as k_rounds_split<1> writes them.  grid = (n / RM_NT, even cosets of the window)
-__global__ __launch_bounds__(RM_NT, 2) void k_rounds_mfma(CeParams p, fp *__restrict__ out) {
+// out = [4 polynomials][4 even cosets][n] as k_rounds_split<1> writes them.  grid = (workgroups per coset, even cosets of the
+// window): a workgroup expands its tables once and then takes every gridDim.x-th block of RM_NT rows of its coset.
+__global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     v4i *inv_lds = (v4i *)lds;
     fp *img_all = (fp *)(lds + RM_LDS_INV);
@@ -162,7 +186,6 @@ __global__ __launch_bounds__(RM_NT, 2) void k_rounds_mfma(CeParams p, fp *__rest
     const size_t n = (size_t)1 << p.log_n;
     const unsigned kk = 2 * blockIdx.y, kc = (p.k0 >> 1) + blockIdx.y, ka = 2 * kc; // (k_rounds_split)
     const int tid = threadIdx.x, lane = tid & 63, nn = lane & 31, h = lane >> 5;
-    const size_t jw = blockIdx.x * (size_t)RM_NT + (size_t)(tid >> 6) * 64; // the wave's first row
     // tile row of this lane as an A operand: r = lane & 31 -> output g = (r >> 2) & 1, byte diagonal d = (r & 3) + 4 (r >> 3)
     const int ag = (nn >> 2) & 1, ad = (nn & 3) + 4 * (nn >> 3);
     uint32_t sel_lo = 0, sel_hi = 0; // byte b of the fragment word = digit ad - b of the entry (0x0c: constant zero)
@@ -186,108 +209,132 @@ __global__ __launch_bounds__(RM_NT, 2) void k_rounds_mfma(CeParams p, fp *__rest
     }
     for (unsigned e = tid; e < RM_LDS_SEC / 8; e += RM_NT) secd_lds[e] = rt[MF_SEC_D + e];
     for (unsigned e = tid; e < RM_LDS_K / 8; e += RM_NT) k_lds[e] = rt[MF_K + e];
-    if (tid < 8 * 14) {
+    if (tid < 8 * 14) { // the round constants' extension has period 8 in the row index: the same 8 x 14 values for every block of rows
         const unsigned r = tid / 14, c = tid % 14;
-        ark2_lds[tid] = p.ptab[((size_t)ka * 48 + P_ARK + 14 + c) * 1024 + ((blockIdx.x * (size_t)RM_NT + r) & 1023)];
+        ark2_lds[tid] = p.ptab[((size_t)ka * 48 + P_ARK + 14 + c) * 1024 + r];
     }
-    if (tid < 2) ark2_lds[8 * 14 + tid] = 0;
     for (unsigned e = tid; e < RT_SECTIONS * 8; e += RM_NT) atab_lds[e] = rt[RT_A + (e >> 3) * 64 + ka * 8 + (e & 7)];
     __syncthreads();
 
     fp *img = img_all + (size_t)(tid >> 6) * RW_IMG;
-    const unsigned jr = (unsigned)(jw & 7); // the rows of both points mod 8 (nn + 32 = nn mod 8): jw + nn
-    const fp *ark2 = ark2_lds + ((jr + nn) & 7) * 14;
-    const unsigned jrp = (jr + nn) & 7;
-    const fp *per = p.ptab + (size_t)(p.k0 + kk) * 48 * 1024;
-    const size_t rA = (jw + nn) & 1023, rB = (jw + nn + 32) & 1023;
-    const fp flA[3] = {per[(size_t)P_SETUP * 1024 + rA], per[(size_t)P_HASH * 1024 + rA], per[(size_t)P_SCHNORR_HASH * 1024 + rA]};
-    const fp flB[3] = {per[(size_t)P_SETUP * 1024 + rB], per[(size_t)P_HASH * 1024 + rB], per[(size_t)P_SCHNORR_HASH * 1024 + rB]};
-    const fp *colbase = p.lde + (size_t)kk * 94 * n;
-    const fp *rows = colbase + jw + 2 * lane; // rows jw + 2 lane, + 1; rows n, n + 1 of the coset's last wave wrap to 0, 1
-    if (lane == 32 && jw + 64 == n) rows -= n;
-    fetch_window(rows, n, c_windows[0].reg, lane, img);
-    fp totA[4] = {0, 0, 0, 0}, totB[4] = {0, 0, 0, 0};
     const fp *imgA = img + nn; // point n: current row at element n, next row at n + 1; point n + 32: + 32
+    const unsigned jrp = (unsigned)(nn & 7); // row of both points mod 8 (blocks and waves start at multiples of 64)
+    const fp *ark2 = ark2_lds + jrp * 14;
+    const fp *per = p.ptab + (size_t)(p.k0 + kk) * 48 * 1024;
+    const fp *colbase = p.lde + (size_t)kk * 94 * n;
+    const uint32_t one = fp_opaque_one();
+    const size_t nblk = n / RM_NT;
+    size_t blk = blockIdx.x;
+    // rows jw + 2 lane, + 1 of the wave's 64 points (first row jw); rows n, n + 1 of the coset's last wave wrap to 0, 1
+    auto rows_of = [&](size_t b) {
+        const size_t jw = b * (size_t)RM_NT + (size_t)(tid >> 6) * 64;
+        return colbase + jw + 2 * lane - ((lane == 32 && jw + 64 == n) ? n : 0);
+    };
+    const fp *rows = rows_of(blk);
+    if (blk < nblk) fetch_window(rows, n, c_windows[0].reg, lane, img);
 #pragma unroll 1
-    for (int wdx = 0; wdx < 5; wdx++) {
-        const RoundWindow w = c_windows[wdx];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // operands of the inverse matrix: (next - ark2) of columns 4 s + 2 h, + 1 (k-step 3 of half 1 is padding: any finite bytes)
-        v4i bA[MF_KS_INV], bB[MF_KS_INV];
-#pragma unroll
-        for (int s = 0; s < MF_KS_INV; s++) {
-            const int jb = (s == 3 && h) ? 12 : 4 * s + 2 * h;
-            const fp k0 = ark2[jb], k1 = ark2[jb + 1];
-            bA[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 1], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 1], k1) ^ X0);
-            bB[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 33], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 33], k1) ^ X0);
-        }
-        // cube(INV_MDS d)_i, i = 2 T + h, of both points; operands of the sections' product as they come
-        v4i cA[MF_KS_SEC], cB[MF_KS_SEC];
-        uint64_t heldA = 0, heldB = 0;
-#pragma unroll
-        for (int T = 0; T < MF_TILES_INV; T++) {
-            v16i a0 = acc_start(), a1 = acc_start();
+    for (; blk < nblk; blk += gridDim.x) {
+        const size_t jw = blk * (size_t)RM_NT + (size_t)(tid >> 6) * 64; // the wave's first row
+        const size_t rA = (jw + nn) & 1023, rB = (jw + nn + 32) & 1023;
+        const fp flA[3] = {per[(size_t)P_SETUP * 1024 + rA], per[(size_t)P_HASH * 1024 + rA], per[(size_t)P_SCHNORR_HASH * 1024 + rA]};
+        const fp flB[3] = {per[(size_t)P_SETUP * 1024 + rB], per[(size_t)P_HASH * 1024 + rB], per[(size_t)P_SCHNORR_HASH * 1024 + rB]};
+        // Sums per STREAM, not per polynomial: a lane's sections are slot u = 0 (h = 0: alpha; h = 1: slot 1) and slot u = 1 (h = 0:
+        // slot 2; h = 1: slot 3) of every flag set, and which polynomial a slot feeds depends on the window alone -- so the register
+        // a term goes to is the same for both lane halves: stream 0 -> polynomial of slot 1 (windows 0..4: 1, 2, 1, 3, 3), stream 1 ->
+        // polynomial of slot 2 (2, 3, 3).  Half 0 reads stream 0 as alpha whatever the register, half 1 reads stream 1 as polynomial 1
+        // (slot 3 is used in window 1 only, there by group 0).
+        fp sA[5] = {0, 0, 0, 0, 0}, sB[5] = {0, 0, 0, 0, 0}; // stream 0 -> polynomials 1, 2, 3 | stream 1 -> polynomials 2, 3
+#pragma unroll 1
+        for (int wdx = 0; wdx < 5; wdx++) {
+            const RoundWindow w = c_windows[wdx];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // operands of the inverse matrix: (next - ark2) of columns 4 s + 2 h, + 1 (k-step 3 of half 1 is padding: its table bytes are 0)
+            v4i bA[MF_KS_INV], bB[MF_KS_INV];
 #pragma unroll
             for (int s = 0; s < MF_KS_INV; s++) {
-                const v4i a = inv_lds[(T * MF_KS_INV + s) * 64 + lane];
-                a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bA[s], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bB[s], a1, 0, 0, 0);
+                const int jb = (s == 3 && h) ? 12 : 4 * s + 2 * h;
+                const fp k0 = ark2[jb], k1 = ark2[jb + 1];
+                bA[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 1], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 1], k1) ^ X0);
+                bB[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 33], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 33], k1) ^ X0);
             }
-            const uint64_t klo = k_lds[2 * (2 * T + h)], khi = k_lds[2 * (2 * T + h) + 1];
-            const uint64_t xa = (fp_cube(mdsmfma::recombine(a0, klo, khi)) - HALF_P) ^ X0;
-            const uint64_t xb = (fp_cube(mdsmfma::recombine(a1, klo, khi)) - HALF_P) ^ X0;
-            if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
-            else { heldA = xa; heldB = xb; }
-        }
-        // forward half: cube(cur_j), j = 2 t + h
+            // cube(INV_MDS d)_i, i = 2 T + h, of both points; operands of the sections' product as they come
+            v4i cA[MF_KS_SEC], cB[MF_KS_SEC];
+            uint64_t heldA = 0, heldB = 0;
 #pragma unroll
-        for (int t = 0; t < 7; t++) {
-            const uint64_t xa = (fp_cube(imgA[(2 * t + h) * RW_ROWS]) - HALF_P) ^ X0;
-            const uint64_t xb = (fp_cube(imgA[(2 * t + h) * RW_ROWS + 32]) - HALF_P) ^ X0;
-            if (t & 1) { heldA = xa; heldB = xb; }
-            else { cA[3 + (t >> 1)] = pack2(heldA, xa); cB[3 + (t >> 1)] = pack2(heldB, xb); }
-        }
-        if (wdx < 4) { // the image is free again: the next window arrives behind the sections' product
+            for (int T = 0; T < MF_TILES_INV; T++) {
+                v16i a0 = acc_start(), a1 = acc_start();
+#pragma unroll
+                for (int s = 0; s < MF_KS_INV; s++) {
+                    const v4i a = inv_lds[(T * MF_KS_INV + s) * 64 + lane];
+                    a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bA[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bB[s], a1, 0, 0, 0);
+                }
+                const uint64_t *kp = k_lds + 4 * (2 * T + h);
+                const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
+                const uint64_t xa = (fp_cube(recombine_mad(a0, kw, one)) - HALF_P) ^ X0;
+                const uint64_t xb = (fp_cube(recombine_mad(a1, kw, one)) - HALF_P) ^ X0;
+                if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
+                else { heldA = xa; heldB = xb; }
+            }
+            // forward half: cube(cur_j), j = 2 t + h
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                const uint64_t xa = (fp_cube(imgA[(2 * t + h) * RW_ROWS]) - HALF_P) ^ X0;
+                const uint64_t xb = (fp_cube(imgA[(2 * t + h) * RW_ROWS + 32]) - HALF_P) ^ X0;
+                if (t & 1) { heldA = xa; heldB = xb; }
+                else { cA[3 + (t >> 1)] = pack2(heldA, xa); cB[3 + (t >> 1)] = pack2(heldB, xb); }
+            }
+            // the image is free again: the next window (of this block, or the first one of the workgroup's next block) arrives behind
+            // the sections' product
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            fetch_window(rows, n, c_windows[wdx + 1].reg, lane, img);
-        }
-        const int t0 = mf_tile_base(wdx), t1 = mf_tile_base(wdx + 1);
+            if (wdx < 4) fetch_window(rows, n, c_windows[wdx + 1].reg, lane, img);
+            else if (blk + gridDim.x < nblk) { rows = rows_of(blk + gridDim.x); fetch_window(rows, n, c_windows[0].reg, lane, img); }
+            fp xA[2] = {0, 0}, xB[2] = {0, 0}; // the window's terms of stream u
+            const int t0 = mf_tile_base(wdx), t1 = mf_tile_base(wdx + 1);
 #pragma unroll 1
-        for (int tile = t0; tile < t1; tile++) {
-            const int local = tile - t0, fs = mf_tile_fs(wdx, local), u = mf_tile_pair(wdx, local);
-            v16i a0 = acc_start(), a1 = acc_start();
-            const uint64_t *dw = secd_lds + (tile * 4 + ag * 2 + h) * 16;
+            for (int tile = t0; tile < t1; tile++) {
+                const int local = tile - t0, fs = mf_tile_fs(wdx, local), u = mf_tile_pair(wdx, local);
+                v16i a0 = acc_start(), a1 = acc_start();
+                const uint64_t *dw = secd_lds + (tile * 4 + ag * 2 + h) * 16;
 #pragma unroll
-            for (int s = 0; s < MF_KS_SEC; s++) {
-                const v4i a = expand_frag(dw[2 * s], dw[2 * s + 1], sel_lo, sel_hi);
-                a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cA[s], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cB[s], a1, 0, 0, 0);
+                for (int s = 0; s < MF_KS_SEC; s++) {
+                    const v4i a = expand_frag(dw[2 * s], dw[2 * s + 1], sel_lo, sel_hi);
+                    a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cA[s], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cB[s], a1, 0, 0, 0);
+                }
+                const uint64_t *kp = k_lds + 4 * (14 + 2 * tile + h);
+                const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
+                const int sec = (wdx * 2 + fs) * 4 + 2 * u + h; // this lane's section: slot 2 u + h
+                const fp at = atab_lds[sec * 8 + jrp];
+                const int fl = fs ? w.flag_b : w.flag_a;
+                const fp fa = fl == 0 ? flA[0] : fl == 1 ? flA[1] : fl == 2 ? flA[2] : fp_add(flA[0], flA[1]);
+                const fp fb = fl == 0 ? flB[0] : fl == 1 ? flB[1] : fl == 2 ? flB[2] : fp_add(flB[0], flB[1]);
+                const fp va = fp_mul(fa, fp_sub(recombine_mad(a0, kw, one), at));
+                const fp vb = fp_mul(fb, fp_sub(recombine_mad(a1, kw, one), at));
+                if (u) { xA[1] = fp_add(xA[1], va); xB[1] = fp_add(xB[1], vb); }
+                else { xA[0] = fp_add(xA[0], va); xB[0] = fp_add(xB[0], vb); }
             }
-            const uint64_t klo = k_lds[2 * (14 + 2 * tile + h)], khi = k_lds[2 * (14 + 2 * tile + h) + 1];
-            const int sec = (wdx * 2 + fs) * 4 + 2 * u + h; // this lane's section: slot 2 u + h
-            const fp at = atab_lds[sec * 8 + jrp];
-            const int fl = fs ? w.flag_b : w.flag_a;
-            const fp fa = fl == 0 ? flA[0] : fl == 1 ? flA[1] : fl == 2 ? flA[2] : fp_add(flA[0], flA[1]);
-            const fp fb = fl == 0 ? flB[0] : fl == 1 ? flB[1] : fl == 2 ? flB[2] : fp_add(flB[0], flB[1]);
-            const fp va = fp_mul(fa, fp_sub(mdsmfma::recombine(a0, klo, khi), at));
-            const fp vb = fp_mul(fb, fp_sub(mdsmfma::recombine(a1, klo, khi), at));
-            // polynomial of slot 0: alpha; of slot s >= 1: beta of group c_window_groups[.][.][s - 1] (an unused slot's rows are zero)
-            const int g0 = u ? c_window_groups[wdx][fs][1] : -2, g1 = c_window_groups[wdx][fs][2 * u];
-            const int q0 = g0 == -2 ? 0 : g0 < 0 ? 0 : 1 + g0, q1 = g1 < 0 ? 0 : 1 + g1;
-            if (q0 == q1) { tot_add(totA, q0, va); tot_add(totB, q0, vb); }
-            else {
-                tot_add(totA, q0, h ? 0 : va); tot_add(totB, q0, h ? 0 : vb);
-                tot_add(totA, q1, h ? va : 0); tot_add(totB, q1, h ? vb : 0);
-            }
+            // stream 0 -> polynomial of slot 1: 1, 2, 1, 3, 3; stream 1 -> polynomial of slot 2: 2, 3, 3 (windows 3, 4: no pair 1)
+            if (wdx == 0 || wdx == 2) { sA[0] = fp_add(sA[0], xA[0]); sB[0] = fp_add(sB[0], xB[0]); }
+            else if (wdx == 1) { sA[1] = fp_add(sA[1], xA[0]); sB[1] = fp_add(sB[1], xB[0]); }
+            else { sA[2] = fp_add(sA[2], xA[0]); sB[2] = fp_add(sB[2], xB[0]); }
+            if (wdx == 0) { sA[3] = fp_add(sA[3], xA[1]); sB[3] = fp_add(sB[3], xB[1]); }
+            else if (wdx < 3) { sA[4] = fp_add(sA[4], xA[1]); sB[4] = fp_add(sB[4], xB[1]); }
         }
-    }
-    // the two halves of a point: lane (n, 0) holds point n's slots 0, 2 in totA and lane (n, 1) its slots 1, 3; likewise totB for n + 32
-    const size_t j = jw + lane;
+        // polynomials 0..3 of this lane's sections: half 0: stream 0 is alpha, stream 1 by register; half 1: stream 0 by register,
+        // stream 1 is polynomial 1.  Then the two halves of a point: lane (n, 0) holds its part of point n in A and lane (n, 1) the
+        // rest, likewise B for point n + 32.
+        const fp a012 = fp_add(fp_add(sA[0], sA[1]), sA[2]), a34 = fp_add(sA[3], sA[4]);
+        const fp b012 = fp_add(fp_add(sB[0], sB[1]), sB[2]), b34 = fp_add(sB[3], sB[4]);
+        const fp totA[4] = {h ? 0 : a012, h ? fp_add(sA[0], a34) : 0, h ? sA[1] : sA[3], h ? sA[2] : sA[4]};
+        const fp totB[4] = {h ? 0 : b012, h ? fp_add(sB[0], b34) : 0, h ? sB[1] : sB[3], h ? sB[2] : sB[4]};
+        const size_t j = jw + lane;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const fp mine = h ? totB[q] : totA[q], give = h ? totA[q] : totB[q]; // what the other half needs from this lane
-        const uint32_t lo = __shfl_xor((uint32_t)give, 32), hi = __shfl_xor((uint32_t)(give >> 32), 32);
-        out[((size_t)q * 4 + kc) * n + j] = fp_add(mine, ((uint64_t)hi << 32) | lo); // table 3: group 2 (k_rounds_split)
+        for (int q = 0; q < 4; q++) {
+            const fp mine = h ? totB[q] : totA[q], give = h ? totA[q] : totB[q]; // what the other half needs from this lane
+            const uint32_t lo = __shfl_xor((uint32_t)give, 32), hi = __shfl_xor((uint32_t)(give >> 32), 32);
+            out[((size_t)q * 4 + kc) * n + j] = fp_add(mine, ((uint64_t)hi << 32) | lo); // table 3: group 2 (k_rounds_split)
+        }
     }
 }
 
@@ -299,7 +346,8 @@ hipError_t launch_rounds_mfma(const CeParams &p, uint64_t *d_even, hipStream_t s
     static const hipError_t attr = hipFuncSetAttribute((const void *)k_rounds_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RM_LDS);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(k_rounds_mfma_tables, dim3(MF_TILES_INV + MF_TILES_SEC), dim3(64), 0, stream, p.rtab);
-    hipLaunchKernelGGL(k_rounds_mfma, dim3((unsigned)(n / RM_NT), p.nkc ? p.nkc : 4), dim3(RM_NT), RM_LDS, stream, p, d_even);
+    const unsigned ny = p.nkc ? p.nkc : 4, nblk = (unsigned)(n / RM_NT), gx = RM_RESIDENT / ny < nblk ? RM_RESIDENT / ny : nblk;
+    hipLaunchKernelGGL(k_rounds_mfma, dim3(gx, ny), dim3(RM_NT), RM_LDS, stream, p, d_even);
     return hipGetLastError();
 }
 
