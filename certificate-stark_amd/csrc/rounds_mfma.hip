@@ -144,24 +144,43 @@ __device__ __forceinline__ v16i acc_start() {
 // v_mad_u64_u32 on top of the constant's word q (a fourth carries diagonal 4 q into the 64-bit sum: multiplication by an opaque
 // one), and the four sums S_q < 2^49 overlap by their high words only: three carry additions.  18 instructions, where packing the
 // diagonals into three carry-free 128-bit words and adding those (mdsmfma::recombine) takes 29.
-__device__ __forceinline__ fp recombine_mad(const v16i &acc, const uint64_t (&k)[4], uint32_t one) {
+// A constant in a scalar register that the compiler cannot see through: x * c + t stays ONE v_mad_u64_u32 where the compiler's own
+// form of a multiplication by 2^8 / 2^16 / 2^24 is a 64-bit shift and a 64-bit add (two instructions of the same issue cost each).
+template <uint32_t V>
+__device__ __forceinline__ uint32_t opaque_const() {
+    uint32_t r;
+    asm("s_mov_b32 %0, %1" : "=s"(r) : "n"(V));
+    return r;
+}
+struct Shifts { uint32_t one, s8, s16, s24; };
+__device__ __forceinline__ fp recombine_mad(const v16i &acc, const uint64_t (&k)[4], const Shifts &c) {
+#ifdef RM_OLD_RECOMBINE
+    return mdsmfma::recombine(acc, k[0] | (k[1] << 32), k[2] | (k[3] << 32));
+#endif
     uint64_t s[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        uint64_t t = mad_u64_u32((uint32_t)acc[4 * q], one, k[q]);
-        t = mad_u64_u32((uint32_t)acc[4 * q + 1], 1u << 8, t);
-        t = mad_u64_u32((uint32_t)acc[4 * q + 2], 1u << 16, t);
-        if (4 * q + 3 < 15) t = mad_u64_u32((uint32_t)acc[4 * q + 3], 1u << 24, t);
+        uint64_t t = mad_u64_u32((uint32_t)acc[4 * q], c.one, k[q]);
+        t = mad_u64_u32((uint32_t)acc[4 * q + 1], c.s8, t);
+        t = mad_u64_u32((uint32_t)acc[4 * q + 2], c.s16, t);
+        if (4 * q + 3 < 15) t = mad_u64_u32((uint32_t)acc[4 * q + 3], c.s24, t);
         s[q] = t;
     }
-    unsigned c;
+    unsigned cy;
     const uint32_t w0 = (uint32_t)s[0];
-    const uint32_t w1 = __builtin_addc((uint32_t)(s[0] >> 32), (uint32_t)s[1], 0u, &c);
-    const uint32_t w2 = __builtin_addc((uint32_t)(s[1] >> 32), (uint32_t)s[2], c, &c);
-    const uint32_t w3 = (uint32_t)(s[2] >> 32) + (uint32_t)s[3] + c;
+    const uint32_t w1 = __builtin_addc((uint32_t)(s[0] >> 32), (uint32_t)s[1], 0u, &cy);
+    const uint32_t w2 = __builtin_addc((uint32_t)(s[1] >> 32), (uint32_t)s[2], cy, &cy);
+    const uint32_t w3 = (uint32_t)(s[2] >> 32) + (uint32_t)s[3] + cy;
     Acc128 a{((uint64_t)w1 << 32) | w0, ((uint64_t)w3 << 32) | w2};
     acc_fold(a);
     return acc_reduce(a);
+}
+// x^3 with the square left unreduced: it is the FIRST factor of the second product, which takes values below 2p (fp.cuh)
+__device__ __forceinline__ fp cube_l(fp x) {
+#ifdef RM_PLAIN_CUBE
+    return fp_cube(x);
+#endif
+    return fp_reduce_once(fp_mul_lazy(fp_mul_lazy(x, x), x));
 }
 
 constexpr size_t RM_LDS_INV = (size_t)MF_TILES_INV * MF_KS_INV * 64 * 16;                 // expanded inverse table
@@ -170,7 +189,10 @@ constexpr size_t RM_LDS_SEC = (size_t)MF_TILES_SEC * 4 * 16 * 8;                
 constexpr size_t RM_LDS_K = (size_t)(14 + 2 * MF_TILES_SEC) * 32;
 constexpr size_t RM_LDS_ARK = 8 * 14 * 8, RM_LDS_ATAB = (size_t)RT_SECTIONS * 8 * 8;
 constexpr size_t RM_LDS = RM_LDS_INV + RM_LDS_IMG + RM_LDS_SEC + RM_LDS_K + RM_LDS_ARK + RM_LDS_ATAB;
-constexpr unsigned RM_RESIDENT = 2 * 256; // workgroups that are resident at once (two per CU: LDS and registers): the grid
+#ifndef RM_RESIDENT_
+#define RM_RESIDENT_ (1u << 30)
+#endif
+constexpr unsigned RM_RESIDENT = RM_RESIDENT_; // workgroups that are resident at once (two per CU: LDS and registers): the grid
 
 // out = [4 polynomials][4 even cosets][n] as k_rounds_split<1> writes them.  grid = (workgroups per coset, even cosets of the
 // window): a workgroup expands its tables once and then takes every gridDim.x-th block of RM_NT rows of its coset.
@@ -222,7 +244,7 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
     const fp *ark2 = ark2_lds + jrp * 14;
     const fp *per = p.ptab + (size_t)(p.k0 + kk) * 48 * 1024;
     const fp *colbase = p.lde + (size_t)kk * 94 * n;
-    const uint32_t one = fp_opaque_one();
+    const Shifts sh{opaque_const<1>(), opaque_const<1u << 8>(), opaque_const<1u << 16>(), opaque_const<1u << 24>()};
     const size_t nblk = n / RM_NT;
     size_t blk = blockIdx.x;
     // rows jw + 2 lane, + 1 of the wave's 64 points (first row jw); rows n, n + 1 of the coset's last wave wrap to 0, 1
@@ -271,16 +293,16 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
                 }
                 const uint64_t *kp = k_lds + 4 * (2 * T + h);
                 const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
-                const uint64_t xa = (fp_cube(recombine_mad(a0, kw, one)) - HALF_P) ^ X0;
-                const uint64_t xb = (fp_cube(recombine_mad(a1, kw, one)) - HALF_P) ^ X0;
+                const uint64_t xa = (cube_l(recombine_mad(a0, kw, sh)) - HALF_P) ^ X0;
+                const uint64_t xb = (cube_l(recombine_mad(a1, kw, sh)) - HALF_P) ^ X0;
                 if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
                 else { heldA = xa; heldB = xb; }
             }
             // forward half: cube(cur_j), j = 2 t + h
 #pragma unroll
             for (int t = 0; t < 7; t++) {
-                const uint64_t xa = (fp_cube(imgA[(2 * t + h) * RW_ROWS]) - HALF_P) ^ X0;
-                const uint64_t xb = (fp_cube(imgA[(2 * t + h) * RW_ROWS + 32]) - HALF_P) ^ X0;
+                const uint64_t xa = (cube_l(imgA[(2 * t + h) * RW_ROWS]) - HALF_P) ^ X0;
+                const uint64_t xb = (cube_l(imgA[(2 * t + h) * RW_ROWS + 32]) - HALF_P) ^ X0;
                 if (t & 1) { heldA = xa; heldB = xb; }
                 else { cA[3 + (t >> 1)] = pack2(heldA, xa); cB[3 + (t >> 1)] = pack2(heldB, xb); }
             }
@@ -309,8 +331,8 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
                 const int fl = fs ? w.flag_b : w.flag_a;
                 const fp fa = fl == 0 ? flA[0] : fl == 1 ? flA[1] : fl == 2 ? flA[2] : fp_add(flA[0], flA[1]);
                 const fp fb = fl == 0 ? flB[0] : fl == 1 ? flB[1] : fl == 2 ? flB[2] : fp_add(flB[0], flB[1]);
-                const fp va = fp_mul(fa, fp_sub(recombine_mad(a0, kw, one), at));
-                const fp vb = fp_mul(fb, fp_sub(recombine_mad(a1, kw, one), at));
+                const fp va = fp_mul(fa, fp_sub(recombine_mad(a0, kw, sh), at));
+                const fp vb = fp_mul(fb, fp_sub(recombine_mad(a1, kw, sh), at));
                 if (u) { xA[1] = fp_add(xA[1], va); xB[1] = fp_add(xB[1], vb); }
                 else { xA[0] = fp_add(xA[0], va); xB[0] = fp_add(xB[0], vb); }
             }
