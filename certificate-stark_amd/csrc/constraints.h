@@ -77,7 +77,7 @@ hipError_t launch_eval_transitions_schnorr(const uint64_t *lde, const uint64_t *
 // MerkleAir likewise (one launch; ptab as for launch_eval_transitions_merkle)
 // d_rtab != null (MERKLE_RTAB_WORDS device words, scratch): the four Rescue round gadgets through their folded form (k_merkle_rounds; blowup
 // at most 8), round_group = p.t_grp of the round slots; null: every constraint through the generic frame evaluator
-constexpr int MERKLE_RTAB_WORDS = 1280;
+constexpr int MERKLE_RTAB_WORDS = 2048;
 hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, unsigned nk, hipStream_t stream, uint64_t *d_rtab = nullptr,
                                unsigned round_group = 0);
 hipError_t launch_schnorr_fused(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, unsigned nk, hipStream_t stream);

@@ -2318,8 +2318,7 @@ __global__ __launch_bounds__(FNT, 2) void k_merkle_fused(AirCombineParams p, con
 // window (alpha, beta: the 56 round slots share ONE declared degree, i.e. one power x^adj) instead of a 14 x 14 product; the window's
 // cells come by LDS-DMA, every LDE cell fetched once.  Exact arithmetic: the merged value is unchanged.
 // rtab (u64 words; sections = (window, {alpha, beta})): A[8][8 cosets][8] | limbs of U[8][14] | limbs of INV_MDS[196] | G[8][14]
-constexpr int MR_SECTIONS = 8, MR_A = 0, MR_UL = MR_SECTIONS * 64, MR_ML = MR_UL + MR_SECTIONS * 14 * 2, MR_G = MR_ML + 196 * 2, MR_SIZE = MR_G + MR_SECTIONS * 14;
-static_assert(MR_SIZE <= MERKLE_RTAB_WORDS, "MerkleAir rounds table");
+// (MR_* offsets: rounds_layout.h)
 // W0: first Rescue window of the AIR in c_windows (MerkleAir 0..3, SchnorrAir's message hash 4); PCOLS / ARKCOL: columns of the AIR's
 // periodic table and the first of its 28 round-constant columns
 template <int W0, int PCOLS, int ARKCOL>
@@ -2552,6 +2551,11 @@ hipError_t launch_schnorr_final_hi(const AirCombineParams &p, const uint64_t *d_
     hipLaunchKernelGGL(k_schnorr_final_hi, dim3((unsigned)(n / 256), 3), dim3(256), 0, stream, d_odd, d_direct, d_hi, half_m, p.log_n);
     return hipGetLastError();
 }
+// the folded round gadgets of the sub-AIRs on the matrix cores (rounds_mfma.hip; same values).  CSTARK_ROUNDS_MFMA=0: vector-ALU kernels
+static bool merkle_rounds_on_matrix_cores(size_t n) {
+    static const bool env = [] { const char *e = getenv("CSTARK_ROUNDS_MFMA"); return !e || atoi(e) != 0; }();
+    return env && n % 256 == 0;
+}
 hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t *aux, const uint64_t *ptab, const uint64_t *d_even, const uint64_t *d_odd,
                                        unsigned g0, unsigned g1, hipStream_t stream, uint64_t *d_rtab, unsigned round_group, const uint64_t *d_hi) {
     const size_t n = (size_t)1 << p.log_n;
@@ -2565,7 +2569,8 @@ hipError_t launch_schnorr_split_finish(const AirCombineParams &p, const uint64_t
     }
     if (d_rtab) { // the message hash's round gadget in the folded form (as MerkleAir's four), added to the output
         hipLaunchKernelGGL((k_merkle_rounds_setup<4, 36, 8>), dim3(2), dim3(64), 0, stream, p.t_alpha, p.t_beta, ptab, d_rtab, 8u);
-        hipLaunchKernelGGL((k_merkle_rounds<4, 1, 56, 36, 7, 8, true>), grid, block, 0, stream, p, ptab, (const fp *)d_rtab, round_group);
+        if (merkle_rounds_on_matrix_cores(n)) { const hipError_t e = launch_merkle_rounds_mfma(p, ptab, d_rtab, 8, round_group, 1, stream); if (e != hipSuccess) return e; }
+        else hipLaunchKernelGGL((k_merkle_rounds<4, 1, 56, 36, 7, 8, true>), grid, block, 0, stream, p, ptab, (const fp *)d_rtab, round_group);
         hipLaunchKernelGGL((k_schnorr_fused<SF_REST, true, true>), grid, block, 0, stream, p, aux, ptab);
     } else {
         hipLaunchKernelGGL((k_schnorr_fused<SF_REST, true>), grid, block, 0, stream, p, aux, ptab);
@@ -2582,7 +2587,8 @@ hipError_t launch_merkle_fused(const AirCombineParams &p, const uint64_t *ptab, 
     }
     if (p.k0 + nk > 8) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_merkle_rounds_setup<0, 33, 5>), dim3(MR_SECTIONS), dim3(64), 0, stream, p.t_alpha, p.t_beta, ptab, d_rtab, p.k0 + nk);
-    hipLaunchKernelGGL((k_merkle_rounds<0, 4, 65, 33, 4, 5, false>), grid, dim3(FNT), 0, stream, p, ptab, (const fp *)d_rtab, round_group);
+    if (merkle_rounds_on_matrix_cores(n)) { const hipError_t e = launch_merkle_rounds_mfma(p, ptab, d_rtab, nk, round_group, 0, stream); if (e != hipSuccess) return e; }
+    else hipLaunchKernelGGL((k_merkle_rounds<0, 4, 65, 33, 4, 5, false>), grid, dim3(FNT), 0, stream, p, ptab, (const fp *)d_rtab, round_group);
     hipLaunchKernelGGL(k_merkle_fused<true>, grid, dim3(FNT), 0, stream, p, ptab);
     return hipGetLastError();
 }
@@ -2661,7 +2667,7 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
     const unsigned m = p.m ? p.m : 1;
     // one coefficient set: the matrix-core kernel (rounds_mfma.hip; same values).  CSTARK_ROUNDS_MFMA=0: the vector-ALU kernel below
     static const bool mfma_env = [] { const char *e = getenv("CSTARK_ROUNDS_MFMA"); return !e || atoi(e) != 0; }();
-    if (m == 1 && mfma_env && n % 512 == 0) return launch_rounds_mfma(p, d_even, stream);
+    if (m == 1 && mfma_env && n % 256 == 0) return launch_rounds_mfma(p, d_even, stream);
     if (m == 1) hipLaunchKernelGGL(k_rounds_split<1>, grid, block, 0, stream, p, d_even);
     else if (m == 2) hipLaunchKernelGGL(k_rounds_split<2>, grid, block, 0, stream, p, d_even);
     else if (m == 3) hipLaunchKernelGGL(k_rounds_split<3>, grid, block, 0, stream, p, d_even);

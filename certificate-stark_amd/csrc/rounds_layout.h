@@ -41,6 +41,17 @@ __host__ __device__ constexpr int mf_tile_window(int t) { return t < 2 ? 0 : t <
 __host__ __device__ constexpr int mf_tile_fs(int w, int local) { return (w == 1 || w == 2) ? local >> 1 : w == 3 ? local : 0; }
 __host__ __device__ constexpr int mf_tile_pair(int w, int local) { return (w == 1 || w == 2) ? local & 1 : w == 0 ? local : 0; }
 
+// MerkleAir's / SchnorrAir's folded round gadgets (k_merkle_rounds_setup, constraints.hip), rtab in u64 words; sections = (window,
+// {alpha, beta}): A[8][8 cosets][8] | limbs of U[8][14] | limbs of INV_MDS[196] | G[8][14] | compact tables of k_merkle_rounds_mfma
+constexpr int MR_SECTIONS = 8, MR_A = 0, MR_UL = MR_SECTIONS * 64, MR_ML = MR_UL + MR_SECTIONS * 14 * 2, MR_G = MR_ML + 196 * 2;
+constexpr int MRF_INV_D = MR_G + MR_SECTIONS * 14;          // [7][2][2][8]
+constexpr int MRF_SEC_D = MRF_INV_D + MF_TILES_INV * 32;   // [4 windows][2][2][16]
+constexpr int MRF_K = MRF_SEC_D + 4 * 64;                  // [14 + 8][4]
+constexpr int MR_SIZE = MRF_K + (14 + 8) * 4;
+static_assert(MR_SIZE <= MERKLE_RTAB_WORDS, "MerkleAir rounds table");
+
+hipError_t launch_merkle_rounds_mfma(const AirCombineParams &p, const uint64_t *ptab, uint64_t *d_rtab, unsigned nk, unsigned round_group, int which,
+                                     hipStream_t stream); // rounds_mfma.hip; after k_merkle_rounds_setup
 hipError_t launch_rounds_mfma(const CeParams &p, uint64_t *d_even, hipStream_t stream); // rounds_mfma.hip; after launch_rounds_setup
 
 } // namespace cs

@@ -63,50 +63,76 @@ __device__ __forceinline__ u128 acc0_offset() { // sum_d ACC0 2^(8d): what the a
     return off;
 }
 
-// Compact tables of one proof from what k_rounds_setup left in rtab (RT_G: the sections' coefficient vectors; RT_UL: limbs of their
-// MDS-folded forms).  grid = 7 inverse tiles + 13 section tiles, 64 threads.
-__global__ void k_rounds_mfma_tables(fp *__restrict__ rtab) {
-    const int t = threadIdx.x;
-    if (blockIdx.x < MF_TILES_INV) { // inverse matrix, tile T: entries [g][h][m], m < 8
-        const int T = blockIdx.x;
-        if (t < 32) {
-            const int g = t >> 4, h = (t >> 3) & 1, m = t & 7, i = 2 * T + g, j = 4 * (m >> 1) + 2 * h + (m & 1);
-            rtab[MF_INV_D + (T * 4 + g * 2 + h) * 8 + m] = j < 14 ? digit_word((int64_t)c_inv_mds[i * 14 + j]) : 0;
-        } else if (t < 34) { // row constant of output i: X0 sum_j M_ij - offset (mod 2^128), the sum itself is below 14 p^2
-            const int i = 2 * T + (t - 32);
-            u128 k = 0;
-            for (int j = 0; j < 14; j++) k += (u128)c_inv_mds[i * 14 + j] * X0;
-            k -= acc0_offset();
-            for (int q = 0; q < 4; q++) rtab[MF_K + 4 * i + q] = (uint32_t)(k >> (32 * q));
-        }
-        return;
+// inverse matrix, tile T: compact entries d_out[g][h][m] (m < 8) and the row constants k_out[2 T + g][4]; threads t < 34
+__device__ inline void build_inverse_tile(int T, int t, uint64_t *d_out, uint64_t *k_out) {
+    if (t < 32) {
+        const int g = t >> 4, h = (t >> 3) & 1, m = t & 7, i = 2 * T + g, j = 4 * (m >> 1) + 2 * h + (m & 1);
+        d_out[(g * 2 + h) * 8 + m] = j < 14 ? digit_word((int64_t)c_inv_mds[i * 14 + j]) : 0;
+    } else if (t < 34) { // row constant of output i: X0 sum_j M_ij - offset (mod 2^128), the sum itself is below 14 p^2
+        const int i = 2 * T + (t - 32);
+        u128 k = 0;
+        for (int j = 0; j < 14; j++) k += (u128)c_inv_mds[i * 14 + j] * X0;
+        k -= acc0_offset();
+        for (int q = 0; q < 4; q++) k_out[4 * (t - 32) + q] = (uint32_t)(k >> (32 * q));
     }
-    const int tile = blockIdx.x - MF_TILES_INV, w = mf_tile_window(tile), local = tile - mf_tile_base(w);
-    const int fs = mf_tile_fs(w, local), u = mf_tile_pair(w, local);
-    __shared__ fp csum[2][32];
+}
+// one section tile: outputs g = 0, 1 are the sections with coefficient vectors gam[g][14] and MDS-folded limbs ul[g] (4 dwords per
+// entry, k_rounds_setup); compact entries d_out[g][h][m] (m < 16) and row constants k_out[g][4].  64 threads, all of them call.
+__device__ inline void build_section_tile(const fp *gam0, const fp *gam1, const uint32_t *ul0, const uint32_t *ul1, int t, uint64_t *d_out,
+                                          uint64_t *k_out, fp (*csum)[32]) {
     if (t < 56) { // [g][h][m], m < 14
-        const int g = t / 28, h = (t / 14) & 1, m = t % 14, sec = (w * 2 + fs) * 4 + 2 * u + g;
+        const int g = t / 28, h = (t / 14) & 1, m = t % 14;
         fp c;
-        if (m < 7) c = rtab[RT_G + sec * 14 + 2 * m + h];
+        if (m < 7) c = (g ? gam1 : gam0)[2 * m + h];
         else {
-            const uint32_t *l = (const uint32_t *)(rtab + RT_UL) + (sec * 14 + 2 * (m - 7) + h) * 4;
+            const uint32_t *l = (g ? ul1 : ul0) + (2 * (m - 7) + h) * 4;
             c = fp_neg((fp)l[0] | ((fp)l[1] << 21) | ((fp)l[2] << 42));
         }
-        rtab[MF_SEC_D + (tile * 4 + g * 2 + h) * 16 + m] = digit_word(c > HALF_P ? (int64_t)(c - FP_P) : (int64_t)c);
+        d_out[(g * 2 + h) * 16 + m] = digit_word(c > HALF_P ? (int64_t)(c - FP_P) : (int64_t)c);
         csum[g][h * 14 + m] = c;
-    } else if (t < 64) { // m = 14, 15 of every (g, h): padding of the last k-step's rows
+    } else { // m = 14, 15 of every (g, h): padding of the last k-step's rows
         const int q = t - 56;
-        rtab[MF_SEC_D + (tile * 4 + (q >> 1)) * 16 + 14 + (q & 1)] = 0;
+        d_out[(q >> 1) * 16 + 14 + (q & 1)] = 0;
     }
     __syncthreads();
     if (t < 2) { // row constant: (X0 + (p-1)/2) sum(c) mod p  -  offset  +  2p 2^64
-        fp s = 0;
-        for (int e = 0; e < 28; e++) s = fp_add(s, csum[t][e]);
-        const fp kc = fp_mul(fp_mul(X0 + HALF_P, s), FP_R2); // the plain product of the two integers mod p
+        fp sum = 0;
+        for (int e = 0; e < 28; e++) sum = fp_add(sum, csum[t][e]);
+        const fp kc = fp_mul(fp_mul(X0 + HALF_P, sum), FP_R2); // the plain product of the two integers mod p
         u128 k = (u128)kc + ((u128)(2 * FP_P) << 64);
         k -= acc0_offset();
-        for (int q = 0; q < 4; q++) rtab[MF_K + 4 * (14 + 2 * tile + t) + q] = (uint32_t)(k >> (32 * q));
+        for (int q = 0; q < 4; q++) k_out[4 * t + q] = (uint32_t)(k >> (32 * q));
     }
+}
+
+// Compact tables of one TransactionAir proof from what k_rounds_setup left in rtab (RT_G: the sections' coefficient vectors; RT_UL:
+// limbs of their MDS-folded forms).  grid = 7 inverse tiles + 13 section tiles, 64 threads.
+__global__ void k_rounds_mfma_tables(fp *__restrict__ rtab) {
+    const int t = threadIdx.x;
+    if (blockIdx.x < MF_TILES_INV) {
+        build_inverse_tile(blockIdx.x, t, rtab + MF_INV_D + blockIdx.x * 32, rtab + MF_K + 8 * blockIdx.x);
+        return;
+    }
+    const int tile = blockIdx.x - MF_TILES_INV, w = mf_tile_window(tile), local = tile - mf_tile_base(w);
+    const int sec = (w * 2 + mf_tile_fs(w, local)) * 4 + 2 * mf_tile_pair(w, local);
+    __shared__ fp csum[2][32];
+    const uint32_t *ul = (const uint32_t *)(rtab + RT_UL);
+    build_section_tile(rtab + RT_G + sec * 14, rtab + RT_G + (sec + 1) * 14, ul + sec * 56, ul + (sec + 1) * 56, t, rtab + MF_SEC_D + tile * 64,
+                       rtab + MF_K + 4 * (14 + 2 * tile), csum);
+}
+// The same for the folded round gadgets of MerkleAir / SchnorrAir's message hash (k_merkle_rounds_setup's rtab, MR_* of
+// rounds_layout.h): one section tile per window (outputs: alpha, beta).  grid = 7 + nwin, 64 threads.
+__global__ void k_merkle_rounds_mfma_tables(fp *__restrict__ rtab) {
+    const int t = threadIdx.x;
+    if (blockIdx.x < MF_TILES_INV) {
+        build_inverse_tile(blockIdx.x, t, rtab + MRF_INV_D + blockIdx.x * 32, rtab + MRF_K + 8 * blockIdx.x);
+        return;
+    }
+    const int w = blockIdx.x - MF_TILES_INV;
+    __shared__ fp csum[2][32];
+    const uint32_t *ul = (const uint32_t *)(rtab + MR_UL);
+    build_section_tile(rtab + MR_G + (2 * w) * 14, rtab + MR_G + (2 * w + 1) * 14, ul + (2 * w) * 56, ul + (2 * w + 1) * 56, t, rtab + MRF_SEC_D + w * 64,
+                       rtab + MRF_K + 4 * (14 + 2 * w), csum);
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -183,16 +209,148 @@ __device__ __forceinline__ fp cube_l(fp x) {
     return fp_reduce_once(fp_mul_lazy(fp_mul_lazy(x, x), x));
 }
 
+#ifndef RM_DBUF
+#define RM_DBUF 16 // vector instructions per MFMA of the next tile in the inverse half (0: one tile at a time); measured 12: 1.91, 16: 1.745, 20: 1.78, 0: 1.82 ms
+#endif
+#ifndef RM_RESIDENT_
+#define RM_RESIDENT_ 4096
+#endif
+constexpr unsigned RM_RESIDENT = RM_RESIDENT_; // workgroups of a launch: each takes every gridDim.x-th block of RM_NT rows of its coset (four blocks at 2^20 rows: 1.83 ms; one: 1.86; all resident at once, 32 blocks each: 1.92)
+
+// what a lane is in the tiles: column n = lane & 31 of the points' operand (points n and n + 32 of the wave), half h = lane >> 5 of a
+// k-step; as a table row r = lane & 31: output g = (r >> 2) & 1, byte diagonal d = (r & 3) + 4 (r >> 3)
+struct Role {
+    int lane, nn, h, ag;
+    uint32_t sel_lo, sel_hi; // v_perm_b32 selectors: byte b of the fragment word = digit d - b of the entry (0x0c: constant zero)
+};
+__device__ __forceinline__ void frag_selectors(int d, uint32_t &lo, uint32_t &hi) {
+    lo = hi = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int a0 = d - b, a1 = d - 4 - b;
+        lo |= (uint32_t)((a0 >= 0 && a0 <= 7 && d < 15) ? a0 : 0x0c) << (8 * b);
+        hi |= (uint32_t)((a1 >= 0 && a1 <= 7 && d < 15) ? a1 : 0x0c) << (8 * b);
+    }
+}
+__device__ __forceinline__ Role make_role(int lane) {
+    Role r;
+    r.lane = lane; r.nn = lane & 31; r.h = lane >> 5; r.ag = (r.nn >> 2) & 1;
+    frag_selectors((r.nn & 3) + 4 * (r.nn >> 3), r.sel_lo, r.sel_hi);
+    return r;
+}
+// the inverse matrix's fragments, expanded once per workgroup: fragment (T, s) of lane l from the entries [T][g][h][2 s], [2 s + 1]
+__device__ __forceinline__ void expand_inverse_table(v4i *inv_lds, const uint64_t *inv_d, int tid, int nthreads) {
+    for (unsigned e = tid; e < MF_TILES_INV * MF_KS_INV * 64; e += nthreads) {
+        const unsigned l = e & 63, ts = e >> 6, r = l & 31, hh = l >> 5, g = (r >> 2) & 1;
+        uint32_t slo, shi;
+        frag_selectors((int)((r & 3) + 4 * (r >> 3)), slo, shi);
+        const uint64_t *dw = inv_d + ((ts >> 2) * 4 + g * 2 + hh) * 8 + 2 * (ts & 3);
+        inv_lds[e] = expand_frag(dw[0], dw[1], slo, shi);
+    }
+}
+// One window, everything that reads the image: the operands of the sections' product for both points of the lane -- half h of the 28
+// values (cube(INV_MDS (next - ark2))_i, i = 2 m + h, then cube(cur_j), j = 2 t + h), centred and byte-offset, two per k-step.
+// imgA = the wave's image + n; ark2 = this row's 14 constants; k_lds = the row constants (four words each) of the inverse matrix.
+__device__ __forceinline__ void window_operands(const fp *imgA, const fp *ark2, const v4i *inv_lds, const uint64_t *k_lds, const Role &ro,
+                                                const Shifts &sh, v4i (&cA)[MF_KS_SEC], v4i (&cB)[MF_KS_SEC]) {
+    const int h = ro.h, lane = ro.lane;
+    // operands of the inverse matrix: (next - ark2) of columns 4 s + 2 h, + 1 (k-step 3 of half 1 is padding: its table bytes are 0)
+    v4i bA[MF_KS_INV], bB[MF_KS_INV];
+#pragma unroll
+    for (int s = 0; s < MF_KS_INV; s++) {
+        const int jb = (s == 3 && h) ? 12 : 4 * s + 2 * h;
+        const fp k0 = ark2[jb], k1 = ark2[jb + 1];
+        bA[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 1], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 1], k1) ^ X0);
+        bB[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 33], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 33], k1) ^ X0);
+    }
+    uint64_t heldA = 0, heldB = 0;
+#if RM_DBUF > 0
+    // tile T + 1 on the matrix pipe while the vector ALU recombines and cubes tile T: a wave issues in order, so the eight
+    // MFMAs are spread through the vector work (one per RM_DBUF vector instructions), not put in front of it
+    v16i acc[2][2];
+    auto inv_tile = [&](int T, v16i &a0, v16i &a1) {
+        a0 = acc_start(); a1 = acc_start();
+#pragma unroll
+        for (int s = 0; s < MF_KS_INV; s++) {
+            const v4i a = inv_lds[(T * MF_KS_INV + s) * 64 + lane];
+            a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bA[s], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bB[s], a1, 0, 0, 0);
+        }
+    };
+    inv_tile(0, acc[0][0], acc[0][1]);
+#pragma unroll
+    for (int T = 0; T < MF_TILES_INV; T++) {
+        if (T + 1 < MF_TILES_INV) inv_tile(T + 1, acc[(T + 1) & 1][0], acc[(T + 1) & 1][1]);
+        const uint64_t *kp = k_lds + 4 * (2 * T + h);
+        const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
+        const uint64_t xa = (cube_l(recombine_mad(acc[T & 1][0], kw, sh)) - HALF_P) ^ X0;
+        const uint64_t xb = (cube_l(recombine_mad(acc[T & 1][1], kw, sh)) - HALF_P) ^ X0;
+        if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
+        else { heldA = xa; heldB = xb; }
+        if (T + 1 < MF_TILES_INV) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, RM_DBUF, 0); // VALU
+            }
+        }
+    }
+#else
+#pragma unroll
+    for (int T = 0; T < MF_TILES_INV; T++) {
+        v16i a0 = acc_start(), a1 = acc_start();
+#pragma unroll
+        for (int s = 0; s < MF_KS_INV; s++) {
+            const v4i a = inv_lds[(T * MF_KS_INV + s) * 64 + lane];
+            a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bA[s], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bB[s], a1, 0, 0, 0);
+        }
+        const uint64_t *kp = k_lds + 4 * (2 * T + h);
+        const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
+        const uint64_t xa = (cube_l(recombine_mad(a0, kw, sh)) - HALF_P) ^ X0;
+        const uint64_t xb = (cube_l(recombine_mad(a1, kw, sh)) - HALF_P) ^ X0;
+        if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
+        else { heldA = xa; heldB = xb; }
+    }
+#endif
+    // forward half: cube(cur_j), j = 2 t + h
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const uint64_t xa = (cube_l(imgA[(2 * t + h) * RW_ROWS]) - HALF_P) ^ X0;
+        const uint64_t xb = (cube_l(imgA[(2 * t + h) * RW_ROWS + 32]) - HALF_P) ^ X0;
+        if (t & 1) { heldA = xa; heldB = xb; }
+        else { cA[3 + (t >> 1)] = pack2(heldA, xa); cB[3 + (t >> 1)] = pack2(heldB, xb); }
+    }
+}
+// one section tile against the window's operands: ra / rb = the value of this lane's section (output g = h of the tile) at the
+// lane's two points: gamma . cube(INV_MDS (next - ark2)) - U . cube(cur).  tile_d = the tile's compact entries [g][h][16], kp = the
+// four words of the lane's row constant
+__device__ __forceinline__ void section_tile(const uint64_t *tile_d, const uint64_t *kp, const Role &ro, const Shifts &sh, const v4i (&cA)[MF_KS_SEC],
+                                             const v4i (&cB)[MF_KS_SEC], fp &ra, fp &rb) {
+    v16i a0 = acc_start(), a1 = acc_start();
+    const uint64_t *dw = tile_d + (ro.ag * 2 + ro.h) * 16;
+#pragma unroll
+    for (int s = 0; s < MF_KS_SEC; s++) {
+        const v4i a = expand_frag(dw[2 * s], dw[2 * s + 1], ro.sel_lo, ro.sel_hi);
+        a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cA[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cB[s], a1, 0, 0, 0);
+    }
+    const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
+    ra = recombine_mad(a0, kw, sh);
+    rb = recombine_mad(a1, kw, sh);
+}
+// value of the other lane half (lane ^ 32)
+__device__ __forceinline__ fp other_half(fp v) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, 32), hi = __shfl_xor((uint32_t)(v >> 32), 32);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 constexpr size_t RM_LDS_INV = (size_t)MF_TILES_INV * MF_KS_INV * 64 * 16;                 // expanded inverse table
 constexpr size_t RM_LDS_IMG = (size_t)(RM_NT / 64) * RW_IMG * 8;
 constexpr size_t RM_LDS_SEC = (size_t)MF_TILES_SEC * 4 * 16 * 8;                          // compact section tables
 constexpr size_t RM_LDS_K = (size_t)(14 + 2 * MF_TILES_SEC) * 32;
 constexpr size_t RM_LDS_ARK = 8 * 14 * 8, RM_LDS_ATAB = (size_t)RT_SECTIONS * 8 * 8;
 constexpr size_t RM_LDS = RM_LDS_INV + RM_LDS_IMG + RM_LDS_SEC + RM_LDS_K + RM_LDS_ARK + RM_LDS_ATAB;
-#ifndef RM_RESIDENT_
-#define RM_RESIDENT_ (1u << 30)
-#endif
-constexpr unsigned RM_RESIDENT = RM_RESIDENT_; // workgroups that are resident at once (two per CU: LDS and registers): the grid
 
 // out = [4 polynomials][4 even cosets][n] as k_rounds_split<1> writes them.  grid = (workgroups per coset, even cosets of the
 // window): a workgroup expands its tables once and then takes every gridDim.x-th block of RM_NT rows of its coset.
@@ -207,28 +365,11 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
 
     const size_t n = (size_t)1 << p.log_n;
     const unsigned kk = 2 * blockIdx.y, kc = (p.k0 >> 1) + blockIdx.y, ka = 2 * kc; // (k_rounds_split)
-    const int tid = threadIdx.x, lane = tid & 63, nn = lane & 31, h = lane >> 5;
-    // tile row of this lane as an A operand: r = lane & 31 -> output g = (r >> 2) & 1, byte diagonal d = (r & 3) + 4 (r >> 3)
-    const int ag = (nn >> 2) & 1, ad = (nn & 3) + 4 * (nn >> 3);
-    uint32_t sel_lo = 0, sel_hi = 0; // byte b of the fragment word = digit ad - b of the entry (0x0c: constant zero)
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const int a0 = ad - b, a1 = ad - 4 - b;
-        sel_lo |= (uint32_t)((a0 >= 0 && a0 <= 7 && ad < 15) ? a0 : 0x0c) << (8 * b);
-        sel_hi |= (uint32_t)((a1 >= 0 && a1 <= 7 && ad < 15) ? a1 : 0x0c) << (8 * b);
-    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const Role ro = make_role(lane);
+    const int nn = ro.nn, h = ro.h;
     const fp *rt = p.rtab;
-    for (unsigned e = tid; e < MF_TILES_INV * MF_KS_INV * 64; e += RM_NT) { // fragment (T, s) of lane l: entries [T][g][h][2s], [2s + 1]
-        const unsigned l = e & 63, ts = e >> 6, r = l & 31, hh = l >> 5, g = (r >> 2) & 1, d = (r & 3) + 4 * (r >> 3);
-        uint32_t slo = 0, shi = 0;
-        for (int b = 0; b < 4; b++) {
-            const int a0 = (int)d - b, a1 = (int)d - 4 - b;
-            slo |= (uint32_t)((a0 >= 0 && a0 <= 7 && d < 15) ? a0 : 0x0c) << (8 * b);
-            shi |= (uint32_t)((a1 >= 0 && a1 <= 7 && d < 15) ? a1 : 0x0c) << (8 * b);
-        }
-        const fp *dw = rt + MF_INV_D + ((ts >> 2) * 4 + g * 2 + hh) * 8 + 2 * (ts & 3);
-        inv_lds[e] = expand_frag(dw[0], dw[1], slo, shi);
-    }
+    expand_inverse_table(inv_lds, rt + MF_INV_D, tid, RM_NT);
     for (unsigned e = tid; e < RM_LDS_SEC / 8; e += RM_NT) secd_lds[e] = rt[MF_SEC_D + e];
     for (unsigned e = tid; e < RM_LDS_K / 8; e += RM_NT) k_lds[e] = rt[MF_K + e];
     if (tid < 8 * 14) { // the round constants' extension has period 8 in the row index: the same 8 x 14 values for every block of rows
@@ -270,42 +411,8 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
         for (int wdx = 0; wdx < 5; wdx++) {
             const RoundWindow w = c_windows[wdx];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // operands of the inverse matrix: (next - ark2) of columns 4 s + 2 h, + 1 (k-step 3 of half 1 is padding: its table bytes are 0)
-            v4i bA[MF_KS_INV], bB[MF_KS_INV];
-#pragma unroll
-            for (int s = 0; s < MF_KS_INV; s++) {
-                const int jb = (s == 3 && h) ? 12 : 4 * s + 2 * h;
-                const fp k0 = ark2[jb], k1 = ark2[jb + 1];
-                bA[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 1], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 1], k1) ^ X0);
-                bB[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 33], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 33], k1) ^ X0);
-            }
-            // cube(INV_MDS d)_i, i = 2 T + h, of both points; operands of the sections' product as they come
             v4i cA[MF_KS_SEC], cB[MF_KS_SEC];
-            uint64_t heldA = 0, heldB = 0;
-#pragma unroll
-            for (int T = 0; T < MF_TILES_INV; T++) {
-                v16i a0 = acc_start(), a1 = acc_start();
-#pragma unroll
-                for (int s = 0; s < MF_KS_INV; s++) {
-                    const v4i a = inv_lds[(T * MF_KS_INV + s) * 64 + lane];
-                    a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bA[s], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bB[s], a1, 0, 0, 0);
-                }
-                const uint64_t *kp = k_lds + 4 * (2 * T + h);
-                const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
-                const uint64_t xa = (cube_l(recombine_mad(a0, kw, sh)) - HALF_P) ^ X0;
-                const uint64_t xb = (cube_l(recombine_mad(a1, kw, sh)) - HALF_P) ^ X0;
-                if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
-                else { heldA = xa; heldB = xb; }
-            }
-            // forward half: cube(cur_j), j = 2 t + h
-#pragma unroll
-            for (int t = 0; t < 7; t++) {
-                const uint64_t xa = (cube_l(imgA[(2 * t + h) * RW_ROWS]) - HALF_P) ^ X0;
-                const uint64_t xb = (cube_l(imgA[(2 * t + h) * RW_ROWS + 32]) - HALF_P) ^ X0;
-                if (t & 1) { heldA = xa; heldB = xb; }
-                else { cA[3 + (t >> 1)] = pack2(heldA, xa); cB[3 + (t >> 1)] = pack2(heldB, xb); }
-            }
+            window_operands(imgA, ark2, inv_lds, k_lds, ro, sh, cA, cB);
             // the image is free again: the next window (of this block, or the first one of the workgroup's next block) arrives behind
             // the sections' product
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -316,23 +423,15 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
 #pragma unroll 1
             for (int tile = t0; tile < t1; tile++) {
                 const int local = tile - t0, fs = mf_tile_fs(wdx, local), u = mf_tile_pair(wdx, local);
-                v16i a0 = acc_start(), a1 = acc_start();
-                const uint64_t *dw = secd_lds + (tile * 4 + ag * 2 + h) * 16;
-#pragma unroll
-                for (int s = 0; s < MF_KS_SEC; s++) {
-                    const v4i a = expand_frag(dw[2 * s], dw[2 * s + 1], sel_lo, sel_hi);
-                    a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cA[s], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cB[s], a1, 0, 0, 0);
-                }
-                const uint64_t *kp = k_lds + 4 * (14 + 2 * tile + h);
-                const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
+                fp ra, rb;
+                section_tile(secd_lds + tile * 64, k_lds + 4 * (14 + 2 * tile + h), ro, sh, cA, cB, ra, rb);
                 const int sec = (wdx * 2 + fs) * 4 + 2 * u + h; // this lane's section: slot 2 u + h
                 const fp at = atab_lds[sec * 8 + jrp];
                 const int fl = fs ? w.flag_b : w.flag_a;
                 const fp fa = fl == 0 ? flA[0] : fl == 1 ? flA[1] : fl == 2 ? flA[2] : fp_add(flA[0], flA[1]);
                 const fp fb = fl == 0 ? flB[0] : fl == 1 ? flB[1] : fl == 2 ? flB[2] : fp_add(flB[0], flB[1]);
-                const fp va = fp_mul(fa, fp_sub(recombine_mad(a0, kw, sh), at));
-                const fp vb = fp_mul(fb, fp_sub(recombine_mad(a1, kw, sh), at));
+                const fp va = fp_mul(fa, fp_sub(ra, at));
+                const fp vb = fp_mul(fb, fp_sub(rb, at));
                 if (u) { xA[1] = fp_add(xA[1], va); xB[1] = fp_add(xB[1], vb); }
                 else { xA[0] = fp_add(xA[0], va); xB[0] = fp_add(xB[0], vb); }
             }
@@ -352,11 +451,91 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
         const fp totB[4] = {h ? 0 : b012, h ? fp_add(sB[0], b34) : 0, h ? sB[1] : sB[3], h ? sB[2] : sB[4]};
         const size_t j = jw + lane;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const fp mine = h ? totB[q] : totA[q], give = h ? totA[q] : totB[q]; // what the other half needs from this lane
-            const uint32_t lo = __shfl_xor((uint32_t)give, 32), hi = __shfl_xor((uint32_t)(give >> 32), 32);
-            out[((size_t)q * 4 + kc) * n + j] = fp_add(mine, ((uint64_t)hi << 32) | lo); // table 3: group 2 (k_rounds_split)
+        for (int q = 0; q < 4; q++) { // this lane's own point: its part + what the other half holds of it
+            const fp mine = h ? totB[q] : totA[q], give = h ? totA[q] : totB[q];
+            out[((size_t)q * 4 + kc) * n + j] = fp_add(mine, other_half(give)); // table 3: group 2 (k_rounds_split)
         }
+    }
+}
+
+// MerkleAir's four round gadgets / the one of SchnorrAir's message hash (k_merkle_rounds of constraints.hip, same template arguments
+// and the same values): per window ONE section tile -- output 0 = the alpha section, output 1 = the beta section (the round slots
+// share one declared degree) -- so half 0 of a wave sums alpha terms and half 1 beta terms; flag (alpha sum + x^adj beta sum) at the end.
+constexpr size_t MRM_LDS_SEC = 4 * 64 * 8, MRM_LDS_K = (14 + 8) * 32, MRM_LDS_ATAB = MR_SECTIONS * 8 * 8;
+constexpr size_t MRM_LDS = RM_LDS_INV + RM_LDS_IMG + MRM_LDS_SEC + MRM_LDS_K + RM_LDS_ARK + MRM_LDS_ATAB;
+struct MerkleRoundsParams { // what the kernel reads of AirCombineParams (the whole block costs registers): x^adj = xshift[k] w^(j xadj)
+    const fp *lde, *w;
+    fp *out;
+    fp xshift[8];
+    uint64_t xadj;
+    uint32_t log_n, k0, stride;
+};
+template <int W0, int NWIN, int WIDTH, int PCOLS, int FLAGCOL, int ARKCOL, bool ADD>
+__global__ __launch_bounds__(RM_NT, RM_WAVES) void k_merkle_rounds_mfma(MerkleRoundsParams p, const fp *__restrict__ ptab, const fp *__restrict__ rtab) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    v4i *inv_lds = (v4i *)lds;
+    fp *img_all = (fp *)(lds + RM_LDS_INV);
+    uint64_t *secd_lds = (uint64_t *)(lds + RM_LDS_INV + RM_LDS_IMG);
+    uint64_t *k_lds = secd_lds + MRM_LDS_SEC / 8;
+    fp *ark2_lds = k_lds + MRM_LDS_K / 8;
+    fp *atab_lds = ark2_lds + RM_LDS_ARK / 8;
+
+    const size_t n = (size_t)1 << p.log_n;
+    const unsigned kk = blockIdx.y, k = p.k0 + kk;
+    if (k % p.stride) return; // uniform over the workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const Role ro = make_role(lane);
+    const int nn = ro.nn, h = ro.h;
+    expand_inverse_table(inv_lds, rtab + MRF_INV_D, tid, RM_NT);
+    for (unsigned e = tid; e < NWIN * 64; e += RM_NT) secd_lds[e] = rtab[MRF_SEC_D + e];
+    for (unsigned e = tid; e < (14 + 2 * NWIN) * 4; e += RM_NT) k_lds[e] = rtab[MRF_K + e];
+    if (tid < 8 * 14) {
+        const unsigned r = tid / 14, c = tid % 14;
+        ark2_lds[tid] = ptab[((size_t)k * PCOLS + ARKCOL + 14 + c) * 512 + r];
+    }
+    if (tid < MR_SECTIONS * 8) atab_lds[tid] = rtab[MR_A + (tid >> 3) * 64 + k * 8 + (tid & 7)];
+    __syncthreads();
+
+    fp *img = img_all + (size_t)(tid >> 6) * RW_IMG;
+    const fp *imgA = img + nn;
+    const unsigned jrp = (unsigned)(nn & 7);
+    const fp *ark2 = ark2_lds + jrp * 14;
+    const fp *colbase = p.lde + (size_t)kk * WIDTH * n;
+    const Shifts sh{opaque_const<1>(), opaque_const<1u << 8>(), opaque_const<1u << 16>(), opaque_const<1u << 24>()};
+    const size_t nblk = n / RM_NT;
+    size_t blk = blockIdx.x;
+    auto rows_of = [&](size_t b) {
+        const size_t jw = b * (size_t)RM_NT + (size_t)(tid >> 6) * 64;
+        return colbase + jw + 2 * lane - ((lane == 32 && jw + 64 == n) ? n : 0);
+    };
+    const fp *rows = rows_of(blk);
+    if (blk < nblk) fetch_window(rows, n, c_windows[W0].reg, lane, img);
+#pragma unroll 1
+    for (; blk < nblk; blk += gridDim.x) {
+        const size_t j = blk * (size_t)RM_NT + (size_t)(tid >> 6) * 64 + lane; // this lane's own point
+        fp tA = 0, tB = 0; // half 0: alpha sums of points n, n + 32; half 1: beta sums
+#pragma unroll 1
+        for (int wdx = 0; wdx < NWIN; wdx++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            v4i cA[MF_KS_SEC], cB[MF_KS_SEC];
+            window_operands(imgA, ark2, inv_lds, k_lds, ro, sh, cA, cB);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (wdx + 1 < NWIN) fetch_window(rows, n, c_windows[W0 + wdx + 1].reg, lane, img);
+            else if (blk + gridDim.x < nblk) { rows = rows_of(blk + gridDim.x); fetch_window(rows, n, c_windows[W0].reg, lane, img); }
+            __builtin_amdgcn_sched_barrier(0); // the section's product after the window's operands, not scheduled into them (16 spills)
+            fp ra, rb;
+            section_tile(secd_lds + wdx * 64, k_lds + 4 * (14 + 2 * wdx + h), ro, sh, cA, cB, ra, rb);
+            const fp at = atab_lds[(2 * wdx + h) * 8 + jrp];
+            tA = fp_add(tA, fp_sub(ra, at));
+            tB = fp_add(tB, fp_sub(rb, at));
+        }
+        const fp got = other_half(h ? tA : tB); // half 0 hands the alpha sum of point n + 32 over, half 1 the beta sum of point n
+        const fp ta = h ? got : tA, tb = h ? tB : got;
+        const fp flag = ptab[((size_t)k * PCOLS + FLAGCOL) * 512 + (j & 511)];
+        const fp xp = fp_mul(p.xshift[k], p.w[(j * p.xadj) & (n - 1)]);
+        const fp v = fp_mul(flag, fp_add(ta, fp_mul(xp, tb)));
+        fp *o = p.out + (size_t)kk * n + j;
+        *o = ADD ? fp_add(*o, v) : v;
     }
 }
 
@@ -370,6 +549,32 @@ hipError_t launch_rounds_mfma(const CeParams &p, uint64_t *d_even, hipStream_t s
     hipLaunchKernelGGL(k_rounds_mfma_tables, dim3(MF_TILES_INV + MF_TILES_SEC), dim3(64), 0, stream, p.rtab);
     const unsigned ny = p.nkc ? p.nkc : 4, nblk = (unsigned)(n / RM_NT), gx = RM_RESIDENT / ny < nblk ? RM_RESIDENT / ny : nblk;
     hipLaunchKernelGGL(k_rounds_mfma, dim3(gx, ny), dim3(RM_NT), RM_LDS, stream, p, d_even);
+    return hipGetLastError();
+}
+
+// constraints.hip: after k_merkle_rounds_setup (same stream); which = 0: MerkleAir's four windows (written), 1: SchnorrAir's message hash (added)
+hipError_t launch_merkle_rounds_mfma(const AirCombineParams &p, const uint64_t *ptab, uint64_t *d_rtab, unsigned nk, unsigned round_group, int which,
+                                     hipStream_t stream) {
+    const size_t n = (size_t)1 << p.log_n;
+    if (n % RM_NT) return hipErrorInvalidValue;
+    const unsigned nblk = (unsigned)(n / RM_NT), gx = RM_RESIDENT / nk ? (RM_RESIDENT / nk < nblk ? RM_RESIDENT / nk : nblk) : 1;
+    if (round_group >= AIR_MAX_GROUPS) return hipErrorInvalidValue;
+    MerkleRoundsParams q;
+    q.lde = p.lde; q.w = p.w; q.out = p.out; q.xadj = p.tgrp_adj[round_group]; q.log_n = p.log_n; q.k0 = p.k0; q.stride = p.stride;
+    for (int k = 0; k < 8; k++) q.xshift[k] = p.tgrp_shift[k][round_group];
+    if (which == 0) {
+        auto kern = k_merkle_rounds_mfma<0, 4, 65, 33, 4, 5, false>;
+        static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MRM_LDS);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(k_merkle_rounds_mfma_tables, dim3(MF_TILES_INV + 4), dim3(64), 0, stream, d_rtab);
+        hipLaunchKernelGGL(kern, dim3(gx, nk), dim3(RM_NT), MRM_LDS, stream, q, ptab, (const fp *)d_rtab);
+    } else {
+        auto kern = k_merkle_rounds_mfma<4, 1, 56, 36, 7, 8, true>;
+        static const hipError_t attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MRM_LDS);
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(k_merkle_rounds_mfma_tables, dim3(MF_TILES_INV + 1), dim3(64), 0, stream, d_rtab);
+        hipLaunchKernelGGL(kern, dim3(gx, nk), dim3(RM_NT), MRM_LDS, stream, q, ptab, (const fp *)d_rtab);
+    }
     return hipGetLastError();
 }
 
