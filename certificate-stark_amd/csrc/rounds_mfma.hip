@@ -201,14 +201,6 @@ __device__ __forceinline__ fp recombine_mad(const v16i &acc, const uint64_t (&k)
     acc_fold(a);
     return acc_reduce(a);
 }
-// x^3 with the square left unreduced: it is the FIRST factor of the second product, which takes values below 2p (fp.cuh)
-__device__ __forceinline__ fp cube_l(fp x) {
-#ifdef RM_PLAIN_CUBE
-    return fp_cube(x);
-#endif
-    return fp_reduce_once(fp_mul_lazy(fp_mul_lazy(x, x), x));
-}
-
 #ifndef RM_DBUF
 #define RM_DBUF 16 // vector instructions per MFMA of the next tile in the inverse half (0: one tile at a time); measured 12: 1.91, 16: 1.745, 20: 1.78, 0: 1.82 ms
 #endif
@@ -283,8 +275,8 @@ __device__ __forceinline__ void window_operands(const fp *imgA, const fp *ark2, 
         if (T + 1 < MF_TILES_INV) inv_tile(T + 1, acc[(T + 1) & 1][0], acc[(T + 1) & 1][1]);
         const uint64_t *kp = k_lds + 4 * (2 * T + h);
         const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
-        const uint64_t xa = (cube_l(recombine_mad(acc[T & 1][0], kw, sh)) - HALF_P) ^ X0;
-        const uint64_t xb = (cube_l(recombine_mad(acc[T & 1][1], kw, sh)) - HALF_P) ^ X0;
+        const uint64_t xa = (fp_cube(recombine_mad(acc[T & 1][0], kw, sh)) - HALF_P) ^ X0;
+        const uint64_t xb = (fp_cube(recombine_mad(acc[T & 1][1], kw, sh)) - HALF_P) ^ X0;
         if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
         else { heldA = xa; heldB = xb; }
         if (T + 1 < MF_TILES_INV) {
@@ -307,8 +299,8 @@ __device__ __forceinline__ void window_operands(const fp *imgA, const fp *ark2, 
         }
         const uint64_t *kp = k_lds + 4 * (2 * T + h);
         const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
-        const uint64_t xa = (cube_l(recombine_mad(a0, kw, sh)) - HALF_P) ^ X0;
-        const uint64_t xb = (cube_l(recombine_mad(a1, kw, sh)) - HALF_P) ^ X0;
+        const uint64_t xa = (fp_cube(recombine_mad(a0, kw, sh)) - HALF_P) ^ X0;
+        const uint64_t xb = (fp_cube(recombine_mad(a1, kw, sh)) - HALF_P) ^ X0;
         if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
         else { heldA = xa; heldB = xb; }
     }
@@ -316,8 +308,8 @@ __device__ __forceinline__ void window_operands(const fp *imgA, const fp *ark2, 
     // forward half: cube(cur_j), j = 2 t + h
 #pragma unroll
     for (int t = 0; t < 7; t++) {
-        const uint64_t xa = (cube_l(imgA[(2 * t + h) * RW_ROWS]) - HALF_P) ^ X0;
-        const uint64_t xb = (cube_l(imgA[(2 * t + h) * RW_ROWS + 32]) - HALF_P) ^ X0;
+        const uint64_t xa = (fp_cube(imgA[(2 * t + h) * RW_ROWS]) - HALF_P) ^ X0;
+        const uint64_t xb = (fp_cube(imgA[(2 * t + h) * RW_ROWS + 32]) - HALF_P) ^ X0;
         if (t & 1) { heldA = xa; heldB = xb; }
         else { cA[3 + (t >> 1)] = pack2(heldA, xa); cB[3 + (t >> 1)] = pack2(heldB, xb); }
     }
