@@ -408,10 +408,17 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
             // the image is free again: the next window (of this block, or the first one of the workgroup's next block) arrives behind
             // the sections' product
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef RM_EXP_NODMA // measurement builds: the windows are not fetched (the image keeps the first window)
             if (wdx < 4) fetch_window(rows, n, c_windows[wdx + 1].reg, lane, img);
             else if (blk + gridDim.x < nblk) { rows = rows_of(blk + gridDim.x); fetch_window(rows, n, c_windows[0].reg, lane, img); }
+#endif
             fp xA[2] = {0, 0}, xB[2] = {0, 0}; // the window's terms of stream u
+#ifdef RM_EXP_NOSEC // measurement builds: without the sections' product
+            const int t0 = 0, t1 = 0;
+            xA[0] = (fp)cA[0][0] ^ (fp)cA[6][3]; xB[0] = (fp)cB[1][1] ^ (fp)cB[5][2];
+#else
             const int t0 = mf_tile_base(wdx), t1 = mf_tile_base(wdx + 1);
+#endif
 #pragma unroll 1
             for (int tile = t0; tile < t1; tile++) {
                 const int local = tile - t0, fs = mf_tile_fs(wdx, local), u = mf_tile_pair(wdx, local);
