@@ -243,6 +243,7 @@ __device__ __forceinline__ void expand_inverse_table(v4i *inv_lds, const uint64_
 // One window, everything that reads the image: the operands of the sections' product for both points of the lane -- half h of the 28
 // values (cube(INV_MDS (next - ark2))_i, i = 2 m + h, then cube(cur_j), j = 2 t + h), centred and byte-offset, two per k-step.
 // imgA = the wave's image + n; ark2 = this row's 14 constants; k_lds = the row constants (four words each) of the inverse matrix.
+template <int DBUF>
 __device__ __forceinline__ void window_operands(const fp *imgA, const fp *ark2, const v4i *inv_lds, const uint64_t *k_lds, const Role &ro,
                                                 const Shifts &sh, v4i (&cA)[MF_KS_SEC], v4i (&cB)[MF_KS_SEC]) {
     const int h = ro.h, lane = ro.lane;
@@ -256,7 +257,7 @@ __device__ __forceinline__ void window_operands(const fp *imgA, const fp *ark2, 
         bB[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 33], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 33], k1) ^ X0);
     }
     uint64_t heldA = 0, heldB = 0;
-#if RM_DBUF > 0
+    if constexpr (DBUF > 0) {
     // tile T + 1 on the matrix pipe while the vector ALU recombines and cubes tile T: a wave issues in order, so the eight
     // MFMAs are spread through the vector work (one per RM_DBUF vector instructions), not put in front of it
     v16i acc[2][2];
@@ -283,11 +284,11 @@ __device__ __forceinline__ void window_operands(const fp *imgA, const fp *ark2, 
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, RM_DBUF, 0); // VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, DBUF, 0); // VALU
             }
         }
     }
-#else
+    } else {
 #pragma unroll
     for (int T = 0; T < MF_TILES_INV; T++) {
         v16i a0 = acc_start(), a1 = acc_start();
@@ -304,7 +305,7 @@ __device__ __forceinline__ void window_operands(const fp *imgA, const fp *ark2, 
         if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
         else { heldA = xa; heldB = xb; }
     }
-#endif
+    }
     // forward half: cube(cur_j), j = 2 t + h
 #pragma unroll
     for (int t = 0; t < 7; t++) {
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
             const RoundWindow w = c_windows[wdx];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             v4i cA[MF_KS_SEC], cB[MF_KS_SEC];
-            window_operands(imgA, ark2, inv_lds, k_lds, ro, sh, cA, cB);
+            window_operands<RM_DBUF>(imgA, ark2, inv_lds, k_lds, ro, sh, cA, cB);
             // the image is free again: the next window (of this block, or the first one of the workgroup's next block) arrives behind
             // the sections' product
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_merkle_rounds_mfma(MerkleRo
         for (int wdx = 0; wdx < NWIN; wdx++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             v4i cA[MF_KS_SEC], cB[MF_KS_SEC];
-            window_operands(imgA, ark2, inv_lds, k_lds, ro, sh, cA, cB);
+            window_operands<0>(imgA, ark2, inv_lds, k_lds, ro, sh, cA, cB); // one tile at a time: 190-198 registers (double-buffered: 256 and 16 spills)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (wdx + 1 < NWIN) fetch_window(rows, n, c_windows[W0 + wdx + 1].reg, lane, img);
             else if (blk + gridDim.x < nblk) { rows = rows_of(blk + gridDim.x); fetch_window(rows, n, c_windows[W0].reg, lane, img); }

@@ -116,6 +116,23 @@ def test_schnorr_air_2_18(oracle, backend):
         assert (got[0:6, 512 * t + 511] == w.sig_rx[t]).all()
 
 
+def test_state_transition_2_20_proof_is_the_same_without_the_matrix_cores():
+    """The Rescue windows of the constraint evaluation run on the matrix cores (csrc/rounds_mfma.hip: int8 GEMMs of byte diagonals);
+    CSTARK_ROUNDS_MFMA=0 -- read once per process -- keeps the vector-ALU kernel k_rounds_split.  Both must write the golden proof
+    (the default path is what every other test of this file runs)."""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, os, hashlib; sys.path.insert(0, %r)\n"
+            "from certificate_stark_amd.prover import ProofOptions, TransactionExample, TransactionMetadata\n"
+            "meta = TransactionMetadata.load(os.path.join(%r, 'tests', 'golden', 'witness_1024_d15.npz'))\n"
+            "print(hashlib.sha256(TransactionExample(ProofOptions(96, 8, 0, 0, 0, 4, 256), meta).prove()).hexdigest())\n") % (ROOT, ROOT)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "proof_1024tx_d15_q96.json")))
+    got = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTARK_ROUNDS_MFMA="0"), capture_output=True, text=True, timeout=600)
+    assert got.returncode == 0, got.stderr[-2000:]
+    assert got.stdout.strip().splitlines()[-1] == gold["sha256"]
+
+
 @pytest.mark.parametrize("switch", ["CSTARK_NTT_V4", "CSTARK_NTT_V2"])
 def test_state_transition_2_20_proof_is_the_same_through_the_other_transform_kernels(switch):
     """The 2^20-point transforms have three kernel generations (half-tile exchanges by default; CSTARK_NTT_V4=1: whole-tile three-step;

@@ -97,6 +97,25 @@ def _check_digest(name, cfg, proof):
     assert hashlib.sha256(proof).hexdigest() == gold["sha256"]
 
 
+@pytest.mark.parametrize("cfg", ["merkle_2_18", "schnorr_2_18"])
+def test_sub_air_proofs_are_the_same_without_the_matrix_cores(cfg):
+    """The sub-AIRs' folded round gadgets run on the matrix cores (k_merkle_rounds_mfma, csrc/rounds_mfma.hip) -- the path the digest
+    tests below pin; CSTARK_ROUNDS_MFMA=0 (read once per process) keeps the vector-ALU kernel k_merkle_rounds.  A child process per
+    setting proves the configuration of tools/bench_air_one.py: the proofs must be byte-identical."""
+    import subprocess
+    import sys
+    code = ("import sys, os, hashlib; sys.path.insert(0, %r); sys.argv = ['bench_air_one.py', %r, '1']\n"
+            "import runpy, builtins\n"
+            "g = runpy.run_path(os.path.join(%r, 'tools', 'bench_air_one.py'))\n"
+            "print(hashlib.sha256(g['p']).hexdigest())\n") % (ROOT, cfg, ROOT)
+    digests = []
+    for v in ("1", "0"):
+        got = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CSTARK_ROUNDS_MFMA=v), capture_output=True, text=True, timeout=600)
+        assert got.returncode == 0, got.stderr[-2000:]
+        digests.append(got.stdout.strip().splitlines()[-1])
+    assert len(digests[0]) == 64 and digests[0] == digests[1]
+
+
 @pytest.mark.parametrize("name", ["range_64", "range_2_16", "merkle_2_18_d15", "merkle_2_18_d31", "schnorr_2_18"])
 def test_sub_air_proofs_at_baseline_size_equal_the_cpu_provers(oracle, backend, name):
     from oracle import verifier as V
