@@ -38,7 +38,9 @@ typedef unsigned __int128 u128;
 #define RM_WAVES 2
 #endif
 constexpr int RM_NT = RM_NT_;                    // threads per workgroup: eight waves share one expanded inverse table
-constexpr int RW_ROWS = 66, RW_IMG = 14 * RW_ROWS; // window image of a wave: 14 columns x rows j0 .. j0 + 65 (k_rounds_split's)
+// window image of a wave of 32 PTS points: 14 columns x rows j0 .. j0 + 32 PTS + 1 (PTS = 2: k_rounds_split's)
+template <int PTS> constexpr int rw_rows = 32 * PTS + 2;
+template <int PTS> constexpr int rw_img = 14 * rw_rows<PTS>;
 constexpr uint64_t X0 = mdsmfma::X0;
 constexpr uint64_t HALF_P = (FP_P - 1) / 2;
 enum { P_SETUP = 0, P_HASH = 4, P_SCHNORR_HASH = 12, P_ARK = 20 }; // periodic columns (constraints.hip)
@@ -137,12 +139,13 @@ __global__ void k_merkle_rounds_mfma_tables(fp *__restrict__ rtab) {
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
-// LDS-DMA of one window: lane l < 33 moves rows j0 + 2l, j0 + 2l + 1 of the 14 columns into the wave's image (k_rounds_split)
+// LDS-DMA of one window: lane l < 16 PTS + 1 moves rows j0 + 2l, j0 + 2l + 1 of the 14 columns into the wave's image (k_rounds_split)
+template <int PTS>
 __device__ __forceinline__ void fetch_window(const fp *rows, size_t n, int reg, int lane, fp *img) {
-    if (lane < 33) {
+    if (lane < 16 * PTS + 1) {
 #pragma unroll
         for (int j = 0; j < 14; j++)
-            __builtin_amdgcn_global_load_lds((glb_void *)(rows + (size_t)(reg + j) * n), (lds_void *)(img + j * RW_ROWS), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(rows + (size_t)(reg + j) * n), (lds_void *)(img + j * rw_rows<PTS>), 16, 0, 0);
     }
 }
 __device__ __forceinline__ v4i pack2(uint64_t a, uint64_t b) {
@@ -202,7 +205,10 @@ __device__ __forceinline__ fp recombine_mad(const v16i &acc, const uint64_t (&k)
     return acc_reduce(a);
 }
 #ifndef RM_DBUF
-#define RM_DBUF 16 // vector instructions per MFMA of the next tile in the inverse half (0: one tile at a time); measured 12: 1.91, 16: 1.745, 20: 1.78, 0: 1.82 ms
+// vector instructions per MFMA of the NEXT tile in the inverse half (two accumulator sets); 0: one tile at a time.  Measured on three
+// boxes: 16 gave 1.745 against 1.82 ms on one, 1.94 against 1.87-1.92 on two others (243-256 registers, spills in the generic form);
+// 12: 1.91, 20: 1.78.  Inside the noise between boxes: the simple form is the default.
+#define RM_DBUF 0
 #endif
 #ifndef RM_RESIDENT_
 #define RM_RESIDENT_ 4096
@@ -240,97 +246,100 @@ __device__ __forceinline__ void expand_inverse_table(v4i *inv_lds, const uint64_
         inv_lds[e] = expand_frag(dw[0], dw[1], slo, shi);
     }
 }
-// One window, everything that reads the image: the operands of the sections' product for both points of the lane -- half h of the 28
-// values (cube(INV_MDS (next - ark2))_i, i = 2 m + h, then cube(cur_j), j = 2 t + h), centred and byte-offset, two per k-step.
-// imgA = the wave's image + n; ark2 = this row's 14 constants; k_lds = the row constants (four words each) of the inverse matrix.
-template <int DBUF>
+// One window, everything that reads the image: the operands of the sections' product for the lane's PTS points (n, and n + 32) --
+// half h of the 28 values (cube(INV_MDS (next - ark2))_i, i = 2 m + h, then cube(cur_j), j = 2 t + h), centred and byte-offset, two
+// per k-step.  imgA = the wave's image + n; ark2 = this row's 14 constants; k_lds = the row constants (four words each) of the
+// inverse matrix.  DBUF > 0: tile T + 1 on the matrix pipe while the vector ALU recombines and cubes tile T -- a wave issues in
+// order, so the MFMAs are spread through the vector work (one per DBUF vector instructions), not put in front of it.
+template <int PTS, int DBUF>
 __device__ __forceinline__ void window_operands(const fp *imgA, const fp *ark2, const v4i *inv_lds, const uint64_t *k_lds, const Role &ro,
-                                                const Shifts &sh, v4i (&cA)[MF_KS_SEC], v4i (&cB)[MF_KS_SEC]) {
+                                                const Shifts &sh, v4i (&c)[PTS][MF_KS_SEC]) {
+    constexpr int RWR = rw_rows<PTS>;
     const int h = ro.h, lane = ro.lane;
     // operands of the inverse matrix: (next - ark2) of columns 4 s + 2 h, + 1 (k-step 3 of half 1 is padding: its table bytes are 0)
-    v4i bA[MF_KS_INV], bB[MF_KS_INV];
+    v4i b[PTS][MF_KS_INV];
 #pragma unroll
     for (int s = 0; s < MF_KS_INV; s++) {
         const int jb = (s == 3 && h) ? 12 : 4 * s + 2 * h;
         const fp k0 = ark2[jb], k1 = ark2[jb + 1];
-        bA[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 1], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 1], k1) ^ X0);
-        bB[s] = pack2(fp_sub(imgA[jb * RW_ROWS + 33], k0) ^ X0, fp_sub(imgA[(jb + 1) * RW_ROWS + 33], k1) ^ X0);
+#pragma unroll
+        for (int pt = 0; pt < PTS; pt++)
+            b[pt][s] = pack2(fp_sub(imgA[jb * RWR + 32 * pt + 1], k0) ^ X0, fp_sub(imgA[(jb + 1) * RWR + 32 * pt + 1], k1) ^ X0);
     }
-    uint64_t heldA = 0, heldB = 0;
-    if constexpr (DBUF > 0) {
-    // tile T + 1 on the matrix pipe while the vector ALU recombines and cubes tile T: a wave issues in order, so the eight
-    // MFMAs are spread through the vector work (one per RM_DBUF vector instructions), not put in front of it
-    v16i acc[2][2];
-    auto inv_tile = [&](int T, v16i &a0, v16i &a1) {
-        a0 = acc_start(); a1 = acc_start();
+    uint64_t held[PTS];
+    auto inv_tile = [&](int T, v16i (&a)[PTS]) {
+#pragma unroll
+        for (int pt = 0; pt < PTS; pt++) a[pt] = acc_start();
 #pragma unroll
         for (int s = 0; s < MF_KS_INV; s++) {
-            const v4i a = inv_lds[(T * MF_KS_INV + s) * 64 + lane];
-            a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bA[s], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bB[s], a1, 0, 0, 0);
+            const v4i fr = inv_lds[(T * MF_KS_INV + s) * 64 + lane];
+#pragma unroll
+            for (int pt = 0; pt < PTS; pt++) a[pt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr, b[pt][s], a[pt], 0, 0, 0);
         }
     };
-    inv_tile(0, acc[0][0], acc[0][1]);
-#pragma unroll
-    for (int T = 0; T < MF_TILES_INV; T++) {
-        if (T + 1 < MF_TILES_INV) inv_tile(T + 1, acc[(T + 1) & 1][0], acc[(T + 1) & 1][1]);
+    auto finish_tile = [&](int T, const v16i (&a)[PTS]) { // recombine, reduce, cube: output i = 2 T + h, entry m = T of the operand
         const uint64_t *kp = k_lds + 4 * (2 * T + h);
         const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
-        const uint64_t xa = (fp_cube(recombine_mad(acc[T & 1][0], kw, sh)) - HALF_P) ^ X0;
-        const uint64_t xb = (fp_cube(recombine_mad(acc[T & 1][1], kw, sh)) - HALF_P) ^ X0;
-        if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
-        else { heldA = xa; heldB = xb; }
-        if (T + 1 < MF_TILES_INV) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, DBUF, 0); // VALU
+        for (int pt = 0; pt < PTS; pt++) {
+            const uint64_t x = (fp_cube(recombine_mad(a[pt], kw, sh)) - HALF_P) ^ X0;
+            if (T & 1) c[pt][T >> 1] = pack2(held[pt], x);
+            else held[pt] = x;
+        }
+    };
+    if constexpr (DBUF > 0) {
+        v16i acc[2][PTS];
+        inv_tile(0, acc[0]);
+#pragma unroll
+        for (int T = 0; T < MF_TILES_INV; T++) {
+            if (T + 1 < MF_TILES_INV) inv_tile(T + 1, acc[(T + 1) & 1]);
+            finish_tile(T, acc[T & 1]);
+            if (T + 1 < MF_TILES_INV) {
+#pragma unroll
+                for (int e = 0; e < 4 * PTS; e++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, DBUF, 0); // VALU
+                }
             }
         }
-    }
     } else {
 #pragma unroll
-    for (int T = 0; T < MF_TILES_INV; T++) {
-        v16i a0 = acc_start(), a1 = acc_start();
-#pragma unroll
-        for (int s = 0; s < MF_KS_INV; s++) {
-            const v4i a = inv_lds[(T * MF_KS_INV + s) * 64 + lane];
-            a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bA[s], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bB[s], a1, 0, 0, 0);
+        for (int T = 0; T < MF_TILES_INV; T++) {
+            v16i acc[PTS];
+            inv_tile(T, acc);
+            finish_tile(T, acc);
         }
-        const uint64_t *kp = k_lds + 4 * (2 * T + h);
-        const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
-        const uint64_t xa = (fp_cube(recombine_mad(a0, kw, sh)) - HALF_P) ^ X0;
-        const uint64_t xb = (fp_cube(recombine_mad(a1, kw, sh)) - HALF_P) ^ X0;
-        if (T & 1) { cA[T >> 1] = pack2(heldA, xa); cB[T >> 1] = pack2(heldB, xb); }
-        else { heldA = xa; heldB = xb; }
     }
-    }
-    // forward half: cube(cur_j), j = 2 t + h
+    // forward half: cube(cur_j), j = 2 t + h: entries m = 7 + t
 #pragma unroll
     for (int t = 0; t < 7; t++) {
-        const uint64_t xa = (fp_cube(imgA[(2 * t + h) * RW_ROWS]) - HALF_P) ^ X0;
-        const uint64_t xb = (fp_cube(imgA[(2 * t + h) * RW_ROWS + 32]) - HALF_P) ^ X0;
-        if (t & 1) { heldA = xa; heldB = xb; }
-        else { cA[3 + (t >> 1)] = pack2(heldA, xa); cB[3 + (t >> 1)] = pack2(heldB, xb); }
+#pragma unroll
+        for (int pt = 0; pt < PTS; pt++) {
+            const uint64_t x = (fp_cube(imgA[(2 * t + h) * RWR + 32 * pt]) - HALF_P) ^ X0;
+            if (t & 1) held[pt] = x;
+            else c[pt][3 + (t >> 1)] = pack2(held[pt], x);
+        }
     }
 }
-// one section tile against the window's operands: ra / rb = the value of this lane's section (output g = h of the tile) at the
-// lane's two points: gamma . cube(INV_MDS (next - ark2)) - U . cube(cur).  tile_d = the tile's compact entries [g][h][16], kp = the
+// one section tile against the window's operands: r[pt] = the value of this lane's section (output g = h of the tile) at the
+// lane's points: gamma . cube(INV_MDS (next - ark2)) - U . cube(cur).  tile_d = the tile's compact entries [g][h][16], kp = the
 // four words of the lane's row constant
-__device__ __forceinline__ void section_tile(const uint64_t *tile_d, const uint64_t *kp, const Role &ro, const Shifts &sh, const v4i (&cA)[MF_KS_SEC],
-                                             const v4i (&cB)[MF_KS_SEC], fp &ra, fp &rb) {
-    v16i a0 = acc_start(), a1 = acc_start();
+template <int PTS>
+__device__ __forceinline__ void section_tile(const uint64_t *tile_d, const uint64_t *kp, const Role &ro, const Shifts &sh, const v4i (&c)[PTS][MF_KS_SEC],
+                                             fp (&r)[PTS]) {
+    v16i a[PTS];
+#pragma unroll
+    for (int pt = 0; pt < PTS; pt++) a[pt] = acc_start();
     const uint64_t *dw = tile_d + (ro.ag * 2 + ro.h) * 16;
 #pragma unroll
     for (int s = 0; s < MF_KS_SEC; s++) {
-        const v4i a = expand_frag(dw[2 * s], dw[2 * s + 1], ro.sel_lo, ro.sel_hi);
-        a0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cA[s], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, cB[s], a1, 0, 0, 0);
+        const v4i fr = expand_frag(dw[2 * s], dw[2 * s + 1], ro.sel_lo, ro.sel_hi);
+#pragma unroll
+        for (int pt = 0; pt < PTS; pt++) a[pt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fr, c[pt][s], a[pt], 0, 0, 0);
     }
     const uint64_t kw[4] = {kp[0], kp[1], kp[2], kp[3]};
-    ra = recombine_mad(a0, kw, sh);
-    rb = recombine_mad(a1, kw, sh);
+#pragma unroll
+    for (int pt = 0; pt < PTS; pt++) r[pt] = recombine_mad(a[pt], kw, sh);
 }
 // value of the other lane half (lane ^ 32)
 __device__ __forceinline__ fp other_half(fp v) {
@@ -338,20 +347,31 @@ __device__ __forceinline__ fp other_half(fp v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+#ifndef RM_DBUF1
+#define RM_DBUF1 0 // the same for one point per lane
+#endif
+#ifndef RM_PTS
+// points per lane of k_rounds_mfma: 2 (a wave = 64 points, 222 registers, two waves per SIMD) or 1 (32 points, 133 registers, three
+// waves per SIMD, 54 KB of LDS per workgroup).  Measured: 1 is SLOWER, 2.14-2.23 against 1.89-1.94 ms -- every table fragment is read and
+// expanded for half as many points, and the third wave does not pay for that: occupancy is not what holds the kernel back.
+#define RM_PTS 2
+#endif
 constexpr size_t RM_LDS_INV = (size_t)MF_TILES_INV * MF_KS_INV * 64 * 16;                 // expanded inverse table
-constexpr size_t RM_LDS_IMG = (size_t)(RM_NT / 64) * RW_IMG * 8;
+template <int PTS> constexpr size_t rm_lds_img = (size_t)(RM_NT / 64) * rw_img<PTS> * 8;
 constexpr size_t RM_LDS_SEC = (size_t)MF_TILES_SEC * 4 * 16 * 8;                          // compact section tables
 constexpr size_t RM_LDS_K = (size_t)(14 + 2 * MF_TILES_SEC) * 32;
-constexpr size_t RM_LDS_ARK = 8 * 14 * 8, RM_LDS_ATAB = (size_t)RT_SECTIONS * 8 * 8;
-constexpr size_t RM_LDS = RM_LDS_INV + RM_LDS_IMG + RM_LDS_SEC + RM_LDS_K + RM_LDS_ARK + RM_LDS_ATAB;
+constexpr size_t RM_LDS_ARK = 8 * 14 * 8, RM_LDS_ATAB = (size_t)2 * MF_TILES_SEC * 8 * 8; // A[section of (tile, g)][row mod 8]
+template <int PTS> constexpr size_t rm_lds = RM_LDS_INV + rm_lds_img<PTS> + RM_LDS_SEC + RM_LDS_K + RM_LDS_ARK + RM_LDS_ATAB;
 
 // out = [4 polynomials][4 even cosets][n] as k_rounds_split<1> writes them.  grid = (workgroups per coset, even cosets of the
-// window): a workgroup expands its tables once and then takes every gridDim.x-th block of RM_NT rows of its coset.
-__global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp *__restrict__ out) {
+// window): a workgroup expands its tables once and then takes every gridDim.x-th block of RM_NT / 64 * 32 PTS rows of its coset.
+template <int PTS>
+__global__ __launch_bounds__(RM_NT, PTS == 1 ? 3 : RM_WAVES) void k_rounds_mfma(CeParams p, fp *__restrict__ out) {
+    constexpr int RWR = rw_rows<PTS>, WROWS = 32 * PTS, BROWS = RM_NT / 64 * WROWS; // rows per wave, per workgroup block
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     v4i *inv_lds = (v4i *)lds;
     fp *img_all = (fp *)(lds + RM_LDS_INV);
-    uint64_t *secd_lds = (uint64_t *)(lds + RM_LDS_INV + RM_LDS_IMG);
+    uint64_t *secd_lds = (uint64_t *)(lds + RM_LDS_INV + rm_lds_img<PTS>);
     uint64_t *k_lds = secd_lds + RM_LDS_SEC / 8;
     fp *ark2_lds = k_lds + RM_LDS_K / 8;
     fp *atab_lds = ark2_lds + RM_LDS_ARK / 8;
@@ -369,91 +389,114 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
         const unsigned r = tid / 14, c = tid % 14;
         ark2_lds[tid] = p.ptab[((size_t)ka * 48 + P_ARK + 14 + c) * 1024 + r];
     }
-    for (unsigned e = tid; e < RT_SECTIONS * 8; e += RM_NT) atab_lds[e] = rt[RT_A + (e >> 3) * 64 + ka * 8 + (e & 7)];
+    for (unsigned e = tid; e < 2 * MF_TILES_SEC * 8; e += RM_NT) { // (tile, g) -> section (window, flag set, slot 2 u + g)
+        const int tile = e >> 4, g = (e >> 3) & 1, w = mf_tile_window(tile), local = tile - mf_tile_base(w);
+        const int sec = (w * 2 + mf_tile_fs(w, local)) * 4 + 2 * mf_tile_pair(w, local) + g;
+        atab_lds[e] = rt[RT_A + sec * 64 + ka * 8 + (e & 7)];
+    }
     __syncthreads();
 
-    fp *img = img_all + (size_t)(tid >> 6) * RW_IMG;
+    fp *img = img_all + (size_t)(tid >> 6) * rw_img<PTS>;
     const fp *imgA = img + nn; // point n: current row at element n, next row at n + 1; point n + 32: + 32
-    const unsigned jrp = (unsigned)(nn & 7); // row of both points mod 8 (blocks and waves start at multiples of 64)
+    const unsigned jrp = (unsigned)(nn & 7); // row of the lane's points mod 8 (blocks and waves start at multiples of 32)
     const fp *ark2 = ark2_lds + jrp * 14;
     const fp *per = p.ptab + (size_t)(p.k0 + kk) * 48 * 1024;
     const fp *colbase = p.lde + (size_t)kk * 94 * n;
     const Shifts sh{opaque_const<1>(), opaque_const<1u << 8>(), opaque_const<1u << 16>(), opaque_const<1u << 24>()};
-    const size_t nblk = n / RM_NT;
+    const size_t nblk = n / BROWS;
     size_t blk = blockIdx.x;
-    // rows jw + 2 lane, + 1 of the wave's 64 points (first row jw); rows n, n + 1 of the coset's last wave wrap to 0, 1
+    // rows jw + 2 lane, + 1 of the wave's points (first row jw); rows n, n + 1 of the coset's last wave wrap to 0, 1
     auto rows_of = [&](size_t b) {
-        const size_t jw = b * (size_t)RM_NT + (size_t)(tid >> 6) * 64;
-        return colbase + jw + 2 * lane - ((lane == 32 && jw + 64 == n) ? n : 0);
+        const size_t jw = b * (size_t)BROWS + (size_t)(tid >> 6) * WROWS;
+        return colbase + jw + 2 * lane - ((lane == 16 * PTS && jw + WROWS == n) ? n : 0);
     };
     const fp *rows = rows_of(blk);
-    if (blk < nblk) fetch_window(rows, n, c_windows[0].reg, lane, img);
+    if (blk < nblk) fetch_window<PTS>(rows, n, c_windows[0].reg, lane, img);
 #pragma unroll 1
     for (; blk < nblk; blk += gridDim.x) {
-        const size_t jw = blk * (size_t)RM_NT + (size_t)(tid >> 6) * 64; // the wave's first row
-        const size_t rA = (jw + nn) & 1023, rB = (jw + nn + 32) & 1023;
-        const fp flA[3] = {per[(size_t)P_SETUP * 1024 + rA], per[(size_t)P_HASH * 1024 + rA], per[(size_t)P_SCHNORR_HASH * 1024 + rA]};
-        const fp flB[3] = {per[(size_t)P_SETUP * 1024 + rB], per[(size_t)P_HASH * 1024 + rB], per[(size_t)P_SCHNORR_HASH * 1024 + rB]};
+        const size_t jw = blk * (size_t)BROWS + (size_t)(tid >> 6) * WROWS; // the wave's first row
+        fp fl[PTS][3];
+#pragma unroll
+        for (int pt = 0; pt < PTS; pt++) {
+            const size_t r = (jw + nn + 32 * pt) & 1023;
+            fl[pt][0] = per[(size_t)P_SETUP * 1024 + r]; fl[pt][1] = per[(size_t)P_HASH * 1024 + r]; fl[pt][2] = per[(size_t)P_SCHNORR_HASH * 1024 + r];
+        }
         // Sums per STREAM, not per polynomial: a lane's sections are slot u = 0 (h = 0: alpha; h = 1: slot 1) and slot u = 1 (h = 0:
         // slot 2; h = 1: slot 3) of every flag set, and which polynomial a slot feeds depends on the window alone -- so the register
         // a term goes to is the same for both lane halves: stream 0 -> polynomial of slot 1 (windows 0..4: 1, 2, 1, 3, 3), stream 1 ->
         // polynomial of slot 2 (2, 3, 3).  Half 0 reads stream 0 as alpha whatever the register, half 1 reads stream 1 as polynomial 1
         // (slot 3 is used in window 1 only, there by group 0).
-        fp sA[5] = {0, 0, 0, 0, 0}, sB[5] = {0, 0, 0, 0, 0}; // stream 0 -> polynomials 1, 2, 3 | stream 1 -> polynomials 2, 3
+        fp sm[PTS][5]; // stream 0 -> polynomials 1, 2, 3 | stream 1 -> polynomials 2, 3
+#pragma unroll
+        for (int pt = 0; pt < PTS; pt++)
+#pragma unroll
+            for (int q = 0; q < 5; q++) sm[pt][q] = 0;
 #pragma unroll 1
         for (int wdx = 0; wdx < 5; wdx++) {
             const RoundWindow w = c_windows[wdx];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            v4i cA[MF_KS_SEC], cB[MF_KS_SEC];
-            window_operands<RM_DBUF>(imgA, ark2, inv_lds, k_lds, ro, sh, cA, cB);
+            v4i c[PTS][MF_KS_SEC];
+            window_operands<PTS, PTS == 1 ? RM_DBUF1 : RM_DBUF>(imgA, ark2, inv_lds, k_lds, ro, sh, c);
             // the image is free again: the next window (of this block, or the first one of the workgroup's next block) arrives behind
             // the sections' product
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef RM_EXP_NODMA // measurement builds: the windows are not fetched (the image keeps the first window)
-            if (wdx < 4) fetch_window(rows, n, c_windows[wdx + 1].reg, lane, img);
-            else if (blk + gridDim.x < nblk) { rows = rows_of(blk + gridDim.x); fetch_window(rows, n, c_windows[0].reg, lane, img); }
+            if (wdx < 4) fetch_window<PTS>(rows, n, c_windows[wdx + 1].reg, lane, img);
+            else if (blk + gridDim.x < nblk) { rows = rows_of(blk + gridDim.x); fetch_window<PTS>(rows, n, c_windows[0].reg, lane, img); }
 #endif
-            fp xA[2] = {0, 0}, xB[2] = {0, 0}; // the window's terms of stream u
-#ifdef RM_EXP_NOSEC // measurement builds: without the sections' product
-            const int t0 = 0, t1 = 0;
-            xA[0] = (fp)cA[0][0] ^ (fp)cA[6][3]; xB[0] = (fp)cB[1][1] ^ (fp)cB[5][2];
-#else
+            fp x[PTS][2]; // the window's terms of stream u
+#pragma unroll
+            for (int pt = 0; pt < PTS; pt++) x[pt][0] = x[pt][1] = 0;
             const int t0 = mf_tile_base(wdx), t1 = mf_tile_base(wdx + 1);
-#endif
 #pragma unroll 1
             for (int tile = t0; tile < t1; tile++) {
                 const int local = tile - t0, fs = mf_tile_fs(wdx, local), u = mf_tile_pair(wdx, local);
-                fp ra, rb;
-                section_tile(secd_lds + tile * 64, k_lds + 4 * (14 + 2 * tile + h), ro, sh, cA, cB, ra, rb);
-                const int sec = (wdx * 2 + fs) * 4 + 2 * u + h; // this lane's section: slot 2 u + h
-                const fp at = atab_lds[sec * 8 + jrp];
-                const int fl = fs ? w.flag_b : w.flag_a;
-                const fp fa = fl == 0 ? flA[0] : fl == 1 ? flA[1] : fl == 2 ? flA[2] : fp_add(flA[0], flA[1]);
-                const fp fb = fl == 0 ? flB[0] : fl == 1 ? flB[1] : fl == 2 ? flB[2] : fp_add(flB[0], flB[1]);
-                const fp va = fp_mul(fa, fp_sub(ra, at));
-                const fp vb = fp_mul(fb, fp_sub(rb, at));
-                if (u) { xA[1] = fp_add(xA[1], va); xB[1] = fp_add(xB[1], vb); }
-                else { xA[0] = fp_add(xA[0], va); xB[0] = fp_add(xB[0], vb); }
+                fp r[PTS];
+                section_tile<PTS>(secd_lds + tile * 64, k_lds + 4 * (14 + 2 * tile + h), ro, sh, c, r);
+                const fp at = atab_lds[(2 * tile + h) * 8 + jrp]; // this lane's section: slot 2 u + h
+                const int fg = fs ? w.flag_b : w.flag_a;
+#pragma unroll
+                for (int pt = 0; pt < PTS; pt++) {
+                    const fp f = fg == 0 ? fl[pt][0] : fg == 1 ? fl[pt][1] : fg == 2 ? fl[pt][2] : fp_add(fl[pt][0], fl[pt][1]);
+                    const fp v = fp_mul(f, fp_sub(r[pt], at));
+                    if (u) x[pt][1] = fp_add(x[pt][1], v);
+                    else x[pt][0] = fp_add(x[pt][0], v);
+                }
             }
             // stream 0 -> polynomial of slot 1: 1, 2, 1, 3, 3; stream 1 -> polynomial of slot 2: 2, 3, 3 (windows 3, 4: no pair 1)
-            if (wdx == 0 || wdx == 2) { sA[0] = fp_add(sA[0], xA[0]); sB[0] = fp_add(sB[0], xB[0]); }
-            else if (wdx == 1) { sA[1] = fp_add(sA[1], xA[0]); sB[1] = fp_add(sB[1], xB[0]); }
-            else { sA[2] = fp_add(sA[2], xA[0]); sB[2] = fp_add(sB[2], xB[0]); }
-            if (wdx == 0) { sA[3] = fp_add(sA[3], xA[1]); sB[3] = fp_add(sB[3], xB[1]); }
-            else if (wdx < 3) { sA[4] = fp_add(sA[4], xA[1]); sB[4] = fp_add(sB[4], xB[1]); }
+#pragma unroll
+            for (int pt = 0; pt < PTS; pt++) {
+                if (wdx == 0 || wdx == 2) sm[pt][0] = fp_add(sm[pt][0], x[pt][0]);
+                else if (wdx == 1) sm[pt][1] = fp_add(sm[pt][1], x[pt][0]);
+                else sm[pt][2] = fp_add(sm[pt][2], x[pt][0]);
+                if (wdx == 0) sm[pt][3] = fp_add(sm[pt][3], x[pt][1]);
+                else if (wdx < 3) sm[pt][4] = fp_add(sm[pt][4], x[pt][1]);
+            }
         }
         // polynomials 0..3 of this lane's sections: half 0: stream 0 is alpha, stream 1 by register; half 1: stream 0 by register,
-        // stream 1 is polynomial 1.  Then the two halves of a point: lane (n, 0) holds its part of point n in A and lane (n, 1) the
-        // rest, likewise B for point n + 32.
-        const fp a012 = fp_add(fp_add(sA[0], sA[1]), sA[2]), a34 = fp_add(sA[3], sA[4]);
-        const fp b012 = fp_add(fp_add(sB[0], sB[1]), sB[2]), b34 = fp_add(sB[3], sB[4]);
-        const fp totA[4] = {h ? 0 : a012, h ? fp_add(sA[0], a34) : 0, h ? sA[1] : sA[3], h ? sA[2] : sA[4]};
-        const fp totB[4] = {h ? 0 : b012, h ? fp_add(sB[0], b34) : 0, h ? sB[1] : sB[3], h ? sB[2] : sB[4]};
-        const size_t j = jw + lane;
+        // stream 1 is polynomial 1.  The other half of a point's sections sits in lane ^ 32.
+        fp tot[PTS][4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { // this lane's own point: its part + what the other half holds of it
-            const fp mine = h ? totB[q] : totA[q], give = h ? totA[q] : totB[q];
-            out[((size_t)q * 4 + kc) * n + j] = fp_add(mine, other_half(give)); // table 3: group 2 (k_rounds_split)
+        for (int pt = 0; pt < PTS; pt++) {
+            const fp s012 = fp_add(fp_add(sm[pt][0], sm[pt][1]), sm[pt][2]), s34 = fp_add(sm[pt][3], sm[pt][4]);
+            tot[pt][0] = h ? 0 : s012; tot[pt][1] = h ? fp_add(sm[pt][0], s34) : 0;
+            tot[pt][2] = h ? sm[pt][1] : sm[pt][3]; tot[pt][3] = h ? sm[pt][2] : sm[pt][4];
+        }
+        if constexpr (PTS == 2) { // lane (n, 0) holds its part of point n in [0] and lane (n, 1) the rest, likewise [1] for point n + 32
+            const size_t j = jw + lane;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { // this lane's own point: its part + what the other half holds of it
+                const fp mine = h ? tot[1][q] : tot[0][q], give = h ? tot[0][q] : tot[1][q];
+                out[((size_t)q * 4 + kc) * n + j] = fp_add(mine, other_half(give)); // table 3: group 2 (k_rounds_split)
+            }
+        } else { // both halves hold parts of point n: half 0 writes polynomials 0, 1 and half 1 writes 2, 3
+            const size_t j = jw + nn;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const fp got = other_half(h ? tot[0][e] : tot[0][2 + e]);
+                const int q = 2 * h + e; // (lane-dependent address only)
+                out[((size_t)q * 4 + kc) * n + j] = fp_add(h ? tot[0][2 + e] : tot[0][e], got);
+            }
         }
     }
 }
@@ -462,7 +505,7 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_rounds_mfma(CeParams p, fp 
 // and the same values): per window ONE section tile -- output 0 = the alpha section, output 1 = the beta section (the round slots
 // share one declared degree) -- so half 0 of a wave sums alpha terms and half 1 beta terms; flag (alpha sum + x^adj beta sum) at the end.
 constexpr size_t MRM_LDS_SEC = 4 * 64 * 8, MRM_LDS_K = (14 + 8) * 32, MRM_LDS_ATAB = MR_SECTIONS * 8 * 8;
-constexpr size_t MRM_LDS = RM_LDS_INV + RM_LDS_IMG + MRM_LDS_SEC + MRM_LDS_K + RM_LDS_ARK + MRM_LDS_ATAB;
+constexpr size_t MRM_LDS = RM_LDS_INV + rm_lds_img<2> + MRM_LDS_SEC + MRM_LDS_K + RM_LDS_ARK + MRM_LDS_ATAB;
 struct MerkleRoundsParams { // what the kernel reads of AirCombineParams (the whole block costs registers): x^adj = xshift[k] w^(j xadj)
     const fp *lde, *w;
     fp *out;
@@ -475,7 +518,7 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_merkle_rounds_mfma(MerkleRo
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     v4i *inv_lds = (v4i *)lds;
     fp *img_all = (fp *)(lds + RM_LDS_INV);
-    uint64_t *secd_lds = (uint64_t *)(lds + RM_LDS_INV + RM_LDS_IMG);
+    uint64_t *secd_lds = (uint64_t *)(lds + RM_LDS_INV + rm_lds_img<2>);
     uint64_t *k_lds = secd_lds + MRM_LDS_SEC / 8;
     fp *ark2_lds = k_lds + MRM_LDS_K / 8;
     fp *atab_lds = ark2_lds + RM_LDS_ARK / 8;
@@ -496,7 +539,7 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_merkle_rounds_mfma(MerkleRo
     if (tid < MR_SECTIONS * 8) atab_lds[tid] = rtab[MR_A + (tid >> 3) * 64 + k * 8 + (tid & 7)];
     __syncthreads();
 
-    fp *img = img_all + (size_t)(tid >> 6) * RW_IMG;
+    fp *img = img_all + (size_t)(tid >> 6) * rw_img<2>;
     const fp *imgA = img + nn;
     const unsigned jrp = (unsigned)(nn & 7);
     const fp *ark2 = ark2_lds + jrp * 14;
@@ -509,7 +552,7 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_merkle_rounds_mfma(MerkleRo
         return colbase + jw + 2 * lane - ((lane == 32 && jw + 64 == n) ? n : 0);
     };
     const fp *rows = rows_of(blk);
-    if (blk < nblk) fetch_window(rows, n, c_windows[W0].reg, lane, img);
+    if (blk < nblk) fetch_window<2>(rows, n, c_windows[W0].reg, lane, img);
 #pragma unroll 1
     for (; blk < nblk; blk += gridDim.x) {
         const size_t j = blk * (size_t)RM_NT + (size_t)(tid >> 6) * 64 + lane; // this lane's own point
@@ -517,17 +560,17 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_merkle_rounds_mfma(MerkleRo
 #pragma unroll 1
         for (int wdx = 0; wdx < NWIN; wdx++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            v4i cA[MF_KS_SEC], cB[MF_KS_SEC];
-            window_operands<0>(imgA, ark2, inv_lds, k_lds, ro, sh, cA, cB); // one tile at a time: 190-198 registers (double-buffered: 256 and 16 spills)
+            v4i c[2][MF_KS_SEC];
+            window_operands<2, 0>(imgA, ark2, inv_lds, k_lds, ro, sh, c); // one tile at a time: 190-198 registers (double-buffered: 256 and 16 spills)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (wdx + 1 < NWIN) fetch_window(rows, n, c_windows[W0 + wdx + 1].reg, lane, img);
-            else if (blk + gridDim.x < nblk) { rows = rows_of(blk + gridDim.x); fetch_window(rows, n, c_windows[W0].reg, lane, img); }
-            __builtin_amdgcn_sched_barrier(0); // the section's product after the window's operands, not scheduled into them (16 spills)
-            fp ra, rb;
-            section_tile(secd_lds + wdx * 64, k_lds + 4 * (14 + 2 * wdx + h), ro, sh, cA, cB, ra, rb);
+            if (wdx + 1 < NWIN) fetch_window<2>(rows, n, c_windows[W0 + wdx + 1].reg, lane, img);
+            else if (blk + gridDim.x < nblk) { rows = rows_of(blk + gridDim.x); fetch_window<2>(rows, n, c_windows[W0].reg, lane, img); }
+            __builtin_amdgcn_sched_barrier(0);
+            fp r[2];
+            section_tile<2>(secd_lds + wdx * 64, k_lds + 4 * (14 + 2 * wdx + h), ro, sh, c, r);
             const fp at = atab_lds[(2 * wdx + h) * 8 + jrp];
-            tA = fp_add(tA, fp_sub(ra, at));
-            tB = fp_add(tB, fp_sub(rb, at));
+            tA = fp_add(tA, fp_sub(r[0], at));
+            tB = fp_add(tB, fp_sub(r[1], at));
         }
         const fp got = other_half(h ? tA : tB); // half 0 hands the alpha sum of point n + 32 over, half 1 the beta sum of point n
         const fp ta = h ? got : tA, tb = h ? tB : got;
@@ -543,12 +586,13 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_merkle_rounds_mfma(MerkleRo
 
 hipError_t launch_rounds_mfma(const CeParams &p, uint64_t *d_even, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    if ((p.m ? p.m : 1) != 1 || n % RM_NT) return hipErrorInvalidValue;
-    static const hipError_t attr = hipFuncSetAttribute((const void *)k_rounds_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RM_LDS);
+    constexpr int PTS = RM_PTS, BROWS = RM_NT / 64 * 32 * PTS;
+    if ((p.m ? p.m : 1) != 1 || n % BROWS) return hipErrorInvalidValue;
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k_rounds_mfma<PTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rm_lds<PTS>);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(k_rounds_mfma_tables, dim3(MF_TILES_INV + MF_TILES_SEC), dim3(64), 0, stream, p.rtab);
-    const unsigned ny = p.nkc ? p.nkc : 4, nblk = (unsigned)(n / RM_NT), gx = RM_RESIDENT / ny < nblk ? RM_RESIDENT / ny : nblk;
-    hipLaunchKernelGGL(k_rounds_mfma, dim3(gx, ny), dim3(RM_NT), RM_LDS, stream, p, d_even);
+    const unsigned ny = p.nkc ? p.nkc : 4, nblk = (unsigned)(n / BROWS), gx = RM_RESIDENT / ny < nblk ? RM_RESIDENT / ny : nblk;
+    hipLaunchKernelGGL(k_rounds_mfma<PTS>, dim3(gx, ny), dim3(RM_NT), rm_lds<PTS>, stream, p, d_even);
     return hipGetLastError();
 }
 

@@ -10,9 +10,12 @@
 """
 import hashlib
 import json
+import os
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 OPTS = (42, 8, 0, 0, 0, 4, 256)
