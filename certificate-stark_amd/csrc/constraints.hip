@@ -2665,9 +2665,9 @@ hipError_t launch_rounds_split(const CeParams &p, uint64_t *d_even, hipStream_t 
     const size_t n = (size_t)1 << p.log_n;
     const dim3 grid((unsigned)(n / FNT), p.nkc ? p.nkc : 4), block(FNT);
     const unsigned m = p.m ? p.m : 1;
-    // one coefficient set: the matrix-core kernel (rounds_mfma.hip; same values).  CSTARK_ROUNDS_MFMA=0: the vector-ALU kernel below
+    // the matrix-core kernel (rounds_mfma.hip; same values).  CSTARK_ROUNDS_MFMA=0: the vector-ALU kernels below
     static const bool mfma_env = [] { const char *e = getenv("CSTARK_ROUNDS_MFMA"); return !e || atoi(e) != 0; }();
-    if (m == 1 && mfma_env && n % 256 == 0) return launch_rounds_mfma(p, d_even, stream);
+    if (m <= 3 && mfma_env && n % 512 == 0) return launch_rounds_mfma(p, d_even, stream);
     if (m == 1) hipLaunchKernelGGL(k_rounds_split<1>, grid, block, 0, stream, p, d_even);
     else if (m == 2) hipLaunchKernelGGL(k_rounds_split<2>, grid, block, 0, stream, p, d_even);
     else if (m == 3) hipLaunchKernelGGL(k_rounds_split<3>, grid, block, 0, stream, p, d_even);

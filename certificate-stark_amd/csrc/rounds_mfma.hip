@@ -110,6 +110,7 @@ __device__ inline void build_section_tile(const fp *gam0, const fp *gam1, const 
 // Compact tables of one TransactionAir proof from what k_rounds_setup left in rtab (RT_G: the sections' coefficient vectors; RT_UL:
 // limbs of their MDS-folded forms).  grid = 7 inverse tiles + 13 section tiles, 64 threads.
 __global__ void k_rounds_mfma_tables(fp *__restrict__ rtab) {
+    rtab += (size_t)blockIdx.y * CE_RTAB_WORDS; // grid.y = coefficient set
     const int t = threadIdx.x;
     if (blockIdx.x < MF_TILES_INV) {
         build_inverse_tile(blockIdx.x, t, rtab + MF_INV_D + blockIdx.x * 32, rtab + MF_K + 8 * blockIdx.x);
@@ -357,24 +358,28 @@ __device__ __forceinline__ fp other_half(fp v) {
 #define RM_PTS 2
 #endif
 constexpr size_t RM_LDS_INV = (size_t)MF_TILES_INV * MF_KS_INV * 64 * 16;                 // expanded inverse table
-template <int PTS> constexpr size_t rm_lds_img = (size_t)(RM_NT / 64) * rw_img<PTS> * 8;
-constexpr size_t RM_LDS_SEC = (size_t)MF_TILES_SEC * 4 * 16 * 8;                          // compact section tables
-constexpr size_t RM_LDS_K = (size_t)(14 + 2 * MF_TILES_SEC) * 32;
-constexpr size_t RM_LDS_ARK = 8 * 14 * 8, RM_LDS_ATAB = (size_t)2 * MF_TILES_SEC * 8 * 8; // A[section of (tile, g)][row mod 8]
-template <int PTS> constexpr size_t rm_lds = RM_LDS_INV + rm_lds_img<PTS> + RM_LDS_SEC + RM_LDS_K + RM_LDS_ARK + RM_LDS_ATAB;
+template <int PTS, int NT = RM_NT> constexpr size_t rm_lds_img = (size_t)(NT / 64) * rw_img<PTS> * 8;
+constexpr size_t RM_LDS_SEC = (size_t)MF_TILES_SEC * 4 * 16 * 8;                          // compact section tables of one coefficient set
+constexpr size_t RM_LDS_KINV = 14 * 32, RM_LDS_KSEC = (size_t)2 * MF_TILES_SEC * 32;       // row constants: inverse matrix | sections of a set
+constexpr size_t RM_LDS_ARK = 8 * 14 * 8, RM_LDS_ATAB = (size_t)2 * MF_TILES_SEC * 8 * 8; // A[section of (tile, g)][row mod 8] of a set
+template <int PTS, int M, int NT> constexpr size_t rm_lds = RM_LDS_INV + rm_lds_img<PTS, NT> + RM_LDS_KINV + RM_LDS_ARK + M * (RM_LDS_SEC + RM_LDS_KSEC + RM_LDS_ATAB);
 
-// out = [4 polynomials][4 even cosets][n] as k_rounds_split<1> writes them.  grid = (workgroups per coset, even cosets of the
-// window): a workgroup expands its tables once and then takes every gridDim.x-th block of RM_NT / 64 * 32 PTS rows of its coset.
-template <int PTS>
-__global__ __launch_bounds__(RM_NT, PTS == 1 ? 3 : RM_WAVES) void k_rounds_mfma(CeParams p, fp *__restrict__ out) {
-    constexpr int RWR = rw_rows<PTS>, WROWS = 32 * PTS, BROWS = RM_NT / 64 * WROWS; // rows per wave, per workgroup block
+// out = per coefficient set [13 polynomials: the first four written here][4 even cosets][n], as k_rounds_split<M> writes them.
+// grid = (workgroups per coset, even cosets of the window): a workgroup expands its tables once and then takes every gridDim.x-th
+// block of NT / 64 * 32 PTS rows of its coset.  M coefficient sets (the components of an extension-field proof): the windows' operands
+// are formed once, every set has its own section tables (rtab + c * CE_RTAB_WORDS), constants and sums.
+template <int PTS, int M, int NT>
+__global__ __launch_bounds__(NT, PTS == 1 ? 3 : RM_WAVES) void k_rounds_mfma(CeParams p, fp *__restrict__ out) {
+    constexpr int RWR = rw_rows<PTS>, WROWS = 32 * PTS, BROWS = NT / 64 * WROWS; // rows per wave, per workgroup block
+    constexpr int RM_NT = NT; // (shadows the default: the loops below stride by the workgroup size)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     v4i *inv_lds = (v4i *)lds;
     fp *img_all = (fp *)(lds + RM_LDS_INV);
-    uint64_t *secd_lds = (uint64_t *)(lds + RM_LDS_INV + rm_lds_img<PTS>);
-    uint64_t *k_lds = secd_lds + RM_LDS_SEC / 8;
-    fp *ark2_lds = k_lds + RM_LDS_K / 8;
-    fp *atab_lds = ark2_lds + RM_LDS_ARK / 8;
+    uint64_t *kinv_lds = (uint64_t *)(lds + RM_LDS_INV + rm_lds_img<PTS, NT>);
+    fp *ark2_lds = kinv_lds + RM_LDS_KINV / 8;
+    uint64_t *secd_lds = ark2_lds + RM_LDS_ARK / 8;           // [M][13 tiles][64]
+    uint64_t *ksec_lds = secd_lds + M * (RM_LDS_SEC / 8);     // [M][26][4]
+    fp *atab_lds = ksec_lds + M * (RM_LDS_KSEC / 8);          // [M][26][8]
 
     const size_t n = (size_t)1 << p.log_n;
     const unsigned kk = 2 * blockIdx.y, kc = (p.k0 >> 1) + blockIdx.y, ka = 2 * kc; // (k_rounds_split)
@@ -383,20 +388,22 @@ __global__ __launch_bounds__(RM_NT, PTS == 1 ? 3 : RM_WAVES) void k_rounds_mfma(
     const int nn = ro.nn, h = ro.h;
     const fp *rt = p.rtab;
     expand_inverse_table(inv_lds, rt + MF_INV_D, tid, RM_NT);
-    for (unsigned e = tid; e < RM_LDS_SEC / 8; e += RM_NT) secd_lds[e] = rt[MF_SEC_D + e];
-    for (unsigned e = tid; e < RM_LDS_K / 8; e += RM_NT) k_lds[e] = rt[MF_K + e];
+    for (unsigned e = tid; e < RM_LDS_KINV / 8; e += RM_NT) kinv_lds[e] = rt[MF_K + e];
+    for (unsigned e = tid; e < M * (RM_LDS_SEC / 8); e += RM_NT) secd_lds[e] = rt[(size_t)(e / (RM_LDS_SEC / 8)) * CE_RTAB_WORDS + MF_SEC_D + e % (RM_LDS_SEC / 8)];
+    for (unsigned e = tid; e < M * (RM_LDS_KSEC / 8); e += RM_NT) ksec_lds[e] = rt[(size_t)(e / (RM_LDS_KSEC / 8)) * CE_RTAB_WORDS + MF_K + 14 * 4 + e % (RM_LDS_KSEC / 8)];
     if (tid < 8 * 14) { // the round constants' extension has period 8 in the row index: the same 8 x 14 values for every block of rows
         const unsigned r = tid / 14, c = tid % 14;
         ark2_lds[tid] = p.ptab[((size_t)ka * 48 + P_ARK + 14 + c) * 1024 + r];
     }
-    for (unsigned e = tid; e < 2 * MF_TILES_SEC * 8; e += RM_NT) { // (tile, g) -> section (window, flag set, slot 2 u + g)
-        const int tile = e >> 4, g = (e >> 3) & 1, w = mf_tile_window(tile), local = tile - mf_tile_base(w);
+    for (unsigned e = tid; e < M * 2 * MF_TILES_SEC * 8; e += RM_NT) { // (set, tile, g) -> section (window, flag set, slot 2 u + g)
+        const int c = e / (2 * MF_TILES_SEC * 8), r = e % (2 * MF_TILES_SEC * 8), tile = r >> 4, g = (r >> 3) & 1, w = mf_tile_window(tile), local = tile - mf_tile_base(w);
         const int sec = (w * 2 + mf_tile_fs(w, local)) * 4 + 2 * mf_tile_pair(w, local) + g;
-        atab_lds[e] = rt[RT_A + sec * 64 + ka * 8 + (e & 7)];
+        atab_lds[e] = rt[(size_t)c * CE_RTAB_WORDS + RT_A + sec * 64 + ka * 8 + (r & 7)];
     }
     __syncthreads();
 
     fp *img = img_all + (size_t)(tid >> 6) * rw_img<PTS>;
+    const uint64_t *k_lds = kinv_lds;
     const fp *imgA = img + nn; // point n: current row at element n, next row at n + 1; point n + 32: + 32
     const unsigned jrp = (unsigned)(nn & 7); // row of the lane's points mod 8 (blocks and waves start at multiples of 32)
     const fp *ark2 = ark2_lds + jrp * 14;
@@ -426,11 +433,13 @@ __global__ __launch_bounds__(RM_NT, PTS == 1 ? 3 : RM_WAVES) void k_rounds_mfma(
         // a term goes to is the same for both lane halves: stream 0 -> polynomial of slot 1 (windows 0..4: 1, 2, 1, 3, 3), stream 1 ->
         // polynomial of slot 2 (2, 3, 3).  Half 0 reads stream 0 as alpha whatever the register, half 1 reads stream 1 as polynomial 1
         // (slot 3 is used in window 1 only, there by group 0).
-        fp sm[PTS][5]; // stream 0 -> polynomials 1, 2, 3 | stream 1 -> polynomials 2, 3
+        fp sm[M][PTS][5]; // per set: stream 0 -> polynomials 1, 2, 3 | stream 1 -> polynomials 2, 3
 #pragma unroll
-        for (int pt = 0; pt < PTS; pt++)
+        for (int c = 0; c < M; c++)
 #pragma unroll
-            for (int q = 0; q < 5; q++) sm[pt][q] = 0;
+            for (int pt = 0; pt < PTS; pt++)
+#pragma unroll
+                for (int q = 0; q < 5; q++) sm[c][pt][q] = 0;
 #pragma unroll 1
         for (int wdx = 0; wdx < 5; wdx++) {
             const RoundWindow w = c_windows[wdx];
@@ -444,58 +453,70 @@ __global__ __launch_bounds__(RM_NT, PTS == 1 ? 3 : RM_WAVES) void k_rounds_mfma(
             if (wdx < 4) fetch_window<PTS>(rows, n, c_windows[wdx + 1].reg, lane, img);
             else if (blk + gridDim.x < nblk) { rows = rows_of(blk + gridDim.x); fetch_window<PTS>(rows, n, c_windows[0].reg, lane, img); }
 #endif
-            fp x[PTS][2]; // the window's terms of stream u
 #pragma unroll
-            for (int pt = 0; pt < PTS; pt++) x[pt][0] = x[pt][1] = 0;
-            const int t0 = mf_tile_base(wdx), t1 = mf_tile_base(wdx + 1);
+            for (int cs = 0; cs < M; cs++) { // one coefficient set after the other against the same operands
+                fp x[PTS][2]; // the window's terms of stream u
+#pragma unroll
+                for (int pt = 0; pt < PTS; pt++) x[pt][0] = x[pt][1] = 0;
+#ifdef RM_EXP_NOSEC // measurement builds: without the sections' product
+                const int t0 = 0, t1 = 0;
+                x[0][0] = (fp)c[0][0][0] ^ (fp)c[0][6][3];
+#else
+                const int t0 = mf_tile_base(wdx), t1 = mf_tile_base(wdx + 1);
+#endif
 #pragma unroll 1
-            for (int tile = t0; tile < t1; tile++) {
-                const int local = tile - t0, fs = mf_tile_fs(wdx, local), u = mf_tile_pair(wdx, local);
-                fp r[PTS];
-                section_tile<PTS>(secd_lds + tile * 64, k_lds + 4 * (14 + 2 * tile + h), ro, sh, c, r);
-                const fp at = atab_lds[(2 * tile + h) * 8 + jrp]; // this lane's section: slot 2 u + h
-                const int fg = fs ? w.flag_b : w.flag_a;
+                for (int tile = t0; tile < t1; tile++) {
+                    const int local = tile - t0, fs = mf_tile_fs(wdx, local), u = mf_tile_pair(wdx, local);
+                    fp r[PTS];
+                    section_tile<PTS>(secd_lds + (cs * MF_TILES_SEC + tile) * 64, ksec_lds + 4 * (cs * 2 * MF_TILES_SEC + 2 * tile + h), ro, sh, c, r);
+                    const fp at = atab_lds[(cs * 2 * MF_TILES_SEC + 2 * tile + h) * 8 + jrp]; // this lane's section: slot 2 u + h
+                    const int fg = fs ? w.flag_b : w.flag_a;
+#pragma unroll
+                    for (int pt = 0; pt < PTS; pt++) {
+                        const fp f = fg == 0 ? fl[pt][0] : fg == 1 ? fl[pt][1] : fg == 2 ? fl[pt][2] : fp_add(fl[pt][0], fl[pt][1]);
+                        const fp v = fp_mul(f, fp_sub(r[pt], at));
+                        if (u) x[pt][1] = fp_add(x[pt][1], v);
+                        else x[pt][0] = fp_add(x[pt][0], v);
+                    }
+                }
+                // stream 0 -> polynomial of slot 1: 1, 2, 1, 3, 3; stream 1 -> polynomial of slot 2: 2, 3, 3 (windows 3, 4: no pair 1)
 #pragma unroll
                 for (int pt = 0; pt < PTS; pt++) {
-                    const fp f = fg == 0 ? fl[pt][0] : fg == 1 ? fl[pt][1] : fg == 2 ? fl[pt][2] : fp_add(fl[pt][0], fl[pt][1]);
-                    const fp v = fp_mul(f, fp_sub(r[pt], at));
-                    if (u) x[pt][1] = fp_add(x[pt][1], v);
-                    else x[pt][0] = fp_add(x[pt][0], v);
+                    if (wdx == 0 || wdx == 2) sm[cs][pt][0] = fp_add(sm[cs][pt][0], x[pt][0]);
+                    else if (wdx == 1) sm[cs][pt][1] = fp_add(sm[cs][pt][1], x[pt][0]);
+                    else sm[cs][pt][2] = fp_add(sm[cs][pt][2], x[pt][0]);
+                    if (wdx == 0) sm[cs][pt][3] = fp_add(sm[cs][pt][3], x[pt][1]);
+                    else if (wdx < 3) sm[cs][pt][4] = fp_add(sm[cs][pt][4], x[pt][1]);
                 }
-            }
-            // stream 0 -> polynomial of slot 1: 1, 2, 1, 3, 3; stream 1 -> polynomial of slot 2: 2, 3, 3 (windows 3, 4: no pair 1)
-#pragma unroll
-            for (int pt = 0; pt < PTS; pt++) {
-                if (wdx == 0 || wdx == 2) sm[pt][0] = fp_add(sm[pt][0], x[pt][0]);
-                else if (wdx == 1) sm[pt][1] = fp_add(sm[pt][1], x[pt][0]);
-                else sm[pt][2] = fp_add(sm[pt][2], x[pt][0]);
-                if (wdx == 0) sm[pt][3] = fp_add(sm[pt][3], x[pt][1]);
-                else if (wdx < 3) sm[pt][4] = fp_add(sm[pt][4], x[pt][1]);
             }
         }
         // polynomials 0..3 of this lane's sections: half 0: stream 0 is alpha, stream 1 by register; half 1: stream 0 by register,
         // stream 1 is polynomial 1.  The other half of a point's sections sits in lane ^ 32.
-        fp tot[PTS][4];
 #pragma unroll
-        for (int pt = 0; pt < PTS; pt++) {
-            const fp s012 = fp_add(fp_add(sm[pt][0], sm[pt][1]), sm[pt][2]), s34 = fp_add(sm[pt][3], sm[pt][4]);
-            tot[pt][0] = h ? 0 : s012; tot[pt][1] = h ? fp_add(sm[pt][0], s34) : 0;
-            tot[pt][2] = h ? sm[pt][1] : sm[pt][3]; tot[pt][3] = h ? sm[pt][2] : sm[pt][4];
-        }
-        if constexpr (PTS == 2) { // lane (n, 0) holds its part of point n in [0] and lane (n, 1) the rest, likewise [1] for point n + 32
-            const size_t j = jw + lane;
+        for (int cs = 0; cs < M; cs++) {
+            fp tot[PTS][4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { // this lane's own point: its part + what the other half holds of it
-                const fp mine = h ? tot[1][q] : tot[0][q], give = h ? tot[0][q] : tot[1][q];
-                out[((size_t)q * 4 + kc) * n + j] = fp_add(mine, other_half(give)); // table 3: group 2 (k_rounds_split)
+            for (int pt = 0; pt < PTS; pt++) {
+                const fp s012 = fp_add(fp_add(sm[cs][pt][0], sm[cs][pt][1]), sm[cs][pt][2]), s34 = fp_add(sm[cs][pt][3], sm[cs][pt][4]);
+                tot[pt][0] = h ? 0 : s012; tot[pt][1] = h ? fp_add(sm[cs][pt][0], s34) : 0;
+                tot[pt][2] = h ? sm[cs][pt][1] : sm[cs][pt][3]; tot[pt][3] = h ? sm[cs][pt][2] : sm[cs][pt][4];
             }
-        } else { // both halves hold parts of point n: half 0 writes polynomials 0, 1 and half 1 writes 2, 3
-            const size_t j = jw + nn;
+            fp *o = out + (size_t)cs * CE_SPLIT_TABLES * 4 * n; // the set's block of polynomials (k_rounds_split)
+            if constexpr (PTS == 2) { // lane (n, 0) holds its part of point n in [0] and lane (n, 1) the rest, likewise [1] for point n + 32
+                const size_t j = jw + lane;
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const fp got = other_half(h ? tot[0][e] : tot[0][2 + e]);
-                const int q = 2 * h + e; // (lane-dependent address only)
-                out[((size_t)q * 4 + kc) * n + j] = fp_add(h ? tot[0][2 + e] : tot[0][e], got);
+                for (int q = 0; q < 4; q++) { // this lane's own point: its part + what the other half holds of it
+                    const fp mine = h ? tot[1][q] : tot[0][q], give = h ? tot[0][q] : tot[1][q];
+                    o[((size_t)q * 4 + kc) * n + j] = fp_add(mine, other_half(give)); // table 3: group 2 (k_rounds_split)
+                }
+            } else { // both halves hold parts of point n: half 0 writes polynomials 0, 1 and half 1 writes 2, 3
+                const size_t j = jw + nn;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const fp got = other_half(h ? tot[0][e] : tot[0][2 + e]);
+                    const int q = 2 * h + e; // (lane-dependent address only)
+                    o[((size_t)q * 4 + kc) * n + j] = fp_add(h ? tot[0][2 + e] : tot[0][e], got);
+                }
             }
         }
     }
@@ -584,16 +605,26 @@ __global__ __launch_bounds__(RM_NT, RM_WAVES) void k_merkle_rounds_mfma(MerkleRo
 
 } // namespace
 
-hipError_t launch_rounds_mfma(const CeParams &p, uint64_t *d_even, hipStream_t stream) {
+template <int PTS, int M, int NT>
+static hipError_t launch_rounds_mfma_as(const CeParams &p, uint64_t *d_even, hipStream_t stream) {
     const size_t n = (size_t)1 << p.log_n;
-    constexpr int PTS = RM_PTS, BROWS = RM_NT / 64 * 32 * PTS;
-    if ((p.m ? p.m : 1) != 1 || n % BROWS) return hipErrorInvalidValue;
-    static const hipError_t attr = hipFuncSetAttribute((const void *)k_rounds_mfma<PTS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rm_lds<PTS>);
+    constexpr int BROWS = NT / 64 * 32 * PTS;
+    constexpr size_t LDS = rm_lds<PTS, M, NT>;
+    if (n % BROWS) return hipErrorInvalidValue;
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k_rounds_mfma<PTS, M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(k_rounds_mfma_tables, dim3(MF_TILES_INV + MF_TILES_SEC), dim3(64), 0, stream, p.rtab);
+    hipLaunchKernelGGL(k_rounds_mfma_tables, dim3(MF_TILES_INV + MF_TILES_SEC, M), dim3(64), 0, stream, p.rtab);
     const unsigned ny = p.nkc ? p.nkc : 4, nblk = (unsigned)(n / BROWS), gx = RM_RESIDENT / ny < nblk ? RM_RESIDENT / ny : nblk;
-    hipLaunchKernelGGL(k_rounds_mfma<PTS>, dim3(gx, ny), dim3(RM_NT), rm_lds<PTS>, stream, p, d_even);
+    hipLaunchKernelGGL((k_rounds_mfma<PTS, M, NT>), dim3(gx, ny), dim3(NT), LDS, stream, p, d_even);
     return hipGetLastError();
+}
+// one coefficient set: two workgroups of 256 per CU; two sets: the same with 76 KB of LDS each; three: one workgroup of 512 (114 KB)
+hipError_t launch_rounds_mfma(const CeParams &p, uint64_t *d_even, hipStream_t stream) {
+    const unsigned m = p.m ? p.m : 1;
+    if (m == 1) return launch_rounds_mfma_as<RM_PTS, 1, RM_NT>(p, d_even, stream);
+    if (m == 2) return launch_rounds_mfma_as<2, 2, 256>(p, d_even, stream);
+    if (m == 3) return launch_rounds_mfma_as<2, 3, 512>(p, d_even, stream);
+    return hipErrorInvalidValue;
 }
 
 // constraints.hip: after k_merkle_rounds_setup (same stream); which = 0: MerkleAir's four windows (written), 1: SchnorrAir's message hash (added)
