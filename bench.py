@@ -583,11 +583,11 @@ def main():
                              launches=lde_pairs)
         nb = (8 // world) if coset_mode else 8
         rounds_bytes = (nb // 2) * n * (58 * 8 + 6 * 8) if split else nb * n * (58 * 8 + 8)
-        rounds_mfma = split and field_ext == 0 and os.environ.get("CSTARK_ROUNDS_MFMA", "1") != "0"  # csrc/rounds_mfma.hip (one coefficient set)
+        rounds_mfma = split and os.environ.get("CSTARK_ROUNDS_MFMA", "1") != "0"  # csrc/rounds_mfma.hip
         roofline_rounds = entry(("k_rounds_mfma (Rescue windows of the constraint evaluation, even cosets; INV_MDS and the sections' sums as int8 GEMMs "
                                  "of byte diagonals on the matrix cores)" if rounds_mfma else "k_rounds_split (Rescue windows of the constraint evaluation, even cosets)")
                                 if split else "k_eval_fused<0> (Rescue windows of the constraint evaluation)", rounds_bytes, part_avg["rounds"],
-                                (["k_rounds_mfma", "k_rounds_mfma_tables"] if rounds_mfma else ["k_rounds_split<1>"]) if split else ["k_eval_fused<0, 1>"],
+                                (["k_rounds_mfma<", "k_rounds_mfma_tables"] if rounds_mfma else ["k_rounds_split<1>"]) if split else ["k_eval_fused<0, 1>"],
                                 "round 4: 3.08 ms on the vector ALU alone (22.9 k instructions per point) -> the constant-matrix products on the matrix "
                                 "cores, cubes / recombination / reductions left on the vector ALU; still bound by vector-instruction issue and by what two "
                                 "waves per SIMD can overlap (profiles/*_valu_pmc.csv; DESIGN.md 5.7)")
@@ -595,10 +595,11 @@ def main():
             # matrix-core side of the same launch: 462 v_mfma_i32_32x32x32_i8 per wave of 64 points (5 windows x 7 tiles x 4 k-steps x 2
             # point halves + 13 section tiles x 7 x 2), 32 * 32 * 32 * 2 integer operations each; peak = dense int8 (2 x the bf16 rate,
             # MI355X_MICROARCH.md).  kernel time = the 'rounds' part minus nothing: the two setup launches are 20 microseconds
-            ops = ((nb // 2) * n / 64) * 462 * 65536
+            n_mfma = 5 * 56 + (field_ext + 1) * 182  # per wave of 64 points: the inverse matrix once, the section tiles per coefficient set
+            ops = ((nb // 2) * n / 64) * n_mfma * 65536
             tops = ops / (part_avg["rounds"] * 1e-3) / 1e12
             roofline_rounds["mfma"] = {"bound": "mfma", "achieved": round(tops, 1), "peak": 5000.0, "unit": "TOP/s (int8, dense)", "frac": round(tops / 5000.0, 4),
-                                       "ops_per_launch": int(ops), "mfma_per_wave": 462,
+                                       "ops_per_launch": int(ops), "mfma_per_wave": n_mfma,
                                        "note": "the matrix pipe is busy for about a quarter of the kernel; what bounds the launch is the vector work per output "
                                                "(one recombination and Montgomery reduction per byte-diagonal set, the cubes) at two waves per SIMD"}
         valu = PmcValu()
@@ -614,7 +615,7 @@ def main():
                 tot = cols["wave_instructions"] * disp["k_ntt_cols_v5<4, 3, 3, false>"] + rows_["wave_instructions"] * disp["k_ntt_rows_v5<4, 3, 3, false>"]
                 roofline_lde["valu"] = {"column_pass": cols, "row_pass": rows_, "insts_per_element": round(tot * 64 / elems, 1),
                                         "note": "lane-instructions per output element of the forward transform pair, all forward transforms of a proof"}
-            r = valu.entry("k_rounds_mfma", 4 * n) if rounds_mfma else valu.entry("k_rounds_split<1>", 4 * n)
+            r = valu.entry("k_rounds_mfma<2, 1, 256>", 4 * n) if rounds_mfma else valu.entry("k_rounds_split<1>", 4 * n)
             if r:
                 roofline_rounds["valu"] = r
         roofline_stages = [roofline_lde] + ([] if coset_mode else [roofline_rounds])
@@ -624,7 +625,7 @@ def main():
                                          "the one HBM-shaped stage; k_hash_rows moves exactly its algorithmic bytes; `traffic` is per kernel NAME and so also "
                                          "holds the small FRI-layer hashes and the composition / layer trees of a proof (about +0.5 GB)"))
             roofline_stages.append(entry("constraint evaluation stage (all launches)", ab["constraints"], stage_ms["constraints"],
-                                         ["k_rounds_split<", "k_rounds_mfma", "k_rounds_mfma_tables", "k_rounds_setup", "k_ec_split<", "k_final_split<", "k_final_hi<", "k_lin_split<", "k_lin_all",
+                                         ["k_rounds_split<", "k_rounds_mfma<", "k_rounds_mfma_tables", "k_rounds_setup", "k_ec_split<", "k_final_split<", "k_final_hi<", "k_lin_split<", "k_lin_all",
                                           "k_coset_even_to_odd", "k_split_finish<"] if split else ["k_eval_fused<", "k_rounds_setup"],
                                          "`traffic` = the stage's own kernels; the interpolation and extension of its split polynomials run through the "
                                          "transform kernels and are counted in the first entry (about 4 GB)" if split else None))
@@ -632,7 +633,7 @@ def main():
         # pass, the static issue cost per instruction, and their ratio = the fraction of the kernel's cycles spent issuing VALU work ----
         issue_roofline = None
         if pts_headline and args.mode == "prove":
-            pts = {"k_ntt_cols_v5<4, 3, 3, false>": 0, "k_ntt_rows_v5<4, 3, 3, false>": 0, "k_rounds_mfma": 4 * n, "k_rounds_split<1>": 4 * n, "k_ec_split<1, false, 1>": 4 * n,
+            pts = {"k_ntt_cols_v5<4, 3, 3, false>": 0, "k_ntt_rows_v5<4, 3, 3, false>": 0, "k_rounds_mfma<2, 1, 256>": 4 * n, "k_rounds_split<1>": 4 * n, "k_ec_split<1, false, 1>": 4 * n,
                    "k_ec_split<2, false, 1>": 4 * n, "k_ec_split<3, true, 1>": 4 * n, "k_ec_split<4, false, 1>": 4 * n, "k_final_split<1>": 4 * n,
                    "k_lin_all<true>": 4 * n, "k_split_finish<1>": 8 * n, "k_hash_rows": 0, "k_trace_schnorr_ec<false, 16>": 2 * n_tx * 511, "k_deep": n}
             issue_roofline = [e for e in (valu.entry(k, p) for k, p in pts.items()) if e is not None] or None
