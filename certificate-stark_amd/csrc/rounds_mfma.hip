@@ -1,7 +1,8 @@
-// TransactionAir's five Rescue windows (split evaluation, one coefficient set) with EVERY constant-matrix product on the matrix cores:
+// TransactionAir's five Rescue windows (split evaluation; one to three coefficient sets) and the folded round gadgets of MerkleAir /
+// SchnorrAir with EVERY constant-matrix product on the matrix cores:
 //   y = INV_MDS (next - ark2)                                    14 x 14, constant                     (src/utils/rescue.rs:345-375)
 //   v_sec = gamma_sec . cube(y) - U_sec . cube(cur),  U = MDS^T gamma   up to 8 sections x 28, per proof   (rescue.rs:269-300 folded)
-// Same values as k_rounds_split (constraints.hip), bit for bit: the 64-bit integer products are byte-decomposed exactly as in
+// Same values as k_rounds_split / k_merkle_rounds (constraints.hip), bit for bit: the 64-bit integer products are byte-decomposed exactly as in
 // mds_mfma.cuh (signed base-256 digits, int8 GEMM of the byte diagonals, carry-free recombination, one Montgomery reduction).
 //
 // What k_rounds_split spends per point: 980 + 322 limb multiply-adds of six v_mad_u64_u32 each (the inverse matrix and the forward
@@ -15,7 +16,7 @@
 //     keeps it: it IS the lane's half of the next product's operand (contraction order of the section tables: m -> i = 2 m + h), so
 //     nothing moves between the two GEMMs either.  The forward cubes cube(cur_j), j = 2 t + h, are formed by the same lane.
 //   * A section's value of point n lands in lane (n, g) for section slot 2 u + g; every lane accumulates its sections' terms for its
-//     two points and the two halves are added once at the end (one cross-half exchange of eight values).
+//     two points and the two halves are added once at the end (one cross-half exchange of four values per point).
 // Tables: compact (one word of eight signed digits per matrix entry, rounds_layout.h); the Toeplitz fragments of the inverse matrix
 // are expanded into LDS once per workgroup (28 KB), those of the sections per use (two v_perm_b32 per word).
 // The 28-term section sums would exceed 2^128 with operands in [0, p): both factors are centred (coefficients in (-p/2, p/2) as
@@ -37,7 +38,7 @@ typedef unsigned __int128 u128;
 #ifndef RM_WAVES
 #define RM_WAVES 2
 #endif
-constexpr int RM_NT = RM_NT_;                    // threads per workgroup: eight waves share one expanded inverse table
+constexpr int RM_NT = RM_NT_;                    // threads per workgroup (one coefficient set): its waves share one expanded inverse table
 // window image of a wave of 32 PTS points: 14 columns x rows j0 .. j0 + 32 PTS + 1 (PTS = 2: k_rounds_split's)
 template <int PTS> constexpr int rw_rows = 32 * PTS + 2;
 template <int PTS> constexpr int rw_img = 14 * rw_rows<PTS>;
@@ -169,11 +170,6 @@ __device__ __forceinline__ v16i acc_start() {
     for (int v = 0; v < 16; v++) a[v] = mdsmfma::ACC0;
     return a;
 }
-// The 15 byte diagonals of one output (non-negative, below 2^24) and the row constant -> Montgomery-reduced field element.
-// Diagonal d sits at bit 8 d: the four diagonals 4 q .. 4 q + 3 of 32-bit word q are summed with their shifts by three
-// v_mad_u64_u32 on top of the constant's word q (a fourth carries diagonal 4 q into the 64-bit sum: multiplication by an opaque
-// one), and the four sums S_q < 2^49 overlap by their high words only: three carry additions.  18 instructions, where packing the
-// diagonals into three carry-free 128-bit words and adding those (mdsmfma::recombine) takes 29.
 // A constant in a scalar register that the compiler cannot see through: x * c + t stays ONE v_mad_u64_u32 where the compiler's own
 // form of a multiplication by 2^8 / 2^16 / 2^24 is a 64-bit shift and a 64-bit add (two instructions of the same issue cost each).
 template <uint32_t V>
@@ -183,6 +179,11 @@ __device__ __forceinline__ uint32_t opaque_const() {
     return r;
 }
 struct Shifts { uint32_t one, s8, s16, s24; };
+// The 15 byte diagonals of one output (non-negative, below 2^24) and the row constant -> Montgomery-reduced field element.
+// Diagonal d sits at bit 8 d: the four diagonals 4 q .. 4 q + 3 of 32-bit word q are summed with their shifts by three
+// v_mad_u64_u32 on top of the constant's word q (a fourth carries diagonal 4 q into the 64-bit sum: multiplication by an opaque
+// one), and the four sums S_q < 2^49 overlap by their high words only: three carry additions.  18 instructions, where packing the
+// diagonals into three carry-free 128-bit words and adding those (mdsmfma::recombine) takes 29.
 __device__ __forceinline__ fp recombine_mad(const v16i &acc, const uint64_t (&k)[4], const Shifts &c) {
 #ifdef RM_OLD_RECOMBINE
     return mdsmfma::recombine(acc, k[0] | (k[1] << 32), k[2] | (k[3] << 32));
