@@ -147,6 +147,7 @@ struct cstark_ctx {
     uint64_t lde_units = 0;
     uint64_t *tail_buf = nullptr; // standalone SchnorrAir: message[26..28] per signature
     std::vector<uint64_t> schnorr_rx; // host copy of the signatures' R.x ([n][6]) for the sequence assertions
+    std::vector<uint64_t> schnorr_av_stage; // [12][n / 512]: the non-zero coefficients of their value polynomials, staged for the upload
     std::vector<uint64_t> schnorr_pub; // messages [n][28] then R.x [n][6]: SchnorrAir's public inputs, for the channel seed
     std::vector<uint8_t> schnorr_s;    // the s halves [n][32]
     uint8_t schnorr_seed[32] = {}, schnorr_seed_key[12] = {}; // the channel seed of the uploaded Schnorr witness under one option set (key[11] = 1: valid)
