@@ -29,4 +29,7 @@ hipError_t fri_fold4_ext(const uint64_t *d_evals, uint64_t *d_out, unsigned log_
 hipError_t fri_fold_ext(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n, unsigned log_f, const uint64_t *d_winv, uint64_t offset_inv,
                         const uint64_t *alpha, unsigned m, uint64_t inv_f, hipStream_t stream);
 
+// dst column m i + q <- column i of src[q] (i < cols, q < m, columns of n words): the components of the composition columns of an
+// extension-field proof side by side, one launch (24 device-to-device copies before)
+hipError_t interleave_set_columns(uint64_t *d_dst, const uint64_t *const src[3], unsigned m, unsigned cols, size_t n, hipStream_t stream);
 } // namespace cs

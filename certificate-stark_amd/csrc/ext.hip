@@ -290,4 +290,20 @@ hipError_t fri_fold_ext(const uint64_t *d_evals, uint64_t *d_out, unsigned log_n
     return hipGetLastError();
 }
 
+namespace {
+struct SetPtrs { const uint64_t *p[3]; };
+// grid = (ceil(n / 256), cols * m)
+__global__ void k_interleave_set_columns(uint64_t *__restrict__ dst, SetPtrs src, unsigned m, size_t n) {
+    const size_t j = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (j >= n) return;
+    const unsigned col = blockIdx.y, i = col / m, q = col % m;
+    dst[(size_t)col * n + j] = src.p[q][(size_t)i * n + j];
+}
+} // namespace
+hipError_t interleave_set_columns(uint64_t *d_dst, const uint64_t *const src[3], unsigned m, unsigned cols, size_t n, hipStream_t stream) {
+    if (m == 0 || m > 3) return hipErrorInvalidValue;
+    SetPtrs sp{{src[0], m > 1 ? src[1] : nullptr, m > 2 ? src[2] : nullptr}};
+    hipLaunchKernelGGL(k_interleave_set_columns, dim3((unsigned)((n + 255) / 256), cols * m), dim3(256), 0, stream, d_dst, sp, m, n);
+    return hipGetLastError();
+}
 } // namespace cs

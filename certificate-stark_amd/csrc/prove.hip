@@ -29,6 +29,7 @@
 #include "blake3.h"
 #include "channel.h"
 #include "deep.h"
+#include "ext.h"
 #include "range_batch.h"
 #include "hostblake3.h"
 #include "keccak.cuh"
@@ -1351,8 +1352,7 @@ int prove_ext(cstark_ctx *c, const cstark_options *opt, AirJob &job, uint8_t *pr
     }
     STAGE();
     for (unsigned q = 0; q < m; q++) RC_TRY(cstark_composition_columns(c, comb[q], cco[q], log_n, log_ce)); // [ce][n] each
-    for (size_t i = 0; i < ce; i++) // column m i + q = component q of composition column i
-        for (unsigned q = 0; q < m; q++) HIP_TRY(hipMemcpyAsync(ccoefs + (m * i + q) * n, cco[q] + i * n, n * 8, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(cs::interleave_set_columns(ccoefs, cco, m, (unsigned)ce, n, st)); // column m i + q = component q of composition column i
     RC_TRY(cstark_lde_columns(c, ccoefs, cldes, (uint32_t)CW, log_n, log_b, lde_offset(), 0, (uint32_t)b));
     RC_TRY(cstark_hash_rows_fn(c, hf, cldes, a->cnodes + 32 * N, (uint32_t)CW, log_n, log_b, 0, (uint32_t)b));
     RC_TRY(cstark_merkle_build_fn(c, hf, a->cnodes, log_N));
